@@ -1,0 +1,259 @@
+"""ctypes loader for the CPU oracle (oracle/s2m_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- parity unpinned (see s2m_oracle.h).  Import this from tests/,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` only.  Nothing under
+``daliti_amd/`` may import it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libs2m_oracle.so")
+K = 5
+DIM = 24
+STATE_DOUBLES = 36  # rot9 pos3 R_LI9 T_LI3 vel3 bg3 ba3 grav3
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("s2m_oracle.c", "s2m_oracle.h", "Makefile")]
+    if (not force and os.path.exists(_SO)
+            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src)):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class Cfg(C.Structure):
+    _fields_ = [("plane_thr", C.c_float), ("knn_d2_gate", C.c_float), ("s_gate", C.c_double),
+                ("res_gate", C.c_double), ("laser_point_cov", C.c_double),
+                ("conv_rot_deg", C.c_double), ("conv_pos_cm", C.c_double),
+                ("extrinsic_est_en", C.c_int), ("max_iter", C.c_int),
+                ("feat_threshold", C.c_int), ("nthreads", C.c_int)]
+
+
+class IterResult(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("rematch_passes", C.c_int32), ("converged", C.c_int32),
+                ("ekf_stop", C.c_int32), ("effct_last", C.c_int32), ("total_res_last", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_kdtree_build.restype = C.c_void_p
+        _lib.orc_kdtree_build.argtypes = [C.c_void_p, C.c_int64]
+        _lib.orc_kdtree_free.argtypes = [C.c_void_p]
+        _lib.orc_esti_plane.restype = C.c_int
+        _lib.orc_eskf_update.restype = C.c_int
+        _lib.orc_eskf_update_dense.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_cfg(**kw):
+    c = Cfg()
+    lib().orc_cfg_default(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def make_state(rot=None, pos=None, R_LI=None, T_LI=None, vel=None, bg=None, ba=None, grav=None):
+    s = np.zeros(STATE_DOUBLES)
+    s[0:9] = np.eye(3).ravel() if rot is None else np.asarray(rot, float).ravel()
+    s[9:12] = 0 if pos is None else pos
+    s[12:21] = np.eye(3).ravel() if R_LI is None else np.asarray(R_LI, float).ravel()
+    s[21:24] = 0 if T_LI is None else T_LI
+    s[24:27] = 0 if vel is None else vel
+    s[27:30] = 0 if bg is None else bg
+    s[30:33] = 0 if ba is None else ba
+    s[33:36] = 0 if grav is None else grav
+    return s
+
+
+def so3_exp(v):
+    R = np.zeros(9)
+    lib().orc_so3_exp(C.c_double(v[0]), C.c_double(v[1]), C.c_double(v[2]), _p(R))
+    return R.reshape(3, 3)
+
+
+def so3_log(R):
+    R = np.ascontiguousarray(R, float).ravel()
+    o = np.zeros(3)
+    lib().orc_so3_log(_p(R), _p(o))
+    return o
+
+
+def boxplus(x, d):
+    x = np.array(x, float)
+    d = np.ascontiguousarray(d, float)
+    lib().orc_state_boxplus(_p(x), _p(d))
+    return x
+
+
+def boxminus(a, b):
+    a = np.ascontiguousarray(a, float)
+    b = np.ascontiguousarray(b, float)
+    o = np.zeros(DIM)
+    lib().orc_state_boxminus(_p(a), _p(b), _p(o))
+    return o
+
+
+class KdTree:
+    def __init__(self, map_xyz):
+        self.xyz = np.ascontiguousarray(map_xyz, np.float32).reshape(-1, 3)
+        self.h = lib().orc_kdtree_build(_p(self.xyz), C.c_int64(len(self.xyz)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_kdtree_free(C.c_void_p(self.h))
+            self.h = None
+
+    def knn5(self, q, nthreads=1):
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+        n = len(q)
+        idx = np.empty((n, K), np.int32)
+        d2 = np.empty((n, K), np.float32)
+        cnt = np.empty(n, np.int32)
+        lib().orc_knn5(C.c_void_p(self.h), _p(q), C.c_int64(n), _p(idx), _p(d2), _p(cnt), C.c_int(nthreads))
+        return idx, d2, cnt
+
+
+def knn5_brute(map_xyz, q):
+    m = np.ascontiguousarray(map_xyz, np.float32).reshape(-1, 3)
+    q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+    n = len(q)
+    idx = np.empty((n, K), np.int32)
+    d2 = np.empty((n, K), np.float32)
+    cnt = np.empty(n, np.int32)
+    lib().orc_knn5_brute(_p(m), C.c_int64(len(m)), _p(q), C.c_int64(n), _p(idx), _p(d2), _p(cnt))
+    return idx, d2, cnt
+
+
+def esti_plane(nb, thr=0.1):
+    nb = np.ascontiguousarray(nb, np.float32).reshape(15)
+    out = np.zeros(4, np.float32)
+    ok = lib().orc_esti_plane(_p(nb), C.c_float(thr), _p(out))
+    return bool(ok), out
+
+
+def body_to_world(x, pb):
+    x = np.ascontiguousarray(x, float)
+    pb = np.ascontiguousarray(pb, np.float32).reshape(-1, 3)
+    out = np.empty_like(pb)
+    for i in range(len(pb)):
+        lib().orc_body_to_world(_p(x), C.c_void_p(pb[i].ctypes.data), C.c_void_p(out[i].ctypes.data))
+    return out
+
+
+class PassState:
+    """Per-scan persistent state + per-pass outputs of orc_residual_pass."""
+
+    def __init__(self, n):
+        self.n = n
+        self.selected = np.ones(n, np.uint8)
+        self.nn_idx = np.full((n, K), -1, np.int32)
+        self.nn_d2 = np.full((n, K), np.inf, np.float32)
+        self.nn_cnt = np.zeros(n, np.int32)
+        self.plane = np.zeros((n, 4), np.float32)
+        self.plane_ok = np.zeros(n, np.uint8)
+        self.pd2 = np.zeros(n, np.float32)
+        self.eff = np.zeros(n, np.uint8)
+        self.HtH = np.zeros((12, 12))
+        self.Htz = np.zeros(12)
+        self.effct = 0
+        self.total_res = 0.0
+        self.Hsub = None
+        self.meas = None
+
+
+def residual_pass(cfg, tree, scan_xyz, x, rematch, ps, want_rows=False):
+    scan = np.ascontiguousarray(scan_xyz, np.float32).reshape(-1, 3)
+    x = np.ascontiguousarray(x, float)
+    n = len(scan)
+    effct = C.c_int32(0)
+    tot = C.c_double(0)
+    Hsub = np.zeros((n, 12)) if want_rows else None
+    meas = np.zeros(n) if want_rows else None
+    lib().orc_residual_pass(C.byref(cfg), C.c_void_p(tree.h), _p(tree.xyz), _p(scan), C.c_int64(n), _p(x),
+                            C.c_int(int(rematch)), _p(ps.selected), _p(ps.nn_idx), _p(ps.nn_d2),
+                            _p(ps.nn_cnt), _p(ps.plane), _p(ps.plane_ok), _p(ps.pd2), _p(ps.eff),
+                            _p(ps.HtH), _p(ps.Htz), C.byref(effct), C.byref(tot), _p(Hsub), _p(meas))
+    ps.effct = effct.value
+    ps.total_res = tot.value
+    if want_rows:
+        ps.Hsub = Hsub[:ps.effct].copy()
+        ps.meas = meas[:ps.effct].copy()
+    return ps
+
+
+def eskf_update(cfg, x, x_prop, P, HtH, Htz):
+    x = np.array(x, float)
+    x_prop = np.ascontiguousarray(x_prop, float)
+    P = np.ascontiguousarray(P, float)
+    HtH = np.ascontiguousarray(HtH, float)
+    Htz = np.ascontiguousarray(Htz, float)
+    sol = np.zeros(DIM)
+    K1 = np.zeros((DIM, DIM))
+    conv = lib().orc_eskf_update(C.byref(cfg), _p(x), _p(x_prop), _p(P), _p(HtH), _p(Htz), _p(sol), _p(K1))
+    return x, sol, K1, bool(conv)
+
+
+def eskf_update_dense(cfg, x, x_prop, P, Hsub, meas):
+    x = np.array(x, float)
+    x_prop = np.ascontiguousarray(x_prop, float)
+    P = np.ascontiguousarray(P, float)
+    Hsub = np.ascontiguousarray(Hsub, float)
+    meas = np.ascontiguousarray(meas, float)
+    sol = np.zeros(DIM)
+    K1 = np.zeros((DIM, DIM))
+    conv = lib().orc_eskf_update_dense(C.byref(cfg), _p(x), _p(x_prop), _p(P), _p(Hsub), _p(meas),
+                                       C.c_int32(len(meas)), _p(sol), _p(K1))
+    return x, sol, K1, bool(conv)
+
+
+def cov_update(K1, HtH, P):
+    P = np.array(P, float)
+    lib().orc_cov_update(_p(np.ascontiguousarray(K1, float)), _p(np.ascontiguousarray(HtH, float)), _p(P))
+    return P
+
+
+def iterated_update(cfg, tree, scan_xyz, x, x_prop, P, feat_queue=None, use_dense=False):
+    """Returns dict with the final state/cov and the per-iteration log."""
+    scan = np.ascontiguousarray(scan_xyz, np.float32).reshape(-1, 3)
+    n = len(scan)
+    x = np.array(x, float)
+    x_prop = np.ascontiguousarray(x_prop, float)
+    P = np.array(P, float)
+    q = np.zeros(11, np.int32)
+    qlen = C.c_int32(0)
+    if feat_queue is not None:
+        fq = list(feat_queue)[-10:]
+        q[:len(fq)] = fq
+        qlen.value = len(fq)
+    mi = cfg.max_iter
+    log_effct = np.zeros(mi, np.int32)
+    log_tot = np.zeros(mi)
+    log_rem = np.zeros(mi, np.int32)
+    log_conv = np.zeros(mi, np.int32)
+    log_sol = np.zeros((mi, DIM))
+    nn = np.zeros((n, K), np.int32)
+    res = IterResult()
+    lib().orc_iterated_update(C.byref(cfg), C.c_void_p(tree.h), _p(tree.xyz), _p(scan), C.c_int64(n), _p(x),
+                              _p(x_prop), _p(P), _p(q), C.byref(qlen), C.c_int(int(use_dense)),
+                              _p(log_effct), _p(log_tot), _p(log_rem), _p(log_conv), _p(log_sol), _p(nn),
+                              C.byref(res))
+    it = res.iters
+    return dict(x=x, P=P, iters=it, rematch_passes=res.rematch_passes, converged=bool(res.converged),
+                ekf_stop=bool(res.ekf_stop), effct=log_effct[:it].copy(), total_res=log_tot[:it].copy(),
+                rematch=log_rem[:it].copy(), conv=log_conv[:it].copy(), solution=log_sol[:it].copy(),
+                nn_idx=nn, feat_queue=q[:qlen.value].copy())
