@@ -1,0 +1,65 @@
+// s2m_device.h -- data layout shared by the HIP kernels of the scan-to-map engine (gfx950).
+//
+// Map layout in HBM ("brick grid", replaces the ikd-Tree of eskf_lio/include/ikd-Tree/):
+//   pts   : M x float4 {x, y, z, bitcast(original index)}, sorted by (brick, cell-in-brick);
+//           one 16-byte load per candidate, a cell's points are contiguous, the cells of one
+//           x-row of a brick are contiguous.
+//   top   : dense nbx*nby*nbz array over the map bounding box, 0 = empty brick else brick id + 1.
+//           A brick is 8x8x8 cells; at c = 0.25 m this array is 58 K entries for a 215 m scene,
+//           so it stays L2-resident.
+//   tab   : per occupied brick a 520-entry row (513 used): exclusive prefix of the point counts of
+//           its 512 cells (x fastest) as absolute indices into pts; tab[cell] .. tab[cell+1] is
+//           the cell, tab[row*8 + x0] .. tab[row*8 + x1 + 1] a run of cells along x.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace s2m {
+
+constexpr int kK = 5;
+constexpr int kBrick = 8;
+constexpr int kBrickCells = 512;
+constexpr int kBrickStride = 520;
+
+enum : uint8_t { kFlagGate = 1, kFlagPlane = 2 };
+
+struct Grid {
+    float ox, oy, oz;   // world coordinate of cell (0,0,0)'s lower corner
+    float c, inv_c;     // cell edge and its reciprocal
+    float slop;         // safety margin of the termination bound, in cells
+    int ncx, ncy, ncz;  // cells per axis (multiples of 8)
+    int nbx, nby, nbz;  // bricks per axis
+    const uint32_t *top;
+    const uint32_t *tab;
+    const float4 *pts;
+    int64_t m;
+};
+
+// rot_end, pos_end, R_L_I, T_L_I of StatesGroup (eskf_lio/include/common_lib.h:219-222)
+struct Pose {
+    double R[9], t[3], RLI[9], TLI[3];
+};
+
+struct Gates {
+    float plane_thr;
+    float knn_d2_gate;
+    double s_gate;
+    double res_gate;
+    int extrinsic;
+};
+
+// p_w = rot_end * (R_L_I * p_b + T_L_I) + pos_end in double, rounded to float
+// (eskf_lio/src/laserMapping.cpp:835-841).  Sums left to right, no contraction.
+__device__ __forceinline__ void body_to_world(const Pose &P, float bx, float by, float bz, float &wx,
+                                              float &wy, float &wz)
+{
+    const double x = (double)bx, y = (double)by, z = (double)bz;
+    const double ix = ((P.RLI[0] * x + P.RLI[1] * y) + P.RLI[2] * z) + P.TLI[0];
+    const double iy = ((P.RLI[3] * x + P.RLI[4] * y) + P.RLI[5] * z) + P.TLI[1];
+    const double iz = ((P.RLI[6] * x + P.RLI[7] * y) + P.RLI[8] * z) + P.TLI[2];
+    wx = (float)(((P.R[0] * ix + P.R[1] * iy) + P.R[2] * iz) + P.t[0]);
+    wy = (float)(((P.R[3] * ix + P.R[4] * iy) + P.R[5] * iz) + P.t[1]);
+    wz = (float)(((P.R[6] * ix + P.R[7] * iy) + P.R[8] * iz) + P.t[2]);
+}
+
+}  // namespace s2m

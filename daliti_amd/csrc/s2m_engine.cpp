@@ -1,0 +1,619 @@
+// s2m_engine.cpp -- host engine and the C ABI of include/daliti_s2m.h.
+//
+// The engine owns what laserMapping.cpp keeps in globals for this path (ikdtree :164,
+// Nearest_Points :578, point_selected_surf :812, effct_feat_numQueue :193, K / H_T_H :696,983) and
+// drives the HIP kernels; there is no CPU fallback for any compute entry point.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/daliti_s2m.h"
+#include "s2m_eskf.h"
+#include "s2m_kernels.h"
+
+namespace s2m {
+void launch_deinterleave(const float *src, int64_t stride, int64_t n, float *sx, float *sy, float *sz,
+                         hipStream_t st);
+}
+
+using namespace s2m;
+
+struct s2m_engine {
+    s2m_config cfg{};
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool timing = false;
+    double last_ms[3] = {0, 0, 0};
+    int match_group = 16;
+    std::string err;
+
+    MapBuffers map;
+    Grid grid{};
+    MapStats stats;
+    bool map_ready = false;
+
+    // staging for host inputs
+    float *d_stage = nullptr;
+    int64_t stage_cap = 0;  // floats
+
+    // scan + per-point state
+    int64_t n = 0, n_cap = 0;
+    bool scan_ready = false, pass_done = false;
+    float *d_scan = nullptr;  // sx | sy | sz, each n_cap floats
+    float4 *d_plane = nullptr;
+    uint8_t *d_flags = nullptr, *d_sel = nullptr, *d_eff = nullptr;
+    float *d_pd2 = nullptr;
+    int32_t *d_nn_idx = nullptr;
+    float *d_nn_d2 = nullptr;
+    double *d_partials = nullptr;
+    double *d_block = nullptr;
+    double *h_block = nullptr;  // pinned
+    // rows on request
+    uint32_t *d_block_off = nullptr;
+    double *d_hx = nullptr, *d_h = nullptr;
+    int32_t *d_rowidx = nullptr;
+    int64_t rows_cap = 0;
+
+    Pose last_pose{};
+    bool nn_valid = false;
+
+    EskfWork work;
+    int32_t queue[S2M_FEAT_QUEUE + 1] = {0};
+    int32_t queue_len = 0;
+};
+
+namespace {
+
+int fail(s2m_engine *e, int code, const char *what, hipError_t he = hipSuccess)
+{
+    if (e) {
+        e->err = what;
+        if (he != hipSuccess) {
+            e->err += ": ";
+            e->err += hipGetErrorString(he);
+        }
+    }
+    return code;
+}
+
+#define S2M_HIP(e, call)                                                 \
+    do {                                                                 \
+        hipError_t he_ = (call);                                         \
+        if (he_ != hipSuccess) return fail((e), S2M_ERR_HIP, #call, he_); \
+    } while (0)
+
+template <class T>
+int grow(s2m_engine *e, T **p, int64_t count)
+{
+    if (*p) S2M_HIP(e, hipFree(*p));
+    *p = nullptr;
+    S2M_HIP(e, hipMalloc((void **)p, (size_t)std::max<int64_t>(count, 1) * sizeof(T)));
+    return S2M_OK;
+}
+
+Gates gates_of(const s2m_config &c)
+{
+    Gates g;
+    g.plane_thr = c.plane_thr;
+    g.knn_d2_gate = c.knn_d2_gate;
+    g.s_gate = c.s_gate;
+    g.res_gate = c.res_gate;
+    g.extrinsic = c.extrinsic_est_en ? 1 : 0;
+    return g;
+}
+
+Pose pose_of(const double s[S2M_STATE_DOUBLES])
+{
+    Pose p;
+    std::memcpy(p.R, s + 0, 9 * sizeof(double));
+    std::memcpy(p.t, s + 9, 3 * sizeof(double));
+    std::memcpy(p.RLI, s + 12, 9 * sizeof(double));
+    std::memcpy(p.TLI, s + 21, 3 * sizeof(double));
+    return p;
+}
+
+int check_config(const s2m_config *c)
+{
+    if (!c) return S2M_ERR_ARG;
+    if (!(c->plane_thr >= 0.0f) || !(c->knn_d2_gate > 0.0f) || !(c->laser_point_cov > 0.0)) return S2M_ERR_ARG;
+    if (c->max_iter < 1 || c->max_iter > 64) return S2M_ERR_ARG;
+    return S2M_OK;
+}
+
+// stage a host or device AoS cloud; returns a device pointer usable until the next stage call
+int stage_cloud(s2m_engine *e, const float *xyz, int64_t stride, int64_t count, int on_device, const float **dev)
+{
+    if (on_device || count == 0) {
+        *dev = xyz;
+        return S2M_OK;
+    }
+    const int64_t floats = (count - 1) * stride + 3;
+    if (floats > e->stage_cap) {
+        int rc = grow(e, &e->d_stage, floats);
+        if (rc) return rc;
+        e->stage_cap = floats;
+    }
+    S2M_HIP(e, hipMemcpyAsync(e->d_stage, xyz, (size_t)floats * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    *dev = e->d_stage;
+    return S2M_OK;
+}
+
+int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, double *d_out)
+{
+    if (!e || !state) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
+    if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
+    if (!rematch && !e->nn_valid) return fail(e, S2M_ERR_STATE, "first pass of a scan must be a rematch pass");
+    S2M_HIP(e, hipSetDevice(e->device));
+    const Pose pose = pose_of(state);
+    const Gates gates = gates_of(e->cfg);
+    const int n = (int)e->n;
+    float *sx = e->d_scan, *sy = e->d_scan + e->n_cap, *sz = e->d_scan + 2 * e->n_cap;
+    if (e->timing) S2M_HIP(e, hipEventRecord(e->ev[0], e->stream));
+    if (rematch) {
+        MatchArgs m;
+        m.grid = e->grid; m.pose = pose; m.gates = gates;
+        m.sx = sx; m.sy = sy; m.sz = sz; m.n = n;
+        m.plane = e->d_plane; m.flags = e->d_flags; m.sel = e->d_sel;
+        m.nn_idx = e->cfg.keep_neighbors ? e->d_nn_idx : nullptr;
+        m.nn_d2 = e->cfg.keep_neighbors ? e->d_nn_d2 : nullptr;
+        launch_match(m, e->match_group, e->stream);
+        e->nn_valid = true;
+    }
+    if (e->timing) S2M_HIP(e, hipEventRecord(e->ev[1], e->stream));
+    ReduceArgs r;
+    r.pose = pose; r.gates = gates;
+    r.sx = sx; r.sy = sy; r.sz = sz; r.n = n;
+    r.plane = e->d_plane; r.flags = e->d_flags; r.sel = e->d_sel; r.eff = e->d_eff; r.pd2 = e->d_pd2;
+    r.partials = e->d_partials; r.block = d_out;
+    launch_reduce(r, e->stream);
+    if (e->timing) S2M_HIP(e, hipEventRecord(e->ev[2], e->stream));
+    S2M_HIP(e, hipGetLastError());
+    e->last_pose = pose;
+    e->pass_done = true;
+    return S2M_OK;
+}
+
+int finish_timing(s2m_engine *e)
+{
+    if (!e->timing) return S2M_OK;
+    S2M_HIP(e, hipEventSynchronize(e->ev[2]));
+    float a = 0.f, b = 0.f;
+    S2M_HIP(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
+    S2M_HIP(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+    e->last_ms[0] = a;
+    e->last_ms[1] = b;
+    e->last_ms[2] = a + b;
+    return S2M_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int s2m_abi_version(void) { return S2M_ABI_VERSION; }
+
+int s2m_config_default(s2m_config *c)
+{
+    if (!c) return S2M_ERR_ARG;
+    std::memset(c, 0, sizeof(*c));
+    c->plane_thr = 0.1f;
+    c->knn_d2_gate = 5.0f;
+    c->s_gate = 0.9;
+    c->res_gate = 2.0;
+    c->laser_point_cov = 0.0015;
+    c->conv_rot_deg = 0.01;
+    c->conv_pos_cm = 0.015;
+    c->extrinsic_est_en = 0;
+    c->max_iter = 10;  // mapping/max_iteration default, laserMapping.cpp:656
+    c->feat_threshold = 100;
+    c->cell_size = 0.0f;
+    c->device = -1;
+    c->keep_neighbors = 0;
+    return S2M_OK;
+}
+
+const char *s2m_strerror(int code)
+{
+    switch (code) {
+        case S2M_OK: return "ok";
+        case S2M_ERR_ARG: return "invalid argument";
+        case S2M_ERR_NO_DEVICE: return "no gfx950 HIP device";
+        case S2M_ERR_HIP: return "HIP runtime error";
+        case S2M_ERR_STATE: return "call order error";
+        case S2M_ERR_CAPACITY: return "capacity exceeded";
+        case S2M_ERR_NUMERIC: return "singular matrix";
+        default: return "unknown error";
+    }
+}
+
+int s2m_create(const s2m_config *cfg, s2m_engine **out)
+{
+    if (!out) return S2M_ERR_ARG;
+    *out = nullptr;
+    int rc = check_config(cfg);
+    if (rc) return rc;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return S2M_ERR_NO_DEVICE;
+    int dev = cfg->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return S2M_ERR_NO_DEVICE;
+    if (dev >= count) return S2M_ERR_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return S2M_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return S2M_ERR_NO_DEVICE;  // kernels are gfx950-only
+    s2m_engine *e = new (std::nothrow) s2m_engine();
+    if (!e) return S2M_ERR_CAPACITY;
+    e->cfg = *cfg;
+    e->device = dev;
+    if (const char *g = std::getenv("S2M_MATCH_GROUP")) {
+        const int v = std::atoi(g);
+        if (v == 8 || v == 16 || v == 32) e->match_group = v;
+    }
+    bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&e->ev[i]) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_block, S2M_BLOCK_DOUBLES * sizeof(double)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&e->h_block, S2M_BLOCK_DOUBLES * sizeof(double), hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        s2m_destroy(e);
+        return S2M_ERR_HIP;
+    }
+    e->stream = e->own_stream;
+    *out = e;
+    return S2M_OK;
+}
+
+int s2m_destroy(s2m_engine *e)
+{
+    if (!e) return S2M_ERR_ARG;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    free_map(e->map);
+    void *ptrs[] = {e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
+                    e->d_nn_d2, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e->h_block) (void)hipHostFree(e->h_block);
+    for (auto &ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+    return S2M_OK;
+}
+
+const char *s2m_last_error(const s2m_engine *e) { return e ? e->err.c_str() : "null handle"; }
+
+int s2m_set_config(s2m_engine *e, const s2m_config *cfg)
+{
+    if (!e) return S2M_ERR_ARG;
+    int rc = check_config(cfg);
+    if (rc) return fail(e, rc, "invalid config");
+    const float cell = e->cfg.cell_size;
+    const int dev = e->cfg.device;
+    const int keep = e->cfg.keep_neighbors;
+    e->cfg = *cfg;
+    e->cfg.cell_size = cell;
+    e->cfg.device = dev;
+    e->cfg.keep_neighbors = keep;
+    return S2M_OK;
+}
+
+int s2m_set_stream(s2m_engine *e, void *hip_stream)
+{
+    if (!e) return S2M_ERR_ARG;
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    return S2M_OK;
+}
+
+int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride, int64_t m, int on_device)
+{
+    if (!e || m < 0 || stride < 3 || (m > 0 && !xyz)) return fail(e, S2M_ERR_ARG, "s2m_map_build: bad argument");
+    if (m >= ((int64_t)1 << 31)) return fail(e, S2M_ERR_CAPACITY, "map too large (>= 2^31 points)");
+    S2M_HIP(e, hipSetDevice(e->device));
+    const float *dev = nullptr;
+    int rc = stage_cloud(e, xyz, stride, m, on_device, &dev);
+    if (rc) return rc;
+    e->map_ready = false;
+    bool too_large = false;
+    hipError_t he = build_map(dev, stride, m, e->cfg.cell_size, e->map, e->grid, e->stats, too_large, e->stream);
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
+    if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
+    e->map_ready = true;
+    e->nn_valid = false;
+    return S2M_OK;
+}
+
+int s2m_map_size(const s2m_engine *e, int64_t *m)
+{
+    if (!e || !m) return S2M_ERR_ARG;
+    *m = e->map_ready ? e->grid.m : 0;
+    return S2M_OK;
+}
+
+int s2m_map_info(const s2m_engine *e, double info[8])
+{
+    if (!e || !info) return S2M_ERR_ARG;
+    if (!e->map_ready) return S2M_ERR_STATE;
+    info[0] = e->grid.c;
+    info[1] = e->grid.ox; info[2] = e->grid.oy; info[3] = e->grid.oz;
+    info[4] = (double)e->stats.bricks;
+    info[5] = (double)e->stats.top_entries;
+    info[6] = (double)e->stats.occupied_cells;
+    info[7] = e->stats.occupied_cells ? (double)e->grid.m / (double)e->stats.occupied_cells : 0.0;
+    return S2M_OK;
+}
+
+int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int on_device)
+{
+    if (!e || n < 0 || stride < 3 || (n > 0 && !xyz)) return fail(e, S2M_ERR_ARG, "s2m_scan_set: bad argument");
+    if (n > (int64_t)1 << 28) return fail(e, S2M_ERR_CAPACITY, "scan too large");
+    S2M_HIP(e, hipSetDevice(e->device));
+    if (n > e->n_cap) {
+        const int64_t cap = ((n + 255) / 256) * 256;
+        int rc = 0;
+        rc = rc ? rc : grow(e, &e->d_scan, 3 * cap);
+        rc = rc ? rc : grow(e, &e->d_plane, cap);
+        rc = rc ? rc : grow(e, &e->d_flags, cap);
+        rc = rc ? rc : grow(e, &e->d_sel, cap);
+        rc = rc ? rc : grow(e, &e->d_eff, cap);
+        rc = rc ? rc : grow(e, &e->d_pd2, cap);
+        rc = rc ? rc : grow(e, &e->d_nn_idx, cap * S2M_K);
+        rc = rc ? rc : grow(e, &e->d_nn_d2, cap * S2M_K);
+        rc = rc ? rc : grow(e, &e->d_partials, (int64_t)reduce_blocks((int)cap) * kRedTerms);
+        rc = rc ? rc : grow(e, &e->d_block_off, (int64_t)reduce_blocks((int)cap) + 1);
+        if (rc) return rc;
+        e->n_cap = cap;
+    }
+    const float *dev = nullptr;
+    int rc = stage_cloud(e, xyz, stride, n, on_device, &dev);
+    if (rc) return rc;
+    if (n > 0) launch_deinterleave(dev, stride, n, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, e->stream);
+    // point_selected_surf(feats_down_size, true) (:812); neighbours invalid until the first rematch
+    S2M_HIP(e, hipMemsetAsync(e->d_sel, 1, (size_t)std::max<int64_t>(n, 1), e->stream));
+    S2M_HIP(e, hipMemsetAsync(e->d_eff, 0, (size_t)std::max<int64_t>(n, 1), e->stream));
+    S2M_HIP(e, hipMemsetAsync(e->d_flags, 0, (size_t)std::max<int64_t>(n, 1), e->stream));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));  // the host buffer may be reused by the caller now
+    e->n = n;
+    e->scan_ready = true;
+    e->pass_done = false;
+    e->nn_valid = false;
+    return S2M_OK;
+}
+
+int s2m_residual_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, s2m_pass_out *out)
+{
+    if (!out) return fail(e, S2M_ERR_ARG, "null output");
+    int rc = run_pass(e, state, rematch, e ? e->d_block : nullptr);
+    if (rc) return rc;
+    S2M_HIP(e, hipMemcpyAsync(e->h_block, e->d_block, S2M_BLOCK_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
+                              e->stream));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    rc = finish_timing(e);
+    if (rc) return rc;
+    std::memcpy(out->HtH, e->h_block, 144 * sizeof(double));
+    std::memcpy(out->Htz, e->h_block + 144, 12 * sizeof(double));
+    out->effct_feat_num = (int32_t)e->h_block[156];
+    out->total_residual = e->h_block[157];
+    out->rematch = rematch ? 1 : 0;
+    return S2M_OK;
+}
+
+int s2m_residual_pass_device(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, double *d_block)
+{
+    if (!d_block) return fail(e, S2M_ERR_ARG, "null device block");
+    return run_pass(e, state, rematch, d_block);
+}
+
+int s2m_get_rows(s2m_engine *e, double *h_x, double *h, int32_t *scan_index, int64_t capacity, int64_t *m_out)
+{
+    if (!e || !m_out) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->pass_done) return fail(e, S2M_ERR_STATE, "no pass yet");
+    S2M_HIP(e, hipSetDevice(e->device));
+    if (e->rows_cap < e->n) {
+        int rc = 0;
+        rc = rc ? rc : grow(e, &e->d_hx, e->n_cap * 12);
+        rc = rc ? rc : grow(e, &e->d_h, e->n_cap);
+        rc = rc ? rc : grow(e, &e->d_rowidx, e->n_cap);
+        if (rc) return rc;
+        e->rows_cap = e->n_cap;
+    }
+    RowsArgs a;
+    a.pose = e->last_pose; a.gates = gates_of(e->cfg);
+    a.sx = e->d_scan; a.sy = e->d_scan + e->n_cap; a.sz = e->d_scan + 2 * e->n_cap; a.n = (int)e->n;
+    a.plane = e->d_plane; a.pd2 = e->d_pd2; a.eff = e->d_eff;
+    a.block_off = e->d_block_off; a.h_x = e->d_hx; a.h = e->d_h; a.scan_index = e->d_rowidx;
+    launch_rows(a, e->stream);
+    uint32_t m = 0;
+    S2M_HIP(e, hipMemcpyAsync(&m, e->d_block_off + reduce_blocks((int)e->n), sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              e->stream));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    *m_out = m;
+    if ((h_x || h || scan_index) && capacity < (int64_t)m) return fail(e, S2M_ERR_CAPACITY, "row buffers too small");
+    if (h_x && m) S2M_HIP(e, hipMemcpy(h_x, e->d_hx, (size_t)m * 12 * sizeof(double), hipMemcpyDeviceToHost));
+    if (h && m) S2M_HIP(e, hipMemcpy(h, e->d_h, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+    if (scan_index && m) S2M_HIP(e, hipMemcpy(scan_index, e->d_rowidx, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return S2M_OK;
+}
+
+int s2m_get_point_state(s2m_engine *e, uint8_t *selected, uint8_t *effective, float *plane, float *pd2)
+{
+    if (!e) return S2M_ERR_ARG;
+    if (!e->pass_done) return fail(e, S2M_ERR_STATE, "no pass yet");
+    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    const size_t n = (size_t)e->n;
+    if (n == 0) return S2M_OK;
+    if (selected) S2M_HIP(e, hipMemcpy(selected, e->d_sel, n, hipMemcpyDeviceToHost));
+    if (effective) S2M_HIP(e, hipMemcpy(effective, e->d_eff, n, hipMemcpyDeviceToHost));
+    if (plane) S2M_HIP(e, hipMemcpy(plane, e->d_plane, n * sizeof(float4), hipMemcpyDeviceToHost));
+    if (pd2) S2M_HIP(e, hipMemcpy(pd2, e->d_pd2, n * sizeof(float), hipMemcpyDeviceToHost));
+    return S2M_OK;
+}
+
+int s2m_get_neighbors(s2m_engine *e, int32_t *idx, float *d2)
+{
+    if (!e) return S2M_ERR_ARG;
+    if (!e->cfg.keep_neighbors) return fail(e, S2M_ERR_STATE, "engine created without keep_neighbors");
+    if (!e->nn_valid) return fail(e, S2M_ERR_STATE, "no rematch pass yet");
+    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    const size_t n = (size_t)e->n;
+    if (n == 0) return S2M_OK;
+    if (idx) S2M_HIP(e, hipMemcpy(idx, e->d_nn_idx, n * S2M_K * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (d2) S2M_HIP(e, hipMemcpy(d2, e->d_nn_d2, n * S2M_K * sizeof(float), hipMemcpyDeviceToHost));
+    return S2M_OK;
+}
+
+int s2m_eskf_update(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double x_prop[S2M_STATE_DOUBLES],
+                    const double P[S2M_DIM * S2M_DIM], const double HtH[144], const double Htz[12],
+                    double solution[S2M_DIM], int32_t *converged)
+{
+    if (!e || !x || !x_prop || !P || !HtH || !Htz || !solution || !converged) return fail(e, S2M_ERR_ARG, "null argument");
+    State xs, xp;
+    Mat24 Pm;
+    std::memcpy(&xs, x, sizeof(xs));
+    std::memcpy(&xp, x_prop, sizeof(xp));
+    std::memcpy(Pm.data(), P, sizeof(double) * S2M_DIM * S2M_DIM);
+    EskfParams prm;
+    prm.laser_point_cov = e->cfg.laser_point_cov;
+    prm.conv_rot_deg = e->cfg.conv_rot_deg;
+    prm.conv_pos_cm = e->cfg.conv_pos_cm;
+    Vec24 sol{};
+    bool conv = false;
+    if (!eskf_update(prm, xs, xp, Pm, HtH, Htz, sol, conv, e->work)) return fail(e, S2M_ERR_NUMERIC, "singular matrix in eskf update");
+    std::memcpy(x, &xs, sizeof(xs));
+    std::memcpy(solution, sol.data(), sizeof(double) * S2M_DIM);
+    *converged = conv ? 1 : 0;
+    return S2M_OK;
+}
+
+int s2m_cov_update(s2m_engine *e, double P[S2M_DIM * S2M_DIM])
+{
+    if (!e || !P) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->work.valid) return fail(e, S2M_ERR_STATE, "no eskf update yet");
+    Mat24 Pm;
+    std::memcpy(Pm.data(), P, sizeof(double) * S2M_DIM * S2M_DIM);
+    cov_update(e->work, Pm);
+    std::memcpy(P, Pm.data(), sizeof(double) * S2M_DIM * S2M_DIM);
+    return S2M_OK;
+}
+
+int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double x_prop[S2M_STATE_DOUBLES],
+                        double P[S2M_DIM * S2M_DIM], s2m_iter_log *log)
+{
+    if (!e || !x || !x_prop || !P) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
+    // a new scan starts with every point selected and no neighbours (laserMapping.cpp:810-818)
+    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_HIP(e, hipMemsetAsync(e->d_sel, 1, (size_t)std::max<int64_t>(e->n, 1), e->stream));
+    e->nn_valid = false;
+    const int max_iter = e->cfg.max_iter;
+    int rematch_num = 0, rematch_en = 0, it = 0, passes = 0;
+    int32_t conv = 0, stop = 0;
+    if (log) std::memset(log, 0, sizeof(*log));
+    for (it = 0; it < max_iter; ++it) {
+        const int rematch = (it == 0) || rematch_en;  // :847
+        passes += rematch;
+        s2m_pass_out out;
+        int rc = s2m_residual_pass(e, x, rematch, &out);
+        if (rc) return rc;
+        // degeneracy queue (:899-918)
+        e->queue[e->queue_len++] = out.effct_feat_num;
+        if (e->queue_len > S2M_FEAT_QUEUE) {
+            std::memmove(e->queue, e->queue + 1, sizeof(int32_t) * S2M_FEAT_QUEUE);
+            e->queue_len = S2M_FEAT_QUEUE;
+        }
+        stop = 0;
+        for (int q = 0; q < e->queue_len; ++q)
+            if (e->queue[q] <= e->cfg.feat_threshold) { stop = 1; break; }
+        double sol[S2M_DIM] = {0};
+        if (!stop) {  // flg_EKF_inited is always true (INIT_TIME == 0, :75,:762)
+            rc = s2m_eskf_update(e, x, x_prop, P, out.HtH, out.Htz, sol, &conv);
+            if (rc) return rc;
+        }
+        if (log) {
+            log->effct[it] = out.effct_feat_num;
+            log->rematch[it] = rematch;
+            log->conv[it] = conv;
+            log->total_residual[it] = out.total_residual;
+            std::memcpy(log->solution[it], sol, sizeof(sol));
+        }
+        rematch_en = 0;  // rematch judgement (:1070-1076)
+        if (conv || (rematch_num == 0 && it == max_iter - 2)) {
+            rematch_en = 1;
+            rematch_num++;
+        }
+        if (rematch_num >= 2 || it == max_iter - 1) {  // :1079-1094
+            if (!stop) {
+                rc = s2m_cov_update(e, P);
+                if (rc) return rc;
+            }
+            ++it;
+            break;
+        } else if (stop) {  // :1095-1101
+            ++it;
+            break;
+        }
+    }
+    if (log) {
+        log->iters = it;
+        log->rematch_passes = passes;
+        log->converged = conv;
+        log->ekf_stop = stop;
+    }
+    return S2M_OK;
+}
+
+int s2m_feat_queue_get(const s2m_engine *e, int32_t q[S2M_FEAT_QUEUE], int32_t *len)
+{
+    if (!e || !q || !len) return S2M_ERR_ARG;
+    std::memcpy(q, e->queue, sizeof(int32_t) * S2M_FEAT_QUEUE);
+    *len = e->queue_len;
+    return S2M_OK;
+}
+
+int s2m_feat_queue_set(s2m_engine *e, const int32_t *q, int32_t len)
+{
+    if (!e || len < 0 || len > S2M_FEAT_QUEUE || (len > 0 && !q)) return S2M_ERR_ARG;
+    if (len) std::memcpy(e->queue, q, sizeof(int32_t) * (size_t)len);
+    e->queue_len = len;
+    return S2M_OK;
+}
+
+int s2m_h_share_model(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int first_iteration,
+                      s2m_dyn_share *d)
+{
+    if (!e || !state || !d) return fail(e, S2M_ERR_ARG, "null argument");
+    s2m_pass_out out;
+    const int rematch = first_iteration || d->converge || !e->nn_valid;
+    int rc = s2m_residual_pass(e, state, rematch, &out);
+    if (rc) return rc;
+    d->rows = out.effct_feat_num;
+    d->total_residual = out.total_residual;
+    d->valid = out.effct_feat_num >= 1;
+    if (!d->valid) return S2M_OK;
+    int64_t m = 0;
+    return s2m_get_rows(e, d->h_x, d->h, nullptr, d->capacity, &m);
+}
+
+int s2m_set_timing(s2m_engine *e, int enabled)
+{
+    if (!e) return S2M_ERR_ARG;
+    e->timing = enabled != 0;
+    return S2M_OK;
+}
+
+int s2m_get_timing(const s2m_engine *e, double ms[3])
+{
+    if (!e || !ms) return S2M_ERR_ARG;
+    ms[0] = e->last_ms[0]; ms[1] = e->last_ms[1]; ms[2] = e->last_ms[2];
+    return S2M_OK;
+}
+
+}  // extern "C"

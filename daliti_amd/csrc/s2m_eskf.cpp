@@ -1,0 +1,198 @@
+// s2m_eskf.cpp -- see s2m_eskf.h.
+#include "s2m_eskf.h"
+
+#include <cmath>
+#include <cstring>
+#include <utility>
+
+namespace s2m {
+namespace {
+
+struct M3 {
+    double a[9];
+    double operator()(int r, int c) const { return a[r * 3 + c]; }
+    double &operator()(int r, int c) { return a[r * 3 + c]; }
+};
+
+M3 load3(const double *p) { M3 m; std::memcpy(m.a, p, sizeof(m.a)); return m; }
+void store3(const M3 &m, double *p) { std::memcpy(p, m.a, sizeof(m.a)); }
+
+M3 mul(const M3 &A, const M3 &B)
+{
+    M3 C;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) C(r, c) = A(r, 0) * B(0, c) + A(r, 1) * B(1, c) + A(r, 2) * B(2, c);
+    return C;
+}
+M3 transposed(const M3 &A)
+{
+    M3 T;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T(r, c) = A(c, r);
+    return T;
+}
+
+// Inverse by LU with partial pivoting (Eigen's fixed-size inverse for n > 4).
+bool invert(const Mat24 &in, Mat24 &out)
+{
+    constexpr int N = kDim;
+    Mat24 lu = in;
+    int perm[N];
+    for (int i = 0; i < N; ++i) perm[i] = i;
+    for (int k = 0; k < N; ++k) {
+        int piv = k;
+        double mag = std::fabs(lu[k * N + k]);
+        for (int r = k + 1; r < N; ++r) {
+            const double v = std::fabs(lu[r * N + k]);
+            if (v > mag) { mag = v; piv = r; }
+        }
+        if (!(mag > 0.0)) return false;
+        if (piv != k) {
+            for (int c = 0; c < N; ++c) std::swap(lu[k * N + c], lu[piv * N + c]);
+            std::swap(perm[k], perm[piv]);
+        }
+        const double d = lu[k * N + k];
+        for (int r = k + 1; r < N; ++r) {
+            const double f = lu[r * N + k] / d;
+            lu[r * N + k] = f;
+            if (f != 0.0)
+                for (int c = k + 1; c < N; ++c) lu[r * N + c] -= f * lu[k * N + c];
+        }
+    }
+    double y[N];
+    for (int col = 0; col < N; ++col) {
+        for (int r = 0; r < N; ++r) {
+            double s = (perm[r] == col) ? 1.0 : 0.0;
+            for (int c = 0; c < r; ++c) s -= lu[r * N + c] * y[c];
+            y[r] = s;
+        }
+        for (int r = N - 1; r >= 0; --r) {
+            double s = y[r];
+            for (int c = r + 1; c < N; ++c) s -= lu[r * N + c] * out[c * N + col];
+            out[r * N + col] = s / lu[r * N + r];
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+void so3_exp(double v1, double v2, double v3, double R[9])
+{
+    // so3_math.h:55-72: identity unless |v| > 1e-5, Rodrigues on the unit axis
+    const double norm = std::sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+    M3 E{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    if (norm > 0.00001) {
+        const double r[3] = {v1 / norm, v2 / norm, v3 / norm};
+        const M3 K{{0.0, -r[2], r[1], r[2], 0.0, -r[0], -r[1], r[0], 0.0}};
+        const double s = std::sin(norm), c1 = 1.0 - std::cos(norm);
+        M3 cK;
+        for (int i = 0; i < 9; ++i) cK.a[i] = c1 * K.a[i];
+        const M3 cKK = mul(cK, K);
+        for (int i = 0; i < 9; ++i) E.a[i] = (E.a[i] + s * K.a[i]) + cKK.a[i];
+    }
+    store3(E, R);
+}
+
+void so3_log(const double R[9], double out[3])
+{
+    // so3_math.h:76-81
+    const double tr = R[0] + R[4] + R[8];
+    const double theta = (tr > 3.0 - 1e-6) ? 0.0 : std::acos(0.5 * (tr - 1));
+    const double K[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+    const double f = (std::fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / std::sin(theta));
+    for (int i = 0; i < 3; ++i) out[i] = f * K[i];
+}
+
+void boxplus(State &x, const Vec24 &d)
+{
+    double E[9];
+    so3_exp(d[0], d[1], d[2], E);
+    store3(mul(load3(x.rot), load3(E)), x.rot);
+    so3_exp(d[6], d[7], d[8], E);
+    store3(mul(load3(x.R_LI), load3(E)), x.R_LI);
+    for (int i = 0; i < 3; ++i) {
+        x.pos[i] += d[3 + i];
+        x.T_LI[i] += d[9 + i];
+        x.vel[i] += d[12 + i];
+        x.bg[i] += d[15 + i];
+        x.ba[i] += d[18 + i];
+        x.grav[i] += d[21 + i];
+    }
+}
+
+Vec24 boxminus(const State &a, const State &b)
+{
+    Vec24 o{};
+    M3 rd = mul(transposed(load3(b.rot)), load3(a.rot));
+    so3_log(rd.a, &o[0]);
+    rd = mul(transposed(load3(b.R_LI)), load3(a.R_LI));
+    so3_log(rd.a, &o[6]);
+    for (int i = 0; i < 3; ++i) {
+        o[3 + i] = a.pos[i] - b.pos[i];
+        o[9 + i] = a.T_LI[i] - b.T_LI[i];
+        o[12 + i] = a.vel[i] - b.vel[i];
+        o[15 + i] = a.bg[i] - b.bg[i];
+        o[18 + i] = a.ba[i] - b.ba[i];
+        o[21 + i] = a.grav[i] - b.grav[i];
+    }
+    return o;
+}
+
+bool eskf_update(const EskfParams &p, State &x, const State &x_prop, const Mat24 &P, const double HtH[144],
+                 const double Htz[12], Vec24 &solution, bool &converged, EskfWork &work)
+{
+    constexpr int N = kDim;
+    work.valid = false;
+    converged = false;
+    Mat24 S, Si;
+    for (int i = 0; i < N * N; ++i) S[i] = P[i] / p.laser_point_cov;
+    if (!invert(S, Si)) return false;                              // (state.cov / LASER_POINT_COV).inverse()
+    for (int r = 0; r < 12; ++r)
+        for (int c = 0; c < 12; ++c) Si[r * N + c] += HtH[r * 12 + c];  // + H_T_H (12x12 block)
+    if (!invert(Si, work.K1)) return false;                        // K_1 (:1017-1018)
+    std::memcpy(work.HtH.data(), HtH, sizeof(double) * 144);
+
+    const Vec24 vec = boxminus(x_prop, x);                         // :1028
+    for (int r = 0; r < N; ++r) {
+        double kz = 0.0;
+        for (int a = 0; a < 12; ++a) kz += work.K1[r * N + a] * Htz[a];
+        double khv = 0.0;
+        for (int b = 0; b < 12; ++b) {
+            double kh = 0.0;
+            for (int a = 0; a < 12; ++a) kh += work.K1[r * N + a] * HtH[a * 12 + b];
+            khv += kh * vec[b];
+        }
+        solution[r] = (kz + vec[r]) - khv;                         // :1032
+    }
+    boxplus(x, solution);                                          // :1033
+    const double rn = std::sqrt(solution[0] * solution[0] + solution[1] * solution[1] + solution[2] * solution[2]);
+    const double tn = std::sqrt(solution[3] * solution[3] + solution[4] * solution[4] + solution[5] * solution[5]);
+    converged = (rn * 57.3 < p.conv_rot_deg) && (tn * 100 < p.conv_pos_cm);  // :1040
+    work.valid = true;
+    return true;
+}
+
+void cov_update(const EskfWork &work, Mat24 &P)
+{
+    constexpr int N = kDim;
+    Mat24 ImG{};
+    for (int r = 0; r < N; ++r) {
+        for (int c = 0; c < N; ++c) ImG[r * N + c] = (r == c) ? 1.0 : 0.0;
+        for (int b = 0; b < 12; ++b) {
+            double kh = 0.0;
+            for (int a = 0; a < 12; ++a) kh += work.K1[r * N + a] * work.HtH[a * 12 + b];
+            ImG[r * N + b] -= kh;
+        }
+    }
+    Mat24 Pn;
+    for (int r = 0; r < N; ++r)
+        for (int c = 0; c < N; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < N; ++k) s += ImG[r * N + k] * P[k * N + c];
+            Pn[r * N + c] = s;
+        }
+    P = Pn;
+}
+
+}  // namespace s2m

@@ -1,0 +1,88 @@
+// s2m_kernels.h -- host-side launchers of the HIP kernels (one per .hip translation unit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "s2m_device.h"
+
+namespace s2m {
+
+// ---- s2m_map.hip : map build (KD_TREE::Build, ikd-Tree/ikd_Tree.cpp:408-423) -------------------
+struct MapBuffers {
+    // owned by the engine, (re)allocated by build_map
+    float4 *pts = nullptr;
+    uint32_t *top = nullptr;
+    uint32_t *tab = nullptr;
+    int64_t pts_cap = 0, top_cap = 0, tab_cap = 0;
+    // scratch
+    uint64_t *keys = nullptr, *keys_alt = nullptr;
+    uint32_t *vals = nullptr, *vals_alt = nullptr;
+    uint32_t *brick_flag = nullptr, *brick_id = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    int64_t scratch_cap = 0;
+    float *bbox = nullptr;       // 6 floats on device
+    uint32_t *counters = nullptr; // small device counters
+};
+
+struct MapStats {
+    int64_t bricks = 0, top_entries = 0, occupied_cells = 0;
+};
+
+// xyz_dev: device pointer, stride in floats.  cell <= 0 selects the cell size from the density.
+// Returns hipSuccess or the failing HIP error; *too_large set when the grid would not fit.
+hipError_t build_map(const float *xyz_dev, int64_t stride, int64_t m, float cell, MapBuffers &buf, Grid &grid,
+                     MapStats &stats, bool &too_large, hipStream_t st);
+void free_map(MapBuffers &buf);
+
+// ---- s2m_match.hip : kNN + plane fit ------------------------------------------------------------
+struct MatchArgs {
+    Grid grid;
+    Pose pose;
+    Gates gates;
+    const float *sx, *sy, *sz;
+    int n;
+    float4 *plane;
+    uint8_t *flags;
+    uint8_t *sel;
+    int32_t *nn_idx;  // optional
+    float *nn_d2;     // optional
+};
+void launch_match(const MatchArgs &a, int group, hipStream_t st);
+
+// ---- s2m_reduce.hip : residual + Jacobian + normal block ------------------------------------------
+constexpr int kRedBlock = 256;
+constexpr int kRedTerms = 96;  // 78 (upper triangle of 12x12) + 12 + total_res + count, padded
+struct ReduceArgs {
+    Pose pose;
+    Gates gates;
+    const float *sx, *sy, *sz;
+    int n;
+    const float4 *plane;
+    const uint8_t *flags;
+    uint8_t *sel;
+    uint8_t *eff;
+    float *pd2;
+    double *partials;  // blocks x kRedTerms
+    double *block;     // S2M_BLOCK_DOUBLES output
+};
+int reduce_blocks(int n);
+void launch_reduce(const ReduceArgs &a, hipStream_t st);
+
+// dense rows of the last pass in index order (laserMapping.cpp:942-979)
+struct RowsArgs {
+    Pose pose;
+    Gates gates;
+    const float *sx, *sy, *sz;
+    int n;
+    const float4 *plane;
+    const float *pd2;
+    const uint8_t *eff;
+    uint32_t *block_off;  // blocks + 1
+    double *h_x;          // m x 12
+    double *h;            // m
+    int32_t *scan_index;  // m
+};
+void launch_rows(const RowsArgs &a, hipStream_t st);
+
+}  // namespace s2m

@@ -1,0 +1,328 @@
+// s2m_map.hip -- builds the brick-grid map (layout: s2m_device.h) from an unordered point cloud.
+//
+// Replaces the map seed of the reference: ikdtree.Build(feats_down_world->points)
+// (eskf_lio/src/laserMapping.cpp:784-790; KD_TREE::Build / BuildTree,
+// eskf_lio/include/ikd-Tree/ikd_Tree.cpp:408-423, 678-733).  Instead of a pointer tree of 176-byte
+// nodes the points are radix-sorted by (brick, cell-in-brick) into one float4 array; a dense
+// top-level array over the bounding box and a 513-entry prefix table per occupied brick locate
+// any run of cells along x with two 4-byte loads.
+//
+// This is the one-off (per map) part of the path, not the per-iteration hot loop; the device-wide
+// radix sort and scan come from rocPRIM (ROCm's native primitives library), everything else is
+// hand-written below.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "s2m_device.h"
+#include "s2m_kernels.h"
+
+namespace s2m {
+
+#define S2M_TRY(x)                      \
+    do {                                \
+        hipError_t e_ = (x);            \
+        if (e_ != hipSuccess) return e_; \
+    } while (0)
+
+// order-preserving float <-> uint map for atomicMin/atomicMax
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+static inline float ord2f(uint32_t u)
+{
+    const uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(const float *__restrict__ xyz, int64_t stride, int64_t m,
+                                                   uint32_t *__restrict__ box /* min xyz, max xyz (ordered) */)
+{
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = xyz[i * stride + k];
+            mn[k] = fminf(mn[k], v);
+            mx[k] = fmaxf(mx[k], v);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&box[k], f2ord(mn[k]));
+            atomicMax(&box[3 + k], f2ord(mx[k]));
+        }
+    }
+}
+
+__device__ __forceinline__ int cell_of(float v, float o, float inv_c, int nc)
+{
+    const int c = (int)floorf((v - o) * inv_c);
+    return min(max(c, 0), nc - 1);
+}
+
+__global__ __launch_bounds__(256) void key_kernel(const float *__restrict__ xyz, int64_t stride, int64_t m, Grid g,
+                                                  uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int cx = cell_of(xyz[i * stride + 0], g.ox, g.inv_c, g.ncx);
+    const int cy = cell_of(xyz[i * stride + 1], g.oy, g.inv_c, g.ncy);
+    const int cz = cell_of(xyz[i * stride + 2], g.oz, g.inv_c, g.ncz);
+    const uint64_t brick = ((uint64_t)(cz >> 3) * g.nby + (cy >> 3)) * g.nbx + (cx >> 3);
+    const uint32_t local = (uint32_t)((((cz & 7) << 3) | (cy & 7)) << 3 | (cx & 7));
+    keys[i] = (brick << 9) | local;
+    vals[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void gather_flag_kernel(const float *__restrict__ xyz, int64_t stride, int64_t m,
+                                                          const uint64_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ vals,
+                                                          float4 *__restrict__ pts, uint32_t *__restrict__ flag)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t src = vals[j];
+    pts[j] = make_float4(xyz[(int64_t)src * stride], xyz[(int64_t)src * stride + 1], xyz[(int64_t)src * stride + 2],
+                         __uint_as_float(src));
+    flag[j] = (j == 0 || (keys[j] >> 9) != (keys[j - 1] >> 9)) ? 1u : 0u;
+}
+
+// brick_id[j] is the inclusive scan of flag (1-based brick id of point j)
+__global__ __launch_bounds__(256) void cell_start_kernel(int64_t m, const uint64_t *__restrict__ keys,
+                                                         const uint32_t *__restrict__ brick_id,
+                                                         uint32_t *__restrict__ top, uint32_t *__restrict__ tab,
+                                                         uint32_t *__restrict__ counters)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t k = keys[j];
+    const uint32_t b = brick_id[j] - 1;
+    const bool cell_first = (j == 0) || (keys[j - 1] != k);
+    if (cell_first) {
+        tab[(int64_t)b * kBrickStride + (uint32_t)(k & 511)] = (uint32_t)j;
+        atomicAdd(&counters[0], 1u);
+        if (j == 0 || (keys[j - 1] >> 9) != (k >> 9)) top[k >> 9] = b + 1;
+    }
+    if (j == m - 1 || (keys[j + 1] >> 9) != (k >> 9)) tab[(int64_t)b * kBrickStride + kBrickCells] = (uint32_t)(j + 1);
+}
+
+// one wave per brick: empty cells (0xffffffff) take the start of the next non-empty cell, which
+// turns the table into the exclusive prefix of the per-cell counts
+__global__ __launch_bounds__(64) void brick_fill_kernel(uint32_t *__restrict__ tab, int64_t bricks)
+{
+    const int64_t b = blockIdx.x;
+    if (b >= bricks) return;
+    uint32_t *t = tab + b * kBrickStride;
+    const int lane = threadIdx.x;
+    uint32_t v[8];
+    uint32_t mn = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k] = t[lane * 8 + k];
+        mn = min(mn, v[k]);
+    }
+    // suffix-min over lanes (exclusive of own lane), seeded with the brick end
+    const uint32_t end = t[kBrickCells];
+    uint32_t suf = mn;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_down(suf, off, 64);
+        if (lane + off < 64) suf = min(suf, o);
+    }
+    uint32_t nxt = __shfl_down(suf, 1, 64);
+    if (lane == 63) nxt = end;
+    nxt = min(nxt, end);
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        if (v[k] == 0xffffffffu) v[k] = nxt;
+        nxt = v[k];
+        t[lane * 8 + k] = v[k];
+    }
+}
+
+static hipError_t ensure(void **p, int64_t *cap, int64_t need, size_t elem)
+{
+    if (*cap >= need && *p) return hipSuccess;
+    if (*p) S2M_TRY(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    S2M_TRY(hipMalloc(p, (size_t)std::max<int64_t>(need, 1) * elem));
+    *cap = need;
+    return hipSuccess;
+}
+
+void free_map(MapBuffers &b)
+{
+    void *ptrs[] = {b.pts, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.brick_flag, b.brick_id,
+                    b.sort_tmp, b.bbox, b.counters};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    b = MapBuffers();
+}
+
+static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float cell, const float lo[3],
+                             const float hi[3], MapBuffers &buf, Grid &g, MapStats &stats, bool &too_large,
+                             hipStream_t st)
+{
+    too_large = false;
+    g = Grid();
+    g.c = cell;
+    g.inv_c = 1.0f / cell;
+    g.m = m;
+    // one cell of padding below the box; extents rounded up to whole bricks
+    int nc[3];
+    float o[3];
+    for (int k = 0; k < 3; ++k) {
+        o[k] = std::floor(lo[k] / cell) * cell - cell;
+        const double span = ((double)hi[k] - (double)o[k]) / (double)cell;
+        const int64_t cells = (int64_t)std::floor(span) + 2;
+        const int64_t rounded = ((cells + kBrick - 1) / kBrick) * kBrick;
+        if (rounded > (int64_t)1 << 24) { too_large = true; return hipSuccess; }
+        nc[k] = (int)rounded;
+    }
+    g.ox = o[0]; g.oy = o[1]; g.oz = o[2];
+    g.ncx = nc[0]; g.ncy = nc[1]; g.ncz = nc[2];
+    g.nbx = nc[0] / kBrick; g.nby = nc[1] / kBrick; g.nbz = nc[2] / kBrick;
+    const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
+    if (top_entries > ((int64_t)1 << 31)) { too_large = true; return hipSuccess; }
+    // the bound of the search uses coordinates in cell units; their float rounding error is a few
+    // ulp of the largest cell coordinate
+    const float max_cells = (float)std::max(std::max(nc[0], nc[1]), nc[2]);
+    g.slop = std::max(1.0e-4f, 16.0f * max_cells * 1.1920929e-7f);
+
+    S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m, sizeof(float4)));
+    S2M_TRY(ensure((void **)&buf.top, &buf.top_cap, top_entries, sizeof(uint32_t)));
+    if (buf.scratch_cap < m) {
+        void **ps[] = {(void **)&buf.keys, (void **)&buf.keys_alt, (void **)&buf.vals, (void **)&buf.vals_alt,
+                       (void **)&buf.brick_flag, (void **)&buf.brick_id};
+        const size_t es[] = {8, 8, 4, 4, 4, 4};
+        for (int k = 0; k < 6; ++k) {
+            int64_t cap = 0;
+            if (*ps[k]) { S2M_TRY(hipFree(*ps[k])); *ps[k] = nullptr; }
+            S2M_TRY(ensure(ps[k], &cap, m, es[k]));
+        }
+        buf.scratch_cap = m;
+    }
+    if (!buf.counters) S2M_TRY(hipMalloc((void **)&buf.counters, 64));
+    S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)top_entries * sizeof(uint32_t), st));
+    S2M_TRY(hipMemsetAsync(buf.counters, 0, 64, st));
+    stats = MapStats();
+    stats.top_entries = top_entries;
+    if (m == 0) {
+        g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts;
+        return hipStreamSynchronize(st);
+    }
+
+    const int blocks = (int)((m + 255) / 256);
+    hipLaunchKernelGGL(key_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, g, buf.keys, buf.vals);
+    int bits = 9;
+    while (((int64_t)1 << (bits - 9)) < top_entries) ++bits;
+    bits = std::min(bits + 1, 64);
+    size_t tmp = 0;
+    S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m, 0,
+                                      (unsigned)bits, st));
+    size_t tmp2 = 0;
+    S2M_TRY(rocprim::inclusive_scan(nullptr, tmp2, buf.brick_flag, buf.brick_id, (size_t)m,
+                                    rocprim::plus<uint32_t>(), st));
+    tmp = std::max(tmp, tmp2);
+    if (tmp > buf.sort_tmp_bytes) {
+        if (buf.sort_tmp) S2M_TRY(hipFree(buf.sort_tmp));
+        buf.sort_tmp = nullptr;
+        S2M_TRY(hipMalloc(&buf.sort_tmp, tmp));
+        buf.sort_tmp_bytes = tmp;
+    }
+    size_t t1 = buf.sort_tmp_bytes;
+    S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t1, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m,
+                                      0, (unsigned)bits, st));
+    hipLaunchKernelGGL(gather_flag_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, buf.keys_alt,
+                       buf.vals_alt, buf.pts, buf.brick_flag);
+    size_t t2 = buf.sort_tmp_bytes;
+    S2M_TRY(rocprim::inclusive_scan(buf.sort_tmp, t2, buf.brick_flag, buf.brick_id, (size_t)m,
+                                    rocprim::plus<uint32_t>(), st));
+    uint32_t bricks = 0;
+    S2M_TRY(hipMemcpyAsync(&bricks, buf.brick_id + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    S2M_TRY(hipStreamSynchronize(st));
+    S2M_TRY(ensure((void **)&buf.tab, &buf.tab_cap, (int64_t)bricks * kBrickStride, sizeof(uint32_t)));
+    S2M_TRY(hipMemsetAsync(buf.tab, 0xff, (size_t)bricks * kBrickStride * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(cell_start_kernel, dim3(blocks), dim3(256), 0, st, m, buf.keys_alt, buf.brick_id, buf.top,
+                       buf.tab, buf.counters);
+    hipLaunchKernelGGL(brick_fill_kernel, dim3(bricks), dim3(64), 0, st, buf.tab, (int64_t)bricks);
+    uint32_t occ = 0;
+    S2M_TRY(hipMemcpyAsync(&occ, buf.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    S2M_TRY(hipStreamSynchronize(st));
+    S2M_TRY(hipGetLastError());
+    stats.bricks = bricks;
+    stats.occupied_cells = occ;
+    g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts;
+    return hipSuccess;
+}
+
+hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, MapBuffers &buf, Grid &grid,
+                     MapStats &stats, bool &too_large, hipStream_t st)
+{
+    float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
+    if (m > 0) {
+        if (!buf.bbox) S2M_TRY(hipMalloc((void **)&buf.bbox, 6 * sizeof(uint32_t)));
+        const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+        S2M_TRY(hipMemcpyAsync(buf.bbox, init, sizeof(init), hipMemcpyHostToDevice, st));
+        const int blocks = (int)std::min<int64_t>((m + 255) / 256, 2048);
+        hipLaunchKernelGGL(bbox_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, (uint32_t *)buf.bbox);
+        uint32_t box[6];
+        S2M_TRY(hipMemcpyAsync(box, buf.bbox, sizeof(box), hipMemcpyDeviceToHost, st));
+        S2M_TRY(hipStreamSynchronize(st));
+        for (int k = 0; k < 3; ++k) { lo[k] = ord2f(box[k]); hi[k] = ord2f(box[3 + k]); }
+    }
+    if (cell > 0.0f) return build_once(xyz, stride, m, cell, lo, hi, buf, grid, stats, too_large, st);
+    // density-driven cell size: LiDAR maps are surfaces, so points per occupied cell ~ c^2; aim for
+    // ~3 points per occupied cell, which makes the 5-NN radius about one cell
+    float c = 0.5f;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        S2M_TRY(build_once(xyz, stride, m, c, lo, hi, buf, grid, stats, too_large, st));
+        if (too_large) { c *= 2.0f; continue; }
+        if (m == 0 || stats.occupied_cells == 0) return hipSuccess;
+        const double mean = (double)m / (double)stats.occupied_cells;
+        if (mean >= 2.0 && mean <= 4.5) return hipSuccess;
+        float cn = c * (float)std::sqrt(3.0 / mean);
+        cn = std::min(std::max(cn, 0.02f), 64.0f);
+        if (std::fabs(cn - c) < 0.05f * c) return hipSuccess;
+        c = cn;
+    }
+    return build_once(xyz, stride, m, c, lo, hi, buf, grid, stats, too_large, st);
+}
+
+// AoS (caller stride) -> SoA scan arrays; feats_down keeps only x, y, z on this path
+__global__ __launch_bounds__(256) void deinterleave_kernel(const float *__restrict__ src, int64_t stride, int64_t n,
+                                                           float *__restrict__ sx, float *__restrict__ sy,
+                                                           float *__restrict__ sz)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sx[i] = src[i * stride];
+    sy[i] = src[i * stride + 1];
+    sz[i] = src[i * stride + 2];
+}
+
+void launch_deinterleave(const float *src, int64_t stride, int64_t n, float *sx, float *sy, float *sz, hipStream_t st)
+{
+    const int blocks = (int)((n + 255) / 256);
+    if (blocks > 0) hipLaunchKernelGGL(deinterleave_kernel, dim3(blocks), dim3(256), 0, st, src, stride, n, sx, sy, sz);
+}
+
+}  // namespace s2m

@@ -1,0 +1,261 @@
+// s2m_reduce.hip -- residual, gates, Jacobian row and the fused H^T H / H^T z contraction.
+//
+// Replaces, per scan point, eskf_lio/src/laserMapping.cpp:857-881 (point-to-plane residual,
+// s-gate, sticky selection), :887-896 (effective set, total_residual), :948-979 (Jacobian row,
+// meas_vec) and the m x 12 GEMMs of :1015 / :1019-1032, of which only Hsub^T*Hsub (12x12) and
+// Hsub^T*meas_vec (12) are needed:  K*z = K_1[:, :12]*(H^T z),  K*H = K_1[:, :12]*(H^T H).
+// No per-point H is written; the reduction is wave shuffles -> LDS -> one fp64 partial row per
+// workgroup -> a fixed-order final sum, so the block is deterministic for a given launch shape.
+//
+// One lane per scan point, SoA loads (x[], y[], z[], float4 plane) are fully coalesced.
+// Compiled with -ffp-contract=off; the row arithmetic follows oracle/s2m_oracle.c:jac_row.
+#include <cmath>
+
+#include "s2m_device.h"
+#include "s2m_kernels.h"
+
+namespace s2m {
+
+// term layout of a partial row: [0,78) upper triangle of the 12x12 (row-major, a <= b),
+// [78,90) H^T z, 90 total_residual, 91 effective count
+__host__ __device__ constexpr int tri_index(int a, int b) { return a * 12 - (a * (a - 1)) / 2 + (b - a); }
+constexpr int kTermHtz = 78, kTermRes = 90, kTermCnt = 91;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// one Jacobian row (laserMapping.cpp:948-978): h = [A, n, B, C] or [A, n, 0, 0], z = -pd2
+template <bool EXT>
+__device__ __forceinline__ void jac_row(const Pose &P, float bx, float by, float bz, const float4 &pl, float pd2,
+                                        double (&h)[12], double &z)
+{
+    const double p0 = (double)bx, p1 = (double)by, p2 = (double)bz;
+    const double i0 = ((P.RLI[0] * p0 + P.RLI[1] * p1) + P.RLI[2] * p2) + P.TLI[0];
+    const double i1 = ((P.RLI[3] * p0 + P.RLI[4] * p1) + P.RLI[5] * p2) + P.TLI[1];
+    const double i2 = ((P.RLI[6] * p0 + P.RLI[7] * p1) + P.RLI[8] * p2) + P.TLI[2];
+    const double n0 = (double)pl.x, n1 = (double)pl.y, n2 = (double)pl.z;
+    // C = rot_end^T * n
+    const double c0 = (P.R[0] * n0 + P.R[3] * n1) + P.R[6] * n2;
+    const double c1 = (P.R[1] * n0 + P.R[4] * n1) + P.R[7] * n2;
+    const double c2 = (P.R[2] * n0 + P.R[5] * n1) + P.R[8] * n2;
+    // A = [p_I]x * C
+    h[0] = (0.0 * c0 + -i2 * c1) + i1 * c2;
+    h[1] = (i2 * c0 + 0.0 * c1) + -i0 * c2;
+    h[2] = (-i1 * c0 + i0 * c1) + 0.0 * c2;
+    h[3] = n0; h[4] = n1; h[5] = n2;
+    if (EXT) {
+        // B = ([p_b]x * R_L_I^T) * C, left to right (laserMapping.cpp:970)
+        const double S[9] = {0.0, -p2, p1, p2, 0.0, -p0, -p1, p0, 0.0};
+        double M[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                M[i * 3 + j] = (S[i * 3 + 0] * P.RLI[j * 3 + 0] + S[i * 3 + 1] * P.RLI[j * 3 + 1]) +
+                               S[i * 3 + 2] * P.RLI[j * 3 + 2];
+        h[6] = (M[0] * c0 + M[1] * c1) + M[2] * c2;
+        h[7] = (M[3] * c0 + M[4] * c1) + M[5] * c2;
+        h[8] = (M[6] * c0 + M[7] * c1) + M[8] * c2;
+        h[9] = c0; h[10] = c1; h[11] = c2;
+    } else {
+#pragma unroll
+        for (int i = 6; i < 12; ++i) h[i] = 0.0;
+    }
+    z = -(double)pd2;
+}
+
+template <bool EXT>
+__global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
+{
+    constexpr int NC = EXT ? 12 : 6;
+    __shared__ double red[kRedBlock / 64][kRedTerms];
+    const int i = blockIdx.x * kRedBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    bool eff = false;
+    double h[12], z = 0.0, absr = 0.0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) h[k] = 0.0;
+    if (i < a.n) {
+        const float bx = a.sx[i], by = a.sy[i], bz = a.sz[i];
+        const uint8_t sel = a.sel[i];
+        if (sel) {
+            uint8_t sel_new = 0;  // sticky: only fit-ok + s-gate re-selects (:862,:873)
+            if (a.flags[i] & kFlagPlane) {
+                const float4 pl = a.plane[i];
+                float wx, wy, wz;
+                body_to_world(a.pose, bx, by, bz, wx, wy, wz);
+                const float pd2 = ((pl.x * wx + pl.y * wy) + pl.z * wz) + pl.w;                    // :866
+                const double pbn = sqrt(((double)bx * (double)bx + (double)by * (double)by) + (double)bz * (double)bz);
+                const double s = 1 - 0.9 * fabs((double)pd2) / sqrt(pbn);                           // :868
+                a.pd2[i] = pd2;
+                if (s > a.gates.s_gate) {
+                    sel_new = 1;
+                    if (fabs((double)pd2) <= a.gates.res_gate) {                                    // :889
+                        eff = true;
+                        jac_row<EXT>(a.pose, bx, by, bz, pl, pd2, h, z);
+                        absr = fabs((double)pd2);
+                    }
+                }
+            }
+            a.sel[i] = sel_new;
+        }
+        a.eff[i] = eff ? 1 : 0;
+    }
+    // ineffective lanes carry h = 0, z = 0 and contribute exact zeros
+#pragma unroll
+    for (int r = 0; r < NC; ++r) {
+#pragma unroll
+        for (int c = r; c < NC; ++c) {
+            const double s = wave_sum(h[r] * h[c]);
+            if (lane == 0) red[wave][tri_index(r, c)] = s;
+        }
+        const double s = wave_sum(h[r] * z);
+        if (lane == 0) red[wave][kTermHtz + r] = s;
+    }
+    {
+        const double s = wave_sum(absr);
+        const double c = wave_sum(eff ? 1.0 : 0.0);
+        if (lane == 0) { red[wave][kTermRes] = s; red[wave][kTermCnt] = c; }
+    }
+    __syncthreads();
+    if (threadIdx.x < kRedTerms) {
+        const int t = threadIdx.x;
+        double s = 0.0;
+        bool used = (t >= kTermHtz) ? (t < kTermHtz + NC || t == kTermRes || t == kTermCnt) : false;
+        if (t < kTermHtz) {
+            // is t the index of some (r, c) with c < NC ?
+#pragma unroll
+            for (int r = 0; r < NC; ++r)
+                if (t >= tri_index(r, r) && t <= tri_index(r, NC - 1)) used = true;
+        }
+        if (used) s = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+        a.partials[(int64_t)blockIdx.x * kRedTerms + t] = s;
+    }
+}
+
+// fixed-order sum of the per-workgroup rows, expanded to the symmetric 12x12
+__global__ __launch_bounds__(128) void finalize_kernel(const double *__restrict__ partials, int blocks,
+                                                       double *__restrict__ out)
+{
+    __shared__ double tot[kRedTerms];
+    const int t = threadIdx.x;
+    if (t < kRedTerms) {
+        double s = 0.0;
+        for (int b = 0; b < blocks; ++b) s += partials[(int64_t)b * kRedTerms + t];
+        tot[t] = s;
+    }
+    __syncthreads();
+    for (int o = t; o < 160; o += blockDim.x) {
+        double v = 0.0;
+        if (o < 144) {
+            const int r = o / 12, c = o % 12;
+            v = tot[r <= c ? tri_index(r, c) : tri_index(c, r)];
+        } else if (o < 156) {
+            v = tot[kTermHtz + (o - 144)];
+        } else if (o == 156) {
+            v = tot[kTermCnt];
+        } else if (o == 157) {
+            v = tot[kTermRes];
+        }
+        out[o] = v;
+    }
+}
+
+int reduce_blocks(int n) { return (n + kRedBlock - 1) / kRedBlock; }
+
+void launch_reduce(const ReduceArgs &a, hipStream_t st)
+{
+    const int blocks = reduce_blocks(a.n);
+    if (blocks > 0) {
+        if (a.gates.extrinsic)
+            hipLaunchKernelGGL(reduce_kernel<true>, dim3(blocks), dim3(kRedBlock), 0, st, a);
+        else
+            hipLaunchKernelGGL(reduce_kernel<false>, dim3(blocks), dim3(kRedBlock), 0, st, a);
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(128), 0, st, a.partials, blocks, a.block);
+}
+
+// ---- dense rows in index order (Hsub / meas_vec / laserCloudOri order), on request --------------
+__global__ __launch_bounds__(kRedBlock) void rows_count_kernel(const uint8_t *__restrict__ eff, int n,
+                                                               uint32_t *__restrict__ block_cnt)
+{
+    __shared__ uint32_t wc[kRedBlock / 64];
+    const int i = blockIdx.x * kRedBlock + threadIdx.x;
+    const bool e = (i < n) && eff[i];
+    const uint64_t b = __ballot(e);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+// exclusive scan of block counts in place, single workgroup; block_off[blocks] = total
+__global__ __launch_bounds__(1024) void rows_scan_kernel(uint32_t *__restrict__ block_off, int blocks)
+{
+    __shared__ uint32_t carry;
+    __shared__ uint32_t ws[16];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < blocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < blocks) ? block_off[i] : 0u;
+        uint32_t x = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t y = __shfl_up(x, off, 64);
+            if ((threadIdx.x & 63) >= off) x += y;
+        }
+        if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += ws[w];
+        const uint32_t c = carry;
+        if (i < blocks) block_off[i] = c + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_off[blocks] = carry;
+}
+
+template <bool EXT>
+__global__ __launch_bounds__(kRedBlock) void rows_emit_kernel(RowsArgs a)
+{
+    __shared__ uint32_t wc[kRedBlock / 64];
+    const int i = blockIdx.x * kRedBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool e = (i < a.n) && a.eff[i];
+    const uint64_t b = __ballot(e);
+    if (lane == 0) wc[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (!e) return;
+    uint32_t pos = a.block_off[blockIdx.x] + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pos += wc[w];
+    double h[12], z;
+    jac_row<EXT>(a.pose, a.sx[i], a.sy[i], a.sz[i], a.plane[i], a.pd2[i], h, z);
+    if (a.h_x) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) a.h_x[(int64_t)pos * 12 + k] = h[k];
+    }
+    if (a.h) a.h[pos] = z;
+    if (a.scan_index) a.scan_index[pos] = i;
+}
+
+void launch_rows(const RowsArgs &a, hipStream_t st)
+{
+    const int blocks = reduce_blocks(a.n);
+    if (blocks > 0) hipLaunchKernelGGL(rows_count_kernel, dim3(blocks), dim3(kRedBlock), 0, st, a.eff, a.n, a.block_off);
+    hipLaunchKernelGGL(rows_scan_kernel, dim3(1), dim3(1024), 0, st, a.block_off, blocks);
+    if (blocks > 0) {
+        if (a.gates.extrinsic)
+            hipLaunchKernelGGL(rows_emit_kernel<true>, dim3(blocks), dim3(kRedBlock), 0, st, a);
+        else
+            hipLaunchKernelGGL(rows_emit_kernel<false>, dim3(blocks), dim3(kRedBlock), 0, st, a);
+    }
+}
+
+}  // namespace s2m

@@ -1,0 +1,272 @@
+"""ctypes binding of include/daliti_s2m.h (one Python method per C entry point)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_lib", "libdaliti_s2m.so")
+
+K = 5
+DIM = 24
+STATE_DOUBLES = 36
+BLOCK_DOUBLES = 160
+FEAT_QUEUE = 10
+MAX_LOG = 64
+
+# every symbol include/daliti_s2m.h declares
+ABI_SYMBOLS = [
+    "s2m_abi_version", "s2m_config_default", "s2m_strerror", "s2m_create", "s2m_destroy",
+    "s2m_last_error", "s2m_set_config", "s2m_set_stream", "s2m_map_build", "s2m_map_size",
+    "s2m_map_info", "s2m_scan_set", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
+    "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
+    "s2m_iterated_update", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
+    "s2m_set_timing", "s2m_get_timing",
+]
+
+
+class S2MError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("s2m error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("plane_thr", C.c_float), ("knn_d2_gate", C.c_float), ("s_gate", C.c_double),
+                ("res_gate", C.c_double), ("laser_point_cov", C.c_double),
+                ("conv_rot_deg", C.c_double), ("conv_pos_cm", C.c_double),
+                ("extrinsic_est_en", C.c_int32), ("max_iter", C.c_int32),
+                ("feat_threshold", C.c_int32), ("cell_size", C.c_float), ("device", C.c_int32),
+                ("keep_neighbors", C.c_int32)]
+
+
+class PassOut(C.Structure):
+    _fields_ = [("HtH", C.c_double * 144), ("Htz", C.c_double * 12), ("effct_feat_num", C.c_int32),
+                ("rematch", C.c_int32), ("total_residual", C.c_double)]
+
+
+class IterLog(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("rematch_passes", C.c_int32), ("converged", C.c_int32),
+                ("ekf_stop", C.c_int32), ("effct", C.c_int32 * MAX_LOG), ("rematch", C.c_int32 * MAX_LOG),
+                ("conv", C.c_int32 * MAX_LOG), ("total_residual", C.c_double * MAX_LOG),
+                ("solution", (C.c_double * DIM) * MAX_LOG)]
+
+
+class DynShare(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("converge", C.c_int32), ("h_x", C.c_void_p), ("h", C.c_void_p),
+                ("capacity", C.c_int64), ("rows", C.c_int64), ("total_residual", C.c_double)]
+
+
+def library_path():
+    return _LIB
+
+
+def build_library(force=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src_dir, "-s", "clean"])
+    subprocess.check_call(["make", "-C", src_dir, "-s", "-j4"])
+    return _LIB
+
+
+_lib = None
+
+
+def load_library():
+    """Load the C-ABI library; fails loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise S2MError(-2, "HIP extension %s is missing: run __graft_entry__.build() "
+                           "(there is no CPU fallback)" % _LIB)
+    lib = C.CDLL(_LIB)
+    lib.s2m_strerror.restype = C.c_char_p
+    lib.s2m_last_error.restype = C.c_char_p
+    lib.s2m_last_error.argtypes = [C.c_void_p]
+    for name in ABI_SYMBOLS:
+        getattr(lib, name)  # AttributeError if the ABI is incomplete
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def default_config(**kw):
+    cfg = Config()
+    load_library().s2m_config_default(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+class Engine:
+    """One handle = one GPU's scan-to-map engine (not re-entrant, like the reference caller)."""
+
+    def __init__(self, cfg=None, **kw):
+        self.lib = load_library()
+        self.cfg = cfg if cfg is not None else default_config(**kw)
+        h = C.c_void_p()
+        rc = self.lib.s2m_create(C.byref(self.cfg), C.byref(h))
+        if rc != 0:
+            raise S2MError(rc, self.lib.s2m_strerror(rc).decode())
+        self.h = h
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.s2m_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise S2MError(rc, "%s (%s)" % (self.lib.s2m_strerror(rc).decode(),
+                                           self.lib.s2m_last_error(self.h).decode()))
+
+    # -- configuration ---------------------------------------------------------------------
+    def set_config(self, **kw):
+        for k, v in kw.items():
+            setattr(self.cfg, k, v)
+        self._ck(self.lib.s2m_set_config(self.h, C.byref(self.cfg)))
+
+    def set_stream(self, hip_stream):
+        self._ck(self.lib.s2m_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    def set_timing(self, on=True):
+        self._ck(self.lib.s2m_set_timing(self.h, C.c_int(int(on))))
+
+    def timing(self):
+        ms = (C.c_double * 3)()
+        self._ck(self.lib.s2m_get_timing(self.h, ms))
+        return list(ms)
+
+    # -- map / scan ------------------------------------------------------------------------
+    def map_build(self, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        assert xyz.ndim == 2 and xyz.shape[1] >= 3
+        self._ck(self.lib.s2m_map_build(self.h, _p(xyz), C.c_int64(xyz.shape[1]), C.c_int64(xyz.shape[0]), 0))
+
+    def map_build_device(self, dev_ptr, stride, m):
+        self._ck(self.lib.s2m_map_build(self.h, C.c_void_p(dev_ptr), C.c_int64(stride), C.c_int64(m), 1))
+
+    def map_size(self):
+        m = C.c_int64()
+        self._ck(self.lib.s2m_map_size(self.h, C.byref(m)))
+        return m.value
+
+    def map_info(self):
+        info = (C.c_double * 8)()
+        self._ck(self.lib.s2m_map_info(self.h, info))
+        return dict(cell=info[0], origin=(info[1], info[2], info[3]), bricks=int(info[4]),
+                    top_entries=int(info[5]), occupied_cells=int(info[6]), mean_per_cell=info[7])
+
+    def scan_set(self, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        assert xyz.ndim == 2 and xyz.shape[1] >= 3
+        self._ck(self.lib.s2m_scan_set(self.h, _p(xyz), C.c_int64(xyz.shape[1]), C.c_int64(xyz.shape[0]), 0))
+        self.n = xyz.shape[0]
+
+    def scan_set_device(self, dev_ptr, stride, n):
+        self._ck(self.lib.s2m_scan_set(self.h, C.c_void_p(dev_ptr), C.c_int64(stride), C.c_int64(n), 1))
+        self.n = n
+
+    # -- passes ----------------------------------------------------------------------------
+    def residual_pass(self, state, rematch):
+        state = np.ascontiguousarray(state, np.float64)
+        out = PassOut()
+        self._ck(self.lib.s2m_residual_pass(self.h, _p(state), C.c_int(int(rematch)), C.byref(out)))
+        return dict(HtH=np.array(out.HtH).reshape(12, 12), Htz=np.array(out.Htz),
+                    effct=out.effct_feat_num, total_res=out.total_residual)
+
+    def residual_pass_device(self, state, rematch, d_block_ptr):
+        state = np.ascontiguousarray(state, np.float64)
+        self._ck(self.lib.s2m_residual_pass_device(self.h, _p(state), C.c_int(int(rematch)), C.c_void_p(d_block_ptr)))
+
+    def get_rows(self):
+        m = C.c_int64()
+        n = max(self.n, 1)
+        hx = np.zeros((n, 12))
+        h = np.zeros(n)
+        idx = np.zeros(n, np.int32)
+        self._ck(self.lib.s2m_get_rows(self.h, _p(hx), _p(h), _p(idx), C.c_int64(n), C.byref(m)))
+        return hx[:m.value].copy(), h[:m.value].copy(), idx[:m.value].copy()
+
+    def get_point_state(self):
+        n = max(self.n, 1)
+        sel = np.zeros(n, np.uint8)
+        eff = np.zeros(n, np.uint8)
+        plane = np.zeros((n, 4), np.float32)
+        pd2 = np.zeros(n, np.float32)
+        self._ck(self.lib.s2m_get_point_state(self.h, _p(sel), _p(eff), _p(plane), _p(pd2)))
+        return dict(selected=sel[:self.n], eff=eff[:self.n], plane=plane[:self.n], pd2=pd2[:self.n])
+
+    def get_neighbors(self):
+        n = max(self.n, 1)
+        idx = np.zeros((n, K), np.int32)
+        d2 = np.zeros((n, K), np.float32)
+        self._ck(self.lib.s2m_get_neighbors(self.h, _p(idx), _p(d2)))
+        return idx[:self.n], d2[:self.n]
+
+    # -- filter ----------------------------------------------------------------------------
+    def eskf_update(self, x, x_prop, P, HtH, Htz):
+        x = np.array(x, np.float64)
+        x_prop = np.ascontiguousarray(x_prop, np.float64)
+        P = np.ascontiguousarray(P, np.float64)
+        HtH = np.ascontiguousarray(HtH, np.float64)
+        Htz = np.ascontiguousarray(Htz, np.float64)
+        sol = np.zeros(DIM)
+        conv = C.c_int32()
+        self._ck(self.lib.s2m_eskf_update(self.h, _p(x), _p(x_prop), _p(P), _p(HtH), _p(Htz), _p(sol), C.byref(conv)))
+        return x, sol, bool(conv.value)
+
+    def cov_update(self, P):
+        P = np.array(P, np.float64)
+        self._ck(self.lib.s2m_cov_update(self.h, _p(P)))
+        return P
+
+    def iterated_update(self, x, x_prop, P):
+        x = np.array(x, np.float64)
+        x_prop = np.ascontiguousarray(x_prop, np.float64)
+        P = np.array(P, np.float64)
+        log = IterLog()
+        self._ck(self.lib.s2m_iterated_update(self.h, _p(x), _p(x_prop), _p(P), C.byref(log)))
+        it = log.iters
+        return dict(x=x, P=P, iters=it, rematch_passes=log.rematch_passes, converged=bool(log.converged),
+                    ekf_stop=bool(log.ekf_stop), effct=np.array(log.effct[:it]), rematch=np.array(log.rematch[:it]),
+                    conv=np.array(log.conv[:it]), total_res=np.array(log.total_residual[:it]),
+                    solution=np.array([list(log.solution[i]) for i in range(it)]).reshape(it, DIM))
+
+    def feat_queue(self):
+        q = (C.c_int32 * FEAT_QUEUE)()
+        n = C.c_int32()
+        self._ck(self.lib.s2m_feat_queue_get(self.h, q, C.byref(n)))
+        return list(q[:n.value])
+
+    def set_feat_queue(self, q):
+        q = list(q)
+        arr = (C.c_int32 * max(len(q), 1))(*q)
+        self._ck(self.lib.s2m_feat_queue_set(self.h, arr, C.c_int32(len(q))))
+
+    def h_share_model(self, state, first_iteration, converge=False):
+        state = np.ascontiguousarray(state, np.float64)
+        n = max(self.n, 1)
+        hx = np.zeros((n, 12))
+        h = np.zeros(n)
+        d = DynShare()
+        d.converge = int(converge)
+        d.h_x = hx.ctypes.data
+        d.h = h.ctypes.data
+        d.capacity = n
+        self._ck(self.lib.s2m_h_share_model(self.h, _p(state), C.c_int(int(first_iteration)), C.byref(d)))
+        return dict(valid=bool(d.valid), rows=d.rows, h_x=hx[:d.rows].copy(), h=h[:d.rows].copy(),
+                    total_res=d.total_residual)

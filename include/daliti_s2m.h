@@ -1,0 +1,186 @@
+/*
+ * daliti_s2m.h -- C ABI of the MI355X scan-to-map registration engine for DaLiTI's eskf_lio.
+ *
+ * The reference has no plugin/FFI interface for this path: the residual loop, Jacobian build
+ * and Kalman update are inline in main() (eskf_lio/src/laserMapping.cpp:820-1102) over globals.
+ * This header defines the seam a patched laserMapping.cpp (or any FFI) binds; every entry point
+ * cites the reference lines it replaces.  INTEGRATION.md shows the node-side patch.
+ *
+ * Conventions
+ *   - plain C, opaque handle, int return codes (S2M_OK == 0, negative = error), never throws;
+ *   - the caller owns every host buffer; the handle owns device memory and one HIP stream;
+ *   - one handle is not re-entrant (the reference caller is single-threaded,
+ *     laserMapping.cpp:726-731); use one handle per GPU / per thread;
+ *   - matrices are row-major doubles; the state is 36 doubles in StatesGroup member order
+ *     (eskf_lio/include/common_lib.h:219-227): rot_end[9] pos_end[3] R_L_I[9] T_L_I[3]
+ *     vel_end[3] bias_g[3] bias_a[3] gravity[3]; the error state is the reference's 24-vector
+ *     [dtheta dpos dtheta_LI dT_LI dv dbg dba dg] (common_lib.h:146-157);
+ *   - point clouds are float xyz with a caller-given stride in floats (3 for packed xyz,
+ *     12 for pcl::PointXYZINormal, eskf_lio/include/my_utility.h:57);
+ *   - there is no CPU fallback: every compute entry point needs a gfx950 device and returns
+ *     S2M_ERR_NO_DEVICE / S2M_ERR_HIP otherwise.
+ */
+#ifndef DALITI_S2M_H
+#define DALITI_S2M_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2M_ABI_VERSION 1
+#define S2M_K 5            /* NUM_MATCH_POINTS, laserMapping.cpp:77 */
+#define S2M_DIM 24         /* DIM_OF_STATES, common_lib.h:23 */
+#define S2M_STATE_DOUBLES 36
+#define S2M_BLOCK_DOUBLES 160 /* HtH[144] Htz[12] effct total_res pad[2] */
+#define S2M_FEAT_QUEUE 10  /* QUEUE_SIZE, laserMapping.cpp:192 */
+
+enum {
+    S2M_OK = 0,
+    S2M_ERR_ARG = -1,        /* null / negative / inconsistent argument            */
+    S2M_ERR_NO_DEVICE = -2,  /* no HIP device, or the device is not gfx950         */
+    S2M_ERR_HIP = -3,        /* a HIP runtime call failed (see s2m_last_error)     */
+    S2M_ERR_STATE = -4,      /* call order: no map / no scan / no pass yet         */
+    S2M_ERR_CAPACITY = -5,   /* caller buffer too small, or grid too large         */
+    S2M_ERR_NUMERIC = -6     /* singular matrix in the Kalman update               */
+};
+
+typedef struct s2m_engine s2m_engine;
+
+/* Gates and constants of the path (defaults = reference values) plus engine knobs. */
+typedef struct {
+    float  plane_thr;        /* 0.1f   esti_plane threshold        laserMapping.cpp:863   */
+    float  knn_d2_gate;      /* 5.0f   d2[4] gate                  laserMapping.cpp:853   */
+    double s_gate;           /* 0.9                                laserMapping.cpp:870   */
+    double res_gate;         /* 2.0                                laserMapping.cpp:889   */
+    double laser_point_cov;  /* 0.0015 LASER_POINT_COV             laserMapping.cpp:76    */
+    double conv_rot_deg;     /* 0.01                               laserMapping.cpp:1040  */
+    double conv_pos_cm;      /* 0.015                              laserMapping.cpp:1040  */
+    int32_t extrinsic_est_en;/* mapping/extrinsic_est_en           laserMapping.cpp:660   */
+    int32_t max_iter;        /* mapping/max_iteration              laserMapping.cpp:656   */
+    int32_t feat_threshold;  /* dynamic_effect_featurepoints_threshold, laserMapping.cpp:97 */
+    float  cell_size;        /* voxel edge of the GPU map in metres; <= 0 = choose from density */
+    int32_t device;          /* HIP device ordinal; < 0 = current device                   */
+    int32_t keep_neighbors;  /* != 0: keep Nearest_Points (idx + d2) for s2m_get_neighbors  */
+} s2m_config;
+
+int s2m_abi_version(void);
+int s2m_config_default(s2m_config *cfg);
+const char *s2m_strerror(int code);
+
+/* Lifetime.  Replaces the globals of laserMapping.cpp:79-195 (ikdtree :164, Nearest_Points
+ * :578, point_selected_surf :812, H_T_H/G :696). */
+int s2m_create(const s2m_config *cfg, s2m_engine **out);
+int s2m_destroy(s2m_engine *e);
+const char *s2m_last_error(const s2m_engine *e);
+/* Change gates between scans (e.g. feat_threshold, laserMapping.cpp:427-430). cell_size/device
+ * are fixed at creation. */
+int s2m_set_config(s2m_engine *e, const s2m_config *cfg);
+/* Run the handle's work on a caller stream (hipStream_t passed as void*; NULL = own stream). */
+int s2m_set_stream(s2m_engine *e, void *hip_stream);
+
+/* Map seed: ikdtree.Build(feats_down_world->points), laserMapping.cpp:784-790
+ * (KD_TREE::Build, ikd-Tree/ikd_Tree.cpp:408-423).  on_device != 0: xyz is a device pointer. */
+int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride_floats, int64_t m, int on_device);
+int s2m_map_size(const s2m_engine *e, int64_t *m);             /* ikdtree.validnum(), :794 */
+/* info[0..7]: cell size, origin xyz, bricks, top-level entries, occupied cells, mean pts/cell */
+int s2m_map_info(const s2m_engine *e, double info[8]);
+
+/* The down-sampled body-frame scan feats_down (laserMapping.cpp:775-778).  Resets the per-scan
+ * state: point_selected_surf := true (:812), Nearest_Points cleared (:810). */
+int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride_floats, int64_t n, int on_device);
+
+/* Output of one residual/Jacobian pass. */
+typedef struct {
+    double  HtH[144];        /* Hsub^T * Hsub, row-major 12x12        laserMapping.cpp:1015 */
+    double  Htz[12];         /* Hsub^T * meas_vec                                           */
+    int32_t effct_feat_num;  /*                                       laserMapping.cpp:885-895 */
+    int32_t rematch;         /* echo                                                          */
+    double  total_residual;  /*                                       laserMapping.cpp:884-893 */
+} s2m_pass_out;
+
+/* One pass of laserMapping.cpp:829-979 fused with the Hsub^T*Hsub / Hsub^T*meas_vec
+ * contraction of :1015-1032.  rematch = (iterCount == 0 || rematch_en) (:847). */
+int s2m_residual_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch,
+                      s2m_pass_out *out);
+/* Same pass, result left on the device for a collective: d_block is a DEVICE pointer to
+ * S2M_BLOCK_DOUBLES doubles laid out HtH[144] Htz[12] effct total_res 0 0 (effct as a double).
+ * No host synchronisation; ordered on the handle's stream. */
+int s2m_residual_pass_device(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch,
+                             double *d_block);
+
+/* Dense rows of the last pass: Hsub (m x 12, column order [rot pos rot_LI trans_LI]) and
+ * meas_vec (m), in scan index order, plus the scan index of each row (laserCloudOri order).
+ * laserMapping.cpp:942-979.  Any pointer may be NULL.  *m_out = effct_feat_num. */
+int s2m_get_rows(s2m_engine *e, double *h_x, double *h, int32_t *scan_index, int64_t capacity,
+                 int64_t *m_out);
+/* Per-point state after the last pass (any pointer may be NULL):
+ * selected[n] point_selected_surf (:812,:857-873); effective[n] (:889); plane[n*4] = (n,d) of
+ * esti_plane (coeffSel_tmpt xyz + fit offset); pd2[n] (coeffSel_tmpt intensity, :877). */
+int s2m_get_point_state(s2m_engine *e, uint8_t *selected, uint8_t *effective, float *plane,
+                        float *pd2);
+/* Nearest_Points of the last rematch pass (:845-850): idx[n*5] indexes the array given to
+ * s2m_map_build (-1 = missing), d2[n*5] ascending.  Needs cfg.keep_neighbors. */
+int s2m_get_neighbors(s2m_engine *e, int32_t *idx, float *d2);
+
+/* Kalman update of laserMapping.cpp:1012-1046 from the normal block:
+ * K_1 = (H_T_H + (P/R)^-1)^-1; solution = K z + vec - K H vec[0:12]; x [+]= solution.
+ * x is updated in place; *converged = flg_EKF_converged (:1040). */
+int s2m_eskf_update(s2m_engine *e, double x[S2M_STATE_DOUBLES],
+                    const double x_prop[S2M_STATE_DOUBLES], const double P[S2M_DIM * S2M_DIM],
+                    const double HtH[144], const double Htz[12], double solution[S2M_DIM],
+                    int32_t *converged);
+/* P <- (I - K H (+) 0) P with K, H of the last s2m_eskf_update (laserMapping.cpp:1084-1085). */
+int s2m_cov_update(s2m_engine *e, double P[S2M_DIM * S2M_DIM]);
+
+/* Per-iteration log of s2m_iterated_update (what Log/mat_out.txt records, :936-937). */
+typedef struct {
+    int32_t iters;           /* iterations executed                                          */
+    int32_t rematch_passes;  /* passes that ran the kNN                                      */
+    int32_t converged;       /* flg_EKF_converged at exit                                    */
+    int32_t ekf_stop;        /* EKF_stop_flg at exit (:907-918); state left unchanged if set */
+    int32_t effct[64];       /* effct_feat_num per iteration                                 */
+    int32_t rematch[64];
+    int32_t conv[64];
+    double  total_residual[64];
+    double  solution[64][S2M_DIM];
+} s2m_iter_log;
+
+/* The whole iterated update of one scan, laserMapping.cpp:820-1102: passes, degeneracy queue
+ * (:899-918, kept in the handle across scans), update, rematch judgement (:1070-1076), exit and
+ * covariance update (:1079-1101).  x, P updated in place.  max_iter <= 64. */
+int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES],
+                        const double x_prop[S2M_STATE_DOUBLES], double P[S2M_DIM * S2M_DIM],
+                        s2m_iter_log *log);
+/* Degeneracy queue access (effct_feat_numQueue, laserMapping.cpp:193). */
+int s2m_feat_queue_get(const s2m_engine *e, int32_t q[S2M_FEAT_QUEUE], int32_t *len);
+int s2m_feat_queue_set(s2m_engine *e, const int32_t *q, int32_t len);
+
+/* h_share_model-shaped adapter (the IKFoM / FAST-LIO2 callback convention named by the north
+ * star; DaLiTI itself has no such callback): fills the dense rows for the given state so an
+ * esekfom-style update_iterated_dyn_share loop can consume them.  Column order is the
+ * reference's [rot pos rot_LI trans_LI] (laserMapping.cpp:971), NOT FAST-LIO2's [pos rot ...].
+ * The caller allocates h_x (capacity x 12) and h (capacity). */
+typedef struct {
+    int32_t valid;      /* out: 0 when effct_feat_num < 1 (FAST-LIO2 semantics)       */
+    int32_t converge;   /* in: caller's flag; != 0 requests a rematch like :847       */
+    double *h_x;        /* out: rows x 12                                             */
+    double *h;          /* out: rows; h = -pd2 like meas_vec (:977)                   */
+    int64_t capacity;   /* in                                                         */
+    int64_t rows;       /* out: effct_feat_num                                        */
+    double  total_residual; /* out */
+} s2m_dyn_share;
+int s2m_h_share_model(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int first_iteration,
+                      s2m_dyn_share *ekfom_data);
+
+/* Timing of the last pass in milliseconds measured with HIP events on the handle's stream:
+ * ms[0] = match (kNN + plane fit) kernel, ms[1] = residual/Jacobian/normal-block kernel,
+ * ms[2] = whole pass.  Enabled by s2m_set_timing(e, 1); costs one event sync per pass. */
+int s2m_set_timing(s2m_engine *e, int enabled);
+int s2m_get_timing(const s2m_engine *e, double ms[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
