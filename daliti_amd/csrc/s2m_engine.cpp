@@ -30,6 +30,8 @@ struct s2m_engine {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timing = false;
     double last_ms[3] = {0, 0, 0};
+    double tstats[4] = {0, 0, 0, 0};
+    bool last_rematch = false;
     int match_group = 16;
     std::string err;
 
@@ -61,6 +63,8 @@ struct s2m_engine {
     int64_t rows_cap = 0;
 
     Pose last_pose{};
+    uint32_t *d_dbg = nullptr;  // S2M_DEBUG_MATCH=1: per-point diagnostics of the match kernel
+    bool dbg = false;
     bool nn_valid = false;
 
     EskfWork work;
@@ -156,6 +160,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     const int n = (int)e->n;
     float *sx = e->d_scan, *sy = e->d_scan + e->n_cap, *sz = e->d_scan + 2 * e->n_cap;
     if (e->timing) S2M_HIP(e, hipEventRecord(e->ev[0], e->stream));
+    e->last_rematch = rematch != 0;
     if (rematch) {
         MatchArgs m;
         m.grid = e->grid; m.pose = pose; m.gates = gates;
@@ -163,6 +168,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         m.plane = e->d_plane; m.flags = e->d_flags; m.sel = e->d_sel;
         m.nn_idx = e->cfg.keep_neighbors ? e->d_nn_idx : nullptr;
         m.nn_d2 = e->cfg.keep_neighbors ? e->d_nn_d2 : nullptr;
+        m.dbg = e->dbg ? e->d_dbg : nullptr;
         launch_match(m, e->match_group, e->stream);
         e->nn_valid = true;
     }
@@ -190,6 +196,9 @@ int finish_timing(s2m_engine *e)
     e->last_ms[0] = a;
     e->last_ms[1] = b;
     e->last_ms[2] = a + b;
+    if (e->last_rematch) { e->tstats[0] += a; e->tstats[1] += 1; }
+    e->tstats[2] += b;
+    e->tstats[3] += 1;
     return S2M_OK;
 }
 
@@ -255,6 +264,7 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
         const int v = std::atoi(g);
         if (v == 8 || v == 16 || v == 32) e->match_group = v;
     }
+    e->dbg = std::getenv("S2M_DEBUG_MATCH") != nullptr;
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&e->ev[i]) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_block, S2M_BLOCK_DOUBLES * sizeof(double)) == hipSuccess;
@@ -275,7 +285,7 @@ int s2m_destroy(s2m_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_map(e->map);
     void *ptrs[] = {e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
-                    e->d_nn_d2, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
+                    e->d_nn_d2, e->d_dbg, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_block) (void)hipHostFree(e->h_block);
@@ -367,6 +377,7 @@ int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int
         rc = rc ? rc : grow(e, &e->d_nn_d2, cap * S2M_K);
         rc = rc ? rc : grow(e, &e->d_partials, (int64_t)reduce_blocks((int)cap) * kRedTerms);
         rc = rc ? rc : grow(e, &e->d_block_off, (int64_t)reduce_blocks((int)cap) + 1);
+        if (e->dbg) rc = rc ? rc : grow(e, &e->d_dbg, cap * 4);
         if (rc) return rc;
         e->n_cap = cap;
     }
@@ -504,11 +515,14 @@ int s2m_cov_update(s2m_engine *e, double P[S2M_DIM * S2M_DIM])
     return S2M_OK;
 }
 
-int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double x_prop[S2M_STATE_DOUBLES],
-                        double P[S2M_DIM * S2M_DIM], s2m_iter_log *log)
+int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double x_prop[S2M_STATE_DOUBLES],
+                                double P[S2M_DIM * S2M_DIM], s2m_iter_log *log, double *d_block,
+                                s2m_allreduce_fn reduce, void *user)
 {
     if (!e || !x || !x_prop || !P) return fail(e, S2M_ERR_ARG, "null argument");
+    if (reduce && !d_block) return fail(e, S2M_ERR_ARG, "sharded update needs a device block");
     if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
+    if (!d_block) d_block = e->d_block;
     // a new scan starts with every point selected and no neighbours (laserMapping.cpp:810-818)
     S2M_HIP(e, hipSetDevice(e->device));
     S2M_HIP(e, hipMemsetAsync(e->d_sel, 1, (size_t)std::max<int64_t>(e->n, 1), e->stream));
@@ -520,11 +534,19 @@ int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double
     for (it = 0; it < max_iter; ++it) {
         const int rematch = (it == 0) || rematch_en;  // :847
         passes += rematch;
-        s2m_pass_out out;
-        int rc = s2m_residual_pass(e, x, rematch, &out);
+        int rc = run_pass(e, x, rematch, d_block);
         if (rc) return rc;
+        if (reduce && reduce(user) != 0) return fail(e, S2M_ERR_HIP, "all-reduce callback failed");
+        S2M_HIP(e, hipMemcpyAsync(e->h_block, d_block, S2M_BLOCK_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
+                                  e->stream));
+        S2M_HIP(e, hipStreamSynchronize(e->stream));
+        rc = finish_timing(e);
+        if (rc) return rc;
+        const double *HtH = e->h_block, *Htz = e->h_block + 144;
+        const int32_t effct = (int32_t)e->h_block[156];
+        const double total_res = e->h_block[157];
         // degeneracy queue (:899-918)
-        e->queue[e->queue_len++] = out.effct_feat_num;
+        e->queue[e->queue_len++] = effct;
         if (e->queue_len > S2M_FEAT_QUEUE) {
             std::memmove(e->queue, e->queue + 1, sizeof(int32_t) * S2M_FEAT_QUEUE);
             e->queue_len = S2M_FEAT_QUEUE;
@@ -534,14 +556,14 @@ int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double
             if (e->queue[q] <= e->cfg.feat_threshold) { stop = 1; break; }
         double sol[S2M_DIM] = {0};
         if (!stop) {  // flg_EKF_inited is always true (INIT_TIME == 0, :75,:762)
-            rc = s2m_eskf_update(e, x, x_prop, P, out.HtH, out.Htz, sol, &conv);
+            rc = s2m_eskf_update(e, x, x_prop, P, HtH, Htz, sol, &conv);
             if (rc) return rc;
         }
         if (log) {
-            log->effct[it] = out.effct_feat_num;
+            log->effct[it] = effct;
             log->rematch[it] = rematch;
             log->conv[it] = conv;
-            log->total_residual[it] = out.total_residual;
+            log->total_residual[it] = total_res;
             std::memcpy(log->solution[it], sol, sizeof(sol));
         }
         rematch_en = 0;  // rematch judgement (:1070-1076)
@@ -568,6 +590,12 @@ int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double
         log->ekf_stop = stop;
     }
     return S2M_OK;
+}
+
+int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double x_prop[S2M_STATE_DOUBLES],
+                        double P[S2M_DIM * S2M_DIM], s2m_iter_log *log)
+{
+    return s2m_iterated_update_sharded(e, x, x_prop, P, log, nullptr, nullptr, nullptr);
 }
 
 int s2m_feat_queue_get(const s2m_engine *e, int32_t q[S2M_FEAT_QUEUE], int32_t *len)
@@ -606,6 +634,7 @@ int s2m_set_timing(s2m_engine *e, int enabled)
 {
     if (!e) return S2M_ERR_ARG;
     e->timing = enabled != 0;
+    for (double &t : e->tstats) t = 0;
     return S2M_OK;
 }
 
@@ -613,6 +642,22 @@ int s2m_get_timing(const s2m_engine *e, double ms[3])
 {
     if (!e || !ms) return S2M_ERR_ARG;
     ms[0] = e->last_ms[0]; ms[1] = e->last_ms[1]; ms[2] = e->last_ms[2];
+    return S2M_OK;
+}
+
+// dev diagnostic (not part of the public header): per-point words written by the match kernel
+int s2m_debug_match(s2m_engine *e, uint32_t *out)
+{
+    if (!e || !out || !e->dbg || !e->d_dbg) return S2M_ERR_STATE;
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    S2M_HIP(e, hipMemcpy(out, e->d_dbg, (size_t)e->n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return S2M_OK;
+}
+
+int s2m_get_timing_stats(const s2m_engine *e, double stats[4])
+{
+    if (!e || !stats) return S2M_ERR_ARG;
+    for (int i = 0; i < 4; ++i) stats[i] = e->tstats[i];
     return S2M_OK;
 }
 

@@ -47,6 +47,7 @@ struct MatchArgs {
     uint8_t *sel;
     int32_t *nn_idx;  // optional
     float *nn_d2;     // optional
+    uint32_t *dbg = nullptr;  // optional, 4 words per scan point: cycles, final radius, candidates, rounds
 };
 void launch_match(const MatchArgs &a, int group, hipStream_t st);
 

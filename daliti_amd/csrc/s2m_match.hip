@@ -218,6 +218,87 @@ __device__ bool fit_plane(const Cand (&nb)[kK], float thr, float4 &pl)
     return ok;
 }
 
+// Streams the points of cells [xa, xb] of one x-row (cell row yy, zz) through the private top-5.
+// A row crosses at most a few bricks; per brick: one top-level load, two table loads, then the
+// candidates in batches of four independent 16-byte loads.
+__device__ __forceinline__ void scan_row(const Grid &g, int yy, int zz, int xa, int xb, float wx, float wy,
+                                         float wz, Cand (&t)[kK])
+{
+    const int by = yy >> 3, bz = zz >> 3;
+    const int rowoff = (((zz & 7) << 3) | (yy & 7)) << 3;
+    const int64_t toprow = ((int64_t)bz * g.nby + by) * g.nbx;
+    for (int bx = xa >> 3; bx <= (xb >> 3); ++bx) {
+        const uint32_t b = g.top[toprow + bx];
+        if (b == 0) continue;
+        const int l0 = max(xa, bx << 3) & 7, l1 = min(xb, (bx << 3) + 7) & 7;
+        const uint32_t *tb = g.tab + (int64_t)(b - 1) * kBrickStride + rowoff;
+        const uint32_t s = tb[l0], e = tb[l1 + 1];
+        for (uint32_t i = s; i < e; i += 4) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = g.pts[min(i + u, e - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i + u < e) {
+                    Cand c;
+                    const float dx = wx - p[u].x, dy = wy - p[u].y, dz = wz - p[u].z;
+                    float d = dx * dx + dy * dy;
+                    d = d + dz * dz;
+                    c.d2 = d; c.x = p[u].x; c.y = p[u].y; c.z = p[u].z; c.w = __float_as_uint(p[u].w);
+                    offer(t, c);
+                }
+            }
+        }
+    }
+}
+
+// Group-wide sorted top-5 of the G private lists (non-destructive: works on a copy).
+template <int G>
+__device__ __forceinline__ int merge_lists(const Cand (&priv)[kK], Cand (&best)[kK], int j, int gbase, uint64_t gmask)
+{
+    Cand t[kK];
+#pragma unroll
+    for (int k = 0; k < kK; ++k) t[k] = priv[k];
+    int found = 0;
+#pragma unroll
+    for (int k = 0; k < kK; ++k) {
+        const float key = t[0].d2;
+        const float m = group_min<G>(key);
+        uint64_t bal = __ballot(key == m && m < INFINITY);
+        uint64_t gb = (bal >> gbase) & gmask;
+        best[k].d2 = INFINITY; best[k].x = 0.f; best[k].y = 0.f; best[k].z = 0.f; best[k].w = 0xffffffffu;
+        if (gb != 0) {
+            int win;
+            if (__popcll(gb) == 1) {
+                win = __ffsll((unsigned long long)gb) - 1;
+            } else {  // equal d2 in several lanes: smallest (x, y, z) wins
+                bool cnd = (gb >> j) & 1ull;
+                const float mx = group_min<G>(cnd ? t[0].x : INFINITY);
+                cnd = cnd && (t[0].x == mx);
+                const float my = group_min<G>(cnd ? t[0].y : INFINITY);
+                cnd = cnd && (t[0].y == my);
+                const float mz = group_min<G>(cnd ? t[0].z : INFINITY);
+                cnd = cnd && (t[0].z == mz);
+                bal = __ballot(cnd);
+                gb = (bal >> gbase) & gmask;
+                win = __ffsll((unsigned long long)gb) - 1;
+            }
+            best[k].d2 = m;
+            best[k].x = __shfl(t[0].x, win, G);
+            best[k].y = __shfl(t[0].y, win, G);
+            best[k].z = __shfl(t[0].z, win, G);
+            best[k].w = __shfl(t[0].w, win, G);
+            ++found;
+            if (j == win) {
+#pragma unroll
+                for (int s = 0; s < kK - 1; ++s) t[s] = t[s + 1];
+                t[kK - 1].d2 = INFINITY;
+            }
+        }
+    }
+    return found;
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void match_kernel(Grid g, Pose pose, Gates gates,
                                                     const float *__restrict__ sx,
@@ -227,8 +308,10 @@ __global__ __launch_bounds__(256) void match_kernel(Grid g, Pose pose, Gates gat
                                                     uint8_t *__restrict__ flags_out,
                                                     uint8_t *__restrict__ sel_out,
                                                     int32_t *__restrict__ nn_idx,
-                                                    float *__restrict__ nn_d2)
+                                                    float *__restrict__ nn_d2, uint32_t *__restrict__ dbg)
 {
+    const long long dbg_t0 = dbg ? wall_clock64() : 0;
+    uint32_t dbg_rounds = 0;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int q = tid / G;
     const int j = threadIdx.x & (G - 1);
@@ -251,85 +334,51 @@ __global__ __launch_bounds__(256) void match_kernel(Grid g, Pose pose, Gates gat
     float fmin_ = fminf(fminf(fx - flx, 1.0f - (fx - flx)), fminf(fy - fly, 1.0f - (fy - fly)));
     fmin_ = fminf(fmin_, fminf(fz - flz, 1.0f - (fz - flz)));
 
-    Cand best[kK];
+    Cand t[kK], best[kK];
+#pragma unroll
+    for (int k = 0; k < kK; ++k) { t[k].d2 = INFINITY; t[k].x = 0.f; t[k].y = 0.f; t[k].z = 0.f; t[k].w = 0xffffffffu; }
     int found = 0;
     const int rcap = max(max(g.ncx, g.ncy), g.ncz);
-    for (int r = 1;; ++r) {
-        Cand t[kK];
-#pragma unroll
-        for (int k = 0; k < kK; ++k) { t[k].d2 = INFINITY; t[k].x = 0.f; t[k].y = 0.f; t[k].z = 0.f; t[k].w = 0xffffffffu; }
+    // smallest radius whose bound passes the d2 gate: beyond it the 5th neighbour cannot matter
+    const int rgate = (int)ceilf(sqrtf(gates.knn_d2_gate) * g.inv_c * 1.000002f - fmin_ + g.slop) + 1;
+    int rdone = -1;  // cube of radius rdone around the home cell is fully scanned (-1: nothing)
+    int r = 1;
+    for (;;) {
+        // scan the shell (rdone, r]: new rows completely, old rows only their two new ends
         const int side = 2 * r + 1;
         const int nrows = side * side;
         const int xlo = max(cx - r, 0), xhi = min(cx + r, g.ncx - 1);
-        if (xlo <= xhi) {
-            for (int row = j; row < nrows; row += G) {
-                const int yy = cy + (row % side) - r, zz = cz + (row / side) - r;
-                if (yy < 0 || yy >= g.ncy || zz < 0 || zz >= g.ncz) continue;
-                const int by = yy >> 3, bz = zz >> 3;
-                const int rowoff = (((zz & 7) << 3) | (yy & 7)) << 3;
-                for (int bx = xlo >> 3; bx <= (xhi >> 3); ++bx) {
-                    const uint32_t b = g.top[((int64_t)bz * g.nby + by) * g.nbx + bx];
-                    if (b == 0) continue;
-                    const int l0 = max(xlo, bx << 3) & 7, l1 = min(xhi, (bx << 3) + 7) & 7;
-                    const uint32_t *tb = g.tab + (int64_t)(b - 1) * kBrickStride + rowoff;
-                    const uint32_t s = tb[l0], e = tb[l1 + 1];
-                    for (uint32_t i = s; i < e; ++i) {
-                        const float4 p = g.pts[i];
-                        Cand c;
-                        const float dx = wx - p.x, dy = wy - p.y, dz = wz - p.z;
-                        float d = dx * dx + dy * dy;
-                        d = d + dz * dz;
-                        c.d2 = d; c.x = p.x; c.y = p.y; c.z = p.z; c.w = __float_as_uint(p.w);
-                        offer(t, c);
-                    }
-                }
+        for (int row = j; row < nrows; row += G) {
+            const int dy = (row % side) - r, dz = (row / side) - r;
+            const int yy = cy + dy, zz = cz + dz;
+            if (yy < 0 || yy >= g.ncy || zz < 0 || zz >= g.ncz) continue;
+            if (max(abs(dy), abs(dz)) > rdone) {
+                if (xlo <= xhi) scan_row(g, yy, zz, xlo, xhi, wx, wy, wz, t);
+            } else {
+                const int a1 = min(cx - rdone - 1, g.ncx - 1), b0 = max(cx + rdone + 1, 0);
+                if (xlo <= a1) scan_row(g, yy, zz, xlo, a1, wx, wy, wz, t);
+                if (b0 <= xhi) scan_row(g, yy, zz, b0, xhi, wx, wy, wz, t);
             }
         }
-        // merge the G private lists: five rounds of extract-min over the group
-        found = 0;
-#pragma unroll
-        for (int k = 0; k < kK; ++k) {
-            const float key = t[0].d2;
-            const float m = group_min<G>(key);
-            uint64_t bal = __ballot(key == m && m < INFINITY);
-            uint64_t gb64 = (bal >> gbase) & gmask;
-            best[k].d2 = INFINITY; best[k].x = 0.f; best[k].y = 0.f; best[k].z = 0.f; best[k].w = 0xffffffffu;
-            if (gb64 != 0) {
-                int win;
-                if (__popcll(gb64) == 1) {
-                    win = __ffsll((unsigned long long)gb64) - 1;
-                } else {
-                    bool cnd = (gb64 >> j) & 1ull;
-                    const float mx = group_min<G>(cnd ? t[0].x : INFINITY);
-                    cnd = cnd && (t[0].x == mx);
-                    const float my = group_min<G>(cnd ? t[0].y : INFINITY);
-                    cnd = cnd && (t[0].y == my);
-                    const float mz = group_min<G>(cnd ? t[0].z : INFINITY);
-                    cnd = cnd && (t[0].z == mz);
-                    bal = __ballot(cnd);
-                    gb64 = (bal >> gbase) & gmask;
-                    win = __ffsll((unsigned long long)gb64) - 1;
-                }
-                best[k].d2 = m;
-                best[k].x = __shfl(t[0].x, win, G);
-                best[k].y = __shfl(t[0].y, win, G);
-                best[k].z = __shfl(t[0].z, win, G);
-                best[k].w = __shfl(t[0].w, win, G);
-                ++found;
-                if (j == win) {
-#pragma unroll
-                    for (int s = 0; s < kK - 1; ++s) t[s] = t[s + 1];
-                    t[kK - 1].d2 = INFINITY;
-                }
-            }
-        }
-        // every point outside the visited cube is at least lb away from the query
+        rdone = r;
+        ++dbg_rounds;
+        found = merge_lists<G>(t, best, j, gbase, gmask);
+        // every point outside the scanned cube is at least lb away from the query
         float lb = ((float)r + fmin_ - g.slop) * g.c;
         lb = fmaxf(lb, 0.0f) * 0.999999f;
         const float lb2 = lb * lb;
         if (found == kK && best[kK - 1].d2 <= lb2) break;  // exact 5-NN found
         if (lb2 > gates.knn_d2_gate) break;                // 5th neighbour is beyond the gate
-        if (r >= rcap) break;                              // whole grid visited
+        if (r >= rcap) break;                              // whole grid scanned
+        int rn;
+        if (found == kK) {
+            // all better candidates lie within sqrt(d5): jump straight to the radius covering it
+            rn = (int)ceilf(sqrtf(best[kK - 1].d2) * g.inv_c * 1.000002f - fmin_ + g.slop);
+        } else {
+            rn = 2 * r;
+        }
+        r = min(max(rn, r + 1), max(rgate, r + 1));
+        r = min(r, rcap);
     }
 
     const bool gate = (found == kK) && !(best[kK - 1].d2 > gates.knn_d2_gate);
@@ -340,6 +389,12 @@ __global__ __launch_bounds__(256) void match_kernel(Grid g, Pose pose, Gates gat
         plane_out[q] = pl;
         flags_out[q] = (uint8_t)((gate ? kFlagGate : 0) | (plane_ok ? kFlagPlane : 0));
         sel_out[q] = gate ? 1 : 0;  // point_selected_surf after the gate (:852-854)
+    }
+    if (dbg != nullptr && j == 0) {
+        dbg[4 * (int64_t)q + 0] = (uint32_t)(wall_clock64() - dbg_t0);
+        dbg[4 * (int64_t)q + 1] = (uint32_t)rdone;
+        dbg[4 * (int64_t)q + 2] = 0;
+        dbg[4 * (int64_t)q + 3] = dbg_rounds;
     }
     if (nn_idx != nullptr && j < kK) {
         // lane k of the group stores neighbour k
@@ -360,7 +415,7 @@ static void launch_g(const MatchArgs &a, hipStream_t st)
     const int blocks = (int)((threads + 255) / 256);
     if (blocks == 0) return;
     hipLaunchKernelGGL(match_kernel<G>, dim3(blocks), dim3(256), 0, st, a.grid, a.pose, a.gates, a.sx, a.sy,
-                       a.sz, a.n, a.plane, a.flags, a.sel, a.nn_idx, a.nn_d2);
+                       a.sz, a.n, a.plane, a.flags, a.sel, a.nn_idx, a.nn_d2, a.dbg);
 }
 
 void launch_match(const MatchArgs &a, int group, hipStream_t st)

@@ -138,19 +138,36 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
     }
 }
 
-// fixed-order sum of the per-workgroup rows, expanded to the symmetric 12x12
-__global__ __launch_bounds__(128) void finalize_kernel(const double *__restrict__ partials, int blocks,
-                                                       double *__restrict__ out)
+// fixed-order sum of the per-workgroup rows, expanded to the symmetric 12x12.  kFinChunks lanes
+// per term each sum a strided slice of the rows with independent loads, then the chunk sums are
+// combined in a fixed order, so the result does not depend on timing.
+constexpr int kFinChunks = 8;
+__global__ __launch_bounds__(kRedTerms * kFinChunks) void finalize_kernel(const double *__restrict__ partials,
+                                                                          int blocks, double *__restrict__ out)
 {
+    __shared__ double part[kFinChunks][kRedTerms];
     __shared__ double tot[kRedTerms];
-    const int t = threadIdx.x;
-    if (t < kRedTerms) {
+    const int t = threadIdx.x % kRedTerms, ch = threadIdx.x / kRedTerms;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = ch;
+    for (; b + 3 * kFinChunks < blocks; b += 4 * kFinChunks) {
+        const double v0 = partials[(int64_t)b * kRedTerms + t];
+        const double v1 = partials[(int64_t)(b + kFinChunks) * kRedTerms + t];
+        const double v2 = partials[(int64_t)(b + 2 * kFinChunks) * kRedTerms + t];
+        const double v3 = partials[(int64_t)(b + 3 * kFinChunks) * kRedTerms + t];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; b < blocks; b += kFinChunks) s0 += partials[(int64_t)b * kRedTerms + t];
+    part[ch][t] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (threadIdx.x < kRedTerms) {
         double s = 0.0;
-        for (int b = 0; b < blocks; ++b) s += partials[(int64_t)b * kRedTerms + t];
-        tot[t] = s;
+#pragma unroll
+        for (int c = 0; c < kFinChunks; ++c) s += part[c][threadIdx.x];
+        tot[threadIdx.x] = s;
     }
     __syncthreads();
-    for (int o = t; o < 160; o += blockDim.x) {
+    for (int o = threadIdx.x; o < 160; o += blockDim.x) {
         double v = 0.0;
         if (o < 144) {
             const int r = o / 12, c = o % 12;
@@ -177,7 +194,7 @@ void launch_reduce(const ReduceArgs &a, hipStream_t st)
         else
             hipLaunchKernelGGL(reduce_kernel<false>, dim3(blocks), dim3(kRedBlock), 0, st, a);
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(128), 0, st, a.partials, blocks, a.block);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kRedTerms * kFinChunks), 0, st, a.partials, blocks, a.block);
 }
 
 // ---- dense rows in index order (Hsub / meas_vec / laserCloudOri order), on request --------------

@@ -21,8 +21,8 @@ ABI_SYMBOLS = [
     "s2m_last_error", "s2m_set_config", "s2m_set_stream", "s2m_map_build", "s2m_map_size",
     "s2m_map_info", "s2m_scan_set", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
-    "s2m_iterated_update", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
-    "s2m_set_timing", "s2m_get_timing",
+    "s2m_iterated_update", "s2m_iterated_update_sharded", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
+    "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats",
 ]
 
 
@@ -56,6 +56,9 @@ class IterLog(C.Structure):
 class DynShare(C.Structure):
     _fields_ = [("valid", C.c_int32), ("converge", C.c_int32), ("h_x", C.c_void_p), ("h", C.c_void_p),
                 ("capacity", C.c_int64), ("rows", C.c_int64), ("total_residual", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
 def library_path():
@@ -150,6 +153,11 @@ class Engine:
         self._ck(self.lib.s2m_get_timing(self.h, ms))
         return list(ms)
 
+    def timing_stats(self):
+        st = (C.c_double * 4)()
+        self._ck(self.lib.s2m_get_timing_stats(self.h, st))
+        return dict(match_ms=st[0], match_launches=int(st[1]), reduce_ms=st[2], reduce_launches=int(st[3]))
+
     # -- map / scan ------------------------------------------------------------------------
     def map_build(self, xyz):
         xyz = np.ascontiguousarray(xyz, np.float32)
@@ -240,6 +248,30 @@ class Engine:
         P = np.array(P, np.float64)
         log = IterLog()
         self._ck(self.lib.s2m_iterated_update(self.h, _p(x), _p(x_prop), _p(P), C.byref(log)))
+        it = log.iters
+        return dict(x=x, P=P, iters=it, rematch_passes=log.rematch_passes, converged=bool(log.converged),
+                    ekf_stop=bool(log.ekf_stop), effct=np.array(log.effct[:it]), rematch=np.array(log.rematch[:it]),
+                    conv=np.array(log.conv[:it]), total_res=np.array(log.total_residual[:it]),
+                    solution=np.array([list(log.solution[i]) for i in range(it)]).reshape(it, DIM))
+
+    def iterated_update_sharded(self, x, x_prop, P, d_block_ptr, reduce_cb):
+        """reduce_cb() must sum the device block across ranks on this handle's stream."""
+        x = np.array(x, np.float64)
+        x_prop = np.ascontiguousarray(x_prop, np.float64)
+        P = np.array(P, np.float64)
+        log = IterLog()
+
+        def _cb(_user):
+            try:
+                reduce_cb()
+                return 0
+            except Exception:  # never let an exception cross the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = ALLREDUCE_FN(_cb)
+        self._ck(self.lib.s2m_iterated_update_sharded(self.h, _p(x), _p(x_prop), _p(P), C.byref(log),
+                                                      C.c_void_p(d_block_ptr), cb, None))
         it = log.iters
         return dict(x=x, P=P, iters=it, rematch_passes=log.rematch_passes, converged=bool(log.converged),
                     ekf_stop=bool(log.ekf_stop), effct=np.array(log.effct[:it]), rematch=np.array(log.rematch[:it]),

@@ -153,6 +153,18 @@ typedef struct {
 int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES],
                         const double x_prop[S2M_STATE_DOUBLES], double P[S2M_DIM * S2M_DIM],
                         s2m_iter_log *log);
+/* Multi-GPU form: this handle holds a contiguous shard of the scan's points and the whole map.
+ * After every pass the shard's block (S2M_BLOCK_DOUBLES doubles, layout as in
+ * s2m_residual_pass_device) is in d_block, a DEVICE buffer the caller owns; reduce(user) must
+ * sum it in place across all ranks, ordered after prior work on the handle's stream (e.g. an
+ * RCCL all-reduce enqueued on that stream) and return 0.  Every rank then runs the identical
+ * fp64 update, so states stay bit-identical without a broadcast.  reduce == NULL degenerates to
+ * s2m_iterated_update.  (The reference has no counterpart: it is single-threaded, :827-828.) */
+typedef int (*s2m_allreduce_fn)(void *user);
+int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES],
+                                const double x_prop[S2M_STATE_DOUBLES], double P[S2M_DIM * S2M_DIM],
+                                s2m_iter_log *log, double *d_block, s2m_allreduce_fn reduce,
+                                void *user);
 /* Degeneracy queue access (effct_feat_numQueue, laserMapping.cpp:193). */
 int s2m_feat_queue_get(const s2m_engine *e, int32_t q[S2M_FEAT_QUEUE], int32_t *len);
 int s2m_feat_queue_set(s2m_engine *e, const int32_t *q, int32_t len);
@@ -179,6 +191,9 @@ int s2m_h_share_model(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int 
  * ms[2] = whole pass.  Enabled by s2m_set_timing(e, 1); costs one event sync per pass. */
 int s2m_set_timing(s2m_engine *e, int enabled);
 int s2m_get_timing(const s2m_engine *e, double ms[3]);
+/* Accumulated since the last s2m_set_timing call: stats[0] = sum of match-kernel ms, stats[1] =
+ * match launches, stats[2] = sum of residual/normal-block ms, stats[3] = its launches. */
+int s2m_get_timing_stats(const s2m_engine *e, double stats[4]);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,28 @@
+"""Dev tool: per-query cycle / radius statistics of the match kernel (S2M_DEBUG_MATCH=1)."""
+import os, sys, ctypes as C
+import numpy as np
+os.environ["S2M_DEBUG_MATCH"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from daliti_amd import Engine, synth
+c = synth.CONFIGS["C3"]
+m = synth.make_map(c["M"], c["L"]); s = synth.make_scan(c["beams"], c["az"], c["L"])
+_, xp, P = synth.filter_inputs()
+for g in [int(x) for x in os.environ.get("GROUPS", "16").split(",")]:
+    for cell in [float(x) for x in os.environ.get("CELLS", "0.25,0.5").split(",")]:
+        os.environ["S2M_MATCH_GROUP"] = str(g)
+        e = Engine(cell_size=cell)
+        e.map_build(m); e.scan_set(s)
+        for _ in range(3): e.residual_pass(xp, True)
+        e.set_timing(True)
+        e.residual_pass(xp, True)
+        ms = e.timing()[0]
+        d = np.zeros((e.n, 4), np.uint32)
+        assert e.lib.s2m_debug_match(e.h, C.c_void_p(d.ctypes.data)) == 0
+        cyc = d[:, 0].astype(float)
+        print("G %d cell %.2f match %.1f us | cycles(100MHz ticks?) pct50 %.0f pct90 %.0f pct99 %.0f max %.0f sum %.3g" % (
+            g, cell, ms * 1e3, *np.percentile(cyc, [50, 90, 99, 100]), cyc.sum()))
+        for r in range(1, 12):
+            sel = d[:, 1] == r
+            if sel.any():
+                print("   r=%2d n=%6d  mean cyc %.0f  rounds %.2f" % (r, sel.sum(), cyc[sel].mean(), d[sel, 3].mean()))
+        e.close()

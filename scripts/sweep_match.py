@@ -1,0 +1,31 @@
+"""Dev tool: time the match / reduce kernels over group width and cell size (HIP events)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from daliti_amd import Engine, synth
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
+c = synth.CONFIGS[cfg]
+m = synth.make_map(c["M"], c["L"])
+s = synth.make_scan(c["beams"], c["az"], c["L"])
+_, xp, P = synth.filter_inputs()
+groups = [int(g) for g in os.environ.get("GROUPS", "8,16,32").split(",")]
+cells = [float(g) for g in os.environ.get("CELLS", "0.2,0.25,0.3,0.35,0.5").split(",")]
+for g in groups:
+    for cell in cells:
+        os.environ["S2M_MATCH_GROUP"] = str(g)
+        e = Engine(cell_size=cell, max_iter=5)
+        e.map_build(m)
+        e.scan_set(s)
+        info = e.map_info()
+        for _ in range(3):
+            e.residual_pass(xp, True)
+        e.set_timing(True)
+        for _ in range(20):
+            e.residual_pass(xp, True)
+        st = e.timing_stats()
+        out = e.residual_pass(xp, True)
+        print("group %2d cell %.3f pts/cell %.2f bricks %6d  match %.1f us  reduce %.1f us  effct %d" % (
+            g, info["cell"], info["mean_per_cell"], info["bricks"], 1e3 * st["match_ms"] / st["match_launches"],
+            1e3 * st["reduce_ms"] / st["reduce_launches"], out["effct"]), flush=True)
+        e.close()

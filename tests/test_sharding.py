@@ -1,0 +1,114 @@
+"""N > 1 path on CPU: two gloo ranks each reduce a contiguous shard of the scan (via the oracle),
+all-reduce the 160-double block with the product's helper and run the update redundantly; the
+result must equal the single-rank run to fp64 round-off, and be bit-identical across ranks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_ranges_partition():
+    from daliti_amd.sharding import shard_range
+    for n in (0, 1, 7, 2048, 65536, 131072 + 3):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import oracle
+    from daliti_amd import synth
+    from daliti_amd.sharding import shard_range, allreduce_block
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    sc = synth.make_small()
+    tree = oracle.KdTree(sc["map"])
+    lo, hi = shard_range(len(sc["scan"]), rank, world)
+    scan = sc["scan"][lo:hi]
+    cfg = oracle.default_cfg(max_iter=5)
+    x, P = sc["x_prop"].copy(), sc["P"].copy()
+    ps = oracle.PassState(len(scan))
+    log = []
+    rematch_en, rematch_num, K1 = False, 0, None
+    for it in range(cfg.max_iter):
+        rematch = it == 0 or rematch_en
+        oracle.residual_pass(cfg, tree, scan, x, rematch, ps)
+        blk = torch.zeros(160, dtype=torch.float64)
+        blk[:144] = torch.from_numpy(ps.HtH.ravel())
+        blk[144:156] = torch.from_numpy(ps.Htz)
+        blk[156] = ps.effct
+        blk[157] = ps.total_res
+        allreduce_block(blk)
+        b = blk.numpy()
+        HtH, Htz, effct = b[:144].reshape(12, 12).copy(), b[144:156].copy(), int(b[156])
+        x, sol, K1, conv = oracle.eskf_update(cfg, x, sc["x_prop"], P, HtH, Htz)
+        log.append(effct)
+        rematch_en = False
+        if conv or (rematch_num == 0 and it == cfg.max_iter - 2):
+            rematch_en, rematch_num = True, rematch_num + 1
+        if rematch_num >= 2 or it == cfg.max_iter - 1:
+            P = oracle.cov_update(K1, HtH, P)
+            break
+    q.put((rank, x, P, log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_allreduce_equals_single_rank():
+    sys.path.insert(0, ROOT)
+    import oracle
+    from daliti_amd import synth
+    sc = synth.make_small()
+    ref = oracle.iterated_update(oracle.default_cfg(max_iter=5), oracle.KdTree(sc["map"]), sc["scan"],
+                                 sc["x_prop"], sc["x_prop"], sc["P"])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, x0, P0, log0), (_, x1, P1, log1) = res
+    assert (x0.view(np.uint64) == x1.view(np.uint64)).all()       # ranks agree bit-for-bit
+    assert (P0.view(np.uint64) == P1.view(np.uint64)).all()
+    assert log0 == log1 == list(ref["effct"])                       # integer counts are exact
+    assert np.abs(x0 - ref["x"]).max() < 1e-10 and np.abs(P0 - ref["P"]).max() < 1e-13
+
+
+@pytest.mark.gpu
+def test_gpu_shards_sum_to_full_block():
+    """Testable on one GPU: run the G shards sequentially and sum the partial blocks in rank order."""
+    from daliti_amd import Engine, synth
+    from daliti_amd.sharding import shard_range
+    sc = synth.make_small()
+    x = sc["x_prop"]
+    full = Engine()
+    full.map_build(sc["map"])
+    full.scan_set(sc["scan"])
+    ref = full.residual_pass(x, True)
+    for world in (2, 8):
+        HtH = np.zeros((12, 12)); Htz = np.zeros(12); eff = 0; tot = 0.0
+        for r in range(world):
+            lo, hi = shard_range(len(sc["scan"]), r, world)
+            full.scan_set(sc["scan"][lo:hi])
+            o = full.residual_pass(x, True)
+            HtH += o["HtH"]; Htz += o["Htz"]; eff += o["effct"]; tot += o["total_res"]
+        assert eff == ref["effct"]
+        assert np.abs(HtH - ref["HtH"]).max() <= 1e-12 * np.abs(ref["HtH"]).max()
+        assert np.abs(Htz - ref["Htz"]).max() <= 1e-12 * max(np.abs(ref["Htz"]).max(), 1)
+        assert abs(tot - ref["total_res"]) <= 1e-12 * ref["total_res"]
+    full.close()
