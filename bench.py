@@ -180,9 +180,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_eval": BYTES_REMATCH, "evals_per_launch": n_local,
             "avg_launch_ms": ms, "launches": tstats["match_launches"],
-            "reduce_kernel_avg_ms": tstats["reduce_ms"] / max(tstats["reduce_launches"], 1),
-            "reduce_kernel_GBps": n_local * BYTES_REUSE /
-            (tstats["reduce_ms"] / max(tstats["reduce_launches"], 1) * 1e-3) / 1e9,
+            "note": "one launch = match_easy + match_hard of one rematch pass (HIP events around both)",
         }
     if rank == 0 and world == 1 and not a.no_cpu and a.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(a, map_xyz, scan, x_prop, P0, res)

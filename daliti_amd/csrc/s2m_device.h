@@ -4,9 +4,13 @@
 //   pts   : M x float4 {x, y, z, bitcast(original index)}, sorted by (brick, cell-in-brick);
 //           one 16-byte load per candidate, a cell's points are contiguous, the cells of one
 //           x-row of a brick are contiguous.
-//   top   : dense nbx*nby*nbz array over the map bounding box, 0 = empty brick else brick id + 1.
-//           A brick is 8x8x8 cells; at c = 0.25 m this array is 58 K entries for a 215 m scene,
-//           so it stays L2-resident.
+//   porig : M x float4 {x, y, z, 0} in the caller's original order; neighbour indices returned by
+//           the search refer to it (plane fit gathers 5 points from it).
+//   top   : dense nbx*nby*nbz array of 16-byte entries over the map bounding box:
+//           {brick id + 1 (0 = empty), 0, 64-bit mask of the (y,z) rows of the brick that hold
+//           points}.  A brick is 8x8x8 cells; at c = 0.5 m this array is 7 K entries (0.1 MB) for
+//           a 215 m scene, so it stays L2-resident; the row mask lets the search skip the table
+//           lookups of empty rows.
 //   tab   : per occupied brick a 520-entry row (513 used): exclusive prefix of the point counts of
 //           its 512 cells (x fastest) as absolute indices into pts; tab[cell] .. tab[cell+1] is
 //           the cell, tab[row*8 + x0] .. tab[row*8 + x1 + 1] a run of cells along x.
@@ -29,9 +33,10 @@ struct Grid {
     float slop;         // safety margin of the termination bound, in cells
     int ncx, ncy, ncz;  // cells per axis (multiples of 8)
     int nbx, nby, nbz;  // bricks per axis
-    const uint32_t *top;
+    const uint4 *top;      // {id + 1, 0, rowmask lo, rowmask hi}
     const uint32_t *tab;
     const float4 *pts;
+    const float4 *porig;
     int64_t m;
 };
 

@@ -28,11 +28,11 @@ struct s2m_engine {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    bool timing = false;
+    bool timing = false, timing_all = false;  // timing: match kernels only; timing_all: + reduce kernel
     double last_ms[3] = {0, 0, 0};
     double tstats[4] = {0, 0, 0, 0};
     bool last_rematch = false;
-    int match_group = 16;
+    int match_group = 4;
     std::string err;
 
     MapBuffers map;
@@ -55,7 +55,11 @@ struct s2m_engine {
     float *d_nn_d2 = nullptr;
     double *d_partials = nullptr;
     double *d_block = nullptr;
-    double *h_block = nullptr;  // pinned
+    double *h_block = nullptr;  // pinned host: 160 doubles + completion flag, written by the reduce kernel
+    double *h_block_dev = nullptr;          // the same memory as seen from the device
+    unsigned long long seq = 0;             // pass sequence number published through the flag
+    uint32_t *d_ticket = nullptr;
+    bool host_poll = true;                  // S2M_NO_HOST_POLL=1: use a D2H copy + stream sync instead
     // rows on request
     uint32_t *d_block_off = nullptr;
     double *d_hx = nullptr, *d_h = nullptr;
@@ -63,6 +67,7 @@ struct s2m_engine {
     int64_t rows_cap = 0;
 
     Pose last_pose{};
+    uint32_t *d_hard = nullptr;   // hard list (n entries) followed by its counter
     uint32_t *d_dbg = nullptr;  // S2M_DEBUG_MATCH=1: per-point diagnostics of the match kernel
     bool dbg = false;
     bool nn_valid = false;
@@ -159,27 +164,34 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     const Gates gates = gates_of(e->cfg);
     const int n = (int)e->n;
     float *sx = e->d_scan, *sy = e->d_scan + e->n_cap, *sz = e->d_scan + 2 * e->n_cap;
-    if (e->timing) S2M_HIP(e, hipEventRecord(e->ev[0], e->stream));
     e->last_rematch = rematch != 0;
+    const bool time_match = e->timing && rematch, time_all = e->timing && e->timing_all;
+    if (time_match || time_all) S2M_HIP(e, hipEventRecord(e->ev[0], e->stream));
     if (rematch) {
         MatchArgs m;
         m.grid = e->grid; m.pose = pose; m.gates = gates;
         m.sx = sx; m.sy = sy; m.sz = sz; m.n = n;
-        m.plane = e->d_plane; m.flags = e->d_flags; m.sel = e->d_sel;
-        m.nn_idx = e->cfg.keep_neighbors ? e->d_nn_idx : nullptr;
-        m.nn_d2 = e->cfg.keep_neighbors ? e->d_nn_d2 : nullptr;
+        m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
+        m.hard_list = e->d_hard; m.hard_count = e->d_hard + e->n_cap;
         m.dbg = e->dbg ? e->d_dbg : nullptr;
-        launch_match(m, e->match_group, e->stream);
+        launch_match(m, e->match_group, e->stream);  // hard_count is zero: reset by every reduce launch
         e->nn_valid = true;
     }
-    if (e->timing) S2M_HIP(e, hipEventRecord(e->ev[1], e->stream));
+    if (time_match || time_all) S2M_HIP(e, hipEventRecord(e->ev[1], e->stream));
     ReduceArgs r;
     r.pose = pose; r.gates = gates;
     r.sx = sx; r.sy = sy; r.sz = sz; r.n = n;
+    r.fit = rematch ? 1 : 0;
+    r.nn_idx = e->d_nn_idx; r.nn_d2 = e->d_nn_d2; r.porig = e->grid.porig;
     r.plane = e->d_plane; r.flags = e->d_flags; r.sel = e->d_sel; r.eff = e->d_eff; r.pd2 = e->d_pd2;
     r.partials = e->d_partials; r.block = d_out;
+    r.ticket = e->d_ticket; r.hard_count = e->d_hard + e->n_cap;
+    const bool publish = e->host_poll && d_out == e->d_block;
+    r.host_block = publish ? e->h_block_dev : nullptr;
+    r.host_flag = publish ? reinterpret_cast<unsigned long long *>(e->h_block_dev + S2M_BLOCK_DOUBLES) : nullptr;
+    r.seq = ++e->seq;
     launch_reduce(r, e->stream);
-    if (e->timing) S2M_HIP(e, hipEventRecord(e->ev[2], e->stream));
+    if (time_all) S2M_HIP(e, hipEventRecord(e->ev[2], e->stream));
     S2M_HIP(e, hipGetLastError());
     e->last_pose = pose;
     e->pass_done = true;
@@ -189,16 +201,21 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
 int finish_timing(s2m_engine *e)
 {
     if (!e->timing) return S2M_OK;
-    S2M_HIP(e, hipEventSynchronize(e->ev[2]));
     float a = 0.f, b = 0.f;
-    S2M_HIP(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
-    S2M_HIP(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+    if (e->last_rematch || e->timing_all) {
+        S2M_HIP(e, hipEventSynchronize(e->ev[1]));
+        S2M_HIP(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
+    }
+    if (e->timing_all) {
+        S2M_HIP(e, hipEventSynchronize(e->ev[2]));
+        S2M_HIP(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+        e->tstats[2] += b;
+        e->tstats[3] += 1;
+    }
     e->last_ms[0] = a;
     e->last_ms[1] = b;
     e->last_ms[2] = a + b;
     if (e->last_rematch) { e->tstats[0] += a; e->tstats[1] += 1; }
-    e->tstats[2] += b;
-    e->tstats[3] += 1;
     return S2M_OK;
 }
 
@@ -262,13 +279,17 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
     e->device = dev;
     if (const char *g = std::getenv("S2M_MATCH_GROUP")) {
         const int v = std::atoi(g);
-        if (v == 8 || v == 16 || v == 32) e->match_group = v;
+        if (v == 1 || v == 2 || v == 4 || v == 8) e->match_group = v;
     }
     e->dbg = std::getenv("S2M_DEBUG_MATCH") != nullptr;
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&e->ev[i]) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_block, S2M_BLOCK_DOUBLES * sizeof(double)) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&e->h_block, S2M_BLOCK_DOUBLES * sizeof(double), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&e->h_block, (S2M_BLOCK_DOUBLES + 8) * sizeof(double), hipHostMallocMapped) == hipSuccess;
+    ok = ok && hipHostGetDevicePointer((void **)&e->h_block_dev, e->h_block, 0) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_ticket, 64) == hipSuccess && hipMemset(e->d_ticket, 0, 64) == hipSuccess;
+    if (ok) std::memset(e->h_block, 0, (S2M_BLOCK_DOUBLES + 8) * sizeof(double));
+    e->host_poll = std::getenv("S2M_NO_HOST_POLL") == nullptr;
     if (!ok) {
         s2m_destroy(e);
         return S2M_ERR_HIP;
@@ -285,7 +306,7 @@ int s2m_destroy(s2m_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_map(e->map);
     void *ptrs[] = {e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
-                    e->d_nn_d2, e->d_dbg, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
+                    e->d_nn_d2, e->d_hard, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_block) (void)hipHostFree(e->h_block);
@@ -375,8 +396,10 @@ int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int
         rc = rc ? rc : grow(e, &e->d_pd2, cap);
         rc = rc ? rc : grow(e, &e->d_nn_idx, cap * S2M_K);
         rc = rc ? rc : grow(e, &e->d_nn_d2, cap * S2M_K);
-        rc = rc ? rc : grow(e, &e->d_partials, (int64_t)reduce_blocks((int)cap) * kRedTerms);
-        rc = rc ? rc : grow(e, &e->d_block_off, (int64_t)reduce_blocks((int)cap) + 1);
+        rc = rc ? rc : grow(e, &e->d_partials, (int64_t)std::max(reduce_blocks((int)cap), 1) * kRedTerms);
+        rc = rc ? rc : grow(e, &e->d_block_off, (int64_t)rows_blocks((int)cap) + 1);
+        rc = rc ? rc : grow(e, &e->d_hard, cap + 16);
+        if (!rc) S2M_HIP(e, hipMemsetAsync(e->d_hard + cap, 0, 16 * sizeof(uint32_t), e->stream));
         if (e->dbg) rc = rc ? rc : grow(e, &e->d_dbg, cap * 4);
         if (rc) return rc;
         e->n_cap = cap;
@@ -397,20 +420,45 @@ int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int
     return S2M_OK;
 }
 
+// Wait for the block of the pass just enqueued and return a host pointer to it.  Fast path: the
+// reduce kernel writes the block and a sequence flag straight into pinned host memory and the host
+// spins on the flag (no D2H copy, no driver sync).  Fallback: D2H copy + stream synchronise.
+static int wait_block(s2m_engine *e, const double *d_src, const double **host)
+{
+    if (e->host_poll && d_src == e->d_block) {
+        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(e->h_block + S2M_BLOCK_DOUBLES);
+        bool seen = false;
+        for (long spin = 0; spin < 20000000L; ++spin) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == e->seq) { seen = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!seen) {  // kernel slow or failed: let the runtime tell us
+            S2M_HIP(e, hipStreamSynchronize(e->stream));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != e->seq) return fail(e, S2M_ERR_HIP, "reduce kernel did not publish its block");
+        }
+        *host = e->h_block;
+        return S2M_OK;
+    }
+    S2M_HIP(e, hipMemcpyAsync(e->h_block, d_src, S2M_BLOCK_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    *host = e->h_block;
+    return S2M_OK;
+}
+
 int s2m_residual_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, s2m_pass_out *out)
 {
     if (!out) return fail(e, S2M_ERR_ARG, "null output");
     int rc = run_pass(e, state, rematch, e ? e->d_block : nullptr);
     if (rc) return rc;
-    S2M_HIP(e, hipMemcpyAsync(e->h_block, e->d_block, S2M_BLOCK_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
-                              e->stream));
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    const double *hb = nullptr;
+    rc = wait_block(e, e->d_block, &hb);
+    if (rc) return rc;
     rc = finish_timing(e);
     if (rc) return rc;
-    std::memcpy(out->HtH, e->h_block, 144 * sizeof(double));
-    std::memcpy(out->Htz, e->h_block + 144, 12 * sizeof(double));
-    out->effct_feat_num = (int32_t)e->h_block[156];
-    out->total_residual = e->h_block[157];
+    std::memcpy(out->HtH, hb, 144 * sizeof(double));
+    std::memcpy(out->Htz, hb + 144, 12 * sizeof(double));
+    out->effct_feat_num = (int32_t)hb[156];
+    out->total_residual = hb[157];
     out->rematch = rematch ? 1 : 0;
     return S2M_OK;
 }
@@ -441,7 +489,7 @@ int s2m_get_rows(s2m_engine *e, double *h_x, double *h, int32_t *scan_index, int
     a.block_off = e->d_block_off; a.h_x = e->d_hx; a.h = e->d_h; a.scan_index = e->d_rowidx;
     launch_rows(a, e->stream);
     uint32_t m = 0;
-    S2M_HIP(e, hipMemcpyAsync(&m, e->d_block_off + reduce_blocks((int)e->n), sizeof(uint32_t), hipMemcpyDeviceToHost,
+    S2M_HIP(e, hipMemcpyAsync(&m, e->d_block_off + rows_blocks((int)e->n), sizeof(uint32_t), hipMemcpyDeviceToHost,
                               e->stream));
     S2M_HIP(e, hipStreamSynchronize(e->stream));
     *m_out = m;
@@ -470,7 +518,6 @@ int s2m_get_point_state(s2m_engine *e, uint8_t *selected, uint8_t *effective, fl
 int s2m_get_neighbors(s2m_engine *e, int32_t *idx, float *d2)
 {
     if (!e) return S2M_ERR_ARG;
-    if (!e->cfg.keep_neighbors) return fail(e, S2M_ERR_STATE, "engine created without keep_neighbors");
     if (!e->nn_valid) return fail(e, S2M_ERR_STATE, "no rematch pass yet");
     S2M_HIP(e, hipSetDevice(e->device));
     S2M_HIP(e, hipStreamSynchronize(e->stream));
@@ -537,14 +584,23 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         int rc = run_pass(e, x, rematch, d_block);
         if (rc) return rc;
         if (reduce && reduce(user) != 0) return fail(e, S2M_ERR_HIP, "all-reduce callback failed");
-        S2M_HIP(e, hipMemcpyAsync(e->h_block, d_block, S2M_BLOCK_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
-                                  e->stream));
-        S2M_HIP(e, hipStreamSynchronize(e->stream));
+        const double *hb = nullptr;
+        // after a collective the summed block only exists in d_block: copy it; otherwise poll
+        if (reduce) {
+            S2M_HIP(e, hipMemcpyAsync(e->h_block, d_block, S2M_BLOCK_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
+                                      e->stream));
+            S2M_HIP(e, hipStreamSynchronize(e->stream));
+            hb = e->h_block;
+            rc = S2M_OK;
+        } else {
+            rc = wait_block(e, d_block, &hb);
+        }
+        if (rc) return rc;
         rc = finish_timing(e);
         if (rc) return rc;
-        const double *HtH = e->h_block, *Htz = e->h_block + 144;
-        const int32_t effct = (int32_t)e->h_block[156];
-        const double total_res = e->h_block[157];
+        const double *HtH = hb, *Htz = hb + 144;
+        const int32_t effct = (int32_t)hb[156];
+        const double total_res = hb[157];
         // degeneracy queue (:899-918)
         e->queue[e->queue_len++] = effct;
         if (e->queue_len > S2M_FEAT_QUEUE) {
@@ -634,6 +690,7 @@ int s2m_set_timing(s2m_engine *e, int enabled)
 {
     if (!e) return S2M_ERR_ARG;
     e->timing = enabled != 0;
+    e->timing_all = enabled > 1;
     for (double &t : e->tstats) t = 0;
     return S2M_OK;
 }

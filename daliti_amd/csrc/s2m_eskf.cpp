@@ -32,13 +32,18 @@ M3 transposed(const M3 &A)
     return T;
 }
 
-// Inverse by LU with partial pivoting (Eigen's fixed-size inverse for n > 4).
-bool invert(const Mat24 &in, Mat24 &out)
+// LU with partial pivoting (what Eigen's fixed-size inverse uses for n > 4): factor once, then
+// solve for the unit columns that are needed.
+struct Lu24 {
+    Mat24 lu;
+    int perm[kDim];
+};
+bool lu_factor(const Mat24 &in, Lu24 &f)
 {
     constexpr int N = kDim;
-    Mat24 lu = in;
-    int perm[N];
-    for (int i = 0; i < N; ++i) perm[i] = i;
+    f.lu = in;
+    Mat24 &lu = f.lu;
+    for (int i = 0; i < N; ++i) f.perm[i] = i;
     for (int k = 0; k < N; ++k) {
         int piv = k;
         double mag = std::fabs(lu[k * N + k]);
@@ -49,30 +54,33 @@ bool invert(const Mat24 &in, Mat24 &out)
         if (!(mag > 0.0)) return false;
         if (piv != k) {
             for (int c = 0; c < N; ++c) std::swap(lu[k * N + c], lu[piv * N + c]);
-            std::swap(perm[k], perm[piv]);
+            std::swap(f.perm[k], f.perm[piv]);
         }
         const double d = lu[k * N + k];
         for (int r = k + 1; r < N; ++r) {
-            const double f = lu[r * N + k] / d;
-            lu[r * N + k] = f;
-            if (f != 0.0)
-                for (int c = k + 1; c < N; ++c) lu[r * N + c] -= f * lu[k * N + c];
-        }
-    }
-    double y[N];
-    for (int col = 0; col < N; ++col) {
-        for (int r = 0; r < N; ++r) {
-            double s = (perm[r] == col) ? 1.0 : 0.0;
-            for (int c = 0; c < r; ++c) s -= lu[r * N + c] * y[c];
-            y[r] = s;
-        }
-        for (int r = N - 1; r >= 0; --r) {
-            double s = y[r];
-            for (int c = r + 1; c < N; ++c) s -= lu[r * N + c] * out[c * N + col];
-            out[r * N + col] = s / lu[r * N + r];
+            const double m = lu[r * N + k] / d;
+            lu[r * N + k] = m;
+            if (m != 0.0)
+                for (int c = k + 1; c < N; ++c) lu[r * N + c] -= m * lu[k * N + c];
         }
     }
     return true;
+}
+// column `col` of the inverse, written with stride `ld` starting at out
+void lu_inverse_col(const Lu24 &f, int col, double *out, int ld)
+{
+    constexpr int N = kDim;
+    double y[N];
+    for (int r = 0; r < N; ++r) {
+        double s = (f.perm[r] == col) ? 1.0 : 0.0;
+        for (int c = 0; c < r; ++c) s -= f.lu[r * N + c] * y[c];
+        y[r] = s;
+    }
+    for (int r = N - 1; r >= 0; --r) {
+        double s = y[r];
+        for (int c = r + 1; c < N; ++c) s -= f.lu[r * N + c] * out[c * ld];
+        out[r * ld] = s / f.lu[r * N + r];
+    }
 }
 
 }  // namespace
@@ -145,22 +153,34 @@ bool eskf_update(const EskfParams &p, State &x, const State &x_prop, const Mat24
     constexpr int N = kDim;
     work.valid = false;
     converged = false;
-    Mat24 S, Si;
-    for (int i = 0; i < N * N; ++i) S[i] = P[i] / p.laser_point_cov;
-    if (!invert(S, Si)) return false;                              // (state.cov / LASER_POINT_COV).inverse()
+    if (!work.pinv_valid || work.Rkey != p.laser_point_cov ||
+        std::memcmp(work.Pkey.data(), P.data(), sizeof(double) * N * N) != 0) {
+        Mat24 S;
+        for (int i = 0; i < N * N; ++i) S[i] = P[i] / p.laser_point_cov;
+        Lu24 f;
+        work.pinv_valid = false;
+        if (!lu_factor(S, f)) return false;                        // (state.cov / LASER_POINT_COV).inverse()
+        for (int c = 0; c < N; ++c) lu_inverse_col(f, c, &work.Pinv[c], N);
+        work.Pkey = P;
+        work.Rkey = p.laser_point_cov;
+        work.pinv_valid = true;
+    }
+    Mat24 A = work.Pinv;
     for (int r = 0; r < 12; ++r)
-        for (int c = 0; c < 12; ++c) Si[r * N + c] += HtH[r * 12 + c];  // + H_T_H (12x12 block)
-    if (!invert(Si, work.K1)) return false;                        // K_1 (:1017-1018)
+        for (int c = 0; c < 12; ++c) A[r * N + c] += HtH[r * 12 + c];    // + H_T_H (12x12 block)
+    Lu24 f;
+    if (!lu_factor(A, f)) return false;                            // K_1 (:1017-1018); only K_1[:, :12] is used
+    for (int c = 0; c < 12; ++c) lu_inverse_col(f, c, &work.K1c[c], 12);
     std::memcpy(work.HtH.data(), HtH, sizeof(double) * 144);
 
     const Vec24 vec = boxminus(x_prop, x);                         // :1028
     for (int r = 0; r < N; ++r) {
         double kz = 0.0;
-        for (int a = 0; a < 12; ++a) kz += work.K1[r * N + a] * Htz[a];
+        for (int a = 0; a < 12; ++a) kz += work.K1c[r * 12 + a] * Htz[a];
         double khv = 0.0;
         for (int b = 0; b < 12; ++b) {
             double kh = 0.0;
-            for (int a = 0; a < 12; ++a) kh += work.K1[r * N + a] * HtH[a * 12 + b];
+            for (int a = 0; a < 12; ++a) kh += work.K1c[r * 12 + a] * HtH[a * 12 + b];
             khv += kh * vec[b];
         }
         solution[r] = (kz + vec[r]) - khv;                         // :1032
@@ -181,7 +201,7 @@ void cov_update(const EskfWork &work, Mat24 &P)
         for (int c = 0; c < N; ++c) ImG[r * N + c] = (r == c) ? 1.0 : 0.0;
         for (int b = 0; b < 12; ++b) {
             double kh = 0.0;
-            for (int a = 0; a < 12; ++a) kh += work.K1[r * N + a] * work.HtH[a * 12 + b];
+            for (int a = 0; a < 12; ++a) kh += work.K1c[r * 12 + a] * work.HtH[a * 12 + b];
             ImG[r * N + b] -= kh;
         }
     }

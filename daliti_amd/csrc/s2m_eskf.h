@@ -37,9 +37,14 @@ struct EskfParams {
 };
 
 struct EskfWork {
-    Mat24 K1{};                   // (H_T_H + (P/R)^-1)^-1
-    std::array<double, 144> HtH{};  // normal block of the last update
+    std::array<double, kDim * 12> K1c{};  // first 12 columns of K_1 = (H_T_H + (P/R)^-1)^-1, row-major 24x12
+    std::array<double, 144> HtH{};        // normal block of the last update
     bool valid = false;
+    // (P/R)^-1 is constant while the covariance is (it only changes at the exit of the iterated
+    // update, laserMapping.cpp:1085), so it is inverted once per distinct P
+    Mat24 Pkey{}, Pinv{};
+    double Rkey = 0.0;
+    bool pinv_valid = false;
 };
 
 // Returns false when a matrix is singular.  x is updated in place.

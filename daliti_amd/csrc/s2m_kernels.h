@@ -11,9 +11,10 @@ namespace s2m {
 struct MapBuffers {
     // owned by the engine, (re)allocated by build_map
     float4 *pts = nullptr;
-    uint32_t *top = nullptr;
+    float4 *porig = nullptr;
+    uint4 *top = nullptr;
     uint32_t *tab = nullptr;
-    int64_t pts_cap = 0, top_cap = 0, tab_cap = 0;
+    int64_t pts_cap = 0, porig_cap = 0, top_cap = 0, tab_cap = 0;
     // scratch
     uint64_t *keys = nullptr, *keys_alt = nullptr;
     uint32_t *vals = nullptr, *vals_alt = nullptr;
@@ -35,39 +36,49 @@ hipError_t build_map(const float *xyz_dev, int64_t stride, int64_t m, float cell
                      MapStats &stats, bool &too_large, hipStream_t st);
 void free_map(MapBuffers &buf);
 
-// ---- s2m_match.hip : kNN + plane fit ------------------------------------------------------------
+// ---- s2m_match.hip : exact 5-NN ------------------------------------------------------------------
 struct MatchArgs {
     Grid grid;
     Pose pose;
     Gates gates;
     const float *sx, *sy, *sz;
     int n;
-    float4 *plane;
-    uint8_t *flags;
-    uint8_t *sel;
-    int32_t *nn_idx;  // optional
-    float *nn_d2;     // optional
-    uint32_t *dbg = nullptr;  // optional, 4 words per scan point: cycles, final radius, candidates, rounds
+    int32_t *nn_idx;     // n x 5, index into the caller's map array, -1 = missing
+    float *nn_d2;        // n x 5 ascending, INFINITY = missing
+    uint32_t *hard_list; // n entries of scratch: queries the first-shell kernel could not resolve
+    uint32_t *hard_count;
+    uint32_t *dbg = nullptr;  // optional diagnostics, 4 words per scan point
 };
 void launch_match(const MatchArgs &a, int group, hipStream_t st);
 
-// ---- s2m_reduce.hip : residual + Jacobian + normal block ------------------------------------------
-constexpr int kRedBlock = 256;
-constexpr int kRedTerms = 96;  // 78 (upper triangle of 12x12) + 12 + total_res + count, padded
+// ---- s2m_reduce.hip : [plane fit +] residual + Jacobian + normal block ----------------------------
+constexpr int kRedBlock = 512;   // 8 waves per workgroup: 128 partial rows at 65k points for the in-kernel final sum
+constexpr int kRowsBlock = 256;
+constexpr int kRedTerms = 96;    // 78 (upper triangle of 12x12) + 12 + total_res + count, padded
 struct ReduceArgs {
     Pose pose;
     Gates gates;
     const float *sx, *sy, *sz;
     int n;
-    const float4 *plane;
-    const uint8_t *flags;
+    int fit;             // rematch pass: fit the plane from the fresh neighbours first
+    const int32_t *nn_idx;
+    const float *nn_d2;
+    const float4 *porig;
+    float4 *plane;
+    uint8_t *flags;
     uint8_t *sel;
     uint8_t *eff;
     float *pd2;
     double *partials;  // blocks x kRedTerms
-    double *block;     // S2M_BLOCK_DOUBLES output
+    double *block;     // S2M_BLOCK_DOUBLES output (device)
+    uint32_t *ticket;  // arrival counter of the in-kernel final sum; zero before the first launch
+    uint32_t *hard_count;            // reset to 0 for the next rematch pass
+    double *host_block;              // optional: pinned host copy of block, device-visible pointer
+    unsigned long long *host_flag;   // optional: set to seq (system scope) after host_block is written
+    unsigned long long seq;
 };
 int reduce_blocks(int n);
+int rows_blocks(int n);
 void launch_reduce(const ReduceArgs &a, hipStream_t st);
 
 // dense rows of the last pass in index order (laserMapping.cpp:942-979)

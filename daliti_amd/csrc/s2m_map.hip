@@ -94,20 +94,22 @@ __global__ __launch_bounds__(256) void key_kernel(const float *__restrict__ xyz,
 __global__ __launch_bounds__(256) void gather_flag_kernel(const float *__restrict__ xyz, int64_t stride, int64_t m,
                                                           const uint64_t *__restrict__ keys,
                                                           const uint32_t *__restrict__ vals,
-                                                          float4 *__restrict__ pts, uint32_t *__restrict__ flag)
+                                                          float4 *__restrict__ pts, float4 *__restrict__ porig,
+                                                          uint32_t *__restrict__ flag)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const uint32_t src = vals[j];
     pts[j] = make_float4(xyz[(int64_t)src * stride], xyz[(int64_t)src * stride + 1], xyz[(int64_t)src * stride + 2],
                          __uint_as_float(src));
+    porig[j] = make_float4(xyz[j * stride], xyz[j * stride + 1], xyz[j * stride + 2], 0.0f);
     flag[j] = (j == 0 || (keys[j] >> 9) != (keys[j - 1] >> 9)) ? 1u : 0u;
 }
 
 // brick_id[j] is the inclusive scan of flag (1-based brick id of point j)
 __global__ __launch_bounds__(256) void cell_start_kernel(int64_t m, const uint64_t *__restrict__ keys,
                                                          const uint32_t *__restrict__ brick_id,
-                                                         uint32_t *__restrict__ top, uint32_t *__restrict__ tab,
+                                                         uint4 *__restrict__ top, uint32_t *__restrict__ tab,
                                                          uint32_t *__restrict__ counters)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -118,7 +120,11 @@ __global__ __launch_bounds__(256) void cell_start_kernel(int64_t m, const uint64
     if (cell_first) {
         tab[(int64_t)b * kBrickStride + (uint32_t)(k & 511)] = (uint32_t)j;
         atomicAdd(&counters[0], 1u);
-        if (j == 0 || (keys[j - 1] >> 9) != (k >> 9)) top[k >> 9] = b + 1;
+        // row-occupancy mask of the brick: bit (lz*8 + ly)
+        const uint32_t rowbit = (uint32_t)(k & 511) >> 3;
+        uint32_t *te = reinterpret_cast<uint32_t *>(&top[k >> 9]);
+        atomicOr(&te[2 + (rowbit >> 5)], 1u << (rowbit & 31));
+        if (j == 0 || (keys[j - 1] >> 9) != (k >> 9)) te[0] = b + 1;
     }
     if (j == m - 1 || (keys[j + 1] >> 9) != (k >> 9)) tab[(int64_t)b * kBrickStride + kBrickCells] = (uint32_t)(j + 1);
 }
@@ -170,7 +176,7 @@ static hipError_t ensure(void **p, int64_t *cap, int64_t need, size_t elem)
 
 void free_map(MapBuffers &b)
 {
-    void *ptrs[] = {b.pts, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.brick_flag, b.brick_id,
+    void *ptrs[] = {b.pts, b.porig, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.brick_flag, b.brick_id,
                     b.sort_tmp, b.bbox, b.counters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -208,7 +214,8 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     g.slop = std::max(1.0e-4f, 16.0f * max_cells * 1.1920929e-7f);
 
     S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m, sizeof(float4)));
-    S2M_TRY(ensure((void **)&buf.top, &buf.top_cap, top_entries, sizeof(uint32_t)));
+    S2M_TRY(ensure((void **)&buf.porig, &buf.porig_cap, m, sizeof(float4)));
+    S2M_TRY(ensure((void **)&buf.top, &buf.top_cap, top_entries, sizeof(uint4)));
     if (buf.scratch_cap < m) {
         void **ps[] = {(void **)&buf.keys, (void **)&buf.keys_alt, (void **)&buf.vals, (void **)&buf.vals_alt,
                        (void **)&buf.brick_flag, (void **)&buf.brick_id};
@@ -221,12 +228,12 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
         buf.scratch_cap = m;
     }
     if (!buf.counters) S2M_TRY(hipMalloc((void **)&buf.counters, 64));
-    S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)top_entries * sizeof(uint32_t), st));
+    S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)top_entries * sizeof(uint4), st));
     S2M_TRY(hipMemsetAsync(buf.counters, 0, 64, st));
     stats = MapStats();
     stats.top_entries = top_entries;
     if (m == 0) {
-        g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts;
+        g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.porig = buf.porig;
         return hipStreamSynchronize(st);
     }
 
@@ -252,7 +259,7 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t1, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m,
                                       0, (unsigned)bits, st));
     hipLaunchKernelGGL(gather_flag_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, buf.keys_alt,
-                       buf.vals_alt, buf.pts, buf.brick_flag);
+                       buf.vals_alt, buf.pts, buf.porig, buf.brick_flag);
     size_t t2 = buf.sort_tmp_bytes;
     S2M_TRY(rocprim::inclusive_scan(buf.sort_tmp, t2, buf.brick_flag, buf.brick_id, (size_t)m,
                                     rocprim::plus<uint32_t>(), st));
@@ -270,7 +277,7 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     S2M_TRY(hipGetLastError());
     stats.bricks = bricks;
     stats.occupied_cells = occ;
-    g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts;
+    g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.porig = buf.porig;
     return hipSuccess;
 }
 

@@ -1,4 +1,11 @@
-// s2m_reduce.hip -- residual, gates, Jacobian row and the fused H^T H / H^T z contraction.
+// s2m_reduce.hip -- [gate + plane fit,] residual, gates, Jacobian row and the fused H^T H / H^T z
+// contraction.
+//
+// On a rematch pass (FIT) each lane first applies the neighbour gate (laserMapping.cpp:852-854) to
+// the fresh Nearest_Points of its scan point and fits the plane (esti_plane, :863;
+// common_lib.h:267-299) from the five neighbours gathered by index; the plane only depends on the
+// (world-frame, constant) neighbours, so it is cached and the reuse passes skip the fit -- the
+// reference re-fits the identical plane every iteration.
 //
 // Replaces, per scan point, eskf_lio/src/laserMapping.cpp:857-881 (point-to-plane residual,
 // s-gate, sticky selection), :887-896 (effective set, total_residual), :948-979 (Jacobian row,
@@ -9,10 +16,12 @@
 //
 // One lane per scan point, SoA loads (x[], y[], z[], float4 plane) are fully coalesced.
 // Compiled with -ffp-contract=off; the row arithmetic follows oracle/s2m_oracle.c:jac_row.
+#include <algorithm>
 #include <cmath>
 
 #include "s2m_device.h"
 #include "s2m_kernels.h"
+#include "s2m_plane.h"
 
 namespace s2m {
 
@@ -68,7 +77,19 @@ __device__ __forceinline__ void jac_row(const Pose &P, float bx, float by, float
     z = -(double)pd2;
 }
 
-template <bool EXT>
+// is partial-row slot t written by a kernel that reduces NC Jacobian columns?
+template <int NC>
+__device__ __forceinline__ bool term_used(int t)
+{
+    if (t >= kTermHtz) return t < kTermHtz + NC || t == kTermRes || t == kTermCnt;
+    bool used = false;
+#pragma unroll
+    for (int r = 0; r < NC; ++r)
+        if (t >= tri_index(r, r) && t <= tri_index(r, NC - 1)) used = true;
+    return used;
+}
+
+template <bool EXT, bool FIT>
 __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
 {
     constexpr int NC = EXT ? 12 : 6;
@@ -82,11 +103,35 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
     for (int k = 0; k < 12; ++k) h[k] = 0.0;
     if (i < a.n) {
         const float bx = a.sx[i], by = a.sy[i], bz = a.sz[i];
-        const uint8_t sel = a.sel[i];
+        uint8_t sel, fl;
+        float4 pl;
+        if (FIT) {
+            // neighbour gate: five neighbours and d2[4] <= 5 (:852-854)
+            const int32_t i4 = a.nn_idx[(int64_t)i * kK + (kK - 1)];
+            const bool gate = (i4 >= 0) && !(a.nn_d2[(int64_t)i * kK + (kK - 1)] > a.gates.knn_d2_gate);
+            bool plane_ok = false;
+            pl = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gate) {
+                float nx[kK], ny[kK], nz[kK];
+#pragma unroll
+                for (int k = 0; k < kK; ++k) {
+                    const float4 p = a.porig[a.nn_idx[(int64_t)i * kK + k]];
+                    nx[k] = p.x; ny[k] = p.y; nz[k] = p.z;
+                }
+                plane_ok = fit_plane(nx, ny, nz, a.gates.plane_thr, pl);
+            }
+            sel = gate ? 1 : 0;  // point_selected_surf after the gate
+            fl = (uint8_t)((gate ? kFlagGate : 0) | (plane_ok ? kFlagPlane : 0));
+            a.plane[i] = pl;
+            a.flags[i] = fl;
+        } else {
+            sel = a.sel[i];
+            fl = a.flags[i];
+        }
         if (sel) {
             uint8_t sel_new = 0;  // sticky: only fit-ok + s-gate re-selects (:862,:873)
-            if (a.flags[i] & kFlagPlane) {
-                const float4 pl = a.plane[i];
+            if (fl & kFlagPlane) {
+                if (!FIT) pl = a.plane[i];
                 float wx, wy, wz;
                 body_to_world(a.pose, bx, by, bz, wx, wy, wz);
                 const float pd2 = ((pl.x * wx + pl.y * wy) + pl.z * wz) + pl.w;                    // :866
@@ -103,6 +148,8 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
                 }
             }
             a.sel[i] = sel_new;
+        } else if (FIT) {
+            a.sel[i] = 0;
         }
         a.eff[i] = eff ? 1 : 0;
     }
@@ -123,51 +170,62 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
         if (lane == 0) { red[wave][kTermRes] = s; red[wave][kTermCnt] = c; }
     }
     __syncthreads();
+    // one fp64 row per workgroup, published write-through (agent-scope 8-byte stores) so the last
+    // workgroup to arrive can read every row without a release/acquire fence pair
     if (threadIdx.x < kRedTerms) {
         const int t = threadIdx.x;
         double s = 0.0;
-        bool used = (t >= kTermHtz) ? (t < kTermHtz + NC || t == kTermRes || t == kTermCnt) : false;
-        if (t < kTermHtz) {
-            // is t the index of some (r, c) with c < NC ?
+        if (term_used<NC>(t)) {
 #pragma unroll
-            for (int r = 0; r < NC; ++r)
-                if (t >= tri_index(r, r) && t <= tri_index(r, NC - 1)) used = true;
+            for (int w = 0; w < kRedBlock / 64; ++w) s += red[w][t];
         }
-        if (used) s = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
-        a.partials[(int64_t)blockIdx.x * kRedTerms + t] = s;
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.partials) + (int64_t)blockIdx.x * kRedTerms + t,
+                           (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-}
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
+    __syncthreads();
+    __shared__ uint32_t s_last;
+    if (threadIdx.x == 0) {
+        const uint32_t tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (tk == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
 
-// fixed-order sum of the per-workgroup rows, expanded to the symmetric 12x12.  kFinChunks lanes
-// per term each sum a strided slice of the rows with independent loads, then the chunk sums are
-// combined in a fixed order, so the result does not depend on timing.
-constexpr int kFinChunks = 8;
-__global__ __launch_bounds__(kRedTerms * kFinChunks) void finalize_kernel(const double *__restrict__ partials,
-                                                                          int blocks, double *__restrict__ out)
-{
-    __shared__ double part[kFinChunks][kRedTerms];
+    // ---- last workgroup: fixed-order sum of the rows (independent of arrival order) -----------------
+    constexpr int kChunks = kRedBlock / kRedTerms;  // 5 lanes per term
+    __shared__ double part[kChunks][kRedTerms];
     __shared__ double tot[kRedTerms];
-    const int t = threadIdx.x % kRedTerms, ch = threadIdx.x / kRedTerms;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = ch;
-    for (; b + 3 * kFinChunks < blocks; b += 4 * kFinChunks) {
-        const double v0 = partials[(int64_t)b * kRedTerms + t];
-        const double v1 = partials[(int64_t)(b + kFinChunks) * kRedTerms + t];
-        const double v2 = partials[(int64_t)(b + 2 * kFinChunks) * kRedTerms + t];
-        const double v3 = partials[(int64_t)(b + 3 * kFinChunks) * kRedTerms + t];
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    const int blocks = gridDim.x;
+    if (threadIdx.x < kChunks * kRedTerms) {
+        const int t = threadIdx.x % kRedTerms, ch = threadIdx.x / kRedTerms;
+        const unsigned long long *pp = reinterpret_cast<const unsigned long long *>(a.partials);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int b = ch;
+        for (; b + 3 * kChunks < blocks; b += 4 * kChunks) {  // four independent loads in flight
+            const unsigned long long v0 = __hip_atomic_load(pp + (int64_t)b * kRedTerms + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v1 = __hip_atomic_load(pp + (int64_t)(b + kChunks) * kRedTerms + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v2 = __hip_atomic_load(pp + (int64_t)(b + 2 * kChunks) * kRedTerms + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long v3 = __hip_atomic_load(pp + (int64_t)(b + 3 * kChunks) * kRedTerms + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s0 += __longlong_as_double((long long)v0);
+            s1 += __longlong_as_double((long long)v1);
+            s2 += __longlong_as_double((long long)v2);
+            s3 += __longlong_as_double((long long)v3);
+        }
+        for (; b < blocks; b += kChunks)
+            s0 += __longlong_as_double((long long)__hip_atomic_load(pp + (int64_t)b * kRedTerms + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        part[ch][t] = (s0 + s1) + (s2 + s3);
     }
-    for (; b < blocks; b += kFinChunks) s0 += partials[(int64_t)b * kRedTerms + t];
-    part[ch][t] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (threadIdx.x < kRedTerms) {
         double s = 0.0;
 #pragma unroll
-        for (int c = 0; c < kFinChunks; ++c) s += part[c][threadIdx.x];
+        for (int c = 0; c < kChunks; ++c) s += part[c][threadIdx.x];
         tot[threadIdx.x] = s;
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < 160; o += blockDim.x) {
+    if (threadIdx.x < 160) {
+        const int o = threadIdx.x;
         double v = 0.0;
         if (o < 144) {
             const int r = o / 12, c = o % 12;
@@ -179,30 +237,43 @@ __global__ __launch_bounds__(kRedTerms * kFinChunks) void finalize_kernel(const 
         } else if (o == 157) {
             v = tot[kTermRes];
         }
-        out[o] = v;
+        a.block[o] = v;
+        if (a.host_block) a.host_block[o] = v;
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        if (a.hard_count) *a.hard_count = 0u;
+    }
+    if (a.host_flag) {
+        __threadfence_system();  // every writer of host_block releases to the system
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 int reduce_blocks(int n) { return (n + kRedBlock - 1) / kRedBlock; }
+int rows_blocks(int n) { return (n + kRowsBlock - 1) / kRowsBlock; }
 
 void launch_reduce(const ReduceArgs &a, hipStream_t st)
 {
-    const int blocks = reduce_blocks(a.n);
-    if (blocks > 0) {
-        if (a.gates.extrinsic)
-            hipLaunchKernelGGL(reduce_kernel<true>, dim3(blocks), dim3(kRedBlock), 0, st, a);
-        else
-            hipLaunchKernelGGL(reduce_kernel<false>, dim3(blocks), dim3(kRedBlock), 0, st, a);
+    // an empty scan still produces a (zero) block: one workgroup with no points
+    const int blocks = std::max(reduce_blocks(a.n), 1);
+    if (a.gates.extrinsic) {
+        if (a.fit) hipLaunchKernelGGL((reduce_kernel<true, true>), dim3(blocks), dim3(kRedBlock), 0, st, a);
+        else hipLaunchKernelGGL((reduce_kernel<true, false>), dim3(blocks), dim3(kRedBlock), 0, st, a);
+    } else {
+        if (a.fit) hipLaunchKernelGGL((reduce_kernel<false, true>), dim3(blocks), dim3(kRedBlock), 0, st, a);
+        else hipLaunchKernelGGL((reduce_kernel<false, false>), dim3(blocks), dim3(kRedBlock), 0, st, a);
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kRedTerms * kFinChunks), 0, st, a.partials, blocks, a.block);
 }
 
 // ---- dense rows in index order (Hsub / meas_vec / laserCloudOri order), on request --------------
-__global__ __launch_bounds__(kRedBlock) void rows_count_kernel(const uint8_t *__restrict__ eff, int n,
+__global__ __launch_bounds__(kRowsBlock) void rows_count_kernel(const uint8_t *__restrict__ eff, int n,
                                                                uint32_t *__restrict__ block_cnt)
 {
-    __shared__ uint32_t wc[kRedBlock / 64];
-    const int i = blockIdx.x * kRedBlock + threadIdx.x;
+    __shared__ uint32_t wc[kRowsBlock / 64];
+    const int i = blockIdx.x * kRowsBlock + threadIdx.x;
     const bool e = (i < n) && eff[i];
     const uint64_t b = __ballot(e);
     if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = (uint32_t)__popcll(b);
@@ -240,10 +311,10 @@ __global__ __launch_bounds__(1024) void rows_scan_kernel(uint32_t *__restrict__ 
 }
 
 template <bool EXT>
-__global__ __launch_bounds__(kRedBlock) void rows_emit_kernel(RowsArgs a)
+__global__ __launch_bounds__(kRowsBlock) void rows_emit_kernel(RowsArgs a)
 {
-    __shared__ uint32_t wc[kRedBlock / 64];
-    const int i = blockIdx.x * kRedBlock + threadIdx.x;
+    __shared__ uint32_t wc[kRowsBlock / 64];
+    const int i = blockIdx.x * kRowsBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool e = (i < a.n) && a.eff[i];
     const uint64_t b = __ballot(e);
@@ -264,14 +335,14 @@ __global__ __launch_bounds__(kRedBlock) void rows_emit_kernel(RowsArgs a)
 
 void launch_rows(const RowsArgs &a, hipStream_t st)
 {
-    const int blocks = reduce_blocks(a.n);
-    if (blocks > 0) hipLaunchKernelGGL(rows_count_kernel, dim3(blocks), dim3(kRedBlock), 0, st, a.eff, a.n, a.block_off);
+    const int blocks = rows_blocks(a.n);
+    if (blocks > 0) hipLaunchKernelGGL(rows_count_kernel, dim3(blocks), dim3(kRowsBlock), 0, st, a.eff, a.n, a.block_off);
     hipLaunchKernelGGL(rows_scan_kernel, dim3(1), dim3(1024), 0, st, a.block_off, blocks);
     if (blocks > 0) {
         if (a.gates.extrinsic)
-            hipLaunchKernelGGL(rows_emit_kernel<true>, dim3(blocks), dim3(kRedBlock), 0, st, a);
+            hipLaunchKernelGGL(rows_emit_kernel<true>, dim3(blocks), dim3(kRowsBlock), 0, st, a);
         else
-            hipLaunchKernelGGL(rows_emit_kernel<false>, dim3(blocks), dim3(kRedBlock), 0, st, a);
+            hipLaunchKernelGGL(rows_emit_kernel<false>, dim3(blocks), dim3(kRowsBlock), 0, st, a);
     }
 }
 

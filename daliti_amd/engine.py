@@ -146,6 +146,7 @@ class Engine:
         self._ck(self.lib.s2m_set_stream(self.h, C.c_void_p(hip_stream)))
 
     def set_timing(self, on=True):
+        """True/1: time the match kernels of rematch passes; 2: also the residual kernel."""
         self._ck(self.lib.s2m_set_timing(self.h, C.c_int(int(on))))
 
     def timing(self):

@@ -62,7 +62,7 @@ typedef struct {
     int32_t feat_threshold;  /* dynamic_effect_featurepoints_threshold, laserMapping.cpp:97 */
     float  cell_size;        /* voxel edge of the GPU map in metres; <= 0 = choose from density */
     int32_t device;          /* HIP device ordinal; < 0 = current device                   */
-    int32_t keep_neighbors;  /* != 0: keep Nearest_Points (idx + d2) for s2m_get_neighbors  */
+    int32_t keep_neighbors;  /* reserved (Nearest_Points are always kept); set 0               */
 } s2m_config;
 
 int s2m_abi_version(void);
@@ -121,7 +121,7 @@ int s2m_get_rows(s2m_engine *e, double *h_x, double *h, int32_t *scan_index, int
 int s2m_get_point_state(s2m_engine *e, uint8_t *selected, uint8_t *effective, float *plane,
                         float *pd2);
 /* Nearest_Points of the last rematch pass (:845-850): idx[n*5] indexes the array given to
- * s2m_map_build (-1 = missing), d2[n*5] ascending.  Needs cfg.keep_neighbors. */
+ * s2m_map_build (-1 = missing), d2[n*5] ascending (INFINITY = missing). */
 int s2m_get_neighbors(s2m_engine *e, int32_t *idx, float *d2);
 
 /* Kalman update of laserMapping.cpp:1012-1046 from the normal block:
@@ -188,7 +188,8 @@ int s2m_h_share_model(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int 
 
 /* Timing of the last pass in milliseconds measured with HIP events on the handle's stream:
  * ms[0] = match (kNN + plane fit) kernel, ms[1] = residual/Jacobian/normal-block kernel,
- * ms[2] = whole pass.  Enabled by s2m_set_timing(e, 1); costs one event sync per pass. */
+ * ms[2] = whole pass.  s2m_set_timing(e, 1) times the match kernels of rematch passes only (two
+ * event records per rematch pass); s2m_set_timing(e, 2) also times the residual kernel. */
 int s2m_set_timing(s2m_engine *e, int enabled);
 int s2m_get_timing(const s2m_engine *e, double ms[3]);
 /* Accumulated since the last s2m_set_timing call: stats[0] = sum of match-kernel ms, stats[1] =

@@ -300,22 +300,20 @@ typedef struct {
     int n;
 } top5;
 
-/* strict total order on candidates: (d2, x, y, z) */
-static inline int cand_less(float d2a, float xa, float ya, float za, float d2b, float xb, float yb,
-                            float zb)
+/* strict total order on candidates: (d2, original index).  The reference orders by d2 and breaks
+ * d2 ties by x (ikd_Tree.h:102-108); which of two candidates tied at the 5th place survives there
+ * depends on its traversal order.  Index order is an equally valid, layout-independent choice that
+ * the GPU path reproduces with a single 64-bit compare. */
+static inline int cand_less(float d2a, int32_t ia, float d2b, int32_t ib)
 {
     if (d2a != d2b) return d2a < d2b;
-    if (xa != xb) return xa < xb;
-    if (ya != yb) return ya < yb;
-    return za < zb;
+    return ia < ib;
 }
 static inline void top5_offer(top5 *h, float d2, float x, float y, float z, int32_t idx)
 {
-    if (h->n == ORC_K &&
-        !cand_less(d2, x, y, z, h->d2[ORC_K - 1], h->x[ORC_K - 1], h->y[ORC_K - 1], h->z[ORC_K - 1]))
-        return;
+    if (h->n == ORC_K && !cand_less(d2, idx, h->d2[ORC_K - 1], h->idx[ORC_K - 1])) return;
     int p = (h->n < ORC_K) ? h->n : ORC_K - 1;
-    while (p > 0 && cand_less(d2, x, y, z, h->d2[p - 1], h->x[p - 1], h->y[p - 1], h->z[p - 1])) {
+    while (p > 0 && cand_less(d2, idx, h->d2[p - 1], h->idx[p - 1])) {
         h->d2[p] = h->d2[p - 1]; h->x[p] = h->x[p - 1]; h->y[p] = h->y[p - 1]; h->z[p] = h->z[p - 1];
         h->idx[p] = h->idx[p - 1];
         --p;
@@ -346,7 +344,7 @@ static inline float box_dist2f(const float *b, float qx, float qy, float qz)
 /* ikd_Tree.cpp:1061-1244 without the delete/rebuild machinery: visit the node's own point,
  * then the nearer child first and the farther child only if its box can still hold a better
  * candidate.  "<=" instead of the reference's "<" keeps equal-d2 candidates reachable so the
- * (d2,x,y,z) order is exact. */
+ * (d2, index) order is exact. */
 static void kd_search(const orc_kdtree *t, int64_t l, int64_t r, float qx, float qy, float qz, top5 *h)
 {
     if (l > r) return;

@@ -66,8 +66,9 @@ void orc_state_boxminus(const orc_state *a, const orc_state *b, double out[ORC_D
  * Replaces KD_TREE::Build / Nearest_Search (eskf_lio/include/ikd-Tree/ikd_Tree.cpp:408-461,
  * 678-733, 1061-1244).  Same tree shape rule (median on the longest-extent axis, one point per
  * node, per-node AABB pruning in float) and the same float squared-L2 (ikd_Tree.cpp:1682-1688).
- * Result order: ascending (d2, x, y, z) -- the reference orders by d2 and breaks d2 ties by x
- * (ikd_Tree.h:102-108); y,z are added here to make the order total. */
+ * Result order: ascending (d2, original index) -- the reference orders by d2 and breaks d2 ties
+ * by x (ikd_Tree.h:102-108) with a traversal-dependent choice at the 5th place; the index makes
+ * the order total and independent of the search structure. */
 typedef struct orc_kdtree orc_kdtree;
 orc_kdtree *orc_kdtree_build(const float *xyz, int64_t m);   /* xyz: m x 3 floats, AoS */
 void        orc_kdtree_free(orc_kdtree *t);

@@ -7,13 +7,13 @@ from daliti_amd import Engine, synth
 c = synth.CONFIGS["C3"]
 m = synth.make_map(c["M"], c["L"]); s = synth.make_scan(c["beams"], c["az"], c["L"])
 _, xp, P = synth.filter_inputs()
-for g in [int(x) for x in os.environ.get("GROUPS", "16").split(",")]:
+for g in [int(x) for x in os.environ.get("GROUPS", "4").split(",")]:
     for cell in [float(x) for x in os.environ.get("CELLS", "0.25,0.5").split(",")]:
         os.environ["S2M_MATCH_GROUP"] = str(g)
         e = Engine(cell_size=cell)
         e.map_build(m); e.scan_set(s)
         for _ in range(3): e.residual_pass(xp, True)
-        e.set_timing(True)
+        e.set_timing(2)
         e.residual_pass(xp, True)
         ms = e.timing()[0]
         d = np.zeros((e.n, 4), np.uint32)
@@ -21,6 +21,7 @@ for g in [int(x) for x in os.environ.get("GROUPS", "16").split(",")]:
         cyc = d[:, 0].astype(float)
         print("G %d cell %.2f match %.1f us | cycles(100MHz ticks?) pct50 %.0f pct90 %.0f pct99 %.0f max %.0f sum %.3g" % (
             g, cell, ms * 1e3, *np.percentile(cyc, [50, 90, 99, 100]), cyc.sum()))
+        print("   hard fraction %.3f" % (d[:, 3] > 1).mean())
         for r in range(1, 12):
             sel = d[:, 1] == r
             if sel.any():

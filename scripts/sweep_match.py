@@ -9,7 +9,7 @@ c = synth.CONFIGS[cfg]
 m = synth.make_map(c["M"], c["L"])
 s = synth.make_scan(c["beams"], c["az"], c["L"])
 _, xp, P = synth.filter_inputs()
-groups = [int(g) for g in os.environ.get("GROUPS", "8,16,32").split(",")]
+groups = [int(g) for g in os.environ.get("GROUPS", "1,2,4,8").split(",")]
 cells = [float(g) for g in os.environ.get("CELLS", "0.2,0.25,0.3,0.35,0.5").split(",")]
 for g in groups:
     for cell in cells:
@@ -20,7 +20,7 @@ for g in groups:
         info = e.map_info()
         for _ in range(3):
             e.residual_pass(xp, True)
-        e.set_timing(True)
+        e.set_timing(2)
         for _ in range(20):
             e.residual_pass(xp, True)
         st = e.timing_stats()
