@@ -36,6 +36,10 @@ namespace s2m {
 
 typedef unsigned long long u64;
 constexpr u64 kEmptyKey = ~0ull;
+#ifndef S2M_EASY_BATCH
+#define S2M_EASY_BATCH 8
+#endif
+constexpr int kEasyBatch = S2M_EASY_BATCH;  // point loads in flight per lane in the first-shell kernel
 
 __device__ __forceinline__ u64 make_key(float d2, uint32_t orig)
 {
@@ -57,16 +61,17 @@ __device__ __forceinline__ void insert5(u64 (&t)[kK], u64 k)
     }
 }
 
-// points pts[s, e) -> top-5, four independent 16-byte loads per batch
+// points pts[s, e) -> top-5, B independent 16-byte loads per batch
+template <int B>
 __device__ __forceinline__ void scan_points(const float4 *__restrict__ pts, uint32_t s, uint32_t e, float wx,
                                             float wy, float wz, u64 (&t)[kK])
 {
-    for (uint32_t i = s; i < e; i += 4) {
-        float4 p[4];
+    for (uint32_t i = s; i < e; i += B) {
+        float4 p[B];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = pts[min(i + u, e - 1)];
+        for (int u = 0; u < B; ++u) p[u] = pts[min(i + u, e - 1)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < B; ++u) {
             const float dx = wx - p[u].x, dy = wy - p[u].y, dz = wz - p[u].z;
             float d = dx * dx + dy * dy;
             d = d + dz * dz;
@@ -90,7 +95,7 @@ __device__ __forceinline__ void scan_row(const Grid &g, int yy, int zz, int xa, 
         if (te.x == 0 || ((mword >> (rowbit & 31)) & 1u) == 0) continue;
         const int l0 = max(xa, bx << 3) & 7, l1 = min(xb, (bx << 3) + 7) & 7;
         const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + (rowbit << 3);
-        scan_points(g.pts, tb[l0], tb[l1 + 1], wx, wy, wz, t);
+        scan_points<4>(g.pts, tb[l0], tb[l1 + 1], wx, wy, wz, t);
     }
 }
 
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
 #pragma unroll
     for (int i = 0; i < R; ++i) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) scan_points(g.pts, s[i][p], e[i][p], q.wx, q.wy, q.wz, t);
+        for (int p = 0; p < 2; ++p) scan_points<kEasyBatch>(g.pts, s[i][p], e[i][p], q.wx, q.wy, q.wz, t);
     }
     merge_lists<G>(t, best);
     const bool found5 = best[kK - 1] != kEmptyKey;
@@ -278,21 +283,21 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
         int r = 2;
         uint32_t rounds = 0;
         for (;;) {
-            // scan the shell (rdone, r]: new rows completely, old rows only their two new ends
+            // scan the shell (rdone, r]: one cell per lane, so every lane's top entry, table pair and
+            // point loads are in flight together; cells of the already scanned inner cube are skipped
             const int side = 2 * r + 1;
-            const int nrows = side * side;
-            const int xlo = max(q.cx - r, 0), xhi = min(q.cx + r, g.ncx - 1);
-            for (int row = lane; row < nrows; row += G) {
-                const int dy = (row % side) - r, dz = (row / side) - r;
-                const int yy = q.cy + dy, zz = q.cz + dz;
-                if (yy < 0 || yy >= g.ncy || zz < 0 || zz >= g.ncz) continue;
-                if (max(abs(dy), abs(dz)) > rdone) {
-                    if (xlo <= xhi) scan_row(g, yy, zz, xlo, xhi, q.wx, q.wy, q.wz, t);
-                } else {
-                    const int a1 = min(q.cx - rdone - 1, g.ncx - 1), c0 = max(q.cx + rdone + 1, 0);
-                    if (xlo <= a1) scan_row(g, yy, zz, xlo, a1, q.wx, q.wy, q.wz, t);
-                    if (c0 <= xhi) scan_row(g, yy, zz, c0, xhi, q.wx, q.wy, q.wz, t);
-                }
+            const int ncell = side * side * side;
+            for (int ci = lane; ci < ncell; ci += G) {
+                const int dx = (ci % side) - r, dy = ((ci / side) % side) - r, dz = (ci / (side * side)) - r;
+                if (max(max(abs(dx), abs(dy)), abs(dz)) <= rdone) continue;
+                const int xx = q.cx + dx, yy = q.cy + dy, zz = q.cz + dz;
+                if (xx < 0 || xx >= g.ncx || yy < 0 || yy >= g.ncy || zz < 0 || zz >= g.ncz) continue;
+                const int rowbit = ((zz & 7) << 3) | (yy & 7);
+                const uint4 te = g.top[((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx + (xx >> 3)];
+                const uint32_t mword = (rowbit & 32) ? te.w : te.z;
+                if (te.x == 0 || ((mword >> (rowbit & 31)) & 1u) == 0) continue;
+                const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + (rowbit << 3) + (xx & 7);
+                scan_points<4>(g.pts, tb[0], tb[1], q.wx, q.wy, q.wz, t);
             }
             rdone = r;
             ++rounds;

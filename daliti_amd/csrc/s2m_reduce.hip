@@ -11,8 +11,9 @@
 // s-gate, sticky selection), :887-896 (effective set, total_residual), :948-979 (Jacobian row,
 // meas_vec) and the m x 12 GEMMs of :1015 / :1019-1032, of which only Hsub^T*Hsub (12x12) and
 // Hsub^T*meas_vec (12) are needed:  K*z = K_1[:, :12]*(H^T z),  K*H = K_1[:, :12]*(H^T H).
-// No per-point H is written; the reduction is wave shuffles -> LDS -> one fp64 partial row per
-// workgroup -> a fixed-order final sum, so the block is deterministic for a given launch shape.
+// No per-point H is written; the reduction is a halving shuffle butterfly per wave -> LDS -> one
+// fp64 partial row per workgroup (write-through) -> a fixed-order final sum by the last workgroup
+// to arrive, so the block is deterministic for a given launch shape and needs no second launch.
 //
 // One lane per scan point, SoA loads (x[], y[], z[], float4 plane) are fully coalesced.
 // Compiled with -ffp-contract=off; the row arithmetic follows oracle/s2m_oracle.c:jac_row.
@@ -25,16 +26,54 @@
 
 namespace s2m {
 
-// term layout of a partial row: [0,78) upper triangle of the 12x12 (row-major, a <= b),
-// [78,90) H^T z, 90 total_residual, 91 effective count
-__host__ __device__ constexpr int tri_index(int a, int b) { return a * 12 - (a * (a - 1)) / 2 + (b - a); }
-constexpr int kTermHtz = 78, kTermRes = 90, kTermCnt = 91;
+// Term layout of a partial row for NC Jacobian columns (NC = 6 without extrinsic estimation, 12
+// with): [0, NC(NC+1)/2) upper triangle of H^T H (row-major, r <= c), then NC terms of H^T z, then
+// total_residual and the effective count; padded to a multiple of 32 (32 or 96 slots).
+template <int NC>
+struct Terms {
+    static constexpr int kTri = NC * (NC + 1) / 2;
+    static constexpr int kHtz = kTri;
+    static constexpr int kRes = kTri + NC;
+    static constexpr int kCnt = kTri + NC + 1;
+    static constexpr int kUsed = kTri + NC + 2;             // 29 or 92
+    static constexpr int kSlots = ((kUsed + 31) / 32) * 32;  // 32 or 96
+    __host__ __device__ static constexpr int tri(int r, int c) { return r * NC - (r * (r - 1)) / 2 + (c - r); }
+};
 
-__device__ __forceinline__ double wave_sum(double v)
+// Sum of 32 values per lane across the 64 lanes of a wave with a halving butterfly: at each of
+// the five halving steps a lane keeps one half of its values and hands the other half to its
+// partner, so 32 + 1 shuffles replace 32 x 6.  On return v[0] of lane l is the wave-wide sum of
+// value (l >> 1) & 31 (both lanes of a pair hold it).  Fixed order, hence deterministic.
+template <int HALF>
+__device__ __forceinline__ void halve_step(double (&v)[32], int lane)
 {
+    constexpr int m = HALF * 2;
+    const bool hi = (lane & m) != 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    for (int i = 0; i < HALF; ++i) {
+        const double send = hi ? v[i] : v[i + HALF];
+        const double keep = hi ? v[i + HALF] : v[i];
+        v[i] = keep + __shfl_xor(send, m, 64);
+    }
+}
+__device__ __forceinline__ void wave_sum32(double (&v)[32], int lane)
+{
+    halve_step<16>(v, lane);
+    halve_step<8>(v, lane);
+    halve_step<4>(v, lane);
+    halve_step<2>(v, lane);
+    halve_step<1>(v, lane);
+    v[0] += __shfl_xor(v[0], 1, 64);
+}
+
+// compile-time (row, column) of upper-triangle slot t
+template <int NC>
+__host__ __device__ constexpr int tri_row(int t)
+{
+    int r = 0;
+    for (int rr = 0; rr < NC; ++rr)
+        if (t >= Terms<NC>::tri(rr, rr)) r = rr;
+    return r;
 }
 
 // one Jacobian row (laserMapping.cpp:948-978): h = [A, n, B, C] or [A, n, 0, 0], z = -pd2
@@ -77,23 +116,12 @@ __device__ __forceinline__ void jac_row(const Pose &P, float bx, float by, float
     z = -(double)pd2;
 }
 
-// is partial-row slot t written by a kernel that reduces NC Jacobian columns?
-template <int NC>
-__device__ __forceinline__ bool term_used(int t)
-{
-    if (t >= kTermHtz) return t < kTermHtz + NC || t == kTermRes || t == kTermCnt;
-    bool used = false;
-#pragma unroll
-    for (int r = 0; r < NC; ++r)
-        if (t >= tri_index(r, r) && t <= tri_index(r, NC - 1)) used = true;
-    return used;
-}
-
 template <bool EXT, bool FIT>
 __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
 {
     constexpr int NC = EXT ? 12 : 6;
-    __shared__ double red[kRedBlock / 64][kRedTerms];
+    using T = Terms<NC>;
+    __shared__ double red[kRedBlock / 64][T::kSlots];
     const int i = blockIdx.x * kRedBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -153,33 +181,42 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
         }
         a.eff[i] = eff ? 1 : 0;
     }
-    // ineffective lanes carry h = 0, z = 0 and contribute exact zeros
+    // ineffective lanes carry h = 0, z = 0 and contribute exact zeros.  Terms are reduced 32 at a
+    // time; term index within a chunk = compile-time slot, so everything stays in registers.
+    double hz[12];
 #pragma unroll
-    for (int r = 0; r < NC; ++r) {
+    for (int r = 0; r < 12; ++r) hz[r] = h[r] * z;
 #pragma unroll
-        for (int c = r; c < NC; ++c) {
-            const double s = wave_sum(h[r] * h[c]);
-            if (lane == 0) red[wave][tri_index(r, c)] = s;
+    for (int chunk = 0; chunk < T::kSlots / 32; ++chunk) {
+        double v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int t = chunk * 32 + k;  // compile-time after unrolling
+            double val = 0.0;
+            if (t < T::kTri) {
+                const int r = tri_row<NC>(t), c = r + (t - T::tri(r, r));
+                val = h[r] * h[c];
+            } else if (t < T::kTri + NC) {
+                val = hz[t - T::kTri];
+            } else if (t == T::kRes) {
+                val = absr;
+            } else if (t == T::kCnt) {
+                val = eff ? 1.0 : 0.0;
+            }
+            v[k] = val;
         }
-        const double s = wave_sum(h[r] * z);
-        if (lane == 0) red[wave][kTermHtz + r] = s;
-    }
-    {
-        const double s = wave_sum(absr);
-        const double c = wave_sum(eff ? 1.0 : 0.0);
-        if (lane == 0) { red[wave][kTermRes] = s; red[wave][kTermCnt] = c; }
+        wave_sum32(v, lane);
+        if ((lane & 1) == 0) red[wave][chunk * 32 + ((lane >> 1) & 31)] = v[0];
     }
     __syncthreads();
     // one fp64 row per workgroup, published write-through (agent-scope 8-byte stores) so the last
     // workgroup to arrive can read every row without a release/acquire fence pair
-    if (threadIdx.x < kRedTerms) {
+    if (threadIdx.x < T::kSlots) {
         const int t = threadIdx.x;
         double s = 0.0;
-        if (term_used<NC>(t)) {
 #pragma unroll
-            for (int w = 0; w < kRedBlock / 64; ++w) s += red[w][t];
-        }
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.partials) + (int64_t)blockIdx.x * kRedTerms + t,
+        for (int w = 0; w < kRedBlock / 64; ++w) s += red[w][t];
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.partials) + (int64_t)blockIdx.x * T::kSlots + t,
                            (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
@@ -193,31 +230,33 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
     if (!s_last) return;
 
     // ---- last workgroup: fixed-order sum of the rows (independent of arrival order) -----------------
-    constexpr int kChunks = kRedBlock / kRedTerms;  // 5 lanes per term
-    __shared__ double part[kChunks][kRedTerms];
-    __shared__ double tot[kRedTerms];
+    constexpr int kChunks = kRedBlock / T::kSlots;  // lanes per term: 16 (NC = 6) or 5 (NC = 12)
+    constexpr int kDepth = 8;                       // independent loads in flight per lane
+    __shared__ double part[kChunks][T::kSlots];
+    __shared__ double tot[T::kSlots];
     const int blocks = gridDim.x;
-    if (threadIdx.x < kChunks * kRedTerms) {
-        const int t = threadIdx.x % kRedTerms, ch = threadIdx.x / kRedTerms;
-        const unsigned long long *pp = reinterpret_cast<const unsigned long long *>(a.partials);
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int b = ch;
-        for (; b + 3 * kChunks < blocks; b += 4 * kChunks) {  // four independent loads in flight
-            const unsigned long long v0 = __hip_atomic_load(pp + (int64_t)b * kRedTerms + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long v1 = __hip_atomic_load(pp + (int64_t)(b + kChunks) * kRedTerms + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long v2 = __hip_atomic_load(pp + (int64_t)(b + 2 * kChunks) * kRedTerms + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long v3 = __hip_atomic_load(pp + (int64_t)(b + 3 * kChunks) * kRedTerms + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s0 += __longlong_as_double((long long)v0);
-            s1 += __longlong_as_double((long long)v1);
-            s2 += __longlong_as_double((long long)v2);
-            s3 += __longlong_as_double((long long)v3);
+    if (threadIdx.x < kChunks * T::kSlots) {
+        const int t = threadIdx.x % T::kSlots, ch = threadIdx.x / T::kSlots;
+        const unsigned long long *pp = reinterpret_cast<const unsigned long long *>(a.partials) + t;
+        double acc[kDepth];
+#pragma unroll
+        for (int k = 0; k < kDepth; ++k) acc[k] = 0.0;
+        for (int b0 = ch; b0 < blocks; b0 += kChunks * kDepth) {
+            unsigned long long raw[kDepth];
+#pragma unroll
+            for (int k = 0; k < kDepth; ++k) {
+                const int b = b0 + k * kChunks;
+                raw[k] = (b < blocks) ? __hip_atomic_load(pp + (int64_t)b * T::kSlots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0ull;  // +0.0
+            }
+#pragma unroll
+            for (int k = 0; k < kDepth; ++k) acc[k] += __longlong_as_double((long long)raw[k]);
         }
-        for (; b < blocks; b += kChunks)
-            s0 += __longlong_as_double((long long)__hip_atomic_load(pp + (int64_t)b * kRedTerms + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        part[ch][t] = (s0 + s1) + (s2 + s3);
+        double s01 = acc[0] + acc[1], s23 = acc[2] + acc[3], s45 = acc[4] + acc[5], s67 = acc[6] + acc[7];
+        part[ch][t] = (s01 + s23) + (s45 + s67);
     }
     __syncthreads();
-    if (threadIdx.x < kRedTerms) {
+    if (threadIdx.x < T::kSlots) {
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < kChunks; ++c) s += part[c][threadIdx.x];
@@ -229,13 +268,14 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
         double v = 0.0;
         if (o < 144) {
             const int r = o / 12, c = o % 12;
-            v = tot[r <= c ? tri_index(r, c) : tri_index(c, r)];
+            const int lo = r <= c ? r : c, hi_ = r <= c ? c : r;
+            if (hi_ < NC) v = tot[T::tri(lo, hi_)];
         } else if (o < 156) {
-            v = tot[kTermHtz + (o - 144)];
+            if (o - 144 < NC) v = tot[T::kHtz + (o - 144)];
         } else if (o == 156) {
-            v = tot[kTermCnt];
+            v = tot[T::kCnt];
         } else if (o == 157) {
-            v = tot[kTermRes];
+            v = tot[T::kRes];
         }
         a.block[o] = v;
         if (a.host_block) a.host_block[o] = v;
