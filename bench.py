@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--cell", type=float, default=0.0)
     ap.add_argument("--cpu-steps", type=int, default=8, help="CPU baseline sample: iterated updates (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the sharded/all-reduce code path even with one rank (test hook)")
     return ap.parse_args()
 
 
@@ -59,12 +61,15 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or a.force_collective:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
     cfgd = synth.CONFIGS[a.config]
-    sharded = world > 1 and a.mode == "sharded"
+    sharded = (world > 1 or a.force_collective) and a.mode == "sharded"
     # workload: map replicated; scan = world x (beams x az) points when sharded
     t0 = time.time()
     map_xyz = synth.make_map(cfgd["M"], cfgd["L"], seed=1)
@@ -106,12 +111,20 @@ def main():
             eng.set_feat_queue([])
             return eng.iterated_update_sharded(x_prop, x_prop, P0, blk.data_ptr(), reduce_cb)
     else:
+        from daliti_amd.engine import IterLog
+        xb, xpb, Pb, logb = np.zeros(36), np.ascontiguousarray(x_prop, np.float64), np.zeros((24, 24)), IterLog()
+
         def step():
-            eng.set_feat_queue([])
-            return eng.iterated_update(x_prop, x_prop, P0)
+            # lean call: preallocated buffers, no per-step conversions (the degeneracy queue is cleared so
+            # every step is the same scan arriving fresh)
+            eng.set_feat_queue(())
+            xb[:] = xpb
+            Pb[:] = P0
+            eng.iterated_update_raw(xb, xpb, Pb, logb)
+            return logb
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -123,10 +136,16 @@ def main():
     passes = iters = rematch = 0
     for _ in range(a.steps):
         res = step()
-        iters += res["iters"]
-        rematch += res["rematch_passes"]
+        if sharded:
+            iters += res["iters"]
+            rematch += res["rematch_passes"]
+        else:
+            iters += res.iters
+            rematch += res.rematch_passes
     fence()
     dt = time.perf_counter() - t0
+    if not sharded:  # final state / log of the last step for the report
+        res = dict(x=xb.copy(), P=Pb.copy(), iters=res.iters, effct=np.array(res.effct[:res.iters]))
     tstats = eng.timing_stats()
     eng.set_timing(False)
     passes = iters  # one residual pass per iteration
@@ -185,12 +204,16 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu and a.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(a, map_xyz, scan, x_prop, P0, res)
         out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
+    if dist.is_initialized():
+        dist.destroy_process_group()
     if rank == 0:
         sys.stderr.write("[bench] gen %.1fs, map build %.3fs, cell %.3f m (%.2f pts/cell), %d bricks\n" % (
             t_gen, t_build, info["cell"], info["mean_per_cell"], info["bricks"]))
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        # RCCL prints a version banner through C stdio; flush it first so the JSON is the last line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(a, map_xyz, scan, x_prop, P0, gpu_res):

@@ -138,7 +138,8 @@ __device__ __forceinline__ void merge_lists(const u64 (&priv)[kK], u64 (&best)[k
 struct Query {
     float wx, wy, wz;
     int cx, cy, cz;
-    float fmin;  // distance from the query to the nearest face of its home cell, in cells
+    float frx, fry, frz;  // position inside the home cell, in cells, [0, 1)
+    float fmin;           // distance from the query to the nearest face of its home cell, in cells
 };
 
 __device__ __forceinline__ Query make_query(const Grid &g, const Pose &pose, float bx, float by, float bz)
@@ -153,8 +154,9 @@ __device__ __forceinline__ Query make_query(const Grid &g, const Pose &pose, flo
     q.cx = (int)fminf(fmaxf(flx, -lim), lim);
     q.cy = (int)fminf(fmaxf(fly, -lim), lim);
     q.cz = (int)fminf(fmaxf(flz, -lim), lim);
-    float f = fminf(fminf(fx - flx, 1.0f - (fx - flx)), fminf(fy - fly, 1.0f - (fy - fly)));
-    q.fmin = fminf(f, fminf(fz - flz, 1.0f - (fz - flz)));
+    q.frx = fx - flx; q.fry = fy - fly; q.frz = fz - flz;
+    float f = fminf(fminf(q.frx, 1.0f - q.frx), fminf(q.fry, 1.0f - q.fry));
+    q.fmin = fminf(f, fminf(q.frz, 1.0f - q.frz));
     return q;
 }
 
@@ -165,6 +167,17 @@ __device__ __forceinline__ float cube_bound2(const Grid &g, const Query &q, int 
     float lb = ((float)r + q.fmin - g.slop) * g.c;
     lb = fmaxf(lb, 0.0f) * 0.999999f;
     return lb * lb;
+}
+
+// lower bound (squared) of the distance from the query to any point of the cell at offset
+// (dx, dy, dz) cells from the home cell; slop as in cube_bound2
+__device__ __forceinline__ float cell_bound2(const Grid &g, const Query &q, int dx, int dy, int dz)
+{
+    const float gx = dx > 0 ? (float)dx - q.frx : (dx < 0 ? q.frx - (float)(dx + 1) : 0.0f);
+    const float gy = dy > 0 ? (float)dy - q.fry : (dy < 0 ? q.fry - (float)(dy + 1) : 0.0f);
+    const float gz = dz > 0 ? (float)dz - q.frz : (dz < 0 ? q.frz - (float)(dz + 1) : 0.0f);
+    const float ax = fmaxf(gx - g.slop, 0.0f), ay = fmaxf(gy - g.slop, 0.0f), az = fmaxf(gz - g.slop, 0.0f);
+    return ((ax * ax + ay * ay) + az * az) * (g.c * g.c) * 0.99999f;
 }
 
 __device__ __forceinline__ void store_result(const u64 (&best)[kK], int64_t q, int32_t *__restrict__ nn_idx,
@@ -245,9 +258,9 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
     const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
     const bool done = found5 && d5 <= cube_bound2(g, q, 1);
     if (j == 0) {
-        if (done) {
-            store_result(best, qi, a.nn_idx, a.nn_d2);
-        } else {
+        // unresolved points keep their first-shell list too: match_hard continues from it
+        store_result(best, qi, a.nn_idx, a.nn_d2);
+        if (!done) {
             const uint32_t pos = atomicAdd(a.hard_count, 1u);
             a.hard_list[pos] = (uint32_t)qi;
         }
@@ -276,15 +289,30 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
         const Query q = make_query(g, a.pose, a.sx[qi], a.sy[qi], a.sz[qi]);
         // smallest radius whose bound passes the d2 gate: beyond it the 5th neighbour cannot matter
         const int rgate = (int)ceilf(sqrtf(a.gates.knn_d2_gate) * g.inv_c * 1.000002f - q.fmin + g.slop) + 1;
+        // continue from the first shell: lane 0 carries its five keys, the cube of radius 1 is done
         u64 t[kK], best[kK];
 #pragma unroll
-        for (int k = 0; k < kK; ++k) t[k] = kEmptyKey;
-        int rdone = -1;  // the cube of this radius is fully scanned (-1: nothing yet)
-        int r = 2;
+        for (int k = 0; k < kK; ++k) {
+            const int32_t ci = a.nn_idx[(int64_t)qi * kK + k];
+            const float cd = a.nn_d2[(int64_t)qi * kK + k];
+            t[k] = (lane == 0 && ci >= 0) ? make_key(cd, (uint32_t)ci) : kEmptyKey;
+            best[k] = (ci >= 0) ? make_key(cd, (uint32_t)ci) : kEmptyKey;
+        }
+        int rdone = 1;
+        int r;
+        {
+            const bool f5 = best[kK - 1] != kEmptyKey;
+            const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
+            const int rn = f5 ? (int)ceilf(sqrtf(d5) * g.inv_c * 1.000002f - q.fmin + g.slop) : 2;
+            r = min(min(max(rn, 2), max(rgate, 2)), max(rcap, 2));
+        }
         uint32_t rounds = 0;
         for (;;) {
             // scan the shell (rdone, r]: one cell per lane, so every lane's top entry, table pair and
-            // point loads are in flight together; cells of the already scanned inner cube are skipped
+            // point loads are in flight together; cells of the already scanned inner cube and cells
+            // that cannot hold anything closer than the current 5th-best are skipped
+            const float tau = __uint_as_float((uint32_t)(best[kK - 1] >> 32));  // +inf/NaN pattern when < 5 found
+            const bool have_tau = best[kK - 1] != kEmptyKey;
             const int side = 2 * r + 1;
             const int ncell = side * side * side;
             for (int ci = lane; ci < ncell; ci += G) {
@@ -292,6 +320,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
                 if (max(max(abs(dx), abs(dy)), abs(dz)) <= rdone) continue;
                 const int xx = q.cx + dx, yy = q.cy + dy, zz = q.cz + dz;
                 if (xx < 0 || xx >= g.ncx || yy < 0 || yy >= g.ncy || zz < 0 || zz >= g.ncz) continue;
+                if (have_tau && cell_bound2(g, q, dx, dy, dz) > tau) continue;
                 const int rowbit = ((zz & 7) << 3) | (yy & 7);
                 const uint4 te = g.top[((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx + (xx >> 3)];
                 const uint32_t mword = (rowbit & 32) ? te.w : te.z;

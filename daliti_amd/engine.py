@@ -255,6 +255,12 @@ class Engine:
                     conv=np.array(log.conv[:it]), total_res=np.array(log.total_residual[:it]),
                     solution=np.array([list(log.solution[i]) for i in range(it)]).reshape(it, DIM))
 
+    def iterated_update_raw(self, x, x_prop, P, log):
+        """Lean form for hot loops: x (36,), x_prop (36,), P (24,24) are float64 C-contiguous numpy
+        arrays updated in place, log an IterLog instance; no conversions."""
+        self._ck(self.lib.s2m_iterated_update(self.h, C.c_void_p(x.ctypes.data), C.c_void_p(x_prop.ctypes.data),
+                                              C.c_void_p(P.ctypes.data), C.byref(log)))
+
     def iterated_update_sharded(self, x, x_prop, P, d_block_ptr, reduce_cb):
         """reduce_cb() must sum the device block across ranks on this handle's stream."""
         x = np.array(x, np.float64)
@@ -286,6 +292,9 @@ class Engine:
         return list(q[:n.value])
 
     def set_feat_queue(self, q):
+        if len(q) == 0:
+            self._ck(self.lib.s2m_feat_queue_set(self.h, None, C.c_int32(0)))
+            return
         q = list(q)
         arr = (C.c_int32 * max(len(q), 1))(*q)
         self._ck(self.lib.s2m_feat_queue_set(self.h, arr, C.c_int32(len(q))))

@@ -112,3 +112,22 @@ def test_gpu_shards_sum_to_full_block():
         assert np.abs(Htz - ref["Htz"]).max() <= 1e-12 * max(np.abs(ref["Htz"]).max(), 1)
         assert abs(tot - ref["total_res"]) <= 1e-12 * ref["total_res"]
     full.close()
+
+
+@pytest.mark.gpu
+def test_bench_collective_path_single_rank():
+    """bench.py's N > 1 code path (torch NCCL all-reduce through the C callback) with one rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
+                          "--warmup", "1", "--no-cpu", "--force-collective"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["pose_error_vs_truth_m"] < 0.05
+    ref = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
+                          "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert ref.returncode == 0, ref.stderr[-2000:]
+    rline = json.loads(ref.stdout.strip().splitlines()[-1])
+    assert abs(rline["pose_error_vs_truth_m"] - line["pose_error_vs_truth_m"]) < 1e-12
