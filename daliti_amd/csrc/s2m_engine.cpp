@@ -29,6 +29,8 @@ struct s2m_engine {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timing = false, timing_all = false;  // timing: match kernels only; timing_all: + reduce kernel
+    int timing_stride = 1, timing_phase = 0;   // time every stride-th rematch pass (sampling keeps the probe cheap)
+    bool timed_this_pass = false;
     double last_ms[3] = {0, 0, 0};
     double tstats[4] = {0, 0, 0, 0};
     bool last_rematch = false;
@@ -165,7 +167,14 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     const int n = (int)e->n;
     float *sx = e->d_scan, *sy = e->d_scan + e->n_cap, *sz = e->d_scan + 2 * e->n_cap;
     e->last_rematch = rematch != 0;
-    const bool time_match = e->timing && rematch, time_all = e->timing && e->timing_all;
+    bool time_match = e->timing && rematch;
+    const bool time_all = e->timing && e->timing_all;
+    if (time_match && !time_all && e->timing_stride > 1) {
+        // sample: alternate between the first and later rematch passes so both kinds are covered
+        time_match = (e->timing_phase % e->timing_stride) == 0;
+        e->timing_phase++;
+    }
+    e->timed_this_pass = time_match || time_all;
     if (time_match || time_all) S2M_HIP(e, hipEventRecord(e->ev[0], e->stream));
     if (rematch) {
         MatchArgs m;
@@ -200,7 +209,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
 
 int finish_timing(s2m_engine *e)
 {
-    if (!e->timing) return S2M_OK;
+    if (!e->timing || !e->timed_this_pass) return S2M_OK;
     float a = 0.f, b = 0.f;
     if (e->last_rematch || e->timing_all) {
         S2M_HIP(e, hipEventSynchronize(e->ev[1]));
@@ -570,9 +579,9 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
     if (reduce && !d_block) return fail(e, S2M_ERR_ARG, "sharded update needs a device block");
     if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
     if (!d_block) d_block = e->d_block;
-    // a new scan starts with every point selected and no neighbours (laserMapping.cpp:810-818)
+    // a new scan starts with every point selected and no neighbours (laserMapping.cpp:810-818);
+    // iteration 0 is always a rematch pass, whose gate rewrites point_selected_surf for every point
     S2M_HIP(e, hipSetDevice(e->device));
-    S2M_HIP(e, hipMemsetAsync(e->d_sel, 1, (size_t)std::max<int64_t>(e->n, 1), e->stream));
     e->nn_valid = false;
     const int max_iter = e->cfg.max_iter;
     int rematch_num = 0, rematch_en = 0, it = 0, passes = 0;
@@ -690,7 +699,9 @@ int s2m_set_timing(s2m_engine *e, int enabled)
 {
     if (!e) return S2M_ERR_ARG;
     e->timing = enabled != 0;
-    e->timing_all = enabled > 1;
+    e->timing_all = enabled == 2;
+    e->timing_stride = enabled > 2 ? enabled : 1;  // n > 2: time every n-th rematch pass
+    e->timing_phase = 0;
     for (double &t : e->tstats) t = 0;
     return S2M_OK;
 }

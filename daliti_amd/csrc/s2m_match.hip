@@ -35,7 +35,11 @@
 namespace s2m {
 
 typedef unsigned long long u64;
-constexpr u64 kEmptyKey = ~0ull;
+#ifndef S2M_INSERT_F64
+#define S2M_INSERT_F64 1
+#endif
+// empty slot: +infinity as a double when the f64 exchange chain is used (orders after every key)
+constexpr u64 kEmptyKey = S2M_INSERT_F64 ? 0x7ff0000000000000ull : ~0ull;
 #ifndef S2M_EASY_BATCH
 #define S2M_EASY_BATCH 8
 #endif
@@ -46,9 +50,23 @@ __device__ __forceinline__ u64 make_key(float d2, uint32_t orig)
     return ((u64)__float_as_uint(d2) << 32) | (u64)orig;
 }
 
-// sorted ascending top-5 of unique keys
+// Sorted ascending top-5 of unique keys.  A key with a non-negative float in its high word is a
+// finite positive double whose IEEE order equals the unsigned order of the bits (float exponent
+// 0xFF maps to double exponent <= 0x7FC, still finite), so one compare-exchange is v_min_f64 +
+// v_max_f64: the insertion is ten branch-free instructions with no SGPR/exec traffic.  The empty
+// key ~0 is a NaN as a double, so it is tested on the integer pattern before the exchange chain.
 __device__ __forceinline__ void insert5(u64 (&t)[kK], u64 k)
 {
+#if S2M_INSERT_F64
+    double kd = __longlong_as_double((long long)k);
+#pragma unroll
+    for (int i = 0; i < kK; ++i) {
+        const double ti = __longlong_as_double((long long)t[i]);
+        const double lo = fmin(ti, kd), hi = fmax(ti, kd);
+        t[i] = (u64)__double_as_longlong(lo);
+        kd = hi;
+    }
+#else
     if (k < t[kK - 1]) {
         t[kK - 1] = k;
 #pragma unroll
@@ -59,6 +77,7 @@ __device__ __forceinline__ void insert5(u64 (&t)[kK], u64 k)
             t[i + 1] = sw ? a : b;
         }
     }
+#endif
 }
 
 // points pts[s, e) -> top-5, B independent 16-byte loads per batch

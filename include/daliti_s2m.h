@@ -189,7 +189,9 @@ int s2m_h_share_model(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int 
 /* Timing of the last pass in milliseconds measured with HIP events on the handle's stream:
  * ms[0] = match (kNN + plane fit) kernel, ms[1] = residual/Jacobian/normal-block kernel,
  * ms[2] = whole pass.  s2m_set_timing(e, 1) times the match kernels of rematch passes only (two
- * event records per rematch pass); s2m_set_timing(e, 2) also times the residual kernel. */
+ * event records per rematch pass); s2m_set_timing(e, 2) also times the residual kernel;
+ * s2m_set_timing(e, n > 2) times every n-th rematch pass only (sampling; use an odd n so first
+ * and later rematch passes of a scan are both sampled). */
 int s2m_set_timing(s2m_engine *e, int enabled);
 int s2m_get_timing(const s2m_engine *e, double ms[3]);
 /* Accumulated since the last s2m_set_timing call: stats[0] = sum of match-kernel ms, stats[1] =
