@@ -193,10 +193,11 @@ def main():
     if tstats["match_launches"] > 0:
         ms = tstats["match_ms"] / tstats["match_launches"]
         achieved = n_local * BYTES_REMATCH / (ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic() if (a.config == "C3" and world == 1) else (None, None)
         out["roofline"] = {
             "kernel": "match_kernel (exact 5-NN on the brick grid + plane fit)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_eval": BYTES_REMATCH, "evals_per_launch": n_local,
             "avg_launch_ms": ms, "launches": tstats["match_launches"],
             "note": "one launch = match_easy + match_hard of one rematch pass (HIP events around both, "
@@ -215,6 +216,25 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def pmc_traffic():
+    """HBM traffic of one rematch pass of the match kernels from the newest committed PMC summary
+    (profiles/*_pmc.json, made by scripts/profile_round.sh + summarize_profile.py: separate
+    rocprofv3 --pmc passes of this same command).  Read side doubled as MI355X_MICROARCH.md
+    prescribes for gfx950 (FETCH_SIZE tallies 128-B requests at 64 B), so this is an upper bound."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"]
+        tot = 0.0
+        for name in ("match_easy", "match_hard"):
+            tot += (2.0 * k[name]["FETCH_SIZE_avg"] + k[name]["WRITE_SIZE_avg"]) * 1024.0
+        return tot, os.path.relpath(files[-1], ROOT)
+    except (KeyError, ValueError):
+        return None, None
 
 
 def cpu_baseline(a, map_xyz, scan, x_prop, P0, gpu_res):

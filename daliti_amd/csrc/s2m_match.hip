@@ -292,14 +292,14 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
     }
 }
 
-// ---- the rest: one wave per hard scan point --------------------------------------------------------
+// ---- the rest: G lanes (a whole or a fraction of a wave) per hard scan point ------------------------
+template <int G>
 __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
 {
-    constexpr int G = 64;
     const Grid &g = a.grid;
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & (G - 1);                           // lane within the group
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / G;     // group index
+    const int nwaves = (gridDim.x * blockDim.x) / G;
     const uint32_t count = *a.hard_count;
     const int rcap = max(max(g.ncx, g.ncy), g.ncz);
     for (uint32_t h = wave; h < count; h += nwaves) {
@@ -383,16 +383,20 @@ static void launch_easy(const MatchArgs &a, hipStream_t st)
 void launch_match(const MatchArgs &a, int group, hipStream_t st)
 {
     if (a.n <= 0) return;
-    switch (group) {
+    switch (group & 0xff) {
         case 1: launch_easy<1>(a, st); break;
         case 2: launch_easy<2>(a, st); break;
         case 8: launch_easy<8>(a, st); break;
         default: launch_easy<4>(a, st); break;
     }
-    // fixed grid, waves stride over the hard list whose length is only known on the device
-    const int64_t waves = std::min<int64_t>(a.n, 8192);
-    const int blocks = (int)((waves * 64 + 255) / 256);
-    hipLaunchKernelGGL(match_hard, dim3(blocks), dim3(256), 0, st, a);
+    // fixed grid, groups stride over the hard list whose length is only known on the device
+    const int hg = (group >> 8) ? (group >> 8) : 64;  // hard-kernel group width rides in bits 8.. (tuning hook;
+                                                      // measured: 64 lanes per hard point is fastest, the far tail is latency-bound)
+    const int64_t groups = std::min<int64_t>(a.n, 8192 * (64 / hg));
+    const int blocks = (int)((groups * hg + 255) / 256);
+    if (hg == 16) hipLaunchKernelGGL(match_hard<16>, dim3(blocks), dim3(256), 0, st, a);
+    else if (hg == 64) hipLaunchKernelGGL(match_hard<64>, dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(match_hard<32>, dim3(blocks), dim3(256), 0, st, a);
 }
 
 }  // namespace s2m
