@@ -38,6 +38,8 @@ struct s2m_engine {
     std::string err;
 
     MapBuffers map;
+    UpdateBuffers upd;
+    float built_cell = 0.0f;  // cell size of the current grid (kept across incremental rebuilds)
     Grid grid{};
     MapStats stats;
     bool map_ready = false;
@@ -318,6 +320,7 @@ int s2m_destroy(s2m_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_map(e->map);
+    free_update(e->upd);
     void *ptrs[] = {e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
                     e->d_nn_d2, e->d_hard, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
@@ -370,6 +373,102 @@ int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride, int64_t m, in
     if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
     e->map_ready = true;
     e->nn_valid = false;
+    e->built_cell = e->grid.c;
+    return S2M_OK;
+}
+
+namespace {
+// rebuild the brick grid from upd.list after an update
+int commit_update(s2m_engine *e)
+{
+    int64_t m_new = 0;
+    hipError_t he = update_finish(e->upd, e->grid, &m_new, e->stream);
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "update_finish", he);
+    if (m_new >= ((int64_t)1 << 31)) return fail(e, S2M_ERR_CAPACITY, "map too large (>= 2^31 points)");
+    bool too_large = false;
+    e->map_ready = false;
+    const float cell = e->cfg.cell_size > 0.0f ? e->cfg.cell_size : e->built_cell;
+    he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, cell, e->map, e->grid, e->stats, too_large,
+                   e->stream);
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
+    if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
+    e->map_ready = true;
+    e->nn_valid = false;  // neighbour indices referred to the old point list
+    if (e->built_cell <= 0.0f) e->built_cell = e->grid.c;
+    return S2M_OK;
+}
+}  // namespace
+
+int s2m_map_add(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int downsample_on, float downsample_size,
+                int on_device, int64_t *n_added)
+{
+    if (!e || n < 0 || stride < 3 || (n > 0 && !xyz)) return fail(e, S2M_ERR_ARG, "s2m_map_add: bad argument");
+    if (downsample_on && !(downsample_size > 0.0f)) return fail(e, S2M_ERR_ARG, "s2m_map_add: downsample size must be > 0");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
+    S2M_HIP(e, hipSetDevice(e->device));
+    const float *dev = nullptr;
+    int rc = stage_cloud(e, xyz, stride, n, on_device, &dev);
+    if (rc) return rc;
+    float4 *np = nullptr;
+    S2M_HIP(e, xyz_to_float4(e->upd, dev, stride, n, &np, e->stream));
+    S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
+    int64_t added = 0;
+    S2M_HIP(e, update_add(e->upd, e->grid, np, n, downsample_on != 0, downsample_size, &added, e->stream));
+    if (n_added) *n_added = added;
+    return commit_update(e);
+}
+
+int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *n_deleted)
+{
+    if (!e || n < 0 || (n > 0 && !boxes) || n > 4096) return fail(e, S2M_ERR_ARG, "s2m_map_delete_boxes: bad argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
+    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
+    int64_t del = 0;
+    S2M_HIP(e, update_delete(e->upd, e->grid, boxes, (int)n, &del, e->stream));
+    if (n_deleted) *n_deleted = del;
+    if (del == 0) return S2M_OK;  // nothing changed: keep the grid and the neighbour indices
+    return commit_update(e);
+}
+
+int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], double filter_size_map,
+                        int64_t *n_to_add, int64_t *n_no_downsample)
+{
+    if (!e || !state || !(filter_size_map > 0.0)) return fail(e, S2M_ERR_ARG, "s2m_map_incremental: bad argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
+    if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
+    S2M_HIP(e, hipSetDevice(e->device));
+    const Pose pose = pose_of(state);
+    float4 *la = nullptr, *lb = nullptr;
+    int64_t na = 0, nb = 0;
+    S2M_HIP(e, incr_classify(e->upd, pose, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, (int)e->n,
+                             e->d_nn_idx, e->grid, e->nn_valid, filter_size_map, &la, &na, &lb, &nb, e->stream));
+    if (n_to_add) *n_to_add = na;
+    if (n_no_downsample) *n_no_downsample = nb;
+    S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
+    S2M_HIP(e, update_add(e->upd, e->grid, la, na, true, (float)filter_size_map, nullptr, e->stream));   // :627
+    S2M_HIP(e, update_add(e->upd, e->grid, lb, nb, false, 0.0f, nullptr, e->stream));                    // :628
+    return commit_update(e);
+}
+
+int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity, int64_t *m)
+{
+    if (!e || !m) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map");
+    *m = e->grid.m;
+    if (!xyz) return S2M_OK;
+    if (capacity < e->grid.m) return fail(e, S2M_ERR_CAPACITY, "point buffer too small");
+    if (e->grid.m == 0) return S2M_OK;
+    S2M_HIP(e, hipSetDevice(e->device));
+    const int64_t floats = e->grid.m * 3;
+    if (floats > e->stage_cap) {
+        int rc = grow(e, &e->d_stage, floats);
+        if (rc) return rc;
+        e->stage_cap = floats;
+    }
+    launch_float4_to_xyz(e->grid.porig, e->grid.m, e->d_stage, e->stream);
+    S2M_HIP(e, hipMemcpyAsync(xyz, e->d_stage, (size_t)floats * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
     return S2M_OK;
 }
 

@@ -36,6 +36,43 @@ hipError_t build_map(const float *xyz_dev, int64_t stride, int64_t m, float cell
                      MapStats &stats, bool &too_large, hipStream_t st);
 void free_map(MapBuffers &buf);
 
+// ---- s2m_mapupd.hip : incremental map maintenance (map_incremental / Add_Points / Delete_Point_Boxes) ----
+struct UpdateBuffers {
+    uint8_t *alive = nullptr;      // per old point, 0 = removed by this update
+    int64_t alive_cap = 0;
+    uint32_t *counters = nullptr;  // [1] voxels rewritten (tmp_counter), [2] points deleted by boxes
+    float4 *stage = nullptr;       // points to append, in order
+    int64_t stage_cap = 0, stage_n = 0;
+    // per-batch scratch
+    uint64_t *key = nullptr, *key2 = nullptr;
+    uint32_t *val = nullptr, *val2 = nullptr, *cnt = nullptr, *best_idx = nullptr, *add_flag = nullptr, *pos = nullptr;
+    float *dnew = nullptr, *best_d = nullptr;
+    int64_t batch_cap = 0;
+    // compaction of the old points
+    uint32_t *flag32 = nullptr, *pos_old = nullptr;
+    int64_t old_cap = 0;
+    float4 *list = nullptr;        // the new point list handed to build_map
+    int64_t list_cap = 0;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    float *boxes = nullptr;
+    int64_t boxes_cap = 0;
+    float4 *cvt = nullptr;         // conversion / classification scratch
+    int64_t cvt_cap = 0;
+};
+void free_update(UpdateBuffers &u);
+hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st);
+hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t n, bool downsample, float ds,
+                      int64_t *n_added, hipStream_t st);
+hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_host, int nb, int64_t *n_deleted,
+                         hipStream_t st);
+hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStream_t st);
+hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, const float *sy, const float *sz, int n,
+                         const int32_t *nn_idx, const Grid &g, bool have_nn, double fs, float4 **to_add, int64_t *n_add,
+                         float4 **no_down, int64_t *n_no_down, hipStream_t st);
+hipError_t xyz_to_float4(UpdateBuffers &u, const float *xyz_dev, int64_t stride, int64_t n, float4 **out, hipStream_t st);
+void launch_float4_to_xyz(const float4 *in, int64_t n, float *xyz, hipStream_t st);
+
 // ---- s2m_match.hip : exact 5-NN ------------------------------------------------------------------
 struct MatchArgs {
     Grid grid;

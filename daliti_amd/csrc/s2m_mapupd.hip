@@ -1,0 +1,500 @@
+// s2m_mapupd.hip -- incremental map maintenance on the GPU.
+//
+// Replaces what the node does to the ikd-Tree after every scan:
+//   map_incremental()                     eskf_lio/src/laserMapping.cpp:582-630
+//   KD_TREE::Add_Points(pts, downsample)  eskf_lio/include/ikd-Tree/ikd_Tree.cpp:477-573
+//   KD_TREE::Delete_Point_Boxes           ikd_Tree.cpp:631-658 (called by lasermap_fov_segment,
+//                                         laserMapping.cpp:313-369)
+// The reference inserts point by point: with downsampling on, the new point's voxel [min, max) of
+// edge downsample_size is searched, and the voxel is rewritten to hold only the point closest to its
+// centre when it held several points or when the new point wins (strict "<" against the new point,
+// so a tie goes to the new point).  Applied to a whole batch the end state of a voxel is therefore
+// {argmin of centre distance over old and new points; new beats old on ties; the last of tied new
+// points wins} -- with one exception that keeps an untouched voxel untouched: a single old point
+// that is strictly closer than every new point.  That closed form is what runs here, in parallel:
+//   probe    one lane per new point: count / best old point inside its voxel via the brick grid
+//   sort     radix sort of the new points by voxel key (stable: batch order inside a voxel)
+//   resolve  one lane per voxel: winner among the new points, verdict against the best old point
+//   kill     one lane per rewritten voxel: mark every old point of the voxel except the keeper
+//   compact  survivors in index order, then the winning new points in batch order
+// followed by a rebuild of the brick grid (s2m_map.hip; 7 ms for 5 M points).  Among several OLD
+// points tied for the smallest centre distance the lowest index wins (the reference takes the
+// first in its tree traversal, which has no GPU counterpart); such ties need two points at exactly
+// the same float distance inside one voxel.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "s2m_device.h"
+#include "s2m_kernels.h"
+
+namespace s2m {
+
+#define S2M_TRY(x)                       \
+    do {                                 \
+        hipError_t e_ = (x);             \
+        if (e_ != hipSuccess) return e_; \
+    } while (0)
+
+struct Voxel {
+    float mn[3], mx[3], mid[3];
+};
+
+// Box_of_Point / mid_point of Add_Points (ikd_Tree.cpp:491-499), float arithmetic as written there
+__device__ __forceinline__ Voxel voxel_of(float x, float y, float z, float ds)
+{
+    Voxel v;
+    const float p[3] = {x, y, z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        v.mn[k] = floorf(p[k] / ds) * ds;
+        v.mx[k] = v.mn[k] + ds;
+        v.mid[k] = (float)((double)v.mn[k] + (double)(v.mx[k] - v.mn[k]) / 2.0);
+    }
+    return v;
+}
+__device__ __forceinline__ bool in_box(const float4 &p, const float (&mn)[3], const float (&mx)[3])
+{
+    // Search_by_range / Delete_by_range membership: min <= p < max (ikd_Tree.cpp:1259, 794)
+    return mn[0] <= p.x && mx[0] > p.x && mn[1] <= p.y && mx[1] > p.y && mn[2] <= p.z && mx[2] > p.z;
+}
+__device__ __forceinline__ float dist2(float ax, float ay, float az, const float (&b)[3])
+{
+    float d = (ax - b[0]) * (ax - b[0]) + (ay - b[1]) * (ay - b[1]);
+    d = d + (az - b[2]) * (az - b[2]);
+    return d;
+}
+__device__ __forceinline__ uint64_t voxel_key(float x, float y, float z, float ds)
+{
+    // 21 bits per axis of floor(p / ds), biased; identical floor() to the one that makes the box
+    const int64_t kx = (int64_t)floorf(x / ds) + (1 << 20), ky = (int64_t)floorf(y / ds) + (1 << 20),
+                  kz = (int64_t)floorf(z / ds) + (1 << 20);
+    return ((uint64_t)(kx & 0x1fffff) << 42) | ((uint64_t)(ky & 0x1fffff) << 21) | (uint64_t)(kz & 0x1fffff);
+}
+
+// visit every old point inside box [mn, mx) through the brick grid
+template <class F>
+__device__ __forceinline__ void for_points_in_box(const Grid &g, const float (&mn)[3], const float (&mx)[3], F &&f)
+{
+    if (g.m == 0) return;
+    int c0[3], c1[3];
+    const float o[3] = {g.ox, g.oy, g.oz};
+    const int nc[3] = {g.ncx, g.ncy, g.ncz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        c0[k] = max((int)floorf((mn[k] - o[k]) * g.inv_c) - 1, 0);  // one cell of slack for float rounding
+        c1[k] = min((int)floorf((mx[k] - o[k]) * g.inv_c) + 1, nc[k] - 1);
+    }
+    for (int zz = c0[2]; zz <= c1[2]; ++zz)
+        for (int yy = c0[1]; yy <= c1[1]; ++yy)
+            for (int xx = c0[0]; xx <= c1[0]; ++xx) {
+                const uint4 te = g.top[((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx + (xx >> 3)];
+                if (te.x == 0) continue;
+                const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + ((((zz & 7) << 3) | (yy & 7)) << 3) + (xx & 7);
+                for (uint32_t i = tb[0]; i < tb[1]; ++i) {
+                    const float4 p = g.pts[i];
+                    if (in_box(p, mn, mx)) f(p, __float_as_uint(p.w));
+                }
+            }
+}
+
+__global__ __launch_bounds__(256) void add_probe_kernel(Grid g, const float4 *__restrict__ np, int n, float ds,
+                                                        uint64_t *__restrict__ key, uint32_t *__restrict__ val,
+                                                        float *__restrict__ dnew, uint32_t *__restrict__ cnt,
+                                                        uint32_t *__restrict__ best_idx, float *__restrict__ best_d)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = np[i];
+    const Voxel v = voxel_of(p.x, p.y, p.z, ds);
+    uint32_t c = 0, bi = 0xffffffffu;
+    float bd = INFINITY;
+    for_points_in_box(g, v.mn, v.mx, [&](const float4 &q, uint32_t idx) {
+        ++c;
+        const float d = dist2(q.x, q.y, q.z, v.mid);
+        if (d < bd || (d == bd && idx < bi)) { bd = d; bi = idx; }
+    });
+    key[i] = voxel_key(p.x, p.y, p.z, ds);
+    val[i] = (uint32_t)i;
+    dnew[i] = dist2(p.x, p.y, p.z, v.mid);
+    cnt[i] = c;
+    best_idx[i] = bi;
+    best_d[i] = bd;
+}
+
+// one lane per sorted position; the first position of a voxel segment decides for the voxel
+__global__ __launch_bounds__(256) void add_resolve_kernel(Grid g, const float4 *__restrict__ np, int n, float ds,
+                                                          const uint64_t *__restrict__ skey,
+                                                          const uint32_t *__restrict__ sval,
+                                                          const float *__restrict__ dnew,
+                                                          const uint32_t *__restrict__ cnt,
+                                                          const uint32_t *__restrict__ best_idx,
+                                                          const float *__restrict__ best_d,
+                                                          uint8_t *__restrict__ alive, uint32_t *__restrict__ add_flag,
+                                                          uint32_t *__restrict__ counters)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    if (s > 0 && skey[s - 1] == skey[s]) return;  // not a segment head
+    // winner among the new points of this voxel: smallest centre distance, the last one on ties
+    uint32_t w = sval[s];
+    float wd = dnew[w];
+    for (int t = s + 1; t < n && skey[t] == skey[s]; ++t) {
+        const uint32_t i = sval[t];
+        if (dnew[i] <= wd) { wd = dnew[i]; w = i; }
+    }
+    const uint32_t c = cnt[w], bi = best_idx[w];
+    const float bd = best_d[w];
+    const float4 pw = np[w];
+    bool add_new = false, rewrite = false;
+    uint32_t keep = 0xffffffffu;
+    if (c == 0) {
+        add_new = true;
+        rewrite = true;
+    } else if (!(bd < wd)) {  // the new point is not strictly farther: it wins (:506 is a strict "<")
+        add_new = true;
+        rewrite = true;
+    } else {
+        // an old point stays the closest.  The reference rewrites the voxel when it held several points
+        // or when the result "is" the new point within EPSS (ikd_Tree.cpp:514, 1676-1680)
+        const float4 pe = g.porig[bi];
+        const bool same = fabs((double)(pw.x - pe.x)) < 1e-6 && fabs((double)(pw.y - pe.y)) < 1e-6 &&
+                          fabs((double)(pw.z - pe.z)) < 1e-6;
+        keep = bi;
+        rewrite = (c > 1) || same;
+    }
+    if (add_new) add_flag[w] = 1u;
+    if (rewrite) {
+        atomicAdd(&counters[1], 1u);  // tmp_counter of Add_Points
+        if (c > (keep != 0xffffffffu ? 1u : 0u)) {
+            const Voxel v = voxel_of(pw.x, pw.y, pw.z, ds);
+            for_points_in_box(g, v.mn, v.mx, [&](const float4 &, uint32_t idx) {
+                if (idx != keep) alive[idx] = 0;
+            });
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restrict__ porig, int64_t m,
+                                                           const float *__restrict__ boxes, int nb,
+                                                           uint8_t *__restrict__ alive, uint32_t *__restrict__ counters)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m || !alive[i]) return;
+    const float4 p = porig[i];
+    for (int b = 0; b < nb; ++b) {
+        const float *bx = boxes + 6 * b;
+        const float mn[3] = {bx[0], bx[1], bx[2]}, mx[3] = {bx[3], bx[4], bx[5]};
+        if (in_box(p, mn, mx)) {
+            alive[i] = 0;
+            atomicAdd(&counters[2], 1u);
+            return;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void flags_to_u32_kernel(const uint8_t *__restrict__ a, int64_t m,
+                                                           uint32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i] = a[i] ? 1u : 0u;
+}
+
+// out[pos[i]] = src[i] for flagged i (pos = exclusive scan of the flags), shifted by base
+__global__ __launch_bounds__(256) void scatter_kernel(const float4 *__restrict__ src, const uint32_t *__restrict__ flag,
+                                                      const uint32_t *__restrict__ pos, int64_t m, int64_t base,
+                                                      float4 *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m && flag[i]) {
+        float4 p = src[i];
+        p.w = 0.0f;
+        out[base + pos[i]] = p;
+    }
+}
+
+// map_incremental() (laserMapping.cpp:582-630): class 1 = PointToAdd, 2 = PointNoNeedDownsample, 0 = skip
+__global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const float *__restrict__ sx,
+                                                            const float *__restrict__ sy,
+                                                            const float *__restrict__ sz, int n,
+                                                            const int32_t *__restrict__ nn_idx,
+                                                            const float4 *__restrict__ porig, int have_nn, double fs,
+                                                            float4 *__restrict__ pw_out,
+                                                            uint32_t *__restrict__ f_add, uint32_t *__restrict__ f_nodown)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float wx, wy, wz;
+    body_to_world(pose, sx[i], sy[i], sz[i], wx, wy, wz);  // pointBodyToWorld, :591
+    pw_out[i] = make_float4(wx, wy, wz, 0.0f);
+    int cls = 1;
+    int cnt = 0;
+    if (have_nn) {
+#pragma unroll
+        for (int k = 0; k < kK; ++k) cnt += nn_idx[(int64_t)i * kK + k] >= 0 ? 1 : 0;
+    }
+    if (cnt > 0) {  // !Nearest_Points[i].empty() && flg_EKF_inited (:593)
+        const float mid[3] = {(float)(floor((double)wx / fs) * fs + 0.5 * fs), (float)(floor((double)wy / fs) * fs + 0.5 * fs),
+                              (float)(floor((double)wz / fs) * fs + 0.5 * fs)};  // :599-601
+        const float dist = dist2(wx, wy, wz, mid);                              // :602
+        const float4 n0 = porig[nn_idx[(int64_t)i * kK]];
+        if (fabs((double)(n0.x - mid[0])) > 0.5 * fs && fabs((double)(n0.y - mid[1])) > 0.5 * fs &&
+            fabs((double)(n0.z - mid[2])) > 0.5 * fs) {                         // :603
+            cls = 2;
+        } else {
+            bool need_add = true;
+            if (cnt >= kK) {                                                    // :610
+#pragma unroll
+                for (int r = 0; r < kK; ++r) {
+                    const float4 q = porig[nn_idx[(int64_t)i * kK + r]];
+                    if (need_add && dist2(q.x, q.y, q.z, mid) < dist) need_add = false;  // :612-616
+                }
+            }
+            cls = need_add ? 1 : 0;
+        }
+    }
+    f_add[i] = cls == 1 ? 1u : 0u;
+    f_nodown[i] = cls == 2 ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void xyz_to_float4_kernel(const float *__restrict__ xyz, int64_t stride, int64_t n,
+                                                            float4 *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_float4(xyz[i * stride], xyz[i * stride + 1], xyz[i * stride + 2], 0.0f);
+}
+
+__global__ __launch_bounds__(256) void float4_to_xyz_kernel(const float4 *__restrict__ in, int64_t n, float *__restrict__ xyz)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float4 p = in[i];
+        xyz[3 * i] = p.x; xyz[3 * i + 1] = p.y; xyz[3 * i + 2] = p.z;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+static inline int nblk(int64_t n) { return (int)((n + 255) / 256); }
+
+template <class T>
+static hipError_t grow(T **p, int64_t *cap, int64_t need, bool keep = false, hipStream_t st = nullptr)
+{
+    if (*cap >= need && *p) return hipSuccess;
+    const int64_t c = std::max<int64_t>(need + need / 4, 1024);
+    T *q = nullptr;
+    S2M_TRY(hipMalloc((void **)&q, (size_t)c * sizeof(T)));
+    if (*p) {
+        if (keep && *cap > 0) {
+            S2M_TRY(hipMemcpyAsync(q, *p, (size_t)*cap * sizeof(T), hipMemcpyDeviceToDevice, st));
+            S2M_TRY(hipStreamSynchronize(st));
+        }
+        S2M_TRY(hipFree(*p));
+    }
+    *p = q;
+    *cap = c;
+    return hipSuccess;
+}
+
+void free_update(UpdateBuffers &u)
+{
+    void *ptrs[] = {u.alive, u.counters, u.stage, u.key, u.key2, u.val, u.val2, u.dnew, u.cnt, u.best_idx, u.best_d,
+                    u.add_flag, u.pos, u.flag32, u.pos_old, u.list, u.tmp, u.boxes, u.cvt};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    u = UpdateBuffers();
+}
+
+static hipError_t ensure_tmp(UpdateBuffers &u, size_t bytes)
+{
+    if (bytes <= u.tmp_bytes && u.tmp) return hipSuccess;
+    if (u.tmp) S2M_TRY(hipFree(u.tmp));
+    u.tmp = nullptr;
+    S2M_TRY(hipMalloc(&u.tmp, std::max<size_t>(bytes, 256)));
+    u.tmp_bytes = std::max<size_t>(bytes, 256);
+    return hipSuccess;
+}
+
+static hipError_t scan_u32(UpdateBuffers &u, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st)
+{
+    size_t bytes = 0;
+    S2M_TRY(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+    S2M_TRY(ensure_tmp(u, bytes));
+    size_t b2 = u.tmp_bytes;
+    return rocprim::exclusive_scan(u.tmp, b2, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), st);
+}
+
+// number of set flags = pos[n-1] + flag[n-1]
+static hipError_t count_flags(const uint32_t *flag, const uint32_t *pos, int64_t n, int64_t *out, hipStream_t st)
+{
+    *out = 0;
+    if (n <= 0) return hipSuccess;
+    uint32_t a = 0, b = 0;
+    S2M_TRY(hipMemcpyAsync(&a, pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    S2M_TRY(hipMemcpyAsync(&b, flag + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    S2M_TRY(hipStreamSynchronize(st));
+    *out = (int64_t)a + b;
+    return hipSuccess;
+}
+
+hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st)
+{
+    S2M_TRY(grow(&u.alive, &u.alive_cap, g.m));
+    if (!u.counters) S2M_TRY(hipMalloc((void **)&u.counters, 64));
+    S2M_TRY(hipMemsetAsync(u.alive, 1, (size_t)std::max<int64_t>(g.m, 1), st));
+    S2M_TRY(hipMemsetAsync(u.counters, 0, 64, st));
+    u.stage_n = 0;
+    return hipSuccess;
+}
+
+hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t n, bool downsample, float ds,
+                      int64_t *n_added, hipStream_t st)
+{
+    if (n_added) *n_added = 0;
+    if (n <= 0) return hipSuccess;
+    S2M_TRY(grow(&u.stage, &u.stage_cap, u.stage_n + n, true, st));
+    if (!downsample) {  // Add_Points(points, false): every point is inserted (ikd_Tree.cpp:549-570)
+        S2M_TRY(hipMemcpyAsync(u.stage + u.stage_n, np, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, st));
+        u.stage_n += n;
+        if (n_added) *n_added = n;
+        return hipSuccess;
+    }
+    if (u.batch_cap < n) {
+        int64_t c;
+        c = u.batch_cap; S2M_TRY(grow(&u.key, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.key2, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.val, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.val2, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.dnew, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.cnt, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_idx, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_d, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.add_flag, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.pos, &c, n));
+        u.batch_cap = c;
+    }
+    const int in = (int)n;
+    hipLaunchKernelGGL(add_probe_kernel, dim3(nblk(n)), dim3(256), 0, st, g, np, in, ds, u.key, u.val, u.dnew, u.cnt,
+                       u.best_idx, u.best_d);
+    size_t bytes = 0;
+    S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 63, st));
+    S2M_TRY(ensure_tmp(u, bytes));
+    size_t b2 = u.tmp_bytes;
+    S2M_TRY(rocprim::radix_sort_pairs(u.tmp, b2, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 63, st));
+    S2M_TRY(hipMemsetAsync(u.add_flag, 0, (size_t)n * sizeof(uint32_t), st));
+    uint32_t before = 0;
+    S2M_TRY(hipMemcpyAsync(&before, u.counters + 1, 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(add_resolve_kernel, dim3(nblk(n)), dim3(256), 0, st, g, np, in, ds, u.key2, u.val2, u.dnew,
+                       u.cnt, u.best_idx, u.best_d, u.alive, u.add_flag, u.counters);
+    // winners, in batch order, go to the staging list
+    S2M_TRY(scan_u32(u, u.add_flag, u.pos, n, st));
+    hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage);
+    int64_t won = 0;
+    S2M_TRY(count_flags(u.add_flag, u.pos, n, &won, st));
+    u.stage_n += won;
+    if (n_added) {
+        uint32_t after = 0;
+        S2M_TRY(hipMemcpy(&after, u.counters + 1, 4, hipMemcpyDeviceToHost));
+        *n_added = (int64_t)after - before;  // tmp_counter of Add_Points
+    }
+    return hipGetLastError();
+}
+
+hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_host, int nb, int64_t *n_deleted,
+                         hipStream_t st)
+{
+    if (n_deleted) *n_deleted = 0;
+    if (nb <= 0 || g.m == 0) return hipSuccess;
+    S2M_TRY(grow(&u.boxes, &u.boxes_cap, (int64_t)nb * 6));
+    S2M_TRY(hipMemcpyAsync(u.boxes, boxes_host, (size_t)nb * 6 * sizeof(float), hipMemcpyHostToDevice, st));
+    uint32_t before = 0, after = 0;
+    S2M_TRY(hipMemcpyAsync(&before, u.counters + 2, 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.porig, g.m, u.boxes, nb, u.alive,
+                       u.counters);
+    S2M_TRY(hipMemcpyAsync(&after, u.counters + 2, 4, hipMemcpyDeviceToHost, st));
+    S2M_TRY(hipStreamSynchronize(st));
+    if (n_deleted) *n_deleted = (int64_t)after - before;
+    return hipGetLastError();
+}
+
+// survivors (index order) followed by the staged appends -> u.list; *m_out = new size
+hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStream_t st)
+{
+    int64_t survivors = 0;
+    if (g.m > 0) {
+        if (u.old_cap < g.m) {
+            int64_t c;
+            c = u.old_cap; S2M_TRY(grow(&u.flag32, &c, g.m));
+            c = u.old_cap; S2M_TRY(grow(&u.pos_old, &c, g.m));
+            u.old_cap = c;
+        }
+        hipLaunchKernelGGL(flags_to_u32_kernel, dim3(nblk(g.m)), dim3(256), 0, st, u.alive, g.m, u.flag32);
+        S2M_TRY(scan_u32(u, u.flag32, u.pos_old, g.m, st));
+        S2M_TRY(count_flags(u.flag32, u.pos_old, g.m, &survivors, st));
+    }
+    S2M_TRY(grow(&u.list, &u.list_cap, survivors + u.stage_n));
+    if (g.m > 0)
+        hipLaunchKernelGGL(scatter_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.porig, u.flag32, u.pos_old, g.m,
+                           (int64_t)0, u.list);
+    if (u.stage_n > 0)
+        S2M_TRY(hipMemcpyAsync(u.list + survivors, u.stage, (size_t)u.stage_n * sizeof(float4), hipMemcpyDeviceToDevice, st));
+    *m_out = survivors + u.stage_n;
+    return hipGetLastError();
+}
+
+hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, const float *sy, const float *sz, int n,
+                         const int32_t *nn_idx, const Grid &g, bool have_nn, double fs, float4 **to_add, int64_t *n_add,
+                         float4 **no_down, int64_t *n_no_down, hipStream_t st)
+{
+    *n_add = 0;
+    *n_no_down = 0;
+    *to_add = nullptr;
+    *no_down = nullptr;
+    if (n <= 0) return hipSuccess;
+    // scratch: cvt holds [pw (n) | list A (n) | list B (n)], flags in add_flag / cnt, positions in pos / best_idx
+    S2M_TRY(grow(&u.cvt, &u.cvt_cap, (int64_t)3 * n));
+    if (u.batch_cap < n) {
+        int64_t c;
+        c = u.batch_cap; S2M_TRY(grow(&u.key, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.key2, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.val, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.val2, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.dnew, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.cnt, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_idx, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_d, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.add_flag, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.pos, &c, n));
+        u.batch_cap = c;
+    }
+    float4 *pw = u.cvt, *la = u.cvt + n, *lb = u.cvt + 2 * (int64_t)n;
+    uint32_t *fa = u.val, *fb = u.val2, *pa = u.cnt, *pb = u.best_idx;  // reused as flag / position arrays
+    hipLaunchKernelGGL(incr_classify_kernel, dim3(nblk(n)), dim3(256), 0, st, pose, sx, sy, sz, n, nn_idx, g.porig,
+                       have_nn ? 1 : 0, fs, pw, fa, fb);
+    S2M_TRY(scan_u32(u, fa, pa, n, st));
+    S2M_TRY(scan_u32(u, fb, pb, n, st));
+    hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fa, pa, (int64_t)n, (int64_t)0, la);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fb, pb, (int64_t)n, (int64_t)0, lb);
+    S2M_TRY(count_flags(fa, pa, n, n_add, st));
+    S2M_TRY(count_flags(fb, pb, n, n_no_down, st));
+    *to_add = la;
+    *no_down = lb;
+    return hipGetLastError();
+}
+
+hipError_t xyz_to_float4(UpdateBuffers &u, const float *xyz_dev, int64_t stride, int64_t n, float4 **out, hipStream_t st)
+{
+    S2M_TRY(grow(&u.cvt, &u.cvt_cap, std::max<int64_t>(n, 1)));
+    if (n > 0) hipLaunchKernelGGL(xyz_to_float4_kernel, dim3(nblk(n)), dim3(256), 0, st, xyz_dev, stride, n, u.cvt);
+    *out = u.cvt;
+    return hipGetLastError();
+}
+
+void launch_float4_to_xyz(const float4 *in, int64_t n, float *xyz, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(float4_to_xyz_kernel, dim3(nblk(n)), dim3(256), 0, st, in, n, xyz);
+}
+
+}  // namespace s2m

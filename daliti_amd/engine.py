@@ -19,7 +19,8 @@ MAX_LOG = 64
 ABI_SYMBOLS = [
     "s2m_abi_version", "s2m_config_default", "s2m_strerror", "s2m_create", "s2m_destroy",
     "s2m_last_error", "s2m_set_config", "s2m_set_stream", "s2m_map_build", "s2m_map_size",
-    "s2m_map_info", "s2m_scan_set", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
+    "s2m_map_info", "s2m_map_add", "s2m_map_delete_boxes", "s2m_map_incremental", "s2m_map_get_points",
+    "s2m_scan_set", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
     "s2m_iterated_update", "s2m_iterated_update_sharded", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
     "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats",
@@ -178,6 +179,34 @@ class Engine:
         self._ck(self.lib.s2m_map_info(self.h, info))
         return dict(cell=info[0], origin=(info[1], info[2], info[3]), bricks=int(info[4]),
                     top_entries=int(info[5]), occupied_cells=int(info[6]), mean_per_cell=info[7])
+
+    def map_add(self, xyz, downsample_on, downsample_size=0.5):
+        """ikdtree.Add_Points(points, downsample_on); returns voxels rewritten (or n)."""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        n_added = C.c_int64()
+        self._ck(self.lib.s2m_map_add(self.h, _p(xyz), C.c_int64(xyz.shape[1] if xyz.ndim == 2 else 3),
+                                      C.c_int64(xyz.shape[0]), C.c_int(int(downsample_on)), C.c_float(downsample_size),
+                                      0, C.byref(n_added)))
+        return n_added.value
+
+    def map_delete_boxes(self, boxes):
+        boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+        n_del = C.c_int64()
+        self._ck(self.lib.s2m_map_delete_boxes(self.h, _p(boxes), C.c_int64(len(boxes)), C.byref(n_del)))
+        return n_del.value
+
+    def map_incremental(self, state, filter_size_map=0.5):
+        state = np.ascontiguousarray(state, np.float64)
+        na, nb = C.c_int64(), C.c_int64()
+        self._ck(self.lib.s2m_map_incremental(self.h, _p(state), C.c_double(filter_size_map), C.byref(na), C.byref(nb)))
+        return na.value, nb.value
+
+    def map_points(self):
+        m = C.c_int64()
+        self._ck(self.lib.s2m_map_get_points(self.h, None, C.c_int64(0), C.byref(m)))
+        out = np.zeros((max(m.value, 1), 3), np.float32)
+        self._ck(self.lib.s2m_map_get_points(self.h, _p(out), C.c_int64(len(out)), C.byref(m)))
+        return out[:m.value]
 
     def scan_set(self, xyz):
         xyz = np.ascontiguousarray(xyz, np.float32)

@@ -87,6 +87,29 @@ int s2m_map_size(const s2m_engine *e, int64_t *m);             /* ikdtree.validn
 /* info[0..7]: cell size, origin xyz, bricks, top-level entries, occupied cells, mean pts/cell */
 int s2m_map_info(const s2m_engine *e, double info[8]);
 
+/* ---- incremental map maintenance (each call ends with a rebuild of the GPU map; neighbour indices
+ * of earlier passes become invalid) ------------------------------------------------------------------
+ * ikdtree.Add_Points(points, downsample_on) (ikd-Tree/ikd_Tree.cpp:477-573): with downsample_on the
+ * voxel [min, max) of edge downsample_size around each new point keeps only the point closest to
+ * its centre (ties: a new point beats an old one, the later of two new ones wins).
+ * *n_added = voxels rewritten (downsample_on) or n. */
+int s2m_map_add(s2m_engine *e, const float *xyz, int64_t stride_floats, int64_t n, int downsample_on,
+                float downsample_size, int on_device, int64_t *n_added);
+/* ikdtree.Delete_Point_Boxes(cub_needrm) (ikd_Tree.cpp:631-658; lasermap_fov_segment,
+ * laserMapping.cpp:313-369).  boxes: HOST array n x 6 = {min xyz, max xyz}; a point is removed
+ * when min <= p < max on every axis. */
+int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *n_deleted);
+/* map_incremental() (laserMapping.cpp:582-630) for the current scan: world points from `state`,
+ * the add / no-need-downsample decision from the Nearest_Points of the last rematch pass, then
+ * Add_Points(PointToAdd, true) and Add_Points(PointNoNeedDownsample, false) (:627-628).
+ * filter_size_map = mapping/filter_size_map (feat.yaml: 0.5), also the ikd-Tree downsample size
+ * (:784).  Outputs: the sizes of the two lists (add_point_size = their sum, :629). */
+int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], double filter_size_map,
+                        int64_t *n_to_add, int64_t *n_no_downsample);
+/* ikdtree.flatten(Root_Node, PCL_Storage) (laserMapping.cpp:1170-1175): the current map points,
+ * packed xyz, in the engine's index order (the order neighbour indices refer to). */
+int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity_points, int64_t *m);
+
 /* The down-sampled body-frame scan feats_down (laserMapping.cpp:775-778).  Resets the per-scan
  * state: point_selected_surf := true (:812), Nearest_Points cleared (:810). */
 int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride_floats, int64_t n, int on_device);

@@ -49,6 +49,13 @@ def lib():
         _lib.orc_kdtree_build.restype = C.c_void_p
         _lib.orc_kdtree_build.argtypes = [C.c_void_p, C.c_int64]
         _lib.orc_kdtree_free.argtypes = [C.c_void_p]
+        _lib.orc_map_create.restype = C.c_void_p
+        _lib.orc_map_create.argtypes = [C.c_void_p, C.c_int64]
+        _lib.orc_map_free.argtypes = [C.c_void_p]
+        _lib.orc_map_size.restype = C.c_int64
+        _lib.orc_map_size.argtypes = [C.c_void_p]
+        _lib.orc_map_add.restype = C.c_int64
+        _lib.orc_map_delete_box.restype = C.c_int64
         _lib.orc_esti_plane.restype = C.c_int
         _lib.orc_eskf_update.restype = C.c_int
         _lib.orc_eskf_update_dense.restype = C.c_int
@@ -257,3 +264,47 @@ def iterated_update(cfg, tree, scan_xyz, x, x_prop, P, feat_queue=None, use_dens
                 ekf_stop=bool(res.ekf_stop), effct=log_effct[:it].copy(), total_res=log_tot[:it].copy(),
                 rematch=log_rem[:it].copy(), conv=log_conv[:it].copy(), solution=log_sol[:it].copy(),
                 nn_idx=nn, feat_queue=q[:qlen.value].copy())
+
+
+class Map:
+    """Dynamic map with the ikd-Tree call semantics the node uses (Add_Points / Delete_Point_Boxes)."""
+
+    def __init__(self, xyz):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        self.h = lib().orc_map_create(_p(xyz), C.c_int64(len(xyz)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_map_free(C.c_void_p(self.h))
+            self.h = None
+
+    def size(self):
+        return lib().orc_map_size(C.c_void_p(self.h))
+
+    def points(self):
+        out = np.zeros((max(self.size(), 1), 3), np.float32)
+        lib().orc_map_points(C.c_void_p(self.h), _p(out))
+        return out[:self.size()]
+
+    def add(self, xyz, downsample_on, ds=0.5):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        return lib().orc_map_add(C.c_void_p(self.h), _p(xyz), C.c_int64(len(xyz)), C.c_int(int(downsample_on)),
+                                 C.c_float(ds))
+
+    def delete_box(self, box):
+        box = np.ascontiguousarray(box, np.float32).reshape(6)
+        return lib().orc_map_delete_box(C.c_void_p(self.h), _p(box))
+
+
+def map_incremental_lists(scan_xyz, x, nn_xyz, nn_cnt, fs=0.5):
+    scan = np.ascontiguousarray(scan_xyz, np.float32).reshape(-1, 3)
+    n = len(scan)
+    x = np.ascontiguousarray(x, float)
+    nn_xyz = np.ascontiguousarray(nn_xyz, np.float32).reshape(n, 15)
+    nn_cnt = np.ascontiguousarray(nn_cnt, np.int32)
+    to_add = np.zeros((max(n, 1), 3), np.float32)
+    no_down = np.zeros((max(n, 1), 3), np.float32)
+    na, nd = C.c_int32(0), C.c_int32(0)
+    lib().orc_map_incremental_lists(_p(scan), C.c_int64(n), _p(x), _p(nn_xyz), _p(nn_cnt), C.c_double(fs),
+                                    _p(to_add), C.byref(na), _p(no_down), C.byref(nd))
+    return to_add[:na.value].copy(), no_down[:nd.value].copy()

@@ -822,3 +822,145 @@ void orc_iterated_update(const orc_cfg *cfg, const orc_kdtree *tree, const float
     free(selected); free(plane_ok); free(eff); free(nn_idx); free(nn_cnt); free(nn_d2);
     free(plane); free(pd2); free(Hsub); free(meas);
 }
+
+/* ======================================================================================== */
+/* incremental map maintenance                                             */
+/* ======================================================================================== */
+struct orc_map {
+    float *xyz;        /* 3 floats per slot, insertion order */
+    uint8_t *alive;
+    int64_t n, cap, n_alive;
+};
+
+orc_map *orc_map_create(const float *xyz, int64_t m)
+{
+    orc_map *mp = (orc_map *)calloc(1, sizeof(*mp));
+    mp->cap = m > 16 ? 2 * m : 32;
+    mp->xyz = (float *)malloc(sizeof(float) * 3 * (size_t)mp->cap);
+    mp->alive = (uint8_t *)malloc((size_t)mp->cap);
+    if (m > 0) memcpy(mp->xyz, xyz, sizeof(float) * 3 * (size_t)m);
+    memset(mp->alive, 1, (size_t)(m > 0 ? m : 0));
+    mp->n = m;
+    mp->n_alive = m;
+    return mp;
+}
+void orc_map_free(orc_map *mp)
+{
+    if (!mp) return;
+    free(mp->xyz); free(mp->alive); free(mp);
+}
+int64_t orc_map_size(const orc_map *mp) { return mp->n_alive; }
+void orc_map_points(const orc_map *mp, float *out)
+{
+    int64_t k = 0;
+    for (int64_t i = 0; i < mp->n; ++i)
+        if (mp->alive[i]) { memcpy(out + 3 * k, mp->xyz + 3 * i, 3 * sizeof(float)); ++k; }
+}
+static void map_push(orc_map *mp, const float p[3])
+{
+    if (mp->n == mp->cap) {
+        mp->cap *= 2;
+        mp->xyz = (float *)realloc(mp->xyz, sizeof(float) * 3 * (size_t)mp->cap);
+        mp->alive = (uint8_t *)realloc(mp->alive, (size_t)mp->cap);
+    }
+    memcpy(mp->xyz + 3 * mp->n, p, 3 * sizeof(float));
+    mp->alive[mp->n] = 1;
+    mp->n++;
+    mp->n_alive++;
+}
+/* Search_by_range / Delete_by_range membership: min <= p < max (ikd_Tree.cpp:1259, 794) */
+static inline int in_box(const float *p, const float mn[3], const float mx[3])
+{
+    return mn[0] <= p[0] && mx[0] > p[0] && mn[1] <= p[1] && mx[1] > p[1] && mn[2] <= p[2] && mx[2] > p[2];
+}
+static inline float dist2_pts(const float *a, const float *b)
+{
+    /* calc_dist (ikd_Tree.cpp:1682-1688) */
+    float d = (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]);
+    d = d + (a[2] - b[2]) * (a[2] - b[2]);
+    return d;
+}
+
+int64_t orc_map_add(orc_map *mp, const float *xyz, int64_t n, int downsample_on, float ds)
+{
+    if (!downsample_on) {
+        for (int64_t i = 0; i < n; ++i) map_push(mp, xyz + 3 * i);
+        return n;
+    }
+    int64_t counter = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const float *P = xyz + 3 * i;
+        float mn[3], mx[3], mid[3];
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = floorf(P[k] / ds) * ds;                                   /* :491-496 */
+            mx[k] = mn[k] + ds;
+            mid[k] = (float)((double)mn[k] + (double)(mx[k] - mn[k]) / 2.0);  /* :497-499 */
+        }
+        /* Search_by_range over the current set (brute force: this is the oracle) */
+        float min_dist = dist2_pts(P, mid);
+        int64_t best = -1, cnt = 0;
+        for (int64_t j = 0; j < mp->n; ++j) {
+            if (!mp->alive[j] || !in_box(mp->xyz + 3 * j, mn, mx)) continue;
+            ++cnt;
+            const float td = dist2_pts(mp->xyz + 3 * j, mid);
+            if (td < min_dist) { min_dist = td; best = j; }                   /* :503-511, strict */
+        }
+        /* :514-521: rewrite the voxel when it held several points or the result "is" the new point
+         * (same_point: every coordinate within EPSS = 1e-6, ikd_Tree.cpp:1676-1680) */
+        const float *res = best >= 0 ? mp->xyz + 3 * best : P;
+        const int same = fabs((double)(P[0] - res[0])) < 1e-6 && fabs((double)(P[1] - res[1])) < 1e-6 &&
+                         fabs((double)(P[2] - res[2])) < 1e-6;
+        if (cnt > 1 || same) {
+            float keep[3];
+            memcpy(keep, best >= 0 ? mp->xyz + 3 * best : P, sizeof(keep));
+            for (int64_t j = 0; j < mp->n; ++j)
+                if (mp->alive[j] && in_box(mp->xyz + 3 * j, mn, mx)) { mp->alive[j] = 0; mp->n_alive--; }
+            map_push(mp, keep);
+            ++counter;
+        }
+    }
+    return counter;
+}
+
+int64_t orc_map_delete_box(orc_map *mp, const float box[6])
+{
+    int64_t c = 0;
+    for (int64_t j = 0; j < mp->n; ++j)
+        if (mp->alive[j] && in_box(mp->xyz + 3 * j, box, box + 3)) { mp->alive[j] = 0; mp->n_alive--; ++c; }
+    return c;
+}
+
+void orc_map_incremental_lists(const float *scan_xyz, int64_t n, const orc_state *x, const float *nn_xyz,
+                               const int32_t *nn_cnt, double fs, float *to_add, int32_t *n_add, float *no_down,
+                               int32_t *n_no_down)
+{
+    int32_t na = 0, nd = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        float pw[3];
+        orc_body_to_world(x, scan_xyz + 3 * i, pw);                            /* :591 */
+        if (nn_cnt[i] > 0) {                                                   /* :593, flg_EKF_inited == true */
+            const float *nb = nn_xyz + 15 * i;
+            float mid[3];
+            for (int k = 0; k < 3; ++k) mid[k] = (float)(floor((double)pw[k] / fs) * fs + 0.5 * fs);  /* :599-601 */
+            const float dist = dist2_pts(pw, mid);                             /* :602 */
+            /* float differences, compared in double with 0.5 * fs (:603) */
+            if (fabs((double)(nb[0] - mid[0])) > 0.5 * fs && fabs((double)(nb[1] - mid[1])) > 0.5 * fs &&
+                fabs((double)(nb[2] - mid[2])) > 0.5 * fs) {
+                memcpy(no_down + 3 * nd, pw, sizeof(pw));
+                ++nd;
+                continue;
+            }
+            int need_add = 1;
+            for (int r = 0; r < ORC_K; ++r) {                                  /* :608-617 */
+                if (nn_cnt[i] < ORC_K) break;
+                if (dist2_pts(nb + 3 * r, mid) < dist) { need_add = 0; break; }
+            }
+            if (need_add) { memcpy(to_add + 3 * na, pw, sizeof(pw)); ++na; }
+        } else {
+            memcpy(to_add + 3 * na, pw, sizeof(pw));                           /* :623 */
+            ++na;
+        }
+    }
+    *n_add = na;
+    *n_no_down = nd;
+}

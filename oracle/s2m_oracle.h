@@ -142,6 +142,32 @@ void orc_iterated_update(const orc_cfg *cfg, const orc_kdtree *tree, const float
                          int32_t *log_converged, double *log_solution /* max_iter x 24 */,
                          int32_t *nn_idx_out /* n*5 or NULL */, orc_iter_result *res);
 
+/* ---- incremental map maintenance --------------------------------------------
+ * A dynamic point set with the semantics of the ikd-Tree calls the node makes:
+ *   orc_map_add          KD_TREE::Add_Points(points, downsample_on)   ikd_Tree.cpp:477-573
+ *                        (sequential; with downsample_on the point's voxel [min, max) of edge
+ *                        downsample_size keeps only the point closest to the voxel centre;
+ *                        Search_by_range / Delete_by_range box tests :1245-1265, 766-800)
+ *   orc_map_delete_box   KD_TREE::Delete_Point_Boxes                  ikd_Tree.cpp:631-658
+ *   orc_map_incremental  map_incremental()                            laserMapping.cpp:582-630
+ * Points keep their insertion order; among several existing points tied for the smallest
+ * centre distance the earliest inserted wins (the reference takes the first in its traversal
+ * order, which is not knowable here). */
+typedef struct orc_map orc_map;
+orc_map *orc_map_create(const float *xyz, int64_t m);
+void     orc_map_free(orc_map *mp);
+int64_t  orc_map_size(const orc_map *mp);
+void     orc_map_points(const orc_map *mp, float *xyz_out); /* alive points, insertion order */
+/* returns the reference's tmp_counter (voxels rewritten) for downsample_on, n otherwise */
+int64_t  orc_map_add(orc_map *mp, const float *xyz, int64_t n, int downsample_on, float downsample_size);
+int64_t  orc_map_delete_box(orc_map *mp, const float box[6]); /* min xyz, max xyz; min <= p < max */
+/* nn_xyz: n x 5 x 3 neighbour coordinates of the last rematch (Nearest_Points), nn_cnt: n.
+ * Writes the two lists the reference builds (world points, index order) and their lengths;
+ * to_add / no_down must hold n x 3 floats each. */
+void orc_map_incremental_lists(const float *scan_xyz, int64_t n, const orc_state *x, const float *nn_xyz,
+                               const int32_t *nn_cnt, double filter_size_map, float *to_add,
+                               int32_t *n_add, float *no_down, int32_t *n_no_down);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,135 @@
+"""Incremental map maintenance against the oracle's sequential restatement of
+map_incremental / Add_Points / Delete_Point_Boxes.  Maps are compared as sets of points (the two
+sides keep different insertion orders); poses of a multi-frame run must still agree to 1e-9."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+
+def _rows(a):
+    a = np.ascontiguousarray(a, np.float32).reshape(-1, 3)
+    return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+
+
+def test_oracle_add_points_semantics(oracle):
+    """The voxel rule of Add_Points (ikd_Tree.cpp:477-573) on hand-made cases."""
+    ds = 0.5
+    m = oracle.Map(np.array([[0.30, 0.30, 0.30]], np.float32))          # centre of voxel 0 is 0.25
+    assert m.add([[0.45, 0.45, 0.45]], True, ds) == 0 and m.size() == 1  # old point closer: untouched
+    assert m.add([[0.26, 0.26, 0.26]], True, ds) == 1                    # new point closer: replaces
+    assert (m.points() == np.float32([[0.26, 0.26, 0.26]])).all()
+    m.add([[0.40, 0.40, 0.40], [0.41, 0.41, 0.41]], False)               # no downsample: all kept
+    assert m.size() == 3
+    assert m.add([[0.49, 0.49, 0.49]], True, ds) == 1 and m.size() == 1  # several old points: collapse to best
+    assert (m.points() == np.float32([[0.26, 0.26, 0.26]])).all()
+    # tie between a new and an old point goes to the new one; between two new ones to the later
+    m2 = oracle.Map(np.array([[0.35, 0.25, 0.25]], np.float32))
+    m2.add([[0.15, 0.25, 0.25]], True, ds)
+    assert (m2.points() == np.float32([[0.15, 0.25, 0.25]])).all()
+    m2.add([[0.25, 0.35, 0.25], [0.25, 0.15, 0.25]], True, ds)
+    assert (m2.points() == np.float32([[0.25, 0.15, 0.25]])).all()
+    # box delete is half-open: min <= p < max
+    m3 = oracle.Map(np.array([[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5]], np.float32))
+    assert m3.delete_box([0, 0, 0, 1, 1, 1]) == 2 and (m3.points() == np.float32([[1, 1, 1]])).all()
+
+
+@pytest.mark.gpu
+def test_map_add_delete_match_oracle(oracle, small_scene):
+    from daliti_amd import Engine
+    rs = np.random.RandomState(3)
+    base = small_scene["map"][:12000]
+    e = Engine(cell_size=0.4)
+    e.map_build(base)
+    om = oracle.Map(base)
+    assert (_rows(e.map_points()) == _rows(om.points())).all()
+    # downsample add: many new points per voxel, some closer to the centre than the old ones
+    new = small_scene["map"][12000:16000] + rs.normal(0, 0.05, (4000, 3)).astype(np.float32)
+    got = e.map_add(new, True, 0.5)
+    om.add(new, True, 0.5)
+    assert e.map_size() == om.size()
+    assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
+    assert got > 0
+    # every voxel touched by the batch now holds exactly one point
+    key = np.floor(e.map_points() / np.float32(0.5)).astype(np.int64)
+    tk = np.unique(np.floor(new / np.float32(0.5)).astype(np.int64), axis=0)
+    allk, cnt = np.unique(key, axis=0, return_counts=True)
+    lut = {tuple(k): c for k, c in zip(allk, cnt)}
+    assert all(lut.get(tuple(k), 0) == 1 for k in tk)
+    # plain add
+    new2 = small_scene["map"][16000:17000]
+    assert e.map_add(new2, False) == 1000
+    om.add(new2, False)
+    assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
+    # a second downsample add on top (voxels with several points collapse)
+    new3 = small_scene["map"][17000:19000] + rs.normal(0, 0.2, (2000, 3)).astype(np.float32)
+    e.map_add(new3, True, 0.5)
+    om.add(new3, True, 0.5)
+    assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
+    # box deletes (FOV trimming, laserMapping.cpp:313-369)
+    boxes = np.float32([[-10, -10, -1, -1.0, 10, 20], [2.5, -10, -1, 10, 10, 0.05]])
+    nd = e.map_delete_boxes(boxes)
+    no = sum(om.delete_box(b) for b in boxes)
+    assert nd == no > 0
+    assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
+    assert e.map_delete_boxes(np.float32([[100, 100, 100, 101, 101, 101]])) == 0
+    # the rebuilt grid still answers exact kNN queries
+    x = small_scene["x_prop"]
+    e.scan_set(small_scene["scan"])
+    e.residual_pass(x, True)
+    idx, d2 = e.get_neighbors()
+    pts = e.map_points()
+    oi, od, _ = oracle.KdTree(pts).knn5(oracle.body_to_world(x, small_scene["scan"]))
+    near = od[:, 4] <= 5.0      # the search is exact up to the d2 <= 5 gate (laserMapping.cpp:853) ...
+    assert near.sum() > 100 and (~near).sum() > 10
+    assert (bits(d2[near]) == bits(od[near])).all() and (idx[near] == oi[near]).all()
+    assert (d2[~near, 4] > 5.0).all()   # ... and only reports "beyond the gate" past it
+    e.close()
+
+
+@pytest.mark.gpu
+def test_multi_frame_odometry_with_map_growth(oracle):
+    """Seed the map from the first scan, then register + grow for several frames (the node's loop,
+    laserMapping.cpp:780-793, 820-1102, 1165-1168) on both sides."""
+    from daliti_amd import Engine, synth
+    L, fs = 12.0, 0.5
+    cfg = oracle.default_cfg(max_iter=5, feat_threshold=50)
+    e = Engine(max_iter=5, feat_threshold=50, cell_size=0.5)
+    poses = [np.array([0.06 * k, 0.02 * k, 1.5]) for k in range(5)]
+    # frame 0 seeds the map with its world-frame points (identity attitude: world = body + position)
+    s0 = synth.make_scan(32, 256, L, seed=10, sensor_pos=poses[0])
+    x0 = synth.make_state(np.eye(3), poses[0])
+    seed = oracle.body_to_world(x0, s0)
+    e.map_build(seed)
+    om = oracle.Map(seed)
+    P = np.eye(24) * 1e-4
+    P[:6, :6] = np.eye(6) * 1e-3
+    Pg, Po = P.copy(), P.copy()
+    xg = xo = x0
+    for k in range(1, 5):
+        scan = synth.make_scan(32, 256, L, seed=10 + k, sensor_pos=poses[k])
+        # prediction: previous estimate (constant-position model), so the filter has ~6 cm to correct;
+        # the covariance is re-inflated every frame, standing in for the IMU propagation's process noise
+        xpg, xpo = xg.copy(), xo.copy()
+        Pg, Po = P.copy(), P.copy()
+        e.scan_set(scan)
+        rg = e.iterated_update(xpg, xpg, Pg)
+        tree = oracle.KdTree(om.points())
+        ro = oracle.iterated_update(cfg, tree, scan, xpo, xpo, Po)
+        assert (rg["effct"] == ro["effct"]).all() and rg["iters"] == ro["iters"], k
+        assert np.abs(rg["x"] - ro["x"]).max() < 1e-9 and np.abs(rg["P"] - ro["P"]).max() < 1e-12, k
+        xg, Pg, xo, Po = rg["x"], rg["P"], ro["x"], ro["P"]
+        assert np.abs(xg[9:12] - poses[k]).max() < 0.02, k           # it really tracks the motion
+        na, nb = e.map_incremental(xg, fs)
+        nn = ro["nn_idx"]
+        cnt = (nn >= 0).sum(1).astype(np.int32)
+        nn_xyz = tree.xyz[np.maximum(nn, 0)]
+        to_add, no_down = oracle.map_incremental_lists(scan, xo, nn_xyz, cnt, fs)
+        assert (na, nb) == (len(to_add), len(no_down)), k
+        om.add(to_add, True, fs)
+        om.add(no_down, False)
+        assert e.map_size() == om.size(), k
+        assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all(), k
+    # the raw seed collapses towards one point per 0.5 m voxel as frames are merged in
+    assert 1000 < e.map_size() < len(seed)
+    e.close()
