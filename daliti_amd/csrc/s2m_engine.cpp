@@ -39,6 +39,7 @@ struct s2m_engine {
 
     MapBuffers map;
     UpdateBuffers upd;
+    VoxelBuffers vox;
     float built_cell = 0.0f;  // cell size of the current grid (kept across incremental rebuilds)
     Grid grid{};
     MapStats stats;
@@ -321,6 +322,7 @@ int s2m_destroy(s2m_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_map(e->map);
     free_update(e->upd);
+    free_voxel(e->vox);
     void *ptrs[] = {e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
                     e->d_nn_d2, e->d_hard, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
@@ -492,35 +494,34 @@ int s2m_map_info(const s2m_engine *e, double info[8])
     return S2M_OK;
 }
 
-int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int on_device)
+namespace {
+int scan_reserve(s2m_engine *e, int64_t n)
 {
-    if (!e || n < 0 || stride < 3 || (n > 0 && !xyz)) return fail(e, S2M_ERR_ARG, "s2m_scan_set: bad argument");
-    if (n > (int64_t)1 << 28) return fail(e, S2M_ERR_CAPACITY, "scan too large");
-    S2M_HIP(e, hipSetDevice(e->device));
-    if (n > e->n_cap) {
-        const int64_t cap = ((n + 255) / 256) * 256;
-        int rc = 0;
-        rc = rc ? rc : grow(e, &e->d_scan, 3 * cap);
-        rc = rc ? rc : grow(e, &e->d_plane, cap);
-        rc = rc ? rc : grow(e, &e->d_flags, cap);
-        rc = rc ? rc : grow(e, &e->d_sel, cap);
-        rc = rc ? rc : grow(e, &e->d_eff, cap);
-        rc = rc ? rc : grow(e, &e->d_pd2, cap);
-        rc = rc ? rc : grow(e, &e->d_nn_idx, cap * S2M_K);
-        rc = rc ? rc : grow(e, &e->d_nn_d2, cap * S2M_K);
-        rc = rc ? rc : grow(e, &e->d_partials, (int64_t)std::max(reduce_blocks((int)cap), 1) * kRedTerms);
-        rc = rc ? rc : grow(e, &e->d_block_off, (int64_t)rows_blocks((int)cap) + 1);
-        rc = rc ? rc : grow(e, &e->d_hard, cap + 16);
-        if (!rc) S2M_HIP(e, hipMemsetAsync(e->d_hard + cap, 0, 16 * sizeof(uint32_t), e->stream));
-        if (e->dbg) rc = rc ? rc : grow(e, &e->d_dbg, cap * 4);
-        if (rc) return rc;
-        e->n_cap = cap;
-    }
-    const float *dev = nullptr;
-    int rc = stage_cloud(e, xyz, stride, n, on_device, &dev);
+    if (n <= e->n_cap) return S2M_OK;
+    const int64_t cap = ((n + 255) / 256) * 256;
+    int rc = 0;
+    rc = rc ? rc : grow(e, &e->d_scan, 3 * cap);
+    rc = rc ? rc : grow(e, &e->d_plane, cap);
+    rc = rc ? rc : grow(e, &e->d_flags, cap);
+    rc = rc ? rc : grow(e, &e->d_sel, cap);
+    rc = rc ? rc : grow(e, &e->d_eff, cap);
+    rc = rc ? rc : grow(e, &e->d_pd2, cap);
+    rc = rc ? rc : grow(e, &e->d_nn_idx, cap * S2M_K);
+    rc = rc ? rc : grow(e, &e->d_nn_d2, cap * S2M_K);
+    rc = rc ? rc : grow(e, &e->d_partials, (int64_t)std::max(reduce_blocks((int)cap), 1) * kRedTerms);
+    rc = rc ? rc : grow(e, &e->d_block_off, (int64_t)rows_blocks((int)cap) + 1);
+    rc = rc ? rc : grow(e, &e->d_hard, cap + 16);
+    if (!rc) S2M_HIP(e, hipMemsetAsync(e->d_hard + cap, 0, 16 * sizeof(uint32_t), e->stream));
+    if (e->dbg) rc = rc ? rc : grow(e, &e->d_dbg, cap * 4);
     if (rc) return rc;
-    if (n > 0) launch_deinterleave(dev, stride, n, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, e->stream);
-    // point_selected_surf(feats_down_size, true) (:812); neighbours invalid until the first rematch
+    e->n_cap = cap;
+    e->rows_cap = 0;
+    return S2M_OK;
+}
+
+// point_selected_surf(feats_down_size, true) (:812); neighbours invalid until the first rematch
+int scan_reset(s2m_engine *e, int64_t n)
+{
     S2M_HIP(e, hipMemsetAsync(e->d_sel, 1, (size_t)std::max<int64_t>(n, 1), e->stream));
     S2M_HIP(e, hipMemsetAsync(e->d_eff, 0, (size_t)std::max<int64_t>(n, 1), e->stream));
     S2M_HIP(e, hipMemsetAsync(e->d_flags, 0, (size_t)std::max<int64_t>(n, 1), e->stream));
@@ -529,6 +530,57 @@ int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int
     e->scan_ready = true;
     e->pass_done = false;
     e->nn_valid = false;
+    return S2M_OK;
+}
+}  // namespace
+
+int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int on_device)
+{
+    if (!e || n < 0 || stride < 3 || (n > 0 && !xyz)) return fail(e, S2M_ERR_ARG, "s2m_scan_set: bad argument");
+    if (n > (int64_t)1 << 28) return fail(e, S2M_ERR_CAPACITY, "scan too large");
+    S2M_HIP(e, hipSetDevice(e->device));
+    int rc = scan_reserve(e, n);
+    if (rc) return rc;
+    const float *dev = nullptr;
+    rc = stage_cloud(e, xyz, stride, n, on_device, &dev);
+    if (rc) return rc;
+    if (n > 0) launch_deinterleave(dev, stride, n, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, e->stream);
+    return scan_reset(e, n);
+}
+
+int s2m_scan_set_downsampled(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, float leaf, int on_device,
+                             int64_t *n_out)
+{
+    if (!e || n < 0 || stride < 3 || (n > 0 && !xyz) || !(leaf > 0.0f)) return fail(e, S2M_ERR_ARG, "s2m_scan_set_downsampled: bad argument");
+    if (n > (int64_t)1 << 28) return fail(e, S2M_ERR_CAPACITY, "scan too large");
+    S2M_HIP(e, hipSetDevice(e->device));
+    int rc = scan_reserve(e, n);  // the output cannot be larger than the input
+    if (rc) return rc;
+    const float *dev = nullptr;
+    rc = stage_cloud(e, xyz, stride, n, on_device, &dev);
+    if (rc) return rc;
+    int64_t m = 0;
+    bool too_fine = false;
+    S2M_HIP(e, voxel_downsample(e->vox, dev, stride, n, leaf, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap,
+                                &m, &too_fine, e->stream));
+    if (too_fine) return fail(e, S2M_ERR_CAPACITY, "leaf size too small for the cloud extent (voxel index overflows int32)");
+    if (n_out) *n_out = m;
+    return scan_reset(e, m);
+}
+
+int s2m_scan_get(s2m_engine *e, float *xyz, int64_t capacity, int64_t *n)
+{
+    if (!e || !n) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan");
+    *n = e->n;
+    if (!xyz || e->n == 0) return S2M_OK;
+    if (capacity < e->n) return fail(e, S2M_ERR_CAPACITY, "scan buffer too small");
+    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    // three strided copies SoA -> packed AoS
+    for (int k = 0; k < 3; ++k)
+        S2M_HIP(e, hipMemcpy2D(xyz + k, 3 * sizeof(float), e->d_scan + k * e->n_cap, sizeof(float), sizeof(float),
+                               (size_t)e->n, hipMemcpyDeviceToHost));
     return S2M_OK;
 }
 

@@ -73,6 +73,18 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
 hipError_t xyz_to_float4(UpdateBuffers &u, const float *xyz_dev, int64_t stride, int64_t n, float4 **out, hipStream_t st);
 void launch_float4_to_xyz(const float4 *in, int64_t n, float *xyz, hipStream_t st);
 
+// ---- s2m_voxel.hip : scan voxel down-sampling (pcl::VoxelGrid, laserMapping.cpp:775-776) ------------
+struct VoxelBuffers {
+    uint64_t *key = nullptr, *key2 = nullptr;
+    uint32_t *val = nullptr, *val2 = nullptr, *head = nullptr, *pos = nullptr, *box = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int64_t cap = 0;
+};
+void free_voxel(VoxelBuffers &v);
+hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, int64_t n, float leaf, float *ox,
+                            float *oy, float *oz, int64_t *n_out, bool *too_fine, hipStream_t st);
+
 // ---- s2m_match.hip : exact 5-NN ------------------------------------------------------------------
 struct MatchArgs {
     Grid grid;

@@ -1,0 +1,197 @@
+// s2m_voxel.hip -- scan voxel down-sampling on the GPU.
+//
+// Replaces downSizeFilterSurf.filter(*feats_down) (eskf_lio/src/laserMapping.cpp:153, 703, 775-776):
+// pcl::VoxelGrid<PointType> with leaf = mapping/filter_size_surf (0.5 m).  PCL is not in the reference
+// tree (libpcl-dev 1.10 from Ubuntu focal, Dockerfile:17); its published algorithm
+// (filters/impl/voxel_grid.hpp, applyFilter) is restated here:
+//   min/max of the cloud -> min_b = floor(min * inv_leaf), div_b = max_b - min_b + 1;
+//   per point ijk = (int)(floor(p * inv_leaf) - (float)min_b), idx = ijk0 + ijk1*div0 + ijk2*div0*div1;
+//   sort by idx; one output point per occupied voxel, in ascending idx, = float sum of its points
+//   divided by their count (CentroidPoint / AccumulatorXYZ).
+// PCL sorts with std::sort, which is not stable, so the order in which a voxel's points are summed --
+// and hence the last bit of the centroid -- is implementation-defined there; here the sum runs in
+// ascending input index (stable radix sort), and the oracle does the same.  Only x, y, z are produced:
+// nothing else of feats_down is read on the registration path.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "s2m_device.h"
+#include "s2m_kernels.h"
+
+namespace s2m {
+
+#define S2M_TRY(x)                       \
+    do {                                 \
+        hipError_t e_ = (x);             \
+        if (e_ != hipSuccess) return e_; \
+    } while (0)
+
+__device__ __forceinline__ uint32_t vx_f2ord(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+static inline float vx_ord2f(uint32_t u)
+{
+    const uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+
+__global__ __launch_bounds__(256) void vx_bbox_kernel(const float *__restrict__ xyz, int64_t stride, int64_t n,
+                                                      uint32_t *__restrict__ box)
+{
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float v = xyz[i * stride + k];
+            mn[k] = fminf(mn[k], v);
+            mx[k] = fmaxf(mx[k], v);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&box[k], vx_f2ord(mn[k]));
+            atomicMax(&box[3 + k], vx_f2ord(mx[k]));
+        }
+    }
+}
+
+struct VoxelDims {
+    float inv_leaf;
+    int min_b[3];
+    int64_t mul1, mul2;  // divb_mul_[1], divb_mul_[2]
+};
+
+__global__ __launch_bounds__(256) void vx_key_kernel(const float *__restrict__ xyz, int64_t stride, int64_t n,
+                                                     VoxelDims d, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int i0 = (int)(floorf(xyz[i * stride] * d.inv_leaf) - (float)d.min_b[0]);
+    const int i1 = (int)(floorf(xyz[i * stride + 1] * d.inv_leaf) - (float)d.min_b[1]);
+    const int i2 = (int)(floorf(xyz[i * stride + 2] * d.inv_leaf) - (float)d.min_b[2]);
+    key[i] = (uint64_t)((int64_t)i0 + (int64_t)i1 * d.mul1 + (int64_t)i2 * d.mul2);
+    val[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void vx_head_kernel(const uint64_t *__restrict__ skey, int64_t n, uint32_t *__restrict__ head)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) head[s] = (s == 0 || skey[s - 1] != skey[s]) ? 1u : 0u;
+}
+
+// one lane per voxel: float sum of its points in ascending input index, divided by the count
+__global__ __launch_bounds__(256) void vx_centroid_kernel(const float *__restrict__ xyz, int64_t stride, int64_t n,
+                                                          const uint64_t *__restrict__ skey,
+                                                          const uint32_t *__restrict__ sval,
+                                                          const uint32_t *__restrict__ head,
+                                                          const uint32_t *__restrict__ pos, float *__restrict__ ox,
+                                                          float *__restrict__ oy, float *__restrict__ oz)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n || !head[s]) return;
+    float cx = 0.0f, cy = 0.0f, cz = 0.0f;
+    int cnt = 0;
+    for (int64_t t = s; t < n && skey[t] == skey[s]; ++t) {
+        const int64_t i = sval[t];
+        cx = cx + xyz[i * stride];
+        cy = cy + xyz[i * stride + 1];
+        cz = cz + xyz[i * stride + 2];
+        ++cnt;
+    }
+    const float fn = (float)cnt;
+    const uint32_t o = pos[s];
+    ox[o] = cx / fn;
+    oy[o] = cy / fn;
+    oz[o] = cz / fn;
+}
+
+void free_voxel(VoxelBuffers &v)
+{
+    void *ptrs[] = {v.key, v.key2, v.val, v.val2, v.head, v.pos, v.tmp, v.box};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    v = VoxelBuffers();
+}
+
+// xyz: device AoS cloud; writes the down-sampled cloud as SoA into ox/oy/oz (capacity >= n each)
+hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, int64_t n, float leaf, float *ox,
+                            float *oy, float *oz, int64_t *n_out, bool *too_fine, hipStream_t st)
+{
+    *n_out = 0;
+    *too_fine = false;
+    if (n <= 0) return hipSuccess;
+    if (v.cap < n) {
+        void **ps[] = {(void **)&v.key, (void **)&v.key2, (void **)&v.val, (void **)&v.val2, (void **)&v.head, (void **)&v.pos};
+        const size_t es[] = {8, 8, 4, 4, 4, 4};
+        for (int k = 0; k < 6; ++k) {
+            if (*ps[k]) S2M_TRY(hipFree(*ps[k]));
+            *ps[k] = nullptr;
+            S2M_TRY(hipMalloc(ps[k], (size_t)n * es[k]));
+        }
+        v.cap = n;
+    }
+    if (!v.box) S2M_TRY(hipMalloc((void **)&v.box, 6 * sizeof(uint32_t)));
+    const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    S2M_TRY(hipMemcpyAsync(v.box, init, sizeof(init), hipMemcpyHostToDevice, st));
+    const int nb = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(vx_bbox_kernel, dim3(std::min(nb, 1024)), dim3(256), 0, st, xyz, stride, n, v.box);
+    uint32_t box[6];
+    S2M_TRY(hipMemcpyAsync(box, v.box, sizeof(box), hipMemcpyDeviceToHost, st));
+    S2M_TRY(hipStreamSynchronize(st));
+    VoxelDims d;
+    d.inv_leaf = 1.0f / leaf;  // inverse_leaf_size_ = 1 / leaf_size_
+    int64_t div[3];
+    for (int k = 0; k < 3; ++k) {
+        const float mn = vx_ord2f(box[k]), mx = vx_ord2f(box[3 + k]);
+        d.min_b[k] = (int)std::floor(mn * d.inv_leaf);
+        const int max_b = (int)std::floor(mx * d.inv_leaf);
+        div[k] = (int64_t)max_b - d.min_b[k] + 1;
+    }
+    // PCL refuses (returns the input) when the voxel index would overflow int32; report it instead
+    if (div[0] * div[1] * div[2] > (int64_t)2147483647) { *too_fine = true; return hipSuccess; }
+    d.mul1 = div[0];
+    d.mul2 = div[0] * div[1];
+    hipLaunchKernelGGL(vx_key_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, d, v.key, v.val);
+    size_t bytes = 0, b2 = 0;
+    S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, v.key, v.key2, v.val, v.val2, (size_t)n, 0, 32, st));
+    S2M_TRY(rocprim::exclusive_scan(nullptr, b2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+    bytes = std::max(bytes, b2);
+    if (bytes > v.tmp_bytes) {
+        if (v.tmp) S2M_TRY(hipFree(v.tmp));
+        v.tmp = nullptr;
+        S2M_TRY(hipMalloc(&v.tmp, bytes));
+        v.tmp_bytes = bytes;
+    }
+    size_t t1 = v.tmp_bytes;
+    S2M_TRY(rocprim::radix_sort_pairs(v.tmp, t1, v.key, v.key2, v.val, v.val2, (size_t)n, 0, 32, st));
+    hipLaunchKernelGGL(vx_head_kernel, dim3(nb), dim3(256), 0, st, v.key2, n, v.head);
+    size_t t2 = v.tmp_bytes;
+    S2M_TRY(rocprim::exclusive_scan(v.tmp, t2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL(vx_centroid_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, v.key2, v.val2, v.head, v.pos,
+                       ox, oy, oz);
+    uint32_t a = 0, b = 0;
+    S2M_TRY(hipMemcpyAsync(&a, v.pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    S2M_TRY(hipMemcpyAsync(&b, v.head + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    S2M_TRY(hipStreamSynchronize(st));
+    *n_out = (int64_t)a + b;
+    return hipGetLastError();
+}
+
+}  // namespace s2m

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "s2m_abi_version", "s2m_config_default", "s2m_strerror", "s2m_create", "s2m_destroy",
     "s2m_last_error", "s2m_set_config", "s2m_set_stream", "s2m_map_build", "s2m_map_size",
     "s2m_map_info", "s2m_map_add", "s2m_map_delete_boxes", "s2m_map_incremental", "s2m_map_get_points",
-    "s2m_scan_set", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
+    "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
     "s2m_iterated_update", "s2m_iterated_update_sharded", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
     "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats",
@@ -213,6 +213,23 @@ class Engine:
         assert xyz.ndim == 2 and xyz.shape[1] >= 3
         self._ck(self.lib.s2m_scan_set(self.h, _p(xyz), C.c_int64(xyz.shape[1]), C.c_int64(xyz.shape[0]), 0))
         self.n = xyz.shape[0]
+
+    def scan_set_downsampled(self, xyz, leaf=0.5):
+        """pcl::VoxelGrid(leaf) of the cloud becomes the current scan; returns feats_down_size."""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        assert xyz.ndim == 2 and xyz.shape[1] >= 3
+        m = C.c_int64()
+        self._ck(self.lib.s2m_scan_set_downsampled(self.h, _p(xyz), C.c_int64(xyz.shape[1]), C.c_int64(xyz.shape[0]),
+                                                   C.c_float(leaf), 0, C.byref(m)))
+        self.n = m.value
+        return m.value
+
+    def scan_get(self):
+        n = C.c_int64()
+        self._ck(self.lib.s2m_scan_get(self.h, None, C.c_int64(0), C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.float32)
+        self._ck(self.lib.s2m_scan_get(self.h, _p(out), C.c_int64(len(out)), C.byref(n)))
+        return out[:n.value]
 
     def scan_set_device(self, dev_ptr, stride, n):
         self._ck(self.lib.s2m_scan_set(self.h, C.c_void_p(dev_ptr), C.c_int64(stride), C.c_int64(n), 1))

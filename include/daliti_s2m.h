@@ -114,6 +114,16 @@ int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity_points, int64
  * state: point_selected_surf := true (:812), Nearest_Points cleared (:810). */
 int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride_floats, int64_t n, int on_device);
 
+/* downSizeFilterSurf.filter(*feats_down) followed by the scan hand-over (laserMapping.cpp:775-778):
+ * pcl::VoxelGrid with leaf = mapping/filter_size_surf (one centroid per occupied voxel, ascending
+ * voxel index), result kept on the device as the current scan (same resets as s2m_scan_set).
+ * *n_out = feats_down_size.  S2M_ERR_CAPACITY when the leaf is too small for the cloud's extent
+ * (PCL's int32 voxel-index overflow check). */
+int s2m_scan_set_downsampled(s2m_engine *e, const float *xyz, int64_t stride_floats, int64_t n, float leaf,
+                             int on_device, int64_t *n_out);
+/* The current scan (feats_down), packed xyz, for publishers and callers that keep a host copy. */
+int s2m_scan_get(s2m_engine *e, float *xyz, int64_t capacity_points, int64_t *n);
+
 /* Output of one residual/Jacobian pass. */
 typedef struct {
     double  HtH[144];        /* Hsub^T * Hsub, row-major 12x12        laserMapping.cpp:1015 */

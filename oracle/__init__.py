@@ -56,6 +56,7 @@ def lib():
         _lib.orc_map_size.argtypes = [C.c_void_p]
         _lib.orc_map_add.restype = C.c_int64
         _lib.orc_map_delete_box.restype = C.c_int64
+        _lib.orc_voxel_downsample.restype = C.c_int64
         _lib.orc_esti_plane.restype = C.c_int
         _lib.orc_eskf_update.restype = C.c_int
         _lib.orc_eskf_update_dense.restype = C.c_int
@@ -308,3 +309,12 @@ def map_incremental_lists(scan_xyz, x, nn_xyz, nn_cnt, fs=0.5):
     lib().orc_map_incremental_lists(_p(scan), C.c_int64(n), _p(x), _p(nn_xyz), _p(nn_cnt), C.c_double(fs),
                                     _p(to_add), C.byref(na), _p(no_down), C.byref(nd))
     return to_add[:na.value].copy(), no_down[:nd.value].copy()
+
+
+def voxel_downsample(xyz, leaf=0.5):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.zeros((max(len(xyz), 1), 3), np.float32)
+    m = lib().orc_voxel_downsample(_p(xyz), C.c_int64(len(xyz)), C.c_float(leaf), _p(out))
+    if m < 0:
+        raise OverflowError("leaf too small")
+    return out[:m].copy()

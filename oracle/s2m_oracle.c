@@ -964,3 +964,54 @@ void orc_map_incremental_lists(const float *scan_xyz, int64_t n, const orc_state
     *n_add = na;
     *n_no_down = nd;
 }
+
+/* ======================================================================================== */
+/* scan voxel down-sampling                                                */
+/* ======================================================================================== */
+typedef struct { int64_t idx; int64_t pt; } vx_pair;
+static int vx_cmp(const void *a, const void *b)
+{
+    const vx_pair *x = (const vx_pair *)a, *y = (const vx_pair *)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return x->pt < y->pt ? -1 : (x->pt > y->pt ? 1 : 0); /* stable: ascending input index */
+}
+int64_t orc_voxel_downsample(const float *xyz, int64_t n, float leaf, float *out)
+{
+    if (n <= 0) return 0;
+    const float inv = 1.0f / leaf;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            if (xyz[3 * i + k] < mn[k]) mn[k] = xyz[3 * i + k];
+            if (xyz[3 * i + k] > mx[k]) mx[k] = xyz[3 * i + k];
+        }
+    int min_b[3];
+    int64_t div[3];
+    for (int k = 0; k < 3; ++k) {
+        min_b[k] = (int)floorf(mn[k] * inv);
+        div[k] = (int64_t)(int)floorf(mx[k] * inv) - min_b[k] + 1;
+    }
+    if (div[0] * div[1] * div[2] > 2147483647LL) return -1;
+    vx_pair *v = (vx_pair *)malloc(sizeof(vx_pair) * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const int i0 = (int)(floorf(xyz[3 * i] * inv) - (float)min_b[0]);
+        const int i1 = (int)(floorf(xyz[3 * i + 1] * inv) - (float)min_b[1]);
+        const int i2 = (int)(floorf(xyz[3 * i + 2] * inv) - (float)min_b[2]);
+        v[i].idx = (int64_t)i0 + (int64_t)i1 * div[0] + (int64_t)i2 * div[0] * div[1];
+        v[i].pt = i;
+    }
+    qsort(v, (size_t)n, sizeof(vx_pair), vx_cmp);
+    int64_t m = 0;
+    for (int64_t s = 0; s < n;) {
+        float c[3] = {0.0f, 0.0f, 0.0f};
+        int64_t t = s;
+        for (; t < n && v[t].idx == v[s].idx; ++t)
+            for (int k = 0; k < 3; ++k) c[k] = c[k] + xyz[3 * v[t].pt + k];
+        const float fn = (float)(t - s);
+        for (int k = 0; k < 3; ++k) out[3 * m + k] = c[k] / fn;
+        ++m;
+        s = t;
+    }
+    free(v);
+    return m;
+}

@@ -168,6 +168,15 @@ void orc_map_incremental_lists(const float *scan_xyz, int64_t n, const orc_state
                                const int32_t *nn_cnt, double filter_size_map, float *to_add,
                                int32_t *n_add, float *no_down, int32_t *n_no_down);
 
+/* ---- scan voxel down-sampling ------------------------------------------------
+ * pcl::VoxelGrid<PointType>::applyFilter as called at laserMapping.cpp:775-776 (PCL 1.10,
+ * filters/impl/voxel_grid.hpp; not in the reference tree): one centroid per occupied voxel of edge
+ * `leaf`, ascending voxel index idx = ijk0 + ijk1*div0 + ijk2*div0*div1, centroid = float sum of the
+ * voxel's points / count.  PCL's std::sort leaves the summation order inside a voxel unspecified;
+ * ascending input index is used here.  out must hold n x 3 floats; returns the output size, or -1
+ * when the voxel index would overflow int32 (PCL then returns the input cloud unchanged). */
+int64_t orc_voxel_downsample(const float *xyz, int64_t n, float leaf, float *out);
+
 #ifdef __cplusplus
 }
 #endif
