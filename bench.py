@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--cell", type=float, default=0.0)
     ap.add_argument("--cpu-steps", type=int, default=8, help="CPU baseline sample: iterated updates (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing)")
+    ap.add_argument("--all-on-device0", action="store_true", help="test hook: every rank uses GPU 0")
+    ap.add_argument("--beams-mult", type=int, default=1, help="test hook: single rank over a denser scan")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the sharded/all-reduce code path even with one rank (test hook)")
     return ap.parse_args()
@@ -52,6 +56,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.all_on_device0:
+        local_rank = 0
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
     import torch
@@ -65,8 +71,10 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfgd = synth.CONFIGS[a.config]
     sharded = (world > 1 or a.force_collective) and a.mode == "sharded"
@@ -81,13 +89,18 @@ def main():
     else:
         dx = (rank - (world - 1) / 2.0) * 2.0 if world > 1 else 0.0
         pos = synth.SENSOR_POS + np.array([dx, 0.0, 0.0])
-        scan = synth.make_scan(cfgd["beams"], cfgd["az"], cfgd["L"], seed=2 + rank, sensor_pos=pos)
+        scan = synth.make_scan(cfgd["beams"] * a.beams_mult, cfgd["az"], cfgd["L"], seed=2 + rank, sensor_pos=pos)
     x_true, x_prop, P0 = synth.filter_inputs(pos)
     n_local = len(scan)
     t_gen = time.time() - t0
 
     eng = Engine(max_iter=a.max_iter, cell_size=a.cell, device=local_rank, feat_threshold=100)
-    stream = torch.cuda.current_stream()
+    # one explicit (non-default) stream shared by the engine's kernels and torch's collectives: RCCL orders
+    # its work against torch's *current* stream, so the all-reduce of a block is only correctly ordered
+    # after the kernel that wrote it if both are issued under this stream
+    stream = torch.cuda.Stream(device=local_rank)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     eng.set_stream(stream.cuda_stream)
     # inputs resident in HBM before the timed region: hand the engine device pointers
     d_map = torch.from_numpy(map_xyz).cuda()
@@ -150,7 +163,7 @@ def main():
     eng.set_timing(False)
     passes = iters  # one residual pass per iteration
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -187,6 +200,7 @@ def main():
         "iters_per_step": iters / a.steps,
         "rematch_passes_per_step": rematch / a.steps,
         "pose_error_vs_truth_m": pose_err,
+        "final_pos": [float(v) for v in res["x"][9:12]],
         "map_build_s": t_build,
     }
     # roofline of the dominant kernel: the match (kNN + plane fit) kernel, one launch per rematch pass
@@ -251,6 +265,15 @@ def cpu_baseline(a, map_xyz, scan, x_prop, P0, gpu_res):
         r = oracle.iterated_update(cfg, tree, scan, x_prop, x_prop, P0)
         iters += r["iters"]
     dt = time.perf_counter() - t0
+    # generous variant: the same port with OpenMP over scan points on many host cores
+    nthr = max(1, min(os.cpu_count() or 1, 64))
+    cfg_mt = oracle.default_cfg(max_iter=a.max_iter, nthreads=nthr)
+    oracle.iterated_update(cfg_mt, tree, scan, x_prop, x_prop, P0)
+    t1 = time.perf_counter()
+    it_mt = 0
+    for _ in range(a.cpu_steps):
+        it_mt += oracle.iterated_update(cfg_mt, tree, scan, x_prop, x_prop, P0)["iters"]
+    dt_mt = time.perf_counter() - t1
     dpos = float(np.abs(r["x"][9:12] - gpu_res["x"][9:12]).max())
     dR = r["x"][:9].reshape(3, 3).T @ gpu_res["x"][:9].reshape(3, 3)
     drot = float(np.abs(oracle.so3_log(dR)).max())
@@ -260,6 +283,10 @@ def cpu_baseline(a, map_xyz, scan, x_prop, P0, gpu_res):
                   % (a.cpu_steps, len(scan), len(map_xyz), t_build),
         "eskf_iters_per_sec": iters / dt, "ms_per_step": 1e3 * dt / a.cpu_steps,
         "host_cpus": os.cpu_count(),
+        "all_cores_variant": {"value": len(scan) * it_mt / dt_mt, "unit": "evals/s", "cores": nthr,
+                              "ms_per_step": 1e3 * dt_mt / a.cpu_steps,
+                              "note": "OpenMP over scan points; not the reference's configuration "
+                                      "(its pragmas are commented out, laserMapping.cpp:827-828)"},
         "gpu_vs_cpu_pose_delta_m": dpos, "gpu_vs_cpu_pose_delta_rad": drot,
         "effct_equal": bool((r["effct"] == gpu_res["effct"]).all()) if len(r["effct"]) == len(gpu_res["effct"]) else False,
     }

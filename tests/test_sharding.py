@@ -131,3 +131,28 @@ def test_bench_collective_path_single_rank():
     assert ref.returncode == 0, ref.stderr[-2000:]
     rline = json.loads(ref.stdout.strip().splitlines()[-1])
     assert abs(rline["pose_error_vs_truth_m"] - line["pose_error_vs_truth_m"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_two_process_sharded_bench_equals_single_rank():
+    """Two bench.py ranks (torch.distributed.run, gloo on CUDA tensors, both on GPU 0) shard a 32x625
+    scan; the registered pose must equal one rank processing the whole scan."""
+    import json
+    import subprocess
+    port = str(29700 + os.getpid() % 200)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--config", "C1", "--steps", "3", "--warmup", "1", "--no-cpu",
+                          "--backend", "gloo", "--all-on-device0"], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
+                          "--warmup", "1", "--no-cpu", "--beams-mult", "2"], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l2["n_gpus"] == 2 and l2["scaling"] == "weak"
+    assert l2["config"]["scan_points_per_gpu"] * 2 == l1["config"]["scan_points_per_gpu"]
+    assert np.abs(np.array(l2["final_pos"]) - np.array(l1["final_pos"])).max() < 1e-10
