@@ -40,6 +40,7 @@ struct s2m_engine {
     MapBuffers map;
     UpdateBuffers upd;
     VoxelBuffers vox;
+    UndistBuffers und;
     float built_cell = 0.0f;  // cell size of the current grid (kept across incremental rebuilds)
     Grid grid{};
     MapStats stats;
@@ -323,6 +324,7 @@ int s2m_destroy(s2m_engine *e)
     free_map(e->map);
     free_update(e->upd);
     free_voxel(e->vox);
+    free_undist(e->und);
     void *ptrs[] = {e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
                     e->d_nn_d2, e->d_hard, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
@@ -564,6 +566,93 @@ int s2m_scan_set_downsampled(s2m_engine *e, const float *xyz, int64_t stride, in
     S2M_HIP(e, voxel_downsample(e->vox, dev, stride, n, leaf, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap,
                                 &m, &too_fine, e->stream));
     if (too_fine) return fail(e, S2M_ERR_CAPACITY, "leaf size too small for the cloud extent (voxel index overflows int32)");
+    if (n_out) *n_out = m;
+    return scan_reset(e, m);
+}
+
+namespace {
+int check_undistort_args(s2m_engine *e, const float *points, int64_t stride, int64_t n, int32_t oa, int32_t ob,
+                         const s2m_imu_pose *poses, int32_t np, const double *state_end)
+{
+    if (!e || n < 0 || stride < 3 || (n > 0 && !points) || !poses || np < 1 || !state_end)
+        return fail(e, S2M_ERR_ARG, "undistort: bad argument");
+    if (oa < 0 || oa >= stride || ob >= stride) return fail(e, S2M_ERR_ARG, "undistort: time offsets outside the record");
+    if (n > (int64_t)1 << 28) return fail(e, S2M_ERR_CAPACITY, "scan too large");
+    static_assert(sizeof(s2m_imu_pose) == 22 * sizeof(double), "s2m_imu_pose must be 22 packed doubles");
+    return S2M_OK;
+}
+}  // namespace
+
+int s2m_undistort(s2m_engine *e, const float *points, int64_t stride, int64_t n, int32_t oa, int32_t ob,
+                  const s2m_imu_pose *poses, int32_t np, const double state_end[S2M_STATE_DOUBLES], int sort_by_time,
+                  int on_device, float *out_xyz, uint32_t *perm)
+{
+    int rc = check_undistort_args(e, points, stride, n, oa, ob, poses, np, state_end);
+    if (rc) return rc;
+    if (n > 0 && !out_xyz) return fail(e, S2M_ERR_ARG, "undistort: null output");
+    if (n == 0) return S2M_OK;
+    S2M_HIP(e, hipSetDevice(e->device));
+    const float *dev = nullptr;
+    // stage whole records (the time fields may sit anywhere in the record)
+    if (on_device) {
+        dev = points;
+    } else {
+        const int64_t floats = n * stride;
+        if (floats > e->stage_cap) {
+            rc = grow(e, &e->d_stage, floats);
+            if (rc) return rc;
+            e->stage_cap = floats;
+        }
+        S2M_HIP(e, hipMemcpyAsync(e->d_stage, points, (size_t)floats * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        dev = e->d_stage;
+    }
+    uint32_t *d_perm = nullptr;
+    if (perm) S2M_HIP(e, hipMalloc((void **)&d_perm, (size_t)n * sizeof(uint32_t)));
+    hipError_t he = undistort(e->und, dev, stride, n, oa, ob, reinterpret_cast<const double *>(poses), np,
+                              pose_of(state_end), sort_by_time != 0, d_perm, e->stream);
+    if (he == hipSuccess)
+        he = hipMemcpyAsync(out_xyz, e->und.out, (size_t)n * 3 * sizeof(float),
+                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess && perm) he = hipMemcpyAsync(perm, d_perm, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (d_perm) (void)hipFree(d_perm);
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "undistort", he);
+    return S2M_OK;
+}
+
+int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, int64_t n, int32_t oa, int32_t ob,
+                          const s2m_imu_pose *poses, int32_t np, const double state_end[S2M_STATE_DOUBLES], float leaf,
+                          int on_device, int64_t *n_out)
+{
+    int rc = check_undistort_args(e, points, stride, n, oa, ob, poses, np, state_end);
+    if (rc) return rc;
+    S2M_HIP(e, hipSetDevice(e->device));
+    rc = scan_reserve(e, n);
+    if (rc) return rc;
+    if (n > 0) {
+        const float *dev = points;
+        if (!on_device) {
+            const int64_t floats = n * stride;
+            if (floats > e->stage_cap) {
+                rc = grow(e, &e->d_stage, floats);
+                if (rc) return rc;
+                e->stage_cap = floats;
+            }
+            S2M_HIP(e, hipMemcpyAsync(e->d_stage, points, (size_t)floats * sizeof(float), hipMemcpyHostToDevice, e->stream));
+            dev = e->d_stage;
+        }
+        S2M_HIP(e, undistort(e->und, dev, stride, n, oa, ob, reinterpret_cast<const double *>(poses), np,
+                             pose_of(state_end), true, nullptr, e->stream));
+    }
+    int64_t m = n;
+    float *sx = e->d_scan, *sy = e->d_scan + e->n_cap, *sz = e->d_scan + 2 * e->n_cap;
+    if (leaf > 0.0f && n > 0) {
+        bool too_fine = false;
+        S2M_HIP(e, voxel_downsample(e->vox, e->und.out, 3, n, leaf, sx, sy, sz, &m, &too_fine, e->stream));
+        if (too_fine) return fail(e, S2M_ERR_CAPACITY, "leaf size too small for the cloud extent (voxel index overflows int32)");
+    } else if (n > 0) {
+        launch_deinterleave(e->und.out, 3, n, sx, sy, sz, e->stream);
+    }
     if (n_out) *n_out = m;
     return scan_reset(e, m);
 }

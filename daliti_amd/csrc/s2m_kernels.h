@@ -85,6 +85,21 @@ void free_voxel(VoxelBuffers &v);
 hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, int64_t n, float leaf, float *ox,
                             float *oy, float *oz, int64_t *n_out, bool *too_fine, hipStream_t st);
 
+// ---- s2m_undistort.hip : per-point motion compensation (IMU_Processing.hpp:333-370) ----------------
+struct UndistBuffers {
+    uint32_t *key = nullptr, *key2 = nullptr, *val = nullptr, *val2 = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    double *poses = nullptr;
+    int pose_cap = 0;
+    float *out = nullptr;  // n x 3 packed, device
+    int64_t cap = 0;
+};
+void free_undist(UndistBuffers &u);
+hipError_t undistort(UndistBuffers &u, const float *pts, int64_t stride, int64_t n, int off_a, int off_b,
+                     const double *poses_host, int K, const Pose &end, bool sort_by_time, uint32_t *perm_dev,
+                     hipStream_t st);
+
 // ---- s2m_match.hip : exact 5-NN ------------------------------------------------------------------
 struct MatchArgs {
     Grid grid;

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "s2m_abi_version", "s2m_config_default", "s2m_strerror", "s2m_create", "s2m_destroy",
     "s2m_last_error", "s2m_set_config", "s2m_set_stream", "s2m_map_build", "s2m_map_size",
     "s2m_map_info", "s2m_map_add", "s2m_map_delete_boxes", "s2m_map_incremental", "s2m_map_get_points",
-    "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
+    "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
     "s2m_iterated_update", "s2m_iterated_update_sharded", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
     "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats",
@@ -221,6 +221,32 @@ class Engine:
         m = C.c_int64()
         self._ck(self.lib.s2m_scan_set_downsampled(self.h, _p(xyz), C.c_int64(xyz.shape[1]), C.c_int64(xyz.shape[0]),
                                                    C.c_float(leaf), 0, C.byref(m)))
+        self.n = m.value
+        return m.value
+
+    def undistort(self, records, time_off_a, time_off_b, poses, state_end, sort_by_time=True):
+        """records (n, stride) float32 starting with x, y, z; poses (K, 22) float64 IMUpose rows
+        {offset_time, acc3, gyr3, vel3, pos3, rot9}.  Returns (xyz, perm)."""
+        records = np.ascontiguousarray(records, np.float32)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 22)
+        state_end = np.ascontiguousarray(state_end, np.float64)
+        n = records.shape[0]
+        out = np.zeros((max(n, 1), 3), np.float32)
+        perm = np.zeros(max(n, 1), np.uint32)
+        self._ck(self.lib.s2m_undistort(self.h, _p(records), C.c_int64(records.shape[1]), C.c_int64(n),
+                                        C.c_int32(time_off_a), C.c_int32(time_off_b), _p(poses), C.c_int32(len(poses)),
+                                        _p(state_end), C.c_int(int(sort_by_time)), 0, _p(out), _p(perm)))
+        return out[:n], perm[:n]
+
+    def scan_set_from_raw(self, records, time_off_a, time_off_b, poses, state_end, leaf=0.5):
+        records = np.ascontiguousarray(records, np.float32)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 22)
+        state_end = np.ascontiguousarray(state_end, np.float64)
+        m = C.c_int64()
+        self._ck(self.lib.s2m_scan_set_from_raw(self.h, _p(records), C.c_int64(records.shape[1]),
+                                                C.c_int64(records.shape[0]), C.c_int32(time_off_a),
+                                                C.c_int32(time_off_b), _p(poses), C.c_int32(len(poses)),
+                                                _p(state_end), C.c_float(leaf), 0, C.byref(m)))
         self.n = m.value
         return m.value
 

@@ -124,6 +124,35 @@ int s2m_scan_set_downsampled(s2m_engine *e, const float *xyz, int64_t stride_flo
 /* The current scan (feats_down), packed xyz, for publishers and callers that keep a host copy. */
 int s2m_scan_get(s2m_engine *e, float *xyz, int64_t capacity_points, int64_t *n);
 
+/* One entry of IMUpose (eskf_lio::Pose6D as filled by set_pose6d, common_lib.h:248-265;
+ * IMU_Processing.hpp:224, 310): the IMU state at one IMU sample, offset_time relative to the scan start. */
+typedef struct {
+    double offset_time;
+    double acc[3], gyr[3], vel[3], pos[3];
+    double rot[9]; /* row-major */
+} s2m_imu_pose;
+
+/* Motion compensation of a raw scan: the backward-propagation loop of ImuProcess::UndistortPcl
+ * (IMU_Processing.hpp:333-370) plus the time sort in front of it (:215-216).  The sequential IMU
+ * forward/covariance propagation (:226-308) stays with the caller and provides `poses` (ascending
+ * offset_time) and state_end (rot_end, pos_end, R_L_I, T_L_I after :319-323).
+ * Each point record is `stride_floats` floats starting with x, y, z; its offset time is
+ * rec[time_off_a] * rec[time_off_b] (normal_x * normal_z: 4 and 6 in pcl::PointXYZINormal) or
+ * rec[time_off_a] alone when time_off_b < 0.  sort_by_time != 0 returns the points ordered by time like
+ * the reference (ties keep input order).  out_xyz: n x 3 packed floats (host, or device when
+ * on_device applies to input and output alike); perm (optional, host, n) receives the input index of
+ * each output point. */
+int s2m_undistort(s2m_engine *e, const float *points, int64_t stride_floats, int64_t n, int32_t time_off_a,
+                  int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses,
+                  const double state_end[S2M_STATE_DOUBLES], int sort_by_time, int on_device, float *out_xyz,
+                  uint32_t *perm);
+/* The node's front half of a frame kept on the device: undistort (time-sorted) -> VoxelGrid(leaf)
+ * -> current scan (IMU_Processing.hpp:333-370, laserMapping.cpp:775-778).  leaf <= 0 skips the
+ * down-sampling.  *n_out = feats_down_size. */
+int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride_floats, int64_t n, int32_t time_off_a,
+                          int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses,
+                          const double state_end[S2M_STATE_DOUBLES], float leaf, int on_device, int64_t *n_out);
+
 /* Output of one residual/Jacobian pass. */
 typedef struct {
     double  HtH[144];        /* Hsub^T * Hsub, row-major 12x12        laserMapping.cpp:1015 */

@@ -318,3 +318,15 @@ def voxel_downsample(xyz, leaf=0.5):
     if m < 0:
         raise OverflowError("leaf too small")
     return out[:m].copy()
+
+
+def undistort(records, off_a, off_b, poses, state_end, sort=True):
+    rec = np.ascontiguousarray(records, np.float32)
+    poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 22)
+    st = np.ascontiguousarray(state_end, float)
+    n = len(rec)
+    out = np.zeros((max(n, 1), 3), np.float32)
+    perm = np.zeros(max(n, 1), np.uint32)
+    lib().orc_undistort(_p(rec), C.c_int64(rec.shape[1]), C.c_int64(n), C.c_int(off_a), C.c_int(off_b), _p(poses),
+                        C.c_int(len(poses)), _p(st), C.c_int(int(sort)), _p(out), _p(perm))
+    return out[:n], perm[:n]

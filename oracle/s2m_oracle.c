@@ -1015,3 +1015,82 @@ int64_t orc_voxel_downsample(const float *xyz, int64_t n, float leaf, float *out
     free(v);
     return m;
 }
+
+/* ======================================================================================== */
+/* scan undistortion                                                       */
+/* ======================================================================================== */
+typedef struct { float t; int64_t i; } ud_pair;
+static int ud_cmp(const void *a, const void *b)
+{
+    const ud_pair *x = (const ud_pair *)a, *y = (const ud_pair *)b;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->i < y->i ? -1 : (x->i > y->i ? 1 : 0);
+}
+/* Exp(ang_vel, dt), so3_math.h:31-52 */
+static void so3_exp_rate(const double w[3], double dt, double R[9])
+{
+    double n = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (n > 0.0000001) {
+        double r[3] = {w[0] / n, w[1] / n, w[2] / n};
+        double K[9] = {0.0, -r[2], r[1], r[2], 0.0, -r[0], -r[1], r[0], 0.0};
+        double ang = n * dt, sn = sin(ang), c1 = 1.0 - cos(ang), cK[9], cKK[9];
+        for (int i = 0; i < 9; ++i) cK[i] = c1 * K[i];
+        mat3_mul(cK, K, cKK);
+        for (int i = 0; i < 9; ++i) R[i] = (I[i] + sn * K[i]) + cKK[i];
+    } else {
+        memcpy(R, I, sizeof(I));
+    }
+}
+void orc_undistort(const float *rec, int64_t stride, int64_t n, int off_a, int off_b, const double *poses, int K,
+                   const orc_state *end, int sort, float *out, uint32_t *perm)
+{
+    if (n <= 0) return;
+    ud_pair *v = (ud_pair *)malloc(sizeof(ud_pair) * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const float *r = rec + i * stride;
+        v[i].t = off_b >= 0 ? r[off_a] * r[off_b] : r[off_a];
+        v[i].i = i;
+    }
+    if (sort) qsort(v, (size_t)n, sizeof(ud_pair), ud_cmp);                     /* :216 */
+    for (int64_t s = 0; s < n; ++s) {                                           /* pcl_out = *(meas.lidar) */
+        const float *r = rec + v[s].i * stride;
+        out[3 * s] = r[0]; out[3 * s + 1] = r[1]; out[3 * s + 2] = r[2];
+        if (perm) perm[s] = (uint32_t)v[s].i;
+    }
+    if (!sort) {
+        /* the reference loop walks the cloud backwards in time order; without the sort each point is
+         * still handled by the same head, so process in time order and write back in input order */
+        ud_pair *w = (ud_pair *)malloc(sizeof(ud_pair) * (size_t)n);
+        memcpy(w, v, sizeof(ud_pair) * (size_t)n);
+        qsort(w, (size_t)n, sizeof(ud_pair), ud_cmp);
+        free(v);
+        v = w;
+    }
+    /* :333-370 */
+    int64_t it = n - 1;
+    int stop = 0;
+    for (int kp = K - 1; kp >= 1 && !stop; --kp) {
+        const double *head = poses + 22 * (kp - 1);
+        const double *acc = head + 1, *gyr = head + 4, *vel = head + 7, *pos = head + 10, *R = head + 13;
+        for (; (double)v[it].t > head[0]; --it) {
+            const double dt = (double)v[it].t - head[0];
+            const int64_t o = sort ? it : v[it].i;   /* output slot */
+            double E[9], Ri[9], Tei[3], Pi[3], a[3], b[3], c[3], d[3];
+            so3_exp_rate(gyr, dt, E);
+            mat3_mul(R, E, Ri);
+            for (int k = 0; k < 3; ++k) Tei[k] = ((pos[k] + vel[k] * dt) + (0.5 * acc[k]) * dt * dt) - end->pos[k];
+            for (int k = 0; k < 3; ++k) Pi[k] = (double)out[3 * o + k];
+            mat3_vec(end->R_LI, Pi, a);
+            for (int k = 0; k < 3; ++k) a[k] = a[k] + end->T_LI[k];
+            mat3_vec(Ri, a, b);
+            for (int k = 0; k < 3; ++k) b[k] = b[k] + Tei[k];
+            mat3_tvec(end->rot, b, c);
+            for (int k = 0; k < 3; ++k) c[k] = c[k] - end->T_LI[k];
+            mat3_tvec(end->R_LI, c, d);
+            for (int k = 0; k < 3; ++k) out[3 * o + k] = (float)d[k];
+            if (it == 0) { stop = 1; break; }
+        }
+    }
+    free(v);
+}

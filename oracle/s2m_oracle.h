@@ -177,6 +177,16 @@ void orc_map_incremental_lists(const float *scan_xyz, int64_t n, const orc_state
  * when the voxel index would overflow int32 (PCL then returns the input cloud unchanged). */
 int64_t orc_voxel_downsample(const float *xyz, int64_t n, float leaf, float *out);
 
+/* ---- scan undistortion -------------------------------------------------------
+ * The time sort and the backward-propagation loop of ImuProcess::UndistortPcl
+ * (IMU_Processing.hpp:215-216, 333-370), loop structure as written there.  rec: n records of `stride`
+ * floats starting with x, y, z; offset time = rec[off_a] * rec[off_b] (float) or rec[off_a] when
+ * off_b < 0.  poses: K x 22 doubles {offset_time, acc3, gyr3, vel3, pos3, rot9} = IMUpose.
+ * out: n x 3, in time order when sort != 0 (ties keep input order; std::sort leaves them unspecified);
+ * perm[n] = input index of each output point. */
+void orc_undistort(const float *rec, int64_t stride, int64_t n, int off_a, int off_b, const double *poses, int K,
+                   const orc_state *end, int sort, float *out, uint32_t *perm);
+
 #ifdef __cplusplus
 }
 #endif

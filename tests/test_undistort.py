@@ -1,0 +1,97 @@
+"""Scan undistortion: the backward-propagation loop of ImuProcess::UndistortPcl."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from conftest import bits
+
+
+def _scenario(n=20000, K=12, seed=0):
+    """A 0.1 s sweep with the sensor turning and accelerating; records mimic PointXYZINormal
+    (normal_x = time ratio at float 4, normal_z = time span at float 6)."""
+    rs = np.random.RandomState(seed)
+    span = 0.1
+    rec = np.zeros((n, 12), np.float32)
+    rec[:, :3] = rs.uniform(-30, 30, (n, 3))
+    rec[:, 4] = rs.uniform(0, 1, n)           # normal_x: time ratio
+    rec[:, 6] = span                          # normal_z: time span
+    rec[:5, 4] = 0.0                          # points at t = 0 are left untouched (t <= IMUpose[0].offset_time)
+    rec[5:10, 4] = rec[10, 4]                 # equal times: the stable order must hold
+    times = np.linspace(0.0, span * 1.02, K)  # the last pose lies beyond the scan end, like imu_end > pcl_end
+    poses = np.zeros((K, 22))
+    R = np.eye(3); p = np.array([1.0, 2.0, 0.5]); v = np.array([2.0, -1.0, 0.2])
+    for k in range(K):
+        w = np.array([0.3, -0.2, 0.8]) + 0.05 * k
+        a = np.array([0.5, 0.1, -0.3]) * (1 + 0.1 * k)
+        poses[k, 0] = times[k]
+        poses[k, 1:4], poses[k, 4:7], poses[k, 7:10], poses[k, 10:13] = a, w, v, p
+        poses[k, 13:22] = R.ravel()
+        if k + 1 < K:
+            dt = times[k + 1] - times[k]
+            R = R @ Rotation.from_rotvec(w * dt).as_matrix()
+            p = p + v * dt + 0.5 * a * dt * dt
+            v = v + a * dt
+    end = np.zeros(36)
+    end[0:9] = (R @ Rotation.from_rotvec([0.001, 0.002, -0.001]).as_matrix()).ravel()
+    end[9:12] = p + v * 0.001
+    end[12:21] = Rotation.from_rotvec([0.01, -0.02, 0.03]).as_matrix().ravel()
+    end[21:24] = [0.05, -0.02, 0.1]
+    return rec, poses, end
+
+
+def test_oracle_undistort_against_direct_formula(oracle):
+    rec, poses, end = _scenario(n=3000)
+    out, perm = oracle.undistort(rec, 4, 6, poses, end, sort=True)
+    t = (rec[:, 4] * rec[:, 6])
+    assert (np.diff(t[perm]) >= 0).all()                         # time order
+    same = t[perm][1:] == t[perm][:-1]
+    assert (np.diff(perm.astype(np.int64))[same] > 0).all()      # ties keep input order
+    Rend, pend = end[0:9].reshape(3, 3), end[9:12]
+    RLI, TLI = end[12:21].reshape(3, 3), end[21:24]
+    for s in (0, 7, 100, 1500, 2999):
+        i = perm[s]
+        ti = float(t[i])
+        heads = [h for h in range(len(poses) - 1) if poses[h, 0] < ti]
+        if not heads:
+            assert (out[s] == rec[i, :3]).all()
+            continue
+        h = heads[-1]
+        dt = ti - poses[h, 0]
+        Ri = poses[h, 13:22].reshape(3, 3) @ Rotation.from_rotvec(poses[h, 4:7] * dt).as_matrix()
+        Tei = poses[h, 10:13] + poses[h, 7:10] * dt + 0.5 * poses[h, 1:4] * dt * dt - pend
+        ref = RLI.T @ (Rend.T @ (Ri @ (RLI @ rec[i, :3].astype(np.float64) + TLI) + Tei) - TLI)
+        assert np.abs(out[s] - ref).max() < 2e-5
+    # unsorted variant: same values, input order
+    out2, perm2 = oracle.undistort(rec, 4, 6, poses, end, sort=False)
+    assert (perm2 == np.arange(len(rec))).all() and (bits(out2[perm]) == bits(out)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_undistort_matches_oracle(oracle):
+    from daliti_amd import Engine, synth
+    rec, poses, end = _scenario(n=65536)
+    e = Engine()
+    e.map_build(synth.make_map(20000))
+    for sort in (True, False):
+        got, perm = e.undistort(rec, 4, 6, poses, end, sort_by_time=sort)
+        ref, rperm = oracle.undistort(rec, 4, 6, poses, end, sort=sort)
+        assert (perm == rperm).all()
+        # device sin/cos may differ from glibc in the last bit: at most one float ulp, and rarely
+        diff = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+        assert (diff <= np.spacing(np.abs(ref)).astype(np.float64)).all()
+        assert (bits(got) != bits(ref)).mean() < 1e-3
+    # single time field, no second factor
+    rec1 = rec.copy()
+    rec1[:, 4] = rec[:, 4] * rec[:, 6]
+    got1, _ = e.undistort(rec1, 4, -1, poses, end)
+    ref1, _ = oracle.undistort(rec1, 4, -1, poses, end)
+    assert (np.abs(got1 - ref1) <= np.spacing(np.abs(ref1))).all()
+    # fused front half of a frame: undistort -> VoxelGrid -> current scan, all on the device
+    m = e.scan_set_from_raw(rec, 4, 6, poses, end, leaf=0.5)
+    und, _ = oracle.undistort(rec, 4, 6, poses, end, sort=True)
+    ref_ds = oracle.voxel_downsample(und, 0.5)
+    got_ds = e.scan_get()
+    assert m == len(got_ds) and abs(m - len(ref_ds)) <= 2      # a one-ulp difference can move a point across a voxel face
+    if m == len(ref_ds):
+        assert np.abs(got_ds - ref_ds).max() < 1e-3
+    e.close()
