@@ -185,7 +185,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         m.grid = e->grid; m.pose = pose; m.gates = gates;
         m.sx = sx; m.sy = sy; m.sz = sz; m.n = n;
         m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
-        m.hard_list = e->d_hard; m.hard_count = e->d_hard + e->n_cap;
+        m.hard_list = e->d_hard; m.hard_count = e->d_hard + 3 * e->n_cap;
         m.dbg = e->dbg ? e->d_dbg : nullptr;
         launch_match(m, e->match_group, e->stream);  // hard_count is zero: reset by every reduce launch
         e->nn_valid = true;
@@ -198,7 +198,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     r.nn_idx = e->d_nn_idx; r.nn_d2 = e->d_nn_d2; r.porig = e->grid.porig;
     r.plane = e->d_plane; r.flags = e->d_flags; r.sel = e->d_sel; r.eff = e->d_eff; r.pd2 = e->d_pd2;
     r.partials = e->d_partials; r.block = d_out;
-    r.ticket = e->d_ticket; r.hard_count = e->d_hard + e->n_cap;
+    r.ticket = e->d_ticket; r.hard_count = e->d_hard + 3 * e->n_cap;
     const bool publish = e->host_poll && d_out == e->d_block;
     r.host_block = publish ? e->h_block_dev : nullptr;
     r.host_flag = publish ? reinterpret_cast<unsigned long long *>(e->h_block_dev + S2M_BLOCK_DOUBLES) : nullptr;
@@ -512,8 +512,8 @@ int scan_reserve(s2m_engine *e, int64_t n)
     rc = rc ? rc : grow(e, &e->d_nn_d2, cap * S2M_K);
     rc = rc ? rc : grow(e, &e->d_partials, (int64_t)std::max(reduce_blocks((int)cap), 1) * kRedTerms);
     rc = rc ? rc : grow(e, &e->d_block_off, (int64_t)rows_blocks((int)cap) + 1);
-    rc = rc ? rc : grow(e, &e->d_hard, cap + 16);
-    if (!rc) S2M_HIP(e, hipMemsetAsync(e->d_hard + cap, 0, 16 * sizeof(uint32_t), e->stream));
+    rc = rc ? rc : grow(e, &e->d_hard, 3 * cap + 16);
+    if (!rc) S2M_HIP(e, hipMemsetAsync(e->d_hard + 3 * cap, 0, 16 * sizeof(uint32_t), e->stream));
     if (e->dbg) rc = rc ? rc : grow(e, &e->d_dbg, cap * 4);
     if (rc) return rc;
     e->n_cap = cap;

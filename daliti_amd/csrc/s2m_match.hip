@@ -44,6 +44,10 @@ constexpr u64 kEmptyKey = S2M_INSERT_F64 ? 0x7ff0000000000000ull : ~0ull;
 #define S2M_EASY_BATCH 8
 #endif
 constexpr int kEasyBatch = S2M_EASY_BATCH;  // point loads in flight per lane in the first-shell kernel
+#ifndef S2M_HARD_BATCH
+#define S2M_HARD_BATCH 8
+#endif
+constexpr int kHardBatch = S2M_HARD_BATCH;  // same for the one-cell-per-lane kernel
 
 __device__ __forceinline__ u64 make_key(float d2, uint32_t orig)
 {
@@ -276,13 +280,29 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
     const bool found5 = best[kK - 1] != kEmptyKey;
     const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
     const bool done = found5 && d5 <= cube_bound2(g, q, 1);
+    // Unresolved points go to one of three lists by expected cost (cube radius implied by the current
+    // 5th-best distance; unknown when fewer than five were found): match_hard starts the expensive ones
+    // first so they do not form the tail of the launch.  One atomic per wave and list: same-address
+    // atomics serialise in L2 (~90 per microsecond), ten thousand per-lane atomics would cost > 100 us.
+    const int rn_est = found5 ? (int)ceilf(sqrtf(d5) * g.inv_c * 1.000002f - q.fmin + g.slop) : 4;
+    const int cls = (j == 0 && !done) ? (rn_est <= 2 ? 2 : (rn_est == 3 ? 1 : 0)) : -1;
+    const int lane64 = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned long long mask = __ballot(cls == c);
+        if (mask == 0ull) continue;  // wave-uniform
+        const int leader = __ffsll((long long)mask) - 1;
+        uint32_t base = 0;
+        if (lane64 == leader) base = atomicAdd(a.hard_count + c, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader, 64);
+        if (cls == c) {
+            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull));
+            a.hard_list[(int64_t)c * a.n + base + rank] = (uint32_t)qi;
+        }
+    }
     if (j == 0) {
         // unresolved points keep their first-shell list too: match_hard continues from it
         store_result(best, qi, a.nn_idx, a.nn_d2);
-        if (!done) {
-            const uint32_t pos = atomicAdd(a.hard_count, 1u);
-            a.hard_list[pos] = (uint32_t)qi;
-        }
         if (a.dbg) {
             a.dbg[4 * (int64_t)qi + 0] = (uint32_t)(wall_clock64() - t0);
             a.dbg[4 * (int64_t)qi + 1] = done ? 1u : 0u;
@@ -300,11 +320,15 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
     const int lane = threadIdx.x & (G - 1);                           // lane within the group
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / G;     // group index
     const int nwaves = (gridDim.x * blockDim.x) / G;
-    const uint32_t count = *a.hard_count;
+    const uint32_t c0 = a.hard_count[0], c1 = a.hard_count[1], c2 = a.hard_count[2];
+    const uint32_t count = c0 + c1 + c2;
     const int rcap = max(max(g.ncx, g.ncy), g.ncz);
     for (uint32_t h = wave; h < count; h += nwaves) {
         const long long t0 = a.dbg ? wall_clock64() : 0;
-        const int qi = (int)a.hard_list[h];
+        // concatenation [far | mid | near]: the most expensive points are handed out first
+        const int qi = (int)(h < c0 ? a.hard_list[h]
+                                    : (h < c0 + c1 ? a.hard_list[(int64_t)a.n + (h - c0)]
+                                                   : a.hard_list[2 * (int64_t)a.n + (h - c0 - c1)]));
         const Query q = make_query(g, a.pose, a.sx[qi], a.sy[qi], a.sz[qi]);
         // smallest radius whose bound passes the d2 gate: beyond it the 5th neighbour cannot matter
         const int rgate = (int)ceilf(sqrtf(a.gates.knn_d2_gate) * g.inv_c * 1.000002f - q.fmin + g.slop) + 1;
@@ -345,7 +369,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
                 const uint32_t mword = (rowbit & 32) ? te.w : te.z;
                 if (te.x == 0 || ((mword >> (rowbit & 31)) & 1u) == 0) continue;
                 const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + (rowbit << 3) + (xx & 7);
-                scan_points<4>(g.pts, tb[0], tb[1], q.wx, q.wy, q.wz, t);
+                scan_points<kHardBatch>(g.pts, tb[0], tb[1], q.wx, q.wy, q.wz, t);
             }
             rdone = r;
             ++rounds;
