@@ -122,9 +122,48 @@ __device__ __forceinline__ void scan_row(const Grid &g, int yy, int zz, int xa, 
     }
 }
 
+// ---- group-wide minimum of a 64-bit key ------------------------------------------------------------
+// Generic form: xor-shuffle butterfly (ds_bpermute, ~100+ cycles per step).  For a whole wave and for
+// quads the minimum is taken with DPP instead (v_min_u32_dpp: no LDS pipe, a few cycles per step), in
+// two 32-bit phases: the smallest high word first, then the smallest low word among its holders.
+__device__ __forceinline__ uint32_t dpp_min_step(uint32_t v, const int ctrl_tag)
+{
+    // the control word must be a compile-time constant, hence the switch
+    uint32_t o;
+    switch (ctrl_tag) {
+        case 0: o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x111, 0xf, 0xf, false); break;  // row_shr:1
+        case 1: o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x112, 0xf, 0xf, false); break;  // row_shr:2
+        case 2: o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x114, 0xf, 0xf, false); break;  // row_shr:4
+        case 3: o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x118, 0xf, 0xf, false); break;  // row_shr:8
+        case 4: o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x142, 0xa, 0xf, false); break;  // row_bcast:15
+        case 5: o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x143, 0xc, 0xf, false); break;  // row_bcast:31
+        case 6: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, true); break;              // quad_perm [1,0,3,2]
+        default: o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, true); break;             // quad_perm [2,3,0,1]
+    }
+    return min(v, o);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v = dpp_min_step(v, k);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);  // lane 63 holds the minimum of the whole wave
+}
+__device__ __forceinline__ uint32_t quad_min_u32(uint32_t v)
+{
+    v = dpp_min_step(v, 6);
+    return dpp_min_step(v, 7);
+}
+
 template <int G>
 __device__ __forceinline__ u64 group_min_u64(u64 v)
 {
+    if (G == 64 || G == 4) {
+        const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+        const uint32_t mh = (G == 64) ? wave_min_u32(hi) : quad_min_u32(hi);
+        const uint32_t lo2 = (hi == mh) ? lo : 0xffffffffu;
+        const uint32_t ml = (G == 64) ? wave_min_u32(lo2) : quad_min_u32(lo2);
+        return ((u64)mh << 32) | (u64)ml;
+    }
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) {
         const u64 o = __shfl_xor(v, off, G);
@@ -271,15 +310,49 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
     u64 t[kK], best[kK];
 #pragma unroll
     for (int k = 0; k < kK; ++k) t[k] = kEmptyKey;
+#if defined(S2M_ABLATE) && S2M_ABLATE == 1   // timing experiment: lookups only, no point loads
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) t[0] = t[0] < (u64)(s[i][p] + e[i][p]) ? t[0] : (u64)(s[i][p] + e[i][p]);
+    }
+#elif defined(S2M_ABLATE) && S2M_ABLATE == 2  // timing experiment: point loads + distances, no selection
+    {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                for (uint32_t k = s[i][p]; k < e[i][p]; k += 8) {
+                    float4 pp[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) pp[u] = g.pts[min(k + u, e[i][p] - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float dx = q.wx - pp[u].x, dy = q.wy - pp[u].y, dz = q.wz - pp[u].z;
+                        float d = dx * dx + dy * dy;
+                        d = d + dz * dz;
+                        acc = fminf(acc + 1.0f, d);
+                    }
+                }
+        }
+        t[0] = make_key(acc, 0);
+    }
+#else
 #pragma unroll
     for (int i = 0; i < R; ++i) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) scan_points<kEasyBatch>(g.pts, s[i][p], e[i][p], q.wx, q.wy, q.wz, t);
     }
+#endif
     merge_lists<G>(t, best);
     const bool found5 = best[kK - 1] != kEmptyKey;
     const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
+#ifdef S2M_ABLATE
+    const bool done = true;  // experiments never feed the hard kernel
+#else
     const bool done = found5 && d5 <= cube_bound2(g, q, 1);
+#endif
     // Unresolved points go to one of three lists by expected cost (cube radius implied by the current
     // 5th-best distance; unknown when fewer than five were found): match_hard starts the expensive ones
     // first so they do not form the tail of the launch.  One atomic per wave and list: same-address
@@ -312,17 +385,49 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
     }
 }
 
-// ---- the rest: G lanes (a whole or a fraction of a wave) per hard scan point ------------------------
-template <int G>
+// ---- the rest: one wave per hard scan point, occupied rows only ------------------------------------
+// k-th (0-based) set bit of a 64-bit mask; k < popcount(m)
+__device__ __forceinline__ int kth_set_bit(uint64_t m, int k)
+{
+    int pos = 0;
+    uint32_t lo = (uint32_t)m;
+    int c = __popc(lo);
+    if (k >= c) { k -= c; pos = 32; lo = (uint32_t)(m >> 32); }
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+        const uint32_t part = lo & ((1u << w) - 1u);
+        c = __popc(part);
+        if (k >= c) { k -= c; pos += w; lo >>= w; } else { lo = part; }
+    }
+    return pos;
+}
+
+// A hard point is one whose 5th neighbour is not provably inside the 3x3x3 cells.  Growing a cube
+// cell by cell costs O(r^3) lookups although LiDAR maps are surfaces; instead the wave reads the top
+// entries of the surrounding bricks once (lane b = brick b) and enumerates only their OCCUPIED
+// (y,z) rows from the 64-bit row masks.  Each (brick,row) pair gets a lower bound from its (y,z)
+// offset; a pair is scanned -- restricted to the x-cells the current radius can reach -- only if that
+// bound is within the radius.  With five neighbours already known from the first shell their 5th
+// distance is the radius and a single round finishes the point; otherwise the radius grows band by
+// band over the same pair list until five are found, and stops at the d2 <= 5 gate (:853).
+constexpr int kPairSlots = 6;  // (brick,row) pairs a lane can hold per chunk of 64 bricks
+
 __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
 {
+    constexpr int G = 64;
+    constexpr int kMaxDesc = 192;
+    __shared__ uint32_t desc_all[4][kMaxDesc][3];  // one descriptor list per wave of the workgroup
+    uint32_t (*desc)[3] = desc_all[threadIdx.x >> 6];
     const Grid &g = a.grid;
-    const int lane = threadIdx.x & (G - 1);                           // lane within the group
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / G;     // group index
-    const int nwaves = (gridDim.x * blockDim.x) / G;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint32_t c0 = a.hard_count[0], c1 = a.hard_count[1], c2 = a.hard_count[2];
     const uint32_t count = c0 + c1 + c2;
-    const int rcap = max(max(g.ncx, g.ncy), g.ncz);
+    // brick rings needed so that the neighbourhood covers the gate radius from anywhere in the home brick
+    const float gate_r = sqrtf(a.gates.knn_d2_gate);
+    const int NB = max(1, (int)ceilf(gate_r * g.inv_c * 0.125f + 1e-3f));
+    const int bside = 2 * NB + 1, nbricks = bside * bside * bside;
     for (uint32_t h = wave; h < count; h += nwaves) {
         const long long t0 = a.dbg ? wall_clock64() : 0;
         // concatenation [far | mid | near]: the most expensive points are handed out first
@@ -330,67 +435,171 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
                                     : (h < c0 + c1 ? a.hard_list[(int64_t)a.n + (h - c0)]
                                                    : a.hard_list[2 * (int64_t)a.n + (h - c0 - c1)]));
         const Query q = make_query(g, a.pose, a.sx[qi], a.sy[qi], a.sz[qi]);
-        // smallest radius whose bound passes the d2 gate: beyond it the 5th neighbour cannot matter
-        const int rgate = (int)ceilf(sqrtf(a.gates.knn_d2_gate) * g.inv_c * 1.000002f - q.fmin + g.slop) + 1;
-        // continue from the first shell: lane 0 carries its five keys, the cube of radius 1 is done
+        const float fxq = (float)q.cx + q.frx;  // query x in cell units
+        // radius: the first shell's 5th-best distance when it found five (then one round is exact)
+        const int32_t ci4 = a.nn_idx[(int64_t)qi * kK + (kK - 1)];
+        const float cd4 = a.nn_d2[(int64_t)qi * kK + (kK - 1)];
+        bool have_tau = ci4 >= 0;
+        float tau = have_tau ? cd4 : 0.0f;  // squared
         u64 t[kK], best[kK];
 #pragma unroll
-        for (int k = 0; k < kK; ++k) {
-            const int32_t ci = a.nn_idx[(int64_t)qi * kK + k];
-            const float cd = a.nn_d2[(int64_t)qi * kK + k];
-            t[k] = (lane == 0 && ci >= 0) ? make_key(cd, (uint32_t)ci) : kEmptyKey;
-            best[k] = (ci >= 0) ? make_key(cd, (uint32_t)ci) : kEmptyKey;
-        }
-        int rdone = 1;
-        int r;
-        {
-            const bool f5 = best[kK - 1] != kEmptyKey;
-            const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
-            const int rn = f5 ? (int)ceilf(sqrtf(d5) * g.inv_c * 1.000002f - q.fmin + g.slop) : 2;
-            r = min(min(max(rn, 2), max(rgate, 2)), max(rcap, 2));
-        }
+        for (int k = 0; k < kK; ++k) { t[k] = kEmptyKey; best[k] = kEmptyKey; }
+        float band = 2.0f * g.c;   // band radius while no radius is known (the first shell already covered c)
         uint32_t rounds = 0;
-        for (;;) {
-            // scan the shell (rdone, r]: one cell per lane, so every lane's top entry, table pair and
-            // point loads are in flight together; cells of the already scanned inner cube and cells
-            // that cannot hold anything closer than the current 5th-best are skipped
-            const float tau = __uint_as_float((uint32_t)(best[kK - 1] >> 32));  // +inf/NaN pattern when < 5 found
-            const bool have_tau = best[kK - 1] != kEmptyKey;
-            const int side = 2 * r + 1;
-            const int ncell = side * side * side;
-            for (int ci = lane; ci < ncell; ci += G) {
-                const int dx = (ci % side) - r, dy = ((ci / side) % side) - r, dz = (ci / (side * side)) - r;
-                if (max(max(abs(dx), abs(dy)), abs(dz)) <= rdone) continue;
-                const int xx = q.cx + dx, yy = q.cy + dy, zz = q.cz + dz;
-                if (xx < 0 || xx >= g.ncx || yy < 0 || yy >= g.ncy || zz < 0 || zz >= g.ncz) continue;
-                if (have_tau && cell_bound2(g, q, dx, dy, dz) > tau) continue;
-                const int rowbit = ((zz & 7) << 3) | (yy & 7);
-                const uint4 te = g.top[((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx + (xx >> 3)];
-                const uint32_t mword = (rowbit & 32) ? te.w : te.z;
-                if (te.x == 0 || ((mword >> (rowbit & 31)) & 1u) == 0) continue;
-                const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + (rowbit << 3) + (xx & 7);
-                scan_points<kHardBatch>(g.pts, tb[0], tb[1], q.wx, q.wy, q.wz, t);
+        const int hbx = q.cx >> 3, hby = q.cy >> 3, hbz = q.cz >> 3;
+        uint32_t dbg_top = 0, dbg_scan = 0, dbg_merge = 0;
+        int nq = 0;  // qualifying (brick,row) pairs waiting in the wave's descriptor list (wave-uniform)
+        // Descriptors {brick id, row | cells << 8, first cell}: every lane takes one, the cells of all of them
+        // are numbered with a wave prefix sum, and cell j goes to lane j % 64 -- so the point loads of all
+        // qualifying rows of all slots are in flight together instead of slot after slot.
+        auto flush_desc = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // descriptor stores before the loads below
+            for (int cb = 0; cb < nq; cb += 64) {
+                const int k = cb + lane;
+                uint32_t did = 0, drow = 0, dxa = 0;
+                int dn = 0;
+                if (k < nq) { did = desc[k][0]; const uint32_t w = desc[k][1]; drow = w & 0xffu; dn = (int)(w >> 8); dxa = desc[k][2]; }
+                int cincl = dn;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(cincl, off, 64);
+                    if (lane >= off) cincl += v;
+                }
+                const int cexcl = cincl - dn;
+                const int ctotal = __shfl(cincl, 63, 64);
+                for (int jb = 0; jb < ctotal; jb += 64) {  // wave-uniform trip count
+                    const int j = jb + lane;
+                    int o2 = 0;
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1) {
+                        const int cand = o2 + step;
+                        const int pc = __shfl(cexcl, min(cand, 63), 64);
+                        if (cand < 64 && pc <= j) o2 = cand;
+                    }
+                    const uint32_t jid = __shfl(did, o2, 64);
+                    const int jrow = (int)__shfl(drow, o2, 64), jxa = (int)__shfl(dxa, o2, 64), jex = __shfl(cexcl, o2, 64);
+                    if (j < ctotal) {
+                        const int x = jxa + (j - jex);
+                        const uint32_t *tb = g.tab + (int64_t)(jid - 1) * kBrickStride + (jrow << 3) + (x & 7);
+                        scan_points<kHardBatch>(g.pts, tb[0], tb[1], q.wx, q.wy, q.wz, t);
+                    }
+                }
             }
-            rdone = r;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // loads above before the next stores
+        };
+        for (;;) {
+            const long long ph0 = a.dbg ? wall_clock64() : 0;
+            long long ph1 = ph0;
+            const float r2 = have_tau ? tau : band * band;  // scan every pair whose bound is within r2
+            // x reach (cells) as a function of the pair's bound is computed per pair below
+            for (int bbase = 0; bbase < nbricks; bbase += 64) {
+                // 1. top entries of up to 64 bricks, one per lane
+                const int b = bbase + lane;
+                uint32_t my_id = 0;
+                uint64_t my_mask = 0;
+                int bx = 0, by = 0, bz = 0;
+                if (b < nbricks) {
+                    bx = hbx + (b % bside) - NB;
+                    by = hby + ((b / bside) % bside) - NB;
+                    bz = hbz + (b / (bside * bside)) - NB;
+                    if (bx >= 0 && bx < g.nbx && by >= 0 && by < g.nby && bz >= 0 && bz < g.nbz) {
+                        const uint4 te = g.top[((int64_t)bz * g.nby + by) * g.nbx + bx];
+                        my_id = te.x;
+                        my_mask = te.x ? ((uint64_t)te.w << 32 | te.z) : 0ull;
+                    }
+                }
+                // 2. exclusive prefix of the occupied-row counts over the lanes
+                const int cnt = __popcll(my_mask);
+                int incl = cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += v;
+                }
+                const int excl = incl - cnt;
+                const int total = __shfl(incl, 63, 64);
+                if (a.dbg) { ph1 = wall_clock64(); dbg_top += (uint32_t)(ph1 - ph0); }
+                // 3. (brick,row) pairs, round-robin over the lanes
+                for (int pbase = 0; pbase < total; pbase += 64 * kPairSlots) {
+#pragma unroll
+                    for (int slot = 0; slot < kPairSlots; ++slot) {
+                        if (pbase + slot * 64 >= total) break;  // wave-uniform
+                        const int p = pbase + slot * 64 + lane;
+                        // owner lane o: the last lane whose exclusive prefix is <= p (uniform loop of shuffles)
+                        int o = 0;
+#pragma unroll
+                        for (int step = 32; step >= 1; step >>= 1) {
+                            const int cand = o + step;
+                            const int pc = __shfl(excl, min(cand, 63), 64);
+                            if (cand < 64 && pc <= p) o = cand;
+                        }
+                        const uint32_t mlo = __shfl((uint32_t)my_mask, o, 64), mhi = __shfl((uint32_t)(my_mask >> 32), o, 64);
+                        const uint32_t oid = __shfl(my_id, o, 64);
+                        const int obx = __shfl(bx, o, 64), oby = __shfl(by, o, 64), obz = __shfl(bz, o, 64);
+                        const int oex = __shfl(excl, o, 64);
+                        // a lane's pair qualifies when its (y,z) bound is within the radius; its cells are then
+                        // spread over the whole wave (a row can hold ~100 points: one lane walking it alone
+                        // was measured to be the whole cost of this kernel)
+                        int rowbit = 0, xa = 0, ncell = 0;
+                        if (p < total) {
+                            const uint64_t om = ((uint64_t)mhi << 32) | mlo;
+                            rowbit = kth_set_bit(om, p - oex);
+                            const int yy = (oby << 3) + (rowbit & 7), zz = (obz << 3) + (rowbit >> 3);
+                            // lower bound of the (y,z) distance from the query to this row, in cells
+                            const int dy = yy - q.cy, dz = zz - q.cz;
+                            const float gy = dy > 0 ? (float)dy - q.fry : (dy < 0 ? q.fry - (float)(dy + 1) : 0.0f);
+                            const float gz = dz > 0 ? (float)dz - q.frz : (dz < 0 ? q.frz - (float)(dz + 1) : 0.0f);
+                            const float ay = fmaxf(gy - g.slop, 0.0f), az = fmaxf(gz - g.slop, 0.0f);
+                            const float b2 = (ay * ay + az * az) * (g.c * g.c) * 0.99999f;  // metres^2
+                            if (b2 <= r2) {
+                                // x cells the radius can reach in this row: |x - qx| <= sqrt(r2 - b2)
+                                const float reach = sqrtf(fmaxf(r2 - b2, 0.0f)) * g.inv_c * 1.00001f + g.slop;
+                                xa = max((int)floorf(fxq - reach), obx << 3);
+                                const int xb = min((int)floorf(fxq + reach), (obx << 3) + 7);
+                                ncell = max(xb - xa + 1, 0);
+                            }
+                        }
+                        // append the qualifying pairs to the wave's descriptor list (ballot-ranked)
+                        const unsigned long long qm = __ballot(ncell > 0);
+                        if (qm != 0ull) {
+                            if (nq + 64 > kMaxDesc) { flush_desc(); nq = 0; }
+                            if (ncell > 0) {
+                                const int pos = nq + __popcll(qm & ((1ull << lane) - 1ull));
+                                desc[pos][0] = oid;
+                                desc[pos][1] = (uint32_t)rowbit | ((uint32_t)ncell << 8);
+                                desc[pos][2] = (uint32_t)xa;
+                            }
+                            nq += __popcll(qm);
+                        }
+                    }
+                }
+            }
+            flush_desc();
+            nq = 0;
             ++rounds;
+            const long long ph2 = a.dbg ? wall_clock64() : 0;
             merge_lists<G>(t, best);
+            if (a.dbg) { dbg_scan += (uint32_t)(ph2 - ph1); dbg_merge += (uint32_t)(wall_clock64() - ph2); }
             const bool found5 = best[kK - 1] != kEmptyKey;
             const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
-            const float lb2 = cube_bound2(g, q, r);
-            if (found5 && d5 <= lb2) break;          // exact 5-NN found
-            if (lb2 > a.gates.knn_d2_gate) break;    // the 5th neighbour is beyond the gate (:853)
-            if (r >= rcap) break;                    // whole grid scanned
-            // all better candidates lie within sqrt(d5): jump straight to the radius covering it
-            int rn = found5 ? (int)ceilf(sqrtf(d5) * g.inv_c * 1.000002f - q.fmin + g.slop) : 2 * r;
-            r = min(max(rn, r + 1), max(rgate, r + 1));
-            r = min(r, rcap);
+            if (have_tau) break;  // every point within tau was visited: exact
+            // band mode: rows with bound <= band^2 were scanned over their whole reach of this band only,
+            // so restart the private lists when the radius changes (rows are rescanned with the new reach)
+            if (found5 && d5 <= band * band) break;          // five found inside the fully scanned band
+            if (band * band > a.gates.knn_d2_gate) break;    // beyond the gate: result is "not five within it"
+            if (found5) { have_tau = true; tau = d5; }       // radius known now: one exact round
+            else band = band * 2.0f;
+#pragma unroll
+            for (int k = 0; k < kK; ++k) t[k] = kEmptyKey;
         }
         if (lane == 0) {
             store_result(best, qi, a.nn_idx, a.nn_d2);
             if (a.dbg) {
                 a.dbg[4 * (int64_t)qi + 0] += (uint32_t)(wall_clock64() - t0);
-                a.dbg[4 * (int64_t)qi + 1] = (uint32_t)rdone;
-                a.dbg[4 * (int64_t)qi + 3] = rounds + 1;
+                a.dbg[4 * (int64_t)qi + 2] = (uint32_t)t0;  // absolute start tick (100 MHz) of the hard part
+                a.dbg[4 * (int64_t)qi + 1] = 2u + rounds;
+                a.dbg[4 * (int64_t)qi + 3] = (rounds + 1) | (min(dbg_top, 1023u) << 8) | (min(dbg_scan, 4095u) << 18);
+                (void)dbg_merge;
             }
         }
     }
@@ -414,13 +623,10 @@ void launch_match(const MatchArgs &a, int group, hipStream_t st)
         default: launch_easy<4>(a, st); break;
     }
     // fixed grid, groups stride over the hard list whose length is only known on the device
-    const int hg = (group >> 8) ? (group >> 8) : 64;  // hard-kernel group width rides in bits 8.. (tuning hook;
-                                                      // measured: 64 lanes per hard point is fastest, the far tail is latency-bound)
+    const int hg = 64;  // one wave per hard point (narrower groups measured slower: the far tail is latency-bound)
     const int64_t groups = std::min<int64_t>(a.n, 8192 * (64 / hg));
     const int blocks = (int)((groups * hg + 255) / 256);
-    if (hg == 16) hipLaunchKernelGGL(match_hard<16>, dim3(blocks), dim3(256), 0, st, a);
-    else if (hg == 64) hipLaunchKernelGGL(match_hard<64>, dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(match_hard<32>, dim3(blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(match_hard, dim3(blocks), dim3(256), 0, st, a);
 }
 
 }  // namespace s2m

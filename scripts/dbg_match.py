@@ -21,9 +21,15 @@ for g in [int(x) for x in os.environ.get("GROUPS", "4").split(",")]:
         cyc = d[:, 0].astype(float)
         print("G %d cell %.2f match %.1f us | cycles(100MHz ticks?) pct50 %.0f pct90 %.0f pct99 %.0f max %.0f sum %.3g" % (
             g, cell, ms * 1e3, *np.percentile(cyc, [50, 90, 99, 100]), cyc.sum()))
-        print("   hard fraction %.3f" % (d[:, 3] > 1).mean())
+        print("   hard fraction %.3f" % ((d[:, 3] & 0xff) > 1).mean())
+        hm = (d[:, 3] & 0xff) > 1
+        if hm.any():
+            st = d[hm, 2].astype(np.int64); st -= st.min()
+            print("   hard starts (us): pct50 %.1f pct90 %.1f max %.1f" % tuple(np.percentile(st, [50, 90, 100]) / 100.0))
+            top = ((d[hm, 3] >> 8) & 1023) / 100.0; scan = ((d[hm, 3] >> 18) & 4095) / 100.0
+            print("   hard phases (us, mean): top+prefix %.2f  pairs+scan %.2f  | total hard %.2f" % (top.mean(), scan.mean(), (cyc[hm].mean() - cyc[~hm].mean()) / 100.0))
         for r in range(1, 12):
             sel = d[:, 1] == r
             if sel.any():
-                print("   r=%2d n=%6d  mean cyc %.0f  rounds %.2f" % (r, sel.sum(), cyc[sel].mean(), d[sel, 3].mean()))
+                print("   r=%2d n=%6d  mean cyc %.0f  rounds %.2f" % (r, sel.sum(), cyc[sel].mean(), (d[sel, 3] & 0xff).mean()))
         e.close()
