@@ -254,10 +254,32 @@ __device__ __forceinline__ void store_result(const u64 (&best)[kK], int64_t q, i
 }
 
 // ---- first shell: 3x3x3 cells, G lanes per scan point -----------------------------------------------
+// one cell of the first shell: brick id (0 = nothing to read) and position of its table word
+struct CellRef {
+    uint32_t id;
+    int word;  // row offset + x within the brick
+};
+
+__device__ __forceinline__ CellRef cell_ref(const Grid &g, int xx, int yy, int zz, bool ok)
+{
+    CellRef r;
+    r.id = 0;
+    r.word = 0;
+    if (ok && xx >= 0 && xx < g.ncx && yy >= 0 && yy < g.ncy && zz >= 0 && zz < g.ncz) {
+        const int rowbit = ((zz & 7) << 3) | (yy & 7);
+        const uint4 te = g.top[((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx + (xx >> 3)];
+        const uint32_t mword = (rowbit & 32) ? te.w : te.z;
+        if ((mword >> (rowbit & 31)) & 1u) r.id = te.x;
+        r.word = (rowbit << 3) + (xx & 7);
+    }
+    return r;
+}
+
 template <int G>
 __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
 {
-    constexpr int R = (9 + G - 1) / G;  // x-rows per lane
+    constexpr int HC = (3 + G - 1) / G;  // home-row cells per lane
+    constexpr int RR = (8 + G - 1) / G;  // other x-rows per lane
     const long long t0 = a.dbg ? wall_clock64() : 0;
     const Grid &g = a.grid;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -266,93 +288,65 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
     if (qi >= a.n) return;  // group-uniform
     const Query q = make_query(g, a.pose, a.sx[qi], a.sy[qi], a.sz[qi]);
 
-    const int xlo = max(q.cx - 1, 0), xhi = min(q.cx + 1, g.ncx - 1);
-    const int b0 = xlo >> 3, b1 = xhi >> 3;
-    // phase 1: the top entries of every (row, brick) part of this lane
-    uint32_t id[R][2];
-    int rowoff[R];
+    // phase 1: top entries (brick id + row mask).  Home row first: its three cells one by one; then the
+    // eight other rows, three cells each.  Everything a lane needs in a phase is requested together.
+    CellRef hc[HC], rc[RR][3];
+    int rdy[RR], rdz[RR];
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const int row = j + i * G;
-        const int yy = q.cy + (row % 3) - 1, zz = q.cz + (row / 3) - 1;
-        const bool ok = row < 9 && xlo <= xhi && yy >= 0 && yy < g.ncy && zz >= 0 && zz < g.ncz;
-        const int rowbit = ((zz & 7) << 3) | (yy & 7);
-        rowoff[i] = rowbit << 3;
-        const int64_t toprow = ((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx;
+    for (int i = 0; i < HC; ++i) {
+        const int c = j + i * G;  // 0..2 -> dx = -1..1
+        hc[i] = cell_ref(g, q.cx + c - 1, q.cy, q.cz, c < 3);
+    }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            id[i][p] = 0;
-            if (ok && (p == 0 || b1 != b0)) {
-                const uint4 te = g.top[toprow + (p == 0 ? b0 : b1)];
-                const uint32_t mword = (rowbit & 32) ? te.w : te.z;
-                if ((mword >> (rowbit & 31)) & 1u) id[i][p] = te.x;
-            }
+    for (int i = 0; i < RR; ++i) {
+        const int r8 = j + i * G;             // 0..7 -> the rows (dy,dz) != (0,0)
+        const int row = r8 + (r8 >= 4 ? 1 : 0);  // skip the centre of the 3x3
+        rdy[i] = (row % 3) - 1;
+        rdz[i] = (row / 3) - 1;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rc[i][c] = cell_ref(g, q.cx + c - 1, q.cy + rdy[i], q.cz + rdz[i], r8 < 8);
+    }
+    // phase 2: table words [start, end) of every non-empty cell
+    uint32_t hs[HC], he[HC], rs[RR][3], re[RR][3];
+#pragma unroll
+    for (int i = 0; i < HC; ++i) {
+        hs[i] = 0; he[i] = 0;
+        if (hc[i].id) {
+            const uint32_t *tb = g.tab + (int64_t)(hc[i].id - 1) * kBrickStride + hc[i].word;
+            hs[i] = tb[0]; he[i] = tb[1];
         }
     }
-    // phase 2: the table words of every non-empty part
-    uint32_t s[R][2], e[R][2];
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
+    for (int i = 0; i < RR; ++i)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            s[i][p] = 0;
-            e[i][p] = 0;
-            if (id[i][p] != 0) {
-                const int bx = (p == 0) ? b0 : b1;
-                const int l0 = max(xlo, bx << 3) & 7, l1 = min(xhi, (bx << 3) + 7) & 7;
-                const uint32_t *tb = g.tab + (int64_t)(id[i][p] - 1) * kBrickStride + rowoff[i];
-                s[i][p] = tb[l0];
-                e[i][p] = tb[l1 + 1];
+        for (int c = 0; c < 3; ++c) {
+            rs[i][c] = 0; re[i][c] = 0;
+            if (rc[i][c].id) {
+                const uint32_t *tb = g.tab + (int64_t)(rc[i][c].id - 1) * kBrickStride + rc[i][c].word;
+                rs[i][c] = tb[0]; re[i][c] = tb[1];
             }
         }
-    }
-    // phase 3: the points
+    // phase 3a: the home row; its 5th-best distance (if it holds five points) prunes the rest
     u64 t[kK], best[kK];
 #pragma unroll
     for (int k = 0; k < kK; ++k) t[k] = kEmptyKey;
-#if defined(S2M_ABLATE) && S2M_ABLATE == 1   // timing experiment: lookups only, no point loads
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
+    for (int i = 0; i < HC; ++i) scan_points<kEasyBatch>(g.pts, hs[i], he[i], q.wx, q.wy, q.wz, t);
+    merge_lists<G>(t, best);
+    const bool have_tau = best[kK - 1] != kEmptyKey;
+    const float tau = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
+    // phase 3b: the other 24 cells, skipping those that cannot hold anything closer than tau
 #pragma unroll
-        for (int p = 0; p < 2; ++p) t[0] = t[0] < (u64)(s[i][p] + e[i][p]) ? t[0] : (u64)(s[i][p] + e[i][p]);
-    }
-#elif defined(S2M_ABLATE) && S2M_ABLATE == 2  // timing experiment: point loads + distances, no selection
-    {
-        float acc = 0.f;
+    for (int i = 0; i < RR; ++i)
 #pragma unroll
-        for (int i = 0; i < R; ++i) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-                for (uint32_t k = s[i][p]; k < e[i][p]; k += 8) {
-                    float4 pp[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) pp[u] = g.pts[min(k + u, e[i][p] - 1)];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float dx = q.wx - pp[u].x, dy = q.wy - pp[u].y, dz = q.wz - pp[u].z;
-                        float d = dx * dx + dy * dy;
-                        d = d + dz * dz;
-                        acc = fminf(acc + 1.0f, d);
-                    }
-                }
+        for (int c = 0; c < 3; ++c) {
+            if (rs[i][c] < re[i][c] && !(have_tau && cell_bound2(g, q, c - 1, rdy[i], rdz[i]) > tau))
+                scan_points<kEasyBatch>(g.pts, rs[i][c], re[i][c], q.wx, q.wy, q.wz, t);
         }
-        t[0] = make_key(acc, 0);
-    }
-#else
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) scan_points<kEasyBatch>(g.pts, s[i][p], e[i][p], q.wx, q.wy, q.wz, t);
-    }
-#endif
     merge_lists<G>(t, best);
     const bool found5 = best[kK - 1] != kEmptyKey;
     const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
-#ifdef S2M_ABLATE
-    const bool done = true;  // experiments never feed the hard kernel
-#else
     const bool done = found5 && d5 <= cube_bound2(g, q, 1);
-#endif
     // Unresolved points go to one of three lists by expected cost (cube radius implied by the current
     // 5th-best distance; unknown when fewer than five were found): match_hard starts the expensive ones
     // first so they do not form the tail of the launch.  One atomic per wave and list: same-address
@@ -374,7 +368,7 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
         }
     }
     if (j == 0) {
-        // unresolved points keep their first-shell list too: match_hard continues from it
+        // unresolved points keep their first-shell list too: match_hard takes its radius from it
         store_result(best, qi, a.nn_idx, a.nn_d2);
         if (a.dbg) {
             a.dbg[4 * (int64_t)qi + 0] = (uint32_t)(wall_clock64() - t0);
