@@ -1,0 +1,77 @@
+"""Randomised exactness stress of the GPU search against the oracle: cell sizes from far too small to
+far too large, coordinates kilometres from the origin (float cell arithmetic loses bits there; the
+termination bound carries a slop for it), clustered / planar / collinear / duplicated maps, queries
+inside, at the rim of and far outside the map."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(oracle, m, q, cell, x=None):
+    from daliti_amd import Engine, synth
+    e = Engine(cell_size=cell)
+    e.map_build(m)
+    e.scan_set(q)
+    x = synth.make_state() if x is None else x
+    e.residual_pass(x, True)
+    idx, d2 = e.get_neighbors()
+    st = e.get_point_state()
+    oi, od, oc = oracle.KdTree(m).knn5(oracle.body_to_world(x, q))
+    near = (oc == 5) & (od[:, 4] <= 5.0)
+    assert (bits(d2[near]) == bits(od[near])).all(), "d2 mismatch at cell %g" % cell
+    assert (idx[near] == oi[near]).all(), "index mismatch at cell %g" % cell
+    assert (st["selected"][~near] == 0).all()
+    far = ~near
+    assert ((d2[far, 4] > 5.0) | np.isinf(d2[far, 4])).all()
+    e.close()
+    return near.mean()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_clouds_and_cells(oracle, seed):
+    rs = np.random.RandomState(100 + seed)
+    kind = seed % 3
+    off = np.float32([0, 0, 0]) if seed < 3 else np.float32([3100.0, -2750.0, 410.0])
+    if kind == 0:      # volumetric uniform
+        m = rs.uniform(-8, 8, (30000, 3))
+    elif kind == 1:    # a thin slab + a line + duplicates
+        slab = np.c_[rs.uniform(-10, 10, (20000, 2)), rs.normal(0, 0.01, 20000)]
+        line = np.c_[np.linspace(-10, 10, 3000), np.zeros(3000), np.full(3000, 2.0)]
+        m = np.r_[slab, line, slab[:2000]]
+    else:              # clusters of very different density
+        c = rs.uniform(-10, 10, (12, 3))
+        m = np.r_[tuple(c[k] + rs.normal(0, 0.05 * (1 + k), (2500, 3)) for k in range(12))]
+    m = (m + off).astype(np.float32)
+    q = np.r_[rs.uniform(-11, 11, (1500, 3)), m[rs.choice(len(m), 300)] + rs.normal(0, 0.02, (300, 3)),
+              rs.uniform(-40, 40, (200, 3))]
+    q = (q + off * (np.arange(len(q))[:, None] < 1800)).astype(np.float32)   # the last 200 stay far away
+    fracs = [_check(oracle, m, q, cell) for cell in (0.07, 0.31, 1.0, 2.9, 0.0)]
+    assert min(fracs) == max(fracs)          # the same points are "near" whatever the grid
+
+
+def test_tiny_and_degenerate_maps(oracle):
+    rs = np.random.RandomState(7)
+    q = rs.uniform(-1, 1, (500, 3)).astype(np.float32)
+    for m in (np.zeros((1, 3)), np.zeros((5, 3)), np.zeros((7, 3)) + [0.1, 0, 0],      # identical points
+              rs.uniform(-1, 1, (6, 3)), np.c_[np.linspace(-1, 1, 50), np.zeros(50), np.zeros(50)]):
+        for cell in (0.05, 0.5, 4.0):
+            _check(oracle, m.astype(np.float32), q, cell)
+
+
+def test_rotated_far_pose(oracle):
+    """A non-trivial body->world pose with a large translation (double transform, float result)."""
+    from scipy.spatial.transform import Rotation
+    from daliti_amd import synth
+    rs = np.random.RandomState(9)
+    x = synth.make_state(Rotation.from_rotvec([0.4, -0.9, 2.0]).as_matrix(), [1500.0, 900.0, -30.0])
+    x[12:21] = Rotation.from_rotvec([0.02, 0.01, -0.03]).as_matrix().ravel()
+    x[21:24] = [0.3, -0.1, 0.2]
+    body = rs.uniform(-20, 20, (3000, 3)).astype(np.float32)
+    world = oracle.body_to_world(x, body)
+    m = (world[rs.choice(3000, 2500)] + rs.normal(0, 0.1, (2500, 3))).astype(np.float32)
+    m = np.r_[m, (world.mean(0) + rs.uniform(-25, 25, (40000, 3))).astype(np.float32)]
+    for cell in (0.2, 0.9, 0.0):
+        _check(oracle, m, body, cell, x)
