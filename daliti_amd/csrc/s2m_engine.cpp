@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -831,11 +832,18 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
     int rematch_num = 0, rematch_en = 0, it = 0, passes = 0;
     int32_t conv = 0, stop = 0;
     if (log) std::memset(log, 0, sizeof(*log));
+    static const bool tl = std::getenv("S2M_HOST_TIMELINE") != nullptr;  // dev probe: host-side timings
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::micro>(b - a).count();
+    };
     for (it = 0; it < max_iter; ++it) {
         const int rematch = (it == 0) || rematch_en;  // :847
         passes += rematch;
+        const auto t_a = now();
         int rc = run_pass(e, x, rematch, d_block);
         if (rc) return rc;
+        const auto t_b = now();
         if (reduce && reduce(user) != 0) return fail(e, S2M_ERR_HIP, "all-reduce callback failed");
         const double *hb = nullptr;
         // after a collective the summed block only exists in d_block: copy it; otherwise poll
@@ -848,6 +856,7 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         } else {
             rc = wait_block(e, d_block, &hb);
         }
+        const auto t_c = now();
         if (rc) return rc;
         rc = finish_timing(e);
         if (rc) return rc;
@@ -868,6 +877,8 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
             rc = s2m_eskf_update(e, x, x_prop, P, HtH, Htz, sol, &conv);
             if (rc) return rc;
         }
+        if (tl) std::fprintf(stderr, "[s2m timeline] it %d rematch %d: launch %.1f us, wait %.1f us, solve %.1f us\n", it,
+                             rematch, us(t_a, t_b), us(t_b, t_c), us(t_c, now()));
         if (log) {
             log->effct[it] = effct;
             log->rematch[it] = rematch;

@@ -38,11 +38,17 @@ struct Lu24 {
     Mat24 lu;
     int perm[kDim];
 };
+// LU with partial pivoting (what Eigen's fixed-size inverse uses for n > 4): factor once, then solve for
+// the unit columns that are needed.  Both routines keep, for every matrix element, exactly the sequence
+// of multiply-then-subtract operations of the textbook scalar algorithm; they are only arranged so that
+// independent elements sit in the innermost loop (rows of the trailing block; the right-hand-side columns
+// of the triangular solves) -- that breaks the dependent-add latency chain and lets the compiler
+// vectorise without changing a single rounding.
 bool lu_factor(const Mat24 &in, Lu24 &f)
 {
     constexpr int N = kDim;
     f.lu = in;
-    Mat24 &lu = f.lu;
+    double *lu = f.lu.data();
     for (int i = 0; i < N; ++i) f.perm[i] = i;
     for (int k = 0; k < N; ++k) {
         int piv = k;
@@ -57,29 +63,41 @@ bool lu_factor(const Mat24 &in, Lu24 &f)
             std::swap(f.perm[k], f.perm[piv]);
         }
         const double d = lu[k * N + k];
+        const double *__restrict__ rk = lu + k * N;
         for (int r = k + 1; r < N; ++r) {
-            const double m = lu[r * N + k] / d;
-            lu[r * N + k] = m;
-            if (m != 0.0)
-                for (int c = k + 1; c < N; ++c) lu[r * N + c] -= m * lu[k * N + c];
+            double *__restrict__ rr = lu + r * N;
+            const double m = rr[k] / d;
+            rr[k] = m;
+            for (int c = k + 1; c < N; ++c) rr[c] -= m * rk[c];
         }
     }
     return true;
 }
-// column `col` of the inverse, written with stride `ld` starting at out
-void lu_inverse_col(const Lu24 &f, int col, double *out, int ld)
+// first NC columns of the inverse, row-major N x NC
+template <int NC>
+void lu_inverse_cols(const Lu24 &f, double *__restrict__ out)
 {
     constexpr int N = kDim;
-    double y[N];
-    for (int r = 0; r < N; ++r) {
-        double s = (f.perm[r] == col) ? 1.0 : 0.0;
-        for (int c = 0; c < r; ++c) s -= f.lu[r * N + c] * y[c];
-        y[r] = s;
+    const double *lu = f.lu.data();
+    double y[N][NC];
+    for (int r = 0; r < N; ++r) {  // L y = P e_col, all columns side by side
+        double acc[NC];
+        for (int col = 0; col < NC; ++col) acc[col] = (f.perm[r] == col) ? 1.0 : 0.0;
+        for (int c = 0; c < r; ++c) {
+            const double l = lu[r * N + c];
+            for (int col = 0; col < NC; ++col) acc[col] -= l * y[c][col];
+        }
+        for (int col = 0; col < NC; ++col) y[r][col] = acc[col];
     }
-    for (int r = N - 1; r >= 0; --r) {
-        double s = y[r];
-        for (int c = r + 1; c < N; ++c) s -= f.lu[r * N + c] * out[c * ld];
-        out[r * ld] = s / f.lu[r * N + r];
+    for (int r = N - 1; r >= 0; --r) {  // U x = y
+        double acc[NC];
+        for (int col = 0; col < NC; ++col) acc[col] = y[r][col];
+        for (int c = r + 1; c < N; ++c) {
+            const double u = lu[r * N + c];
+            for (int col = 0; col < NC; ++col) acc[col] -= u * out[c * NC + col];
+        }
+        const double d = lu[r * N + r];
+        for (int col = 0; col < NC; ++col) out[r * NC + col] = acc[col] / d;
     }
 }
 
@@ -160,7 +178,7 @@ bool eskf_update(const EskfParams &p, State &x, const State &x_prop, const Mat24
         Lu24 f;
         work.pinv_valid = false;
         if (!lu_factor(S, f)) return false;                        // (state.cov / LASER_POINT_COV).inverse()
-        for (int c = 0; c < N; ++c) lu_inverse_col(f, c, &work.Pinv[c], N);
+        lu_inverse_cols<N>(f, work.Pinv.data());
         work.Pkey = P;
         work.Rkey = p.laser_point_cov;
         work.pinv_valid = true;
@@ -170,7 +188,7 @@ bool eskf_update(const EskfParams &p, State &x, const State &x_prop, const Mat24
         for (int c = 0; c < 12; ++c) A[r * N + c] += HtH[r * 12 + c];    // + H_T_H (12x12 block)
     Lu24 f;
     if (!lu_factor(A, f)) return false;                            // K_1 (:1017-1018); only K_1[:, :12] is used
-    for (int c = 0; c < 12; ++c) lu_inverse_col(f, c, &work.K1c[c], 12);
+    lu_inverse_cols<12>(f, work.K1c.data());
     std::memcpy(work.HtH.data(), HtH, sizeof(double) * 144);
 
     const Vec24 vec = boxminus(x_prop, x);                         // :1028
