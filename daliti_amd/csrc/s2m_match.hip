@@ -422,6 +422,10 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
     const float gate_r = sqrtf(a.gates.knn_d2_gate);
     const int NB = max(1, (int)ceilf(gate_r * g.inv_c * 0.125f + 1e-3f));
     const int bside = 2 * NB + 1, nbricks = bside * bside * bside;
+    // the brick this lane inspects in the first chunk of 64 bricks, relative to the home brick (the common
+    // case NB = 1 has 27 bricks, one chunk): computed once, not per point
+    const int ob0 = lane < nbricks ? lane : 0;
+    const int odx0 = (ob0 % bside) - NB, ody0 = ((ob0 / bside) % bside) - NB, odz0 = (ob0 / (bside * bside)) - NB;
     for (uint32_t h = wave; h < count; h += nwaves) {
         const long long t0 = a.dbg ? wall_clock64() : 0;
         // concatenation [far | mid | near]: the most expensive points are handed out first
@@ -493,9 +497,13 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
                 uint64_t my_mask = 0;
                 int bx = 0, by = 0, bz = 0;
                 if (b < nbricks) {
-                    bx = hbx + (b % bside) - NB;
-                    by = hby + ((b / bside) % bside) - NB;
-                    bz = hbz + (b / (bside * bside)) - NB;
+                    if (bbase == 0) {
+                        bx = hbx + odx0; by = hby + ody0; bz = hbz + odz0;
+                    } else {
+                        bx = hbx + (b % bside) - NB;
+                        by = hby + ((b / bside) % bside) - NB;
+                        bz = hbz + (b / (bside * bside)) - NB;
+                    }
                     if (bx >= 0 && bx < g.nbx && by >= 0 && by < g.nby && bz >= 0 && bz < g.nbz) {
                         const uint4 te = g.top[((int64_t)bz * g.nby + by) * g.nbx + bx];
                         my_id = te.x;

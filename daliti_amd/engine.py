@@ -20,6 +20,7 @@ ABI_SYMBOLS = [
     "s2m_abi_version", "s2m_config_default", "s2m_strerror", "s2m_create", "s2m_destroy",
     "s2m_last_error", "s2m_set_config", "s2m_set_stream", "s2m_map_build", "s2m_map_size",
     "s2m_map_info", "s2m_map_add", "s2m_map_delete_boxes", "s2m_map_incremental", "s2m_map_get_points",
+    "s2m_fov_segment", "s2m_fov_reset",
     "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
     "s2m_iterated_update", "s2m_iterated_update_sharded", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
@@ -194,6 +195,17 @@ class Engine:
         n_del = C.c_int64()
         self._ck(self.lib.s2m_map_delete_boxes(self.h, _p(boxes), C.c_int64(len(boxes)), C.byref(n_del)))
         return n_del.value
+
+    def fov_segment(self, pos_lid, cube_len):
+        """lasermap_fov_segment(); returns (local_map[6], n_boxes, n_deleted)."""
+        pos = np.ascontiguousarray(pos_lid, np.float64)
+        lm = np.zeros(6, np.float32)
+        nb, nd = C.c_int32(), C.c_int64()
+        self._ck(self.lib.s2m_fov_segment(self.h, _p(pos), C.c_double(cube_len), _p(lm), C.byref(nb), C.byref(nd)))
+        return lm, nb.value, nd.value
+
+    def fov_reset(self):
+        self._ck(self.lib.s2m_fov_reset(self.h))
 
     def map_incremental(self, state, filter_size_map=0.5):
         state = np.ascontiguousarray(state, np.float64)

@@ -99,6 +99,17 @@ int s2m_map_add(s2m_engine *e, const float *xyz, int64_t stride_floats, int64_t 
  * laserMapping.cpp:313-369).  boxes: HOST array n x 6 = {min xyz, max xyz}; a point is removed
  * when min <= p < max on every axis. */
 int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *n_deleted);
+/* lasermap_fov_segment() (laserMapping.cpp:304-369): keeps the local-map cube of edge cube_len
+ * (mapping/cube_side_length) around the LiDAR; when the LiDAR comes within MOV_THRESHOLD * DET_RANGE
+ * = 1.5 * 300 m of a face the cube is shifted by mov_dist (:345) and the slabs that fall out are
+ * removed with Delete_Point_Boxes (:368).  pos_lid = pos_end + rot_end * T_L_I (:753).  The first call
+ * only initialises the cube (:320-328).  Outputs (optional): local_map[6] = the cube after the call
+ * (min xyz, max xyz), *n_boxes = slabs removed (0..3), *n_deleted = kdtree_delete_counter. */
+int s2m_fov_segment(s2m_engine *e, const double pos_lid[3], double cube_len, float local_map[6],
+                    int32_t *n_boxes, int64_t *n_deleted);
+/* forget the cube (Localmap_Initialized = false), e.g. when a rosbag loops back */
+int s2m_fov_reset(s2m_engine *e);
+
 /* map_incremental() (laserMapping.cpp:582-630) for the current scan: world points from `state`,
  * the add / no-need-downsample decision from the Nearest_Points of the last rematch pass, then
  * Add_Points(PointToAdd, true) and Add_Points(PointNoNeedDownsample, false) (:627-628).

@@ -330,3 +330,45 @@ def undistort(records, off_a, off_b, poses, state_end, sort=True):
     lib().orc_undistort(_p(rec), C.c_int64(rec.shape[1]), C.c_int64(n), C.c_int(off_a), C.c_int(off_b), _p(poses),
                         C.c_int(len(poses)), _p(st), C.c_int(int(sort)), _p(out), _p(perm))
     return out[:n], perm[:n]
+
+
+class FovSegmenter:
+    """lasermap_fov_segment() (eskf_lio/src/laserMapping.cpp:304-369) restated in numpy float32:
+    returns the slabs (boxes) to delete for each LiDAR position."""
+    DET_RANGE = np.float32(300.0)
+    MOV_THRESHOLD = np.float32(1.5)
+
+    def __init__(self, cube_len):
+        self.cube_len = float(cube_len)
+        self.init = False
+        self.mn = np.zeros(3, np.float32)
+        self.mx = np.zeros(3, np.float32)
+
+    def step(self, pos):
+        pos = np.asarray(pos, np.float64)
+        if not self.init:                                             # :320-328
+            self.mn = (pos - self.cube_len / 2.0).astype(np.float32)
+            self.mx = (pos + self.cube_len / 2.0).astype(np.float32)
+            self.init = True
+            return []
+        d0 = np.abs(pos - self.mn.astype(np.float64)).astype(np.float32)
+        d1 = np.abs(pos - self.mx.astype(np.float64)).astype(np.float32)
+        thr = self.MOV_THRESHOLD * self.DET_RANGE
+        if not ((d0 <= thr) | (d1 <= thr)).any():
+            return []
+        mov = np.float32(max((self.cube_len - 2.0 * float(thr)) * 0.5 * 0.9,
+                             float(self.DET_RANGE * (self.MOV_THRESHOLD - np.float32(1)))))   # :345
+        boxes = []
+        nmn, nmx = self.mn.copy(), self.mx.copy()
+        for i in range(3):                                            # :346-363
+            bmn, bmx = self.mn.copy(), self.mx.copy()
+            if d0[i] <= thr:
+                nmx[i] -= mov; nmn[i] -= mov
+                bmn[i] = self.mx[i] - mov
+                boxes.append(np.r_[bmn, bmx])
+            elif d1[i] <= thr:
+                nmx[i] += mov; nmn[i] += mov
+                bmx[i] = self.mn[i] + mov
+                boxes.append(np.r_[bmn, bmx])
+        self.mn, self.mx = nmn, nmx
+        return boxes

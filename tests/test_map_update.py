@@ -133,3 +133,39 @@ def test_multi_frame_odometry_with_map_growth(oracle):
     # the raw seed collapses towards one point per 0.5 m voxel as frames are merged in
     assert 1000 < e.map_size() < len(seed)
     e.close()
+
+
+def test_oracle_fov_segmenter_moves_the_cube(oracle):
+    f = oracle.FovSegmenter(1000.0)
+    assert f.step([0, 0, 0]) == [] and (f.mn == -500).all() and (f.mx == 500).all()
+    assert f.step([40, 0, 0]) == []                         # 460 m from the +x face: still > 450 m
+    b = f.step([51, 0, 0])                                  # 449 m: move by max((1000-900)*0.45, 150) = 150 m
+    assert len(b) == 1 and f.mn[0] == -350 and f.mx[0] == 650
+    assert (b[0] == np.float32([-500, -500, -500, -350, 500, 500])).all()   # the slab that fell out
+
+
+@pytest.mark.gpu
+def test_fov_segment_matches_oracle(oracle):
+    from daliti_amd import Engine
+    rs = np.random.RandomState(5)
+    pts = rs.uniform(-600, 600, (200000, 3)).astype(np.float32)
+    e = Engine(cell_size=8.0)
+    e.map_build(pts)
+    om = oracle.Map(pts)
+    f = oracle.FovSegmenter(1000.0)
+    path = [[0, 0, 0], [30, 10, 0], [60, -20, 5], [120, -60, 10], [240, -200, 20], [300, -320, 20], [200, -100, 0]]
+    moved = 0
+    for pos in path:
+        lm, nb, nd = e.fov_segment(pos, 1000.0)
+        boxes = f.step(pos)
+        no = sum(om.delete_box(b) for b in boxes)
+        assert nb == len(boxes) and nd == no
+        assert (lm == np.r_[f.mn, f.mx]).all()
+        assert e.map_size() == om.size()
+        moved += nb
+    assert moved >= 2 and e.map_size() < len(pts)
+    assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
+    e.fov_reset()
+    lm, nb, nd = e.fov_segment([1000, 0, 0], 1000.0)        # re-initialises around the new position
+    assert nb == 0 and lm[0] == 500 and lm[3] == 1500
+    e.close()
