@@ -46,6 +46,9 @@ def parse():
                     help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing)")
     ap.add_argument("--all-on-device0", action="store_true", help="test hook: every rank uses GPU 0")
     ap.add_argument("--beams-mult", type=int, default=1, help="test hook: single rank over a denser scan")
+    ap.add_argument("--torch-collective", action="store_true",
+                    help="sum the block with torch.distributed.all_reduce through the C callback instead of the "
+                         "engine's own RCCL communicator")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the sharded/all-reduce code path even with one rank (test hook)")
     return ap.parse_args()
@@ -114,7 +117,15 @@ def main():
     info = eng.map_info()
 
     blk = torch.zeros(160, dtype=torch.float64, device="cuda")
-    if sharded:
+    builtin_comm = False
+    if sharded and a.backend == "nccl" and not a.torch_collective:
+        # the engine's own RCCL communicator: the all-reduce is issued from the C++ loop on the engine's
+        # stream; torch.distributed only ships the 128-byte unique id
+        ids = [Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        eng.comm_init(ids[0], world, rank)
+        builtin_comm = True
+    if sharded and not builtin_comm:
         from daliti_amd.sharding import allreduce_block
 
         def reduce_cb():
@@ -123,7 +134,7 @@ def main():
         def step():
             eng.set_feat_queue([])
             return eng.iterated_update_sharded(x_prop, x_prop, P0, blk.data_ptr(), reduce_cb)
-    else:
+    if not sharded or builtin_comm:
         from daliti_amd.engine import IterLog
         xb, xpb, Pb, logb = np.zeros(36), np.ascontiguousarray(x_prop, np.float64), np.zeros((24, 24)), IterLog()
 
@@ -149,7 +160,7 @@ def main():
     passes = iters = rematch = 0
     for _ in range(a.steps):
         res = step()
-        if sharded:
+        if sharded and not builtin_comm:
             iters += res["iters"]
             rematch += res["rematch_passes"]
         else:
@@ -157,7 +168,7 @@ def main():
             rematch += res.rematch_passes
     fence()
     dt = time.perf_counter() - t0
-    if not sharded:  # final state / log of the last step for the report
+    if not sharded or builtin_comm:  # final state / log of the last step for the report
         res = dict(x=xb.copy(), P=Pb.copy(), iters=res.iters, effct=np.array(res.effct[:res.iters]))
     tstats = eng.timing_stats()
     eng.set_timing(False)
@@ -189,9 +200,10 @@ def main():
                 a.config, a.max_iter, n_local, " shard" if sharded else "", len(map_xyz)),
             "scan_points_per_gpu": n_local,
             "map_points": len(map_xyz),
-            "parallelism": ("single GPU" if world == 1 else
-                            ("scan points sharded x%d, map replicated, RCCL all-reduce of 158 f64 per iteration"
-                             % world if sharded else "replicas x%d (independent scans, no collective)" % world)),
+            "parallelism": ("single GPU" if (world == 1 and not sharded) else
+                            ("scan points sharded x%d, map replicated, RCCL all-reduce of 158 f64 per iteration (%s)"
+                             % (world, "engine-owned communicator" if builtin_comm else "torch.distributed callback")
+                             if sharded else "replicas x%d (independent scans, no collective)" % world)),
             "cell_size_m": info["cell"],
             "mean_points_per_cell": info["mean_per_cell"],
         },

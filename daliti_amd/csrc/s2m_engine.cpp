@@ -15,6 +15,7 @@
 #include <string>
 
 #include "../../include/daliti_s2m.h"
+#include "s2m_comm.h"
 #include "s2m_eskf.h"
 #include "s2m_kernels.h"
 
@@ -84,6 +85,7 @@ struct s2m_engine {
     bool nn_valid = false;
 
     EskfWork work;
+    Comm comm;  // attached RCCL communicator (multi-GPU form), handle == nullptr when single GPU
     int32_t queue[S2M_FEAT_QUEUE + 1] = {0};
     int32_t queue_len = 0;
 };
@@ -204,7 +206,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     r.plane = e->d_plane; r.flags = e->d_flags; r.sel = e->d_sel; r.eff = e->d_eff; r.pd2 = e->d_pd2;
     r.partials = e->d_partials; r.block = d_out;
     r.ticket = e->d_ticket; r.hard_count = e->d_hard + 3 * e->n_cap;
-    const bool publish = e->host_poll && d_out == e->d_block;
+    const bool publish = e->host_poll && d_out == e->d_block && !e->comm.handle;
     r.host_block = publish ? e->h_block_dev : nullptr;
     r.host_flag = publish ? reinterpret_cast<unsigned long long *>(e->h_block_dev + S2M_BLOCK_DOUBLES) : nullptr;
     r.seq = ++e->seq;
@@ -330,6 +332,7 @@ int s2m_destroy(s2m_engine *e)
     free_update(e->upd);
     free_voxel(e->vox);
     free_undist(e->und);
+    comm_destroy(e->comm);
     void *ptrs[] = {e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
                     e->d_nn_d2, e->d_hard, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
@@ -916,6 +919,14 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         const auto t_b = now();
         if (reduce && reduce(user) != 0) return fail(e, S2M_ERR_HIP, "all-reduce callback failed");
         const double *hb = nullptr;
+        if (!reduce && e->comm.handle) {
+            // built-in collective: sum the block over the ranks on this stream, then publish it to the host
+            std::string cerr_;
+            if (!comm_allreduce_sum_f64(e->comm, d_block, S2M_BLOCK_DOUBLES, e->stream, cerr_)) return fail(e, S2M_ERR_HIP, cerr_.c_str());
+            if (e->host_poll && d_block == e->d_block)
+                launch_publish(d_block, e->h_block_dev, reinterpret_cast<unsigned long long *>(e->h_block_dev + S2M_BLOCK_DOUBLES),
+                               e->seq, e->stream);
+        }
         // after a collective the summed block only exists in d_block: copy it; otherwise poll
         if (reduce) {
             S2M_HIP(e, hipMemcpyAsync(e->h_block, d_block, S2M_BLOCK_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
@@ -986,6 +997,30 @@ int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double
                         double P[S2M_DIM * S2M_DIM], s2m_iter_log *log)
 {
     return s2m_iterated_update_sharded(e, x, x_prop, P, log, nullptr, nullptr, nullptr);
+}
+
+int s2m_comm_unique_id(uint8_t id[S2M_COMM_ID_BYTES])
+{
+    if (!id) return S2M_ERR_ARG;
+    std::string err;
+    return comm_unique_id(id, err) ? S2M_OK : S2M_ERR_HIP;
+}
+
+int s2m_comm_init(s2m_engine *e, const uint8_t id[S2M_COMM_ID_BYTES], int32_t nranks, int32_t rank)
+{
+    if (!e || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(e, S2M_ERR_ARG, "s2m_comm_init: bad argument");
+    S2M_HIP(e, hipSetDevice(e->device));
+    comm_destroy(e->comm);
+    std::string err;
+    if (!comm_init(e->comm, id, nranks, rank, err)) return fail(e, S2M_ERR_HIP, err.c_str());
+    return S2M_OK;
+}
+
+int s2m_comm_destroy(s2m_engine *e)
+{
+    if (!e) return S2M_ERR_ARG;
+    comm_destroy(e->comm);
+    return S2M_OK;
 }
 
 int s2m_feat_queue_get(const s2m_engine *e, int32_t q[S2M_FEAT_QUEUE], int32_t *len)

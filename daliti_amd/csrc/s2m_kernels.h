@@ -143,6 +143,8 @@ struct ReduceArgs {
 };
 int reduce_blocks(int n);
 int rows_blocks(int n);
+void launch_publish(const double *block, double *host_block, unsigned long long *host_flag, unsigned long long seq,
+                    hipStream_t st);
 void launch_reduce(const ReduceArgs &a, hipStream_t st);
 
 // dense rows of the last pass in index order (laserMapping.cpp:942-979)

@@ -292,6 +292,21 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
     }
 }
 
+// after a collective: copy the summed block to pinned host memory and raise the sequence flag
+__global__ __launch_bounds__(192) void publish_kernel(const double *__restrict__ block, double *__restrict__ host_block,
+                                                      unsigned long long *__restrict__ host_flag, unsigned long long seq)
+{
+    if (threadIdx.x < 160) host_block[threadIdx.x] = block[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_publish(const double *block, double *host_block, unsigned long long *host_flag, unsigned long long seq,
+                    hipStream_t st)
+{
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(192), 0, st, block, host_block, host_flag, seq);
+}
+
 int reduce_blocks(int n) { return (n + kRedBlock - 1) / kRedBlock; }
 int rows_blocks(int n) { return (n + kRowsBlock - 1) / kRowsBlock; }
 

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "s2m_fov_segment", "s2m_fov_reset",
     "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
-    "s2m_iterated_update", "s2m_iterated_update_sharded", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
+    "s2m_iterated_update", "s2m_iterated_update_sharded", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
     "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats",
 ]
 
@@ -368,6 +368,22 @@ class Engine:
                     ekf_stop=bool(log.ekf_stop), effct=np.array(log.effct[:it]), rematch=np.array(log.rematch[:it]),
                     conv=np.array(log.conv[:it]), total_res=np.array(log.total_residual[:it]),
                     solution=np.array([list(log.solution[i]) for i in range(it)]).reshape(it, DIM))
+
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL unique id (call on rank 0, ship to the other ranks)."""
+        buf = (C.c_uint8 * 128)()
+        rc = load_library().s2m_comm_unique_id(buf)
+        if rc != 0:
+            raise S2MError(rc, "s2m_comm_unique_id failed (is librccl available?)")
+        return bytes(buf)
+
+    def comm_init(self, uid, nranks, rank):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._ck(self.lib.s2m_comm_init(self.h, buf, C.c_int32(nranks), C.c_int32(rank)))
+
+    def comm_destroy(self):
+        self._ck(self.lib.s2m_comm_destroy(self.h))
 
     def feat_queue(self):
         q = (C.c_int32 * FEAT_QUEUE)()

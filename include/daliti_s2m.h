@@ -238,6 +238,17 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES],
                                 const double x_prop[S2M_STATE_DOUBLES], double P[S2M_DIM * S2M_DIM],
                                 s2m_iter_log *log, double *d_block, s2m_allreduce_fn reduce,
                                 void *user);
+/* Built-in collective for the multi-GPU form: an RCCL communicator owned by the handle.  Rank 0 calls
+ * s2m_comm_unique_id and ships the 128 bytes to the other ranks by any means (bench.py uses a
+ * torch.distributed broadcast); every rank then calls s2m_comm_init.  While a communicator is attached
+ * s2m_iterated_update treats the handle's scan as this rank's shard: after every pass the block is
+ * summed with ncclAllReduce(sum, ncclDouble, 160) on the handle's stream, straight from the C++ loop.
+ * RCCL is loaded at run time; without it these calls return S2M_ERR_HIP and nothing else is affected. */
+#define S2M_COMM_ID_BYTES 128
+int s2m_comm_unique_id(uint8_t id[S2M_COMM_ID_BYTES]);
+int s2m_comm_init(s2m_engine *e, const uint8_t id[S2M_COMM_ID_BYTES], int32_t nranks, int32_t rank);
+int s2m_comm_destroy(s2m_engine *e);
+
 /* Degeneracy queue access (effct_feat_numQueue, laserMapping.cpp:193). */
 int s2m_feat_queue_get(const s2m_engine *e, int32_t q[S2M_FEAT_QUEUE], int32_t *len);
 int s2m_feat_queue_set(s2m_engine *e, const int32_t *q, int32_t len);

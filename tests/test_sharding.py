@@ -120,12 +120,18 @@ def test_bench_collective_path_single_rank():
     import json
     import subprocess
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300))
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
-                          "--warmup", "1", "--no-cpu", "--force-collective"], env=env, capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 1 and line["value"] > 0 and line["pose_error_vs_truth_m"] < 0.05
+    lines = []
+    for extra in ([], ["--torch-collective"]):   # the engine-owned RCCL communicator, then the torch callback
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
+                              "--warmup", "1", "--no-cpu", "--force-collective"] + extra, env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
+        assert lines[-1]["n_gpus"] == 1 and lines[-1]["value"] > 0 and lines[-1]["pose_error_vs_truth_m"] < 0.05
+    assert "engine-owned communicator" in lines[0]["config"]["parallelism"]
+    assert "torch.distributed callback" in lines[1]["config"]["parallelism"]
+    assert lines[0]["final_pos"] == lines[1]["final_pos"]
+    line = lines[0]
     ref = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
                           "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
     assert ref.returncode == 0, ref.stderr[-2000:]
