@@ -350,7 +350,7 @@ __global__ __launch_bounds__(1024) void rows_scan_kernel(uint32_t *__restrict__ 
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t y = __shfl_up(x, off, 64);
-            if ((threadIdx.x & 63) >= off) x += y;
+            if ((int)(threadIdx.x & 63) >= off) x += y;
         }
         if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = x;
         __syncthreads();
