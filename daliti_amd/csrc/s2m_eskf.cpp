@@ -32,8 +32,6 @@ M3 transposed(const M3 &A)
     return T;
 }
 
-// LU with partial pivoting (what Eigen's fixed-size inverse uses for n > 4): factor once, then
-// solve for the unit columns that are needed.
 struct Lu24 {
     Mat24 lu;
     int perm[kDim];

@@ -445,7 +445,6 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
         float band = 2.0f * g.c;   // band radius while no radius is known (the first shell already covered c)
         uint32_t rounds = 0;
         const int hbx = q.cx >> 3, hby = q.cy >> 3, hbz = q.cz >> 3;
-        uint32_t dbg_top = 0, dbg_scan = 0, dbg_merge = 0;
         int nq = 0;  // qualifying (brick,row) pairs waiting in the wave's descriptor list (wave-uniform)
         // Descriptors {brick id, row | cells << 8, first cell}: every lane takes one, the cells of all of them
         // are numbered with a wave prefix sum, and cell j goes to lane j % 64 -- so the point loads of all
@@ -486,8 +485,6 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // loads above before the next stores
         };
         for (;;) {
-            const long long ph0 = a.dbg ? wall_clock64() : 0;
-            long long ph1 = ph0;
             const float r2 = have_tau ? tau : band * band;  // scan every pair whose bound is within r2
             // x reach (cells) as a function of the pair's bound is computed per pair below
             for (int bbase = 0; bbase < nbricks; bbase += 64) {
@@ -520,7 +517,6 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
                 }
                 const int excl = incl - cnt;
                 const int total = __shfl(incl, 63, 64);
-                if (a.dbg) { ph1 = wall_clock64(); dbg_top += (uint32_t)(ph1 - ph0); }
                 // 3. (brick,row) pairs, round-robin over the lanes
                 for (int pbase = 0; pbase < total; pbase += 64 * kPairSlots) {
 #pragma unroll
@@ -579,9 +575,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
             flush_desc();
             nq = 0;
             ++rounds;
-            const long long ph2 = a.dbg ? wall_clock64() : 0;
             merge_lists<G>(t, best);
-            if (a.dbg) { dbg_scan += (uint32_t)(ph2 - ph1); dbg_merge += (uint32_t)(wall_clock64() - ph2); }
             const bool found5 = best[kK - 1] != kEmptyKey;
             const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
             if (have_tau) break;  // every point within tau was visited: exact
@@ -600,8 +594,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
                 a.dbg[4 * (int64_t)qi + 0] += (uint32_t)(wall_clock64() - t0);
                 a.dbg[4 * (int64_t)qi + 2] = (uint32_t)t0;  // absolute start tick (100 MHz) of the hard part
                 a.dbg[4 * (int64_t)qi + 1] = 2u + rounds;
-                a.dbg[4 * (int64_t)qi + 3] = (rounds + 1) | (min(dbg_top, 1023u) << 8) | (min(dbg_scan, 4095u) << 18);
-                (void)dbg_merge;
+                a.dbg[4 * (int64_t)qi + 3] = rounds + 1;
             }
         }
     }

@@ -26,8 +26,6 @@ for g in [int(x) for x in os.environ.get("GROUPS", "4").split(",")]:
         if hm.any():
             st = d[hm, 2].astype(np.int64); st -= st.min()
             print("   hard starts (us): pct50 %.1f pct90 %.1f max %.1f" % tuple(np.percentile(st, [50, 90, 100]) / 100.0))
-            top = ((d[hm, 3] >> 8) & 1023) / 100.0; scan = ((d[hm, 3] >> 18) & 4095) / 100.0
-            print("   hard phases (us, mean): top+prefix %.2f  pairs+scan %.2f  | total hard %.2f" % (top.mean(), scan.mean(), (cyc[hm].mean() - cyc[~hm].mean()) / 100.0))
         for r in range(1, 12):
             sel = d[:, 1] == r
             if sel.any():
