@@ -26,6 +26,14 @@ for g in [int(x) for x in os.environ.get("GROUPS", "4").split(",")]:
         if hm.any():
             st = d[hm, 2].astype(np.int64); st -= st.min()
             print("   hard starts (us): pct50 %.1f pct90 %.1f max %.1f" % tuple(np.percentile(st, [50, 90, 100]) / 100.0))
+        if hm.any():
+            hd = (d[hm, 3] >> 8) / 100.0
+            print("   hard part per point (us): mean %.1f pct50 %.1f pct90 %.1f max %.1f" % (hd.mean(), *np.percentile(hd, [50, 90, 100])))
+            en = (st + (d[hm, 3] >> 8).astype(np.int64)) / 100.0
+            print("   hard ends (us after first start): pct50 %.1f pct90 %.1f max %.1f" % tuple(np.percentile(en, [50, 90, 100])))
+            for rr in range(2, 6):
+                sl = (d[hm, 3] & 0xff) == rr
+                if sl.any(): print("     rounds %d: n %d  hard part mean %.1f us" % (rr - 1, sl.sum(), hd[sl].mean()))
         for r in range(1, 12):
             sel = d[:, 1] == r
             if sel.any():
