@@ -121,10 +121,28 @@ def main():
     if sharded and a.backend == "nccl" and not a.torch_collective:
         # the engine's own RCCL communicator: the all-reduce is issued from the C++ loop on the engine's
         # stream; torch.distributed only ships the 128-byte unique id
-        ids = [Engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        eng.comm_init(ids[0], world, rank)
-        builtin_comm = True
+        # every rank first proves it can reach RCCL (a rank that cannot must not leave the others blocked
+        # inside ncclCommInitRank); any failure sends all ranks to the torch.distributed callback instead
+        def all_ok(flag):
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        try:
+            probe = Engine.comm_unique_id()
+        except Exception as ex:  # noqa: BLE001 - reported, then the fallback path is taken
+            probe = None
+            sys.stderr.write("rank %d: engine RCCL communicator unavailable (%s)\n" % (rank, ex))
+        if all_ok(probe is not None):
+            ids = [probe if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            try:
+                eng.comm_init(ids[0], world, rank)
+                ok = True
+            except Exception as ex:  # noqa: BLE001
+                ok = False
+                sys.stderr.write("rank %d: s2m_comm_init failed (%s)\n" % (rank, ex))
+            builtin_comm = all_ok(ok)
     if sharded and not builtin_comm:
         from daliti_amd.sharding import allreduce_block
 
