@@ -1,11 +1,10 @@
 #!/bin/bash
-# Dev tool (runs on the MI355X box): rebuild s2m_match.hip with extra -D flags per variant and bench each.
+# Dev tool (runs on the MI355X box): rebuild the library with extra -D flags per variant and bench each.
 # usage: scripts/ab_build.sh "<name>:<flags>" ...     e.g.  "w4b8:-DS2M_HARD_WAVES=4" "w3:-DS2M_HARD_WAVES=3"
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
-  touch daliti_amd/csrc/s2m_match.hip
-  make -C daliti_amd/csrc -s CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result $flags" > /dev/null 2>&1 || { echo "$name build failed"; continue; }
+  make -B -j8 -C daliti_amd/csrc -s CXXFLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result $flags" > /dev/null 2>&1 || { echo "$name build failed"; continue; }
   python bench.py --steps 200 --warmup 20 --no-cpu 2>/dev/null | tail -1 > gpurun_out/ab_$name.json
   python - "$name" <<'PY'
 import json,sys
