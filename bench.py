@@ -238,12 +238,17 @@ def main():
         ms = tstats["match_ms"] / tstats["match_launches"]
         achieved = n_local * BYTES_REMATCH / (ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic() if (a.config == "C3" and world == 1) else (None, None)
+        copy_peak = measured_copy_peak(torch) if rank == 0 else None
         out["roofline"] = {
             "kernel": "match_kernel (exact 5-NN on the brick grid + plane fit)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_eval": BYTES_REMATCH, "evals_per_launch": n_local,
             "avg_launch_ms": ms, "launches": tstats["match_launches"],
+            # both fractions, and the box's own copy peak as a second denominator
+            "frac_of_measured_traffic": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "peak_measured_copy": copy_peak,
+            "frac_of_measured_peak": (achieved / copy_peak) if copy_peak else None,
             "note": "one launch = match_easy + match_hard of one rematch pass (HIP events around both, "
                     "every 5th rematch pass of the timed region sampled)",
         }
@@ -260,6 +265,24 @@ def main():
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def measured_copy_peak(torch, nbytes=1 << 30, reps=10):
+    """Device-to-device copy of 1 GiB, read + written bytes per second in GB/s (the box's own HBM peak)."""
+    try:
+        src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    except Exception:  # noqa: BLE001 - a diagnostic, never fatal
+        return None
 
 
 def pmc_traffic():
