@@ -238,7 +238,7 @@ def main():
         ms = tstats["match_ms"] / tstats["match_launches"]
         achieved = n_local * BYTES_REMATCH / (ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic() if (a.config == "C3" and world == 1) else (None, None)
-        copy_peak = measured_copy_peak(torch) if rank == 0 else None
+        copy_peak = measured_copy_peak(torch) if (rank == 0 and not a.no_cpu) else None  # --no-cpu: no side legs
         out["roofline"] = {
             "kernel": "match_kernel (exact 5-NN on the brick grid + plane fit)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
