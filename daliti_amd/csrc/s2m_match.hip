@@ -450,7 +450,9 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
         u64 t[kK], best[kK];
 #pragma unroll
         for (int k = 0; k < kK; ++k) { t[k] = kEmptyKey; best[k] = kEmptyKey; }
-        float band = 2.0f * g.c;   // band radius while no radius is known (the first shell already covered c)
+        // band radius while no radius is known: the first shell covered (1 + fmin) c; 1.7 c measured best at C3
+        // (1.3 / 1.5 / 1.7 / 2.0 / 2.5 c -> 68 / 67 / 61 / 64 / 68 us for the first-pass launch)
+        float band = 1.7f * g.c;
         uint32_t rounds = 0;
         const int hbx = q.cx >> 3, hby = q.cy >> 3, hbz = q.cz >> 3;
         int nq = 0;  // qualifying (brick,row) pairs waiting in the wave's descriptor list (wave-uniform)
