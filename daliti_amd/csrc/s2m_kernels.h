@@ -8,6 +8,12 @@
 namespace s2m {
 
 // ---- s2m_map.hip : map build (KD_TREE::Build, ikd-Tree/ikd_Tree.cpp:408-423) -------------------
+// bounding box of an AoS cloud (s2m_map.hip): scratch holds the per-workgroup partial boxes + the result
+constexpr int kBboxBlocks = 1024;
+constexpr int kBboxScratchFloats = (kBboxBlocks + 1) * 6;
+hipError_t cloud_bbox(const float *xyz, int64_t stride, int64_t n, float *scratch, float lo[3], float hi[3],
+                      hipStream_t st);
+
 struct MapBuffers {
     // owned by the engine, (re)allocated by build_map
     float4 *pts = nullptr;
@@ -22,7 +28,7 @@ struct MapBuffers {
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     int64_t scratch_cap = 0;
-    float *bbox = nullptr;       // 6 floats on device
+    float *bbox = nullptr;       // kBboxScratchFloats floats on device (cloud_bbox scratch)
     uint32_t *counters = nullptr; // small device counters
 };
 
@@ -76,7 +82,8 @@ void launch_float4_to_xyz(const float4 *in, int64_t n, float *xyz, hipStream_t s
 // ---- s2m_voxel.hip : scan voxel down-sampling (pcl::VoxelGrid, laserMapping.cpp:775-776) ------------
 struct VoxelBuffers {
     uint64_t *key = nullptr, *key2 = nullptr;
-    uint32_t *val = nullptr, *val2 = nullptr, *head = nullptr, *pos = nullptr, *box = nullptr;
+    uint32_t *val = nullptr, *val2 = nullptr, *head = nullptr, *pos = nullptr;
+    float *box = nullptr;  // cloud_bbox scratch
     void *tmp = nullptr;
     size_t tmp_bytes = 0;
     int64_t cap = 0;

@@ -75,7 +75,11 @@ __device__ __forceinline__ uint64_t voxel_key(float x, float y, float z, float d
     return ((uint64_t)(kx & 0x1fffff) << 42) | ((uint64_t)(ky & 0x1fffff) << 21) | (uint64_t)(kz & 0x1fffff);
 }
 
-// visit every old point inside box [mn, mx) through the brick grid
+// visit every old point inside box [mn, mx) through the brick grid.  The cell of a coordinate,
+// floor((v - o) * inv_c) clamped to the grid, is a monotone function of v (every float step in it is), and
+// the map points were binned with the same expression (cell_of, s2m_map.hip): a point with mn <= p < mx lies
+// in a cell between cell(mn) and cell(mx), so no slack cells are needed.  Per x-row the cells of one brick
+// are one contiguous run of the sorted array.
 template <class F>
 __device__ __forceinline__ void for_points_in_box(const Grid &g, const float (&mn)[3], const float (&mx)[3], F &&f)
 {
@@ -85,20 +89,26 @@ __device__ __forceinline__ void for_points_in_box(const Grid &g, const float (&m
     const int nc[3] = {g.ncx, g.ncy, g.ncz};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        c0[k] = max((int)floorf((mn[k] - o[k]) * g.inv_c) - 1, 0);  // one cell of slack for float rounding
-        c1[k] = min((int)floorf((mx[k] - o[k]) * g.inv_c) + 1, nc[k] - 1);
+        c0[k] = min(max((int)floorf((mn[k] - o[k]) * g.inv_c), 0), nc[k] - 1);
+        c1[k] = min(max((int)floorf((mx[k] - o[k]) * g.inv_c), 0), nc[k] - 1);
     }
     for (int zz = c0[2]; zz <= c1[2]; ++zz)
-        for (int yy = c0[1]; yy <= c1[1]; ++yy)
-            for (int xx = c0[0]; xx <= c1[0]; ++xx) {
-                const uint4 te = g.top[((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx + (xx >> 3)];
-                if (te.x == 0) continue;
-                const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + ((((zz & 7) << 3) | (yy & 7)) << 3) + (xx & 7);
-                for (uint32_t i = tb[0]; i < tb[1]; ++i) {
+        for (int yy = c0[1]; yy <= c1[1]; ++yy) {
+            const int rowbit = ((zz & 7) << 3) | (yy & 7);
+            const int64_t toprow = ((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx;
+            for (int bx = c0[0] >> 3; bx <= (c1[0] >> 3); ++bx) {
+                const uint4 te = g.top[toprow + bx];
+                const uint32_t mword = (rowbit & 32) ? te.w : te.z;
+                if (te.x == 0 || ((mword >> (rowbit & 31)) & 1u) == 0) continue;
+                const int l0 = max(c0[0], bx << 3) & 7, l1 = min(c1[0], (bx << 3) + 7) & 7;
+                const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + (rowbit << 3);
+                const uint32_t e = tb[l1 + 1];
+                for (uint32_t i = tb[l0]; i < e; ++i) {
                     const float4 p = g.pts[i];
                     if (in_box(p, mn, mx)) f(p, __float_as_uint(p.w));
                 }
             }
+        }
 }
 
 __global__ __launch_bounds__(256) void add_probe_kernel(Grid g, const float4 *__restrict__ np, int n, float ds,
@@ -167,8 +177,10 @@ __global__ __launch_bounds__(256) void add_resolve_kernel(Grid g, const float4 *
         rewrite = (c > 1) || same;
     }
     if (add_new) add_flag[w] = 1u;
+    // tmp_counter of Add_Points: one atomic per wave (same-address atomics serialise at ~11 ns each)
+    const unsigned long long rw = __ballot(rewrite);
+    if (rewrite && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)rw) - 1)) atomicAdd(&counters[1], (uint32_t)__popcll(rw));
     if (rewrite) {
-        atomicAdd(&counters[1], 1u);  // tmp_counter of Add_Points
         if (c > (keep != 0xffffffffu ? 1u : 0u)) {
             const Voxel v = voxel_of(pw.x, pw.y, pw.z, ds);
             for_points_in_box(g, v.mn, v.mx, [&](const float4 &, uint32_t idx) {
@@ -183,17 +195,20 @@ __global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restr
                                                            uint8_t *__restrict__ alive, uint32_t *__restrict__ counters)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m || !alive[i]) return;
-    const float4 p = porig[i];
-    for (int b = 0; b < nb; ++b) {
-        const float *bx = boxes + 6 * b;
-        const float mn[3] = {bx[0], bx[1], bx[2]}, mx[3] = {bx[3], bx[4], bx[5]};
-        if (in_box(p, mn, mx)) {
-            alive[i] = 0;
-            atomicAdd(&counters[2], 1u);
-            return;
+    bool hit = false;
+    if (i < m && alive[i]) {
+        const float4 p = porig[i];
+        for (int b = 0; b < nb && !hit; ++b) {
+            const float *bx = boxes + 6 * b;
+            const float mn[3] = {bx[0], bx[1], bx[2]}, mx[3] = {bx[3], bx[4], bx[5]};
+            hit = in_box(p, mn, mx);
         }
+        if (hit) alive[i] = 0;
     }
+    // one atomic per workgroup: a field-of-view trim deletes 1e5..1e6 points, per-point atomics on one
+    // address would take milliseconds
+    const int cnt = __syncthreads_count(hit ? 1 : 0);
+    if (threadIdx.x == 0 && cnt) atomicAdd(&counters[2], (uint32_t)cnt);
 }
 
 __global__ __launch_bounds__(256) void flags_to_u32_kernel(const uint8_t *__restrict__ a, int64_t m,

@@ -30,48 +30,6 @@ namespace s2m {
         if (e_ != hipSuccess) return e_; \
     } while (0)
 
-__device__ __forceinline__ uint32_t vx_f2ord(float f)
-{
-    const uint32_t b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-static inline float vx_ord2f(uint32_t u)
-{
-    const uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    float f;
-    std::memcpy(&f, &b, 4);
-    return f;
-}
-
-__global__ __launch_bounds__(256) void vx_bbox_kernel(const float *__restrict__ xyz, int64_t stride, int64_t n,
-                                                      uint32_t *__restrict__ box)
-{
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float v = xyz[i * stride + k];
-            mn[k] = fminf(mn[k], v);
-            mx[k] = fmaxf(mx[k], v);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64));
-            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
-        }
-    }
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            atomicMin(&box[k], vx_f2ord(mn[k]));
-            atomicMax(&box[3 + k], vx_f2ord(mx[k]));
-        }
-    }
-}
-
 struct VoxelDims {
     float inv_leaf;
     int min_b[3];
@@ -147,19 +105,15 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
         }
         v.cap = n;
     }
-    if (!v.box) S2M_TRY(hipMalloc((void **)&v.box, 6 * sizeof(uint32_t)));
-    const uint32_t init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    S2M_TRY(hipMemcpyAsync(v.box, init, sizeof(init), hipMemcpyHostToDevice, st));
+    if (!v.box) S2M_TRY(hipMalloc((void **)&v.box, kBboxScratchFloats * sizeof(float)));
     const int nb = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(vx_bbox_kernel, dim3(std::min(nb, 1024)), dim3(256), 0, st, xyz, stride, n, v.box);
-    uint32_t box[6];
-    S2M_TRY(hipMemcpyAsync(box, v.box, sizeof(box), hipMemcpyDeviceToHost, st));
-    S2M_TRY(hipStreamSynchronize(st));
+    float blo[3], bhi[3];
+    S2M_TRY(cloud_bbox(xyz, stride, n, v.box, blo, bhi, st));
     VoxelDims d;
     d.inv_leaf = 1.0f / leaf;  // inverse_leaf_size_ = 1 / leaf_size_
     int64_t div[3];
     for (int k = 0; k < 3; ++k) {
-        const float mn = vx_ord2f(box[k]), mx = vx_ord2f(box[3 + k]);
+        const float mn = blo[k], mx = bhi[k];
         d.min_b[k] = (int)std::floor(mn * d.inv_leaf);
         const int max_b = (int)std::floor(mx * d.inv_leaf);
         div[k] = (int64_t)max_b - d.min_b[k] + 1;
