@@ -84,6 +84,38 @@ __device__ __forceinline__ void insert5(u64 (&t)[kK], u64 k)
 #endif
 }
 
+#ifndef S2M_BATCH_SORT
+#define S2M_BATCH_SORT 1
+#endif
+__device__ __forceinline__ void cex(double &a, double &b)
+{
+    const double lo = fmin(a, b), hi = fmax(a, b);
+    a = lo; b = hi;
+}
+// Eight new keys into the sorted top-5 in 48 min/max instead of 80: the 19-comparator sorting network for
+// eight inputs with everything that only feeds outputs 5..7 left to dead-code elimination (33 operations),
+// then c[i] = min(t[i], s[4-i]) -- the five smallest of both lists, as an up-down sequence -- and the
+// five-comparator network that sorts every up-down sequence of five (found by exhaustive search over the
+// 0/1 inputs).  Keys are unique (or +inf), so the result is the same list insert5 produces one by one.
+__device__ __forceinline__ void insert_batch8(u64 (&t)[kK], const u64 (&k)[8])
+{
+    double v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = __longlong_as_double((long long)k[i]);
+    cex(v[0], v[2]); cex(v[1], v[3]); cex(v[4], v[6]); cex(v[5], v[7]);
+    cex(v[0], v[4]); cex(v[1], v[5]); cex(v[2], v[6]); cex(v[3], v[7]);
+    cex(v[0], v[1]); cex(v[2], v[3]); cex(v[4], v[5]); cex(v[6], v[7]);
+    cex(v[2], v[4]); cex(v[3], v[5]);
+    cex(v[1], v[4]); cex(v[3], v[6]);
+    cex(v[1], v[2]); cex(v[3], v[4]); cex(v[5], v[6]);
+    double c[kK];
+#pragma unroll
+    for (int i = 0; i < kK; ++i) c[i] = fmin(__longlong_as_double((long long)t[i]), v[kK - 1 - i]);
+    cex(c[0], c[4]); cex(c[1], c[3]); cex(c[1], c[4]); cex(c[2], c[4]); cex(c[3], c[4]);
+#pragma unroll
+    for (int i = 0; i < kK; ++i) t[i] = (u64)__double_as_longlong(c[i]);
+}
+
 // points pts[s, e) -> top-5, B independent 16-byte loads per batch
 template <int B>
 __device__ __forceinline__ void scan_points(const float4 *__restrict__ pts, uint32_t s, uint32_t e, float wx,
@@ -93,13 +125,22 @@ __device__ __forceinline__ void scan_points(const float4 *__restrict__ pts, uint
         float4 p[B];
 #pragma unroll
         for (int u = 0; u < B; ++u) p[u] = pts[min(i + u, e - 1)];
+        u64 key[B];
 #pragma unroll
         for (int u = 0; u < B; ++u) {
             const float dx = wx - p[u].x, dy = wy - p[u].y, dz = wz - p[u].z;
             float d = dx * dx + dy * dy;
             d = d + dz * dz;
-            const u64 k = (i + u < e) ? make_key(d, __float_as_uint(p[u].w)) : kEmptyKey;
-            insert5(t, k);
+            key[u] = (i + u < e) ? make_key(d, __float_as_uint(p[u].w)) : kEmptyKey;
+        }
+        if (S2M_BATCH_SORT && S2M_INSERT_F64 && B == 8) {
+            u64 k8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) k8[u] = key[u < B ? u : 0];
+            insert_batch8(t, k8);
+        } else {
+#pragma unroll
+            for (int u = 0; u < B; ++u) insert5(t, key[u]);
         }
     }
 }
