@@ -262,7 +262,13 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     const float max_cells = (float)std::max(std::max(nc[0], nc[1]), nc[2]);
     g.slop = std::max(1.0e-4f, 16.0f * max_cells * 1.1920929e-7f);
 
-    S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m, sizeof(float4)));
+    // one extra element: the sentinel point the search kernels load for the padding slots of a batch (far
+    // enough for its squared distance to overflow to +inf; index word 0xffffffff)
+    S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m + 1, sizeof(float4)));
+    {
+        static const uint32_t sentinel[4] = {0x7f61b1e6u, 0x7f61b1e6u, 0x7f61b1e6u, 0xffffffffu};  // 3.0e38f x3
+        S2M_TRY(hipMemcpyAsync(buf.pts + m, sentinel, sizeof(sentinel), hipMemcpyHostToDevice, st));
+    }
     S2M_TRY(ensure((void **)&buf.porig, &buf.porig_cap, m, sizeof(float4)));
     S2M_TRY(ensure((void **)&buf.top, &buf.top_cap, top_entries, sizeof(uint4)));
     if (buf.scratch_cap < m) {

@@ -40,6 +40,10 @@ typedef unsigned long long u64;
 #endif
 // empty slot: +infinity as a double when the f64 exchange chain is used (orders after every key)
 constexpr u64 kEmptyKey = S2M_INSERT_F64 ? 0x7ff0000000000000ull : ~0ull;
+// A slot is empty when the float in its high word is not a finite distance: the initial +inf pattern
+// above, or the key of the sentinel point pts[m] = (3e38, 3e38, 3e38) that padding lanes of a batch load
+// (its squared distance overflows to +inf), so padding needs no predicate anywhere after the address.
+__device__ __forceinline__ bool is_empty(u64 k) { return (uint32_t)(k >> 32) >= 0x7f800000u; }
 #ifndef S2M_EASY_BATCH
 #define S2M_EASY_BATCH 8
 #endif
@@ -54,6 +58,22 @@ __device__ __forceinline__ u64 make_key(float d2, uint32_t orig)
     return ((u64)__float_as_uint(d2) << 32) | (u64)orig;
 }
 
+// v_min_f64 / v_max_f64 issued directly: fmin()/fmax() make the compiler canonicalise every operand first
+// (one extra v_max_f64 x, x, x per key -- 13 of ~61 operations per batch); the keys are never NaN as
+// doubles (a float's bits in the high word give an exponent below 0x7fd, see insert5), so the result is
+// the same.  Not volatile: unused halves of a comparator are still removed.
+__device__ __forceinline__ double min_raw(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double max_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // Sorted ascending top-5 of unique keys.  A key with a non-negative float in its high word is a
 // finite positive double whose IEEE order equals the unsigned order of the bits (float exponent
 // 0xFF maps to double exponent <= 0x7FC, still finite), so one compare-exchange is v_min_f64 +
@@ -66,7 +86,7 @@ __device__ __forceinline__ void insert5(u64 (&t)[kK], u64 k)
 #pragma unroll
     for (int i = 0; i < kK; ++i) {
         const double ti = __longlong_as_double((long long)t[i]);
-        const double lo = fmin(ti, kd), hi = fmax(ti, kd);
+        const double lo = min_raw(ti, kd), hi = max_raw(ti, kd);
         t[i] = (u64)__double_as_longlong(lo);
         kd = hi;
     }
@@ -89,7 +109,7 @@ __device__ __forceinline__ void insert5(u64 (&t)[kK], u64 k)
 #endif
 __device__ __forceinline__ void cex(double &a, double &b)
 {
-    const double lo = fmin(a, b), hi = fmax(a, b);
+    const double lo = min_raw(a, b), hi = max_raw(a, b);
     a = lo; b = hi;
 }
 // Eight new keys into the sorted top-5 in 48 min/max instead of 80: the 19-comparator sorting network for
@@ -110,7 +130,7 @@ __device__ __forceinline__ void insert_batch8(u64 (&t)[kK], const u64 (&k)[8])
     cex(v[1], v[2]); cex(v[3], v[4]); cex(v[5], v[6]);
     double c[kK];
 #pragma unroll
-    for (int i = 0; i < kK; ++i) c[i] = fmin(__longlong_as_double((long long)t[i]), v[kK - 1 - i]);
+    for (int i = 0; i < kK; ++i) c[i] = min_raw(__longlong_as_double((long long)t[i]), v[kK - 1 - i]);
     cex(c[0], c[4]); cex(c[1], c[3]); cex(c[1], c[4]); cex(c[2], c[4]); cex(c[3], c[4]);
 #pragma unroll
     for (int i = 0; i < kK; ++i) t[i] = (u64)__double_as_longlong(c[i]);
@@ -118,20 +138,20 @@ __device__ __forceinline__ void insert_batch8(u64 (&t)[kK], const u64 (&k)[8])
 
 // points pts[s, e) -> top-5, B independent 16-byte loads per batch
 template <int B>
-__device__ __forceinline__ void scan_points(const float4 *__restrict__ pts, uint32_t s, uint32_t e, float wx,
-                                            float wy, float wz, u64 (&t)[kK])
+__device__ __forceinline__ void scan_points(const float4 *__restrict__ pts, uint32_t sent, uint32_t s, uint32_t e,
+                                            float wx, float wy, float wz, u64 (&t)[kK])
 {
     for (uint32_t i = s; i < e; i += B) {
         float4 p[B];
 #pragma unroll
-        for (int u = 0; u < B; ++u) p[u] = pts[min(i + u, e - 1)];
+        for (int u = 0; u < B; ++u) p[u] = pts[(i + u < e) ? i + u : sent];
         u64 key[B];
 #pragma unroll
         for (int u = 0; u < B; ++u) {
             const float dx = wx - p[u].x, dy = wy - p[u].y, dz = wz - p[u].z;
             float d = dx * dx + dy * dy;
             d = d + dz * dz;
-            key[u] = (i + u < e) ? make_key(d, __float_as_uint(p[u].w)) : kEmptyKey;
+            key[u] = make_key(d, __float_as_uint(p[u].w));
         }
         if (S2M_BATCH_SORT && S2M_INSERT_F64 && B == 8) {
             u64 k8[8];
@@ -159,7 +179,7 @@ __device__ __forceinline__ void scan_row(const Grid &g, int yy, int zz, int xa, 
         if (te.x == 0 || ((mword >> (rowbit & 31)) & 1u) == 0) continue;
         const int l0 = max(xa, bx << 3) & 7, l1 = min(xb, (bx << 3) + 7) & 7;
         const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + (rowbit << 3);
-        scan_points<4>(g.pts, tb[l0], tb[l1 + 1], wx, wy, wz, t);
+        scan_points<4>(g.pts, (uint32_t)g.m, tb[l0], tb[l1 + 1], wx, wy, wz, t);
     }
 }
 
@@ -230,7 +250,7 @@ __device__ __forceinline__ void merge_lists(const u64 (&priv)[kK], u64 (&best)[k
     for (int k = 0; k < kK; ++k) {
         const u64 m = group_min_u64<G>(t[0]);
         best[k] = m;
-        if (t[0] == m && m != kEmptyKey) {
+        if (t[0] == m && !is_empty(m)) {
 #pragma unroll
             for (int s = 0; s < kK - 1; ++s) t[s] = t[s + 1];
             t[kK - 1] = kEmptyKey;
@@ -288,7 +308,7 @@ __device__ __forceinline__ void store_result(const u64 (&best)[kK], int64_t q, i
 {
 #pragma unroll
     for (int k = 0; k < kK; ++k) {
-        const bool has = best[k] != kEmptyKey;
+        const bool has = !is_empty(best[k]);
         nn_idx[q * kK + k] = has ? (int32_t)(uint32_t)(best[k] & 0xffffffffull) : -1;
         nn_d2[q * kK + k] = has ? __uint_as_float((uint32_t)(best[k] >> 32)) : INFINITY;
     }
@@ -372,9 +392,9 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
 #pragma unroll
     for (int k = 0; k < kK; ++k) t[k] = kEmptyKey;
 #pragma unroll
-    for (int i = 0; i < HC; ++i) scan_points<kEasyBatch>(g.pts, hs[i], he[i], q.wx, q.wy, q.wz, t);
+    for (int i = 0; i < HC; ++i) scan_points<kEasyBatch>(g.pts, (uint32_t)g.m, hs[i], he[i], q.wx, q.wy, q.wz, t);
     merge_lists<G>(t, best);
-    const bool have_tau = best[kK - 1] != kEmptyKey;
+    const bool have_tau = !is_empty(best[kK - 1]);
     const float tau = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
     // phase 3b: the other 24 cells, skipping those that cannot hold anything closer than tau
 #pragma unroll
@@ -382,10 +402,10 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (rs[i][c] < re[i][c] && !(have_tau && cell_bound2(g, q, c - 1, rdy[i], rdz[i]) > tau))
-                scan_points<kEasyBatch>(g.pts, rs[i][c], re[i][c], q.wx, q.wy, q.wz, t);
+                scan_points<kEasyBatch>(g.pts, (uint32_t)g.m, rs[i][c], re[i][c], q.wx, q.wy, q.wz, t);
         }
     merge_lists<G>(t, best);
-    const bool found5 = best[kK - 1] != kEmptyKey;
+    const bool found5 = !is_empty(best[kK - 1]);
     const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
     const bool done = found5 && d5 <= cube_bound2(g, q, 1);
     // Unresolved points go to one of three lists by expected cost (cube radius implied by the current
@@ -529,7 +549,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
                     if (j < ctotal) {
                         const int x = jxa + (j - jex);
                         const uint32_t *tb = g.tab + (int64_t)(jid - 1) * kBrickStride + (jrow << 3) + (x & 7);
-                        scan_points<kHardBatch>(g.pts, tb[0], tb[1], q.wx, q.wy, q.wz, t);
+                        scan_points<kHardBatch>(g.pts, (uint32_t)g.m, tb[0], tb[1], q.wx, q.wy, q.wz, t);
                     }
                 }
             }
@@ -670,7 +690,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
             nq = 0;
             ++rounds;
             merge_lists<G>(t, best);
-            const bool found5 = best[kK - 1] != kEmptyKey;
+            const bool found5 = !is_empty(best[kK - 1]);
             const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
             if (have_tau) break;  // every point within tau was visited: exact
             // band mode: rows with bound <= band^2 were scanned over their whole reach of this band only,
