@@ -38,6 +38,7 @@ struct Grid {
     const float4 *pts;
     const float4 *porig;
     int64_t m;
+    uint32_t sent_off;  // byte offset of the sentinel block pts[m..m+8) (valid while it fits 32 bits), else 0
 };
 
 // rot_end, pos_end, R_L_I, T_L_I of StatesGroup (eskf_lio/include/common_lib.h:219-222)

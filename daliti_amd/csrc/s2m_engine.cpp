@@ -305,6 +305,8 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
         const int v = std::atoi(g);
         if (v == 16 || v == 32 || v == 64) e->match_group |= v << 8;
     }
+    if (const char *g = std::getenv("S2M_WIDE_ADDR"))
+        if (std::atoi(g) != 0) e->match_group |= 0x10000;
     e->dbg = std::getenv("S2M_DEBUG_MATCH") != nullptr;
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&e->ev[i]) == hipSuccess;

@@ -237,6 +237,7 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     g.c = cell;
     g.inv_c = 1.0f / cell;
     g.m = m;
+    g.sent_off = (m + kSentinelPoints) < ((int64_t)1 << 28) ? (uint32_t)(m << 4) : 0u;
     // one cell of padding below the box; extents rounded up to whole bricks.  The origin is shifted
     // by an odd fraction of a cell per axis: man-made scenes have planes at round coordinates, and a
     // plane that coincides with a cell face splits its points over two cell layers and leaves every
@@ -262,11 +263,12 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     const float max_cells = (float)std::max(std::max(nc[0], nc[1]), nc[2]);
     g.slop = std::max(1.0e-4f, 16.0f * max_cells * 1.1920929e-7f);
 
-    // one extra element: the sentinel point the search kernels load for the padding slots of a batch (far
-    // enough for its squared distance to overflow to +inf; index word 0xffffffff)
-    S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m + 1, sizeof(float4)));
+    // eight extra elements: the sentinel points the search kernels load for the padding slots of a batch
+    // (far enough for the squared distance to overflow to +inf; index word 0xffffffff)
+    S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m + kSentinelPoints, sizeof(float4)));
     {
-        static const uint32_t sentinel[4] = {0x7f61b1e6u, 0x7f61b1e6u, 0x7f61b1e6u, 0xffffffffu};  // 3.0e38f x3
+        static uint32_t sentinel[kSentinelPoints][4];
+        for (auto &q : sentinel) { q[0] = q[1] = q[2] = 0x7f61b1e6u; q[3] = 0xffffffffu; }  // 3.0e38f x3
         S2M_TRY(hipMemcpyAsync(buf.pts + m, sentinel, sizeof(sentinel), hipMemcpyHostToDevice, st));
     }
     S2M_TRY(ensure((void **)&buf.porig, &buf.porig_cap, m, sizeof(float4)));

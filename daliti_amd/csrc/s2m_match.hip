@@ -136,15 +136,28 @@ __device__ __forceinline__ void insert_batch8(u64 (&t)[kK], const u64 (&k)[8])
     for (int i = 0; i < kK; ++i) t[i] = (u64)__double_as_longlong(c[i]);
 }
 
-// points pts[s, e) -> top-5, B independent 16-byte loads per batch
-template <int B>
-__device__ __forceinline__ void scan_points(const float4 *__restrict__ pts, uint32_t sent, uint32_t s, uint32_t e,
-                                            float wx, float wy, float wz, u64 (&t)[kK])
+// points pts[s, e) -> top-5, B independent 16-byte loads per batch.  Addresses are a uniform base plus a
+// 32-bit byte offset (the saddr form of global_load: no 64-bit address arithmetic per slot); padding slots
+// select the offset of the sentinel block pts[m .. m+B), which the instruction's immediate offset then
+// indexes like any other batch.  Maps beyond 2^28 - 8 points take 64-bit addresses (WIDE).
+template <int B, bool WIDE = false>
+__device__ __forceinline__ void scan_points(const Grid &g, uint32_t s, uint32_t e, float wx, float wy, float wz,
+                                            u64 (&t)[kK])
 {
+    const float4 *__restrict__ pts = g.pts;
     for (uint32_t i = s; i < e; i += B) {
         float4 p[B];
+        if (WIDE) {
+            const uint32_t sent = (uint32_t)g.m;
 #pragma unroll
-        for (int u = 0; u < B; ++u) p[u] = pts[(i + u < e) ? i + u : sent];
+            for (int u = 0; u < B; ++u) p[u] = pts[(i + u < e) ? i + u : sent];
+        } else {
+            const uint32_t left = e - i, off = i << 4, soff = g.sent_off;
+            const char *base = reinterpret_cast<const char *>(pts);
+#pragma unroll
+            for (int u = 0; u < B; ++u)
+                p[u] = *reinterpret_cast<const float4 *>(base + (size_t)(((uint32_t)u < left) ? off : soff) + 16 * u);
+        }
         u64 key[B];
 #pragma unroll
         for (int u = 0; u < B; ++u) {
@@ -162,24 +175,6 @@ __device__ __forceinline__ void scan_points(const float4 *__restrict__ pts, uint
 #pragma unroll
             for (int u = 0; u < B; ++u) insert5(t, key[u]);
         }
-    }
-}
-
-// cells [xa, xb] of x-row (yy, zz): per brick one 16-byte top entry (id + row mask), two table
-// words, then the point run
-__device__ __forceinline__ void scan_row(const Grid &g, int yy, int zz, int xa, int xb, float wx, float wy,
-                                         float wz, u64 (&t)[kK])
-{
-    const int by = yy >> 3, bz = zz >> 3;
-    const int rowbit = ((zz & 7) << 3) | (yy & 7);
-    const int64_t toprow = ((int64_t)bz * g.nby + by) * g.nbx;
-    for (int bx = xa >> 3; bx <= (xb >> 3); ++bx) {
-        const uint4 te = g.top[toprow + bx];
-        const uint32_t mword = (rowbit & 32) ? te.w : te.z;
-        if (te.x == 0 || ((mword >> (rowbit & 31)) & 1u) == 0) continue;
-        const int l0 = max(xa, bx << 3) & 7, l1 = min(xb, (bx << 3) + 7) & 7;
-        const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + (rowbit << 3);
-        scan_points<4>(g.pts, (uint32_t)g.m, tb[l0], tb[l1 + 1], wx, wy, wz, t);
     }
 }
 
@@ -336,7 +331,7 @@ __device__ __forceinline__ CellRef cell_ref(const Grid &g, int xx, int yy, int z
     return r;
 }
 
-template <int G>
+template <int G, bool WIDE>
 __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
 {
     constexpr int HC = (3 + G - 1) / G;  // home-row cells per lane
@@ -392,7 +387,7 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
 #pragma unroll
     for (int k = 0; k < kK; ++k) t[k] = kEmptyKey;
 #pragma unroll
-    for (int i = 0; i < HC; ++i) scan_points<kEasyBatch>(g.pts, (uint32_t)g.m, hs[i], he[i], q.wx, q.wy, q.wz, t);
+    for (int i = 0; i < HC; ++i) scan_points<kEasyBatch, WIDE>(g, hs[i], he[i], q.wx, q.wy, q.wz, t);
     merge_lists<G>(t, best);
     const bool have_tau = !is_empty(best[kK - 1]);
     const float tau = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
@@ -402,7 +397,7 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (rs[i][c] < re[i][c] && !(have_tau && cell_bound2(g, q, c - 1, rdy[i], rdz[i]) > tau))
-                scan_points<kEasyBatch>(g.pts, (uint32_t)g.m, rs[i][c], re[i][c], q.wx, q.wy, q.wz, t);
+                scan_points<kEasyBatch, WIDE>(g, rs[i][c], re[i][c], q.wx, q.wy, q.wz, t);
         }
     merge_lists<G>(t, best);
     const bool found5 = !is_empty(best[kK - 1]);
@@ -471,6 +466,7 @@ __device__ __forceinline__ int kth_set_bit(uint64_t m, int k)
 // of 4 vs 8 make no difference -- the kernel is VALU-issue bound at ~58 %, TA ~27 % busy).
 constexpr int kPairSlots = 6;  // (brick,row) pairs a lane can hold per chunk of 64 bricks
 
+template <bool WIDE>
 __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
 {
     constexpr int G = 64;
@@ -549,7 +545,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
                     if (j < ctotal) {
                         const int x = jxa + (j - jex);
                         const uint32_t *tb = g.tab + (int64_t)(jid - 1) * kBrickStride + (jrow << 3) + (x & 7);
-                        scan_points<kHardBatch>(g.pts, (uint32_t)g.m, tb[0], tb[1], q.wx, q.wy, q.wz, t);
+                        scan_points<kHardBatch, WIDE>(g, tb[0], tb[1], q.wx, q.wy, q.wz, t);
                     }
                 }
             }
@@ -715,27 +711,33 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
 }
 
 template <int G>
-static void launch_easy(const MatchArgs &a, hipStream_t st)
+static void launch_easy(const MatchArgs &a, bool wide, hipStream_t st)
 {
     const int64_t threads = (int64_t)a.n * G;
     const int blocks = (int)((threads + 255) / 256);
-    hipLaunchKernelGGL(match_easy<G>, dim3(blocks), dim3(256), 0, st, a);
+    // 32-bit byte offsets into the sorted point array unless the map is too large for them
+    if (!wide) hipLaunchKernelGGL((match_easy<G, false>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((match_easy<G, true>), dim3(blocks), dim3(256), 0, st, a);
 }
 
 void launch_match(const MatchArgs &a, int group, hipStream_t st)
 {
     if (a.n <= 0) return;
+    // 64-bit point addresses when the sentinel block is out of reach of a 32-bit byte offset (or on request:
+    // bit 16 of `group`, S2M_WIDE_ADDR=1, so the tests can cover that path on a small map)
+    const bool wide = (a.grid.sent_off == 0 && a.grid.m != 0) || (group & 0x10000);
     switch (group & 0xff) {
-        case 1: launch_easy<1>(a, st); break;
-        case 2: launch_easy<2>(a, st); break;
-        case 8: launch_easy<8>(a, st); break;
-        default: launch_easy<4>(a, st); break;
+        case 1: launch_easy<1>(a, wide, st); break;
+        case 2: launch_easy<2>(a, wide, st); break;
+        case 8: launch_easy<8>(a, wide, st); break;
+        default: launch_easy<4>(a, wide, st); break;
     }
     // fixed grid, groups stride over the hard list whose length is only known on the device
     const int hg = 64;  // one wave per hard point (narrower groups measured slower: the far tail is latency-bound)
     const int64_t groups = std::min<int64_t>(a.n, 8192 * (64 / hg));
     const int blocks = (int)((groups * hg + 255) / 256);
-    hipLaunchKernelGGL(match_hard, dim3(blocks), dim3(256), 0, st, a);
+    if (!wide) hipLaunchKernelGGL(match_hard<false>, dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(match_hard<true>, dim3(blocks), dim3(256), 0, st, a);
 }
 
 }  // namespace s2m

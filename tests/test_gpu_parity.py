@@ -152,6 +152,28 @@ def test_group_width_invariance(eng, small_scene, group):
     e.close()
 
 
+def test_wide_address_path(eng, small_scene):
+    """Maps beyond 2^28 points address the sorted array with 64-bit pointers; force that code path on a
+    small map (S2M_WIDE_ADDR=1) and require the identical result."""
+    from daliti_amd import Engine
+    x = small_scene["x_prop"]
+    eng.scan_set(small_scene["scan"])
+    ref_out = eng.residual_pass(x, True)
+    ref_idx, ref_d2 = eng.get_neighbors()
+    os.environ["S2M_WIDE_ADDR"] = "1"
+    try:
+        e = Engine(keep_neighbors=1)
+    finally:
+        del os.environ["S2M_WIDE_ADDR"]
+    e.map_build(small_scene["map"])
+    e.scan_set(small_scene["scan"])
+    out = e.residual_pass(x, True)
+    idx, d2 = e.get_neighbors()
+    assert (idx == ref_idx).all() and (bits(d2) == bits(ref_d2)).all()
+    assert (bits(out["HtH"]) == bits(ref_out["HtH"])).all()
+    e.close()
+
+
 def test_edge_cases(oracle, small_scene):
     from daliti_amd import Engine, S2MError
     e = Engine(keep_neighbors=1, cell_size=0.25)
