@@ -1,7 +1,8 @@
 // s2m_device.h -- data layout shared by the HIP kernels of the scan-to-map engine (gfx950).
 //
 // Map layout in HBM ("brick grid", replaces the ikd-Tree of eskf_lio/include/ikd-Tree/):
-//   pts   : M x float4 {x, y, z, bitcast(original index)}, sorted by (brick, cell-in-brick);
+//   pts   : M x float4 {x, y, bitcast(original index), z} (make_map_point), sorted by (brick, cell-in-brick),
+//           followed by 8 sentinel points (padding targets of the search kernels' batches);
 //           one 16-byte load per candidate, a cell's points are contiguous, the cells of one
 //           x-row of a brick are contiguous.
 //   porig : M x float4 {x, y, z, 0} in the caller's original order; neighbour indices returned by
@@ -40,6 +41,24 @@ struct Grid {
     int64_t m;
     uint32_t sent_off;  // byte offset of the sentinel block pts[m..m+8) (valid while it fits 32 bits), else 0
 };
+
+// Element of the sorted point array Grid::pts: {x, y, bitcast(original index), z}.  The index sits in the
+// third word so that a search key (index, d2) is formed in place: the 64-bit key needs an even-aligned
+// register pair, the index already is in one, and d2 is written over z once dz has been taken -- no
+// register moves per candidate (three with the natural {x, y, z, index} order).
+__host__ __device__ inline float4 make_map_point(float x, float y, float z, uint32_t idx)
+{
+    float4 p;
+    p.x = x; p.y = y; p.w = z;
+#if defined(__HIP_DEVICE_COMPILE__)
+    p.z = __uint_as_float(idx);
+#else
+    __builtin_memcpy(&p.z, &idx, 4);
+#endif
+    return p;
+}
+__device__ __forceinline__ float map_point_z(const float4 &p) { return p.w; }
+__device__ __forceinline__ uint32_t map_point_index(const float4 &p) { return __float_as_uint(p.z); }
 
 // rot_end, pos_end, R_L_I, T_L_I of StatesGroup (eskf_lio/include/common_lib.h:219-222)
 struct Pose {

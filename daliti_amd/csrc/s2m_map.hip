@@ -129,8 +129,8 @@ __global__ __launch_bounds__(256) void gather_flag_kernel(const float *__restric
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const uint32_t src = vals[j];
-    pts[j] = make_float4(xyz[(int64_t)src * stride], xyz[(int64_t)src * stride + 1], xyz[(int64_t)src * stride + 2],
-                         __uint_as_float(src));
+    pts[j] = make_map_point(xyz[(int64_t)src * stride], xyz[(int64_t)src * stride + 1], xyz[(int64_t)src * stride + 2],
+                            src);
     porig[j] = make_float4(xyz[j * stride], xyz[j * stride + 1], xyz[j * stride + 2], 0.0f);
     flag[j] = (j == 0 || (keys[j] >> 9) != (keys[j - 1] >> 9)) ? 1u : 0u;
 }
@@ -268,7 +268,7 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m + kSentinelPoints, sizeof(float4)));
     {
         static uint32_t sentinel[kSentinelPoints][4];
-        for (auto &q : sentinel) { q[0] = q[1] = q[2] = 0x7f61b1e6u; q[3] = 0xffffffffu; }  // 3.0e38f x3
+        for (auto &q : sentinel) { q[0] = q[1] = q[3] = 0x7f61b1e6u; q[2] = 0xffffffffu; }  // make_map_point(3e38f x3, ~0)
         S2M_TRY(hipMemcpyAsync(buf.pts + m, sentinel, sizeof(sentinel), hipMemcpyHostToDevice, st));
     }
     S2M_TRY(ensure((void **)&buf.porig, &buf.porig_cap, m, sizeof(float4)));

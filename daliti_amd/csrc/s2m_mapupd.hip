@@ -104,8 +104,9 @@ __device__ __forceinline__ void for_points_in_box(const Grid &g, const float (&m
                 const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + (rowbit << 3);
                 const uint32_t e = tb[l1 + 1];
                 for (uint32_t i = tb[l0]; i < e; ++i) {
-                    const float4 p = g.pts[i];
-                    if (in_box(p, mn, mx)) f(p, __float_as_uint(p.w));
+                    const float4 q = g.pts[i];  // {x, y, index, z}
+                    const float4 p = make_float4(q.x, q.y, map_point_z(q), 0.0f);
+                    if (in_box(p, mn, mx)) f(p, map_point_index(q));
                 }
             }
         }

@@ -144,7 +144,9 @@ template <int B, bool WIDE = false>
 __device__ __forceinline__ void scan_points(const Grid &g, uint32_t s, uint32_t e, float wx, float wy, float wz,
                                             u64 (&t)[kK])
 {
+    typedef float f2 __attribute__((ext_vector_type(2)));
     const float4 *__restrict__ pts = g.pts;
+    const f2 wxy = {wx, wy};
     for (uint32_t i = s; i < e; i += B) {
         float4 p[B];
         if (WIDE) {
@@ -161,10 +163,14 @@ __device__ __forceinline__ void scan_points(const Grid &g, uint32_t s, uint32_t 
         u64 key[B];
 #pragma unroll
         for (int u = 0; u < B; ++u) {
-            const float dx = wx - p[u].x, dy = wy - p[u].y, dz = wz - p[u].z;
-            float d = dx * dx + dy * dy;
+            // (dx, dy) as one packed pair straight from the loaded words; same operations and order as
+            // the scalar form: (dx*dx + dy*dy) + dz*dz
+            const f2 dxy = wxy - f2{p[u].x, p[u].y};
+            const f2 sq = dxy * dxy;
+            const float dz = wz - map_point_z(p[u]);
+            float d = sq.x + sq.y;
             d = d + dz * dz;
-            key[u] = make_key(d, __float_as_uint(p[u].w));
+            key[u] = make_key(d, map_point_index(p[u]));
         }
         if (S2M_BATCH_SORT && S2M_INSERT_F64 && B == 8) {
             u64 k8[8];
