@@ -116,6 +116,24 @@ __device__ __forceinline__ void jac_row(const Pose &P, float bx, float by, float
     z = -(double)pd2;
 }
 
+// Hand-off of the 160-double block to the spinning host thread.  A system-scope release fence (or release
+// store) makes the compiler write back the whole L2 first (buffer_wbl2) -- microseconds, with the per-point
+// outputs of this very launch dirty in it -- although only these 160 stores have to be visible.  So: the
+// payload goes out as write-through system-scope stores, every storing wave drains them (vmcnt(0): the
+// fabric has accepted them), the workgroup meets, and the flag follows as one more such store on the same
+// ordered path to the pinned host page.
+__device__ __forceinline__ void publish_store(double *dst, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void publish_flag(unsigned long long *flag, unsigned long long seq)  // whole workgroup
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <bool EXT, bool FIT>
 __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
 {
@@ -278,28 +296,21 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
             v = tot[T::kRes];
         }
         a.block[o] = v;
-        if (a.host_block) a.host_block[o] = v;
+        if (a.host_block) publish_store(a.host_block + o, v);
     }
     if (threadIdx.x == 0) {
         __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
         if (a.hard_count) { a.hard_count[0] = 0u; a.hard_count[1] = 0u; a.hard_count[2] = 0u; }
     }
-    if (a.host_flag) {
-        __threadfence_system();  // every writer of host_block releases to the system
-        __syncthreads();
-        if (threadIdx.x == 0)
-            __hip_atomic_store(a.host_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (a.host_flag) publish_flag(a.host_flag, a.seq);
 }
 
 // after a collective: copy the summed block to pinned host memory and raise the sequence flag
 __global__ __launch_bounds__(192) void publish_kernel(const double *__restrict__ block, double *__restrict__ host_block,
                                                       unsigned long long *__restrict__ host_flag, unsigned long long seq)
 {
-    if (threadIdx.x < 160) host_block[threadIdx.x] = block[threadIdx.x];
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x < 160) publish_store(host_block + threadIdx.x, block[threadIdx.x]);
+    publish_flag(host_flag, seq);
 }
 void launch_publish(const double *block, double *host_block, unsigned long long *host_flag, unsigned long long seq,
                     hipStream_t st)
