@@ -80,6 +80,7 @@ struct s2m_engine {
 
     Pose last_pose{};
     uint32_t *d_hard = nullptr;   // hard list (n entries) followed by its counter
+    float *d_wq = nullptr;        // world-frame query points of the hard list (3 x n_cap)
     uint32_t *d_dbg = nullptr;  // S2M_DEBUG_MATCH=1: per-point diagnostics of the match kernel
     bool dbg = false;
     bool nn_valid = false;
@@ -193,6 +194,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         m.sx = sx; m.sy = sy; m.sz = sz; m.n = n;
         m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
         m.hard_list = e->d_hard; m.hard_count = e->d_hard + 3 * e->n_cap;
+        m.wq = e->d_wq;
         m.dbg = e->dbg ? e->d_dbg : nullptr;
         launch_match(m, e->match_group, e->stream);  // hard_count is zero: reset by every reduce launch
         e->nn_valid = true;
@@ -336,7 +338,7 @@ int s2m_destroy(s2m_engine *e)
     free_undist(e->und);
     comm_destroy(e->comm);
     void *ptrs[] = {e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
-                    e->d_nn_d2, e->d_hard, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
+                    e->d_nn_d2, e->d_hard, e->d_wq, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_block) (void)hipHostFree(e->h_block);
@@ -589,6 +591,7 @@ int scan_reserve(s2m_engine *e, int64_t n)
     rc = rc ? rc : grow(e, &e->d_partials, (int64_t)std::max(reduce_blocks((int)cap), 1) * kRedTerms);
     rc = rc ? rc : grow(e, &e->d_block_off, (int64_t)rows_blocks((int)cap) + 1);
     rc = rc ? rc : grow(e, &e->d_hard, 3 * cap + 16);
+    rc = rc ? rc : grow(e, &e->d_wq, 3 * cap);
     if (!rc) S2M_HIP(e, hipMemsetAsync(e->d_hard + 3 * cap, 0, 16 * sizeof(uint32_t), e->stream));
     if (e->dbg) rc = rc ? rc : grow(e, &e->d_dbg, cap * 4);
     if (rc) return rc;

@@ -119,6 +119,7 @@ struct MatchArgs {
     float *nn_d2;        // n x 5 ascending, INFINITY = missing
     uint32_t *hard_list; // 3 x n entries of scratch: points the first-shell kernel could not resolve, by cost class
     uint32_t *hard_count; // 3 counters (far, mid, near)
+    float *wq = nullptr;      // 3 x n scratch: world-frame query point of every unresolved scan point (SoA)
     uint32_t *dbg = nullptr;  // optional diagnostics, 4 words per scan point
 };
 void launch_match(const MatchArgs &a, int group, hipStream_t st);

@@ -279,10 +279,11 @@ struct Query {
     float fmin;           // distance from the query to the nearest face of its home cell, in cells
 };
 
-__device__ __forceinline__ Query make_query(const Grid &g, const Pose &pose, float bx, float by, float bz)
+// home cell and in-cell position of a world-frame query point
+__device__ __forceinline__ Query query_at(const Grid &g, float wx, float wy, float wz)
 {
     Query q;
-    body_to_world(pose, bx, by, bz, q.wx, q.wy, q.wz);
+    q.wx = wx; q.wy = wy; q.wz = wz;
     const float fx = (q.wx - g.ox) * g.inv_c, fy = (q.wy - g.oy) * g.inv_c, fz = (q.wz - g.oz) * g.inv_c;
     const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
     // clamp far-away queries so the int conversion is defined; the bound stays valid because the
@@ -295,6 +296,12 @@ __device__ __forceinline__ Query make_query(const Grid &g, const Pose &pose, flo
     float f = fminf(fminf(q.frx, 1.0f - q.frx), fminf(q.fry, 1.0f - q.fry));
     q.fmin = fminf(f, fminf(q.frz, 1.0f - q.frz));
     return q;
+}
+__device__ __forceinline__ Query make_query(const Grid &g, const Pose &pose, float bx, float by, float bz)
+{
+    float wx, wy, wz;
+    body_to_world(pose, bx, by, bz, wx, wy, wz);
+    return query_at(g, wx, wy, wz);
 }
 
 // every point outside the cube of radius r (cells) around the home cell is at least this far
@@ -443,8 +450,10 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
         }
     }
     if (j == 0) {
-        // unresolved points keep their first-shell list too: match_hard takes its radius from it
+        // unresolved points keep their first-shell list too: match_hard takes its radius from it, and its
+        // query point from here (the pose alone is 48 SGPRs that kernel would spill around every point)
         store_result(best, qi, a.nn_idx, a.nn_d2);
+        if (!done) { a.wq[qi] = q.wx; a.wq[(int64_t)a.n + qi] = q.wy; a.wq[2 * (int64_t)a.n + qi] = q.wz; }
         if (a.dbg) {
             a.dbg[4 * (int64_t)qi + 0] = (uint32_t)(wall_clock64() - t0);
             a.dbg[4 * (int64_t)qi + 1] = done ? 1u : 0u;
@@ -516,7 +525,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
         const int qi = (int)(h < c0 ? a.hard_list[h]
                                     : (h < c0 + c1 ? a.hard_list[(int64_t)a.n + (h - c0)]
                                                    : a.hard_list[2 * (int64_t)a.n + (h - c0 - c1)]));
-        const Query q = make_query(g, a.pose, a.sx[qi], a.sy[qi], a.sz[qi]);
+        const Query q = query_at(g, a.wq[qi], a.wq[(int64_t)a.n + qi], a.wq[2 * (int64_t)a.n + qi]);
         const float fxq = (float)q.cx + q.frx;  // query x in cell units
         // radius: the first shell's 5th-best distance when it found five (then one round is exact)
         const int32_t ci4 = a.nn_idx[(int64_t)qi * kK + (kK - 1)];
