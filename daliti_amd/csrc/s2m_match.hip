@@ -18,9 +18,14 @@
 //                   every lane has all its loads of a phase in flight together.  If the 5th-best
 //                   distance is provably inside the cube the result is final; otherwise the point
 //                   is appended to the hard list.
-//   match_hard    : one wave per hard point; the 64 lanes split the x-rows of a growing cube (only
-//                   new shells are scanned), jump straight to the radius implied by the current
-//                   5th-best distance, and stop once the bound passes the d2 <= 5 gate (:853).
+//   match_hard    : one wave per hard point.  The x-rows that can hold a point within the current radius
+//                   (the first shell's 5th distance, else a growing band) are found either directly -- the
+//                   7x7 rows around the home row while the radius is within three cells -- or from the
+//                   row masks of the surrounding bricks; their cells are expanded into an LDS cell list by
+//                   a DPP prefix sum and dealt to the 64 lanes, so the point loads of all rows are in
+//                   flight together.  Stops once the bound passes the d2 <= 5 gate (:853).
+// Padding slots of a point batch load a sentinel point beyond the array (distance +inf), so the inner loop
+// has no predicate; keys go into the top-5 eight at a time through a pruned sorting network.
 // Brick row masks (s2m_device.h) skip the table lookups of rows that hold no points.
 //
 // Arithmetic contract: compiled with -ffp-contract=off; d2 = ((dx*dx + dy*dy) + dz*dz) in float
@@ -498,9 +503,9 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
 {
     constexpr int G = 64;
-    constexpr int kMaxDesc = 192;
-    __shared__ uint32_t desc_all[4][kMaxDesc][3];  // one descriptor list per wave of the workgroup
-    uint32_t (*desc)[3] = desc_all[threadIdx.x >> 6];
+    constexpr int kMaxCells = 1024;  // an append adds at most 64 rows x 8 cells
+    __shared__ uint2 cells_all[4][kMaxCells];  // one cell list per wave of the workgroup
+    uint2 *cells = cells_all[threadIdx.x >> 6];
     const Grid &g = a.grid;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -540,39 +545,33 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
         float band = 1.7f * g.c;
         uint32_t rounds = 0;
         const int hbx = q.cx >> 3, hby = q.cy >> 3, hbz = q.cz >> 3;
-        int nq = 0;  // qualifying (brick,row) pairs waiting in the wave's descriptor list (wave-uniform)
-        // Descriptors {brick id, row | cells << 8, first cell}: every lane takes one, the cells of all of them
-        // are numbered with a wave prefix sum, and cell j goes to lane j % 64 -- so the point loads of all
-        // qualifying rows of all slots are in flight together instead of slot after slot.
-        auto flush_desc = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // descriptor stores before the loads below
-            for (int cb = 0; cb < nq; cb += 64) {
-                const int k = cb + lane;
-                uint32_t did = 0, drow = 0, dxa = 0;
-                int dn = 0;
-                if (k < nq) { did = desc[k][0]; const uint32_t w = desc[k][1]; drow = w & 0xffu; dn = (int)(w >> 8); dxa = desc[k][2]; }
-                const int cincl = wave_incl_scan(dn);
-                const int cexcl = cincl - dn;
-                const int ctotal = __shfl(cincl, 63, 64);
-                for (int jb = 0; jb < ctotal; jb += 64) {  // wave-uniform trip count
-                    const int j = jb + lane;
-                    int o2 = 0;
+        int nc = 0;  // cells waiting in the wave's list (wave-uniform)
+        // Every qualifying row piece (cells xa .. xa+ncell-1 of one x-row of one brick) is expanded into the
+        // wave's cell list {brick id, table word}: positions come from a DPP prefix sum over the lanes, so
+        // the list needs no search afterwards.  flush_cells hands cell j to lane j % 64 -- the point loads of
+        // all qualifying rows are in flight together, however unevenly the rows are filled.
+        auto append_cells = [&](uint32_t id, int rowbit, int xa, int ncell) {
+            const int incl = wave_incl_scan(ncell);
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (total == 0) return;  // wave-uniform
+            const int at = nc + incl - ncell;
 #pragma unroll
-                    for (int step = 32; step >= 1; step >>= 1) {
-                        const int cand = o2 + step;
-                        const int pc = __shfl(cexcl, min(cand, 63), 64);
-                        if (cand < 64 && pc <= j) o2 = cand;
-                    }
-                    const uint32_t jid = __shfl(did, o2, 64);
-                    const int jrow = (int)__shfl(drow, o2, 64), jxa = (int)__shfl(dxa, o2, 64), jex = __shfl(cexcl, o2, 64);
-                    if (j < ctotal) {
-                        const int x = jxa + (j - jex);
-                        const uint32_t *tb = g.tab + (int64_t)(jid - 1) * kBrickStride + (jrow << 3) + (x & 7);
-                        scan_points<kHardBatch, WIDE>(g, tb[0], tb[1], q.wx, q.wy, q.wz, t);
-                    }
+            for (int c = 0; c < 8; ++c)
+                if (c < ncell) cells[at + c] = make_uint2(id, (uint32_t)((rowbit << 3) + ((xa + c) & 7)));
+            nc += total;
+        };
+        auto flush_cells = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // list stores before the loads below
+            for (int jb = 0; jb < nc; jb += 64) {  // wave-uniform trip count
+                const int j = jb + lane;
+                if (j < nc) {
+                    const uint2 ce = cells[j];
+                    const uint32_t *tb = g.tab + (int64_t)(ce.x - 1) * kBrickStride + ce.y;
+                    scan_points<kHardBatch, WIDE>(g, tb[0], tb[1], q.wx, q.wy, q.wz, t);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // loads above before the next stores
+            nc = 0;
         };
         for (;;) {
             const float r2 = have_tau ? tau : band * band;  // scan every pair whose bound is within r2
@@ -608,17 +607,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
                     }
                 }
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const unsigned long long qm = __ballot(ncl[k] > 0);
-                    if (qm == 0ull) continue;  // wave-uniform
-                    if (ncl[k] > 0) {
-                        const int pos = nq + __popcll(qm & ((1ull << lane) - 1ull));
-                        desc[pos][0] = nid[k];
-                        desc[pos][1] = (uint32_t)nrow | ((uint32_t)ncl[k] << 8);
-                        desc[pos][2] = (uint32_t)nxa[k];
-                    }
-                    nq += __popcll(qm);
-                }
+                for (int k = 0; k < 2; ++k) append_cells(nid[k], nrow, nxa[k], ncl[k]);  // <= 2 x 49 x 7 cells
             } else
             for (int bbase = 0; bbase < nbricks; bbase += 64) {
                 // 1. top entries of up to 64 bricks, one per lane
@@ -685,23 +674,13 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
                                 ncell = max(xb - xa + 1, 0);
                             }
                         }
-                        // append the qualifying pairs to the wave's descriptor list (ballot-ranked)
-                        const unsigned long long qm = __ballot(ncell > 0);
-                        if (qm != 0ull) {
-                            if (nq + 64 > kMaxDesc) { flush_desc(); nq = 0; }
-                            if (ncell > 0) {
-                                const int pos = nq + __popcll(qm & ((1ull << lane) - 1ull));
-                                desc[pos][0] = oid;
-                                desc[pos][1] = (uint32_t)rowbit | ((uint32_t)ncell << 8);
-                                desc[pos][2] = (uint32_t)xa;
-                            }
-                            nq += __popcll(qm);
-                        }
+                        // the qualifying pairs' cells go to the wave's list
+                        if (nc + 512 > kMaxCells) flush_cells();
+                        append_cells(oid, rowbit, xa, min(ncell, 8));
                     }
                 }
             }
-            flush_desc();
-            nq = 0;
+            flush_cells();
             ++rounds;
             merge_lists<G>(t, best);
             const bool found5 = !is_empty(best[kK - 1]);
