@@ -303,10 +303,6 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
         const int v = std::atoi(g);
         if (v == 1 || v == 2 || v == 4 || v == 8) e->match_group = v;
     }
-    if (const char *g = std::getenv("S2M_HARD_GROUP")) {
-        const int v = std::atoi(g);
-        if (v == 16 || v == 32 || v == 64) e->match_group |= v << 8;
-    }
     if (const char *g = std::getenv("S2M_WIDE_ADDR"))
         if (std::atoi(g) != 0) e->match_group |= 0x10000;
     e->dbg = std::getenv("S2M_DEBUG_MATCH") != nullptr;
