@@ -311,7 +311,8 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
     ok = ok && hipMalloc((void **)&e->d_block, S2M_BLOCK_DOUBLES * sizeof(double)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&e->h_block, (S2M_BLOCK_DOUBLES + 8) * sizeof(double), hipHostMallocMapped) == hipSuccess;
     ok = ok && hipHostGetDevicePointer((void **)&e->h_block_dev, e->h_block, 0) == hipSuccess;
-    ok = ok && hipMalloc((void **)&e->d_ticket, 64) == hipSuccess && hipMemset(e->d_ticket, 0, 64) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_ticket, kTicketWords * sizeof(uint32_t)) == hipSuccess &&
+         hipMemset(e->d_ticket, 0, kTicketWords * sizeof(uint32_t)) == hipSuccess;
     if (ok) std::memset(e->h_block, 0, (S2M_BLOCK_DOUBLES + 8) * sizeof(double));
     e->host_poll = std::getenv("S2M_NO_HOST_POLL") == nullptr;
     if (!ok) {

@@ -127,6 +127,9 @@ void launch_match(const MatchArgs &a, int group, hipStream_t st);
 // ---- s2m_reduce.hip : [plane fit +] residual + Jacobian + normal block ----------------------------
 constexpr int kRedBlock = 512;   // 8 waves per workgroup: 128 partial rows at 65k points for the in-kernel final sum
 constexpr int kRowsBlock = 256;
+constexpr int kTicketGroups = 16;  // group counters of the two-level arrival count, one cache line apart
+constexpr int kTicketStride = 32;  // words (128 B)
+constexpr int kTicketWords = kTicketStride * (1 + kTicketGroups);
 constexpr int kRedTerms = 96;    // 78 (upper triangle of 12x12) + 12 + total_res + count, padded
 struct ReduceArgs {
     Pose pose;
@@ -144,7 +147,7 @@ struct ReduceArgs {
     float *pd2;
     double *partials;  // blocks x kRedTerms
     double *block;     // S2M_BLOCK_DOUBLES output (device)
-    uint32_t *ticket;  // arrival counter of the in-kernel final sum; zero before the first launch
+    uint32_t *ticket;  // arrival counters of the in-kernel final sum (kTicketWords words, zero before the first launch)
     uint32_t *hard_count;            // reset to 0 for the next rematch pass
     double *host_block;              // optional: pinned host copy of block, device-visible pointer
     unsigned long long *host_flag;   // optional: set to seq (system scope) after host_block is written

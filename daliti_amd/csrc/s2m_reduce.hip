@@ -241,8 +241,19 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
     __syncthreads();
     __shared__ uint32_t s_last;
     if (threadIdx.x == 0) {
-        const uint32_t tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (tk == gridDim.x - 1) ? 1u : 0u;
+        // Two-level arrival count: same-address atomics serialise in L2 (~11 ns each), so 128 workgroups on
+        // one counter keep the last one waiting 1.4 us.  Sixteen group counters on separate cache lines take
+        // the arrivals in parallel; the last of each group takes the top-level ticket.
+        const uint32_t groups = min(gridDim.x, (uint32_t)kTicketGroups);
+        const uint32_t grp = blockIdx.x % groups;
+        const uint32_t gsize = (gridDim.x - grp + groups - 1) / groups;
+        uint32_t *gt = a.ticket + kTicketStride * (1 + grp);
+        uint32_t last = 0;
+        if (__hip_atomic_fetch_add(gt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
+            __hip_atomic_store(gt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            last = (__hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) ? 1u : 0u;
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
