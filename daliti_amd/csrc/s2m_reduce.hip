@@ -134,6 +134,13 @@ __device__ __forceinline__ void publish_flag(unsigned long long *flag, unsigned 
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// an empty asm that "uses" a loaded value: the load has to be issued before this point
+template <class T>
+__device__ __forceinline__ void pin(T &v)
+{
+    asm volatile("" : "+v"(v));
+}
+
 template <bool EXT, bool FIT>
 __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
 {
@@ -148,20 +155,29 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
 #pragma unroll
     for (int k = 0; k < 12; ++k) h[k] = 0.0;
     if (i < a.n) {
-        const float bx = a.sx[i], by = a.sy[i], bz = a.sz[i];
+        // Everything a lane may need is requested up front, in one round trip: left to itself the compiler
+        // sinks each load into the branch that uses it (selected? -> flags -> plane and coordinates), i.e.
+        // three dependent trips of ~0.7 us each in a kernel whose whole per-point phase is 3.5 us.
+        float bx = a.sx[i], by = a.sy[i], bz = a.sz[i];
         uint8_t sel, fl;
         float4 pl;
         if (FIT) {
             // neighbour gate: five neighbours and d2[4] <= 5 (:852-854)
-            const int32_t i4 = a.nn_idx[(int64_t)i * kK + (kK - 1)];
-            const bool gate = (i4 >= 0) && !(a.nn_d2[(int64_t)i * kK + (kK - 1)] > a.gates.knn_d2_gate);
+            int32_t ni[kK];
+#pragma unroll
+            for (int k = 0; k < kK; ++k) ni[k] = a.nn_idx[(int64_t)i * kK + k];
+            float d4 = a.nn_d2[(int64_t)i * kK + (kK - 1)];
+            pin(bx); pin(by); pin(bz); pin(d4);  // all issued above; pinned only now (a pin waits for its value)
+#pragma unroll
+            for (int k = 0; k < kK; ++k) pin(ni[k]);
+            const bool gate = (ni[kK - 1] >= 0) && !(d4 > a.gates.knn_d2_gate);
             bool plane_ok = false;
             pl = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gate) {
                 float nx[kK], ny[kK], nz[kK];
 #pragma unroll
                 for (int k = 0; k < kK; ++k) {
-                    const float4 p = a.porig[a.nn_idx[(int64_t)i * kK + k]];
+                    const float4 p = a.porig[ni[k]];
                     nx[k] = p.x; ny[k] = p.y; nz[k] = p.z;
                 }
                 plane_ok = fit_plane(nx, ny, nz, a.gates.plane_thr, pl);
@@ -171,13 +187,16 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
             a.plane[i] = pl;
             a.flags[i] = fl;
         } else {
-            sel = a.sel[i];
-            fl = a.flags[i];
+            uint32_t s32 = a.sel[i], f32 = a.flags[i];
+            pl = a.plane[i];
+            pin(bx); pin(by); pin(bz);  // all issued above; pinned only now (a pin waits for its value)
+            pin(s32); pin(f32); pin(pl.x); pin(pl.y); pin(pl.z); pin(pl.w);
+            sel = (uint8_t)s32;
+            fl = (uint8_t)f32;
         }
         if (sel) {
             uint8_t sel_new = 0;  // sticky: only fit-ok + s-gate re-selects (:862,:873)
             if (fl & kFlagPlane) {
-                if (!FIT) pl = a.plane[i];
                 float wx, wy, wz;
                 body_to_world(a.pose, bx, by, bz, wx, wy, wz);
                 const float pd2 = ((pl.x * wx + pl.y * wy) + pl.z * wz) + pl.w;                    // :866
