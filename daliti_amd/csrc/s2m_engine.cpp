@@ -51,6 +51,7 @@ struct s2m_engine {
     Grid grid{};
     MapStats stats;
     bool map_ready = false;
+    bool map_borrowed = false;  // grid points into another handle's buffers (s2m_map_share)
 
     // staging for host inputs
     float *d_stage = nullptr;
@@ -380,6 +381,7 @@ int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride, int64_t m, in
     int rc = stage_cloud(e, xyz, stride, m, on_device, &dev);
     if (rc) return rc;
     e->map_ready = false;
+    e->map_borrowed = false;
     bool too_large = false;
     hipError_t he = build_map(dev, stride, m, e->cfg.cell_size, e->map, e->grid, e->stats, too_large, e->stream);
     if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
@@ -387,6 +389,23 @@ int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride, int64_t m, in
     e->map_ready = true;
     e->nn_valid = false;
     e->built_cell = e->grid.c;
+    return S2M_OK;
+}
+
+int s2m_map_share(s2m_engine *e, const s2m_engine *owner)
+{
+    if (!e || !owner || e == owner) return fail(e, S2M_ERR_ARG, "s2m_map_share: bad argument");
+    if (!owner->map_ready) return fail(e, S2M_ERR_STATE, "s2m_map_share: the owner has no map");
+    if (owner->device != e->device) return fail(e, S2M_ERR_ARG, "s2m_map_share: handles on different devices");
+    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    S2M_HIP(e, hipStreamSynchronize(owner->stream));  // the owner's build has finished
+    e->grid = owner->grid;
+    e->stats = owner->stats;
+    e->built_cell = owner->built_cell;
+    e->map_ready = true;
+    e->map_borrowed = true;
+    e->nn_valid = false;
     return S2M_OK;
 }
 
@@ -418,6 +437,7 @@ int s2m_map_add(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int 
     if (!e || n < 0 || stride < 3 || (n > 0 && !xyz)) return fail(e, S2M_ERR_ARG, "s2m_map_add: bad argument");
     if (downsample_on && !(downsample_size > 0.0f)) return fail(e, S2M_ERR_ARG, "s2m_map_add: downsample size must be > 0");
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
+    if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
     S2M_HIP(e, hipSetDevice(e->device));
     const float *dev = nullptr;
     int rc = stage_cloud(e, xyz, stride, n, on_device, &dev);
@@ -435,6 +455,7 @@ int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *
 {
     if (!e || n < 0 || (n > 0 && !boxes) || n > 4096) return fail(e, S2M_ERR_ARG, "s2m_map_delete_boxes: bad argument");
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
+    if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
     S2M_HIP(e, hipSetDevice(e->device));
     S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
     int64_t del = 0;
@@ -515,6 +536,7 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
 {
     if (!e || !state || !(filter_size_map > 0.0)) return fail(e, S2M_ERR_ARG, "s2m_map_incremental: bad argument");
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
+    if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
     if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
     S2M_HIP(e, hipSetDevice(e->device));
     const Pose pose = pose_of(state);

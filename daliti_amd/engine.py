@@ -19,7 +19,7 @@ MAX_LOG = 64
 ABI_SYMBOLS = [
     "s2m_abi_version", "s2m_config_default", "s2m_strerror", "s2m_create", "s2m_destroy",
     "s2m_last_error", "s2m_set_config", "s2m_set_stream", "s2m_map_build", "s2m_map_size",
-    "s2m_map_info", "s2m_map_add", "s2m_map_delete_boxes", "s2m_map_incremental", "s2m_map_get_points",
+    "s2m_map_info", "s2m_map_share", "s2m_map_add", "s2m_map_delete_boxes", "s2m_map_incremental", "s2m_map_get_points",
     "s2m_fov_segment", "s2m_fov_reset",
     "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
@@ -169,6 +169,11 @@ class Engine:
 
     def map_build_device(self, dev_ptr, stride, m):
         self._ck(self.lib.s2m_map_build(self.h, C.c_void_p(dev_ptr), C.c_int64(stride), C.c_int64(m), 1))
+
+    def map_share(self, owner):
+        """Search `owner`'s map instead of holding a copy (several scans in flight against one map)."""
+        self._ck(self.lib.s2m_map_share(self.h, owner.h))
+        self._map_owner = owner  # keep the owner alive as long as this handle borrows its map
 
     def map_size(self):
         m = C.c_int64()

@@ -83,6 +83,13 @@ int s2m_set_stream(s2m_engine *e, void *hip_stream);
 /* Map seed: ikdtree.Build(feats_down_world->points), laserMapping.cpp:784-790
  * (KD_TREE::Build, ikd-Tree/ikd_Tree.cpp:408-423).  on_device != 0: xyz is a device pointer. */
 int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride_floats, int64_t m, int on_device);
+/* Several handles, one map (design, not reference: the reference has one scan in flight against one
+ * global ikdtree, laserMapping.cpp:164): `e` searches the map built in `owner` instead of holding a copy,
+ * so K scans can be registered concurrently -- K handles, K streams, K host threads -- against one
+ * HBM-resident map.  The borrower never modifies the map (S2M_ERR_STATE from the update entry points);
+ * `owner` must stay alive, on the same device, and must not rebuild or update its map while a borrower
+ * has a pass in flight.  s2m_map_build on `e` ends the loan. */
+int s2m_map_share(s2m_engine *e, const s2m_engine *owner);
 int s2m_map_size(const s2m_engine *e, int64_t *m);             /* ikdtree.validnum(), :794 */
 /* info[0..7]: cell size, origin xyz, bricks, top-level entries, occupied cells, mean pts/cell */
 int s2m_map_info(const s2m_engine *e, double info[8]);

@@ -17,7 +17,10 @@ for K in [int(v) for v in os.environ.get("KS", "1,2,4,8").split(",")]:
         s = synth.make_scan(c["beams"], c["az"], c["L"], seed=2 + k, sensor_pos=pos)
         _, xp, P0 = synth.filter_inputs(pos)
         e = Engine(max_iter=5, feat_threshold=100)
-        e.map_build_device(d_map.data_ptr(), 3, len(m))
+        if k > 0 and os.environ.get("SHARE", "1") != "0":
+            e.map_share(engs[0])      # one HBM-resident map for all handles
+        else:
+            e.map_build_device(d_map.data_ptr(), 3, len(m))
         e.scan_set(s)
         engs.append(e)
         bufs.append((np.zeros(36), np.ascontiguousarray(xp, np.float64), np.zeros((24, 24)), P0, IterLog()))
@@ -36,5 +39,5 @@ for K in [int(v) for v in os.environ.get("KS", "1,2,4,8").split(",")]:
     for t in ths: t.start()
     for t in ths: t.join()
     dt = time.perf_counter() - t0
-    print("K=%d: %.1f scans/s total, %.3f ms per scan per handle, pos %s" % (K, K * steps / dt, dt / steps * 1e3, bufs[0][0][9:12]))
+    print("K=%d (%s map): %.1f scans/s total, %.3f ms per scan per handle, pos %s" % (K, "own" if os.environ.get("SHARE", "1") == "0" else "shared", K * steps / dt, dt / steps * 1e3, bufs[0][0][9:12]))
     for e in engs: e.close()

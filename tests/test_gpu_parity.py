@@ -174,6 +174,30 @@ def test_wide_address_path(eng, small_scene):
     e.close()
 
 
+def test_map_share(eng, small_scene):
+    """A second handle borrowing the first one's map returns the identical pass and may not modify the map."""
+    from daliti_amd import Engine, S2MError
+    x = small_scene["x_prop"]
+    eng.scan_set(small_scene["scan"])
+    ref_out = eng.residual_pass(x, True)
+    ref_idx, ref_d2 = eng.get_neighbors()
+    e = Engine(keep_neighbors=1)
+    e.map_share(eng)
+    assert e.map_size() == eng.map_size()
+    e.scan_set(small_scene["scan"][::-1].copy())          # its own scan (reversed order)
+    out = e.residual_pass(x, True)
+    idx, d2 = e.get_neighbors()
+    assert (idx[::-1] == ref_idx).all() and (bits(d2[::-1]) == bits(ref_d2)).all()
+    assert out["effct"] == ref_out["effct"]
+    with pytest.raises(S2MError):
+        e.map_add(small_scene["scan"][:10], False)
+    with pytest.raises(S2MError):
+        e.map_delete_boxes(np.float32([[-1, -1, -1, 1, 1, 1]]))
+    e.map_build(small_scene["map"][:1000])                # ends the loan
+    assert e.map_size() == 1000 and eng.map_size() == len(small_scene["map"])
+    e.close()
+
+
 def test_edge_cases(oracle, small_scene):
     from daliti_amd import Engine, S2MError
     e = Engine(keep_neighbors=1, cell_size=0.25)
