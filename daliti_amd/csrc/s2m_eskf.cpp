@@ -6,6 +6,11 @@
 #include <utility>
 
 namespace s2m {
+// Wider vectors for the 24-wide rows where the CPU has them (resolved once at load time).  Same operations
+// in the same order per element -- the file is compiled with -ffp-contract=off, so no clone fuses a multiply
+// with an add -- hence bit-identical results on every clone.
+#define S2M_CPU_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+
 namespace {
 
 struct M3 {
@@ -42,7 +47,7 @@ struct Lu24 {
 // independent elements sit in the innermost loop (rows of the trailing block; the right-hand-side columns
 // of the triangular solves) -- that breaks the dependent-add latency chain and lets the compiler
 // vectorise without changing a single rounding.
-bool lu_factor(const Mat24 &in, Lu24 &f)
+S2M_CPU_CLONES bool lu_factor(const Mat24 &in, Lu24 &f)
 {
     constexpr int N = kDim;
     f.lu = in;
@@ -73,7 +78,7 @@ bool lu_factor(const Mat24 &in, Lu24 &f)
 }
 // first NC columns of the inverse, row-major N x NC
 template <int NC>
-void lu_inverse_cols(const Lu24 &f, double *__restrict__ out)
+inline __attribute__((always_inline)) void lu_inverse_cols_impl(const Lu24 &f, double *__restrict__ out)
 {
     constexpr int N = kDim;
     const double *lu = f.lu.data();
@@ -98,6 +103,10 @@ void lu_inverse_cols(const Lu24 &f, double *__restrict__ out)
         for (int col = 0; col < NC; ++col) out[r * NC + col] = acc[col] / d;
     }
 }
+
+// (multiversioning does not apply to templates: two cloned wrappers, the body inlined into each clone)
+S2M_CPU_CLONES void lu_inverse_24(const Lu24 &f, double *__restrict__ out) { lu_inverse_cols_impl<kDim>(f, out); }
+S2M_CPU_CLONES void lu_inverse_12(const Lu24 &f, double *__restrict__ out) { lu_inverse_cols_impl<12>(f, out); }
 
 }  // namespace
 
@@ -176,7 +185,7 @@ bool eskf_update(const EskfParams &p, State &x, const State &x_prop, const Mat24
         Lu24 f;
         work.pinv_valid = false;
         if (!lu_factor(S, f)) return false;                        // (state.cov / LASER_POINT_COV).inverse()
-        lu_inverse_cols<N>(f, work.Pinv.data());
+        lu_inverse_24(f, work.Pinv.data());
         work.Pkey = P;
         work.Rkey = p.laser_point_cov;
         work.pinv_valid = true;
@@ -186,7 +195,7 @@ bool eskf_update(const EskfParams &p, State &x, const State &x_prop, const Mat24
         for (int c = 0; c < 12; ++c) A[r * N + c] += HtH[r * 12 + c];    // + H_T_H (12x12 block)
     Lu24 f;
     if (!lu_factor(A, f)) return false;                            // K_1 (:1017-1018); only K_1[:, :12] is used
-    lu_inverse_cols<12>(f, work.K1c.data());
+    lu_inverse_12(f, work.K1c.data());
     std::memcpy(work.HtH.data(), HtH, sizeof(double) * 144);
 
     const Vec24 vec = boxminus(x_prop, x);                         // :1028
@@ -209,7 +218,7 @@ bool eskf_update(const EskfParams &p, State &x, const State &x_prop, const Mat24
     return true;
 }
 
-void cov_update(const EskfWork &work, Mat24 &P)
+S2M_CPU_CLONES void cov_update(const EskfWork &work, Mat24 &P)
 {
     constexpr int N = kDim;
     Mat24 ImG{};
