@@ -1,4 +1,5 @@
-"""Parity at BASELINE.json's full sizes (C3: 65,536-point scan vs 5,000,000-point map).
+"""Parity at BASELINE.json's full sizes (C3: 65,536-point scan vs 5,000,000-point map; C1, C2 and the
+20 M-point C4 shape at the end of the file).
 
 The oracle's k-d tree handles this size in seconds, so the first rematch pass is checked against it
 directly; the rest are size-independent properties that need no reference at all: grid invariance
@@ -97,3 +98,73 @@ def test_fullsize_registration_recovers_true_pose(eng3, c3, oracle):
     assert np.abs(ro["x"][9:12] - r["x"][9:12]).max() < 1e-9
     dR = ro["x"][:9].reshape(3, 3).T @ r["x"][:9].reshape(3, 3)
     assert np.abs(oracle.so3_log(dR)).max() < 1e-9
+
+
+# ---- the other BASELINE.json configurations (parity cases, not bench lines) --------------------------
+def test_c1_one_iteration_matches_oracle(oracle):
+    """configs[0]: 10 000-point scan vs 100 000-point map, one ESKF iteration."""
+    from daliti_amd import Engine, synth
+    c = synth.make_config("C1")
+    e = Engine(max_iter=1)
+    e.map_build(c["map"])
+    e.scan_set(c["scan"])
+    got = e.iterated_update(c["x_prop"], c["x_prop"], c["P"])
+    idx, d2 = e.get_neighbors()
+    tree = oracle.KdTree(c["map"])
+    ref = oracle.iterated_update(oracle.default_cfg(max_iter=1), tree, c["scan"], c["x_prop"], c["x_prop"], c["P"])
+    oi, od, oc = tree.knn5(oracle.body_to_world(c["x_prop"], c["scan"]))
+    near = (oc == 5) & (od[:, 4] <= 5.0)
+    assert (idx[near] == oi[near]).all() and (bits(d2[near]) == bits(od[near])).all()
+    assert got["iters"] == ref["iters"] == 1 and list(got["effct"]) == list(ref["effct"])
+    assert np.abs(got["x"] - ref["x"]).max() <= 1e-9 and np.abs(got["P"] - ref["P"]).max() <= 1e-12
+    e.close()
+
+
+def test_c2_single_pass_matches_oracle(oracle):
+    """configs[1]: 65 536-point scan vs 1 000 000-point map, one residual/Jacobian pass."""
+    from daliti_amd import Engine, synth
+    c = synth.make_config("C2")
+    e = Engine()
+    e.map_build(c["map"])
+    e.scan_set(c["scan"])
+    out = e.residual_pass(c["x_prop"], True)
+    st = e.get_point_state()
+    tree = oracle.KdTree(c["map"])
+    ps = oracle.residual_pass(oracle.default_cfg(nthreads=16), tree, c["scan"], c["x_prop"], True,
+                              oracle.PassState(len(c["scan"])))
+    assert (st["selected"] == ps.selected).all() and (st["eff"] == ps.eff).all()
+    ok = ps.plane_ok.astype(bool)
+    assert (bits(st["plane"][ok]) == bits(ps.plane[ok])).all() and (bits(st["pd2"][ok]) == bits(ps.pd2[ok])).all()
+    assert out["effct"] == ps.effct
+    assert np.abs(out["HtH"] - ps.HtH).max() <= 1e-11 * np.abs(ps.HtH).max()
+    assert np.abs(out["Htz"] - ps.Htz).max() <= 1e-11 * max(np.abs(ps.Htz).max(), 1.0)
+    e.close()
+
+
+def test_c4_sharded_scan_against_20m_map(oracle):
+    """configs[2] shape: 131 072-point scan vs 20 000 000-point map, the scan in 8 shards whose blocks must
+    add up to the whole scan's; a 4 096-point sample of the neighbours is checked against the oracle."""
+    from daliti_amd import Engine, synth
+    c = synth.make_config("C4")
+    e = Engine(max_iter=5)
+    e.map_build(c["map"])
+    x = c["x_prop"]
+    e.scan_set(c["scan"])
+    full = e.residual_pass(x, True)
+    idx, d2 = e.get_neighbors()
+    rs = np.random.RandomState(3)
+    pick = np.sort(rs.choice(len(c["scan"]), 4096, replace=False))
+    oi, od, oc = oracle.KdTree(c["map"]).knn5(oracle.body_to_world(x, c["scan"][pick]), 8)
+    near = (oc == 5) & (od[:, 4] <= 5.0)
+    assert near.mean() > 0.95
+    assert (idx[pick][near] == oi[near]).all() and (bits(d2[pick][near]) == bits(od[near])).all()
+    n = len(c["scan"])
+    HtH = np.zeros((12, 12)); effct = 0
+    for r in range(8):
+        lo, hi = r * n // 8, (r + 1) * n // 8
+        e.scan_set(c["scan"][lo:hi])
+        o = e.residual_pass(x, True)
+        HtH += o["HtH"]; effct += o["effct"]
+    assert effct == full["effct"]
+    assert np.abs(HtH - full["HtH"]).max() <= 1e-11 * np.abs(full["HtH"]).max()
+    e.close()
