@@ -46,6 +46,8 @@ def parse():
                     help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing)")
     ap.add_argument("--all-on-device0", action="store_true", help="test hook: every rank uses GPU 0")
     ap.add_argument("--beams-mult", type=int, default=1, help="test hook: single rank over a denser scan")
+    ap.add_argument("--extrinsic", action="store_true",
+                    help="extrinsic_est_en = true: 12-column Jacobian rows, 92-term normal block (SURVEY 8d's extra run)")
     ap.add_argument("--torch-collective", action="store_true",
                     help="sum the block with torch.distributed.all_reduce through the C callback instead of the "
                          "engine's own RCCL communicator")
@@ -97,7 +99,8 @@ def main():
     n_local = len(scan)
     t_gen = time.time() - t0
 
-    eng = Engine(max_iter=a.max_iter, cell_size=a.cell, device=local_rank, feat_threshold=100)
+    eng = Engine(max_iter=a.max_iter, cell_size=a.cell, device=local_rank, feat_threshold=100,
+                 extrinsic_est_en=int(a.extrinsic))
     # one explicit (non-default) stream shared by the engine's kernels and torch's collectives: RCCL orders
     # its work against torch's *current* stream, so the all-reduce of a block is only correctly ordered
     # after the kernel that wrote it if both are issued under this stream
@@ -214,8 +217,9 @@ def main():
         "dtype": "f32 per-point / f64 normal block + ESKF",
         "data": "synthetic (seeded closed-box map, ray-cast scan; SURVEY.md 8d)",
         "config": {
-            "workload": "%s: full iterated ESKF (max_iter %d), %d-pt scan%s vs %d-pt map" % (
-                a.config, a.max_iter, n_local, " shard" if sharded else "", len(map_xyz)),
+            "workload": "%s: full iterated ESKF (max_iter %d%s), %d-pt scan%s vs %d-pt map" % (
+                a.config, a.max_iter, ", extrinsic_est_en" if a.extrinsic else "", n_local,
+                " shard" if sharded else "", len(map_xyz)),
             "scan_points_per_gpu": n_local,
             "map_points": len(map_xyz),
             "parallelism": ("single GPU" if (world == 1 and not sharded) else
@@ -311,7 +315,7 @@ def cpu_baseline(a, map_xyz, scan, x_prop, P0, gpu_res):
     t0 = time.perf_counter()
     tree = oracle.KdTree(map_xyz)
     t_build = time.perf_counter() - t0
-    cfg = oracle.default_cfg(max_iter=a.max_iter, nthreads=1)
+    cfg = oracle.default_cfg(max_iter=a.max_iter, nthreads=1, extrinsic_est_en=int(a.extrinsic))
     t0 = time.perf_counter()
     iters = 0
     for _ in range(a.cpu_steps):
@@ -320,7 +324,7 @@ def cpu_baseline(a, map_xyz, scan, x_prop, P0, gpu_res):
     dt = time.perf_counter() - t0
     # generous variant: the same port with OpenMP over scan points on many host cores
     nthr = max(1, min(os.cpu_count() or 1, 64))
-    cfg_mt = oracle.default_cfg(max_iter=a.max_iter, nthreads=nthr)
+    cfg_mt = oracle.default_cfg(max_iter=a.max_iter, nthreads=nthr, extrinsic_est_en=int(a.extrinsic))
     oracle.iterated_update(cfg_mt, tree, scan, x_prop, x_prop, P0)
     t1 = time.perf_counter()
     it_mt = 0
