@@ -2,18 +2,32 @@
 """bench.py -- residual+Jacobian evals/s and ESKF-iterations/s of the scan-to-map engine.
 
 A "step" is one full iterated ESKF update of one scan (eskf_lio/src/laserMapping.cpp:820-1102)
-with the reference's rematch schedule: BASELINE.json configs[2] -- a 64x1024 = 65,536-point
-synthetic scan against a 5,000,000-point map, max_iteration = 5 -- with map and scan already
-resident in HBM.  ``value`` = scan points x passes executed / wall time, over all ranks.
+with the reference's rematch schedule.  Default workload: BASELINE.json configs[2] (C3) -- a
+64x1024 = 65,536-point synthetic scan against a 5,000,000-point map, max_iteration = 5 -- with map
+and scan already resident in HBM.  ``value`` = scan points x passes executed / wall time, summed
+over all ranks.
 
-N > 1 (launched by torch.distributed.run): the scan grows to N x 65,536 points (N x 64 beams),
-each rank holds a contiguous 65,536-point shard and a replica of the map, and the 158-double
-normal block is summed with one RCCL all-reduce per iteration ("weak" scaling: per-GPU work is
-fixed).  ``--mode replicas`` runs BASELINE configs[4] instead (independent scans, no collective).
+Workloads (``--config``; daliti_amd/synth.py):
+  C1..C4   BASELINE.json configs[0..3]
+  C5       BASELINE.json configs[4]: 8 independent 65,536-point scans (seeds 2..9, sensor offsets
+           (k - 3.5) * 2 m) against the replicated C3 map; rank r serves replicas r, r + N, ...
+           (no collective); reports scans/s
+  R1       reference-density variant of C3: the map is the C3 cloud pushed through
+           s2m_map_add(downsample 0.5 m) (~1 point per voxel, like ikd-Tree's Add_Points,
+           ikd_Tree.cpp:489-521) and the scan through s2m_scan_set_downsampled(0.5)
+           (laserMapping.cpp:775-776)
 
-Extra objects: ``roofline`` for the dominant kernel (the kNN + plane-fit match kernel; HIP-event
-timed inside the engine over the timed region) and ``cpu_baseline`` (the CPU oracle, 1 thread,
-rank 0 at N = 1 only).
+N > 1 (launched by torch.distributed.run), ``--mode sharded``: the scan points are split over the
+ranks, the map is replicated, the 158-double normal block is summed with one RCCL all-reduce per
+iteration.  ``--scaling strong`` (default for C4 = BASELINE configs[3]): ONE scan of the config's
+size, shard_range() per rank (131,072 / 8 = 16,384 points per GPU at N = 8).  ``--scaling weak``
+(default otherwise, so that the driver's `--gpus N` sweep keeps the per-GPU work fixed): the scan
+grows to N x beams, one config-sized shard per rank.
+
+Extra objects on the JSON line: ``roofline`` (the rematch pass: search kernels + reduce<FIT>,
+88 algorithmic bytes per eval; HIP-event timed inside the engine on its stream, every 7th pass of
+the timed region sampled), ``roofline_reuse`` (the reduce kernel of a reuse pass, 28 B/eval) and
+``cpu_baseline`` (the CPU oracle, 1 thread, rank 0 at N = 1 only).
 """
 import argparse
 import json
@@ -29,6 +43,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 BYTES_REMATCH = 88              # 12 B scan point + 5 x 12 B neighbours + 16 B plane
 BYTES_REUSE = 28                # 12 B scan point + 16 B cached plane
+TIMING_STRIDE = 7               # coprime to the 5 passes of a step: every kind of pass gets sampled
 
 
 def parse():
@@ -36,8 +51,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4"])
-    ap.add_argument("--mode", default="sharded", choices=["sharded", "replicas"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "R1"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "sharded", "replicas"],
+                    help="auto: replicas for C5, sharded otherwise")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="sharded mode only; auto: strong for C4 (BASELINE configs[3]), weak otherwise")
     ap.add_argument("--max-iter", type=int, default=5)
     ap.add_argument("--cell", type=float, default=0.0)
     ap.add_argument("--cpu-steps", type=int, default=8, help="CPU baseline sample: iterated updates (0 = skip)")
@@ -53,7 +71,16 @@ def parse():
                          "engine's own RCCL communicator")
     ap.add_argument("--force-collective", action="store_true",
                     help="run the sharded/all-reduce code path even with one rank (test hook)")
+    ap.add_argument("--replicas", type=int, default=0, help="C5: number of independent scans (default 8)")
     return ap.parse_args()
+
+
+def build_reference_density_map(eng, cloud, leaf=0.5, chunk=1 << 20):
+    """R1: seed with one point, then feed the dense cloud through Add_Points(downsample) chunk by chunk."""
+    eng.map_build(cloud[:1])
+    for lo in range(0, len(cloud), chunk):
+        eng.map_add(cloud[lo:lo + chunk], True, leaf)
+    return eng.map_size()
 
 
 def main():
@@ -68,6 +95,7 @@ def main():
     import torch
     import torch.distributed as dist
     from daliti_amd import Engine, synth
+    from daliti_amd.sharding import shard_range
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
@@ -82,50 +110,88 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfgd = synth.CONFIGS[a.config]
-    sharded = (world > 1 or a.force_collective) and a.mode == "sharded"
-    # workload: map replicated; scan = world x (beams x az) points when sharded
+    mode = a.mode if a.mode != "auto" else ("replicas" if a.config == "C5" else "sharded")
+    sharded = (world > 1 or a.force_collective) and mode == "sharded"
+    scaling = a.scaling if a.scaling != "auto" else ("strong" if a.config == "C4" else "weak")
+    if not sharded:
+        scaling = "weak"   # replicas / one GPU: per-GPU work is fixed by construction
+    # ---- workload -------------------------------------------------------------------------------
     t0 = time.time()
     map_xyz = synth.make_map(cfgd["M"], cfgd["L"], seed=1)
+    scans = []            # one entry per independent scan this rank serves: (body points, sensor position)
     if sharded:
-        scan_all = synth.make_scan(cfgd["beams"] * world, cfgd["az"], cfgd["L"], seed=2)
-        per = cfgd["beams"] * cfgd["az"]
-        scan = scan_all[rank * per:(rank + 1) * per]
-        pos = synth.SENSOR_POS
+        if scaling == "strong":   # ONE scan of the config's size, split over the ranks
+            scan_all = synth.make_scan(cfgd["beams"], cfgd["az"], cfgd["L"], seed=2)
+            lo, hi = shard_range(len(scan_all), rank, world)
+        else:                     # the scan grows with the job: one config-sized shard per rank
+            scan_all = synth.make_scan(cfgd["beams"] * world, cfgd["az"], cfgd["L"], seed=2)
+            per = cfgd["beams"] * cfgd["az"]
+            lo, hi = rank * per, (rank + 1) * per
+        scans.append((scan_all[lo:hi], synth.SENSOR_POS))
+        n_scan_total = len(scan_all)
+    elif mode == "replicas" and (a.config == "C5" or world > 1):
+        nrep = a.replicas or cfgd.get("replicas", world)
+        for k in range(rank, nrep, world):   # seeds 2..9, sensor offsets (k - 3.5) * 2 m in x
+            sc, pos = synth.replica_scan(a.config, k)
+            scans.append((sc, pos))
+        n_scan_total = sum(len(s) for s, _ in scans)
     else:
-        dx = (rank - (world - 1) / 2.0) * 2.0 if world > 1 else 0.0
-        pos = synth.SENSOR_POS + np.array([dx, 0.0, 0.0])
-        scan = synth.make_scan(cfgd["beams"] * a.beams_mult, cfgd["az"], cfgd["L"], seed=2 + rank, sensor_pos=pos)
-    x_true, x_prop, P0 = synth.filter_inputs(pos)
-    n_local = len(scan)
+        scans.append((synth.make_scan(cfgd["beams"] * a.beams_mult, cfgd["az"], cfgd["L"], seed=2), synth.SENSOR_POS))
+        n_scan_total = len(scans[0][0])
+    if not scans:
+        raise SystemExit("rank %d has no scan to serve (more ranks than replicas)" % rank)
+    filt = [synth.filter_inputs(pos) for _, pos in scans]
     t_gen = time.time() - t0
 
-    eng = Engine(max_iter=a.max_iter, cell_size=a.cell, device=local_rank, feat_threshold=100,
-                 extrinsic_est_en=int(a.extrinsic))
     # one explicit (non-default) stream shared by the engine's kernels and torch's collectives: RCCL orders
     # its work against torch's *current* stream, so the all-reduce of a block is only correctly ordered
     # after the kernel that wrote it if both are issued under this stream
     stream = torch.cuda.Stream(device=local_rank)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    eng.set_stream(stream.cuda_stream)
+    engs = []
+    d_keep = []   # device tensors handed to the engine as raw pointers stay alive until the end
+    for k, (scan, _pos) in enumerate(scans):
+        e = Engine(max_iter=a.max_iter, cell_size=a.cell, device=local_rank, feat_threshold=100,
+                   extrinsic_est_en=int(a.extrinsic))
+        if k == 0:
+            e.set_stream(stream.cuda_stream)
+        engs.append(e)
+    eng = engs[0]
     # inputs resident in HBM before the timed region: hand the engine device pointers
-    d_map = torch.from_numpy(map_xyz).cuda()
-    d_scan = torch.from_numpy(np.ascontiguousarray(scan)).cuda()
     torch.cuda.synchronize()
     t0 = time.time()
-    eng.map_build_device(d_map.data_ptr(), 3, len(map_xyz))
+    if a.config == "R1":
+        m_map = build_reference_density_map(eng, map_xyz)
+    else:
+        d_map = torch.from_numpy(map_xyz).cuda()
+        d_keep.append(d_map)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        eng.map_build_device(d_map.data_ptr(), 3, len(map_xyz))
+        m_map = len(map_xyz)
     torch.cuda.synchronize()
     t_build = time.time() - t0
-    eng.scan_set_device(d_scan.data_ptr(), 3, n_local)
+    for e in engs[1:]:
+        e.map_share(eng)   # several scans in flight search ONE HBM-resident map
+    n_local = 0
+    for e, (scan, _pos) in zip(engs, scans):
+        if a.config == "R1":
+            n_local += e.scan_set_downsampled(scan, 0.5)
+        else:
+            d_scan = torch.from_numpy(np.ascontiguousarray(scan)).cuda()
+            d_keep.append(d_scan)
+            e.scan_set_device(d_scan.data_ptr(), 3, len(scan))
+            n_local += len(scan)
     info = eng.map_info()
 
     blk = torch.zeros(160, dtype=torch.float64, device="cuda")
     builtin_comm = False
     if sharded and a.backend == "nccl" and not a.torch_collective:
         # the engine's own RCCL communicator: the all-reduce is issued from the C++ loop on the engine's
-        # stream; torch.distributed only ships the 128-byte unique id
-        # every rank first proves it can reach RCCL (a rank that cannot must not leave the others blocked
-        # inside ncclCommInitRank); any failure sends all ranks to the torch.distributed callback instead
+        # stream; torch.distributed only ships the 128-byte unique id.  Every rank first proves it can reach
+        # RCCL (a rank that cannot must not leave the others blocked inside ncclCommInitRank); any failure
+        # sends all ranks to the torch.distributed callback instead
         def all_ok(flag):
             t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -146,63 +212,96 @@ def main():
                 ok = False
                 sys.stderr.write("rank %d: s2m_comm_init failed (%s)\n" % (rank, ex))
             builtin_comm = all_ok(ok)
-    if sharded and not builtin_comm:
+
+    from daliti_amd.engine import IterLog
+    x_prop0, P0 = filt[0][1], filt[0][2]
+    use_callback = sharded and not builtin_comm
+    if use_callback:
         from daliti_amd.sharding import allreduce_block
 
         def reduce_cb():
             allreduce_block(blk)
 
-        def step():
-            eng.set_feat_queue([])
-            return eng.iterated_update_sharded(x_prop, x_prop, P0, blk.data_ptr(), reduce_cb)
-    if not sharded or builtin_comm:
-        from daliti_amd.engine import IterLog
-        xb, xpb, Pb, logb = np.zeros(36), np.ascontiguousarray(x_prop, np.float64), np.zeros((24, 24)), IterLog()
+    # preallocated per-scan buffers: lean calls, no per-step conversions
+    bufs = [dict(x=np.zeros(36), xp=np.ascontiguousarray(f[1], np.float64), P=np.zeros((24, 24)), P0=f[2],
+                 log=IterLog()) for f in filt]
+    last = {}
 
-        def step():
-            # lean call: preallocated buffers, no per-step conversions (the degeneracy queue is cleared so
-            # every step is the same scan arriving fresh)
-            eng.set_feat_queue(())
-            xb[:] = xpb
-            Pb[:] = P0
-            eng.iterated_update_raw(xb, xpb, Pb, logb)
-            return logb
+    def step(k_step):
+        """One iterated update per scan this rank serves.  The degeneracy queue is cleared so that every step
+        is the same scan arriving fresh.  P differs from the previous step's P in its last bit: in a real
+        stream the covariance changes every scan, so the engine's per-distinct-P cache of (P/R)^-1 must MISS
+        once per scan -- that 24x24 inverse is part of the step (round-1 bench skipped it)."""
+        it = rm = 0
+        for e, b in zip(engs, bufs):
+            e.set_feat_queue(())
+            b["x"][:] = b["xp"]
+            b["P"][:] = b["P0"]
+            b["P"][0, 0] += (k_step & 1) * 1e-15
+            if use_callback:
+                r = e.iterated_update_sharded(b["x"], b["xp"], b["P"], blk.data_ptr(), reduce_cb)
+                b["x"][:], b["P"][:] = r["x"], r["P"]
+                it += r["iters"]
+                rm += r["rematch_passes"]
+                last[id(e)] = (r["iters"], r["effct"])
+            else:
+                e.iterated_update_raw(b["x"], b["xp"], b["P"], b["log"])
+                it += b["log"].iters
+                rm += b["log"].rematch_passes
+        return it, rm
 
     def fence():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        res = step()
-    eng.set_timing(5)  # HIP-event time every 5th rematch pass of the timed region (odd: covers both kinds)
+    for k in range(a.warmup):
+        step(k)
+    eng.set_timing(TIMING_STRIDE)
     fence()
     t0 = time.perf_counter()
-    passes = iters = rematch = 0
-    for _ in range(a.steps):
-        res = step()
-        if sharded and not builtin_comm:
-            iters += res["iters"]
-            rematch += res["rematch_passes"]
-        else:
-            iters += res.iters
-            rematch += res.rematch_passes
+    iters = rematch = 0
+    for k in range(a.steps):
+        it, rm = step(k)
+        iters += it
+        rematch += rm
     fence()
     dt = time.perf_counter() - t0
-    if not sharded or builtin_comm:  # final state / log of the last step for the report
-        res = dict(x=xb.copy(), P=Pb.copy(), iters=res.iters, effct=np.array(res.effct[:res.iters]))
     tstats = eng.timing_stats()
     eng.set_timing(False)
-    passes = iters  # one residual pass per iteration
+    b0 = bufs[0]
+    if use_callback:
+        res = dict(x=b0["x"].copy(), P=b0["P"].copy(), iters=last[id(eng)][0], effct=np.array(last[id(eng)][1]))
+    else:
+        res = dict(x=b0["x"].copy(), P=b0["P"].copy(), iters=b0["log"].iters,
+                   effct=np.array(b0["log"].effct[:b0["log"].iters]))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    evals_total = float(n_local) * passes * world
+        tot = torch.tensor([float(n_local) * iters / max(len(scans), 1), float(iters), float(len(scans) * a.steps)],
+                           dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+        # evals: every rank's points x its passes; iterations / scans: summed over independent scans only
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        evals_total, iters_all, scans_all = [float(v) for v in tot.tolist()]
+    else:
+        evals_total = float(n_local) * iters / max(len(scans), 1)
+        iters_all, scans_all = float(iters), float(len(scans) * a.steps)
+    if sharded:  # the ranks iterate one and the same scan together
+        iters_all, scans_all = float(iters), float(a.steps)
     value = evals_total / dt
+    x_true = filt[0][0]
     pose_err = float(np.abs(res["x"][9:12] - x_true[9:12]).max())
+    n_per_scan = n_local // max(len(scans), 1)
 
+    if sharded:
+        par = ("scan points sharded x%d (%s scaling: %d-pt scan, %d per rank), map replicated, RCCL all-reduce of 158 f64 "
+               "per iteration (%s)" % (world, scaling, n_scan_total, n_local,
+                                       "engine-owned communicator" if builtin_comm else "torch.distributed callback"))
+    elif len(scans) > 1 or world > 1:
+        par = "replicas: %d independent scans on %d GPU(s), one shared map per GPU, no collective" % (int(scans_all / a.steps), world)
+    else:
+        par = "single GPU"
     out = {
         "metric": "residual+Jacobian evals/sec",
         "value": value,
@@ -212,52 +311,76 @@ def main():
         "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32 per-point / f64 normal block + ESKF",
         "data": "synthetic (seeded closed-box map, ray-cast scan; SURVEY.md 8d)",
         "config": {
-            "workload": "%s: full iterated ESKF (max_iter %d%s), %d-pt scan%s vs %d-pt map" % (
-                a.config, a.max_iter, ", extrinsic_est_en" if a.extrinsic else "", n_local,
-                " shard" if sharded else "", len(map_xyz)),
+            "workload": "%s: full iterated ESKF (max_iter %d%s), %d-pt scan%s vs %d-pt map%s" % (
+                a.config, a.max_iter, ", extrinsic_est_en" if a.extrinsic else "", n_per_scan,
+                " shard" if sharded else "", m_map,
+                " (reference density: map through Add_Points(downsample 0.5 m), scan through VoxelGrid 0.5 m)"
+                if a.config == "R1" else ""),
             "scan_points_per_gpu": n_local,
-            "map_points": len(map_xyz),
-            "parallelism": ("single GPU" if (world == 1 and not sharded) else
-                            ("scan points sharded x%d, map replicated, RCCL all-reduce of 158 f64 per iteration (%s)"
-                             % (world, "engine-owned communicator" if builtin_comm else "torch.distributed callback")
-                             if sharded else "replicas x%d (independent scans, no collective)" % world)),
+            "scans_per_gpu": len(scans),
+            "map_points": m_map,
+            "parallelism": par,
             "cell_size_m": info["cell"],
             "mean_points_per_cell": info["mean_per_cell"],
         },
-        "eskf_iters_per_sec": iters * (world if not sharded else 1) / dt,
-        "scans_per_sec": a.steps * (world if not sharded else 1) / dt,
-        "iters_per_step": iters / a.steps,
-        "rematch_passes_per_step": rematch / a.steps,
+        "eskf_iters_per_sec": iters_all / dt,
+        "scans_per_sec": scans_all / dt,
+        "iters_per_step": iters / a.steps / max(len(scans), 1),
+        "rematch_passes_per_step": rematch / a.steps / max(len(scans), 1),
         "pose_error_vs_truth_m": pose_err,
         "final_pos": [float(v) for v in res["x"][9:12]],
         "map_build_s": t_build,
+        "host_inverse_per_step": "included (P perturbed in its last bit every step: the (P/R)^-1 cache misses once per scan)",
     }
-    # roofline of the dominant kernel: the match (kNN + plane fit) kernel, one launch per rematch pass
-    if tstats["match_launches"] > 0:
-        ms = tstats["match_ms"] / tstats["match_launches"]
-        achieved = n_local * BYTES_REMATCH / (ms * 1e-3) / 1e9
+    # ---- rooflines (engine 0's scan; HIP events on the engine's stream, sampled passes) -----------
+    n0 = len(scans[0][0]) if a.config != "R1" else eng.n
+    if tstats["match_launches"] > 0 and tstats["fit_launches"] > 0:
+        ms_match = tstats["match_ms"] / tstats["match_launches"]
+        ms_fit = tstats["fit_ms"] / tstats["fit_launches"]
+        ms = ms_match + ms_fit
+        achieved = n0 * BYTES_REMATCH / (ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic() if (a.config == "C3" and world == 1) else (None, None)
         copy_peak = measured_copy_peak(torch) if (rank == 0 and not a.no_cpu) else None  # --no-cpu: no side legs
         out["roofline"] = {
-            "kernel": "match_kernel (exact 5-NN on the brick grid + plane fit)",
+            "kernel": "rematch pass = match_easy + match_hard (exact 5-NN on the brick grid) + reduce_kernel<FIT> "
+                      "(neighbour gate, plane fit, residual, Jacobian row, normal block)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_eval": BYTES_REMATCH, "evals_per_launch": n_local,
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_eval": BYTES_REMATCH, "evals_per_launch": n0,
             "avg_launch_ms": ms, "launches": tstats["match_launches"],
+            "search_kernels_only": {"avg_ms": ms_match, "achieved": n0 * BYTES_REMATCH / (ms_match * 1e-3) / 1e9,
+                                    "frac": n0 * BYTES_REMATCH / (ms_match * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "the 88 B also hold the 5-neighbour gather and the plane, which live "
+                                            "in reduce<FIT>: this fraction flatters; `frac` above is the pass"},
+            "reduce_fit_avg_ms": ms_fit,
             # both fractions, and the box's own copy peak as a second denominator
             "frac_of_measured_traffic": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "peak_measured_copy": copy_peak,
             "frac_of_measured_peak": (achieved / copy_peak) if copy_peak else None,
-            "note": "one launch = match_easy + match_hard of one rematch pass (HIP events around both, "
-                    "every 5th rematch pass of the timed region sampled)",
+            "note": "one launch = the three kernels of one rematch pass (HIP events on the engine's stream around "
+                    "the search kernels and around reduce<FIT>; every %dth pass of the timed region sampled)" % TIMING_STRIDE,
+        }
+    if tstats["reduce_launches"] > 0:
+        ms_r = tstats["reduce_ms"] / tstats["reduce_launches"]
+        ach_r = n0 * BYTES_REUSE / (ms_r * 1e-3) / 1e9
+        out["roofline_reuse"] = {
+            "kernel": "reuse pass = reduce_kernel (cached plane: residual, gates, Jacobian row, normal block)",
+            "bound": "hbm", "achieved": ach_r, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_r / HBM_PEAK_GBS,
+            "traffic": None, "algorithmic_bytes_per_eval": BYTES_REUSE, "evals_per_launch": n0,
+            "avg_launch_ms": ms_r, "launches": tstats["reduce_launches"],
+            "note": "latency-bound at this size: 1.8 MB per launch is 0.23 us at 8 TB/s",
         }
     if rank == 0 and world == 1 and not a.no_cpu and a.cpu_steps > 0:
-        out["cpu_baseline"] = cpu_baseline(a, map_xyz, scan, x_prop, P0, res)
+        cpu_map = eng.map_points() if a.config == "R1" else map_xyz
+        cpu_scan = eng.scan_get() if a.config == "R1" else scans[0][0]
+        out["cpu_baseline"] = cpu_baseline(a, cpu_map, cpu_scan, x_prop0, P0, res)
         out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -290,22 +413,26 @@ def measured_copy_peak(torch, nbytes=1 << 30, reps=10):
 
 
 def pmc_traffic():
-    """HBM traffic of one rematch pass of the match kernels from the newest committed PMC summary
-    (profiles/*_pmc.json, made by scripts/profile_round.sh + summarize_profile.py: separate
-    rocprofv3 --pmc passes of this same command).  Read side doubled as MI355X_MICROARCH.md
-    prescribes for gfx950 (FETCH_SIZE tallies 128-B requests at 64 B), so this is an upper bound."""
+    """Fabric traffic of one rematch pass (search kernels + reduce<FIT>) from the newest COMMITTED counter
+    summary that holds FETCH_SIZE / WRITE_SIZE for those kernels (profiles/*_pmc.json, made by
+    scripts/profile_round.sh + summarize_profile.py: separate rocprofv3 --pmc passes of this same command).
+    This is a STATIC figure of the profiled build, not something measured in this run -- the label says so.
+    Read side doubled as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE tallies 128-B requests at
+    64 B), so it is an upper bound; at C3 every structure sits in the Infinity Cache, so this is fabric
+    (L2 <-> Infinity Cache) traffic rather than HBM traffic."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files:
-        return None, None
-    try:
-        k = json.load(open(files[-1]))["kernels"]
-        tot = 0.0
-        for name in ("match_easy", "match_hard"):
-            tot += (2.0 * k[name]["FETCH_SIZE_avg"] + k[name]["WRITE_SIZE_avg"]) * 1024.0
-        return tot, os.path.relpath(files[-1], ROOT)
-    except (KeyError, ValueError):
-        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+            k = doc["kernels"]
+            tot = 0.0
+            for name in ("match_easy", "match_hard", "reduce_kernel<false, true>"):
+                tot += (2.0 * k[name]["FETCH_SIZE_avg"] + k[name]["WRITE_SIZE_avg"]) * 1024.0
+            return tot, "%s (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the profiled build '%s', " \
+                        "read side x2; not measured in this run)" % (os.path.relpath(path, ROOT), doc.get("tag", "?"))
+        except (KeyError, ValueError, OSError):
+            continue
+    return None, None
 
 
 def cpu_baseline(a, map_xyz, scan, x_prop, P0, gpu_res):

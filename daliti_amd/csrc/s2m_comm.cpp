@@ -12,6 +12,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "s2m_comm.h"
 
@@ -26,9 +27,11 @@ struct Api {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 Api g_api;
+std::mutex g_api_mutex;  // handles may attach communicators from different host threads
 
 bool load_api(std::string &err)
 {
+    std::lock_guard<std::mutex> lock(g_api_mutex);
     if (g_api.lib) return true;
     const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;

@@ -31,11 +31,11 @@ struct s2m_engine {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    bool timing = false, timing_all = false;  // timing: match kernels only; timing_all: + reduce kernel
-    int timing_stride = 1, timing_phase = 0;   // time every stride-th rematch pass (sampling keeps the probe cheap)
+    bool timing = false;
+    int timing_stride = 1, timing_phase = 0;   // time every stride-th pass (sampling keeps the probe cheap)
     bool timed_this_pass = false;
     double last_ms[3] = {0, 0, 0};
-    double tstats[4] = {0, 0, 0, 0};
+    double tstats[6] = {0, 0, 0, 0, 0, 0};     // {match ms, n, reduce<FIT> ms, n, reduce (reuse pass) ms, n}
     bool last_rematch = false;
     int match_group = 4;
     std::string err;
@@ -168,7 +168,10 @@ int stage_cloud(s2m_engine *e, const float *xyz, int64_t stride, int64_t count, 
     return S2M_OK;
 }
 
-int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, double *d_out)
+// defer_publish: the caller sums d_out over the ranks first and publishes the result itself (launch_publish);
+// every other caller gets the block and the flag in pinned host memory straight from the reduce kernel, with or
+// without a communicator attached to the handle.
+int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, double *d_out, bool defer_publish = false)
 {
     if (!e || !state) return fail(e, S2M_ERR_ARG, "null argument");
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
@@ -180,15 +183,12 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     const int n = (int)e->n;
     float *sx = e->d_scan, *sy = e->d_scan + e->n_cap, *sz = e->d_scan + 2 * e->n_cap;
     e->last_rematch = rematch != 0;
-    bool time_match = e->timing && rematch;
-    const bool time_all = e->timing && e->timing_all;
-    if (time_match && !time_all && e->timing_stride > 1) {
-        // sample: alternate between the first and later rematch passes so both kinds are covered
-        time_match = (e->timing_phase % e->timing_stride) == 0;
-        e->timing_phase++;
-    }
-    e->timed_this_pass = time_match || time_all;
-    if (time_match || time_all) S2M_HIP(e, hipEventRecord(e->ev[0], e->stream));
+    // HIP events on the engine's stream around the search kernels and around the reduce kernel of every
+    // stride-th pass (a stride coprime to the passes per scan walks through every kind of pass)
+    bool timed = e->timing;
+    if (timed && e->timing_stride > 1) timed = (e->timing_phase++ % e->timing_stride) == 0;
+    e->timed_this_pass = timed;
+    if (timed) S2M_HIP(e, hipEventRecord(e->ev[0], e->stream));
     if (rematch) {
         MatchArgs m;
         m.grid = e->grid; m.pose = pose; m.gates = gates;
@@ -200,7 +200,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         launch_match(m, e->match_group, e->stream);  // hard_count is zero: reset by every reduce launch
         e->nn_valid = true;
     }
-    if (time_match || time_all) S2M_HIP(e, hipEventRecord(e->ev[1], e->stream));
+    if (timed) S2M_HIP(e, hipEventRecord(e->ev[1], e->stream));
     ReduceArgs r;
     r.pose = pose; r.gates = gates;
     r.sx = sx; r.sy = sy; r.sz = sz; r.n = n;
@@ -209,12 +209,12 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     r.plane = e->d_plane; r.flags = e->d_flags; r.sel = e->d_sel; r.eff = e->d_eff; r.pd2 = e->d_pd2;
     r.partials = e->d_partials; r.block = d_out;
     r.ticket = e->d_ticket; r.hard_count = e->d_hard + 3 * e->n_cap;
-    const bool publish = e->host_poll && d_out == e->d_block && !e->comm.handle;
+    const bool publish = e->host_poll && d_out == e->d_block && !defer_publish;
     r.host_block = publish ? e->h_block_dev : nullptr;
     r.host_flag = publish ? reinterpret_cast<unsigned long long *>(e->h_block_dev + S2M_BLOCK_DOUBLES) : nullptr;
     r.seq = ++e->seq;
     launch_reduce(r, e->stream);
-    if (time_all) S2M_HIP(e, hipEventRecord(e->ev[2], e->stream));
+    if (timed) S2M_HIP(e, hipEventRecord(e->ev[2], e->stream));
     S2M_HIP(e, hipGetLastError());
     e->last_pose = pose;
     e->pass_done = true;
@@ -225,20 +225,18 @@ int finish_timing(s2m_engine *e)
 {
     if (!e->timing || !e->timed_this_pass) return S2M_OK;
     float a = 0.f, b = 0.f;
-    if (e->last_rematch || e->timing_all) {
-        S2M_HIP(e, hipEventSynchronize(e->ev[1]));
-        S2M_HIP(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
-    }
-    if (e->timing_all) {
-        S2M_HIP(e, hipEventSynchronize(e->ev[2]));
-        S2M_HIP(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
-        e->tstats[2] += b;
-        e->tstats[3] += 1;
-    }
-    e->last_ms[0] = a;
+    S2M_HIP(e, hipEventSynchronize(e->ev[2]));
+    S2M_HIP(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
+    S2M_HIP(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+    e->last_ms[0] = e->last_rematch ? a : 0.0;
     e->last_ms[1] = b;
     e->last_ms[2] = a + b;
-    if (e->last_rematch) { e->tstats[0] += a; e->tstats[1] += 1; }
+    if (e->last_rematch) {
+        e->tstats[0] += a; e->tstats[1] += 1;
+        e->tstats[2] += b; e->tstats[3] += 1;
+    } else {
+        e->tstats[4] += b; e->tstats[5] += 1;
+    }
     return S2M_OK;
 }
 
@@ -424,6 +422,19 @@ int commit_update(s2m_engine *e)
                    e->stream);
     if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
     if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
+    // The cell size is kept across updates (a stable grid) unless the density has drifted by more than 2x from
+    // the ~11 points per occupied cell it was chosen for -- e.g. a map seeded from a handful of points and then
+    // grown, or a dense seed thinned by the voxel rule: then it is chosen again from the density.
+    if (!(e->cfg.cell_size > 0.0f) && e->stats.occupied_cells > 0) {
+        const double mean = (double)m_new / (double)e->stats.occupied_cells;
+        if (mean < 5.5 || mean > 22.0) {
+            he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, 0.0f, e->map, e->grid, e->stats, too_large,
+                           e->stream);
+            if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
+            if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
+            e->built_cell = e->grid.c;
+        }
+    }
     e->map_ready = true;
     e->nn_valid = false;  // neighbour indices referred to the old point list
     if (e->built_cell <= 0.0f) e->built_cell = e->grid.c;
@@ -532,7 +543,7 @@ int s2m_fov_segment(s2m_engine *e, const double pos_lid[3], double cube_len, flo
 }
 
 int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], double filter_size_map,
-                        int64_t *n_to_add, int64_t *n_no_downsample)
+                        int32_t ekf_inited, int64_t *n_to_add, int64_t *n_no_downsample)
 {
     if (!e || !state || !(filter_size_map > 0.0)) return fail(e, S2M_ERR_ARG, "s2m_map_incremental: bad argument");
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
@@ -543,7 +554,7 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     float4 *la = nullptr, *lb = nullptr;
     int64_t na = 0, nb = 0;
     S2M_HIP(e, incr_classify(e->upd, pose, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, (int)e->n,
-                             e->d_nn_idx, e->grid, e->nn_valid, filter_size_map, &la, &na, &lb, &nb, e->stream));
+                             e->d_nn_idx, e->grid, e->nn_valid && ekf_inited != 0, filter_size_map, &la, &na, &lb, &nb, e->stream));
     if (n_to_add) *n_to_add = na;
     if (n_no_downsample) *n_no_downsample = nb;
     S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
@@ -596,8 +607,8 @@ int s2m_map_info(const s2m_engine *e, double info[8])
 namespace {
 int scan_reserve(s2m_engine *e, int64_t n)
 {
-    if (n <= e->n_cap) return S2M_OK;
-    const int64_t cap = ((n + 255) / 256) * 256;
+    if (n <= e->n_cap && e->n_cap > 0) return S2M_OK;
+    const int64_t cap = ((std::max<int64_t>(n, 1) + 255) / 256) * 256;  // an empty first scan still gets buffers
     int rc = 0;
     rc = rc ? rc : grow(e, &e->d_scan, 3 * cap);
     rc = rc ? rc : grow(e, &e->d_plane, cap);
@@ -705,7 +716,16 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride, int64_t n,
         dev = e->d_stage;
     }
     uint32_t *d_perm = nullptr;
-    if (perm) S2M_HIP(e, hipMalloc((void **)&d_perm, (size_t)n * sizeof(uint32_t)));
+    if (perm) {  // kept across calls (sized with the other undistort buffers)
+        if (e->und.perm_cap < n) {
+            if (e->und.perm) S2M_HIP(e, hipFree(e->und.perm));
+            e->und.perm = nullptr;
+            e->und.perm_cap = 0;
+            S2M_HIP(e, hipMalloc((void **)&e->und.perm, (size_t)n * sizeof(uint32_t)));
+            e->und.perm_cap = n;
+        }
+        d_perm = e->und.perm;
+    }
     hipError_t he = undistort(e->und, dev, stride, n, oa, ob, reinterpret_cast<const double *>(poses), np,
                               pose_of(state_end), sort_by_time != 0, d_perm, e->stream);
     if (he == hipSuccess)
@@ -713,7 +733,6 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride, int64_t n,
                             on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess && perm) he = hipMemcpyAsync(perm, d_perm, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
-    if (d_perm) (void)hipFree(d_perm);
     if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "undistort", he);
     return S2M_OK;
 }
@@ -928,7 +947,15 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
     const int max_iter = e->cfg.max_iter;
     int rematch_num = 0, rematch_en = 0, it = 0, passes = 0;
     int32_t conv = 0, stop = 0;
-    if (log) std::memset(log, 0, sizeof(*log));
+    if (log) {  // header fields + the rows this call can write (the struct holds 64 rows, 13 KB)
+        log->iters = log->rematch_passes = log->converged = log->ekf_stop = 0;
+        const size_t rows = (size_t)std::min(max_iter, 64);
+        std::memset(log->effct, 0, rows * sizeof(log->effct[0]));
+        std::memset(log->rematch, 0, rows * sizeof(log->rematch[0]));
+        std::memset(log->conv, 0, rows * sizeof(log->conv[0]));
+        std::memset(log->total_residual, 0, rows * sizeof(log->total_residual[0]));
+        std::memset(log->solution, 0, rows * sizeof(log->solution[0]));
+    }
     static const bool tl = std::getenv("S2M_HOST_TIMELINE") != nullptr;  // dev probe: host-side timings
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -938,12 +965,13 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         const int rematch = (it == 0) || rematch_en;  // :847
         passes += rematch;
         const auto t_a = now();
-        int rc = run_pass(e, x, rematch, d_block);
+        const bool collective = !reduce && e->comm.handle;  // built-in RCCL sum of the block before the hand-off
+        int rc = run_pass(e, x, rematch, d_block, collective);
         if (rc) return rc;
         const auto t_b = now();
         if (reduce && reduce(user) != 0) return fail(e, S2M_ERR_HIP, "all-reduce callback failed");
         const double *hb = nullptr;
-        if (!reduce && e->comm.handle) {
+        if (collective) {
             // built-in collective: sum the block over the ranks on this stream, then publish it to the host
             std::string cerr_;
             if (!comm_allreduce_sum_f64(e->comm, d_block, S2M_BLOCK_DOUBLES, e->stream, cerr_)) return fail(e, S2M_ERR_HIP, cerr_.c_str());
@@ -1083,8 +1111,7 @@ int s2m_set_timing(s2m_engine *e, int enabled)
 {
     if (!e) return S2M_ERR_ARG;
     e->timing = enabled != 0;
-    e->timing_all = enabled == 2;
-    e->timing_stride = enabled > 2 ? enabled : 1;  // n > 2: time every n-th rematch pass
+    e->timing_stride = enabled > 2 ? enabled : 1;  // n > 2: time every n-th pass
     e->timing_phase = 0;
     for (double &t : e->tstats) t = 0;
     return S2M_OK;
@@ -1106,10 +1133,10 @@ int s2m_debug_match(s2m_engine *e, uint32_t *out)
     return S2M_OK;
 }
 
-int s2m_get_timing_stats(const s2m_engine *e, double stats[4])
+int s2m_get_timing_stats(const s2m_engine *e, double stats[6])
 {
     if (!e || !stats) return S2M_ERR_ARG;
-    for (int i = 0; i < 4; ++i) stats[i] = e->tstats[i];
+    for (int i = 0; i < 6; ++i) stats[i] = e->tstats[i];
     return S2M_OK;
 }
 

@@ -102,6 +102,8 @@ struct UndistBuffers {
     int pose_cap = 0;
     float *out = nullptr;  // n x 3 packed, device
     int64_t cap = 0;
+    uint32_t *perm = nullptr;  // sorted position -> input index, on request
+    int64_t perm_cap = 0;
 };
 void free_undist(UndistBuffers &u);
 hipError_t undistort(UndistBuffers &u, const float *pts, int64_t stride, int64_t n, int off_a, int off_b,

@@ -201,9 +201,10 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
                 body_to_world(a.pose, bx, by, bz, wx, wy, wz);
                 const float pd2 = ((pl.x * wx + pl.y * wy) + pl.z * wz) + pl.w;                    // :866
                 const double pbn = sqrt(((double)bx * (double)bx + (double)by * (double)by) + (double)bz * (double)bz);
-                const double s = 1 - 0.9 * fabs((double)pd2) / sqrt(pbn);                           // :868
+                // "float s" (:868): the double expression is rounded to float before the compare of :870
+                const float s = (float)(1 - 0.9 * fabs((double)pd2) / sqrt(pbn));
                 a.pd2[i] = pd2;
-                if (s > a.gates.s_gate) {
+                if ((double)s > a.gates.s_gate) {
                     sel_new = 1;
                     if (fabs((double)pd2) <= a.gates.res_gate) {                                    // :889
                         eff = true;

@@ -63,28 +63,11 @@ __device__ __forceinline__ void m3tv(const double *A, const double *v, double *o
     o[0] = t0; o[1] = t1; o[2] = t2;
 }
 
-// poses: K records of 22 doubles {offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]} in device memory.
-// order: optional permutation (sorted position -> input index); out is written in sorted position.
-__global__ __launch_bounds__(256) void undistort_kernel(const float *__restrict__ pts, int64_t stride, int64_t n,
-                                                        int off_a, int off_b, const uint32_t *__restrict__ order,
-                                                        const double *__restrict__ poses, int K, Pose end,
-                                                        float *__restrict__ out, uint32_t *__restrict__ perm_out)
+// one application of :347-363 to the point (x, y, z) with time t under the head pose ph (22 doubles)
+__device__ __forceinline__ void compensate(const double *__restrict__ ph, double t, const Pose &end, float &x, float &y,
+                                           float &z)
 {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    const int64_t i = order ? (int64_t)order[s] : s;
-    const float *rec = pts + i * stride;
-    const float tf = point_time(rec, off_a, off_b);
-    const double t = (double)tf;
-    float ox = rec[0], oy = rec[1], oz = rec[2];
-    // head = last h in [0, K-2] with offset_time[h] < t  (binary search, offset times ascend)
-    int lo = 0, hi = K - 2, head = -1;
-    while (lo <= hi) {
-        const int mid = (lo + hi) >> 1;
-        if (poses[22 * mid] < t) { head = mid; lo = mid + 1; } else { hi = mid - 1; }
-    }
-    if (head >= 0) {
-        const double *ph = poses + 22 * head;
+    {
         const double dt = t - ph[0];
         const double *acc = ph + 1, *gyr = ph + 4, *vel = ph + 7, *pos = ph + 10, *R = ph + 13;
         // Exp(gyr, dt), so3_math.h:31-52
@@ -113,7 +96,7 @@ __global__ __launch_bounds__(256) void undistort_kernel(const float *__restrict_
         double Tei[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) Tei[k] = ((pos[k] + vel[k] * dt) + (0.5 * acc[k]) * dt * dt) - end.t[k];
-        const double Pi[3] = {(double)rec[0], (double)rec[1], (double)rec[2]};
+        const double Pi[3] = {(double)x, (double)y, (double)z};
         double a[3], b[3], c[3], d[3];
         m3v(end.RLI, Pi, a);
 #pragma unroll
@@ -125,7 +108,39 @@ __global__ __launch_bounds__(256) void undistort_kernel(const float *__restrict_
 #pragma unroll
         for (int k = 0; k < 3; ++k) c[k] = c[k] - end.TLI[k];
         m3tv(end.RLI, c, d);
-        ox = (float)d[0]; oy = (float)d[1]; oz = (float)d[2];
+        x = (float)d[0]; y = (float)d[1]; z = (float)d[2];
+    }
+}
+
+// poses: K records of 22 doubles {offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]} in device memory.
+// order: optional permutation (sorted position -> input index); out is written in sorted position.
+__global__ __launch_bounds__(256) void undistort_kernel(const float *__restrict__ pts, int64_t stride, int64_t n,
+                                                        int off_a, int off_b, const uint32_t *__restrict__ order,
+                                                        const double *__restrict__ poses, int K, Pose end,
+                                                        float *__restrict__ out, uint32_t *__restrict__ perm_out)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int64_t i = order ? (int64_t)order[s] : s;
+    const float *rec = pts + i * stride;
+    const float tf = point_time(rec, off_a, off_b);
+    const double t = (double)tf;
+    float ox = rec[0], oy = rec[1], oz = rec[2];
+    // head = last h in [0, K-2] with offset_time[h] < t  (binary search, offset times ascend)
+    int lo = 0, hi = K - 2, head = -1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        if (poses[22 * mid] < t) { head = mid; lo = mid + 1; } else { hi = mid - 1; }
+    }
+    if (head >= 0) {
+        compensate(poses + 22 * head, t, end, ox, oy, oz);
+        // The reference's `break` at it_pcl == begin() (:366-367) leaves only the inner loop; the outer loop
+        // carries on over the earlier heads and compensates the first point of the sorted cloud again -- from
+        // its already compensated float coordinates -- for every earlier head whose offset time is below the
+        // point's time.  Restated as is (sorted cloud only; sort_by_time == 0 is an extension without it).
+        if (s == 0 && order)
+            for (int h = head - 1; h >= 0; --h)
+                if (t > poses[22 * h]) compensate(poses + 22 * h, t, end, ox, oy, oz);
     }
     out[3 * s] = ox; out[3 * s + 1] = oy; out[3 * s + 2] = oz;
     if (perm_out) perm_out[s] = (uint32_t)i;
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(256) void undistort_kernel(const float *__restrict_
 
 void free_undist(UndistBuffers &u)
 {
-    void *ptrs[] = {u.key, u.key2, u.val, u.val2, u.tmp, u.poses, u.out};
+    void *ptrs[] = {u.key, u.key2, u.val, u.val2, u.tmp, u.poses, u.out, u.perm};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     u = UndistBuffers();

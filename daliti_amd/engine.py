@@ -148,7 +148,7 @@ class Engine:
         self._ck(self.lib.s2m_set_stream(self.h, C.c_void_p(hip_stream)))
 
     def set_timing(self, on=True):
-        """True/1: time the match kernels of rematch passes; 2: also the residual kernel."""
+        """1/2: HIP-event time every pass (search kernels and reduce kernel); n > 2: every n-th pass."""
         self._ck(self.lib.s2m_set_timing(self.h, C.c_int(int(on))))
 
     def timing(self):
@@ -157,9 +157,10 @@ class Engine:
         return list(ms)
 
     def timing_stats(self):
-        st = (C.c_double * 4)()
+        st = (C.c_double * 6)()
         self._ck(self.lib.s2m_get_timing_stats(self.h, st))
-        return dict(match_ms=st[0], match_launches=int(st[1]), reduce_ms=st[2], reduce_launches=int(st[3]))
+        return dict(match_ms=st[0], match_launches=int(st[1]), fit_ms=st[2], fit_launches=int(st[3]),
+                    reduce_ms=st[4], reduce_launches=int(st[5]))
 
     # -- map / scan ------------------------------------------------------------------------
     def map_build(self, xyz):
@@ -212,10 +213,11 @@ class Engine:
     def fov_reset(self):
         self._ck(self.lib.s2m_fov_reset(self.h))
 
-    def map_incremental(self, state, filter_size_map=0.5):
+    def map_incremental(self, state, filter_size_map=0.5, ekf_inited=True):
         state = np.ascontiguousarray(state, np.float64)
         na, nb = C.c_int64(), C.c_int64()
-        self._ck(self.lib.s2m_map_incremental(self.h, _p(state), C.c_double(filter_size_map), C.byref(na), C.byref(nb)))
+        self._ck(self.lib.s2m_map_incremental(self.h, _p(state), C.c_double(filter_size_map),
+                                              C.c_int32(int(bool(ekf_inited))), C.byref(na), C.byref(nb)))
         return na.value, nb.value
 
     def map_points(self):

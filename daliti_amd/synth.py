@@ -14,6 +14,11 @@ CONFIGS = {
     "C2": dict(beams=64, az=1024, M=1_000_000, L=95.0),
     "C3": dict(beams=64, az=1024, M=5_000_000, L=215.0),
     "C4": dict(beams=128, az=1024, M=20_000_000, L=440.0),
+    # batched odometry: 8 independent C3-sized scans (seeds 2..9, sensor offsets (k - 3.5) * 2 m) vs one map
+    "C5": dict(beams=64, az=1024, M=5_000_000, L=215.0, replicas=8),
+    # C3's cloud at the reference's map density: map through Add_Points(downsample 0.5 m), scan through
+    # VoxelGrid(0.5 m) (bench.py / tests build it with s2m_map_add and s2m_scan_set_downsampled)
+    "R1": dict(beams=64, az=1024, M=5_000_000, L=215.0),
 }
 SENSOR_POS = np.array([0.0, 0.0, 1.5])
 DTHETA0 = np.array([0.010, -0.008, 0.015])
@@ -101,6 +106,18 @@ def filter_inputs(sensor_pos=SENSOR_POS, dtheta=DTHETA0, dpos=DPOS0):
     P = np.eye(24) * 1e-4
     P[:6, :6] = np.eye(6) * 1e-3
     return x_true, x_prop, P
+
+
+def replica_offset(k):
+    """Sensor offset along x of replica k of a batched-odometry config ((k - 3.5) * 2 m)."""
+    return (k - 3.5) * 2.0
+
+
+def replica_scan(name, k):
+    """(body-frame scan, sensor position) of replica k: seed 2 + k, sensor moved by replica_offset(k)."""
+    c = CONFIGS[name]
+    pos = SENSOR_POS + np.array([replica_offset(k), 0.0, 0.0])
+    return make_scan(c["beams"], c["az"], c["L"], seed=2 + k, sensor_pos=pos), pos
 
 
 def make_config(name, scan_seed=2, sensor_dx=0.0):

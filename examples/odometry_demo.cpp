@@ -106,7 +106,7 @@ int main(int argc, char **argv)
         s2m_iter_log log;
         CK(s2m_iterated_update(eng, x, xp, P.data(), &log));
         int64_t n_add = 0, n_nodown = 0, m = 0;
-        CK(s2m_map_incremental(eng, x, 0.25, &n_add, &n_nodown));
+        if (!log.ekf_stop) CK(s2m_map_incremental(eng, x, 0.25, 1, &n_add, &n_nodown));  // laserMapping.cpp:1165
         CK(s2m_map_size(eng, &m));
         const double err = std::sqrt((x[9] - truth[0]) * (x[9] - truth[0]) + (x[10] - truth[1]) * (x[10] - truth[1]) +
                                      (x[11] - truth[2]) * (x[11] - truth[2]));

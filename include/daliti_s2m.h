@@ -121,9 +121,14 @@ int s2m_fov_reset(s2m_engine *e);
  * the add / no-need-downsample decision from the Nearest_Points of the last rematch pass, then
  * Add_Points(PointToAdd, true) and Add_Points(PointNoNeedDownsample, false) (:627-628).
  * filter_size_map = mapping/filter_size_map (feat.yaml: 0.5), also the ikd-Tree downsample size
- * (:784).  Outputs: the sizes of the two lists (add_point_size = their sum, :629). */
+ * (:784).  ekf_inited = the reference's flg_EKF_inited at the call (:593): with a zero value no point is
+ * classified and all go to PointToAdd (:623).  In the shipped node the flag is 1 whenever map_incremental
+ * runs: it is set every frame (:762, INIT_TIME == 0), only the EKF_stop branch clears it (:1062), and on
+ * such a scan the node does not call map_incremental at all (`if (!EKF_stop_flg)`, :1165) -- a faithful
+ * caller does the same (s2m_iter_log.ekf_stop) and passes 1 otherwise.
+ * Outputs: the sizes of the two lists (add_point_size = their sum, :629). */
 int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], double filter_size_map,
-                        int64_t *n_to_add, int64_t *n_no_downsample);
+                        int32_t ekf_inited, int64_t *n_to_add, int64_t *n_no_downsample);
 /* ikdtree.flatten(Root_Node, PCL_Storage) (laserMapping.cpp:1170-1175): the current map points,
  * packed xyz, in the engine's index order (the order neighbour indices refer to). */
 int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity_points, int64_t *m);
@@ -277,17 +282,18 @@ typedef struct {
 int s2m_h_share_model(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int first_iteration,
                       s2m_dyn_share *ekfom_data);
 
-/* Timing of the last pass in milliseconds measured with HIP events on the handle's stream:
- * ms[0] = match (kNN + plane fit) kernel, ms[1] = residual/Jacobian/normal-block kernel,
- * ms[2] = whole pass.  s2m_set_timing(e, 1) times the match kernels of rematch passes only (two
- * event records per rematch pass); s2m_set_timing(e, 2) also times the residual kernel;
- * s2m_set_timing(e, n > 2) times every n-th rematch pass only (sampling; use an odd n so first
- * and later rematch passes of a scan are both sampled). */
+/* Timing of the last timed pass in milliseconds, measured with HIP events on the handle's stream:
+ * ms[0] = the search kernels (exact 5-NN; 0 on a reuse pass), ms[1] = the reduce kernel ([gate + plane
+ * fit,] residual, Jacobian row, normal block), ms[2] = whole pass.  s2m_set_timing(e, 1 or 2) times
+ * every pass (three event records each); s2m_set_timing(e, n > 2) times every n-th pass only (sampling:
+ * choose n coprime to the passes per scan so that every kind of pass is visited); 0 switches it off. */
 int s2m_set_timing(s2m_engine *e, int enabled);
 int s2m_get_timing(const s2m_engine *e, double ms[3]);
-/* Accumulated since the last s2m_set_timing call: stats[0] = sum of match-kernel ms, stats[1] =
- * match launches, stats[2] = sum of residual/normal-block ms, stats[3] = its launches. */
-int s2m_get_timing_stats(const s2m_engine *e, double stats[4]);
+/* Accumulated over the timed passes since the last s2m_set_timing call: stats[0] = sum of search-kernel
+ * ms over rematch passes, stats[1] = their count, stats[2] = sum of the reduce kernel's ms on rematch
+ * passes (gate + plane fit included), stats[3] = count, stats[4] = sum of the reduce kernel's ms on reuse
+ * passes, stats[5] = count. */
+int s2m_get_timing_stats(const s2m_engine *e, double stats[6]);
 
 #ifdef __cplusplus
 }

@@ -297,7 +297,7 @@ class Map:
         return lib().orc_map_delete_box(C.c_void_p(self.h), _p(box))
 
 
-def map_incremental_lists(scan_xyz, x, nn_xyz, nn_cnt, fs=0.5):
+def map_incremental_lists(scan_xyz, x, nn_xyz, nn_cnt, fs=0.5, ekf_inited=True):
     scan = np.ascontiguousarray(scan_xyz, np.float32).reshape(-1, 3)
     n = len(scan)
     x = np.ascontiguousarray(x, float)
@@ -306,7 +306,8 @@ def map_incremental_lists(scan_xyz, x, nn_xyz, nn_cnt, fs=0.5):
     to_add = np.zeros((max(n, 1), 3), np.float32)
     no_down = np.zeros((max(n, 1), 3), np.float32)
     na, nd = C.c_int32(0), C.c_int32(0)
-    lib().orc_map_incremental_lists(_p(scan), C.c_int64(n), _p(x), _p(nn_xyz), _p(nn_cnt), C.c_double(fs),
+    lib().orc_map_incremental_lists(_p(scan), C.c_int64(n), _p(x), _p(nn_xyz), _p(nn_cnt), C.c_int(int(bool(ekf_inited))),
+                                    C.c_double(fs),
                                     _p(to_add), C.byref(na), _p(no_down), C.byref(nd))
     return to_add[:na.value].copy(), no_down[:nd.value].copy()
 

@@ -601,10 +601,13 @@ void orc_residual_pass(const orc_cfg *cfg, const orc_kdtree *tree, const float *
             float r = ((pl[0] * pw[0] + pl[1] * pw[1]) + pl[2] * pw[2]) + pl[3];        /* :866 */
             double pbn = sqrt(((double)pb[0] * (double)pb[0] + (double)pb[1] * (double)pb[1]) +
                               (double)pb[2] * (double)pb[2]);
-            double s = 1 - 0.9 * fabs((double)r) / sqrt(pbn);                            /* :868 */
+            /* "float s = 1 - 0.9 * fabs(pd2) / sqrt(p_body.norm())" (:868): the double expression is ROUNDED
+             * TO FLOAT before "s > 0.9" (:870) promotes it back, so s_double in (0.9, 0.9000000059604645] --
+             * which rounds to float(0.9) = 0.89999997615... -- is rejected */
+            const float s = (float)(1 - 0.9 * fabs((double)r) / sqrt(pbn));
             plane[4 * i] = pl[0]; plane[4 * i + 1] = pl[1]; plane[4 * i + 2] = pl[2]; plane[4 * i + 3] = pl[3];
             pd2[i] = r;
-            if (s > cfg->s_gate) {
+            if ((double)s > cfg->s_gate) {
                 selected[i] = 1;
                 if (fabs((double)r) <= cfg->res_gate) eff[i] = 1;                        /* :889 */
             }
@@ -931,14 +934,14 @@ int64_t orc_map_delete_box(orc_map *mp, const float box[6])
 }
 
 void orc_map_incremental_lists(const float *scan_xyz, int64_t n, const orc_state *x, const float *nn_xyz,
-                               const int32_t *nn_cnt, double fs, float *to_add, int32_t *n_add, float *no_down,
-                               int32_t *n_no_down)
+                               const int32_t *nn_cnt, int ekf_inited, double fs, float *to_add, int32_t *n_add,
+                               float *no_down, int32_t *n_no_down)
 {
     int32_t na = 0, nd = 0;
     for (int64_t i = 0; i < n; ++i) {
         float pw[3];
         orc_body_to_world(x, scan_xyz + 3 * i, pw);                            /* :591 */
-        if (nn_cnt[i] > 0) {                                                   /* :593, flg_EKF_inited == true */
+        if (nn_cnt[i] > 0 && ekf_inited) {                                     /* :593 */
             const float *nb = nn_xyz + 15 * i;
             float mid[3];
             for (int k = 0; k < 3; ++k) mid[k] = (float)(floor((double)pw[k] / fs) * fs + 0.5 * fs);  /* :599-601 */
@@ -1067,7 +1070,11 @@ void orc_undistort(const float *rec, int64_t stride, int64_t n, int off_a, int o
         free(v);
         v = w;
     }
-    /* :333-370 */
+    /* :333-370.  The `break` at it_pcl == begin() (:366-367) leaves only the INNER loop: the outer loop goes on
+     * over the earlier heads, and for each of them whose offset time is still below the first point's time
+     * that point is compensated AGAIN, from its already compensated (float) coordinates.  Restated as is for
+     * the sorted cloud (the only form the reference runs); with sort == 0 (an extension) every point is
+     * handled once by its own head. */
     int64_t it = n - 1;
     int stop = 0;
     for (int kp = K - 1; kp >= 1 && !stop; --kp) {
@@ -1089,7 +1096,7 @@ void orc_undistort(const float *rec, int64_t stride, int64_t n, int off_a, int o
             for (int k = 0; k < 3; ++k) c[k] = c[k] - end->T_LI[k];
             mat3_tvec(end->R_LI, c, d);
             for (int k = 0; k < 3; ++k) out[3 * o + k] = (float)d[k];
-            if (it == 0) { stop = 1; break; }
+            if (it == 0) { stop = !sort; break; }
         }
     }
     free(v);

@@ -162,10 +162,11 @@ void     orc_map_points(const orc_map *mp, float *xyz_out); /* alive points, ins
 int64_t  orc_map_add(orc_map *mp, const float *xyz, int64_t n, int downsample_on, float downsample_size);
 int64_t  orc_map_delete_box(orc_map *mp, const float box[6]); /* min xyz, max xyz; min <= p < max */
 /* nn_xyz: n x 5 x 3 neighbour coordinates of the last rematch (Nearest_Points), nn_cnt: n.
- * Writes the two lists the reference builds (world points, index order) and their lengths;
+ * ekf_inited: flg_EKF_inited at the call (laserMapping.cpp:593); zero sends every point to PointToAdd
+ * (:623).  The shipped node only calls map_incremental with the flag set (:762, :1062, :1165).  Writes the two lists the reference builds (world points, index order) and their lengths;
  * to_add / no_down must hold n x 3 floats each. */
 void orc_map_incremental_lists(const float *scan_xyz, int64_t n, const orc_state *x, const float *nn_xyz,
-                               const int32_t *nn_cnt, double filter_size_map, float *to_add,
+                               const int32_t *nn_cnt, int ekf_inited, double filter_size_map, float *to_add,
                                int32_t *n_add, float *no_down, int32_t *n_no_down);
 
 /* ---- scan voxel down-sampling ------------------------------------------------

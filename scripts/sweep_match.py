@@ -31,8 +31,8 @@ for g, hg in [(g, hg) for g in groups for hg in hgs]:
         for _ in range(20):
             e.residual_pass(xt, True)
         st2 = e.timing_stats()
-        print("hard %2d " % hg + "group %2d cell %.3f pts/cell %.2f bricks %6d  match(prop) %.1f us  match(true pose) %.1f us  reduce %.1f us  effct %d" % (
+        print("hard %2d " % hg + "group %2d cell %.3f pts/cell %.2f bricks %6d  match(prop) %.1f us  match(true pose) %.1f us  reduce<FIT> %.1f us  effct %d" % (
             g, info["cell"], info["mean_per_cell"], info["bricks"], 1e3 * st["match_ms"] / st["match_launches"],
             1e3 * st2["match_ms"] / st2["match_launches"],
-            1e3 * st["reduce_ms"] / st["reduce_launches"], out["effct"]), flush=True)
+            1e3 * st["fit_ms"] / st["fit_launches"], out["effct"]), flush=True)
         e.close()

@@ -35,3 +35,20 @@ def bits(a):
     """View a float array as integers so that equality is bit-exact (and NaN == NaN)."""
     a = np.ascontiguousarray(a)
     return a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+
+
+def s_gate_candidates():
+    """A five-point planar patch (z = 1) and 4,096 scan points whose s = 1 - 0.9 |pd2| / sqrt(|p_body|)
+    straddles 0.9 within a few float ulps: the s gate of laserMapping.cpp:868-870 at its rounding edge."""
+    patch = np.array([[10.0, 0.0, 1.0], [10.2, 0.1, 1.0], [9.8, 0.1, 1.0], [10.1, -0.15, 1.0], [9.9, -0.1, 1.0]],
+                     np.float32)
+    k = np.arange(4096)
+    bx = (np.float32(10.0) + k.astype(np.float32) * np.float32(2 ** -20)).astype(np.float32)
+    by = np.full_like(bx, 0.02)
+    # |pd2| = bz - 1 chosen so that 0.9 |pd2| / sqrt(norm) ~ 0.1 (s ~ 0.9); the float grid of bz scatters
+    # s over ~ +-3e-7 around the gate, the window of interest is 6e-9 wide
+    bz0 = np.full(len(bx), 1.35)
+    for _ in range(8):  # fixed point of bz = 1 + (0.1 / 0.9) sqrt(|p|)
+        bz0 = 1.0 + (0.1 / 0.9) * np.sqrt(np.sqrt(bx.astype(np.float64) ** 2 + float(by[0]) ** 2 + bz0 ** 2))
+    bz = bz0.astype(np.float32)
+    return patch, np.stack([bx, by, bz], 1)

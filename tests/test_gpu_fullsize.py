@@ -168,3 +168,67 @@ def test_c4_sharded_scan_against_20m_map(oracle):
     assert effct == full["effct"]
     assert np.abs(HtH - full["HtH"]).max() <= 1e-11 * np.abs(full["HtH"]).max()
     e.close()
+
+
+def test_c5_two_replicas_share_one_map(c3, eng3, oracle):
+    """configs[4] shape on one GPU: replicas 0 and 1 of C5 (seeds 2, 3; sensors at -7 m and -5 m in x) served by
+    two handles that search ONE HBM-resident map (s2m_map_share); each against the oracle on its own scan."""
+    from daliti_amd import Engine, synth
+    tree = oracle.KdTree(c3["map"])
+    cfg = oracle.default_cfg(max_iter=5, nthreads=16)
+    handles = []
+    for k in (0, 1):
+        scan, pos = synth.replica_scan("C5", k)
+        assert abs(pos[0] - (k - 3.5) * 2.0) < 1e-12
+        x_true, x_prop, P = synth.filter_inputs(pos)
+        e = Engine(max_iter=5)
+        e.map_share(eng3)
+        e.scan_set(scan)
+        handles.append((e, scan, x_true, x_prop, P))
+    results = [e.iterated_update(xp, xp, P) for e, _s, _xt, xp, P in handles]   # both scans resident side by side
+    for (e, scan, x_true, x_prop, P), r in zip(handles, results):
+        ro = oracle.iterated_update(cfg, tree, scan, x_prop, x_prop, P)
+        assert r["iters"] == ro["iters"] and (r["effct"] == ro["effct"]).all()
+        assert np.abs(r["x"][9:12] - ro["x"][9:12]).max() < 1e-9
+        dR = ro["x"][:9].reshape(3, 3).T @ r["x"][:9].reshape(3, 3)
+        assert np.abs(oracle.so3_log(dR)).max() < 1e-9
+        assert np.abs(r["x"][9:12] - x_true[9:12]).max() < 0.02
+        e.close()
+    assert synth.CONFIGS["C5"]["replicas"] == 8
+
+
+def test_r1_reference_density_matches_oracle(c3, oracle):
+    """R1: the C3 cloud at the reference's map density -- map through Add_Points(downsample 0.5 m)
+    (ikd_Tree.cpp:489-521), scan through VoxelGrid(0.5 m) (laserMapping.cpp:775-776): ~1 point per voxel, so
+    the 5-NN spans several cells and most queries go through the far-point kernel.  Whole iterated update
+    against the oracle on the engine's own (downsampled) map and scan."""
+    from daliti_amd import Engine
+    e = Engine(max_iter=5)
+    e.map_build(c3["map"][:1])
+    for lo in range(0, len(c3["map"]), 1 << 20):
+        e.map_add(c3["map"][lo:lo + (1 << 20)], True, 0.5)
+    m = e.map_points()
+    key = np.floor(m.astype(np.float64) / 0.5).astype(np.int64)
+    assert len(np.unique(key, axis=0)) == len(m)            # one point per 0.5 m voxel
+    assert 200_000 < len(m) < 1_000_000
+    assert 5.0 < e.map_info()["mean_per_cell"] < 25.0        # the grid followed the density (seeded from 1 point)
+    n = e.scan_set_downsampled(c3["scan"], 0.5)
+    scan = e.scan_get()
+    assert n == len(scan) and 5_000 < n < 65_536
+    assert (bits(scan) == bits(oracle.voxel_downsample(c3["scan"], 0.5))).all()
+    x = c3["x_prop"]
+    out = e.residual_pass(x, True)
+    idx, d2 = e.get_neighbors()
+    st = e.get_point_state()
+    tree = oracle.KdTree(m)
+    ps = oracle.residual_pass(oracle.default_cfg(nthreads=16), tree, scan, x, True, oracle.PassState(n))
+    near = (ps.nn_cnt == 5) & (ps.nn_d2[:, 4] <= 5.0)
+    assert near.mean() > 0.5
+    assert (idx[near] == ps.nn_idx[near]).all() and (bits(d2[near]) == bits(ps.nn_d2[near])).all()
+    assert (st["selected"] == ps.selected).all() and (st["eff"] == ps.eff).all() and out["effct"] == ps.effct
+    r = e.iterated_update(x, x, c3["P"])
+    ro = oracle.iterated_update(oracle.default_cfg(max_iter=5, nthreads=16), tree, scan, x, x, c3["P"])
+    assert r["iters"] == ro["iters"] and (r["effct"] == ro["effct"]).all()
+    assert np.abs(r["x"][9:12] - ro["x"][9:12]).max() < 1e-9
+    assert np.abs(oracle.so3_log(ro["x"][:9].reshape(3, 3).T @ r["x"][:9].reshape(3, 3))).max() < 1e-9
+    e.close()

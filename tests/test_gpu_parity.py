@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import bits
+from conftest import bits, s_gate_candidates
 
 pytestmark = pytest.mark.gpu
 
@@ -271,3 +271,28 @@ def test_map_permutation_invariance(small_scene):
     assert (res[0][0] == res[1][0]).all() and (bits(res[0][1]) == bits(res[1][1])).all()
     assert (bits(res[0][2]["plane"]) == bits(res[1][2]["plane"])).all()
     assert (bits(res[0][3]["HtH"]) == bits(res[1][3]["HtH"])).all()
+
+
+def test_s_gate_float_rounding_edge(oracle):
+    """`float s` of laserMapping.cpp:868: points whose double s lies in (0.9, 0.9000000059604645] are
+    rejected; the kernel's masks equal the oracle's on a scene built to hit that window."""
+    from daliti_amd import Engine
+    patch, scan = s_gate_candidates()
+    e = Engine(max_iter=5)
+    e.map_build(patch)
+    e.scan_set(scan)
+    x = oracle.make_state()
+    out = e.residual_pass(x, True)
+    ps = oracle.residual_pass(oracle.default_cfg(), oracle.KdTree(patch), scan, x, True, oracle.PassState(len(scan)))
+    st = e.get_point_state()
+    pbn = np.sqrt((scan[:, 0].astype(np.float64) ** 2 + scan[:, 1].astype(np.float64) ** 2)
+                  + scan[:, 2].astype(np.float64) ** 2)
+    s_d = 1 - 0.9 * np.abs(st["pd2"].astype(np.float64)) / np.sqrt(pbn)
+    want = s_d.astype(np.float32).astype(np.float64) > 0.9
+    edge = (s_d > 0.9) & ~want
+    assert edge.sum() >= 5
+    assert (bits(st["pd2"]) == bits(ps.pd2)).all()
+    assert (st["selected"].astype(bool) == want).all()
+    assert (st["selected"] == ps.selected).all() and (st["eff"] == ps.eff).all()
+    assert out["effct"] == ps.effct
+    e.close()

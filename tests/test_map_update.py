@@ -169,3 +169,32 @@ def test_fov_segment_matches_oracle(oracle):
     lm, nb, nd = e.fov_segment([1000, 0, 0], 1000.0)        # re-initialises around the new position
     assert nb == 0 and lm[0] == 500 and lm[3] == 1500
     e.close()
+
+
+def test_oracle_map_incremental_after_ekf_stop(oracle, small_scene, small_tree):
+    """flg_EKF_inited is cleared by the EKF_stop branch (laserMapping.cpp:1062): map_incremental (:593)
+    then skips the Nearest_Points classification and every point goes to PointToAdd (:623)."""
+    scan, x = small_scene["scan"][:500], small_scene["x_prop"]
+    nn, _, cnt = small_tree.knn5(oracle.body_to_world(x, scan))
+    nn_xyz = small_tree.xyz[np.maximum(nn, 0)]
+    a1, b1 = oracle.map_incremental_lists(scan, x, nn_xyz, cnt, 0.5, ekf_inited=True)
+    a0, b0 = oracle.map_incremental_lists(scan, x, nn_xyz, cnt, 0.5, ekf_inited=False)
+    assert len(a1) + len(b1) < len(scan) and len(a1) < len(scan)      # the classification drops points
+    assert len(b0) == 0 and (bits(a0) == bits(oracle.body_to_world(x, scan))).all()
+
+
+@pytest.mark.gpu
+def test_map_incremental_after_ekf_stop(oracle, small_scene, small_tree):
+    from daliti_amd import Engine
+    scan, x = small_scene["scan"][:3000], small_scene["x_prop"]
+    e = Engine(cell_size=0.5)
+    e.map_build(small_scene["map"])
+    e.scan_set(scan)
+    e.residual_pass(x, True)
+    om = oracle.Map(small_scene["map"])
+    na, nb = e.map_incremental(x, 0.5, ekf_inited=False)
+    assert (na, nb) == (len(scan), 0)
+    om.add(oracle.body_to_world(x, scan), True, 0.5)
+    assert e.map_size() == om.size()
+    assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
+    e.close()

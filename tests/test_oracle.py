@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 from scipy.spatial.transform import Rotation
 
-from conftest import bits
+from conftest import bits, s_gate_candidates
 
 
 def test_kdtree_matches_bruteforce(oracle):
@@ -195,3 +195,24 @@ def test_multithreaded_oracle_is_identical(oracle, small_scene, small_tree):
     a = oracle.iterated_update(oracle.default_cfg(nthreads=1), small_tree, sc["scan"], sc["x_prop"], sc["x_prop"], sc["P"])
     b = oracle.iterated_update(oracle.default_cfg(nthreads=4), small_tree, sc["scan"], sc["x_prop"], sc["x_prop"], sc["P"])
     assert (bits(a["x"]) == bits(b["x"])).all() and (a["effct"] == b["effct"]).all()
+
+
+def test_s_gate_is_a_float_compare(oracle):
+    """laserMapping.cpp:868 stores s in a `float` before `s > 0.9` (:870): s_double in
+    (0.9, 0.9000000059604645] rounds to float(0.9) = 0.8999999762 and is REJECTED.  (A double-s port
+    accepts those points: the round-1 deviation.)"""
+    patch, scan = s_gate_candidates()
+    tree = oracle.KdTree(patch)
+    x = oracle.make_state()
+    ps = oracle.residual_pass(oracle.default_cfg(), tree, scan, x, True, oracle.PassState(len(scan)))
+    assert ps.plane_ok.all() and (ps.nn_cnt == 5).all()
+    pbn = np.sqrt((scan[:, 0].astype(np.float64) ** 2 + scan[:, 1].astype(np.float64) ** 2)
+                  + scan[:, 2].astype(np.float64) ** 2)
+    s_d = 1 - 0.9 * np.abs(ps.pd2.astype(np.float64)) / np.sqrt(pbn)
+    want = s_d.astype(np.float32).astype(np.float64) > 0.9          # the reference's compare
+    edge = (s_d > 0.9) & ~want                                       # accepted by a double compare only
+    assert edge.sum() >= 5, "scene does not exercise the rounding window"
+    assert (s_d[edge] <= 0.9000000059604645).all()
+    assert want.sum() > 100 and (~want).sum() > 100
+    assert (ps.selected.astype(bool) == want).all()
+    assert not ps.selected[edge].any() and not ps.eff[edge].any()

@@ -162,3 +162,82 @@ def test_two_process_sharded_bench_equals_single_rank():
     assert l2["n_gpus"] == 2 and l2["scaling"] == "weak"
     assert l2["config"]["scan_points_per_gpu"] * 2 == l1["config"]["scan_points_per_gpu"]
     assert np.abs(np.array(l2["final_pos"]) - np.array(l1["final_pos"])).max() < 1e-10
+
+
+@pytest.mark.gpu
+def test_single_pass_entry_points_with_communicator_attached():
+    """A handle that carries an RCCL communicator still serves s2m_residual_pass / s2m_h_share_model: only the
+    sharded loop defers the host hand-off of the block until after its collective."""
+    from daliti_amd import Engine, synth
+    sc = synth.make_small()
+    plain = Engine(max_iter=5)
+    plain.map_build(sc["map"])
+    plain.scan_set(sc["scan"])
+    ref = plain.residual_pass(sc["x_prop"], True)
+    e = Engine(max_iter=5)
+    e.comm_init(Engine.comm_unique_id(), 1, 0)
+    e.map_build(sc["map"])
+    e.scan_set(sc["scan"])
+    got = e.residual_pass(sc["x_prop"], True)
+    assert got["effct"] == ref["effct"] and (got["HtH"] == ref["HtH"]).all()
+    got2 = e.residual_pass(sc["x_prop"], False)
+    assert got2["effct"] == ref["effct"]
+    r1 = e.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])       # the built-in collective path, one rank
+    r0 = plain.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
+    assert (r1["x"] == r0["x"]).all() and (r1["effct"] == r0["effct"]).all()
+    e.close()
+    plain.close()
+
+
+@pytest.mark.gpu
+def test_empty_first_scan():
+    """s2m_scan_set(n = 0) on a fresh handle (no buffers yet) is a valid empty scan: zero block, EKF stop."""
+    from daliti_amd import Engine, synth
+    sc = synth.make_small()
+    e = Engine(max_iter=5)
+    e.map_build(sc["map"])
+    e.scan_set(np.zeros((0, 3), np.float32))
+    out = e.residual_pass(sc["x_prop"], True)
+    assert out["effct"] == 0 and not out["HtH"].any()
+    r = e.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
+    assert r["ekf_stop"] and r["iters"] == 1 and (r["x"] == sc["x_prop"]).all()
+    e.close()
+
+
+@pytest.mark.gpu
+def test_two_process_strong_scaling_bench_equals_single_rank():
+    """`--scaling strong` (BASELINE configs[3] form): ONE scan split by shard_range over two ranks (gloo on CUDA
+    tensors, both on GPU 0) registers to the same pose as one rank over the same scan."""
+    import json
+    import subprocess
+    port = str(29900 + os.getpid() % 90)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--config", "C1", "--scaling", "strong", "--steps", "3", "--warmup", "1",
+                          "--no-cpu", "--backend", "gloo", "--all-on-device0"], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
+                          "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l2["n_gpus"] == 2 and l2["scaling"] == "strong"
+    assert l2["config"]["scan_points_per_gpu"] * 2 == l1["config"]["scan_points_per_gpu"] == 10000
+    assert np.abs(np.array(l2["final_pos"]) - np.array(l1["final_pos"])).max() < 1e-10
+
+
+def test_bench_defaults_follow_baseline_configs():
+    """CPU-side check of bench.py's argument logic: C4 defaults to strong scaling (one 131,072-point scan,
+    16,384 points per GPU at N = 8), C5 to replicas with the survey's seeds and offsets."""
+    from daliti_amd import synth
+    from daliti_amd.sharding import shard_range
+    c4 = synth.CONFIGS["C4"]
+    n = c4["beams"] * c4["az"]
+    assert n == 131072 and [shard_range(n, r, 8) for r in (0, 7)] == [(0, 16384), (114688, 131072)]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"strong" if a.config == "C4" else "weak"' in src and '"replicas" if a.config == "C5"' in src
+    c5 = synth.CONFIGS["C5"]
+    assert c5["replicas"] == 8 and (c5["M"], c5["beams"] * c5["az"]) == (5_000_000, 65536)
+    assert [synth.replica_offset(k) for k in (0, 7)] == [-7.0, 7.0]

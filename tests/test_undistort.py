@@ -6,7 +6,7 @@ from scipy.spatial.transform import Rotation
 from conftest import bits
 
 
-def _scenario(n=20000, K=12, seed=0):
+def _scenario(n=20000, K=12, seed=0, tmin=0.0):
     """A 0.1 s sweep with the sensor turning and accelerating; records mimic PointXYZINormal
     (normal_x = time ratio at float 4, normal_z = time span at float 6)."""
     rs = np.random.RandomState(seed)
@@ -17,6 +17,8 @@ def _scenario(n=20000, K=12, seed=0):
     rec[:, 6] = span                          # normal_z: time span
     rec[:5, 4] = 0.0                          # points at t = 0 are left untouched (t <= IMUpose[0].offset_time)
     rec[5:10, 4] = rec[10, 4]                 # equal times: the stable order must hold
+    if tmin > 0.0:                            # a sweep whose first point is later than several IMU poses
+        rec[:, 4] = tmin + (1.0 - tmin) * rec[:, 4]
     times = np.linspace(0.0, span * 1.02, K)  # the last pose lies beyond the scan end, like imu_end > pcl_end
     poses = np.zeros((K, 22))
     R = np.eye(3); p = np.array([1.0, 2.0, 0.5]); v = np.array([2.0, -1.0, 0.2])
@@ -64,6 +66,47 @@ def test_oracle_undistort_against_direct_formula(oracle):
     # unsorted variant: same values, input order
     out2, perm2 = oracle.undistort(rec, 4, 6, poses, end, sort=False)
     assert (perm2 == np.arange(len(rec))).all() and (bits(out2[perm]) == bits(out)).all()
+
+
+def _direct(rec_xyz, ti, h, poses, end):
+    Rend, pend = end[0:9].reshape(3, 3), end[9:12]
+    RLI, TLI = end[12:21].reshape(3, 3), end[21:24]
+    dt = ti - poses[h, 0]
+    Ri = poses[h, 13:22].reshape(3, 3) @ Rotation.from_rotvec(poses[h, 4:7] * dt).as_matrix()
+    Tei = poses[h, 10:13] + poses[h, 7:10] * dt + 0.5 * poses[h, 1:4] * dt * dt - pend
+    return RLI.T @ (Rend.T @ (Ri @ (RLI @ np.asarray(rec_xyz, np.float64) + TLI) + Tei) - TLI)
+
+
+def test_oracle_first_point_is_recompensated(oracle):
+    """IMU_Processing.hpp:366-367: the `break` at the first point leaves only the inner loop, so the
+    earliest point of the sorted cloud is compensated once more per remaining earlier head."""
+    rec, poses, end = _scenario(n=2000, tmin=0.35)
+    out, perm = oracle.undistort(rec, 4, 6, poses, end, sort=True)
+    t = rec[:, 4] * rec[:, 6]
+    i0, t0 = perm[0], float(t[perm[0]])
+    heads = [h for h in range(len(poses) - 1) if poses[h, 0] < t0]
+    assert len(heads) >= 3
+    p = rec[i0, :3].astype(np.float64)
+    for h in reversed(heads):                       # own head first, then every earlier one
+        p = _direct(p, t0, h, poses, end).astype(np.float32).astype(np.float64)
+    assert np.abs(out[0] - p).max() < 2e-5
+    once = _direct(rec[i0, :3], t0, heads[-1], poses, end)
+    assert np.abs(out[0] - once).max() > 1e-3       # it really differs from a single application
+    i1, t1 = perm[1], float(t[perm[1]])            # the second point is handled once
+    h1 = [h for h in range(len(poses) - 1) if poses[h, 0] < t1][-1]
+    assert np.abs(out[1] - _direct(rec[i1, :3], t1, h1, poses, end)).max() < 2e-5
+
+
+@pytest.mark.gpu
+def test_gpu_undistort_first_point_quirk(oracle):
+    from daliti_amd import Engine
+    rec, poses, end = _scenario(n=4096, tmin=0.35)
+    e = Engine()
+    got, perm = e.undistort(rec, 4, 6, poses, end, sort_by_time=True)
+    ref, rperm = oracle.undistort(rec, 4, 6, poses, end, sort=True)
+    assert (perm == rperm).all()
+    assert (np.abs(got.astype(np.float64) - ref) <= 4 * np.spacing(np.abs(ref)).astype(np.float64)).all()
+    e.close()
 
 
 @pytest.mark.gpu
