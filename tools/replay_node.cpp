@@ -1,0 +1,234 @@
+// replay_node.cpp -- ROS-free replay of the lio_laserMapping per-scan loop through the C ABI.
+//
+// Links only libdaliti_s2m.so (plain g++; no HIP, ROS, PCL or Eigen headers).  It stands where
+// eskf_lio/src/laserMapping.cpp's `while (sync_packages(Measures))` body stands (:731-1290) and consumes,
+// per frame, exactly what that body has in hand after `p_imu->Process` up to the undistortion loop:
+//   * the serialised sensor_msgs/PointCloud2 of /laser_cloud_surf (pcl::PointXYZINormal records,
+//     feature_extract.cpp:335-346) -- parsed with include/daliti_s2m_wire.h,
+//   * IMUpose (IMU_Processing.hpp:224, :310) and the propagated state + covariance (the sequential IMU
+//     forward propagation :226-323 stays on the host side of the boundary and is an input here),
+// and writes what the node writes:
+//   * Log/mat_out.txt rows, one per ESKF iteration (:936-937), with the same iostream formatting,
+//   * /cloud_effected (laserCloudOri in the world frame, :1213-1227) as serialised PointCloud2 (PointXYZI),
+//   * the flattened map of the last frame (/Laser_map, :1170-1175, 1229-1235) as PointCloud2 (PointXYZINormal),
+//   * odometry.txt: time, position, rotation, iterations, last effct_feat_num, map size (full precision).
+// The TIS / zeta fusion (:1105-1129), the TIS fallback (:1054-1063) and every publisher stay in the node.
+//
+// Stream format ("S2MREPL1", little-endian):
+//   char magic[8]; uint32 n_frames; int32 max_iter; int32 extrinsic_est_en; int32 feat_threshold;
+//   double filter_size_surf, filter_size_map, cube_len;
+//   per frame: uint32 n_imu; uint32 msg_len; double state[36]; double P[576]; double imu[n_imu][22];
+//              uint8 msg[msg_len] (padded with zeros to a multiple of 8 bytes)
+//
+// usage: replay_node <stream.bin> <out_dir>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <string>
+#include <vector>
+
+#include "daliti_s2m.h"
+#include "daliti_s2m_wire.h"
+
+#define CK(call)                                                                                     \
+    do {                                                                                             \
+        const int rc_ = (call);                                                                      \
+        if (rc_ != S2M_OK) {                                                                         \
+            std::fprintf(stderr, "%s -> %d (%s) %s\n", #call, rc_, s2m_strerror(rc_), eng ? s2m_last_error(eng) : ""); \
+            return rc_ == S2M_ERR_NO_DEVICE ? 2 : 1;                                                 \
+        }                                                                                            \
+    } while (0)
+
+namespace {
+struct Reader {
+    std::vector<uint8_t> buf;
+    size_t at = 0;
+    bool ok = true;
+    template <class T>
+    T get()
+    {
+        T v{};
+        if (at + sizeof(T) > buf.size()) { ok = false; return v; }
+        std::memcpy(&v, buf.data() + at, sizeof(T));
+        at += sizeof(T);
+        return v;
+    }
+    const uint8_t *take(size_t n)
+    {
+        if (at + n > buf.size()) { ok = false; return nullptr; }
+        const uint8_t *p = buf.data() + at;
+        at += n;
+        return p;
+    }
+};
+
+// pointBodyToWorld / RGBpointBodyToWorld (laserMapping.cpp:260-269, 283-291): double math, float result
+void body_to_world(const double x[S2M_STATE_DOUBLES], const float pb[3], float pw[3])
+{
+    const double *R = x, *t = x + 9, *RLI = x + 12, *TLI = x + 21;
+    const double p[3] = {(double)pb[0], (double)pb[1], (double)pb[2]};
+    double q[3], g[3];
+    for (int i = 0; i < 3; ++i) q[i] = ((RLI[3 * i] * p[0] + RLI[3 * i + 1] * p[1]) + RLI[3 * i + 2] * p[2]) + TLI[i];
+    for (int i = 0; i < 3; ++i) g[i] = ((R[3 * i] * q[0] + R[3 * i + 1] * q[1]) + R[3 * i + 2] * q[2]) + t[i];
+    for (int i = 0; i < 3; ++i) pw[i] = (float)g[i];
+}
+
+void append_msg(std::vector<uint8_t> &out, int kind, uint32_t seq, double stamp, const void *rec, uint32_t n)
+{
+    const size_t sz = s2m_pc2_serialized_size(kind, n, "camera_init");
+    const size_t at = out.size();
+    out.resize(at + 4 + sz);
+    s2m_wire_put_u32(out.data() + at, (uint32_t)sz);
+    s2m_pc2_write(out.data() + at + 4, sz, kind, seq, stamp, "camera_init", rec, n);
+}
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    s2m_engine *eng = nullptr;
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: %s <stream.bin> <out_dir>\n", argv[0]);
+        return 64;
+    }
+    Reader rd;
+    {
+        std::ifstream f(argv[1], std::ios::binary);
+        if (!f) { std::fprintf(stderr, "cannot open %s\n", argv[1]); return 66; }
+        rd.buf.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    }
+    const uint8_t *magic = rd.take(8);
+    if (!magic || std::memcmp(magic, "S2MREPL1", 8) != 0) { std::fprintf(stderr, "not an S2MREPL1 stream\n"); return 65; }
+    const uint32_t n_frames = rd.get<uint32_t>();
+    const int32_t max_iter = rd.get<int32_t>(), extrinsic = rd.get<int32_t>(), feat_thr = rd.get<int32_t>();
+    const double fs_surf = rd.get<double>(), fs_map = rd.get<double>(), cube_len = rd.get<double>();
+    if (!rd.ok) { std::fprintf(stderr, "truncated header\n"); return 65; }
+
+    s2m_config cfg;
+    s2m_config_default(&cfg);
+    cfg.max_iter = max_iter;                 // mapping/max_iteration (:656)
+    cfg.extrinsic_est_en = extrinsic;        // mapping/extrinsic_est_en (:662)
+    cfg.feat_threshold = feat_thr;           // dynamic_effect_featurepoints_threshold (:427-430)
+    CK(s2m_create(&cfg, &eng));
+
+    const std::string dir = argv[2];
+    std::ofstream fout_out(dir + "/mat_out.txt"), fodom(dir + "/odometry.txt");
+    std::vector<uint8_t> effected_msgs;
+    if (!fout_out || !fodom) { std::fprintf(stderr, "cannot write into %s\n", argv[2]); return 73; }
+    fodom << std::setprecision(17);
+
+    bool first_scan = true, have_map = false;
+    double first_lidar_time = 0.0;
+    std::vector<float> xyz, world;
+    std::vector<int32_t> ridx;
+    std::vector<s2m_imu_pose> poses;
+    std::vector<float> blob;
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        const uint32_t n_imu = rd.get<uint32_t>(), msg_len = rd.get<uint32_t>();
+        double state[S2M_STATE_DOUBLES], P[S2M_DIM * S2M_DIM];
+        const uint8_t *ps = rd.take(sizeof(state)), *pP = rd.take(sizeof(P));
+        const uint8_t *pimu = rd.take((size_t)n_imu * sizeof(s2m_imu_pose));
+        const uint8_t *pmsg = rd.take(((size_t)msg_len + 7) & ~(size_t)7);
+        if (!rd.ok) { std::fprintf(stderr, "truncated frame %u\n", f); return 65; }
+        std::memcpy(state, ps, sizeof(state));
+        std::memcpy(P, pP, sizeof(P));
+        poses.resize(n_imu);
+        std::memcpy(poses.data(), pimu, (size_t)n_imu * sizeof(s2m_imu_pose));
+
+        // pcl::fromROSMsg(*(lidar_buffer.front()), *(meas.lidar)) (:545) without PCL
+        s2m_pc2_view v;
+        if (s2m_pc2_parse(pmsg, msg_len, &v, nullptr) != S2M_WIRE_OK) { std::fprintf(stderr, "bad PointCloud2 in frame %u\n", f); return 65; }
+        const float *pts = nullptr;
+        int64_t stride = 0;
+        int32_t oa = 0, ob = 0;
+        int wrc = s2m_pc2_scan_args(&v, &pts, &stride, &oa, &ob);
+        if (wrc == S2M_WIRE_UNALIGNED) {  // the blob starts wherever the header ends: realign it once
+            blob.resize((v.data_len + 3) / 4);
+            std::memcpy(blob.data(), v.data, v.data_len);
+            v.data = reinterpret_cast<const uint8_t *>(blob.data());
+            wrc = s2m_pc2_scan_args(&v, &pts, &stride, &oa, &ob);
+        }
+        if (wrc != S2M_WIRE_OK) {
+            std::fprintf(stderr, "frame %u: /laser_cloud_surf layout not usable (need float32 x,y,z,normal_x,normal_z)\n", f);
+            return 65;
+        }
+        const double lidar_beg_time = (double)v.stamp_sec + 1e-9 * (double)v.stamp_nsec;  // :546
+        if (first_scan) { first_lidar_time = lidar_beg_time; first_scan = false; }          // :737-741
+        // observation_end_time = lidar_beg_time + points.back().normal_z (:547): the stamp of everything published
+        const double obs_end = v.n_points ? lidar_beg_time + (double)pts[(int64_t)(v.n_points - 1) * stride + ob] : lidar_beg_time;
+
+        // UndistortPcl's sort + backward loop (IMU_Processing.hpp:215-216, 333-370) and the surf voxel filter
+        // (:775-776) on the device; the result is feats_down
+        int64_t n_down = 0;
+        CK(s2m_scan_set_from_raw(eng, pts, stride, v.n_points, oa, ob, poses.data(), (int32_t)n_imu, state, (float)fs_surf,
+                                 0, &n_down));
+        // lasermap_fov_segment (:772): pos_lid = pos_end + rot_end * T_L_I (:753)
+        double pos_lid[3];
+        for (int i = 0; i < 3; ++i)
+            pos_lid[i] = state[9 + i] + ((state[3 * i] * state[21] + state[3 * i + 1] * state[22]) + state[3 * i + 2] * state[23]);
+        CK(s2m_fov_segment(eng, pos_lid, cube_len, nullptr, nullptr, nullptr));
+        xyz.resize((size_t)std::max<int64_t>(n_down, 1) * 3);
+        int64_t got = 0;
+        CK(s2m_scan_get(eng, xyz.data(), n_down, &got));
+        if (!have_map) {  // :780-793: the first usable scan seeds the map with its world-frame points
+            if (n_down > 5) {
+                world.resize((size_t)n_down * 3);
+                for (int64_t i = 0; i < n_down; ++i) body_to_world(state, &xyz[3 * i], &world[3 * i]);
+                CK(s2m_map_build(eng, world.data(), 3, n_down, 0));
+                have_map = true;
+            }
+            fodom << lidar_beg_time - first_lidar_time << " seed " << n_down << "\n";
+            continue;
+        }
+        double x[S2M_STATE_DOUBLES];
+        std::memcpy(x, state, sizeof(x));  // state_propagat(state) (:752)
+        s2m_iter_log log;
+        CK(s2m_iterated_update(eng, x, state, P, &log));
+        // Log/mat_out.txt (:936-937), one row per iteration; flg_EKF_converged is the value BEFORE this iteration's
+        // update (0 at iteration 0, :815), RECV_LIO_FAIL_FLAG / recv_n belong to the node (0 here)
+        for (int it = 0; it < log.iters; ++it) {
+            const int effct = log.effct[it];
+            const double res_mean_last = log.total_residual[it] / effct;  // :932 (NaN when effct == 0, like the node)
+            const int conv_before = it ? log.conv[it - 1] : 0;
+            const int stop = (it == log.iters - 1) ? log.ekf_stop : 0;     // a stop ends the loop (:1095-1101)
+            fout_out << std::setw(10) << lidar_beg_time - first_lidar_time << " " << effct << " " << res_mean_last << " "
+                     << (conv_before != 0) << " " << (stop != 0) << " " << n_down << " " << 0 << " " << 0 << std::endl;
+        }
+        // /cloud_effected (:1213-1227): laserCloudOri = the effective points of the LAST pass in index order
+        int64_t m_eff = 0;
+        ridx.resize((size_t)std::max<int64_t>(n_down, 1));
+        CK(s2m_get_rows(eng, nullptr, nullptr, ridx.data(), n_down, &m_eff));
+        std::vector<float> rec((size_t)m_eff * S2M_PXYZI_FLOATS, 0.0f);
+        for (int64_t i = 0; i < m_eff; ++i) body_to_world(x, &xyz[3 * (size_t)ridx[i]], &rec[(size_t)i * S2M_PXYZI_FLOATS]);
+        append_msg(effected_msgs, 0, f, obs_end, rec.data(), (uint32_t)m_eff);
+        // map_incremental (:1165-1168)
+        int64_t n_add = 0, n_nodown = 0, m_map = 0;
+        if (!log.ekf_stop) CK(s2m_map_incremental(eng, x, fs_map, 1, &n_add, &n_nodown));
+        CK(s2m_map_size(eng, &m_map));
+        fodom << lidar_beg_time - first_lidar_time;
+        for (int i = 0; i < 3; ++i) fodom << " " << x[9 + i];
+        for (int i = 0; i < 9; ++i) fodom << " " << x[i];
+        fodom << " " << log.iters << " " << log.effct[log.iters - 1] << " " << (int)log.ekf_stop << " " << n_down << " " << m_map
+              << " " << (n_add + n_nodown) << "\n";
+    }
+    {
+        std::ofstream fe(dir + "/cloud_effected.pc2s", std::ios::binary);
+        fe.write(reinterpret_cast<const char *>(effected_msgs.data()), (std::streamsize)effected_msgs.size());
+    }
+    if (have_map) {  // ikdtree.flatten -> featsFromMap -> /Laser_map (:1170-1175, 1229-1235), last frame only here
+        int64_t m = 0;
+        CK(s2m_map_get_points(eng, nullptr, 0, &m));
+        std::vector<float> mp((size_t)std::max<int64_t>(m, 1) * 3), rec((size_t)m * S2M_PXYZIN_FLOATS, 0.0f);
+        CK(s2m_map_get_points(eng, mp.data(), m, &m));
+        for (int64_t i = 0; i < m; ++i) std::memcpy(&rec[(size_t)i * S2M_PXYZIN_FLOATS], &mp[3 * (size_t)i], 3 * sizeof(float));
+        std::vector<uint8_t> out;
+        append_msg(out, 1, n_frames, 0.0, rec.data(), (uint32_t)m);
+        std::ofstream fm(dir + "/laser_map.pc2s", std::ios::binary);
+        fm.write(reinterpret_cast<const char *>(out.data()), (std::streamsize)out.size());
+    }
+    s2m_destroy(eng);
+    return 0;
+}
