@@ -426,7 +426,7 @@ def pmc_traffic():
             doc = json.load(open(path))
             k = doc["kernels"]
             tot = 0.0
-            for name in ("match_easy", "match_hard", "reduce_kernel<false, true>"):
+            for name in ("match_rows", "match_hard", "reduce_kernel<false, true>"):
                 tot += (2.0 * k[name]["FETCH_SIZE_avg"] + k[name]["WRITE_SIZE_avg"]) * 1024.0
             return tot, "%s (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the profiled build '%s', " \
                         "read side x2; not measured in this run)" % (os.path.relpath(path, ROOT), doc.get("tag", "?"))

@@ -37,7 +37,7 @@ struct s2m_engine {
     double last_ms[3] = {0, 0, 0};
     double tstats[6] = {0, 0, 0, 0, 0, 0};     // {match ms, n, reduce<FIT> ms, n, reduce (reuse pass) ms, n}
     bool last_rematch = false;
-    int match_group = 4;
+    int match_group = 2;  // lanes per scan point in the first-shell search (measured best with 3 batches per trip)
     std::string err;
 
     MapBuffers map;
@@ -304,6 +304,12 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
     }
     if (const char *g = std::getenv("S2M_WIDE_ADDR"))
         if (std::atoi(g) != 0) e->match_group |= 0x10000;
+    if (const char *g = std::getenv("S2M_EASY_CELLS"))
+        if (std::atoi(g) != 0) e->match_group |= 0x20000;
+    if (const char *g = std::getenv("S2M_EASY_NB")) {
+        const int v = std::atoi(g);
+        if (v >= 1 && v <= 3) e->match_group |= v << 8;
+    }
     e->dbg = std::getenv("S2M_DEBUG_MATCH") != nullptr;
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&e->ev[i]) == hipSuccess;

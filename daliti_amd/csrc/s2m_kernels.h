@@ -119,8 +119,8 @@ struct MatchArgs {
     int n;
     int32_t *nn_idx;     // n x 5, index into the caller's map array, -1 = missing
     float *nn_d2;        // n x 5 ascending, INFINITY = missing
-    uint32_t *hard_list; // 3 x n entries of scratch: points the first-shell kernel could not resolve, by cost class
-    uint32_t *hard_count; // 3 counters (far, mid, near)
+    uint32_t *hard_list; // n entries of scratch: the points the first-shell kernel could not resolve
+    uint32_t *hard_count; // its length (device counter, reset by every reduce launch)
     float *wq = nullptr;      // 3 x n scratch: world-frame query point of every unresolved scan point (SoA)
     uint32_t *dbg = nullptr;  // optional diagnostics, 4 words per scan point
 };

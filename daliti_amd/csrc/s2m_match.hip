@@ -12,12 +12,15 @@
 // handful of 64-bit compare/selects with no tie branches (ikd-Tree ranks by d2, then x,
 // ikd_Tree.h:102-108; exact ties are ~1e-7 of queries and either choice is a valid exact 5-NN).
 //
-// Two kernels, because measured cost is VALU issue + a long tail of far queries:
-//   match_easy<G> : G lanes (1..8) per scan point scan the 3x3x3 cells around it -- 9 x-rows, each
-//                   one or two (top entry, table pair, point run) lookups, issued phase by phase so
-//                   every lane has all its loads of a phase in flight together.  If the 5th-best
-//                   distance is provably inside the cube the result is final; otherwise the point
-//                   is appended to the hard list.
+// Two kernels, because measured cost is a long tail of far queries on top of the first-shell work:
+//   match_rows<G> : G lanes (default 2) per scan point scan the 3x3x3 cells around it as nine x-ROWS: the three
+//                   cells of a row are one contiguous run of points (two when the row straddles a brick), the
+//                   home row first, the other rows trimmed by its 5th-best distance, all of a lane's runs walked
+//                   as one flat sequence of 8-point batches, three batches (24 loads) in flight per trip.  If the
+//                   5th-best distance is provably inside the cube the result is final; otherwise the point is
+//                   appended to the hard list.  (match_easy<G> is the earlier per-CELL form of the same search,
+//                   kept behind S2M_EASY_CELLS=1 for A/B measurements: 2.6x the VALU and 2.8x the vector-memory
+//                   instructions for the same answer.)
 //   match_hard    : one wave per hard point.  The x-rows that can hold a point within the current radius
 //                   (the first shell's 5th distance, else a growing band) are found either directly -- the
 //                   7x7 rows around the home row while the radius is within three cells -- or from the
@@ -58,6 +61,8 @@ constexpr int kEasyBatch = S2M_EASY_BATCH;  // point loads in flight per lane in
 #endif
 constexpr int kHardBatch = S2M_HARD_BATCH;  // same for the one-cell-per-lane kernel
 
+__device__ __forceinline__ void append_list(uint32_t *__restrict__ list, uint32_t *__restrict__ counter, bool want,
+                                            uint32_t value);
 __device__ __forceinline__ u64 make_key(float d2, uint32_t orig)
 {
     return ((u64)__float_as_uint(d2) << 32) | (u64)orig;
@@ -438,22 +443,7 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
     // 5th-best distance; unknown when fewer than five were found): match_hard starts the expensive ones
     // first so they do not form the tail of the launch.  One atomic per wave and list: same-address
     // atomics serialise in L2 (~90 per microsecond), ten thousand per-lane atomics would cost > 100 us.
-    const int rn_est = found5 ? (int)ceilf(sqrtf(d5) * g.inv_c * 1.000002f - q.fmin + g.slop) : 4;
-    const int cls = (j == 0 && !done) ? (rn_est <= 2 ? 2 : (rn_est == 3 ? 1 : 0)) : -1;
-    const int lane64 = threadIdx.x & 63;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const unsigned long long mask = __ballot(cls == c);
-        if (mask == 0ull) continue;  // wave-uniform
-        const int leader = __ffsll((long long)mask) - 1;
-        uint32_t base = 0;
-        if (lane64 == leader) base = atomicAdd(a.hard_count + c, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader, 64);
-        if (cls == c) {
-            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull));
-            a.hard_list[(int64_t)c * a.n + base + rank] = (uint32_t)qi;
-        }
-    }
+    append_list(a.hard_list, a.hard_count, j == 0 && !done, (uint32_t)qi);  // unresolved: match_hard's list
     if (j == 0) {
         // unresolved points keep their first-shell list too: match_hard takes its radius from it, and its
         // query point from here (the pose alone is 48 SGPRs that kernel would spill around every point)
@@ -466,6 +456,226 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
             a.dbg[4 * (int64_t)qi + 3] = 1;
         }
     }
+}
+
+// ---- first shell, second form: whole x-rows as point runs, one flattened work list per lane ---------------
+// The cells of one x-row of a brick are contiguous in pts, so the three cells (cx-1, cx, cx+1) of a row are ONE run
+// of points -- two when the row straddles a brick boundary in x (cx & 7 is 0 or 7) -- found with one top entry and
+// four consecutive prefix words of the brick table.  Padding a batch of eight then costs at most seven slots per
+// RUN instead of per CELL (measured on the cell form: 488 point-load slots per query for ~108 real candidates;
+// 8.48 M VALU and 0.50 M vector-memory wave-instructions per launch at C3 against 3.3-4.7 M and 0.17-0.21 M here).
+// A lane's runs (its contiguous share of each run when G lanes serve one query) are chained through a small
+// per-lane list in LDS into ONE flat sequence of batches, walked with the next batch's eight loads already in
+// flight while the current one goes through the distance arithmetic and the top-5 network -- with half the
+// instructions the kernel is latency- rather than issue-bound.  The home row goes first; its 5th-best distance
+// (group-wide for G > 1) trims every other row to the cells that can still hold something closer.
+struct __attribute__((packed, aligned(4))) TabQuad {
+    uint32_t w[4];
+};
+__device__ __forceinline__ uint32_t sel4(const TabQuad &q, int k)
+{
+    return k == 0 ? q.w[0] : (k == 1 ? q.w[1] : (k == 2 ? q.w[2] : q.w[3]));
+}
+// run of the cells [lo, hi] (absolute x indices) of a segment that starts at cell sx0 and whose prefix words are q
+__device__ __forceinline__ void seg_run(const TabQuad &q, int sx0, int sx1, int lo, int hi, uint32_t &s, uint32_t &e)
+{
+    lo = max(lo, sx0);
+    hi = min(hi, sx1);
+    s = 0; e = 0;
+    if (lo <= hi) { s = sel4(q, lo - sx0); e = sel4(q, hi - sx0 + 1); }
+}
+
+// eight candidates pts[i .. i+8) clipped to e; slots beyond e (all of them when i >= e) read the sentinel block
+template <bool WIDE>
+__device__ __forceinline__ void load_batch(const Grid &g, uint32_t i, uint32_t e, float4 (&p)[8])
+{
+    const float4 *__restrict__ pts = g.pts;
+    const uint32_t left = e > i ? e - i : 0u;
+    if (WIDE) {
+        const uint32_t sent = (uint32_t)g.m;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = pts[((uint32_t)u < left) ? i + u : sent + u];
+    } else {
+        const uint32_t off = i << 4, soff = g.sent_off;
+        const char *base = reinterpret_cast<const char *>(pts);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            p[u] = *reinterpret_cast<const float4 *>(base + (size_t)(((uint32_t)u < left) ? off : soff) + 16 * u);
+    }
+}
+__device__ __forceinline__ void consume_batch(const float4 (&p)[8], float wx, float wy, float wz, u64 (&t)[kK])
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 wxy = {wx, wy};
+    u64 key[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const f2 dxy = wxy - f2{p[u].x, p[u].y};
+        const f2 sq = dxy * dxy;
+        const float dz = wz - map_point_z(p[u]);
+        float d = sq.x + sq.y;
+        d = d + dz * dz;
+        key[u] = make_key(d, map_point_index(p[u]));
+    }
+    insert_batch8(t, key);
+}
+
+constexpr int kRunSlots = 16;  // 8 rows x 2 segments besides the home row
+
+// position in a lane's chain of runs: run k of nr, next batch at i, run end e (i = e = 0 once exhausted)
+struct RunCursor {
+    uint32_t k, i, e;
+};
+
+template <int G, bool WIDE, int NB>
+__global__ __launch_bounds__(256) void match_rows(MatchArgs a)
+{
+    __shared__ uint2 runs[kRunSlots * 256];  // [slot][thread]: conflict-free whatever the per-lane fill
+    const long long t0 = a.dbg ? wall_clock64() : 0;
+    const Grid &g = a.grid;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int qi = tid / G;
+    const int j = tid % G;
+    if (qi >= a.n) return;  // group-uniform
+    const Query q = make_query(g, a.pose, a.sx[qi], a.sy[qi], a.sz[qi]);
+    // x extent of the neighbourhood inside the grid; segment A lies in brick bA, segment B (if any) in bA + 1
+    const int x_lo = max(q.cx - 1, 0), x_hi = min(q.cx + 1, g.ncx - 1);
+    const bool xok = x_lo <= x_hi;
+    const int bA = x_lo >> 3, bB = x_hi >> 3;
+    const bool split = xok && bB != bA;
+    const int ax1 = split ? (bA << 3) + 7 : x_hi;  // last cell of segment A
+    const int bx0 = bB << 3;                         // first cell of segment B
+    // phase 1: brick ids of the nine rows (two per row where the row is split).  The row masks are not consulted:
+    // an empty row's prefix words are equal, i.e. an empty run.
+    uint32_t idA[9], idB[9];
+    int rowbit[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const int yy = q.cy + (r % 3) - 1, zz = q.cz + (r / 3) - 1;
+        const bool ok = xok && yy >= 0 && yy < g.ncy && zz >= 0 && zz < g.ncz;
+        rowbit[r] = ((zz & 7) << 3) | (yy & 7);
+        const int64_t toprow = ((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx;
+        idA[r] = 0u;
+        idB[r] = 0u;
+        if (ok) idA[r] = g.top[toprow + bA].x;
+        if (ok && split) idB[r] = g.top[toprow + bB].x;
+    }
+    // phase 2: the home row's prefix words (four consecutive words cover its three cells); the other rows' words are
+    // fetched after the home row has produced a bound -- only for the rows and cells that survive it
+    TabQuad qa4 = TabQuad{{0u, 0u, 0u, 0u}}, qb4 = TabQuad{{0u, 0u, 0u, 0u}};
+    if (idA[4]) qa4 = *reinterpret_cast<const TabQuad *>(g.tab + (int64_t)(idA[4] - 1) * kBrickStride + (rowbit[4] << 3) + (x_lo & 7));
+    if (idB[4]) qb4 = *reinterpret_cast<const TabQuad *>(g.tab + (int64_t)(idB[4] - 1) * kBrickStride + (rowbit[4] << 3));
+    u64 t[kK], best[kK];
+#pragma unroll
+    for (int k = 0; k < kK; ++k) t[k] = kEmptyKey;
+    uint32_t nr = 0;
+    // this lane's contiguous share of the run [s, e): ceil(len / G) rounded up to whole batches
+    auto push_run = [&](uint32_t s, uint32_t e) {
+        if (s >= e) return;
+        const uint32_t chunk = (((e - s) + 8u * G - 1u) / (8u * G)) * 8u;
+        const uint32_t ms = s + (uint32_t)j * chunk, me = min(ms + chunk, e);
+        if (ms < me) { runs[nr * 256 + threadIdx.x] = make_uint2(ms, me); ++nr; }
+    };
+    // the lane's batches, NB at a time: all 8 * NB point loads of a trip are in flight together (an exhausted cursor
+    // loads the sentinel block -- distance +inf, nothing is inserted -- so the trip has no branches around its loads)
+    auto walk_runs = [&]() {
+        if (nr == 0) return;
+        RunCursor c;
+        c.k = 0;
+        { const uint2 r0 = runs[threadIdx.x]; c.i = r0.x; c.e = r0.y; }
+        auto advance = [&]() {
+            c.i += 8u;
+            if (c.i >= c.e) {
+                ++c.k;
+                c.i = 0u; c.e = 0u;
+                if (c.k < nr) { const uint2 rk = runs[c.k * 256 + threadIdx.x]; c.i = rk.x; c.e = rk.y; }
+            }
+        };
+        while (c.k < nr) {
+            float4 p[NB][8];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                load_batch<WIDE>(g, c.i, c.e, p[b]);
+                advance();
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) consume_batch(p[b], q.wx, q.wy, q.wz, t);
+        }
+    };
+    // phase 3a: the home row (r = 4), all G lanes of the group on it
+    {
+        uint32_t s, e;
+        seg_run(qa4, x_lo, ax1, x_lo, x_hi, s, e);
+        push_run(s, e);
+        seg_run(qb4, bx0, x_hi, x_lo, x_hi, s, e);
+        push_run(s, e);
+    }
+    walk_runs();
+    merge_lists<G>(t, best);
+    const bool have_tau = !is_empty(best[kK - 1]);
+    const float tau = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
+    // phase 3b: the other rows, trimmed to the cells that can hold something closer than tau, as one work list.
+    // First the two prefix words that delimit each surviving piece (all requested together), then the list.
+    nr = 0;
+    uint32_t sA[9], eA[9], sB[9], eB[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        sA[r] = eA[r] = sB[r] = eB[r] = 0u;
+        if (r == 4) continue;
+        const int dy = (r % 3) - 1, dz = (r / 3) - 1;
+        // the cell bound grows with |dx|: the cells that survive are a contiguous range around dx = 0
+        if (have_tau && cell_bound2(g, q, 0, dy, dz) > tau) continue;
+        int xa = q.cx, xb = q.cx;
+        if (!(have_tau && cell_bound2(g, q, -1, dy, dz) > tau)) xa = q.cx - 1;
+        if (!(have_tau && cell_bound2(g, q, 1, dy, dz) > tau)) xb = q.cx + 1;
+        const int la = max(xa, x_lo), ha = min(xb, ax1);  // piece inside segment A
+        if (idA[r] && la <= ha) {
+            const uint32_t *tb = g.tab + (int64_t)(idA[r] - 1) * kBrickStride + (rowbit[r] << 3);
+            sA[r] = tb[la & 7]; eA[r] = tb[(ha & 7) + 1];
+        }
+        const int lb = max(xa, bx0), hb = min(xb, x_hi);  // piece inside segment B
+        if (idB[r] && lb <= hb) {
+            const uint32_t *tb = g.tab + (int64_t)(idB[r] - 1) * kBrickStride + (rowbit[r] << 3);
+            sB[r] = tb[lb & 7]; eB[r] = tb[(hb & 7) + 1];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        if (r == 4) continue;
+        push_run(sA[r], eA[r]);
+        push_run(sB[r], eB[r]);
+    }
+    walk_runs();
+    merge_lists<G>(t, best);
+    const bool found5 = !is_empty(best[kK - 1]);
+    const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
+    const bool done = found5 && d5 <= cube_bound2(g, q, 1);
+    append_list(a.hard_list, a.hard_count, j == 0 && !done, (uint32_t)qi);  // unresolved: match_hard's list
+    if (j == 0) {
+        store_result(best, qi, a.nn_idx, a.nn_d2);
+        if (!done) { a.wq[qi] = q.wx; a.wq[(int64_t)a.n + qi] = q.wy; a.wq[2 * (int64_t)a.n + qi] = q.wz; }
+        if (a.dbg) {
+            a.dbg[4 * (int64_t)qi + 0] = (uint32_t)(wall_clock64() - t0);
+            a.dbg[4 * (int64_t)qi + 1] = done ? 1u : 0u;
+            a.dbg[4 * (int64_t)qi + 2] = 0;
+            a.dbg[4 * (int64_t)qi + 3] = 1;
+        }
+    }
+}
+
+// one atomic per wave for a list append: same-address atomics serialise in L2 (~90 per microsecond), ten thousand
+// per-lane atomics would cost > 100 us
+__device__ __forceinline__ void append_list(uint32_t *__restrict__ list, uint32_t *__restrict__ counter, bool want,
+                                            uint32_t value)
+{
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;  // wave-uniform
+    const int lane64 = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane64 == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (want) list[base + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull))] = value;
 }
 
 // ---- the rest: one wave per hard scan point, occupied rows only ------------------------------------
@@ -510,8 +720,8 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t c0 = a.hard_count[0], c1 = a.hard_count[1], c2 = a.hard_count[2];
-    const uint32_t count = c0 + c1 + c2;
+    const uint32_t count = a.hard_count[0];
+    const uint32_t *__restrict__ hlist = a.hard_list;
     // brick rings needed so that the neighbourhood covers the gate radius from anywhere in the home brick
     const float gate_r = sqrtf(a.gates.knn_d2_gate);
     const int NB = max(1, (int)ceilf(gate_r * g.inv_c * 0.125f + 1e-3f));
@@ -526,10 +736,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
     const float near_r2 = near_r * near_r;
     for (uint32_t h = wave; h < count; h += nwaves) {
         const long long t0 = a.dbg ? wall_clock64() : 0;
-        // concatenation [far | mid | near]: the most expensive points are handed out first
-        const int qi = (int)(h < c0 ? a.hard_list[h]
-                                    : (h < c0 + c1 ? a.hard_list[(int64_t)a.n + (h - c0)]
-                                                   : a.hard_list[2 * (int64_t)a.n + (h - c0 - c1)]));
+        const int qi = (int)hlist[h];
         const Query q = query_at(g, a.wq[qi], a.wq[(int64_t)a.n + qi], a.wq[2 * (int64_t)a.n + qi]);
         const float fxq = (float)q.cx + q.frx;  // query x in cell units
         // radius: the first shell's 5th-best distance when it found five (then one round is exact)
@@ -708,13 +915,24 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
 }
 
 template <int G>
-static void launch_easy(const MatchArgs &a, bool wide, hipStream_t st)
+static void launch_easy(const MatchArgs &a, bool wide, bool cells, int nb, hipStream_t st)
 {
     const int64_t threads = (int64_t)a.n * G;
     const int blocks = (int)((threads + 255) / 256);
     // 32-bit byte offsets into the sorted point array unless the map is too large for them
-    if (!wide) hipLaunchKernelGGL((match_easy<G, false>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((match_easy<G, true>), dim3(blocks), dim3(256), 0, st, a);
+    if (cells) {  // the per-cell form (S2M_EASY_CELLS=1), kept for A/B measurements
+        if (!wide) hipLaunchKernelGGL((match_easy<G, false>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((match_easy<G, true>), dim3(blocks), dim3(256), 0, st, a);
+    } else if (nb == 1) {
+        if (!wide) hipLaunchKernelGGL((match_rows<G, false, 1>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((match_rows<G, true, 1>), dim3(blocks), dim3(256), 0, st, a);
+    } else if (nb == 2) {
+        if (!wide) hipLaunchKernelGGL((match_rows<G, false, 2>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((match_rows<G, true, 2>), dim3(blocks), dim3(256), 0, st, a);
+    } else {  // default: three batches (24 point loads) per trip
+        if (!wide) hipLaunchKernelGGL((match_rows<G, false, 3>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((match_rows<G, true, 3>), dim3(blocks), dim3(256), 0, st, a);
+    }
 }
 
 void launch_match(const MatchArgs &a, int group, hipStream_t st)
@@ -723,14 +941,16 @@ void launch_match(const MatchArgs &a, int group, hipStream_t st)
     // 64-bit point addresses when the sentinel block is out of reach of a 32-bit byte offset (or on request:
     // bit 16 of `group`, S2M_WIDE_ADDR=1, so the tests can cover that path on a small map)
     const bool wide = (a.grid.sent_off == 0 && a.grid.m != 0) || (group & 0x10000);
+    const bool cells = (group & 0x20000) != 0;
+    const int nb = (group >> 8) & 0xf;  // batches per trip of the row-run kernel (0 = default)
     switch (group & 0xff) {
-        case 1: launch_easy<1>(a, wide, st); break;
-        case 2: launch_easy<2>(a, wide, st); break;
-        case 8: launch_easy<8>(a, wide, st); break;
-        default: launch_easy<4>(a, wide, st); break;
+        case 1: launch_easy<1>(a, wide, cells, nb, st); break;
+        case 4: launch_easy<4>(a, wide, cells, nb, st); break;
+        case 8: launch_easy<8>(a, wide, cells, nb, st); break;
+        default: launch_easy<2>(a, wide, cells, nb, st); break;
     }
-    // fixed grid, groups stride over the hard list whose length is only known on the device
-    const int hg = 64;  // one wave per hard point (narrower groups measured slower: the far tail is latency-bound)
+    // the rest: one wave per point (narrower groups measured slower: the far tail is latency-bound)
+    const int hg = 64;
     const int64_t groups = std::min<int64_t>(a.n, 8192 * (64 / hg));
     const int blocks = (int)((groups * hg + 255) / 256);
     if (!wide) hipLaunchKernelGGL(match_hard<false>, dim3(blocks), dim3(256), 0, st, a);

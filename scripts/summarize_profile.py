@@ -14,7 +14,7 @@ dst = os.path.join(root, "profiles")
 
 
 def short(name):
-    for k in ("match_easy", "match_hard", "reduce_kernel<false, true>", "reduce_kernel<false, false>",
+    for k in ("match_rows", "match_easy", "match_hard", "reduce_kernel<false, true>", "reduce_kernel<false, false>",
               "reduce_kernel<true, true>", "reduce_kernel<true, false>"):
         if k in name:
             return k
