@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the sharded/all-reduce code path even with one rank (test hook)")
     ap.add_argument("--replicas", type=int, default=0, help="C5: number of independent scans (default 8)")
+    ap.add_argument("--sequential", action="store_true",
+                    help="C5 on one GPU: serve the scans one after the other instead of through s2m_iterated_update_batch")
     return ap.parse_args()
 
 
@@ -227,6 +229,24 @@ def main():
                  log=IterLog()) for f in filt]
     last = {}
 
+    batched = len(engs) > 1 and not use_callback and not a.sequential
+    if batched:  # all of this rank's scans in flight at once, one host thread (s2m_iterated_update_batch)
+        from daliti_amd.engine import IterLog as _IL
+        bx = np.zeros((len(engs), 36)); bxp = np.ascontiguousarray(np.stack([b["xp"] for b in bufs]))
+        bP = np.zeros((len(engs), 24, 24)); blogs = (_IL * len(engs))()
+
+    def step_batched(k_step):
+        for e in engs:
+            e.set_feat_queue(())
+        bx[:] = bxp
+        for i, b in enumerate(bufs):
+            bP[i] = b["P0"]
+            bP[i, 0, 0] += (k_step & 1) * 1e-15
+        Engine.iterated_update_batch(engs, bx, bxp, bP, blogs)
+        bufs[0]["x"][:] = bx[0]; bufs[0]["P"][:] = bP[0]
+        bufs[0]["log"] = blogs[0]
+        return sum(l.iters for l in blogs), sum(l.rematch_passes for l in blogs)
+
     def step(k_step):
         """One iterated update per scan this rank serves.  The degeneracy queue is cleared so that every step
         is the same scan arriving fresh.  P differs from the previous step's P in its last bit: in a real
@@ -255,6 +275,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if batched:
+        step = step_batched
     for k in range(a.warmup):
         step(k)
     eng.set_timing(TIMING_STRIDE)
@@ -299,7 +321,9 @@ def main():
                "per iteration (%s)" % (world, scaling, n_scan_total, n_local,
                                        "engine-owned communicator" if builtin_comm else "torch.distributed callback"))
     elif len(scans) > 1 or world > 1:
-        par = "replicas: %d independent scans on %d GPU(s), one shared map per GPU, no collective" % (int(scans_all / a.steps), world)
+        par = "replicas: %d independent scans on %d GPU(s), one shared map per GPU, no collective; %s" % (
+            int(scans_all / a.steps), world,
+            "all of a GPU's scans in flight from one host thread (s2m_iterated_update_batch)" if batched else "one scan in flight per GPU")
     else:
         par = "single GPU"
     out = {

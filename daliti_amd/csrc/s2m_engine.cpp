@@ -938,6 +938,77 @@ int s2m_cov_update(s2m_engine *e, double P[S2M_DIM * S2M_DIM])
     return S2M_OK;
 }
 
+namespace {
+// loop variables of the iterated update (laserMapping.cpp:813-818, 820)
+struct IterCtl {
+    int it, rematch, rematch_num, rematch_en;
+    int32_t conv, stop;
+};
+
+// Everything the reference does with the result of one pass (:899-918, 1012-1101): degeneracy queue, Kalman update,
+// log row, rematch judgement, exit test + covariance update.  finished = the loop ends after this iteration.
+int consume_block(s2m_engine *e, const double *hb, IterCtl &c, double x[S2M_STATE_DOUBLES],
+                  const double x_prop[S2M_STATE_DOUBLES], double P[S2M_DIM * S2M_DIM], s2m_iter_log *log, bool &finished,
+                  double *solve_us)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const int max_iter = e->cfg.max_iter;
+    const double *HtH = hb, *Htz = hb + 144;
+    const int32_t effct = (int32_t)hb[156];
+    const double total_res = hb[157];
+    // degeneracy queue (:899-918)
+    e->queue[e->queue_len++] = effct;
+    if (e->queue_len > S2M_FEAT_QUEUE) {
+        std::memmove(e->queue, e->queue + 1, sizeof(int32_t) * S2M_FEAT_QUEUE);
+        e->queue_len = S2M_FEAT_QUEUE;
+    }
+    c.stop = 0;
+    for (int q = 0; q < e->queue_len; ++q)
+        if (e->queue[q] <= e->cfg.feat_threshold) { c.stop = 1; break; }
+    double sol[S2M_DIM] = {0};
+    if (!c.stop) {  // flg_EKF_inited is always true (INIT_TIME == 0, :75,:762)
+        int rc = s2m_eskf_update(e, x, x_prop, P, HtH, Htz, sol, &c.conv);
+        if (rc) return rc;
+    }
+    if (solve_us) *solve_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (log) {
+        log->effct[c.it] = effct;
+        log->rematch[c.it] = c.rematch;
+        log->conv[c.it] = c.conv;
+        log->total_residual[c.it] = total_res;
+        std::memcpy(log->solution[c.it], sol, sizeof(sol));
+    }
+    c.rematch_en = 0;  // rematch judgement (:1070-1076)
+    if (c.conv || (c.rematch_num == 0 && c.it == max_iter - 2)) {
+        c.rematch_en = 1;
+        c.rematch_num++;
+    }
+    finished = false;
+    if (c.rematch_num >= 2 || c.it == max_iter - 1) {  // :1079-1094
+        if (!c.stop) {
+            int rc = s2m_cov_update(e, P);
+            if (rc) return rc;
+        }
+        finished = true;
+    } else if (c.stop) {  // :1095-1101
+        finished = true;
+    }
+    return S2M_OK;
+}
+
+void reset_log(s2m_iter_log *log, int max_iter)
+{
+    if (!log) return;  // header fields + the rows this call can write (the struct holds 64 rows, 13 KB)
+    log->iters = log->rematch_passes = log->converged = log->ekf_stop = 0;
+    const size_t rows = (size_t)std::min(max_iter, 64);
+    std::memset(log->effct, 0, rows * sizeof(log->effct[0]));
+    std::memset(log->rematch, 0, rows * sizeof(log->rematch[0]));
+    std::memset(log->conv, 0, rows * sizeof(log->conv[0]));
+    std::memset(log->total_residual, 0, rows * sizeof(log->total_residual[0]));
+    std::memset(log->solution, 0, rows * sizeof(log->solution[0]));
+}
+}  // namespace
+
 int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double x_prop[S2M_STATE_DOUBLES],
                                 double P[S2M_DIM * S2M_DIM], s2m_iter_log *log, double *d_block,
                                 s2m_allreduce_fn reduce, void *user)
@@ -953,16 +1024,9 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
     const int max_iter = e->cfg.max_iter;
     int rematch_num = 0, rematch_en = 0, it = 0, passes = 0;
     int32_t conv = 0, stop = 0;
-    if (log) {  // header fields + the rows this call can write (the struct holds 64 rows, 13 KB)
-        log->iters = log->rematch_passes = log->converged = log->ekf_stop = 0;
-        const size_t rows = (size_t)std::min(max_iter, 64);
-        std::memset(log->effct, 0, rows * sizeof(log->effct[0]));
-        std::memset(log->rematch, 0, rows * sizeof(log->rematch[0]));
-        std::memset(log->conv, 0, rows * sizeof(log->conv[0]));
-        std::memset(log->total_residual, 0, rows * sizeof(log->total_residual[0]));
-        std::memset(log->solution, 0, rows * sizeof(log->solution[0]));
-    }
+    reset_log(log, max_iter);
     static const bool tl = std::getenv("S2M_HOST_TIMELINE") != nullptr;  // dev probe: host-side timings
+    double t_solve_us = 0.0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::micro>(b - a).count();
@@ -974,6 +1038,15 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         const bool collective = !reduce && e->comm.handle;  // built-in RCCL sum of the block before the hand-off
         int rc = run_pass(e, x, rematch, d_block, collective);
         if (rc) return rc;
+        if (it == 0) {
+            // (state.cov / LASER_POINT_COV).inverse() (:1017) depends on the covariance alone: 8 us of host LU that
+            // run here, behind the launch of the first pass, instead of after its block has arrived
+            Mat24 Pm;
+            std::memcpy(Pm.data(), P, sizeof(double) * S2M_DIM * S2M_DIM);
+            EskfParams prm;
+            prm.laser_point_cov = e->cfg.laser_point_cov;
+            (void)eskf_prepare(prm, Pm, e->work);  // a singular P is reported by the update itself
+        }
         const auto t_b = now();
         if (reduce && reduce(user) != 0) return fail(e, S2M_ERR_HIP, "all-reduce callback failed");
         const double *hb = nullptr;
@@ -999,48 +1072,14 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         if (rc) return rc;
         rc = finish_timing(e);
         if (rc) return rc;
-        const double *HtH = hb, *Htz = hb + 144;
-        const int32_t effct = (int32_t)hb[156];
-        const double total_res = hb[157];
-        // degeneracy queue (:899-918)
-        e->queue[e->queue_len++] = effct;
-        if (e->queue_len > S2M_FEAT_QUEUE) {
-            std::memmove(e->queue, e->queue + 1, sizeof(int32_t) * S2M_FEAT_QUEUE);
-            e->queue_len = S2M_FEAT_QUEUE;
-        }
-        stop = 0;
-        for (int q = 0; q < e->queue_len; ++q)
-            if (e->queue[q] <= e->cfg.feat_threshold) { stop = 1; break; }
-        double sol[S2M_DIM] = {0};
-        if (!stop) {  // flg_EKF_inited is always true (INIT_TIME == 0, :75,:762)
-            rc = s2m_eskf_update(e, x, x_prop, P, HtH, Htz, sol, &conv);
-            if (rc) return rc;
-        }
+        IterCtl ctl{it, rematch, rematch_num, rematch_en, conv, stop};
+        bool finished = false;
+        rc = consume_block(e, hb, ctl, x, x_prop, P, log, finished, tl ? &t_solve_us : nullptr);
+        rematch_num = ctl.rematch_num; rematch_en = ctl.rematch_en; conv = ctl.conv; stop = ctl.stop;
+        if (rc) return rc;
         if (tl) std::fprintf(stderr, "[s2m timeline] it %d rematch %d: launch %.1f us, wait %.1f us, solve %.1f us\n", it,
-                             rematch, us(t_a, t_b), us(t_b, t_c), us(t_c, now()));
-        if (log) {
-            log->effct[it] = effct;
-            log->rematch[it] = rematch;
-            log->conv[it] = conv;
-            log->total_residual[it] = total_res;
-            std::memcpy(log->solution[it], sol, sizeof(sol));
-        }
-        rematch_en = 0;  // rematch judgement (:1070-1076)
-        if (conv || (rematch_num == 0 && it == max_iter - 2)) {
-            rematch_en = 1;
-            rematch_num++;
-        }
-        if (rematch_num >= 2 || it == max_iter - 1) {  // :1079-1094
-            if (!stop) {
-                rc = s2m_cov_update(e, P);
-                if (rc) return rc;
-            }
-            ++it;
-            break;
-        } else if (stop) {  // :1095-1101
-            ++it;
-            break;
-        }
+                             rematch, us(t_a, t_b), us(t_b, t_c), t_solve_us);
+        if (finished) { ++it; break; }
     }
     if (log) {
         log->iters = it;
@@ -1055,6 +1094,103 @@ int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double
                         double P[S2M_DIM * S2M_DIM], s2m_iter_log *log)
 {
     return s2m_iterated_update_sharded(e, x, x_prop, P, log, nullptr, nullptr, nullptr);
+}
+
+// K scans in flight on one GPU from ONE host thread (BASELINE configs[4] on a single device): every handle keeps its
+// own stream and per-scan state and the same loop as s2m_iterated_update, but the host never sits in one handle's
+// wait -- it goes round the handles, picks up whichever block has arrived, solves, and launches that handle's next
+// pass, so the kernels of different scans fill each other's latency gaps (a single scan in flight leaves the GPU
+// idle during every host turn-around and most of every latency-bound kernel).
+int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, const double *x_prop, double *P,
+                              s2m_iter_log *logs)
+{
+    if (!handles || k < 1 || k > 256 || !x || !x_prop || !P) return S2M_ERR_ARG;
+    struct Slot {
+        IterCtl c{0, 1, 0, 0, 0, 0};
+        int passes = 0;
+        bool active = true;
+        unsigned long long seq = 0;
+        bool timed = false;
+        int evset = 0;
+    };
+    Slot slots[256];
+    auto xk = [&](int i) { return x + (size_t)i * S2M_STATE_DOUBLES; };
+    auto xpk = [&](int i) { return x_prop + (size_t)i * S2M_STATE_DOUBLES; };
+    auto Pk = [&](int i) { return P + (size_t)i * S2M_DIM * S2M_DIM; };
+    for (int i = 0; i < k; ++i) {
+        s2m_engine *e = handles[i];
+        if (!e) return S2M_ERR_ARG;
+        for (int j = 0; j < i; ++j)
+            if (handles[j] == e) return fail(e, S2M_ERR_ARG, "s2m_iterated_update_batch: a handle appears twice");
+        if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
+        if (e->comm.handle || !e->host_poll) return fail(e, S2M_ERR_STATE, "s2m_iterated_update_batch: single-GPU handles with the host-polled block only");
+    }
+    auto launch = [&](int i) -> int {
+        s2m_engine *e = handles[i];
+        Slot &s = slots[i];
+        s.c.rematch = (s.c.it == 0) || s.c.rematch_en;  // :847
+        s.passes += s.c.rematch;
+        int rc = run_pass(e, xk(i), s.c.rematch, e->d_block);
+        if (rc) return rc;
+        s.seq = e->seq;
+        s.timed = e->timed_this_pass;
+        if (s.c.it == 0) {  // (P/R)^-1 behind the launch of the first pass, see s2m_iterated_update_sharded
+            Mat24 Pm;
+            std::memcpy(Pm.data(), Pk(i), sizeof(double) * S2M_DIM * S2M_DIM);
+            EskfParams prm;
+            prm.laser_point_cov = e->cfg.laser_point_cov;
+            (void)eskf_prepare(prm, Pm, e->work);
+        }
+        return S2M_OK;
+    };
+    for (int i = 0; i < k; ++i) {
+        s2m_engine *e = handles[i];
+        S2M_HIP(e, hipSetDevice(e->device));
+        e->nn_valid = false;
+        reset_log(logs ? logs + i : nullptr, e->cfg.max_iter);
+        int rc = launch(i);
+        if (rc) return rc;
+    }
+    int active = k;
+    long idle_spins = 0;
+    while (active > 0) {
+        bool progress = false;
+        for (int i = 0; i < k; ++i) {
+            Slot &s = slots[i];
+            if (!s.active) continue;
+            s2m_engine *e = handles[i];
+            volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(e->h_block + S2M_BLOCK_DOUBLES);
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != s.seq) continue;
+            progress = true;
+            int rc = finish_timing(e);
+            if (rc) return rc;
+            bool finished = false;
+            rc = consume_block(e, e->h_block, s.c, xk(i), xpk(i), Pk(i), logs ? logs + i : nullptr, finished, nullptr);
+            if (rc) return rc;
+            ++s.c.it;
+            if (finished) {
+                s.active = false;
+                --active;
+                if (logs) {
+                    logs[i].iters = s.c.it;
+                    logs[i].rematch_passes = s.passes;
+                    logs[i].converged = s.c.conv;
+                    logs[i].ekf_stop = s.c.stop;
+                }
+            } else {
+                rc = launch(i);
+                if (rc) return rc;
+            }
+        }
+        if (progress) { idle_spins = 0; continue; }
+        __builtin_ia32_pause();
+        if (++idle_spins > 200000000L) {  // a kernel failed: let the runtime say which
+            for (int i = 0; i < k; ++i)
+                if (slots[i].active) S2M_HIP(handles[i], hipStreamSynchronize(handles[i]->stream));
+            return fail(handles[0], S2M_ERR_HIP, "s2m_iterated_update_batch: a pass did not publish its block");
+        }
+    }
+    return S2M_OK;
 }
 
 int s2m_comm_unique_id(uint8_t id[S2M_COMM_ID_BYTES])

@@ -172,24 +172,31 @@ Vec24 boxminus(const State &a, const State &b)
     return o;
 }
 
+bool eskf_prepare(const EskfParams &p, const Mat24 &P, EskfWork &work)
+{
+    constexpr int N = kDim;
+    if (work.pinv_valid && work.Rkey == p.laser_point_cov &&
+        std::memcmp(work.Pkey.data(), P.data(), sizeof(double) * N * N) == 0)
+        return true;
+    Mat24 S;
+    for (int i = 0; i < N * N; ++i) S[i] = P[i] / p.laser_point_cov;
+    Lu24 f;
+    work.pinv_valid = false;
+    if (!lu_factor(S, f)) return false;                            // (state.cov / LASER_POINT_COV).inverse()
+    lu_inverse_24(f, work.Pinv.data());
+    work.Pkey = P;
+    work.Rkey = p.laser_point_cov;
+    work.pinv_valid = true;
+    return true;
+}
+
 bool eskf_update(const EskfParams &p, State &x, const State &x_prop, const Mat24 &P, const double HtH[144],
                  const double Htz[12], Vec24 &solution, bool &converged, EskfWork &work)
 {
     constexpr int N = kDim;
     work.valid = false;
     converged = false;
-    if (!work.pinv_valid || work.Rkey != p.laser_point_cov ||
-        std::memcmp(work.Pkey.data(), P.data(), sizeof(double) * N * N) != 0) {
-        Mat24 S;
-        for (int i = 0; i < N * N; ++i) S[i] = P[i] / p.laser_point_cov;
-        Lu24 f;
-        work.pinv_valid = false;
-        if (!lu_factor(S, f)) return false;                        // (state.cov / LASER_POINT_COV).inverse()
-        lu_inverse_24(f, work.Pinv.data());
-        work.Pkey = P;
-        work.Rkey = p.laser_point_cov;
-        work.pinv_valid = true;
-    }
+    if (!eskf_prepare(p, P, work)) return false;
     Mat24 A = work.Pinv;
     for (int r = 0; r < 12; ++r)
         for (int c = 0; c < 12; ++c) A[r * N + c] += HtH[r * 12 + c];    // + H_T_H (12x12 block)

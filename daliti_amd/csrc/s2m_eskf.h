@@ -47,6 +47,9 @@ struct EskfWork {
     bool pinv_valid = false;
 };
 
+// (P/R)^-1 for the given covariance into work (a no-op when work already holds it).  The covariance only changes at
+// the exit of the iterated update, so the engine calls this once per scan while the first pass runs on the GPU.
+bool eskf_prepare(const EskfParams &p, const Mat24 &P, EskfWork &work);
 // Returns false when a matrix is singular.  x is updated in place.
 bool eskf_update(const EskfParams &p, State &x, const State &x_prop, const Mat24 &P,
                  const double HtH[144], const double Htz[12], Vec24 &solution, bool &converged,

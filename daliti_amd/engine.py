@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "s2m_fov_segment", "s2m_fov_reset",
     "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
-    "s2m_iterated_update", "s2m_iterated_update_sharded", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
+    "s2m_iterated_update", "s2m_iterated_update_batch", "s2m_iterated_update_sharded", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
     "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats",
 ]
 
@@ -351,6 +351,23 @@ class Engine:
         arrays updated in place, log an IterLog instance; no conversions."""
         self._ck(self.lib.s2m_iterated_update(self.h, C.c_void_p(x.ctypes.data), C.c_void_p(x_prop.ctypes.data),
                                               C.c_void_p(P.ctypes.data), C.byref(log)))
+
+    @staticmethod
+    def iterated_update_batch(engines, x, x_prop, P, logs=None):
+        """k scans in flight on one GPU from this thread.  x (k, 36), x_prop (k, 36), P (k, 24, 24) float64
+        C-contiguous arrays, updated in place; logs: optional ctypes array (IterLog * k).  Returns logs."""
+        k = len(engines)
+        assert x.shape == (k, STATE_DOUBLES) and x_prop.shape == (k, STATE_DOUBLES) and P.shape == (k, DIM, DIM)
+        assert x.flags.c_contiguous and x_prop.flags.c_contiguous and P.flags.c_contiguous
+        hs = (C.c_void_p * k)(*[e.h for e in engines])
+        if logs is None:
+            logs = (IterLog * k)()
+        rc = engines[0].lib.s2m_iterated_update_batch(hs, C.c_int32(k), C.c_void_p(x.ctypes.data),
+                                                      C.c_void_p(x_prop.ctypes.data), C.c_void_p(P.ctypes.data), logs)
+        if rc != 0:
+            msgs = [e.lib.s2m_last_error(e.h).decode() for e in engines]
+            raise S2MError(rc, "%s (%s)" % (engines[0].lib.s2m_strerror(rc).decode(), "; ".join(m for m in msgs if m)))
+        return logs
 
     def iterated_update_sharded(self, x, x_prop, P, d_block_ptr, reduce_cb):
         """reduce_cb() must sum the device block across ranks on this handle's stream."""

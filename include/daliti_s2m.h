@@ -238,6 +238,15 @@ typedef struct {
 int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES],
                         const double x_prop[S2M_STATE_DOUBLES], double P[S2M_DIM * S2M_DIM],
                         s2m_iter_log *log);
+
+/* The same update for k scans at once on ONE GPU, driven by one host thread (BASELINE configs[4] --
+ * batched odometry -- on a single device): handles[i] holds scan i (its own s2m_scan_set; the map may be
+ * shared through s2m_map_share), x / x_prop are k x 36 doubles, P is k x 576, logs k records (optional).
+ * Every scan runs exactly the loop of s2m_iterated_update (results are identical); the host goes round the
+ * handles and serves whichever pass has finished, so the scans fill each other's latency gaps.  Handles
+ * must be distinct, on one device, without a communicator. */
+int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, const double *x_prop,
+                              double *P, s2m_iter_log *logs);
 /* Multi-GPU form: this handle holds a contiguous shard of the scan's points and the whole map.
  * After every pass the shard's block (S2M_BLOCK_DOUBLES doubles, layout as in
  * s2m_residual_pass_device) is in d_block, a DEVICE buffer the caller owns; reduce(user) must

@@ -232,3 +232,32 @@ def test_r1_reference_density_matches_oracle(c3, oracle):
     assert np.abs(r["x"][9:12] - ro["x"][9:12]).max() < 1e-9
     assert np.abs(oracle.so3_log(ro["x"][:9].reshape(3, 3).T @ r["x"][:9].reshape(3, 3))).max() < 1e-9
     e.close()
+
+
+def test_c5_batch_call_equals_one_by_one(c3, eng3):
+    """s2m_iterated_update_batch: four C5 replicas in flight from one host thread give, scan for scan, the very
+    bits that s2m_iterated_update gives one after the other (same kernels, same launch shapes, same host solve)."""
+    from daliti_amd import Engine, synth
+    from daliti_amd.engine import IterLog
+    K = 4
+    engs, xs, Ps = [], [], []
+    for k in range(K):
+        scan, pos = synth.replica_scan("C5", k)
+        _xt, x_prop, P = synth.filter_inputs(pos)
+        e = Engine(max_iter=5)
+        e.map_share(eng3)
+        e.scan_set(scan)
+        engs.append(e); xs.append(x_prop); Ps.append(P)
+    one = [e.iterated_update(x, x, P) for e, x, P in zip(engs, xs, Ps)]
+    for e in engs:
+        e.set_feat_queue(())
+    x = np.ascontiguousarray(np.stack(xs)); xp = x.copy(); P = np.ascontiguousarray(np.stack(Ps))
+    logs = Engine.iterated_update_batch(engs, x, xp, P)
+    for k in range(K):
+        assert logs[k].iters == one[k]["iters"] and logs[k].rematch_passes == one[k]["rematch_passes"]
+        assert list(logs[k].effct[:logs[k].iters]) == list(one[k]["effct"])
+        assert (bits(x[k]) == bits(one[k]["x"])).all() and (bits(P[k]) == bits(one[k]["P"])).all()
+    with pytest.raises(Exception):
+        Engine.iterated_update_batch([engs[0], engs[0]], x[:2].copy(), xp[:2].copy(), P[:2].copy())
+    for e in engs:
+        e.close()
