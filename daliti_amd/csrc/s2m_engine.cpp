@@ -81,6 +81,7 @@ struct s2m_engine {
 
     Pose last_pose{};
     uint32_t *d_hard = nullptr;   // hard list (n entries) followed by its counter
+    uint32_t *d_qheads = nullptr; // match_hard's dequeue heads (kQueueWords)
     float *d_wq = nullptr;        // world-frame query points of the hard list (3 x n_cap)
     uint32_t *d_dbg = nullptr;  // S2M_DEBUG_MATCH=1: per-point diagnostics of the match kernel
     bool dbg = false;
@@ -196,6 +197,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
         m.hard_list = e->d_hard; m.hard_count = e->d_hard + 3 * e->n_cap;
         m.wq = e->d_wq;
+        m.qheads = e->d_qheads;
         m.dbg = e->dbg ? e->d_dbg : nullptr;
         launch_match(m, e->match_group, e->stream);  // hard_count is zero: reset by every reduce launch
         e->nn_valid = true;
@@ -209,6 +211,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     r.plane = e->d_plane; r.flags = e->d_flags; r.sel = e->d_sel; r.eff = e->d_eff; r.pd2 = e->d_pd2;
     r.partials = e->d_partials; r.block = d_out;
     r.ticket = e->d_ticket; r.hard_count = e->d_hard + 3 * e->n_cap;
+    r.qheads = e->d_qheads;
     const bool publish = e->host_poll && d_out == e->d_block && !defer_publish;
     r.host_block = publish ? e->h_block_dev : nullptr;
     r.host_flag = publish ? reinterpret_cast<unsigned long long *>(e->h_block_dev + S2M_BLOCK_DOUBLES) : nullptr;
@@ -318,6 +321,8 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
     ok = ok && hipHostGetDevicePointer((void **)&e->h_block_dev, e->h_block, 0) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_ticket, kTicketWords * sizeof(uint32_t)) == hipSuccess &&
          hipMemset(e->d_ticket, 0, kTicketWords * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_qheads, kQueueWords * sizeof(uint32_t)) == hipSuccess &&
+         hipMemset(e->d_qheads, 0, kQueueWords * sizeof(uint32_t)) == hipSuccess;
     if (ok) std::memset(e->h_block, 0, (S2M_BLOCK_DOUBLES + 8) * sizeof(double));
     e->host_poll = std::getenv("S2M_NO_HOST_POLL") == nullptr;
     if (!ok) {
@@ -340,7 +345,7 @@ int s2m_destroy(s2m_engine *e)
     free_undist(e->und);
     comm_destroy(e->comm);
     void *ptrs[] = {e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
-                    e->d_nn_d2, e->d_hard, e->d_wq, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
+                    e->d_nn_d2, e->d_hard, e->d_qheads, e->d_wq, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_block) (void)hipHostFree(e->h_block);

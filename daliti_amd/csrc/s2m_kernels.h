@@ -111,6 +111,12 @@ hipError_t undistort(UndistBuffers &u, const float *pts, int64_t stride, int64_t
                      hipStream_t st);
 
 // ---- s2m_match.hip : exact 5-NN ------------------------------------------------------------------
+// match_hard hands its list out dynamically: every resident wave takes the point of its own index first, then pulls
+// further ones from one of kQueueShards heads (separate cache lines: one head would serialise at ~90 tickets per
+// microsecond).  The heads are zeroed by every reduce launch, like the list length.
+constexpr int kQueueShards = 64;
+constexpr int kQueueStride = 32;  // words (128 B)
+constexpr int kQueueWords = kQueueShards * kQueueStride;
 struct MatchArgs {
     Grid grid;
     Pose pose;
@@ -121,6 +127,7 @@ struct MatchArgs {
     float *nn_d2;        // n x 5 ascending, INFINITY = missing
     uint32_t *hard_list; // n entries of scratch: the points the first-shell kernel could not resolve
     uint32_t *hard_count; // its length (device counter, reset by every reduce launch)
+    uint32_t *qheads = nullptr;  // kQueueShards dequeue heads of match_hard's work queue, kQueueStride words apart
     float *wq = nullptr;      // 3 x n scratch: world-frame query point of every unresolved scan point (SoA)
     uint32_t *dbg = nullptr;  // optional diagnostics, 4 words per scan point
 };
@@ -151,6 +158,7 @@ struct ReduceArgs {
     double *block;     // S2M_BLOCK_DOUBLES output (device)
     uint32_t *ticket;  // arrival counters of the in-kernel final sum (kTicketWords words, zero before the first launch)
     uint32_t *hard_count;            // reset to 0 for the next rematch pass
+    uint32_t *qheads = nullptr;      // match_hard's dequeue heads, reset likewise
     double *host_block;              // optional: pinned host copy of block, device-visible pointer
     unsigned long long *host_flag;   // optional: set to seq (system scope) after host_block is written
     unsigned long long seq;

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
         __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
         if (a.hard_count) { a.hard_count[0] = 0u; a.hard_count[1] = 0u; a.hard_count[2] = 0u; }
     }
+    if (a.qheads && threadIdx.x < kQueueShards) a.qheads[threadIdx.x * kQueueStride] = 0u;
     if (a.host_flag) publish_flag(a.host_flag, a.seq);
 }
 
