@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the sharded/all-reduce code path even with one rank (test hook)")
     ap.add_argument("--replicas", type=int, default=0, help="C5: number of independent scans (default 8)")
+    ap.add_argument("--sort-scan", default="none", choices=["none", "morton"],
+                    help="experiment: hand the scan over in Morton order of 0.5 m body-frame cells instead of ring order")
     ap.add_argument("--sequential", action="store_true",
                     help="C5 on one GPU: serve the scans one after the other instead of through s2m_iterated_update_batch")
     return ap.parse_args()
@@ -142,6 +144,15 @@ def main():
         n_scan_total = len(scans[0][0])
     if not scans:
         raise SystemExit("rank %d has no scan to serve (more ranks than replicas)" % rank)
+    if a.sort_scan == "morton":
+        def morton_order(pts, cell=0.5):
+            q = np.floor((pts - pts.min(0)) / cell).astype(np.uint64)
+            code = np.zeros(len(pts), np.uint64)
+            for b in range(16):
+                for ax in range(3):
+                    code |= ((q[:, ax] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + ax)
+            return np.argsort(code, kind="stable")
+        scans = [(s[morton_order(s.astype(np.float64))], pos) for s, pos in scans]
     filt = [synth.filter_inputs(pos) for _, pos in scans]
     t_gen = time.time() - t0
 

@@ -517,6 +517,14 @@ __device__ __forceinline__ void consume_batch(const float4 (&p)[8], float wx, fl
         d = d + dz * dz;
         key[u] = make_key(d, map_point_index(p[u]));
     }
+#ifdef S2M_EXP_BATCH_REJECT
+    // experiment (DESIGN, rejected table): skip the 48-operation network when no lane of the wave holds a candidate
+    // closer than its current 5th best
+    bool better = false;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) better = better || key[u] < t[kK - 1];
+    if (!__any(better)) return;
+#endif
     insert_batch8(t, key);
 }
 

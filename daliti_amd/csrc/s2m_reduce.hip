@@ -177,7 +177,13 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
                 float nx[kK], ny[kK], nz[kK];
 #pragma unroll
                 for (int k = 0; k < kK; ++k) {
+#ifdef S2M_EXP_FIT_COALESCED
+                    // experiment (timing only, results are wrong): consecutive instead of gathered neighbours, to
+                    // bound what the five random 16-byte reads per point cost
+                    const float4 p = a.porig[(int64_t)i * kK + k + (ni[k] & 0)];
+#else
                     const float4 p = a.porig[ni[k]];
+#endif
                     nx[k] = p.x; ny[k] = p.y; nz[k] = p.z;
                 }
                 plane_ok = fit_plane(nx, ny, nz, a.gates.plane_thr, pl);
