@@ -1129,6 +1129,7 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
             if (handles[j] == e) return fail(e, S2M_ERR_ARG, "s2m_iterated_update_batch: a handle appears twice");
         if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
         if (e->comm.handle || !e->host_poll) return fail(e, S2M_ERR_STATE, "s2m_iterated_update_batch: single-GPU handles with the host-polled block only");
+        if (e->device != handles[0]->device) return fail(e, S2M_ERR_ARG, "s2m_iterated_update_batch: handles on different devices");
     }
     auto launch = [&](int i) -> int {
         s2m_engine *e = handles[i];

@@ -152,6 +152,29 @@ def test_group_width_invariance(eng, small_scene, group):
     e.close()
 
 
+@pytest.mark.parametrize("var,val", [("S2M_EASY_NB", "1"), ("S2M_EASY_NB", "2"), ("S2M_EASY_CELLS", "1")])
+def test_first_shell_kernel_variants(eng, small_scene, var, val):
+    """The row-run search with one / two batches per trip (default three) and the round-1 per-cell form of the
+    first-shell kernel return the identical neighbours and block."""
+    from daliti_amd import Engine
+    x = small_scene["x_prop"]
+    eng.scan_set(small_scene["scan"])
+    ref_out = eng.residual_pass(x, True)
+    ref_idx, ref_d2 = eng.get_neighbors()
+    os.environ[var] = val
+    try:
+        e = Engine()
+    finally:
+        del os.environ[var]
+    e.map_build(small_scene["map"])
+    e.scan_set(small_scene["scan"])
+    out = e.residual_pass(x, True)
+    idx, d2 = e.get_neighbors()
+    assert (idx == ref_idx).all() and (bits(d2) == bits(ref_d2)).all()
+    assert (bits(out["HtH"]) == bits(ref_out["HtH"])).all()
+    e.close()
+
+
 def test_wide_address_path(eng, small_scene):
     """Maps beyond 2^28 points address the sorted array with 64-bit pointers; force that code path on a
     small map (S2M_WIDE_ADDR=1) and require the identical result."""
