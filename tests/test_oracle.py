@@ -216,3 +216,19 @@ def test_s_gate_is_a_float_compare(oracle):
     assert want.sum() > 100 and (~want).sum() > 100
     assert (ps.selected.astype(bool) == want).all()
     assert not ps.selected[edge].any() and not ps.eff[edge].any()
+
+
+def test_kdtree_matches_scipy_ckdtree_at_scale(oracle):
+    """An independent exact k-NN (scipy's cKDTree, float64 arithmetic on the same float32 coordinates) on a
+    100,000-point surface map: same neighbour sets wherever the five distances are distinct in float32."""
+    from scipy.spatial import cKDTree
+    from daliti_amd import synth
+    m = synth.make_map(100_000, seed=5)
+    q = synth.make_scan(16, 625, synth.side_for_points(100_000), seed=6) + np.float32([0.0, 0.0, 1.5])
+    i1, d1, c1 = oracle.KdTree(m).knn5(q.astype(np.float32))
+    dd, ii = cKDTree(m.astype(np.float64)).query(q.astype(np.float64), k=5)
+    assert (c1 == 5).all()
+    distinct = (np.diff(d1, axis=1) > 0).all(1)
+    assert distinct.mean() > 0.99
+    assert (np.sort(i1[distinct], 1) == np.sort(ii[distinct], 1)).all()
+    assert np.abs(np.sqrt(d1.astype(np.float64)) - dd).max() < 1e-5
