@@ -626,16 +626,23 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
     // First the two prefix words that delimit each surviving piece (all requested together), then the list.
     nr = 0;
     uint32_t sA[9], eA[9], sB[9], eB[9];
+    // squared per-axis gaps to the neighbouring cells, once: cell_bound2(dx, dy, dz) = ((gx2 + gy2) + gz2) * c^2 * 0.99999
+    // with exactly the products and sums of that function (24 bounds from 9 squares instead of 24 x 3)
+    const float gxm = fmaxf(q.frx - g.slop, 0.0f), gxp = fmaxf((1.0f - q.frx) - g.slop, 0.0f);
+    const float gym = fmaxf(q.fry - g.slop, 0.0f), gyp = fmaxf((1.0f - q.fry) - g.slop, 0.0f);
+    const float gzm = fmaxf(q.frz - g.slop, 0.0f), gzp = fmaxf((1.0f - q.frz) - g.slop, 0.0f);
+    const float gx2[3] = {gxm * gxm, 0.0f, gxp * gxp}, gy2[3] = {gym * gym, 0.0f, gyp * gyp}, gz2[3] = {gzm * gzm, 0.0f, gzp * gzp};
+    const float cc = g.c * g.c;
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
         sA[r] = eA[r] = sB[r] = eB[r] = 0u;
         if (r == 4) continue;
-        const int dy = (r % 3) - 1, dz = (r / 3) - 1;
+        const float gyz0 = gy2[r % 3];  // dy = r % 3 - 1, dz = r / 3 - 1
         // the cell bound grows with |dx|: the cells that survive are a contiguous range around dx = 0
-        if (have_tau && cell_bound2(g, q, 0, dy, dz) > tau) continue;
+        if (have_tau && ((gx2[1] + gyz0) + gz2[r / 3]) * cc * 0.99999f > tau) continue;
         int xa = q.cx, xb = q.cx;
-        if (!(have_tau && cell_bound2(g, q, -1, dy, dz) > tau)) xa = q.cx - 1;
-        if (!(have_tau && cell_bound2(g, q, 1, dy, dz) > tau)) xb = q.cx + 1;
+        if (!(have_tau && ((gx2[0] + gyz0) + gz2[r / 3]) * cc * 0.99999f > tau)) xa = q.cx - 1;
+        if (!(have_tau && ((gx2[2] + gyz0) + gz2[r / 3]) * cc * 0.99999f > tau)) xb = q.cx + 1;
         const int la = max(xa, x_lo), ha = min(xb, ax1);  // piece inside segment A
         if (idA[r] && la <= ha) {
             const uint32_t *tb = g.tab + (int64_t)(idA[r] - 1) * kBrickStride + (rowbit[r] << 3);
