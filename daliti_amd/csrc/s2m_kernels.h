@@ -125,8 +125,8 @@ struct MatchArgs {
     int n;
     int32_t *nn_idx;     // n x 5, index into the caller's map array, -1 = missing
     float *nn_d2;        // n x 5 ascending, INFINITY = missing
-    uint32_t *hard_list; // n entries of scratch: the points the first-shell kernel could not resolve
-    uint32_t *hard_count; // its length (device counter, reset by every reduce launch)
+    uint32_t *hard_list; // 2 x n entries of scratch: the points the first-shell kernel could not resolve, without / with a radius
+    uint32_t *hard_count; // the two lengths (device counters, reset by every reduce launch)
     uint32_t *qheads = nullptr;  // kQueueShards dequeue heads of match_hard's work queue, kQueueStride words apart
     float *wq = nullptr;      // 3 x n scratch: world-frame query point of every unresolved scan point (SoA)
     uint32_t *dbg = nullptr;  // optional diagnostics, 4 words per scan point

@@ -443,7 +443,10 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
     // 5th-best distance; unknown when fewer than five were found): match_hard starts the expensive ones
     // first so they do not form the tail of the launch.  One atomic per wave and list: same-address
     // atomics serialise in L2 (~90 per microsecond), ten thousand per-lane atomics would cost > 100 us.
-    append_list(a.hard_list, a.hard_count, j == 0 && !done, (uint32_t)qi);  // unresolved: match_hard's list
+    // unresolved: match_hard's list, in two parts -- the points without a radius (fewer than five neighbours in the
+    // shell: two rounds there, ~11 us against ~5.5 us) are handed out first so that they do not form the launch's tail
+    append_list(a.hard_list, a.hard_count, j == 0 && !done && !found5, (uint32_t)qi);
+    append_list(a.hard_list + (int64_t)a.n, a.hard_count + 1, j == 0 && !done && found5, (uint32_t)qi);
     if (j == 0) {
         // unresolved points keep their first-shell list too: match_hard takes its radius from it, and its
         // query point from here (the pose alone is 48 SGPRs that kernel would spill around every point)
@@ -665,7 +668,10 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
     const bool found5 = !is_empty(best[kK - 1]);
     const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
     const bool done = found5 && d5 <= cube_bound2(g, q, 1);
-    append_list(a.hard_list, a.hard_count, j == 0 && !done, (uint32_t)qi);  // unresolved: match_hard's list
+    // unresolved: match_hard's list, in two parts -- the points without a radius (fewer than five neighbours in the
+    // shell: two rounds there, ~11 us against ~5.5 us) are handed out first so that they do not form the launch's tail
+    append_list(a.hard_list, a.hard_count, j == 0 && !done && !found5, (uint32_t)qi);
+    append_list(a.hard_list + (int64_t)a.n, a.hard_count + 1, j == 0 && !done && found5, (uint32_t)qi);
     if (j == 0) {
         store_result(best, qi, a.nn_idx, a.nn_d2);
         if (!done) { a.wq[qi] = q.wx; a.wq[(int64_t)a.n + qi] = q.wy; a.wq[2 * (int64_t)a.n + qi] = q.wz; }
@@ -735,8 +741,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int nwaves = (gridDim.x * blockDim.x) >> 6;
-    const uint32_t count = a.hard_count[0];
-    const uint32_t *__restrict__ hlist = a.hard_list;
+    const uint32_t c0 = a.hard_count[0], count = c0 + a.hard_count[1];  // [no radius yet | radius known]
     // brick rings needed so that the neighbourhood covers the gate radius from anywhere in the home brick
     const float gate_r = sqrtf(a.gates.knn_d2_gate);
     const int NB = max(1, (int)ceilf(gate_r * g.inv_c * 0.125f + 1e-3f));
@@ -757,7 +762,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
     uint32_t h = (uint32_t)wave;
     while (h < count) {
         const long long t0 = a.dbg ? wall_clock64() : 0;
-        const int qi = (int)hlist[h];
+        const int qi = (int)(h < c0 ? a.hard_list[h] : a.hard_list[(int64_t)a.n + (h - c0)]);
         const Query q = query_at(g, a.wq[qi], a.wq[(int64_t)a.n + qi], a.wq[2 * (int64_t)a.n + qi]);
         const float fxq = (float)q.cx + q.frx;  // query x in cell units
         // radius: the first shell's 5th-best distance when it found five (then one round is exact)
