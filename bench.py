@@ -58,7 +58,8 @@ def parse():
                     help="sharded mode only; auto: strong for C4 (BASELINE configs[3]), weak otherwise")
     ap.add_argument("--max-iter", type=int, default=5)
     ap.add_argument("--cell", type=float, default=0.0)
-    ap.add_argument("--cpu-steps", type=int, default=8, help="CPU baseline sample: iterated updates (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=32,
+                    help="CPU baseline sample: iterated updates of the same scan, 1 thread (0 = skip); 32 is ~7 s at C3")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing)")
