@@ -56,14 +56,88 @@ __device__ __forceinline__ void halve_step(double (&v)[32], int lane)
         v[i] = keep + __shfl_xor(send, m, 64);
     }
 }
+// The two widest steps (partner lane ^ 32 and lane ^ 16: 24 of the 32 exchanges) with gfx950's v_permlane32_swap /
+// v_permlane16_swap: one VALU instruction exchanges the upper half (the odd 16-lane rows) of one register with the
+// lower half (the even rows) of another, which IS the keep / send pattern of a halving step -- no selects, no trip
+// through the LDS crossbar (ds_bpermute), and the sums are the same two operands as before (bit-identical results).
+// Measured on the last workgroup of the reuse-pass kernel: butterfly + LDS stage 2.4 us with shuffles.
+template <int M>
+__device__ __forceinline__ double swap_add(double x, double y)
+{
+    const uint32_t xl = (uint32_t)__double_as_longlong(x), xh = (uint32_t)((unsigned long long)__double_as_longlong(x) >> 32);
+    const uint32_t yl = (uint32_t)__double_as_longlong(y), yh = (uint32_t)((unsigned long long)__double_as_longlong(y) >> 32);
+    uint32_t al, bl, ah, bh;
+    if (M == 32) {
+        const auto l = __builtin_amdgcn_permlane32_swap(xl, yl, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(xh, yh, false, false);
+        al = l[0]; bl = l[1]; ah = h[0]; bh = h[1];
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap(xl, yl, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(xh, yh, false, false);
+        al = l[0]; bl = l[1]; ah = h[0]; bh = h[1];
+    }
+    const double a = __longlong_as_double((long long)(((unsigned long long)ah << 32) | al));
+    const double b = __longlong_as_double((long long)(((unsigned long long)bh << 32) | bl));
+    return a + b;  // lanes with bit M clear: x[l] + x[l ^ M]; with bit M set: y[l ^ M] + y[l]
+}
+template <int HALF>
+__device__ __forceinline__ void halve_step_swap(double (&v)[32])
+{
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) v[i] = swap_add<HALF * 2>(v[i], v[i + HALF]);
+}
+
+// The narrow steps (partner lane ^ 8, ^ 4, ^ 2, ^ 1) stay inside a 16-lane row, where DPP moves reach: row_ror:8 is
+// lane ^ 8; lane ^ 4 is row_ror:4 for the banks whose lanes have bit 2 set and row_ror:12 for the others (bank masks);
+// quad_perm covers ^ 2 and ^ 1.  Same operands and sums as the shuffle form.
+template <int M>
+__device__ __forceinline__ uint32_t dpp_xor(uint32_t v)
+{
+    if (M == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);          // row_ror:8
+    if (M == 4) {
+        const int a = __builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xa, false);                      // row_ror:4 -> banks 1, 3: lane - 4
+        return (uint32_t)__builtin_amdgcn_update_dpp(a, (int)v, 0x12c, 0xf, 0x5, false);                    // row_ror:12 -> banks 0, 2: lane + 4
+    }
+    if (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);            // quad_perm [2,3,0,1]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);                          // quad_perm [1,0,3,2]
+}
+template <int M>
+__device__ __forceinline__ double dpp_xor(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = dpp_xor<M>((uint32_t)b), hi = dpp_xor<M>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int HALF>
+__device__ __forceinline__ void halve_step_dpp(double (&v)[32], int lane)
+{
+    constexpr int m = HALF * 2;
+    const bool hi = (lane & m) != 0;
+#pragma unroll
+    for (int i = 0; i < HALF; ++i) {
+        const double send = hi ? v[i] : v[i + HALF];
+        const double keep = hi ? v[i + HALF] : v[i];
+        v[i] = keep + dpp_xor<m>(send);
+    }
+}
+
 __device__ __forceinline__ void wave_sum32(double (&v)[32], int lane)
 {
+#ifdef S2M_EXP_SHUFFLE_BUTTERFLY
     halve_step<16>(v, lane);
     halve_step<8>(v, lane);
     halve_step<4>(v, lane);
     halve_step<2>(v, lane);
     halve_step<1>(v, lane);
     v[0] += __shfl_xor(v[0], 1, 64);
+#else
+    halve_step_swap<16>(v);
+    halve_step_swap<8>(v);
+    halve_step_dpp<4>(v, lane);
+    halve_step_dpp<2>(v, lane);
+    halve_step_dpp<1>(v, lane);
+    v[0] += dpp_xor<1>(v[0]);
+#endif
 }
 
 // compile-time (row, column) of upper-triangle slot t
@@ -141,9 +215,21 @@ __device__ __forceinline__ void pin(T &v)
     asm volatile("" : "+v"(v));
 }
 
+#ifdef S2M_EXP_REDUCE_TIMELINE
+// experiment: stage stamps (100 MHz wall clock) of thread 0 of the LAST workgroup, packed 12 bits each into the two
+// free slots of the block (read with s2m_residual_pass_device; scripts/reduce_timeline.py)
+#define S2M_STAMP(k) do { if (threadIdx.x == 0) tl_[k] = wall_clock64(); } while (0)
+#else
+#define S2M_STAMP(k) do { } while (0)
+#endif
+
 template <bool EXT, bool FIT>
 __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
 {
+#ifdef S2M_EXP_REDUCE_TIMELINE
+    long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    S2M_STAMP(0);
     constexpr int NC = EXT ? 12 : 6;
     using T = Terms<NC>;
     __shared__ double red[kRedBlock / 64][T::kSlots];
@@ -200,6 +286,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
             sel = (uint8_t)s32;
             fl = (uint8_t)f32;
         }
+        S2M_STAMP(1);
         if (sel) {
             uint8_t sel_new = 0;  // sticky: only fit-ok + s-gate re-selects (:862,:873)
             if (fl & kFlagPlane) {
@@ -227,6 +314,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
     }
     // ineffective lanes carry h = 0, z = 0 and contribute exact zeros.  Terms are reduced 32 at a
     // time; term index within a chunk = compile-time slot, so everything stays in registers.
+    S2M_STAMP(2);
     double hz[12];
 #pragma unroll
     for (int r = 0; r < 12; ++r) hz[r] = h[r] * z;
@@ -253,6 +341,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
         if ((lane & 1) == 0) red[wave][chunk * 32 + ((lane >> 1) & 31)] = v[0];
     }
     __syncthreads();
+    S2M_STAMP(3);
     // one fp64 row per workgroup, published write-through (agent-scope 8-byte stores) so the last
     // workgroup to arrive can read every row without a release/acquire fence pair
     if (threadIdx.x < T::kSlots) {
@@ -265,6 +354,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
     __syncthreads();
+    S2M_STAMP(4);
     __shared__ uint32_t s_last;
     if (threadIdx.x == 0) {
         // Two-level arrival count: same-address atomics serialise in L2 (~11 ns each), so 128 workgroups on
@@ -283,6 +373,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
     }
     __syncthreads();
     if (!s_last) return;
+    S2M_STAMP(5);
 
     // ---- last workgroup: fixed-order sum of the rows (independent of arrival order) -----------------
     constexpr int kChunks = kRedBlock / T::kSlots;  // lanes per term: 16 (NC = 6) or 5 (NC = 12)
@@ -318,6 +409,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
         tot[threadIdx.x] = s;
     }
     __syncthreads();
+    S2M_STAMP(6);
     if (threadIdx.x < 160) {
         const int o = threadIdx.x;
         double v = 0.0;
@@ -341,6 +433,17 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
     }
     if (a.qheads && threadIdx.x < kQueueShards) a.qheads[threadIdx.x * kQueueStride] = 0u;
     if (a.host_flag) publish_flag(a.host_flag, a.seq);
+#ifdef S2M_EXP_REDUCE_TIMELINE
+    if (threadIdx.x == 0) {
+        const long long t7 = wall_clock64();
+        unsigned long long lo = 0, hi = 0;
+        for (int k = 1; k <= 4; ++k) lo |= (unsigned long long)((tl_[k] - tl_[k - 1]) & 0xfff) << (12 * (k - 1));
+        hi = (unsigned long long)((tl_[5] - tl_[4]) & 0xfff) | ((unsigned long long)((tl_[6] - tl_[5]) & 0xfff) << 12) |
+             ((unsigned long long)((t7 - tl_[6]) & 0xfff) << 24);
+        a.block[158] = (double)lo;
+        a.block[159] = (double)hi;
+    }
+#endif
 }
 
 // after a collective: copy the summed block to pinned host memory and raise the sequence flag
