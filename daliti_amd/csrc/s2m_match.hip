@@ -249,6 +249,12 @@ __device__ __forceinline__ u64 group_min_u64(u64 v)
         const uint32_t ml = (G == 64) ? wave_min_u32(lo2) : quad_min_u32(lo2);
         return ((u64)mh << 32) | (u64)ml;
     }
+    if (G == 2) {  // the partner is lane ^ 1: one quad_perm DPP move per word instead of a trip through ds_bpermute
+        const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0xB1, 0xf, 0xf, false);
+        const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0xB1, 0xf, 0xf, false);
+        const u64 o = ((u64)oh << 32) | (u64)ol;
+        return o < v ? o : v;
+    }
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) {
         const u64 o = __shfl_xor(v, off, G);
