@@ -544,17 +544,28 @@ struct RunCursor {
     uint32_t k, i, e;
 };
 
+#ifdef S2M_EXP_ROWS_TIMELINE
+// experiment: a stamp that waits for `dep` (a value that depends on the stage's loads) before reading the clock
+#define S2M_ROWS_STAMP(k, dep) do { auto d_ = (dep); asm volatile("" : "+v"(d_)); st_[k] = wall_clock64(); } while (0)
+#else
+#define S2M_ROWS_STAMP(k, dep) do { } while (0)
+#endif
+
 template <int G, bool WIDE, int NB>
 __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
 {
     __shared__ uint2 runs[kRunSlots * 256];  // [slot][thread]: conflict-free whatever the per-lane fill
     const long long t0 = a.dbg ? wall_clock64() : 0;
+#ifdef S2M_EXP_ROWS_TIMELINE
+    long long st_[4] = {0, 0, 0, 0};
+#endif
     const Grid &g = a.grid;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int qi = tid / G;
     const int j = tid % G;
     if (qi >= a.n) return;  // group-uniform
     const Query q = make_query(g, a.pose, a.sx[qi], a.sy[qi], a.sz[qi]);
+    S2M_ROWS_STAMP(0, q.cx);
     // x extent of the neighbourhood inside the grid; segment A lies in brick bA, segment B (if any) in bA + 1
     const int x_lo = max(q.cx - 1, 0), x_hi = min(q.cx + 1, g.ncx - 1);
     const bool xok = x_lo <= x_hi;
@@ -577,6 +588,14 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
         if (ok) idA[r] = g.top[toprow + bA].x;
         if (ok && split) idB[r] = g.top[toprow + bB].x;
     }
+#ifdef S2M_EXP_ROWS_TIMELINE
+    {
+        uint32_t all = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) all |= idA[r] | idB[r];
+        S2M_ROWS_STAMP(1, all);
+    }
+#endif
     // phase 2: the home row's prefix words (four consecutive words cover its three cells); the other rows' words are
     // fetched after the home row has produced a bound -- only for the rows and cells that survive it
     TabQuad qa4 = TabQuad{{0u, 0u, 0u, 0u}}, qb4 = TabQuad{{0u, 0u, 0u, 0u}};
@@ -631,6 +650,7 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
     merge_lists<G>(t, best);
     const bool have_tau = !is_empty(best[kK - 1]);
     const float tau = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
+    S2M_ROWS_STAMP(2, tau);
     // phase 3b: the other rows, trimmed to the cells that can hold something closer than tau, as one work list.
     // First the two prefix words that delimit each surviving piece (all requested together), then the list.
     nr = 0;
@@ -652,6 +672,8 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
         int xa = q.cx, xb = q.cx;
         if (!(have_tau && ((gx2[0] + gyz0) + gz2[r / 3]) * cc * 0.99999f > tau)) xa = q.cx - 1;
         if (!(have_tau && ((gx2[2] + gyz0) + gz2[r / 3]) * cc * 0.99999f > tau)) xb = q.cx + 1;
+        // (two dword loads per piece; one 4-byte-aligned dwordx4 covering both words measured slower: 3.0 vs 2.6 us
+        // for this stage)
         const int la = max(xa, x_lo), ha = min(xb, ax1);  // piece inside segment A
         if (idA[r] && la <= ha) {
             const uint32_t *tb = g.tab + (int64_t)(idA[r] - 1) * kBrickStride + (rowbit[r] << 3);
@@ -669,6 +691,7 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
         push_run(sA[r], eA[r]);
         push_run(sB[r], eB[r]);
     }
+    S2M_ROWS_STAMP(3, nr);
     walk_runs();
     merge_lists<G>(t, best);
     const bool found5 = !is_empty(best[kK - 1]);
@@ -686,6 +709,11 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
             a.dbg[4 * (int64_t)qi + 1] = done ? 1u : 0u;
             a.dbg[4 * (int64_t)qi + 2] = 0;
             a.dbg[4 * (int64_t)qi + 3] = 1;
+#ifdef S2M_EXP_ROWS_TIMELINE
+            // stage stamps relative to the kernel's first instruction of this wave, 16 bits each (100 MHz ticks)
+            a.dbg[4 * (int64_t)qi + 2] = (uint32_t)((st_[0] - t0) & 0xffff) | ((uint32_t)((st_[1] - t0) & 0xffff) << 16);
+            a.dbg[4 * (int64_t)qi + 3] = (uint32_t)((st_[2] - t0) & 0xffff) | ((uint32_t)((st_[3] - t0) & 0xffff) << 16);
+#endif
         }
     }
 }
