@@ -60,6 +60,9 @@ constexpr int kEasyBatch = S2M_EASY_BATCH;  // point loads in flight per lane in
 #define S2M_HARD_BATCH 8
 #endif
 constexpr int kHardBatch = S2M_HARD_BATCH;  // same for the one-cell-per-lane kernel
+#ifndef S2M_HARD_BAND
+#define S2M_HARD_BAND 1.7f  // first band of match_hard in cells (measured sweeps in DESIGN.md)
+#endif
 
 __device__ __forceinline__ void append_list(uint32_t *__restrict__ list, uint32_t *__restrict__ counter, bool want,
                                             uint32_t value);
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(256) void match_hard(MatchArgs a)
         for (int k = 0; k < kK; ++k) { t[k] = kEmptyKey; best[k] = kEmptyKey; }
         // band radius while no radius is known: the first shell covered (1 + fmin) c; 1.7 c measured best at C3
         // (1.3 / 1.5 / 1.7 / 2.0 / 2.5 c -> 68 / 67 / 61 / 64 / 68 us for the first-pass launch)
-        float band = 1.7f * g.c;
+        float band = S2M_HARD_BAND * g.c;
         uint32_t rounds = 0;
         const int hbx = q.cx >> 3, hby = q.cy >> 3, hbz = q.cz >> 3;
         int nc = 0;  // cells waiting in the wave's list (wave-uniform)
