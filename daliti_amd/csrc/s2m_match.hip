@@ -767,8 +767,11 @@ __device__ __forceinline__ int kth_set_bit(uint64_t m, int k)
 // of 4 vs 8 make no difference -- the kernel is VALU-issue bound at ~58 %, TA ~27 % busy).
 constexpr int kPairSlots = 6;  // (brick,row) pairs a lane can hold per chunk of 64 bricks
 
+#ifndef S2M_HARD_OCC
+#define S2M_HARD_OCC 4  // waves per SIMD match_hard is compiled for (116 VGPRs at 4; 5 needs spills) = resident waves / 1024
+#endif
 template <bool WIDE>
-__global__ __launch_bounds__(256) void match_hard(MatchArgs a)
+__global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
 {
     constexpr int G = 64;
     constexpr int kMaxCells = 1024;  // an append adds at most 64 rows x 8 cells
@@ -1024,7 +1027,7 @@ void launch_match(const MatchArgs &a, int group, hipStream_t st)
     const int hg = 64;
     // as many waves as stay resident together (116 VGPRs: 4 per SIMD, 4,096 on the chip); the rest of the list is
     // pulled through the queue heads
-    const int64_t groups = std::min<int64_t>(a.n, (a.qheads ? 4096 : 8192) * (64 / hg));
+    const int64_t groups = std::min<int64_t>(a.n, (a.qheads ? 1024 * S2M_HARD_OCC : 8192) * (64 / hg));
     const int blocks = (int)((groups * hg + 255) / 256);
     if (!wide) hipLaunchKernelGGL(match_hard<false>, dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(match_hard<true>, dim3(blocks), dim3(256), 0, st, a);
