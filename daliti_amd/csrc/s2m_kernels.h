@@ -19,13 +19,19 @@ struct MapBuffers {
     // owned by the engine, (re)allocated by build_map
     float4 *pts = nullptr;
     float4 *porig = nullptr;
+    float4 *pts2 = nullptr, *porig2 = nullptr;  // the other halves of the double buffers a merge update writes into
     uint4 *top = nullptr;
     uint32_t *tab = nullptr;
-    int64_t pts_cap = 0, porig_cap = 0, top_cap = 0, tab_cap = 0;
-    // scratch
+    int64_t pts_cap = 0, porig_cap = 0, pts2_cap = 0, porig2_cap = 0, top_cap = 0, tab_cap = 0;
+    // per-point arrays of scratch_cap + 1 elements.  keys_alt / vals_alt hold the SORTED keys of the current map
+    // and the caller index of every sorted position (they stay valid between updates: the merge update reads
+    // them); keys / vals are the unsorted input of a build or the output of a merge
     uint64_t *keys = nullptr, *keys_alt = nullptr;
     uint32_t *vals = nullptr, *vals_alt = nullptr;
-    uint32_t *brick_flag = nullptr, *brick_id = nullptr;
+    uint32_t *work_a = nullptr, *work_b = nullptr, *work_c = nullptr;
+    uint32_t *rank = nullptr;    // per top entry (+1): number of occupied bricks before it
+    uint32_t *bstart = nullptr;  // per occupied brick: first position in pts
+    int64_t rank_cap = 0, bstart_cap = 0;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     int64_t scratch_cap = 0;
@@ -39,8 +45,9 @@ struct MapStats {
 
 // xyz_dev: device pointer, stride in floats.  cell <= 0 selects the cell size from the density.
 // Returns hipSuccess or the failing HIP error; *too_large set when the grid would not fit.
+// with_margin: leave free bricks around the bounding box (maps that will be updated incrementally).
 hipError_t build_map(const float *xyz_dev, int64_t stride, int64_t m, float cell, MapBuffers &buf, Grid &grid,
-                     MapStats &stats, bool &too_large, hipStream_t st);
+                     MapStats &stats, bool &too_large, hipStream_t st, bool with_margin = false);
 void free_map(MapBuffers &buf);
 
 // ---- s2m_mapupd.hip : incremental map maintenance (map_incremental / Add_Points / Delete_Point_Boxes) ----

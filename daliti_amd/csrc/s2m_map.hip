@@ -16,6 +16,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "s2m_device.h"
 #include "s2m_kernels.h"
@@ -120,11 +121,9 @@ __global__ __launch_bounds__(256) void key_kernel(const float *__restrict__ xyz,
     vals[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void gather_flag_kernel(const float *__restrict__ xyz, int64_t stride, int64_t m,
-                                                          const uint64_t *__restrict__ keys,
-                                                          const uint32_t *__restrict__ vals,
-                                                          float4 *__restrict__ pts, float4 *__restrict__ porig,
-                                                          uint32_t *__restrict__ flag)
+__global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ xyz, int64_t stride, int64_t m,
+                                                     const uint32_t *__restrict__ vals, float4 *__restrict__ pts,
+                                                     float4 *__restrict__ porig)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
@@ -132,79 +131,104 @@ __global__ __launch_bounds__(256) void gather_flag_kernel(const float *__restric
     pts[j] = make_map_point(xyz[(int64_t)src * stride], xyz[(int64_t)src * stride + 1], xyz[(int64_t)src * stride + 2],
                             src);
     porig[j] = make_float4(xyz[j * stride], xyz[j * stride + 1], xyz[j * stride + 2], 0.0f);
-    flag[j] = (j == 0 || (keys[j] >> 9) != (keys[j - 1] >> 9)) ? 1u : 0u;
 }
 
-// brick_id[j] is the inclusive scan of flag (1-based brick id of point j)
-__global__ __launch_bounds__(256) void cell_start_kernel(int64_t m, const uint64_t *__restrict__ keys,
-                                                         const uint32_t *__restrict__ brick_id,
-                                                         uint4 *__restrict__ top, uint32_t *__restrict__ tab,
-                                                         uint32_t *__restrict__ counters)
+// ---- top entries and per-brick prefix tables from the SORTED keys -------------------------------------------
+// Used by the full build and by the merge update alike.  (1) every first point of a brick leaves its position in
+// the second word of the brick's top entry; (2) an exclusive scan over the dense top array numbers the occupied
+// bricks in key order; (3) ids and brick starts are written; (4) one wave per occupied brick reads the brick's
+// keys once, coalesced, drops the first position of every cell into a 512-entry LDS table, turns it into the
+// exclusive prefix of the cell counts (an empty cell takes the start of the next non-empty one), and derives the
+// row mask and the occupied-cell count from it.  No per-point brick id, no global atomics per cell.
+__global__ __launch_bounds__(256) void brick_head_kernel(int64_t m, const uint64_t *__restrict__ keys, uint4 *__restrict__ top)
 {
-    int mine = 0;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
-        bool cell_first = false;
         const uint64_t k = keys[j];
-        const uint64_t kp = j > 0 ? keys[j - 1] : ~0ull;
-        const uint32_t b = brick_id[j] - 1;
-        cell_first = (j == 0) || (kp != k);
-        if (cell_first) {
-            tab[(int64_t)b * kBrickStride + (uint32_t)(k & 511)] = (uint32_t)j;
-            uint32_t *te = reinterpret_cast<uint32_t *>(&top[k >> 9]);
-            // row-occupancy mask of the brick: bit (lz*8 + ly), set once per row (by its first cell)
-            if (j == 0 || (kp >> 3) != (k >> 3)) {
-                const uint32_t rowbit = (uint32_t)(k & 511) >> 3;
-                atomicOr(&te[2 + (rowbit >> 5)], 1u << (rowbit & 31));
-            }
-            if (j == 0 || (kp >> 9) != (k >> 9)) te[0] = b + 1;
-        }
-        if (j == m - 1 || (keys[j + 1] >> 9) != (k >> 9)) tab[(int64_t)b * kBrickStride + kBrickCells] = (uint32_t)(j + 1);
-        mine += cell_first ? 1 : 0;
+        if (j == 0 || (keys[j - 1] >> 9) != (k >> 9)) reinterpret_cast<uint32_t *>(&top[k >> 9])[1] = (uint32_t)(j + 1);
     }
-    // occupied-cell count: same-address atomics cost ~11 ns each (0.8 ms when every cell issued one, 0.2 ms
-    // with one per 256 points), so the grid is capped and each workgroup issues one
-    __shared__ int wsum[4];
+}
+
+struct TopOccupied {
+    __host__ __device__ uint32_t operator()(const uint4 &t) const { return t.y != 0u ? 1u : 0u; }
+};
+
+__global__ __launch_bounds__(256) void brick_assign_kernel(int64_t top_entries, uint4 *__restrict__ top,
+                                                           const uint32_t *__restrict__ rank,
+                                                           uint32_t *__restrict__ bstart)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= top_entries) return;
+    const uint32_t y = top[b].y;
+    if (y == 0u) return;
+    const uint32_t id = rank[b];
+    reinterpret_cast<uint32_t *>(&top[b])[0] = id + 1u;
+    bstart[id] = y - 1u;
+}
+
+constexpr int kOccShards = 64;  // occupied-cell counters, 128 B apart (same-address atomics cost ~11 ns each)
+
+__global__ __launch_bounds__(256) void brick_table_kernel(int64_t bricks, int64_t m, const uint64_t *__restrict__ keys,
+                                                          const uint32_t *__restrict__ bstart, uint4 *__restrict__ top,
+                                                          uint32_t *__restrict__ tab, uint32_t *__restrict__ occ)
+{
+    __shared__ uint32_t lds[4][kBrickCells];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t id = (int64_t)blockIdx.x * 4 + wave;
+    int cells = 0;
+    if (id < bricks) {
+        uint32_t *t = lds[wave];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+        for (int k = 0; k < 8; ++k) t[lane * 8 + k] = 0xffffffffu;
+        const uint32_t s = bstart[id];
+        const uint32_t e = (id + 1 < bricks) ? bstart[id + 1] : (uint32_t)m;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (uint32_t j = s + (uint32_t)lane; j < e; j += 64u) {
+            const uint64_t k = keys[j];
+            if (j == s || keys[j - 1] != k) t[(uint32_t)k & 511u] = j;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        uint32_t v[8];
+        uint32_t mn = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = t[lane * 8 + k];
+            mn = min(mn, v[k]);
+            cells += v[k] != 0xffffffffu ? 1 : 0;
+        }
+        // row lane = (z,y) row of the brick: occupied when any of its eight cells is
+        const unsigned long long mask = __ballot(mn != 0xffffffffu);
+        // suffix-min over the lanes behind this one, seeded with the brick end
+        uint32_t suf = mn;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_down(suf, off, 64);
+            if (lane + off < 64) suf = min(suf, o);
+        }
+        uint32_t nxt = __shfl_down(suf, 1, 64);
+        if (lane == 63) nxt = e;
+        nxt = min(nxt, e);
+        uint32_t *out = tab + id * kBrickStride;
+#pragma unroll
+        for (int k = 7; k >= 0; --k) {
+            if (v[k] == 0xffffffffu) v[k] = nxt;
+            nxt = v[k];
+            out[lane * 8 + k] = v[k];
+        }
+        if (lane == 0) {
+            out[kBrickCells] = e;
+            uint32_t *te = reinterpret_cast<uint32_t *>(&top[keys[s] >> 9]);
+            te[2] = (uint32_t)mask;
+            te[3] = (uint32_t)(mask >> 32);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cells += __shfl_xor(cells, off, 64);
+    __shared__ int wsum[4];
+    if (lane == 0) wsum[wave] = cells;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int cnt = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (cnt) atomicAdd(&counters[0], (uint32_t)cnt);
-    }
-}
-
-// one wave per brick: empty cells (0xffffffff) take the start of the next non-empty cell, which
-// turns the table into the exclusive prefix of the per-cell counts
-__global__ __launch_bounds__(64) void brick_fill_kernel(uint32_t *__restrict__ tab, int64_t bricks)
-{
-    const int64_t b = blockIdx.x;
-    if (b >= bricks) return;
-    uint32_t *t = tab + b * kBrickStride;
-    const int lane = threadIdx.x;
-    uint32_t v[8];
-    uint32_t mn = 0xffffffffu;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        v[k] = t[lane * 8 + k];
-        mn = min(mn, v[k]);
-    }
-    // suffix-min over lanes (exclusive of own lane), seeded with the brick end
-    const uint32_t end = t[kBrickCells];
-    uint32_t suf = mn;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_down(suf, off, 64);
-        if (lane + off < 64) suf = min(suf, o);
-    }
-    uint32_t nxt = __shfl_down(suf, 1, 64);
-    if (lane == 63) nxt = end;
-    nxt = min(nxt, end);
-#pragma unroll
-    for (int k = 7; k >= 0; --k) {
-        if (v[k] == 0xffffffffu) v[k] = nxt;
-        nxt = v[k];
-        t[lane * 8 + k] = v[k];
+        const int c = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (c) atomicAdd(&occ[(blockIdx.x % kOccShards) * 32], (uint32_t)c);
     }
 }
 
@@ -221,16 +245,93 @@ static hipError_t ensure(void **p, int64_t *cap, int64_t need, size_t elem)
 
 void free_map(MapBuffers &b)
 {
-    void *ptrs[] = {b.pts, b.porig, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.brick_flag, b.brick_id,
-                    b.sort_tmp, b.bbox, b.counters};
+    void *ptrs[] = {b.pts, b.porig, b.pts2, b.porig2, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.work_a, b.work_b,
+                    b.work_c, b.rank, b.bstart, b.sort_tmp, b.bbox, b.counters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     b = MapBuffers();
 }
 
+static hipError_t ensure_sort_tmp(MapBuffers &buf, size_t bytes)
+{
+    if (bytes <= buf.sort_tmp_bytes && buf.sort_tmp) return hipSuccess;
+    if (buf.sort_tmp) S2M_TRY(hipFree(buf.sort_tmp));
+    buf.sort_tmp = nullptr;
+    buf.sort_tmp_bytes = 0;
+    S2M_TRY(hipMalloc(&buf.sort_tmp, std::max<size_t>(bytes, 256)));
+    buf.sort_tmp_bytes = std::max<size_t>(bytes, 256);
+    return hipSuccess;
+}
+
+// per-point scratch (keys, sorted keys, source indices, three work arrays of cap + 1 words); with headroom, so
+// that a map that grows a little with every scan does not reallocate (and fall back to a full rebuild) each time
+static hipError_t ensure_scratch(MapBuffers &buf, int64_t m)
+{
+    if (buf.scratch_cap >= m) return hipSuccess;
+    const int64_t cap = m + m / 4 + 65536;
+    void **ps[] = {(void **)&buf.keys, (void **)&buf.keys_alt, (void **)&buf.vals, (void **)&buf.vals_alt,
+                   (void **)&buf.work_a, (void **)&buf.work_b, (void **)&buf.work_c};
+    const size_t es[] = {8, 8, 4, 4, 4, 4, 4};
+    buf.scratch_cap = 0;
+    for (int k = 0; k < 7; ++k) {
+        int64_t c = 0;
+        if (*ps[k]) { S2M_TRY(hipFree(*ps[k])); *ps[k] = nullptr; }
+        S2M_TRY(ensure(ps[k], &c, cap + 1, es[k]));
+    }
+    buf.scratch_cap = cap;
+    return hipSuccess;
+}
+
+static hipError_t put_sentinels(float4 *pts, int64_t m, hipStream_t st)
+{
+    // eight extra elements: the sentinel points the search kernels load for the padding slots of a batch
+    // (far enough for the squared distance to overflow to +inf; index word 0xffffffff)
+    static uint32_t sentinel[kSentinelPoints][4];
+    for (auto &q : sentinel) { q[0] = q[1] = q[3] = 0x7f61b1e6u; q[2] = 0xffffffffu; }  // make_map_point(3e38f x3, ~0)
+    return hipMemcpyAsync(pts + m, sentinel, sizeof(sentinel), hipMemcpyHostToDevice, st);
+}
+
+// top entries + brick tables of the m points whose sorted keys are `keys` (buf.top zeroed by the caller)
+static hipError_t build_tables(MapBuffers &buf, const uint64_t *keys, int64_t m, int64_t top_entries, MapStats &stats,
+                               hipStream_t st)
+{
+    const int blocks = (int)std::min<int64_t>((m + 255) / 256, 4096);
+    hipLaunchKernelGGL(brick_head_kernel, dim3(blocks), dim3(256), 0, st, m, keys, buf.top);
+    S2M_TRY(ensure((void **)&buf.rank, &buf.rank_cap, top_entries + 1, sizeof(uint32_t)));
+    auto occupied = rocprim::make_transform_iterator(static_cast<const uint4 *>(buf.top), TopOccupied());
+    size_t tmp = 0;
+    S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, occupied, buf.rank, 0u, (size_t)top_entries + 1, rocprim::plus<uint32_t>(), st));
+    S2M_TRY(ensure_sort_tmp(buf, tmp));
+    size_t t1 = buf.sort_tmp_bytes;
+    // one element past the end (top has a zero spare entry): rank[top_entries] = number of occupied bricks
+    S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t1, occupied, buf.rank, 0u, (size_t)top_entries + 1, rocprim::plus<uint32_t>(), st));
+    uint32_t bricks = 0;
+    S2M_TRY(hipMemcpyAsync(&bricks, buf.rank + top_entries, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    S2M_TRY(hipStreamSynchronize(st));
+    S2M_TRY(ensure((void **)&buf.tab, &buf.tab_cap, ((int64_t)bricks + bricks / 4 + 64) * kBrickStride, sizeof(uint32_t)));
+    S2M_TRY(ensure((void **)&buf.bstart, &buf.bstart_cap, (int64_t)bricks + bricks / 4 + 64, sizeof(uint32_t)));
+    hipLaunchKernelGGL(brick_assign_kernel, dim3((unsigned)((top_entries + 255) / 256)), dim3(256), 0, st, top_entries,
+                       buf.top, buf.rank, buf.bstart);
+    S2M_TRY(hipMemsetAsync(buf.counters + 64, 0, kOccShards * 32 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(brick_table_kernel, dim3((bricks + 3) / 4), dim3(256), 0, st, (int64_t)bricks, m, keys, buf.bstart,
+                       buf.top, buf.tab, buf.counters + 64);
+    uint32_t occ[kOccShards * 32];
+    S2M_TRY(hipMemcpyAsync(occ, buf.counters + 64, sizeof(occ), hipMemcpyDeviceToHost, st));
+    S2M_TRY(hipStreamSynchronize(st));
+    S2M_TRY(hipGetLastError());
+    int64_t cells = 0;
+    for (int k = 0; k < kOccShards; ++k) cells += occ[k * 32];
+    stats.bricks = bricks;
+    stats.occupied_cells = cells;
+    return hipSuccess;
+}
+
+// margin_cells: free cells kept around the bounding box on every side (rounded up to whole bricks by the
+// caller's arithmetic below); a map that is maintained incrementally gets one so that points just outside the
+// current box can be merged in without a new grid
 static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float cell, const float lo[3],
-                             const float hi[3], MapBuffers &buf, Grid &g, MapStats &stats, bool &too_large,
-                             hipStream_t st)
+                             const float hi[3], int margin_cells, MapBuffers &buf, Grid &g, MapStats &stats,
+                             bool &too_large, hipStream_t st)
 {
     too_large = false;
     g = Grid();
@@ -246,9 +347,9 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     int nc[3];
     float o[3];
     for (int k = 0; k < 3; ++k) {
-        o[k] = std::floor(lo[k] / cell) * cell - cell - shift[k] * cell;
+        o[k] = std::floor(lo[k] / cell) * cell - cell - shift[k] * cell - (float)margin_cells * cell;
         const double span = ((double)hi[k] - (double)o[k]) / (double)cell;
-        const int64_t cells = (int64_t)std::floor(span) + 2;
+        const int64_t cells = (int64_t)std::floor(span) + 2 + margin_cells;
         const int64_t rounded = ((cells + kBrick - 1) / kBrick) * kBrick;
         if (rounded > (int64_t)1 << 24) { too_large = true; return hipSuccess; }
         nc[k] = (int)rounded;
@@ -263,30 +364,14 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     const float max_cells = (float)std::max(std::max(nc[0], nc[1]), nc[2]);
     g.slop = std::max(1.0e-4f, 16.0f * max_cells * 1.1920929e-7f);
 
-    // eight extra elements: the sentinel points the search kernels load for the padding slots of a batch
-    // (far enough for the squared distance to overflow to +inf; index word 0xffffffff)
-    S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m + kSentinelPoints, sizeof(float4)));
-    {
-        static uint32_t sentinel[kSentinelPoints][4];
-        for (auto &q : sentinel) { q[0] = q[1] = q[3] = 0x7f61b1e6u; q[2] = 0xffffffffu; }  // make_map_point(3e38f x3, ~0)
-        S2M_TRY(hipMemcpyAsync(buf.pts + m, sentinel, sizeof(sentinel), hipMemcpyHostToDevice, st));
-    }
-    S2M_TRY(ensure((void **)&buf.porig, &buf.porig_cap, m, sizeof(float4)));
-    S2M_TRY(ensure((void **)&buf.top, &buf.top_cap, top_entries, sizeof(uint4)));
-    if (buf.scratch_cap < m) {
-        void **ps[] = {(void **)&buf.keys, (void **)&buf.keys_alt, (void **)&buf.vals, (void **)&buf.vals_alt,
-                       (void **)&buf.brick_flag, (void **)&buf.brick_id};
-        const size_t es[] = {8, 8, 4, 4, 4, 4};
-        for (int k = 0; k < 6; ++k) {
-            int64_t cap = 0;
-            if (*ps[k]) { S2M_TRY(hipFree(*ps[k])); *ps[k] = nullptr; }
-            S2M_TRY(ensure(ps[k], &cap, m, es[k]));
-        }
-        buf.scratch_cap = m;
-    }
-    if (!buf.counters) S2M_TRY(hipMalloc((void **)&buf.counters, 64));
-    S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)top_entries * sizeof(uint4), st));
-    S2M_TRY(hipMemsetAsync(buf.counters, 0, 64, st));
+    S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m + m / 4 + 65536 + kSentinelPoints, sizeof(float4)));
+    S2M_TRY(put_sentinels(buf.pts, m, st));
+    S2M_TRY(ensure((void **)&buf.porig, &buf.porig_cap, m + m / 4 + 65536, sizeof(float4)));
+    S2M_TRY(ensure((void **)&buf.top, &buf.top_cap, top_entries + 1, sizeof(uint4)));
+    S2M_TRY(ensure_scratch(buf, m));
+    if (!buf.counters) S2M_TRY(hipMalloc((void **)&buf.counters, (64 + kOccShards * 32) * sizeof(uint32_t)));
+    S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(top_entries + 1) * sizeof(uint4), st));
+    S2M_TRY(hipMemsetAsync(buf.counters, 0, 64 * sizeof(uint32_t), st));
     stats = MapStats();
     stats.top_entries = top_entries;
     if (m == 0) {
@@ -302,57 +387,39 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     size_t tmp = 0;
     S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m, 0,
                                       (unsigned)bits, st));
-    size_t tmp2 = 0;
-    S2M_TRY(rocprim::inclusive_scan(nullptr, tmp2, buf.brick_flag, buf.brick_id, (size_t)m,
-                                    rocprim::plus<uint32_t>(), st));
-    tmp = std::max(tmp, tmp2);
-    if (tmp > buf.sort_tmp_bytes) {
-        if (buf.sort_tmp) S2M_TRY(hipFree(buf.sort_tmp));
-        buf.sort_tmp = nullptr;
-        S2M_TRY(hipMalloc(&buf.sort_tmp, tmp));
-        buf.sort_tmp_bytes = tmp;
-    }
+    S2M_TRY(ensure_sort_tmp(buf, tmp));
     size_t t1 = buf.sort_tmp_bytes;
     S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t1, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m,
                                       0, (unsigned)bits, st));
-    hipLaunchKernelGGL(gather_flag_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, buf.keys_alt,
-                       buf.vals_alt, buf.pts, buf.porig, buf.brick_flag);
-    size_t t2 = buf.sort_tmp_bytes;
-    S2M_TRY(rocprim::inclusive_scan(buf.sort_tmp, t2, buf.brick_flag, buf.brick_id, (size_t)m,
-                                    rocprim::plus<uint32_t>(), st));
-    uint32_t bricks = 0;
-    S2M_TRY(hipMemcpyAsync(&bricks, buf.brick_id + (m - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    S2M_TRY(hipStreamSynchronize(st));
-    S2M_TRY(ensure((void **)&buf.tab, &buf.tab_cap, (int64_t)bricks * kBrickStride, sizeof(uint32_t)));
-    S2M_TRY(hipMemsetAsync(buf.tab, 0xff, (size_t)bricks * kBrickStride * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(cell_start_kernel, dim3(std::min(blocks, 2048)), dim3(256), 0, st, m, buf.keys_alt, buf.brick_id, buf.top,
-                       buf.tab, buf.counters);
-    hipLaunchKernelGGL(brick_fill_kernel, dim3(bricks), dim3(64), 0, st, buf.tab, (int64_t)bricks);
-    uint32_t occ = 0;
-    S2M_TRY(hipMemcpyAsync(&occ, buf.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    S2M_TRY(hipStreamSynchronize(st));
-    S2M_TRY(hipGetLastError());
-    stats.bricks = bricks;
-    stats.occupied_cells = occ;
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, buf.vals_alt, buf.pts, buf.porig);
+    S2M_TRY(build_tables(buf, buf.keys_alt, m, top_entries, stats, st));
+    stats.top_entries = top_entries;
     g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.porig = buf.porig;
     return hipSuccess;
 }
 
 hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, MapBuffers &buf, Grid &grid,
-                     MapStats &stats, bool &too_large, hipStream_t st)
+                     MapStats &stats, bool &too_large, hipStream_t st, bool with_margin)
 {
     float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
     if (m > 0) {
         if (!buf.bbox) S2M_TRY(hipMalloc((void **)&buf.bbox, kBboxScratchFloats * sizeof(float)));
         S2M_TRY(cloud_bbox(xyz, stride, m, buf.bbox, lo, hi, st));
     }
-    if (cell > 0.0f) return build_once(xyz, stride, m, cell, lo, hi, buf, grid, stats, too_large, st);
+    // margin of an incrementally maintained map: an eighth of the longest extent, 2 to 64 bricks
+    auto margin_for = [&](float c) {
+        if (!with_margin) return 0;
+        const double ext = std::max(std::max((double)hi[0] - lo[0], (double)hi[1] - lo[1]), (double)hi[2] - lo[2]);
+        const int64_t cells = (int64_t)(ext / (8.0 * (double)c));
+        return (int)(std::min<int64_t>(std::max<int64_t>(cells / kBrick, 2), 64) * kBrick);
+    };
+    if (cell > 0.0f) return build_once(xyz, stride, m, cell, lo, hi, margin_for(cell), buf, grid, stats, too_large, st);
     // density-driven cell size: LiDAR maps are surfaces, so points per occupied cell ~ c^2; aim for
     // ~11 points per occupied cell (cell edge about twice the 5-NN radius): measured fastest on
     // MI355X for the first-shell + hard-list search, including the large-displacement first pass
     float c = 0.5f;
     for (int attempt = 0; attempt < 4; ++attempt) {
-        S2M_TRY(build_once(xyz, stride, m, c, lo, hi, buf, grid, stats, too_large, st));
+        S2M_TRY(build_once(xyz, stride, m, c, lo, hi, margin_for(c), buf, grid, stats, too_large, st));
         if (too_large) { c *= 2.0f; continue; }
         if (m == 0 || stats.occupied_cells == 0) return hipSuccess;
         const double mean = (double)m / (double)stats.occupied_cells;
@@ -362,7 +429,7 @@ hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, Ma
         if (std::fabs(cn - c) < 0.05f * c) return hipSuccess;
         c = cn;
     }
-    return build_once(xyz, stride, m, c, lo, hi, buf, grid, stats, too_large, st);
+    return build_once(xyz, stride, m, c, lo, hi, margin_for(c), buf, grid, stats, too_large, st);
 }
 
 // AoS (caller stride) -> SoA scan arrays; feats_down keeps only x, y, z on this path
