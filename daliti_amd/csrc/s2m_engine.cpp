@@ -48,6 +48,8 @@ struct s2m_engine {
     float local_map[6] = {0, 0, 0, 0, 0, 0};
     bool local_map_init = false;
     float built_cell = 0.0f;  // cell size of the current grid (kept across incremental rebuilds)
+    bool no_merge = false;          // S2M_NO_MERGE=1: every update rebuilds the grid from scratch (A/B and tests)
+    bool last_update_merged = false;
     Grid grid{};
     MapStats stats;
     bool map_ready = false;
@@ -314,6 +316,7 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
         if (v >= 1 && v <= 3) e->match_group |= v << 8;
     }
     e->dbg = std::getenv("S2M_DEBUG_MATCH") != nullptr;
+    e->no_merge = std::getenv("S2M_NO_MERGE") != nullptr;
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&e->ev[i]) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_block, S2M_BLOCK_DOUBLES * sizeof(double)) == hipSuccess;
@@ -409,6 +412,7 @@ int s2m_map_share(s2m_engine *e, const s2m_engine *owner)
     S2M_HIP(e, hipSetDevice(e->device));
     S2M_HIP(e, hipStreamSynchronize(e->stream));
     S2M_HIP(e, hipStreamSynchronize(owner->stream));  // the owner's build has finished
+    (void)resolve_stats(const_cast<s2m_engine *>(owner)->map, const_cast<s2m_engine *>(owner)->stats);
     e->grid = owner->grid;
     e->stats = owner->stats;
     e->built_cell = owner->built_cell;
@@ -419,28 +423,44 @@ int s2m_map_share(s2m_engine *e, const s2m_engine *owner)
 }
 
 namespace {
-// rebuild the brick grid from upd.list after an update
+// the map after an update: merged into the sorted arrays when possible (s2m_map.hip, merge_update), else rebuilt
+// from upd.list (survivors in index order, then the staged points) -- the same caller order either way
 int commit_update(s2m_engine *e)
 {
-    int64_t m_new = 0;
-    hipError_t he = update_finish(e->upd, e->grid, &m_new, e->stream);
-    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "update_finish", he);
-    if (m_new >= ((int64_t)1 << 31)) return fail(e, S2M_ERR_CAPACITY, "map too large (>= 2^31 points)");
-    bool too_large = false;
+    bool merged = false;
     e->map_ready = false;
-    const float cell = e->cfg.cell_size > 0.0f ? e->cfg.cell_size : e->built_cell;
-    he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, cell, e->map, e->grid, e->stats, too_large,
-                   e->stream);
-    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
-    if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
+    hipError_t he = resolve_stats(e->map, e->stats);  // counts of the previous build / merge
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "resolve_stats", he);
     // The cell size is kept across updates (a stable grid) unless the density has drifted by more than 2x from
     // the ~11 points per occupied cell it was chosen for -- e.g. a map seeded from a handful of points and then
-    // grown, or a dense seed thinned by the voxel rule: then it is chosen again from the density.
-    if (!(e->cfg.cell_size > 0.0f) && e->stats.occupied_cells > 0) {
-        const double mean = (double)m_new / (double)e->stats.occupied_cells;
-        if (mean < 5.5 || mean > 22.0) {
+    // grown, or a dense seed thinned by the voxel rule: then it is chosen again from the density.  A merged update
+    // does not wait for its own counts, so the drift it causes is seen when the next update begins.
+    auto drifted = [&](int64_t m) {
+        if (e->cfg.cell_size > 0.0f || e->stats.occupied_cells <= 0) return false;
+        const double mean = (double)m / (double)e->stats.occupied_cells;
+        return mean < 5.5 || mean > 22.0;
+    };
+    const bool drift_before = drifted(e->grid.m);
+    if (!e->no_merge && !drift_before) {
+        he = merge_update(e->map, e->grid, e->stats, e->upd.alive, e->upd.alive_s, e->upd.stage, e->upd.stage_n, merged, e->stream);
+        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "merge_update", he);
+    }
+    e->last_update_merged = merged;
+    if (!merged) {
+        int64_t m_new = 0;
+        bool too_large = false;
+        he = update_finish(e->upd, e->grid, &m_new, e->stream);
+        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "update_finish", he);
+        if (m_new >= ((int64_t)1 << 31)) return fail(e, S2M_ERR_CAPACITY, "map too large (>= 2^31 points)");
+        const float cell = e->cfg.cell_size > 0.0f ? e->cfg.cell_size : e->built_cell;
+        // with a margin of free bricks around the box, so that the next updates can be merged
+        he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, cell, e->map, e->grid, e->stats, too_large,
+                       e->stream, true);
+        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
+        if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
+        if (drifted(m_new)) {
             he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, 0.0f, e->map, e->grid, e->stats, too_large,
-                           e->stream);
+                           e->stream, true);
             if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
             if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
             e->built_cell = e->grid.c;
@@ -602,10 +622,19 @@ int s2m_map_size(const s2m_engine *e, int64_t *m)
     return S2M_OK;
 }
 
-int s2m_map_info(const s2m_engine *e, double info[8])
+int s2m_map_last_update(const s2m_engine *e, int32_t *merged)
 {
-    if (!e || !info) return S2M_ERR_ARG;
-    if (!e->map_ready) return S2M_ERR_STATE;
+    if (!e || !merged) return S2M_ERR_ARG;
+    *merged = e->last_update_merged ? 1 : 0;
+    return S2M_OK;
+}
+
+int s2m_map_info(const s2m_engine *ce, double info[8])
+{
+    if (!ce || !info) return S2M_ERR_ARG;
+    if (!ce->map_ready) return S2M_ERR_STATE;
+    s2m_engine *e = const_cast<s2m_engine *>(ce);  // the counts of a merged update are fetched on demand
+    if (!e->map_borrowed && resolve_stats(e->map, e->stats) != hipSuccess) return S2M_ERR_HIP;
     info[0] = e->grid.c;
     info[1] = e->grid.ox; info[2] = e->grid.oy; info[3] = e->grid.oz;
     info[4] = (double)e->stats.bricks;

@@ -23,15 +23,23 @@ struct MapBuffers {
     uint4 *top = nullptr;
     uint32_t *tab = nullptr;
     int64_t pts_cap = 0, porig_cap = 0, pts2_cap = 0, porig2_cap = 0, top_cap = 0, tab_cap = 0;
-    // per-point arrays of scratch_cap + 1 elements.  keys_alt / vals_alt hold the SORTED keys of the current map
-    // and the caller index of every sorted position (they stay valid between updates: the merge update reads
-    // them); keys / vals are the unsorted input of a build or the output of a merge
+    // per-point arrays of scratch_cap + 1 elements.  keys_alt holds the SORTED keys of the current map (it stays
+    // valid between updates: the merge update reads it); keys is the unsorted input of a build or the output of a
+    // merge; vals / vals_alt are the build sort's payload
     uint64_t *keys = nullptr, *keys_alt = nullptr;
     uint32_t *vals = nullptr, *vals_alt = nullptr;
     uint32_t *work_a = nullptr, *work_b = nullptr, *work_c = nullptr;
     uint32_t *rank = nullptr;    // per top entry (+1): number of occupied bricks before it
     uint32_t *bstart = nullptr;  // per occupied brick: first position in pts
     int64_t rank_cap = 0, bstart_cap = 0;
+    uint64_t *mk = nullptr;      // merge update: sorted keys of the new points
+    uint32_t *mv = nullptr;      // merge update: their stage positions, then their lower bounds among the old keys
+    int64_t mk_cap = 0, mv_cap = 0;
+    unsigned long long *dword = nullptr;  // merge update: bit mask of the removed points per 64 caller indices
+    int64_t dword_cap = 0;
+    uint32_t *h_stats = nullptr;  // pinned: occupied bricks, then the occupied-cell counters, copied behind a merge
+    hipEvent_t stats_event = nullptr;
+    bool stats_pending = false;
     void *sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
     int64_t scratch_cap = 0;
@@ -49,11 +57,20 @@ struct MapStats {
 hipError_t build_map(const float *xyz_dev, int64_t stride, int64_t m, float cell, MapBuffers &buf, Grid &grid,
                      MapStats &stats, bool &too_large, hipStream_t st, bool with_margin = false);
 void free_map(MapBuffers &buf);
+// bricks / occupied_cells of the last build or merge (a merge does not wait for them: they arrive behind it)
+hipError_t resolve_stats(MapBuffers &buf, MapStats &stats);
+// The map after an update without a new sort (s2m_map.hip, "merge update"): alive[caller index] and alive_s[sorted
+// position] for the m old points (m + 1 readable bytes each), n_new staged points in their order.  merged = false (and nothing changed) when the
+// update cannot be merged -- a new point outside the grid, no room in the scratch arrays, empty map -- and the caller
+// falls back to update_finish + build_map.
+hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive, const uint8_t *alive_s,
+                        const float4 *stage, int64_t n_new, bool &merged, hipStream_t st);
 
 // ---- s2m_mapupd.hip : incremental map maintenance (map_incremental / Add_Points / Delete_Point_Boxes) ----
 struct UpdateBuffers {
-    uint8_t *alive = nullptr;      // per old point, 0 = removed by this update
-    int64_t alive_cap = 0;
+    uint8_t *alive = nullptr;      // per old point by caller index, 0 = removed by this update (m + 1 bytes)
+    uint8_t *alive_s = nullptr;    // the same flags by sorted position (position in Grid::pts)
+    int64_t alive_cap = 0, alive_s_cap = 0;
     uint32_t *counters = nullptr;  // [1] voxels rewritten (tmp_counter), [2] points deleted by boxes
     float4 *stage = nullptr;       // points to append, in order
     int64_t stage_cap = 0, stage_n = 0;

@@ -80,8 +80,11 @@ __device__ __forceinline__ uint64_t voxel_key(float x, float y, float z, float d
 // the map points were binned with the same expression (cell_of, s2m_map.hip): a point with mn <= p < mx lies
 // in a cell between cell(mn) and cell(mx), so no slack cells are needed.  Per x-row the cells of one brick
 // are one contiguous run of the sorted array.
+// `sub` of `stride`: the lanes of a group share one box and take every stride-th point of each run -- a lane that
+// walks a run alone waits a full memory latency per point (measured: 75 us for 11 k boxes of ~100 points).
 template <class F>
-__device__ __forceinline__ void for_points_in_box(const Grid &g, const float (&mn)[3], const float (&mx)[3], F &&f)
+__device__ __forceinline__ void for_points_in_box(const Grid &g, const float (&mn)[3], const float (&mx)[3], F &&f,
+                                                  uint32_t sub = 0, uint32_t stride = 1)
 {
     if (g.m == 0) return;
     int c0[3], c1[3];
@@ -103,31 +106,45 @@ __device__ __forceinline__ void for_points_in_box(const Grid &g, const float (&m
                 const int l0 = max(c0[0], bx << 3) & 7, l1 = min(c1[0], (bx << 3) + 7) & 7;
                 const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + (rowbit << 3);
                 const uint32_t e = tb[l1 + 1];
-                for (uint32_t i = tb[l0]; i < e; ++i) {
+                for (uint32_t i = tb[l0] + sub; i < e; i += stride) {
                     const float4 q = g.pts[i];  // {x, y, index, z}
                     const float4 p = make_float4(q.x, q.y, map_point_z(q), 0.0f);
-                    if (in_box(p, mn, mx)) f(p, map_point_index(q));
+                    if (in_box(p, mn, mx)) f(p, map_point_index(q), i);
                 }
             }
         }
 }
+
+constexpr int kBoxLanes = 8;  // lanes that share one voxel box
 
 __global__ __launch_bounds__(256) void add_probe_kernel(Grid g, const float4 *__restrict__ np, int n, float ds,
                                                         uint64_t *__restrict__ key, uint32_t *__restrict__ val,
                                                         float *__restrict__ dnew, uint32_t *__restrict__ cnt,
                                                         uint32_t *__restrict__ best_idx, float *__restrict__ best_d)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = np[i];
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = tid / kBoxLanes;
+    const uint32_t sub = (uint32_t)(tid % kBoxLanes);
+    const bool live = i < n;
+    const float4 p = np[live ? i : 0];
     const Voxel v = voxel_of(p.x, p.y, p.z, ds);
     uint32_t c = 0, bi = 0xffffffffu;
     float bd = INFINITY;
-    for_points_in_box(g, v.mn, v.mx, [&](const float4 &q, uint32_t idx) {
-        ++c;
-        const float d = dist2(q.x, q.y, q.z, v.mid);
-        if (d < bd || (d == bd && idx < bi)) { bd = d; bi = idx; }
-    });
+    if (live)
+        for_points_in_box(g, v.mn, v.mx, [&](const float4 &q, uint32_t idx, uint32_t) {
+            ++c;
+            const float d = dist2(q.x, q.y, q.z, v.mid);
+            if (d < bd || (d == bd && idx < bi)) { bd = d; bi = idx; }
+        }, sub, kBoxLanes);
+    // group result: counts add up; the best old point is the smallest (distance, index) pair
+#pragma unroll
+    for (int off = kBoxLanes / 2; off > 0; off >>= 1) {
+        c += __shfl_xor(c, off, kBoxLanes);
+        const float od = __shfl_xor(bd, off, kBoxLanes);
+        const uint32_t oi = __shfl_xor(bi, off, kBoxLanes);
+        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if (!live || sub != 0) return;
     key[i] = voxel_key(p.x, p.y, p.z, ds);
     val[i] = (uint32_t)i;
     dnew[i] = dist2(p.x, p.y, p.z, v.mid);
@@ -144,67 +161,75 @@ __global__ __launch_bounds__(256) void add_resolve_kernel(Grid g, const float4 *
                                                           const uint32_t *__restrict__ cnt,
                                                           const uint32_t *__restrict__ best_idx,
                                                           const float *__restrict__ best_d,
-                                                          uint8_t *__restrict__ alive, uint32_t *__restrict__ add_flag,
-                                                          uint32_t *__restrict__ counters)
+                                                          uint8_t *__restrict__ alive, uint8_t *__restrict__ alive_s,
+                                                          uint32_t *__restrict__ add_flag, uint32_t *__restrict__ counters)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    if (s > 0 && skey[s - 1] == skey[s]) return;  // not a segment head
-    // winner among the new points of this voxel: smallest centre distance, the last one on ties
-    uint32_t w = sval[s];
-    float wd = dnew[w];
-    for (int t = s + 1; t < n && skey[t] == skey[s]; ++t) {
-        const uint32_t i = sval[t];
-        if (dnew[i] <= wd) { wd = dnew[i]; w = i; }
-    }
-    const uint32_t c = cnt[w], bi = best_idx[w];
-    const float bd = best_d[w];
-    const float4 pw = np[w];
+    // kBoxLanes lanes per sorted position: all of them take the (cheap) decision, the walk that marks the voxel's old
+    // points is shared between them
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = tid / kBoxLanes;
+    const uint32_t sub = (uint32_t)(tid % kBoxLanes);
+    const bool head = s < n && !(s > 0 && skey[s - 1] == skey[s]);  // first position of a voxel segment
     bool add_new = false, rewrite = false;
-    uint32_t keep = 0xffffffffu;
-    if (c == 0) {
-        add_new = true;
-        rewrite = true;
-    } else if (!(bd < wd)) {  // the new point is not strictly farther: it wins (:506 is a strict "<")
-        add_new = true;
-        rewrite = true;
-    } else {
-        // an old point stays the closest.  The reference rewrites the voxel when it held several points
-        // or when the result "is" the new point within EPSS (ikd_Tree.cpp:514, 1676-1680)
-        const float4 pe = g.porig[bi];
-        const bool same = fabs((double)(pw.x - pe.x)) < 1e-6 && fabs((double)(pw.y - pe.y)) < 1e-6 &&
-                          fabs((double)(pw.z - pe.z)) < 1e-6;
-        keep = bi;
-        rewrite = (c > 1) || same;
-    }
-    if (add_new) add_flag[w] = 1u;
-    // tmp_counter of Add_Points: one atomic per wave (same-address atomics serialise at ~11 ns each)
-    const unsigned long long rw = __ballot(rewrite);
-    if (rewrite && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)rw) - 1)) atomicAdd(&counters[1], (uint32_t)__popcll(rw));
-    if (rewrite) {
-        if (c > (keep != 0xffffffffu ? 1u : 0u)) {
-            const Voxel v = voxel_of(pw.x, pw.y, pw.z, ds);
-            for_points_in_box(g, v.mn, v.mx, [&](const float4 &, uint32_t idx) {
-                if (idx != keep) alive[idx] = 0;
-            });
+    uint32_t keep = 0xffffffffu, w = 0, c = 0;
+    float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (head) {
+        // winner among the new points of this voxel: smallest centre distance, the last one on ties
+        w = sval[s];
+        float wd = dnew[w];
+        for (int t = s + 1; t < n && skey[t] == skey[s]; ++t) {
+            const uint32_t i = sval[t];
+            if (dnew[i] <= wd) { wd = dnew[i]; w = i; }
         }
+        c = cnt[w];
+        const uint32_t bi = best_idx[w];
+        const float bd = best_d[w];
+        pw = np[w];
+        if (c == 0) {
+            add_new = true;
+            rewrite = true;
+        } else if (!(bd < wd)) {  // the new point is not strictly farther: it wins (:506 is a strict "<")
+            add_new = true;
+            rewrite = true;
+        } else {
+            // an old point stays the closest.  The reference rewrites the voxel when it held several points
+            // or when the result "is" the new point within EPSS (ikd_Tree.cpp:514, 1676-1680)
+            const float4 pe = g.porig[bi];
+            const bool same = fabs((double)(pw.x - pe.x)) < 1e-6 && fabs((double)(pw.y - pe.y)) < 1e-6 &&
+                              fabs((double)(pw.z - pe.z)) < 1e-6;
+            keep = bi;
+            rewrite = (c > 1) || same;
+        }
+    }
+    if (add_new && sub == 0) add_flag[w] = 1u;
+    // tmp_counter of Add_Points: one atomic per wave (same-address atomics serialise at ~11 ns each)
+    const unsigned long long rw = __ballot(rewrite && sub == 0);
+    if (rw != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)rw) - 1)) atomicAdd(&counters[1], (uint32_t)__popcll(rw));
+    if (rewrite && c > (keep != 0xffffffffu ? 1u : 0u)) {
+        const Voxel v = voxel_of(pw.x, pw.y, pw.z, ds);
+        for_points_in_box(g, v.mn, v.mx, [&](const float4 &, uint32_t idx, uint32_t pos) {
+            if (idx != keep) { alive[idx] = 0; alive_s[pos] = 0; }  // by caller index and by sorted position
+        }, sub, kBoxLanes);
     }
 }
 
-__global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restrict__ porig, int64_t m,
+// over the SORTED array (it holds the coordinates and the caller index): both alive arrays are written without a gather
+__global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restrict__ pts, int64_t m,
                                                            const float *__restrict__ boxes, int nb,
-                                                           uint8_t *__restrict__ alive, uint32_t *__restrict__ counters)
+                                                           uint8_t *__restrict__ alive, uint8_t *__restrict__ alive_s,
+                                                           uint32_t *__restrict__ counters)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool hit = false;
-    if (i < m && alive[i]) {
-        const float4 p = porig[i];
+    if (j < m && alive_s[j]) {
+        const float4 q = pts[j];
+        const float4 p = make_float4(q.x, q.y, map_point_z(q), 0.0f);
         for (int b = 0; b < nb && !hit; ++b) {
             const float *bx = boxes + 6 * b;
             const float mn[3] = {bx[0], bx[1], bx[2]}, mx[3] = {bx[3], bx[4], bx[5]};
             hit = in_box(p, mn, mx);
         }
-        if (hit) alive[i] = 0;
+        if (hit) { alive_s[j] = 0; alive[map_point_index(q)] = 0; }
     }
     // one atomic per workgroup: a field-of-view trim deletes 1e5..1e6 points, per-point atomics on one
     // address would take milliseconds
@@ -316,7 +341,7 @@ static hipError_t grow(T **p, int64_t *cap, int64_t need, bool keep = false, hip
 
 void free_update(UpdateBuffers &u)
 {
-    void *ptrs[] = {u.alive, u.counters, u.stage, u.key, u.key2, u.val, u.val2, u.dnew, u.cnt, u.best_idx, u.best_d,
+    void *ptrs[] = {u.alive, u.alive_s, u.counters, u.stage, u.key, u.key2, u.val, u.val2, u.dnew, u.cnt, u.best_idx, u.best_d,
                     u.add_flag, u.pos, u.flag32, u.pos_old, u.list, u.tmp, u.boxes, u.cvt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -357,9 +382,11 @@ static hipError_t count_flags(const uint32_t *flag, const uint32_t *pos, int64_t
 
 hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st)
 {
-    S2M_TRY(grow(&u.alive, &u.alive_cap, g.m));
+    S2M_TRY(grow(&u.alive, &u.alive_cap, g.m + 1));
+    S2M_TRY(grow(&u.alive_s, &u.alive_s_cap, g.m + 1));
     if (!u.counters) S2M_TRY(hipMalloc((void **)&u.counters, 64));
-    S2M_TRY(hipMemsetAsync(u.alive, 1, (size_t)std::max<int64_t>(g.m, 1), st));
+    S2M_TRY(hipMemsetAsync(u.alive, 1, (size_t)g.m + 1, st));
+    S2M_TRY(hipMemsetAsync(u.alive_s, 1, (size_t)g.m + 1, st));
     S2M_TRY(hipMemsetAsync(u.counters, 0, 64, st));
     u.stage_n = 0;
     return hipSuccess;
@@ -392,7 +419,7 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
         u.batch_cap = c;
     }
     const int in = (int)n;
-    hipLaunchKernelGGL(add_probe_kernel, dim3(nblk(n)), dim3(256), 0, st, g, np, in, ds, u.key, u.val, u.dnew, u.cnt,
+    hipLaunchKernelGGL(add_probe_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, u.key, u.val, u.dnew, u.cnt,
                        u.best_idx, u.best_d);
     size_t bytes = 0;
     S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 63, st));
@@ -402,8 +429,8 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
     S2M_TRY(hipMemsetAsync(u.add_flag, 0, (size_t)n * sizeof(uint32_t), st));
     uint32_t before = 0;
     S2M_TRY(hipMemcpyAsync(&before, u.counters + 1, 4, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(add_resolve_kernel, dim3(nblk(n)), dim3(256), 0, st, g, np, in, ds, u.key2, u.val2, u.dnew,
-                       u.cnt, u.best_idx, u.best_d, u.alive, u.add_flag, u.counters);
+    hipLaunchKernelGGL(add_resolve_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, u.key2, u.val2, u.dnew,
+                       u.cnt, u.best_idx, u.best_d, u.alive, u.alive_s, u.add_flag, u.counters);
     // winners, in batch order, go to the staging list
     S2M_TRY(scan_u32(u, u.add_flag, u.pos, n, st));
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage);
@@ -427,8 +454,8 @@ hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_hos
     S2M_TRY(hipMemcpyAsync(u.boxes, boxes_host, (size_t)nb * 6 * sizeof(float), hipMemcpyHostToDevice, st));
     uint32_t before = 0, after = 0;
     S2M_TRY(hipMemcpyAsync(&before, u.counters + 2, 4, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.porig, g.m, u.boxes, nb, u.alive,
-                       u.counters);
+    hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.pts, g.m, u.boxes, nb, u.alive,
+                       u.alive_s, u.counters);
     S2M_TRY(hipMemcpyAsync(&after, u.counters + 2, 4, hipMemcpyDeviceToHost, st));
     S2M_TRY(hipStreamSynchronize(st));
     if (n_deleted) *n_deleted = (int64_t)after - before;
@@ -493,8 +520,16 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
     S2M_TRY(scan_u32(u, fb, pb, n, st));
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fa, pa, (int64_t)n, (int64_t)0, la);
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fb, pb, (int64_t)n, (int64_t)0, lb);
-    S2M_TRY(count_flags(fa, pa, n, n_add, st));
-    S2M_TRY(count_flags(fb, pb, n, n_no_down, st));
+    {   // both list lengths with one hand-back
+        uint32_t h[4] = {0, 0, 0, 0};
+        S2M_TRY(hipMemcpyAsync(&h[0], pa + (n - 1), 4, hipMemcpyDeviceToHost, st));
+        S2M_TRY(hipMemcpyAsync(&h[1], fa + (n - 1), 4, hipMemcpyDeviceToHost, st));
+        S2M_TRY(hipMemcpyAsync(&h[2], pb + (n - 1), 4, hipMemcpyDeviceToHost, st));
+        S2M_TRY(hipMemcpyAsync(&h[3], fb + (n - 1), 4, hipMemcpyDeviceToHost, st));
+        S2M_TRY(hipStreamSynchronize(st));
+        *n_add = (int64_t)h[0] + h[1];
+        *n_no_down = (int64_t)h[2] + h[3];
+    }
     *to_add = la;
     *no_down = lb;
     return hipGetLastError();

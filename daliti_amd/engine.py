@@ -19,7 +19,7 @@ MAX_LOG = 64
 ABI_SYMBOLS = [
     "s2m_abi_version", "s2m_config_default", "s2m_strerror", "s2m_create", "s2m_destroy",
     "s2m_last_error", "s2m_set_config", "s2m_set_stream", "s2m_map_build", "s2m_map_size",
-    "s2m_map_info", "s2m_map_share", "s2m_map_add", "s2m_map_delete_boxes", "s2m_map_incremental", "s2m_map_get_points",
+    "s2m_map_info", "s2m_map_last_update", "s2m_map_share", "s2m_map_add", "s2m_map_delete_boxes", "s2m_map_incremental", "s2m_map_get_points",
     "s2m_fov_segment", "s2m_fov_reset",
     "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
@@ -186,6 +186,12 @@ class Engine:
         self._ck(self.lib.s2m_map_info(self.h, info))
         return dict(cell=info[0], origin=(info[1], info[2], info[3]), bricks=int(info[4]),
                     top_entries=int(info[5]), occupied_cells=int(info[6]), mean_per_cell=info[7])
+
+    def map_last_update_merged(self):
+        """True when the last map update was merged into the current grid (no re-sort), False after a rebuild."""
+        m = C.c_int32()
+        self._ck(self.lib.s2m_map_last_update(self.h, C.byref(m)))
+        return bool(m.value)
 
     def map_add(self, xyz, downsample_on, downsample_size=0.5):
         """ikdtree.Add_Points(points, downsample_on); returns voxels rewritten (or n)."""

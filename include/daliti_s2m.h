@@ -94,8 +94,9 @@ int s2m_map_size(const s2m_engine *e, int64_t *m);             /* ikdtree.validn
 /* info[0..7]: cell size, origin xyz, bricks, top-level entries, occupied cells, mean pts/cell */
 int s2m_map_info(const s2m_engine *e, double info[8]);
 
-/* ---- incremental map maintenance (each call ends with a rebuild of the GPU map; neighbour indices
- * of earlier passes become invalid) ------------------------------------------------------------------
+/* ---- incremental map maintenance (each call ends with a new GPU map -- the survivors in index order followed
+ * by the added points, merged into the sorted arrays when the new points fit the current grid, rebuilt
+ * otherwise; neighbour indices of earlier passes become invalid) ------------------------------------
  * ikdtree.Add_Points(points, downsample_on) (ikd-Tree/ikd_Tree.cpp:477-573): with downsample_on the
  * voxel [min, max) of edge downsample_size around each new point keeps only the point closest to
  * its centre (ties: a new point beats an old one, the later of two new ones wins).
@@ -132,6 +133,10 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
 /* ikdtree.flatten(Root_Node, PCL_Storage) (laserMapping.cpp:1170-1175): the current map points,
  * packed xyz, in the engine's index order (the order neighbour indices refer to). */
 int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity_points, int64_t *m);
+/* How the last map_add / map_delete_boxes / fov_segment / map_incremental produced the new map (design, not
+ * reference): *merged = 1 when the update was merged into the sorted arrays of the current grid, 0 when the grid
+ * was rebuilt (first update after s2m_map_build, a new point outside the grid, a density drift). */
+int s2m_map_last_update(const s2m_engine *e, int32_t *merged);
 
 /* The down-sampled body-frame scan feats_down (laserMapping.cpp:775-778).  Resets the per-scan
  * state: point_selected_surf := true (:812), Nearest_Points cleared (:810). */

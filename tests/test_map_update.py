@@ -198,3 +198,63 @@ def test_map_incremental_after_ekf_stop(oracle, small_scene, small_tree):
     assert e.map_size() == om.size()
     assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
     e.close()
+
+
+@pytest.mark.gpu
+def test_merge_update_equals_rebuild(oracle, small_scene, monkeypatch):
+    """An update merged into the sorted arrays of the current grid (s2m_map.hip, merge_update) and the same update
+    through a full rebuild give the same map in the same caller order, and the same exact neighbours afterwards."""
+    from daliti_amd import Engine
+    rs = np.random.RandomState(11)
+    base = small_scene["map"][:12000]
+    steps = [("add", small_scene["map"][12000:15000] + rs.normal(0, 0.05, (3000, 3)).astype(np.float32), True),
+             ("add", small_scene["map"][15000:15600], False),
+             ("del", np.float32([[-10, -10, -1, -1.0, 10, 20]]), None),
+             ("add", small_scene["map"][16000:18000] + rs.normal(0, 0.2, (2000, 3)).astype(np.float32), True),
+             ("del", np.float32([[2.5, -10, -1, 10, 10, 0.05], [0, 0, 0, 1, 1, 1]]), None),
+             # far outside the grid (margin included): this one cannot be merged on either engine
+             ("add", np.float32([[500.0, 400.0, 30.0], [500.2, 400.1, 30.0]]), False),
+             ("add", small_scene["map"][18000:19000], True)]
+    x = small_scene["x_prop"]
+    om = oracle.Map(base)
+    results = {}
+    for mode in ("merge", "rebuild"):
+        if mode == "rebuild":
+            monkeypatch.setenv("S2M_NO_MERGE", "1")
+        else:
+            monkeypatch.delenv("S2M_NO_MERGE", raising=False)
+        e = Engine(cell_size=0.4)
+        e.map_build(base)
+        merged, maps, nns = [], [], []
+        for kind, arg, ds in steps:
+            if kind == "add":
+                e.map_add(arg, ds, 0.5)
+                if mode == "merge":
+                    om.add(arg, ds, 0.5) if ds else om.add(arg, False)
+            else:
+                e.map_delete_boxes(arg)
+                if mode == "merge":
+                    for b in arg:
+                        om.delete_box(b)
+            merged.append(e.map_last_update_merged())
+            maps.append(e.map_points().copy())
+            if mode == "merge":
+                assert (bits(_rows(maps[-1])) == bits(_rows(om.points()))).all(), len(maps)
+            e.scan_set(small_scene["scan"])
+            e.residual_pass(x, True)
+            nns.append(tuple(a.copy() for a in e.get_neighbors()))
+        results[mode] = (merged, maps, nns)
+        e.close()
+    mg, rb = results["merge"], results["rebuild"]
+    # every update merges except the one with points far outside the grid
+    assert mg[0] == [True, True, True, True, True, False, True], mg[0]
+    assert not any(rb[0])
+    for k in range(len(steps)):
+        assert mg[1][k].shape == rb[1][k].shape and (bits(mg[1][k]) == bits(rb[1][k])).all(), k   # same ORDER too
+        assert (mg[2][k][0] == rb[2][k][0]).all() and (bits(mg[2][k][1]) == bits(rb[2][k][1])).all(), k
+    # and the neighbours are the exact ones of the final map
+    pts = mg[1][-1]
+    oi, od, _ = oracle.KdTree(pts).knn5(oracle.body_to_world(x, small_scene["scan"]))
+    idx, d2 = mg[2][-1]
+    near = od[:, 4] <= 5.0
+    assert (bits(d2[near]) == bits(od[near])).all() and (idx[near] == oi[near]).all()
