@@ -7,6 +7,18 @@
 
 namespace s2m {
 
+// ---- a few device words handed to the host: one kernel that writes them into pinned memory + one stream sync.
+// (Every hipMemcpyAsync of 4 bytes is a kernel launch plus ~20 us of turn-around on this stack; the update path
+// used to issue eleven of them.)
+struct Mailbox {
+    uint32_t *h = nullptr;    // pinned host words
+    uint32_t *dev = nullptr;  // the same memory as the device sees it
+};
+constexpr int kMailSlots = 8;
+void free_mailbox(Mailbox &mb);
+// out[i] = *src[i] for i < k (k <= kMailSlots); synchronises the stream
+hipError_t mail_fetch(Mailbox &mb, const uint32_t *const *src, int k, uint32_t *out, hipStream_t st);
+
 // ---- s2m_map.hip : map build (KD_TREE::Build, ikd-Tree/ikd_Tree.cpp:408-423) -------------------
 // bounding box of an AoS cloud (s2m_map.hip): scratch holds the per-workgroup partial boxes + the result
 constexpr int kBboxBlocks = 1024;
@@ -37,6 +49,8 @@ struct MapBuffers {
     int64_t mk_cap = 0, mv_cap = 0;
     unsigned long long *dword = nullptr;  // merge update: bit mask of the removed points per 64 caller indices
     int64_t dword_cap = 0;
+    Mailbox mail;
+    uint32_t *h_stats_dev = nullptr;
     uint32_t *h_stats = nullptr;  // pinned: occupied bricks, then the occupied-cell counters, copied behind a merge
     hipEvent_t stats_event = nullptr;
     bool stats_pending = false;
@@ -74,6 +88,7 @@ struct UpdateBuffers {
     uint32_t *counters = nullptr;  // [1] voxels rewritten (tmp_counter), [2] points deleted by boxes
     float4 *stage = nullptr;       // points to append, in order
     int64_t stage_cap = 0, stage_n = 0;
+    uint32_t deleted_reported = 0;  // box deletes already reported to the caller within this update
     // per-batch scratch
     uint64_t *key = nullptr, *key2 = nullptr;
     uint32_t *val = nullptr, *val2 = nullptr, *cnt = nullptr, *best_idx = nullptr, *add_flag = nullptr, *pos = nullptr;
@@ -90,6 +105,7 @@ struct UpdateBuffers {
     int64_t boxes_cap = 0;
     float4 *cvt = nullptr;         // conversion / classification scratch
     int64_t cvt_cap = 0;
+    Mailbox mail;
 };
 void free_update(UpdateBuffers &u);
 hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st);
@@ -112,6 +128,7 @@ struct VoxelBuffers {
     void *tmp = nullptr;
     size_t tmp_bytes = 0;
     int64_t cap = 0;
+    Mailbox mail;
 };
 void free_voxel(VoxelBuffers &v);
 hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, int64_t n, float leaf, float *ox,

@@ -149,15 +149,18 @@ __global__ __launch_bounds__(256) void brick_head_kernel(int64_t m, const uint64
     }
 }
 
+constexpr int kOccShards = 64;  // occupied-cell counters, 128 B apart (same-address atomics cost ~11 ns each)
+
 struct TopOccupied {
     __host__ __device__ uint32_t operator()(const uint4 &t) const { return t.y != 0u ? 1u : 0u; }
 };
 
 __global__ __launch_bounds__(256) void brick_assign_kernel(int64_t top_entries, uint4 *__restrict__ top,
                                                            const uint32_t *__restrict__ rank,
-                                                           uint32_t *__restrict__ bstart)
+                                                           uint32_t *__restrict__ bstart, uint32_t *__restrict__ occ)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < kOccShards) occ[b * 32] = 0u;  // the occupied-cell counters brick_table_kernel adds to
     if (b >= top_entries) return;
     const uint32_t y = top[b].y;
     if (y == 0u) return;
@@ -166,7 +169,6 @@ __global__ __launch_bounds__(256) void brick_assign_kernel(int64_t top_entries, 
     bstart[id] = y - 1u;
 }
 
-constexpr int kOccShards = 64;  // occupied-cell counters, 128 B apart (same-address atomics cost ~11 ns each)
 
 // bricks_dev: the number of occupied bricks when the host only knows an upper bound for it (merge update)
 __global__ __launch_bounds__(256) void brick_table_kernel(int64_t bricks, const uint32_t *__restrict__ bricks_dev, int64_t m,
@@ -254,6 +256,7 @@ void free_map(MapBuffers &b)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b.h_stats) { (void)hipHostFree(b.h_stats); (void)hipEventDestroy(b.stats_event); }
+    free_mailbox(b.mail);
     b = MapBuffers();
 }
 
@@ -296,6 +299,13 @@ static hipError_t put_sentinels(float4 *pts, int64_t m, hipStream_t st)
     return hipMemcpyAsync(pts + m, sentinel, sizeof(sentinel), hipMemcpyHostToDevice, st);
 }
 
+__global__ void stats_mail_kernel(const uint32_t *__restrict__ bricks, const uint32_t *__restrict__ occ, uint32_t *__restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i == 0) __hip_atomic_store(out, *bricks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (i <= kOccShards) __hip_atomic_store(out + i, occ[(i - 1) * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // occupied-brick and occupied-cell counts of a merge update travel to pinned host memory behind the kernels and
 // are read when somebody asks (resolve_stats): the update itself does not wait for them
 hipError_t resolve_stats(MapBuffers &buf, MapStats &stats)
@@ -304,7 +314,7 @@ hipError_t resolve_stats(MapBuffers &buf, MapStats &stats)
     S2M_TRY(hipEventSynchronize(buf.stats_event));
     buf.stats_pending = false;
     int64_t cells = 0;
-    for (int k = 0; k < kOccShards; ++k) cells += buf.h_stats[1 + k * 32];
+    for (int k = 0; k < kOccShards; ++k) cells += buf.h_stats[1 + k];
     stats.bricks = buf.h_stats[0];
     stats.occupied_cells = cells;
     return hipSuccess;
@@ -330,8 +340,8 @@ static hipError_t build_tables(MapBuffers &buf, const uint64_t *keys, int64_t m,
     int64_t bricks = brick_bound;
     if (!lazy) {
         uint32_t b32 = 0;
-        S2M_TRY(hipMemcpyAsync(&b32, buf.rank + top_entries, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        S2M_TRY(hipStreamSynchronize(st));
+        const uint32_t *src[1] = {buf.rank + top_entries};
+        S2M_TRY(mail_fetch(buf.mail, src, 1, &b32, st));
         bricks = b32;
     }
     if (buf.tab_cap < bricks * kBrickStride || !buf.tab)
@@ -339,18 +349,17 @@ static hipError_t build_tables(MapBuffers &buf, const uint64_t *keys, int64_t m,
     if (buf.bstart_cap < bricks || !buf.bstart)
         S2M_TRY(ensure((void **)&buf.bstart, &buf.bstart_cap, bricks + bricks / 4 + 64, sizeof(uint32_t)));
     hipLaunchKernelGGL(brick_assign_kernel, dim3((unsigned)((top_entries + 255) / 256)), dim3(256), 0, st, top_entries,
-                       buf.top, buf.rank, buf.bstart);
-    S2M_TRY(hipMemsetAsync(buf.counters + 64, 0, kOccShards * 32 * sizeof(uint32_t), st));
+                       buf.top, buf.rank, buf.bstart, buf.counters + 64);
     if (bricks > 0)
         hipLaunchKernelGGL(brick_table_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks,
                            lazy ? buf.rank + top_entries : (const uint32_t *)nullptr, m, keys, buf.bstart, buf.top, buf.tab,
                            buf.counters + 64);
     if (!buf.h_stats) {
-        S2M_TRY(hipHostMalloc((void **)&buf.h_stats, (1 + kOccShards * 32) * sizeof(uint32_t), hipHostMallocDefault));
+        S2M_TRY(hipHostMalloc((void **)&buf.h_stats, (1 + kOccShards) * sizeof(uint32_t), hipHostMallocMapped));
+        S2M_TRY(hipHostGetDevicePointer((void **)&buf.h_stats_dev, buf.h_stats, 0));
         S2M_TRY(hipEventCreateWithFlags(&buf.stats_event, hipEventDisableTiming));
     }
-    S2M_TRY(hipMemcpyAsync(buf.h_stats, buf.rank + top_entries, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    S2M_TRY(hipMemcpyAsync(buf.h_stats + 1, buf.counters + 64, kOccShards * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(stats_mail_kernel, dim3(1), dim3(128), 0, st, buf.rank + top_entries, buf.counters + 64, buf.h_stats_dev);
     S2M_TRY(hipEventRecord(buf.stats_event, st));
     buf.stats_pending = true;
     if (!lazy) {
@@ -482,9 +491,11 @@ hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, Ma
 // every word (312 KB + 625 KB at 5 M points: L2-resident, so renumbering a caller index costs two cache hits
 // instead of a gather from a 20 MB array)
 __global__ __launch_bounds__(256) void dead_words_kernel(int64_t m, const uint8_t *__restrict__ alive,
-                                                         unsigned long long *__restrict__ word, uint32_t *__restrict__ cnt)
+                                                         unsigned long long *__restrict__ word, uint32_t *__restrict__ cnt,
+                                                         uint32_t *__restrict__ outside_flag)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { cnt[(m + 63) >> 6] = 0u; *outside_flag = 0u; }  // the scan's spare element; merge_newkey_kernel's flag
     const bool dead = i < m && alive[i] == 0;
     const unsigned long long w = __ballot(dead);
     if ((threadIdx.x & 63) == 0 && (i >> 6) <= ((m - 1) >> 6)) {
@@ -630,12 +641,11 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     }
 
     // dead rank over the caller indices (element `words` of the counts is zero: the prefix there is the total)
-    S2M_TRY(hipMemsetAsync(dcnt + words, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(dead_words_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, alive, buf.dword, dcnt);
+    hipLaunchKernelGGL(dead_words_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, alive, buf.dword, dcnt,
+                       buf.counters + 8);
     size_t t = buf.sort_tmp_bytes;
     S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
     uint32_t dead = 0, outside = 0;
-    S2M_TRY(hipMemcpyAsync(&dead, dprefix + words, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(dead_pack_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, words, buf.dword, dprefix, rank);
     // announcements of the new points among the old keys
     S2M_TRY(hipMemsetAsync(c, 0, (size_t)(m + 1) * sizeof(uint32_t), st));
@@ -643,10 +653,8 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     uint32_t *nv_sorted = buf.mv, *lb = buf.mv + n_new;
     if (n > 0) {
         // keys in the CURRENT grid: keys / vals [0, n) unsorted, [n, 2n) sorted (both free until the merge writes them)
-        S2M_TRY(hipMemsetAsync(buf.counters + 8, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(merge_newkey_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals,
                            buf.counters + 8);
-        S2M_TRY(hipMemcpyAsync(&outside, buf.counters + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         t = buf.sort_tmp_bytes;
         S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, buf.keys + n_new, buf.vals, buf.vals + n_new, (size_t)n_new, 0, 64, st));
         S2M_TRY(hipMemcpyAsync(nk_sorted, buf.keys + n_new, (size_t)n_new * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
@@ -655,7 +663,13 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     }
     t = buf.sort_tmp_bytes;
     S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, merged_in, S, 0u, (size_t)m + 1, rocprim::plus<uint32_t>(), st));
-    S2M_TRY(hipStreamSynchronize(st));  // the one hand-back: number of dead, "a new point lies outside the grid"
+    {   // the one hand-back: number of dead, "a new point lies outside the grid"
+        const uint32_t *src[2] = {dprefix + words, buf.counters + 8};
+        uint32_t v[2] = {0, 0};
+        S2M_TRY(mail_fetch(buf.mail, src, 2, v, st));
+        dead = v[0];
+        outside = v[1];
+    }
     if (outside) return hipSuccess;     // full rebuild (with a fresh margin)
     const int64_t survivors = m - (int64_t)dead;
     const int64_t m_new = survivors + n_new;

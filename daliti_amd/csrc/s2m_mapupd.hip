@@ -317,7 +317,39 @@ __global__ __launch_bounds__(256) void float4_to_xyz_kernel(const float4 *__rest
     }
 }
 
+struct MailArgs {
+    const uint32_t *src[kMailSlots];
+    int k;
+};
+__global__ void mail_kernel(MailArgs a, uint32_t *__restrict__ out)
+{
+    const int i = threadIdx.x;
+    if (i < a.k) __hip_atomic_store(out + i, *a.src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
+void free_mailbox(Mailbox &mb)
+{
+    if (mb.h) (void)hipHostFree(mb.h);
+    mb = Mailbox();
+}
+
+hipError_t mail_fetch(Mailbox &mb, const uint32_t *const *src, int k, uint32_t *out, hipStream_t st)
+{
+    if (k <= 0 || k > kMailSlots) return hipErrorInvalidValue;
+    if (!mb.h) {
+        S2M_TRY(hipHostMalloc((void **)&mb.h, 64 * sizeof(uint32_t), hipHostMallocMapped));
+        S2M_TRY(hipHostGetDevicePointer((void **)&mb.dev, mb.h, 0));
+    }
+    MailArgs a;
+    for (int i = 0; i < kMailSlots; ++i) a.src[i] = src[i < k ? i : 0];
+    a.k = k;
+    hipLaunchKernelGGL(mail_kernel, dim3(1), dim3(64), 0, st, a, mb.dev);
+    S2M_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < k; ++i) out[i] = mb.h[i];
+    return hipGetLastError();
+}
+
 static inline int nblk(int64_t n) { return (int)((n + 255) / 256); }
 
 template <class T>
@@ -345,6 +377,7 @@ void free_update(UpdateBuffers &u)
                     u.add_flag, u.pos, u.flag32, u.pos_old, u.list, u.tmp, u.boxes, u.cvt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    free_mailbox(u.mail);
     u = UpdateBuffers();
 }
 
@@ -368,15 +401,14 @@ static hipError_t scan_u32(UpdateBuffers &u, const uint32_t *in, uint32_t *out, 
 }
 
 // number of set flags = pos[n-1] + flag[n-1]
-static hipError_t count_flags(const uint32_t *flag, const uint32_t *pos, int64_t n, int64_t *out, hipStream_t st)
+static hipError_t count_flags(UpdateBuffers &u, const uint32_t *flag, const uint32_t *pos, int64_t n, int64_t *out, hipStream_t st)
 {
     *out = 0;
     if (n <= 0) return hipSuccess;
-    uint32_t a = 0, b = 0;
-    S2M_TRY(hipMemcpyAsync(&a, pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    S2M_TRY(hipMemcpyAsync(&b, flag + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    S2M_TRY(hipStreamSynchronize(st));
-    *out = (int64_t)a + b;
+    const uint32_t *src[2] = {pos + (n - 1), flag + (n - 1)};
+    uint32_t v[2] = {0, 0};
+    S2M_TRY(mail_fetch(u.mail, src, 2, v, st));
+    *out = (int64_t)v[0] + v[1];
     return hipSuccess;
 }
 
@@ -389,6 +421,7 @@ hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st)
     S2M_TRY(hipMemsetAsync(u.alive_s, 1, (size_t)g.m + 1, st));
     S2M_TRY(hipMemsetAsync(u.counters, 0, 64, st));
     u.stage_n = 0;
+    u.deleted_reported = 0;
     return hipSuccess;
 }
 
@@ -428,20 +461,20 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
     S2M_TRY(rocprim::radix_sort_pairs(u.tmp, b2, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 63, st));
     S2M_TRY(hipMemsetAsync(u.add_flag, 0, (size_t)n * sizeof(uint32_t), st));
     uint32_t before = 0;
-    S2M_TRY(hipMemcpyAsync(&before, u.counters + 1, 4, hipMemcpyDeviceToHost, st));
+    if (n_added) {  // tmp_counter of Add_Points before this batch (zero unless several batches share one update)
+        const uint32_t *src[1] = {u.counters + 1};
+        S2M_TRY(mail_fetch(u.mail, src, 1, &before, st));
+    }
     hipLaunchKernelGGL(add_resolve_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, u.key2, u.val2, u.dnew,
                        u.cnt, u.best_idx, u.best_d, u.alive, u.alive_s, u.add_flag, u.counters);
     // winners, in batch order, go to the staging list
     S2M_TRY(scan_u32(u, u.add_flag, u.pos, n, st));
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage);
-    int64_t won = 0;
-    S2M_TRY(count_flags(u.add_flag, u.pos, n, &won, st));
-    u.stage_n += won;
-    if (n_added) {
-        uint32_t after = 0;
-        S2M_TRY(hipMemcpy(&after, u.counters + 1, 4, hipMemcpyDeviceToHost));
-        *n_added = (int64_t)after - before;  // tmp_counter of Add_Points
-    }
+    const uint32_t *src[3] = {u.pos + (n - 1), u.add_flag + (n - 1), u.counters + 1};
+    uint32_t v[3] = {0, 0, 0};
+    S2M_TRY(mail_fetch(u.mail, src, 3, v, st));
+    u.stage_n += (int64_t)v[0] + v[1];
+    if (n_added) *n_added = (int64_t)v[2] - before;  // tmp_counter of Add_Points
     return hipGetLastError();
 }
 
@@ -452,13 +485,15 @@ hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_hos
     if (nb <= 0 || g.m == 0) return hipSuccess;
     S2M_TRY(grow(&u.boxes, &u.boxes_cap, (int64_t)nb * 6));
     S2M_TRY(hipMemcpyAsync(u.boxes, boxes_host, (size_t)nb * 6 * sizeof(float), hipMemcpyHostToDevice, st));
-    uint32_t before = 0, after = 0;
-    S2M_TRY(hipMemcpyAsync(&before, u.counters + 2, 4, hipMemcpyDeviceToHost, st));
+    // counters[2] is zero at update_begin and only this entry point adds to it: the count after the launch, minus
+    // what earlier calls of the same update reported
     hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.pts, g.m, u.boxes, nb, u.alive,
                        u.alive_s, u.counters);
-    S2M_TRY(hipMemcpyAsync(&after, u.counters + 2, 4, hipMemcpyDeviceToHost, st));
-    S2M_TRY(hipStreamSynchronize(st));
-    if (n_deleted) *n_deleted = (int64_t)after - before;
+    const uint32_t *src[1] = {u.counters + 2};
+    uint32_t after = 0;
+    S2M_TRY(mail_fetch(u.mail, src, 1, &after, st));
+    if (n_deleted) *n_deleted = (int64_t)after - u.deleted_reported;
+    u.deleted_reported = after;
     return hipGetLastError();
 }
 
@@ -475,7 +510,7 @@ hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStr
         }
         hipLaunchKernelGGL(flags_to_u32_kernel, dim3(nblk(g.m)), dim3(256), 0, st, u.alive, g.m, u.flag32);
         S2M_TRY(scan_u32(u, u.flag32, u.pos_old, g.m, st));
-        S2M_TRY(count_flags(u.flag32, u.pos_old, g.m, &survivors, st));
+        S2M_TRY(count_flags(u, u.flag32, u.pos_old, g.m, &survivors, st));
     }
     S2M_TRY(grow(&u.list, &u.list_cap, survivors + u.stage_n));
     if (g.m > 0)
@@ -521,12 +556,9 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fa, pa, (int64_t)n, (int64_t)0, la);
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fb, pb, (int64_t)n, (int64_t)0, lb);
     {   // both list lengths with one hand-back
+        const uint32_t *src[4] = {pa + (n - 1), fa + (n - 1), pb + (n - 1), fb + (n - 1)};
         uint32_t h[4] = {0, 0, 0, 0};
-        S2M_TRY(hipMemcpyAsync(&h[0], pa + (n - 1), 4, hipMemcpyDeviceToHost, st));
-        S2M_TRY(hipMemcpyAsync(&h[1], fa + (n - 1), 4, hipMemcpyDeviceToHost, st));
-        S2M_TRY(hipMemcpyAsync(&h[2], pb + (n - 1), 4, hipMemcpyDeviceToHost, st));
-        S2M_TRY(hipMemcpyAsync(&h[3], fb + (n - 1), 4, hipMemcpyDeviceToHost, st));
-        S2M_TRY(hipStreamSynchronize(st));
+        S2M_TRY(mail_fetch(u.mail, src, 4, h, st));
         *n_add = (int64_t)h[0] + h[1];
         *n_no_down = (int64_t)h[2] + h[3];
     }

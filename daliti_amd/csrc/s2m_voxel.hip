@@ -85,6 +85,7 @@ void free_voxel(VoxelBuffers &v)
     void *ptrs[] = {v.key, v.key2, v.val, v.val2, v.head, v.pos, v.tmp, v.box};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    free_mailbox(v.mail);
     v = VoxelBuffers();
 }
 
@@ -140,11 +141,10 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
     S2M_TRY(rocprim::exclusive_scan(v.tmp, t2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
     hipLaunchKernelGGL(vx_centroid_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, v.key2, v.val2, v.head, v.pos,
                        ox, oy, oz);
-    uint32_t a = 0, b = 0;
-    S2M_TRY(hipMemcpyAsync(&a, v.pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    S2M_TRY(hipMemcpyAsync(&b, v.head + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    S2M_TRY(hipStreamSynchronize(st));
-    *n_out = (int64_t)a + b;
+    const uint32_t *src[2] = {v.pos + (n - 1), v.head + (n - 1)};
+    uint32_t ab[2] = {0, 0};
+    S2M_TRY(mail_fetch(v.mail, src, 2, ab, st));
+    *n_out = (int64_t)ab[0] + ab[1];
     return hipGetLastError();
 }
 
