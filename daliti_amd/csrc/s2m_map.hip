@@ -671,6 +671,10 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
         outside = v[1];
     }
     if (outside) return hipSuccess;     // full rebuild (with a fresh margin)
+    if (dead == 0 && n_new == 0) {      // nothing was removed and nothing is added: the map stands as it is
+        merged = true;
+        return hipSuccess;
+    }
     const int64_t survivors = m - (int64_t)dead;
     const int64_t m_new = survivors + n_new;
     if (m_new > buf.scratch_cap || m_new >= ((int64_t)1 << 31) || m_new == 0) return hipSuccess;

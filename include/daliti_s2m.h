@@ -88,7 +88,8 @@ int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride_floats, int64_
  * so K scans can be registered concurrently -- K handles, K streams, K host threads -- against one
  * HBM-resident map.  The borrower never modifies the map (S2M_ERR_STATE from the update entry points);
  * `owner` must stay alive, on the same device, and must not rebuild or update its map while a borrower
- * has a pass in flight.  s2m_map_build on `e` ends the loan. */
+ * has a pass in flight; after an update of the owner's map the borrower calls s2m_map_share again to see it (an
+ * update writes the other half of the owner's double buffers).  s2m_map_build on `e` ends the loan. */
 int s2m_map_share(s2m_engine *e, const s2m_engine *owner);
 int s2m_map_size(const s2m_engine *e, int64_t *m);             /* ikdtree.validnum(), :794 */
 /* info[0..7]: cell size, origin xyz, bricks, top-level entries, occupied cells, mean pts/cell */
