@@ -22,6 +22,7 @@
 namespace s2m {
 void launch_deinterleave(const float *src, int64_t stride, int64_t n, float *sx, float *sy, float *sz,
                          hipStream_t st);
+void launch_scan_reset(int64_t n, uint8_t *sel, uint8_t *eff, uint8_t *flags, hipStream_t st);
 }
 
 using namespace s2m;
@@ -673,9 +674,7 @@ int scan_reserve(s2m_engine *e, int64_t n)
 // point_selected_surf(feats_down_size, true) (:812); neighbours invalid until the first rematch
 int scan_reset(s2m_engine *e, int64_t n)
 {
-    S2M_HIP(e, hipMemsetAsync(e->d_sel, 1, (size_t)std::max<int64_t>(n, 1), e->stream));
-    S2M_HIP(e, hipMemsetAsync(e->d_eff, 0, (size_t)std::max<int64_t>(n, 1), e->stream));
-    S2M_HIP(e, hipMemsetAsync(e->d_flags, 0, (size_t)std::max<int64_t>(n, 1), e->stream));
+    launch_scan_reset(n, e->d_sel, e->d_eff, e->d_flags, e->stream);
     S2M_HIP(e, hipStreamSynchronize(e->stream));  // the host buffer may be reused by the caller now
     e->n = n;
     e->scan_ready = true;

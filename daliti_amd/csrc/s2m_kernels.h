@@ -23,7 +23,7 @@ hipError_t mail_fetch(Mailbox &mb, const uint32_t *const *src, int k, uint32_t *
 // bounding box of an AoS cloud (s2m_map.hip): scratch holds the per-workgroup partial boxes + the result
 constexpr int kBboxBlocks = 1024;
 constexpr int kBboxScratchFloats = (kBboxBlocks + 1) * 6;
-hipError_t cloud_bbox(const float *xyz, int64_t stride, int64_t n, float *scratch, float lo[3], float hi[3],
+hipError_t cloud_bbox(const float *xyz, int64_t stride, int64_t n, float *scratch, Mailbox &mail, float lo[3], float hi[3],
                       hipStream_t st);
 
 constexpr int kSentinelPoints = 8;  // pts[m .. m+8): padding targets of the search kernels' point batches

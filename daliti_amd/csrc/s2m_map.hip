@@ -86,18 +86,20 @@ __global__ __launch_bounds__(256) void bbox_final_kernel(const float *__restrict
     block_minmax(mn, mx, out6);
 }
 
-hipError_t cloud_bbox(const float *xyz, int64_t stride, int64_t n, float *scratch, float lo[3], float hi[3],
+hipError_t cloud_bbox(const float *xyz, int64_t stride, int64_t n, float *scratch, Mailbox &mail, float lo[3], float hi[3],
                       hipStream_t st)
 {
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, kBboxBlocks);
     float *out = scratch + (int64_t)kBboxBlocks * 6;
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, n, scratch);
     hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(256), 0, st, scratch, blocks, out);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(out);
+    const uint32_t *src[6] = {w, w + 1, w + 2, w + 3, w + 4, w + 5};
+    uint32_t bits[6];
+    hipError_t e = mail_fetch(mail, src, 6, bits, st);
+    if (e != hipSuccess) return e;
     float box[6];
-    hipError_t e = hipMemcpyAsync(box, out, sizeof(box), hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(st);
-    if (e != hipSuccess) return e;
+    std::memcpy(box, bits, sizeof(box));
     for (int k = 0; k < 3; ++k) { lo[k] = box[k]; hi[k] = box[3 + k]; }
     return hipGetLastError();
 }
@@ -449,7 +451,7 @@ hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, Ma
     float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
     if (m > 0) {
         if (!buf.bbox) S2M_TRY(hipMalloc((void **)&buf.bbox, kBboxScratchFloats * sizeof(float)));
-        S2M_TRY(cloud_bbox(xyz, stride, m, buf.bbox, lo, hi, st));
+        S2M_TRY(cloud_bbox(xyz, stride, m, buf.bbox, buf.mail, lo, hi, st));
     }
     // margin of an incrementally maintained map: an eighth of the longest extent, 2 to 64 bricks
     auto margin_for = [&](float c) {
@@ -715,6 +717,21 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const float *__restri
     sx[i] = src[i * stride];
     sy[i] = src[i * stride + 1];
     sz[i] = src[i * stride + 2];
+}
+
+// per-scan state of a new scan in one launch: point_selected_surf = true (laserMapping.cpp:812), nothing effective,
+// no flags (three memsets are six launches on this stack)
+__global__ __launch_bounds__(256) void scan_reset_kernel(int64_t n, uint8_t *__restrict__ sel, uint8_t *__restrict__ eff,
+                                                         uint8_t *__restrict__ flags)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { sel[i] = 1; eff[i] = 0; flags[i] = 0; }
+}
+
+void launch_scan_reset(int64_t n, uint8_t *sel, uint8_t *eff, uint8_t *flags, hipStream_t st)
+{
+    const int64_t m = std::max<int64_t>(n, 1);
+    hipLaunchKernelGGL(scan_reset_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, sel, eff, flags);
 }
 
 void launch_deinterleave(const float *src, int64_t stride, int64_t n, float *sx, float *sy, float *sz, hipStream_t st)

@@ -109,7 +109,7 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
     if (!v.box) S2M_TRY(hipMalloc((void **)&v.box, kBboxScratchFloats * sizeof(float)));
     const int nb = (int)((n + 255) / 256);
     float blo[3], bhi[3];
-    S2M_TRY(cloud_bbox(xyz, stride, n, v.box, blo, bhi, st));
+    S2M_TRY(cloud_bbox(xyz, stride, n, v.box, v.mail, blo, bhi, st));
     VoxelDims d;
     d.inv_leaf = 1.0f / leaf;  // inverse_leaf_size_ = 1 / leaf_size_
     int64_t div[3];
