@@ -631,11 +631,16 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     uint32_t *c = buf.work_a, *S = buf.work_b;
     auto merged_in = rocprim::make_transform_iterator(rocprim::make_zip_iterator(rocprim::make_tuple(alive_s, static_cast<const uint32_t *>(c))),
                                                       AlivePlusNew());
+    unsigned kbits = 10;  // (brick << 9 | cell) of this grid
+    {
+        const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
+        while (kbits < 64 && ((int64_t)1 << (kbits - 9)) < top_entries) ++kbits;
+    }
     size_t tmp = 0, tmp2 = 0, tmp3 = 0;
     S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
     S2M_TRY(rocprim::exclusive_scan(nullptr, tmp2, merged_in, S, 0u, (size_t)m + 1, rocprim::plus<uint32_t>(), st));
     if (n > 0)
-        S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, buf.keys, buf.keys + n_new, buf.vals, buf.vals + n_new, (size_t)n_new, 0, 64, st));
+        S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, buf.keys, buf.keys + n_new, buf.vals, buf.vals + n_new, (size_t)n_new, 0, kbits, st));
     S2M_TRY(ensure_sort_tmp(buf, std::max(std::max(tmp, tmp2), tmp3)));
     if (n > 0) {
         S2M_TRY(ensure((void **)&buf.mk, &buf.mk_cap, n_new, sizeof(uint64_t)));
@@ -658,7 +663,7 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
         hipLaunchKernelGGL(merge_newkey_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals,
                            buf.counters + 8);
         t = buf.sort_tmp_bytes;
-        S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, buf.keys + n_new, buf.vals, buf.vals + n_new, (size_t)n_new, 0, 64, st));
+        S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, buf.keys + n_new, buf.vals, buf.vals + n_new, (size_t)n_new, 0, kbits, st));
         S2M_TRY(hipMemcpyAsync(nk_sorted, buf.keys + n_new, (size_t)n_new * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
         S2M_TRY(hipMemcpyAsync(nv_sorted, buf.vals + n_new, (size_t)n_new * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(merge_lb_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, buf.keys_alt, m, lb, c);

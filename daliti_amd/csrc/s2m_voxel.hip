@@ -124,8 +124,11 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
     d.mul1 = div[0];
     d.mul2 = div[0] * div[1];
     hipLaunchKernelGGL(vx_key_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, d, v.key, v.val);
+    // the voxel index is below div0 * div1 * div2: sort only the bits it can have
+    unsigned kbits = 1;
+    while (kbits < 32 && ((int64_t)1 << kbits) < div[0] * div[1] * div[2]) ++kbits;
     size_t bytes = 0, b2 = 0;
-    S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, v.key, v.key2, v.val, v.val2, (size_t)n, 0, 32, st));
+    S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, v.key, v.key2, v.val, v.val2, (size_t)n, 0, kbits, st));
     S2M_TRY(rocprim::exclusive_scan(nullptr, b2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
     bytes = std::max(bytes, b2);
     if (bytes > v.tmp_bytes) {
@@ -135,7 +138,7 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
         v.tmp_bytes = bytes;
     }
     size_t t1 = v.tmp_bytes;
-    S2M_TRY(rocprim::radix_sort_pairs(v.tmp, t1, v.key, v.key2, v.val, v.val2, (size_t)n, 0, 32, st));
+    S2M_TRY(rocprim::radix_sort_pairs(v.tmp, t1, v.key, v.key2, v.val, v.val2, (size_t)n, 0, kbits, st));
     hipLaunchKernelGGL(vx_head_kernel, dim3(nb), dim3(256), 0, st, v.key2, n, v.head);
     size_t t2 = v.tmp_bytes;
     S2M_TRY(rocprim::exclusive_scan(v.tmp, t2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
