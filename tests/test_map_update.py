@@ -258,3 +258,59 @@ def test_merge_update_equals_rebuild(oracle, small_scene, monkeypatch):
     idx, d2 = mg[2][-1]
     near = od[:, 4] <= 5.0
     assert (bits(d2[near]) == bits(od[near])).all() and (idx[near] == oi[near]).all()
+
+
+@pytest.mark.gpu
+def test_merge_update_random_sequence(oracle, monkeypatch):
+    """Twenty random updates (downsampled adds, plain adds, box deletes, points beyond the grid) on a small map:
+    merged and rebuilt maps agree in order after every step, and with the oracle as sets."""
+    from daliti_amd import Engine
+    rs = np.random.RandomState(23)
+    base = rs.uniform(-6, 6, (6000, 3)).astype(np.float32)
+    base[:, 2] = np.float32(0.02) * rs.standard_normal(6000).astype(np.float32)     # a floor
+    steps = []
+    for k in range(20):
+        kind = rs.randint(4)
+        if kind == 0:
+            c = rs.uniform(-7, 7, 3); c[2] = 0
+            pts = (c + rs.normal(0, [1.5, 1.5, 0.05], (rs.randint(1, 1500), 3))).astype(np.float32)
+            steps.append(("add", pts, True))
+        elif kind == 1:
+            pts = rs.uniform(-8, 8, (rs.randint(1, 200), 3)).astype(np.float32) * np.float32([1, 1, 0.05])
+            steps.append(("add", pts, False))
+        elif kind == 2:
+            lo = rs.uniform(-6, 4, 3); lo[2] = -1
+            steps.append(("del", np.float32([np.r_[lo, lo + [rs.uniform(0.2, 3), rs.uniform(0.2, 3), 2]]]), None))
+        else:
+            steps.append(("add", (rs.uniform(-1, 1, (3, 3)) + [40.0 + 10 * k, -30.0, 2.0]).astype(np.float32), False))
+    om = oracle.Map(base)
+    maps = {}
+    for mode in ("merge", "rebuild"):
+        if mode == "rebuild":
+            monkeypatch.setenv("S2M_NO_MERGE", "1")
+        else:
+            monkeypatch.delenv("S2M_NO_MERGE", raising=False)
+        e = Engine(cell_size=0.4)
+        e.map_build(base)
+        seq, merged = [], 0
+        for kind, arg, ds in steps:
+            if kind == "add":
+                e.map_add(arg, ds, 0.5)
+                if mode == "merge":
+                    om.add(arg, True, 0.5) if ds else om.add(arg, False)
+            else:
+                e.map_delete_boxes(arg)
+                if mode == "merge":
+                    for b in arg:
+                        om.delete_box(b)
+            merged += e.map_last_update_merged()
+            seq.append(e.map_points().copy())
+            if mode == "merge":
+                assert e.map_size() == om.size(), len(seq)
+                assert (bits(_rows(seq[-1])) == bits(_rows(om.points()))).all(), len(seq)
+        maps[mode] = seq
+        if mode == "merge":
+            assert 8 <= merged < 20          # both paths were exercised
+        e.close()
+    for k, (a, b) in enumerate(zip(maps["merge"], maps["rebuild"])):
+        assert a.shape == b.shape and (bits(a) == bits(b)).all(), k
