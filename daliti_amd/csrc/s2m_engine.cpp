@@ -49,6 +49,7 @@ struct s2m_engine {
     float local_map[6] = {0, 0, 0, 0, 0, 0};
     bool local_map_init = false;
     float built_cell = 0.0f;  // cell size of the current grid (kept across incremental rebuilds)
+    Mailbox mail;                   // stream waits of the per-frame entry points (polled, not hipStreamSynchronize)
     bool no_merge = false;          // S2M_NO_MERGE=1: every update rebuilds the grid from scratch (A/B and tests)
     bool last_update_merged = false;
     Grid grid{};
@@ -345,6 +346,7 @@ int s2m_destroy(s2m_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     free_map(e->map);
     free_update(e->upd);
+    free_mailbox(e->mail);
     free_voxel(e->vox);
     free_undist(e->und);
     comm_destroy(e->comm);
@@ -675,7 +677,7 @@ int scan_reserve(s2m_engine *e, int64_t n)
 int scan_reset(s2m_engine *e, int64_t n)
 {
     launch_scan_reset(n, e->d_sel, e->d_eff, e->d_flags, e->stream);
-    S2M_HIP(e, hipStreamSynchronize(e->stream));  // the host buffer may be reused by the caller now
+    S2M_HIP(e, mail_wait(e->mail, e->stream));  // the host buffer may be reused by the caller now
     e->n = n;
     e->scan_ready = true;
     e->pass_done = false;

@@ -13,11 +13,15 @@ namespace s2m {
 struct Mailbox {
     uint32_t *h = nullptr;    // pinned host words
     uint32_t *dev = nullptr;  // the same memory as the device sees it
+    uint32_t seq = 0;         // word 0 of the buffer carries the sequence number of the last fetch
 };
 constexpr int kMailSlots = 8;
 void free_mailbox(Mailbox &mb);
-// out[i] = *src[i] for i < k (k <= kMailSlots); synchronises the stream
+// out[i] = *src[i] for i < k (k <= kMailSlots); returns when the kernel -- and with it everything queued on the
+// stream before it -- has finished (the host polls the pinned sequence word instead of synchronising the stream)
 hipError_t mail_fetch(Mailbox &mb, const uint32_t *const *src, int k, uint32_t *out, hipStream_t st);
+// the same wait without a payload: returns when everything queued on the stream has finished
+hipError_t mail_wait(Mailbox &mb, hipStream_t st);
 
 // ---- s2m_map.hip : map build (KD_TREE::Build, ikd-Tree/ikd_Tree.cpp:408-423) -------------------
 // bounding box of an AoS cloud (s2m_map.hip): scratch holds the per-workgroup partial boxes + the result
