@@ -621,7 +621,7 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     merged = false;
     const int64_t m = g.m;
     if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || m > buf.scratch_cap) return hipSuccess;
-    if (n_new >= ((int64_t)1 << 30) || 2 * n_new > buf.scratch_cap) return hipSuccess;
+    if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return hipSuccess;
     const int n = (int)n_new;
     const int64_t words = (m + 63) / 64;
     // work_c: [dead counts per word | their exclusive prefix]; mv: [stage positions | lower bounds] of the new points
@@ -640,7 +640,7 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
     S2M_TRY(rocprim::exclusive_scan(nullptr, tmp2, merged_in, S, 0u, (size_t)m + 1, rocprim::plus<uint32_t>(), st));
     if (n > 0)
-        S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, buf.keys, buf.keys + n_new, buf.vals, buf.vals + n_new, (size_t)n_new, 0, kbits, st));
+        S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, buf.keys, buf.keys, buf.vals, buf.vals, (size_t)n_new, 0, kbits, st));
     S2M_TRY(ensure_sort_tmp(buf, std::max(std::max(tmp, tmp2), tmp3)));
     if (n > 0) {
         S2M_TRY(ensure((void **)&buf.mk, &buf.mk_cap, n_new, sizeof(uint64_t)));
@@ -659,13 +659,11 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     uint64_t *nk_sorted = buf.mk;
     uint32_t *nv_sorted = buf.mv, *lb = buf.mv + n_new;
     if (n > 0) {
-        // keys in the CURRENT grid: keys / vals [0, n) unsorted, [n, 2n) sorted (both free until the merge writes them)
+        // keys in the CURRENT grid (keys / vals are free until the merge writes them), sorted into the small arrays
         hipLaunchKernelGGL(merge_newkey_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals,
                            buf.counters + 8);
         t = buf.sort_tmp_bytes;
-        S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, buf.keys + n_new, buf.vals, buf.vals + n_new, (size_t)n_new, 0, kbits, st));
-        S2M_TRY(hipMemcpyAsync(nk_sorted, buf.keys + n_new, (size_t)n_new * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-        S2M_TRY(hipMemcpyAsync(nv_sorted, buf.vals + n_new, (size_t)n_new * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, nk_sorted, buf.vals, nv_sorted, (size_t)n_new, 0, kbits, st));
         hipLaunchKernelGGL(merge_lb_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, buf.keys_alt, m, lb, c);
     }
     t = buf.sort_tmp_bytes;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
                                                             const int32_t *__restrict__ nn_idx,
                                                             const float4 *__restrict__ porig, int have_nn, double fs,
                                                             float4 *__restrict__ pw_out,
-                                                            uint32_t *__restrict__ f_add, uint32_t *__restrict__ f_nodown)
+                                                            unsigned long long *__restrict__ cls_out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -297,8 +297,23 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
             cls = need_add ? 1 : 0;
         }
     }
-    f_add[i] = cls == 1 ? 1u : 0u;
-    f_nodown[i] = cls == 2 ? 1u : 0u;
+    // both list flags in one word (low half: PointToAdd, high half: PointNoNeedDownsample): one scan gives both positions
+    cls_out[i] = cls == 1 ? 1ull : (cls == 2 ? (1ull << 32) : 0ull);
+}
+
+// list A (low halves) and list B (high halves) of the packed flags / positions
+__global__ __launch_bounds__(256) void scatter2_kernel(const float4 *__restrict__ src, const unsigned long long *__restrict__ flag,
+                                                       const unsigned long long *__restrict__ pos, int64_t n,
+                                                       float4 *__restrict__ out_a, float4 *__restrict__ out_b)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long f = flag[i];
+    if (f == 0ull) return;
+    float4 p = src[i];
+    p.w = 0.0f;
+    const unsigned long long q = pos[i];
+    if (f & 1ull) out_a[(uint32_t)q] = p; else out_b[(uint32_t)(q >> 32)] = p;
 }
 
 __global__ __launch_bounds__(256) void xyz_to_float4_kernel(const float *__restrict__ xyz, int64_t stride, int64_t n,
@@ -581,15 +596,20 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
         u.batch_cap = c;
     }
     float4 *pw = u.cvt, *la = u.cvt + n, *lb = u.cvt + 2 * (int64_t)n;
-    uint32_t *fa = u.val, *fb = u.val2, *pa = u.cnt, *pb = u.best_idx;  // reused as flag / position arrays
+    unsigned long long *fl = reinterpret_cast<unsigned long long *>(u.key), *ps = reinterpret_cast<unsigned long long *>(u.key2);
     hipLaunchKernelGGL(incr_classify_kernel, dim3(nblk(n)), dim3(256), 0, st, pose, sx, sy, sz, n, nn_idx, g.porig,
-                       have_nn ? 1 : 0, fs, pw, fa, fb);
-    S2M_TRY(scan_u32(u, fa, pa, n, st));
-    S2M_TRY(scan_u32(u, fb, pb, n, st));
-    hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fa, pa, (int64_t)n, (int64_t)0, la);
-    hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fb, pb, (int64_t)n, (int64_t)0, lb);
-    {   // both list lengths with one hand-back
-        const uint32_t *src[4] = {pa + (n - 1), fa + (n - 1), pb + (n - 1), fb + (n - 1)};
+                       have_nn ? 1 : 0, fs, pw, fl);
+    {
+        size_t bytes = 0;
+        S2M_TRY(rocprim::exclusive_scan(nullptr, bytes, fl, ps, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), st));
+        S2M_TRY(ensure_tmp(u, bytes));
+        size_t b2 = u.tmp_bytes;
+        S2M_TRY(rocprim::exclusive_scan(u.tmp, b2, fl, ps, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), st));
+    }
+    hipLaunchKernelGGL(scatter2_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fl, ps, (int64_t)n, la, lb);
+    {   // both list lengths with one hand-back: last position + last flag, as four 32-bit words
+        const uint32_t *p32 = reinterpret_cast<const uint32_t *>(ps + (n - 1)), *f32 = reinterpret_cast<const uint32_t *>(fl + (n - 1));
+        const uint32_t *src[4] = {p32, f32, p32 + 1, f32 + 1};
         uint32_t h[4] = {0, 0, 0, 0};
         S2M_TRY(mail_fetch(u.mail, src, 4, h, st));
         *n_add = (int64_t)h[0] + h[1];
