@@ -8,8 +8,8 @@
 //   porig : M x float4 {x, y, z, 0} in the caller's original order; neighbour indices returned by
 //           the search refer to it (plane fit gathers 5 points from it).
 //   top   : dense nbx*nby*nbz array of 16-byte entries over the map bounding box:
-//           {brick id + 1 (0 = empty), 0, 64-bit mask of the (y,z) rows of the brick that hold
-//           points}.  A brick is 8x8x8 cells; at c = 0.5 m this array is 7 K entries (0.1 MB) for
+//           {brick id + 1 (0 = empty), position of the brick's first point + 1, 64-bit mask of the (y,z)
+//           rows of the brick that hold points}.  A brick is 8x8x8 cells; at c = 0.5 m this array is 7 K entries (0.1 MB) for
 //           a 215 m scene, so it stays L2-resident; the row mask lets the search skip the table
 //           lookups of empty rows.
 //   tab   : per occupied brick a 520-entry row (513 used): exclusive prefix of the point counts of
@@ -34,7 +34,7 @@ struct Grid {
     float slop;         // safety margin of the termination bound, in cells
     int ncx, ncy, ncz;  // cells per axis (multiples of 8)
     int nbx, nby, nbz;  // bricks per axis
-    const uint4 *top;      // {id + 1, 0, rowmask lo, rowmask hi}
+    const uint4 *top;      // {id + 1, first point + 1 (used by the table builder only), rowmask lo, rowmask hi}
     const uint32_t *tab;
     const float4 *pts;
     const float4 *porig;

@@ -7,9 +7,10 @@
 // top-level array over the bounding box and a 513-entry prefix table per occupied brick locate
 // any run of cells along x with two 4-byte loads.
 //
-// This is the one-off (per map) part of the path, not the per-iteration hot loop; the device-wide
-// radix sort and scan come from rocPRIM (ROCm's native primitives library), everything else is
-// hand-written below.
+// This is the per-map part of the path, not the per-iteration hot loop: the full build (radix sort of all points),
+// the tables that both the build and an update derive from the sorted keys, and the merge update that turns the
+// verdicts of s2m_mapupd.hip into the new map without sorting it again.  The device-wide radix sort and scans come
+// from rocPRIM (ROCm's native primitives library), everything else is hand-written below.
 #include <algorithm>
 #include <cmath>
 #include <cstring>

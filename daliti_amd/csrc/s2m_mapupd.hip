@@ -12,12 +12,14 @@
 // {argmin of centre distance over old and new points; new beats old on ties; the last of tied new
 // points wins} -- with one exception that keeps an untouched voxel untouched: a single old point
 // that is strictly closer than every new point.  That closed form is what runs here, in parallel:
-//   probe    one lane per new point: count / best old point inside its voxel via the brick grid
+//   probe    eight lanes per new point: count / best old point inside its voxel via the brick grid
 //   sort     radix sort of the new points by voxel key (stable: batch order inside a voxel)
-//   resolve  one lane per voxel: winner among the new points, verdict against the best old point
-//   kill     one lane per rewritten voxel: mark every old point of the voxel except the keeper
-//   compact  survivors in index order, then the winning new points in batch order
-// followed by a rebuild of the brick grid (s2m_map.hip; 7 ms for 5 M points).  Among several OLD
+//   resolve  eight lanes per voxel: winner among the new points, verdict against the best old point, and the old
+//            points of a rewritten voxel (except the keeper) marked dead -- by caller index and by sorted position
+//   stage    the winning new points in batch order
+// The new map is "survivors in index order, then the staged points": merged into the sorted arrays of the current
+// grid (s2m_map.hip, merge_update) or, when a new point lies outside the grid, compacted here (update_finish) and
+// rebuilt.  Counts travel to the host through the pinned mailbox (mail_fetch), not through 4-byte copies.  Among several OLD
 // points tied for the smallest centre distance the lowest index wins (the reference takes the
 // first in its tree traversal, which has no GPU counterpart); such ties need two points at exactly
 // the same float distance inside one voxel.
