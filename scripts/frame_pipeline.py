@@ -37,3 +37,14 @@ for frame in range(6):
 rows = np.array(rows[2:])
 print("warm mean: raw->scan %.3f | update %.3f | map_incremental %.3f | fov %.3f | total %.3f ms -> %.0f frames/s"
       % (*rows.mean(0), rows.sum(1).mean(), 1e3 / rows.sum(1).mean()))
+# the same frames back to back, synchronised only at the end (no per-stage sync: the asynchronous tail of one stage --
+# e.g. the table build of a merged map update -- overlaps the host side of the next)
+N = 20
+sync(); t0 = time.perf_counter()
+for frame in range(N):
+    e.scan_set_from_raw(rec, 4, 6, poses, end, leaf)
+    r = e.iterated_update(xp, xp, P)
+    e.map_incremental(r["x"], 0.5)
+    e.fov_segment(r["x"][9:12], 1000.0)
+sync(); dt = (time.perf_counter() - t0) / N * 1e3
+print("back to back, no per-stage sync: %.3f ms per frame -> %.0f frames/s" % (dt, 1e3 / dt))
