@@ -358,6 +358,19 @@ class Engine:
         self._ck(self.lib.s2m_iterated_update(self.h, C.c_void_p(x.ctypes.data), C.c_void_p(x_prop.ctypes.data),
                                               C.c_void_p(P.ctypes.data), C.byref(log)))
 
+    def iterated_update_bound(self, x, x_prop, P, log):
+        """The lean form with its arguments bound once: returns a zero-argument callable that runs
+        s2m_iterated_update on these buffers (which must stay alive and in place)."""
+        fn, h = self.lib.s2m_iterated_update, self.h
+        ax, ap, aP, al = C.c_void_p(x.ctypes.data), C.c_void_p(x_prop.ctypes.data), C.c_void_p(P.ctypes.data), C.byref(log)
+        ck = self._ck
+
+        def call():
+            rc = fn(h, ax, ap, aP, al)
+            if rc:
+                ck(rc)
+        return call
+
     @staticmethod
     def iterated_update_batch(engines, x, x_prop, P, logs=None):
         """k scans in flight on one GPU from this thread.  x (k, 36), x_prop (k, 36), P (k, 24, 24) float64
