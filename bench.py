@@ -301,6 +301,8 @@ def main():
         if a.steps * 5 // cand >= 40:
             stride = cand
     eng.set_timing(stride)
+    import gc
+    gc.disable()  # no collector pauses inside the timed region (harness hygiene)
     fence()
     t0 = time.perf_counter()
     iters = rematch = 0
@@ -310,6 +312,7 @@ def main():
         rematch += rm
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
     tstats = eng.timing_stats()
     eng.set_timing(False)
     b0 = bufs[0]
