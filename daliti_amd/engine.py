@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "_lib", "libdaliti_s2m.so")
+_LIB = os.environ.get("S2M_LIB") or os.path.join(_HERE, "_lib", "libdaliti_s2m.so")  # S2M_LIB: A/B builds of the same ABI
 
 K = 5
 DIM = 24
