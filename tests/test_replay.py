@@ -48,6 +48,22 @@ def test_wire_header_roundtrip_in_plain_c(tmp_path):
         assert used == len(msg) and (bits(back["records"]) == bits(rec)).all() and back["point_step"] == width * 4
 
 
+def test_wire_parser_never_reads_past_its_input(tmp_path):
+    """Every truncation and a few thousand corrupted copies of a valid message through s2m_pc2_parse, under
+    AddressSanitizer, in buffers of exactly the size handed over."""
+    exe = str(tmp_path / "wire_fuzz")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "wire_fuzz.c"), "-o", exe])
+    rs = np.random.RandomState(1)
+    for kind, fields, width in ((1, rf.FIELDS_XYZINORMAL, 12), (0, rf.FIELDS_XYZI, 8)):
+        rec = rs.uniform(-50, 50, (33, width)).astype(np.float32)
+        msg = rf.serialize_pointcloud2(rec, fields, 99.5, "camera_init", seq=3)
+        src = tmp_path / ("fuzz%d.bin" % kind)
+        src.write_bytes(msg)
+        r = subprocess.run([exe, str(src)], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout + r.stderr
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree only exists in the build container")
 def test_node_patch_applies_to_the_reference():
     patch = os.path.join(ROOT, "integration", "laserMapping_s2m.patch")
