@@ -1,0 +1,48 @@
+"""The product's host-side ESKF algebra (s2m_eskf.cpp: boxplus / boxminus, Exp / Log, K_1 by partial-pivot LU, the
+solution, the convergence test, the covariance update) compiled for the CPU with sanitizers and compared with the
+oracle -- the part of the product path that needs no GPU (laserMapping.cpp:1012-1046, 1084-1085)."""
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "daliti_amd", "csrc")
+
+
+def test_host_eskf_matches_oracle(oracle, small_scene, small_tree, tmp_path):
+    exe = str(tmp_path / "eskf_host_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fsanitize=address,undefined",
+                           "-fno-omit-frame-pointer", "-Wall", "-I", CSRC, os.path.join(ROOT, "tests", "eskf_host_check.cpp"),
+                           os.path.join(CSRC, "s2m_eskf.cpp"), "-o", exe])
+    cfg = oracle.default_cfg()
+    rs = np.random.RandomState(4)
+    x0 = small_scene["x_prop"]
+    ps = oracle.residual_pass(cfg, small_tree, small_scene["scan"], x0, True, oracle.PassState(len(small_scene["scan"])))
+    cases = []
+    for k in range(40):
+        # current state: the prediction moved by a random error state (rotation up to a few degrees, or tiny: the
+        # small-angle branches of Exp / Log), extrinsic included
+        scale = [1e-1, 1e-3, 1e-6, 1e-9][k % 4]
+        d = rs.normal(0, 1, 24) * scale
+        xc = oracle.boxplus(x0, d)
+        xp = oracle.boxplus(x0, rs.normal(0, 1, 24) * scale * 0.5)
+        A = rs.normal(0, 1, (24, 24))
+        P = small_scene["P"] + 1e-5 * (A @ A.T) * (k % 3 == 0)           # the bench's diagonal P and dense SPD ones
+        if k % 5 == 4:                                                      # a random normal block instead of the scene's
+            H = rs.normal(0, 1, (200, 12)); z = rs.normal(0, 0.05, 200)
+            HtH, Htz = H.T @ H, H.T @ z
+        else:
+            w = 1.0 + 0.1 * k
+            HtH, Htz = ps.HtH * w, ps.Htz * w
+        x1, sol, K1, conv = oracle.eskf_update(cfg, xc, xp, P, HtH, Htz)
+        Pn = oracle.cov_update(K1, HtH, P)
+        cases.append(np.r_[xc, xp, P.ravel(), np.asarray(HtH).ravel(), Htz, x1, sol, float(conv), Pn.ravel()])
+    blob = np.ascontiguousarray(np.array(cases), np.float64)
+    path = tmp_path / "cases.bin"
+    path.write_bytes(blob.tobytes())
+    r = subprocess.run([exe, str(path), str(len(cases))], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = dict(zip(r.stdout.split()[::2], r.stdout.split()[1::2]))
+    assert int(f["failed"]) == 0 and int(f["conv_mismatch"]) == 0, r.stdout
+    assert float(f["worst_x"]) < 1e-12 and float(f["worst_solution_rel"]) < 1e-9 and float(f["worst_P_rel"]) < 1e-11, r.stdout
