@@ -17,6 +17,7 @@
 #include "../../include/daliti_s2m.h"
 #include "s2m_comm.h"
 #include "s2m_eskf.h"
+#include "s2m_iterctl.h"
 #include "s2m_kernels.h"
 
 namespace s2m {
@@ -974,12 +975,6 @@ int s2m_cov_update(s2m_engine *e, double P[S2M_DIM * S2M_DIM])
 }
 
 namespace {
-// loop variables of the iterated update (laserMapping.cpp:813-818, 820)
-struct IterCtl {
-    int it, rematch, rematch_num, rematch_en;
-    int32_t conv, stop;
-};
-
 // Everything the reference does with the result of one pass (:899-918, 1012-1101): degeneracy queue, Kalman update,
 // log row, rematch judgement, exit test + covariance update.  finished = the loop ends after this iteration.
 int consume_block(s2m_engine *e, const double *hb, IterCtl &c, double x[S2M_STATE_DOUBLES],
@@ -991,15 +986,7 @@ int consume_block(s2m_engine *e, const double *hb, IterCtl &c, double x[S2M_STAT
     const double *HtH = hb, *Htz = hb + 144;
     const int32_t effct = (int32_t)hb[156];
     const double total_res = hb[157];
-    // degeneracy queue (:899-918)
-    e->queue[e->queue_len++] = effct;
-    if (e->queue_len > S2M_FEAT_QUEUE) {
-        std::memmove(e->queue, e->queue + 1, sizeof(int32_t) * S2M_FEAT_QUEUE);
-        e->queue_len = S2M_FEAT_QUEUE;
-    }
-    c.stop = 0;
-    for (int q = 0; q < e->queue_len; ++q)
-        if (e->queue[q] <= e->cfg.feat_threshold) { c.stop = 1; break; }
+    c.stop = degeneracy_push(e->queue, e->queue_len, effct, e->cfg.feat_threshold);  // :899-918 (s2m_iterctl.h)
     double sol[S2M_DIM] = {0};
     if (!c.stop) {  // flg_EKF_inited is always true (INIT_TIME == 0, :75,:762)
         int rc = s2m_eskf_update(e, x, x_prop, P, HtH, Htz, sol, &c.conv);
@@ -1013,20 +1000,11 @@ int consume_block(s2m_engine *e, const double *hb, IterCtl &c, double x[S2M_STAT
         log->total_residual[c.it] = total_res;
         std::memcpy(log->solution[c.it], sol, sizeof(sol));
     }
-    c.rematch_en = 0;  // rematch judgement (:1070-1076)
-    if (c.conv || (c.rematch_num == 0 && c.it == max_iter - 2)) {
-        c.rematch_en = 1;
-        c.rematch_num++;
-    }
-    finished = false;
-    if (c.rematch_num >= 2 || c.it == max_iter - 1) {  // :1079-1094
-        if (!c.stop) {
-            int rc = s2m_cov_update(e, P);
-            if (rc) return rc;
-        }
-        finished = true;
-    } else if (c.stop) {  // :1095-1101
-        finished = true;
+    bool update_cov = false;
+    iter_judge(c, max_iter, finished, update_cov);  // rematch judgement and exit test (:1070-1101, s2m_iterctl.h)
+    if (update_cov) {
+        int rc = s2m_cov_update(e, P);
+        if (rc) return rc;
     }
     return S2M_OK;
 }

@@ -46,3 +46,30 @@ def test_host_eskf_matches_oracle(oracle, small_scene, small_tree, tmp_path):
     f = dict(zip(r.stdout.split()[::2], r.stdout.split()[1::2]))
     assert int(f["failed"]) == 0 and int(f["conv_mismatch"]) == 0, r.stdout
     assert float(f["worst_x"]) < 1e-12 and float(f["worst_solution_rel"]) < 1e-9 and float(f["worst_P_rel"]) < 1e-11, r.stdout
+
+
+def test_host_loop_control_matches_oracle(oracle, small_scene, small_tree, tmp_path):
+    """s2m_iterctl.h (degeneracy queue, rematch judgement, exit test) replayed over the oracle's per-iteration
+    (effct_feat_num, converged) sequences: same number of iterations, same rematch flags, same stop flag and queue."""
+    exe = str(tmp_path / "iterctl_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-Wall", "-I", CSRC,
+                           os.path.join(ROOT, "tests", "iterctl_check.cpp"), "-o", exe])
+    scan = small_scene["scan"]
+    x, P = small_scene["x_prop"], small_scene["P"]
+    runs = 0
+    for max_iter in (1, 2, 3, 4, 5, 7, 10):
+        for thr, queue in ((50, None), (2045, None), (50, [3000, 10, 3000]), (50, [3000] * 10), (10 ** 6, None)):
+            cfg = oracle.default_cfg(max_iter=max_iter, feat_threshold=thr)
+            ro = oracle.iterated_update(cfg, small_tree, scan, x, x, P, feat_queue=queue)
+            q = list(queue or [])[-10:]
+            line = "%d %d %d %s %d %s\n" % (max_iter, thr, len(q), " ".join(map(str, q)), ro["iters"],
+                                            " ".join("%d %d" % (e, c) for e, c in zip(ro["effct"], ro["conv"])))
+            r = subprocess.run([exe], input=line, capture_output=True, text=True)
+            assert r.returncode == 0, (line, r.stdout, r.stderr)
+            head, rem = r.stdout.strip().split("|")
+            h = list(map(int, head.split()))
+            assert h[0] == ro["iters"] and h[1] == int(ro["ekf_stop"]), (line, r.stdout, ro["iters"], ro["ekf_stop"])
+            assert h[3:3 + h[2]] == list(ro["feat_queue"]), (line, r.stdout, ro["feat_queue"])
+            assert list(map(int, rem.split())) == list(ro["rematch"]), (line, r.stdout, ro["rematch"])
+            runs += 1
+    assert runs == 35
