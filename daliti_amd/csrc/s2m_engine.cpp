@@ -17,6 +17,7 @@
 #include "../../include/daliti_s2m.h"
 #include "s2m_comm.h"
 #include "s2m_eskf.h"
+#include "s2m_fov.h"
 #include "s2m_iterctl.h"
 #include "s2m_kernels.h"
 
@@ -522,56 +523,11 @@ int s2m_fov_segment(s2m_engine *e, const double pos_lid[3], double cube_len, flo
                     int64_t *n_deleted)
 {
     if (!e || !pos_lid || !(cube_len > 0.0)) return fail(e, S2M_ERR_ARG, "s2m_fov_segment: bad argument");
-    const float DET_RANGE = 300.0f, MOV_THRESHOLD = 1.5f;  // laserMapping.cpp:304-305
     if (n_boxes) *n_boxes = 0;
     if (n_deleted) *n_deleted = 0;
-    float *mn = e->local_map, *mx = e->local_map + 3;
-    auto report = [&]() {
-        if (local_map) std::memcpy(local_map, e->local_map, sizeof(e->local_map));
-    };
-    if (!e->local_map_init) {  // :320-328
-        for (int i = 0; i < 3; ++i) {
-            mn[i] = (float)(pos_lid[i] - cube_len / 2.0);
-            mx[i] = (float)(pos_lid[i] + cube_len / 2.0);
-        }
-        e->local_map_init = true;
-        report();
-        return S2M_OK;
-    }
-    float dist[3][2];
-    bool need_move = false;
-    for (int i = 0; i < 3; ++i) {  // :331-337
-        dist[i][0] = (float)std::fabs(pos_lid[i] - (double)mn[i]);
-        dist[i][1] = (float)std::fabs(pos_lid[i] - (double)mx[i]);
-        if (dist[i][0] <= MOV_THRESHOLD * DET_RANGE || dist[i][1] <= MOV_THRESHOLD * DET_RANGE) need_move = true;
-    }
-    if (!need_move) {
-        report();
-        return S2M_OK;
-    }
     float boxes[3][6];
-    int nb = 0;
-    float new_map[6];
-    std::memcpy(new_map, e->local_map, sizeof(new_map));
-    const float mov_dist = (float)std::max((cube_len - 2.0 * MOV_THRESHOLD * DET_RANGE) * 0.5 * 0.9,
-                                           (double)(DET_RANGE * (MOV_THRESHOLD - 1)));  // :345
-    for (int i = 0; i < 3; ++i) {  // :346-363
-        float tmp[6];
-        std::memcpy(tmp, e->local_map, sizeof(tmp));
-        if (dist[i][0] <= MOV_THRESHOLD * DET_RANGE) {
-            new_map[3 + i] -= mov_dist;
-            new_map[i] -= mov_dist;
-            tmp[i] = mx[i] - mov_dist;
-            std::memcpy(boxes[nb++], tmp, sizeof(tmp));
-        } else if (dist[i][1] <= MOV_THRESHOLD * DET_RANGE) {
-            new_map[3 + i] += mov_dist;
-            new_map[i] += mov_dist;
-            tmp[3 + i] = mn[i] + mov_dist;
-            std::memcpy(boxes[nb++], tmp, sizeof(tmp));
-        }
-    }
-    std::memcpy(e->local_map, new_map, sizeof(new_map));
-    report();
+    const int nb = fov_step(e->local_map, e->local_map_init, pos_lid, cube_len, boxes);  // :313-366 (s2m_fov.h)
+    if (local_map) std::memcpy(local_map, e->local_map, sizeof(e->local_map));
     if (n_boxes) *n_boxes = nb;
     if (nb > 0 && e->map_ready) return s2m_map_delete_boxes(e, &boxes[0][0], nb, n_deleted);  // :367-368
     return S2M_OK;

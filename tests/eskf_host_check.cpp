@@ -1,5 +1,5 @@
 // Test helper: the product's host-side ESKF algebra (daliti_amd/csrc/s2m_eskf.cpp, pure C++, no HIP) run on the CPU
-// against cases written by tests/test_eskf_host.py from the oracle.  Built with -fsanitize=address,undefined.
+// against cases written by tests/test_host_logic.py from the oracle.  Built with -fsanitize=address,undefined.
 // File layout per case (doubles): x[36] x_prop[36] P[576] HtH[144] Htz[12] | expected x[36] solution[24] converged P[576]
 // usage: eskf_host_check <cases file> <n cases>
 #include <cmath>

@@ -73,3 +73,29 @@ def test_host_loop_control_matches_oracle(oracle, small_scene, small_tree, tmp_p
             assert list(map(int, rem.split())) == list(ro["rematch"]), (line, r.stdout, ro["rematch"])
             runs += 1
     assert runs == 35
+
+
+def test_host_fov_cube_matches_oracle(oracle, tmp_path):
+    """s2m_fov.h (lasermap_fov_segment's cube bookkeeping, laserMapping.cpp:304-366) on random walks: the same cube and
+    the same slabs as the oracle's float32 restatement, value for value."""
+    exe = str(tmp_path / "fov_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-Wall", "-I", CSRC,
+                           os.path.join(ROOT, "tests", "fov_check.cpp"), "-o", exe])
+    rs = np.random.RandomState(9)
+    moved = 0
+    for cube in (1000.0, 2000.0, 905.0):
+        pos = np.cumsum(rs.normal(0, 60.0, (200, 3)) * [1, 1, 0.05], axis=0)
+        text = "%r %d\n" % (cube, len(pos)) + "\n".join("%r %r %r" % tuple(float(v) for v in p) for p in pos) + "\n"
+        r = subprocess.run([exe], input=text, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        f = oracle.FovSegmenter(cube)
+        for p, line in zip(pos, r.stdout.strip().split("\n")):
+            v = line.split()
+            boxes = f.step(p)
+            assert int(v[0]) == len(boxes), (p, line)
+            got = np.array(v[1:], np.float32)
+            assert (got[:6] == np.r_[f.mn, f.mx]).all(), (p, line, f.mn, f.mx)
+            for b, box in enumerate(boxes):
+                assert (got[6 + 6 * b: 12 + 6 * b] == np.asarray(box, np.float32)).all(), (p, line, box)
+            moved += len(boxes)
+    assert moved > 10
