@@ -15,8 +15,9 @@
 namespace s2m {
 
 // esti_plane<float>: column-pivoted Householder QR least squares of A x = -1, same operation
-// order as orc_esti_plane (oracle/s2m_oracle.c).  Returns the inlier verdict.
-__device__ __forceinline__ bool fit_plane(const float (&nx)[kK], const float (&ny)[kK], const float (&nz)[kK], float thr,
+// order as orc_esti_plane (oracle/s2m_oracle.c).  Returns the inlier verdict.  (__host__ too: tests/plane_check.cpp
+// runs it on the CPU against the oracle.)
+__host__ __device__ __forceinline__ bool fit_plane(const float (&nx)[kK], const float (&ny)[kK], const float (&nz)[kK], float thr,
                                           float4 &pl)
 {
     float A[kK][3], c[kK];

@@ -99,3 +99,48 @@ def test_host_fov_cube_matches_oracle(oracle, tmp_path):
                 assert (got[6 + 6 * b: 12 + 6 * b] == np.asarray(box, np.float32)).all(), (p, line, box)
             moved += len(boxes)
     assert moved > 10
+
+
+def test_host_plane_fit_is_bit_identical_to_oracle(oracle, small_scene, small_tree, tmp_path):
+    """s2m_plane.h -- the column-pivoted Householder QR that reduce<FIT> runs per point -- executed on the HOST (the
+    function is __host__ __device__; built with hipcc and -ffp-contract=off like the library, no GPU involved) on
+    real neighbourhoods of the small scene plus random, non-planar and degenerate ones: verdict and plane bits equal
+    the oracle's esti_plane (common_lib.h:267-299)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not installed")
+    exe = str(tmp_path / "plane_check")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-ffp-contract=off", "-I", CSRC,
+                           os.path.join(ROOT, "tests", "plane_check.cpp"), "-o", exe])
+    rs = np.random.RandomState(6)
+    w = oracle.body_to_world(small_scene["x_prop"], small_scene["scan"][:1500])
+    idx, d2, cnt = small_tree.knn5(w)
+    full = cnt == 5
+    cases = [small_tree.xyz[idx[full]].astype(np.float32)]                               # real 5-neighbourhoods
+    cases.append(rs.uniform(-30, 30, (300, 5, 3)).astype(np.float32))                    # random: mostly rejected
+    base = rs.uniform(-40, 40, (300, 1, 3)).astype(np.float32)
+    cases.append(base + rs.normal(0, 0.2, (300, 5, 3)).astype(np.float32) * np.float32([1, 1, 0.02]))   # thin slabs
+    deg = np.ones((4, 5, 3), np.float32)
+    deg[1, :, 0] = np.arange(5)                                                          # collinear
+    deg[2] = 0                                                                           # all at the origin
+    deg[3, :, :2] = rs.uniform(-1, 1, (5, 2)); deg[3, :, 2] = 0                          # the plane z = 0 (d = 0: no solution of n.x = -1)
+    cases.append(deg)
+    nb = np.ascontiguousarray(np.concatenate(cases), np.float32)
+    path = tmp_path / "nb.bin"
+    path.write_bytes(nb.tobytes())
+    r = subprocess.run([exe, str(path), str(len(nb))], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert len(lines) == len(nb)
+    accepted = 0
+    for k, line in enumerate(lines):
+        v = line.split()
+        ok, pl = oracle.esti_plane(nb[k])
+        got = np.array([int(h, 16) for h in v[1:]], np.uint32)
+        assert int(v[0]) == int(ok), (k, line, ok, pl)
+        same = got == pl.view(np.uint32)
+        nan_both = np.isnan(got.view(np.float32)) & np.isnan(pl)
+        assert (same | nan_both).all(), (k, line, pl, pl.view(np.uint32))
+        accepted += int(ok)
+    assert accepted > 800 and accepted < len(nb) - 100
