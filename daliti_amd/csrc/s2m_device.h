@@ -75,7 +75,7 @@ struct Gates {
 
 // p_w = rot_end * (R_L_I * p_b + T_L_I) + pos_end in double, rounded to float
 // (eskf_lio/src/laserMapping.cpp:835-841).  Sums left to right, no contraction.
-__device__ __forceinline__ void body_to_world(const Pose &P, float bx, float by, float bz, float &wx,
+__host__ __device__ __forceinline__ void body_to_world(const Pose &P, float bx, float by, float bz, float &wx,
                                               float &wy, float &wz)
 {
     const double x = (double)bx, y = (double)by, z = (double)bz;

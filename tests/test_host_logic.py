@@ -144,3 +144,31 @@ def test_host_plane_fit_is_bit_identical_to_oracle(oracle, small_scene, small_tr
         assert (same | nan_both).all(), (k, line, pl, pl.view(np.uint32))
         accepted += int(ok)
     assert accepted > 800 and accepted < len(nb) - 100
+
+
+def test_host_body_to_world_is_bit_identical_to_oracle(oracle, tmp_path):
+    """s2m_device.h's body->world transform (fp64 products summed left to right, rounded to float;
+    laserMapping.cpp:835-841) on the host against the oracle, for random attitudes, extrinsics and km-scale offsets."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not installed")
+    exe = str(tmp_path / "world_check")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-ffp-contract=off", "-I", CSRC,
+                           os.path.join(ROOT, "tests", "world_check.cpp"), "-o", exe])
+    from scipy.spatial.transform import Rotation
+    rs = np.random.RandomState(8)
+    for k in range(6):
+        x = np.zeros(36)
+        x[0:9] = Rotation.from_rotvec(rs.normal(0, 1.0, 3)).as_matrix().ravel()
+        x[9:12] = rs.normal(0, [1, 10, 1000, 5, 0.1, 3000][k], 3)
+        x[12:21] = Rotation.from_rotvec(rs.normal(0, 0.05 * k, 3)).as_matrix().ravel()
+        x[21:24] = rs.normal(0, 0.1, 3)
+        pts = (rs.normal(0, 30, (2000, 3)) * [1, 1, 0.2]).astype(np.float32)
+        path = tmp_path / ("w%d.bin" % k)
+        path.write_bytes(x.tobytes() + pts.tobytes())
+        r = subprocess.run([exe, str(path), str(len(pts))], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = np.array([[int(h, 16) for h in line.split()] for line in r.stdout.strip().split("\n")], np.uint32)
+        ref = oracle.body_to_world(x, pts).view(np.uint32)
+        assert (got == ref).all(), k
