@@ -23,6 +23,7 @@
 #include "s2m_device.h"
 #include "s2m_kernels.h"
 #include "s2m_plane.h"
+#include "s2m_point.h"
 
 namespace s2m {
 
@@ -150,46 +151,6 @@ __host__ __device__ constexpr int tri_row(int t)
     return r;
 }
 
-// one Jacobian row (laserMapping.cpp:948-978): h = [A, n, B, C] or [A, n, 0, 0], z = -pd2
-template <bool EXT>
-__device__ __forceinline__ void jac_row(const Pose &P, float bx, float by, float bz, const float4 &pl, float pd2,
-                                        double (&h)[12], double &z)
-{
-    const double p0 = (double)bx, p1 = (double)by, p2 = (double)bz;
-    const double i0 = ((P.RLI[0] * p0 + P.RLI[1] * p1) + P.RLI[2] * p2) + P.TLI[0];
-    const double i1 = ((P.RLI[3] * p0 + P.RLI[4] * p1) + P.RLI[5] * p2) + P.TLI[1];
-    const double i2 = ((P.RLI[6] * p0 + P.RLI[7] * p1) + P.RLI[8] * p2) + P.TLI[2];
-    const double n0 = (double)pl.x, n1 = (double)pl.y, n2 = (double)pl.z;
-    // C = rot_end^T * n
-    const double c0 = (P.R[0] * n0 + P.R[3] * n1) + P.R[6] * n2;
-    const double c1 = (P.R[1] * n0 + P.R[4] * n1) + P.R[7] * n2;
-    const double c2 = (P.R[2] * n0 + P.R[5] * n1) + P.R[8] * n2;
-    // A = [p_I]x * C
-    h[0] = (0.0 * c0 + -i2 * c1) + i1 * c2;
-    h[1] = (i2 * c0 + 0.0 * c1) + -i0 * c2;
-    h[2] = (-i1 * c0 + i0 * c1) + 0.0 * c2;
-    h[3] = n0; h[4] = n1; h[5] = n2;
-    if (EXT) {
-        // B = ([p_b]x * R_L_I^T) * C, left to right (laserMapping.cpp:970)
-        const double S[9] = {0.0, -p2, p1, p2, 0.0, -p0, -p1, p0, 0.0};
-        double M[9];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                M[i * 3 + j] = (S[i * 3 + 0] * P.RLI[j * 3 + 0] + S[i * 3 + 1] * P.RLI[j * 3 + 1]) +
-                               S[i * 3 + 2] * P.RLI[j * 3 + 2];
-        h[6] = (M[0] * c0 + M[1] * c1) + M[2] * c2;
-        h[7] = (M[3] * c0 + M[4] * c1) + M[5] * c2;
-        h[8] = (M[6] * c0 + M[7] * c1) + M[8] * c2;
-        h[9] = c0; h[10] = c1; h[11] = c2;
-    } else {
-#pragma unroll
-        for (int i = 6; i < 12; ++i) h[i] = 0.0;
-    }
-    z = -(double)pd2;
-}
-
 // Hand-off of the 160-double block to the spinning host thread.  A system-scope release fence (or release
 // store) makes the compiler write back the whole L2 first (buffer_wbl2) -- microseconds, with the per-point
 // outputs of this very launch dirty in it -- although only these 160 stores have to be visible.  So: the
@@ -290,20 +251,13 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
         if (sel) {
             uint8_t sel_new = 0;  // sticky: only fit-ok + s-gate re-selects (:862,:873)
             if (fl & kFlagPlane) {
-                float wx, wy, wz;
-                body_to_world(a.pose, bx, by, bz, wx, wy, wz);
-                const float pd2 = ((pl.x * wx + pl.y * wy) + pl.z * wz) + pl.w;                    // :866
-                const double pbn = sqrt(((double)bx * (double)bx + (double)by * (double)by) + (double)bz * (double)bz);
-                // "float s" (:868): the double expression is rounded to float before the compare of :870
-                const float s = (float)(1 - 0.9 * fabs((double)pd2) / sqrt(pbn));
+                bool keep = false;
+                const float pd2 = point_residual(a.pose, a.gates, bx, by, bz, pl, keep, eff);  // :866-889 (s2m_point.h)
                 a.pd2[i] = pd2;
-                if ((double)s > a.gates.s_gate) {
-                    sel_new = 1;
-                    if (fabs((double)pd2) <= a.gates.res_gate) {                                    // :889
-                        eff = true;
-                        jac_row<EXT>(a.pose, bx, by, bz, pl, pd2, h, z);
-                        absr = fabs((double)pd2);
-                    }
+                if (keep) sel_new = 1;
+                if (eff) {
+                    jac_row<EXT>(a.pose, bx, by, bz, pl, pd2, h, z);
+                    absr = fabs((double)pd2);
                 }
             }
             a.sel[i] = sel_new;

@@ -172,3 +172,44 @@ def test_host_body_to_world_is_bit_identical_to_oracle(oracle, tmp_path):
         got = np.array([[int(h, 16) for h in line.split()] for line in r.stdout.strip().split("\n")], np.uint32)
         ref = oracle.body_to_world(x, pts).view(np.uint32)
         assert (got == ref).all(), k
+
+
+def test_host_point_residual_and_jacobian_rows_are_bit_identical_to_oracle(oracle, small_scene, small_tree, tmp_path):
+    """s2m_point.h -- residual, s-gate, residual gate and the Jacobian row of one point (laserMapping.cpp:866-889,
+    948-978), the code every lane of reduce_kernel runs -- on the host: pd2, the two verdicts, every row entry and z equal
+    the oracle's bit for bit, with and without extrinsic estimation."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not installed")
+    exe = str(tmp_path / "point_check")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-ffp-contract=off", "-I", CSRC,
+                           os.path.join(ROOT, "tests", "point_check.cpp"), "-o", exe])
+    scan = small_scene["scan"]
+    x = np.array(small_scene["x_prop"], float)
+    from scipy.spatial.transform import Rotation
+    x[12:21] = Rotation.from_rotvec([0.01, -0.02, 0.015]).as_matrix().ravel()      # a non-trivial extrinsic
+    x[21:24] = [0.05, -0.03, 0.02]
+    for ext in (0, 1):
+        cfg = oracle.default_cfg(extrinsic_est_en=ext)
+        ps = oracle.residual_pass(cfg, small_tree, scan, x, True, oracle.PassState(len(scan)), want_rows=True)
+        ok = ps.plane_ok.astype(bool)
+        rec = np.concatenate([scan[ok], ps.plane[ok]], axis=1).astype(np.float32)
+        path = tmp_path / ("pt%d.bin" % ext)
+        path.write_bytes(x.tobytes() + np.int32([ext, len(rec)]).tobytes() + np.ascontiguousarray(rec).tobytes())
+        r = subprocess.run([exe, str(path)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        rows = [line.split() for line in r.stdout.strip().split("\n")]
+        assert len(rows) == len(rec)
+        keep = np.array([int(v[0]) for v in rows], bool)
+        eff = np.array([int(v[1]) for v in rows], bool)
+        pd2 = np.array([int(v[2], 16) for v in rows], np.uint32)
+        assert (keep == ps.selected[ok].astype(bool)).all()          # sticky selection after a first pass = the s-gate
+        assert (eff == ps.eff[ok].astype(bool)).all() and eff.sum() == ps.effct > 1000
+        assert (pd2 == ps.pd2[ok].view(np.uint32)).all()
+        H = np.array([[int(h, 16) for h in v[3:15]] for v in rows], np.uint64)[eff]
+        z = np.array([int(v[15], 16) for v in rows], np.uint64)[eff]
+        assert (H == ps.Hsub.view(np.uint64)).all()
+        assert (z == ps.meas.view(np.uint64)).all()
+        if ext:
+            assert np.abs(ps.Hsub[:, 6:]).max() > 0
