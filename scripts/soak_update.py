@@ -1,4 +1,4 @@
-"""Soak: several hundred frames of register + map_incremental (+ FOV trim) with the sensor moving through the C2 room;
+"""Soak: several hundred frames of register + map_incremental (+ FOV trim) with the sensor wandering through the C2 room;
 watches device memory, how many updates merged, and checks the final map against a brute-force 5-NN on a sample."""
 import os, sys, time
 import numpy as np
@@ -16,7 +16,7 @@ merged = 0
 x = None
 t0 = time.perf_counter()
 for k in range(frames):
-    pos = synth.SENSOR_POS + np.array([0.05 * k, 0.02 * k, 0.0])
+    pos = synth.SENSOR_POS + np.array([25.0 * np.sin(k / 150.0), 20.0 * np.sin(k / 230.0), 0.0])   # stays inside the room
     s = synth.make_scan(32, 512, c["L"], seed=100 + k, sensor_pos=pos)
     xt, xp, P = synth.filter_inputs(pos, dtheta=synth.DTHETA0 * 0.2, dpos=synth.DPOS0 * 0.2)
     e.scan_set_downsampled(s, 0.5)
