@@ -136,11 +136,13 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
 int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity_points, int64_t *m);
 /* How the last map_add / map_delete_boxes / fov_segment / map_incremental produced the new map (design, not
  * reference): *merged = 1 when the update was merged into the sorted arrays of the current grid, 0 when the grid
- * was rebuilt (first update after s2m_map_build, a new point outside the grid, a density drift). */
+ * was rebuilt (a new point outside the grid and its margin, a density drift, an empty map). */
 int s2m_map_last_update(const s2m_engine *e, int32_t *merged);
 
 /* The down-sampled body-frame scan feats_down (laserMapping.cpp:775-778).  Resets the per-scan
- * state: point_selected_surf := true (:812), Nearest_Points cleared (:810). */
+ * state: point_selected_surf := true (:812), Nearest_Points cleared (:810).  Coordinates must be finite -- the
+ * reference's clouds are is_dense (its preprocessing drops invalid returns); an infinite coordinate makes the voxel
+ * grid of the *_downsampled / *_from_raw entry points report S2M_ERR_CAPACITY. */
 int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride_floats, int64_t n, int on_device);
 
 /* downSizeFilterSurf.filter(*feats_down) followed by the scan hand-over (laserMapping.cpp:775-778):
