@@ -75,3 +75,38 @@ def test_rotated_far_pose(oracle):
     m = np.r_[m, (world.mean(0) + rs.uniform(-25, 25, (40000, 3))).astype(np.float32)]
     for cell in (0.2, 0.9, 0.0):
         _check(oracle, m, body, cell, x)
+
+
+def test_non_finite_scan_points_are_harmless(oracle, small_scene):
+    """NaN / Inf coordinates in the scan (the reference's clouds are is_dense, a caller's may not be): no fault, the bad
+    points end up unselected without neighbours, and every other point's result is unchanged -- in the single pass and
+    through the whole iterated update."""
+    from daliti_amd import Engine
+    scan = small_scene["scan"][:2000].copy()
+    bad = np.array([3, 64, 65, 511, 1024, 1999])
+    dirty = scan.copy()
+    dirty[bad[0]] = np.nan
+    dirty[bad[1], 0] = np.inf
+    dirty[bad[2], 2] = -np.inf
+    dirty[bad[3], 1] = np.nan
+    dirty[bad[4]] = [np.inf, np.nan, 0.0]
+    dirty[bad[5]] = 3.0e38
+    x, P = small_scene["x_prop"], small_scene["P"]
+    res = {}
+    for name, s in (("clean", np.delete(scan, bad, axis=0)), ("dirty", dirty)):
+        e = Engine(max_iter=5)
+        e.map_build(small_scene["map"])
+        e.scan_set(s)
+        e.residual_pass(x, True)
+        idx, d2 = e.get_neighbors()
+        st = e.get_point_state()
+        r = e.iterated_update(x, x, P)
+        res[name] = (idx, d2, st["selected"], r)
+        e.close()
+    keep = np.ones(len(scan), bool); keep[bad] = False
+    ci, cd, cs, cr = res["clean"]
+    di, dd, ds, dr = res["dirty"]
+    assert (ds[bad] == 0).all()
+    assert (di[keep] == ci).all() and (bits(dd[keep]) == bits(cd)).all() and (ds[keep] == cs).all()
+    assert dr["iters"] == cr["iters"] and (dr["effct"] == cr["effct"]).all()
+    assert np.abs(dr["x"] - cr["x"]).max() < 1e-12
