@@ -314,3 +314,41 @@ def test_merge_update_random_sequence(oracle, monkeypatch):
         e.close()
     for k, (a, b) in enumerate(zip(maps["merge"], maps["rebuild"])):
         assert a.shape == b.shape and (bits(a) == bits(b)).all(), k
+
+
+@pytest.mark.gpu
+def test_two_handles_updating_their_maps_from_two_threads(small_scene):
+    """Two engines, each with its own map, scan, stream and pinned mailboxes, run register + map_incremental loops on
+    two host threads at once: every frame's pose, counts and final map equal those of the same loop run alone."""
+    import threading
+    from daliti_amd import Engine, synth
+
+    def loop(seed, out):
+        e = Engine(max_iter=5, feat_threshold=50, cell_size=0.5)
+        e.map_build(small_scene["map"])
+        rows = []
+        for k in range(12):
+            pos = synth.SENSOR_POS + np.array([0.05 * k * (1 + seed), 0.03 * k, 0.0])
+            s = synth.make_scan(16, 256, small_scene["L"], seed=50 + 7 * seed + k, sensor_pos=pos)
+            xt, xp, P = synth.filter_inputs(pos, dtheta=synth.DTHETA0 * 0.3, dpos=synth.DPOS0 * 0.3)
+            e.scan_set_downsampled(s, 0.5)
+            r = e.iterated_update(xp, xp, P)
+            na, nb = e.map_incremental(r["x"], 0.5)
+            rows.append((r["x"].copy(), r["iters"], tuple(r["effct"]), na, nb, e.map_size(), e.map_last_update_merged()))
+        out.append((rows, e.map_points().copy()))
+        e.close()
+
+    alone = []
+    for seed in (0, 1):
+        loop(seed, alone)
+    together = [[], []]
+    ts = [threading.Thread(target=loop, args=(seed, together[seed])) for seed in (0, 1)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    for seed in (0, 1):
+        (ra, ma), (rt, mt) = alone[seed], together[seed][0]
+        assert len(ra) == len(rt) == 12
+        for a, b in zip(ra, rt):
+            assert (bits(a[0]) == bits(b[0])).all() and a[1:] == b[1:]
+        assert ma.shape == mt.shape and (bits(ma) == bits(mt)).all()
+        assert sum(r[6] for r in ra) >= 10      # the loops really went through the merge path
