@@ -297,9 +297,12 @@ static hipError_t put_sentinels(float4 *pts, int64_t m, hipStream_t st)
 {
     // eight extra elements: the sentinel points the search kernels load for the padding slots of a batch
     // (far enough for the squared distance to overflow to +inf; index word 0xffffffff)
-    static uint32_t sentinel[kSentinelPoints][4];
-    for (auto &q : sentinel) { q[0] = q[1] = q[3] = 0x7f61b1e6u; q[2] = 0xffffffffu; }  // make_map_point(3e38f x3, ~0)
-    return hipMemcpyAsync(pts + m, sentinel, sizeof(sentinel), hipMemcpyHostToDevice, st);
+    struct Block {
+        uint32_t w[kSentinelPoints][4];
+        Block() { for (auto &q : w) { q[0] = q[1] = q[3] = 0x7f61b1e6u; q[2] = 0xffffffffu; } }  // make_map_point(3e38f x3, ~0)
+    };
+    static const Block sentinel;  // built once (thread-safe static initialisation), read-only afterwards
+    return hipMemcpyAsync(pts + m, sentinel.w, sizeof(sentinel.w), hipMemcpyHostToDevice, st);
 }
 
 __global__ void stats_mail_kernel(const uint32_t *__restrict__ bricks, const uint32_t *__restrict__ occ, uint32_t *__restrict__ out)
