@@ -25,7 +25,7 @@ size, shard_range() per rank (131,072 / 8 = 16,384 points per GPU at N = 8).  ``
 grows to N x beams, one config-sized shard per rank.
 
 Extra objects on the JSON line: ``roofline`` (the rematch pass: search kernels + reduce<FIT>,
-88 algorithmic bytes per eval; HIP-event timed inside the engine on its stream, every 7th pass of
+88 algorithmic bytes per eval; HIP-event timed inside the engine on its stream, every 17th pass (default run length) of
 the timed region sampled), ``roofline_reuse`` (the reduce kernel of a reuse pass, 28 B/eval) and
 ``cpu_baseline`` (the CPU oracle, 1 thread, rank 0 at N = 1 only).
 """
