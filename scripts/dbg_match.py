@@ -4,7 +4,7 @@ import numpy as np
 os.environ["S2M_DEBUG_MATCH"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from daliti_amd import Engine, synth
-c = synth.CONFIGS["C3"]
+c = synth.CONFIGS[os.environ.get("CONFIG", "C3")]
 m = synth.make_map(c["M"], c["L"]); s = synth.make_scan(c["beams"], c["az"], c["L"])
 _, xp, P = synth.filter_inputs()
 for g in [int(x) for x in os.environ.get("GROUPS", "4").split(",")]:
@@ -38,4 +38,9 @@ for g in [int(x) for x in os.environ.get("GROUPS", "4").split(",")]:
             sel = d[:, 1] == r
             if sel.any():
                 print("   r=%2d n=%6d  mean cyc %.0f  rounds %.2f" % (r, sel.sum(), cyc[sel].mean(), (d[sel, 3] & 0xff).mean()))
+        idx, d2 = e.get_neighbors()
+        miss = idx[:, 4] < 0
+        print("   points without five neighbours inside the gate: %d (%.3f); of the hard points: %.3f" % (miss.sum(), miss.mean(), miss[hm].mean() if hm.any() else 0))
+        none = idx[:, 0] < 0
+        print("   points with NO neighbour inside the gate: %d" % none.sum())
         e.close()
