@@ -767,6 +767,9 @@ __device__ __forceinline__ int kth_set_bit(uint64_t m, int k)
 // of 4 vs 8 make no difference -- the kernel is VALU-issue bound at ~58 %, TA ~27 % busy).
 constexpr int kPairSlots = 6;  // (brick,row) pairs a lane can hold per chunk of 64 bricks
 
+#ifndef S2M_HARD_BAND_EMPTY
+#define S2M_HARD_BAND_EMPTY 2.8f  // first band (cells) of a far point whose first shell held nothing
+#endif
 #ifndef S2M_HARD_OCC
 #define S2M_HARD_OCC 4  // waves per SIMD match_hard is compiled for (116 VGPRs at 4; 5 needs spills) = resident waves / 1024
 #endif
@@ -816,6 +819,13 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
         // band radius while no radius is known: the first shell covered (1 + fmin) c; 1.7 c measured best at C3
         // (1.3 / 1.5 / 1.7 / 2.0 / 2.5 c -> 68 / 67 / 61 / 64 / 68 us for the first-pass launch)
         float band = S2M_HARD_BAND * g.c;
+        // A point whose first shell was EMPTY (the predicted pose put it more than a cell off every surface) starts wider:
+        // 2.8 cells is the widest band that still takes the direct 7x7-row path below (radius within 3 cells), and its
+        // successor is the gate.  Measured with the gate clamps in place, search kernels per rematch pass, 1.7 -> 2.8
+        // cells for these points: C3 38.0 -> 37.7 us, C4 77.4 -> 65.6, R1 24.1 -> 23.8, C2 27.2 -> 27.3; 3.1 cells (the
+        // general path) 41.3 / 74.2 / 24.0 / 29.9.
+        if (!have_tau && a.nn_idx[(int64_t)qi * kK] < 0) band = S2M_HARD_BAND_EMPTY * g.c;
+        band = fminf(band, sqrtf(a.gates.knn_d2_gate * 1.0001f));  // no first band beyond the gate either (coarse grids)
         uint32_t rounds = 0;
         const int hbx = q.cx >> 3, hby = q.cy >> 3, hbz = q.cz >> 3;
         int nc = 0;  // cells waiting in the wave's list (wave-uniform)
