@@ -52,6 +52,7 @@ struct s2m_engine {
     bool local_map_init = false;
     float built_cell = 0.0f;  // cell size of the current grid (kept across incremental rebuilds)
     Mailbox mail;                   // stream waits of the per-frame entry points (polled, not hipStreamSynchronize)
+    bool in_batch = false;          // set while the handle is served by s2m_iterated_update_batch with several scans
     bool no_merge = false;          // S2M_NO_MERGE=1: every update rebuilds the grid from scratch (A/B and tests)
     bool last_update_merged = false;
     Grid grid{};
@@ -205,7 +206,13 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         m.wq = e->d_wq;
         m.qheads = e->d_qheads;
         m.dbg = e->dbg ? e->d_dbg : nullptr;
-        launch_match(m, e->match_group, e->stream);  // hard_count is zero: reset by every reduce launch
+        // Point batches per trip of the first-shell kernel (unless S2M_EASY_NB fixed it): three (24 loads in flight, 160
+        // VGPRs, 3 waves/SIMD) is fastest while all of the launch's waves are resident anyway -- up to 98 k points; beyond
+        // that, or when several scans are in flight on the chip (the batch entry), two (128 VGPRs, 4 waves/SIMD) wins:
+        // C4 0.225 -> 0.214 ms/step, C5 batch 13.3 -> 14.2 k scans/s, against C3 20.3 -> 21.1 us the other way.
+        int group = e->match_group;
+        if (((group >> 8) & 0xf) == 0 && ((int64_t)n * 2 > 3072 * 64 || e->in_batch)) group |= 2 << 8;
+        launch_match(m, group, e->stream);  // hard_count is zero: reset by every reduce launch
         e->nn_valid = true;
     }
     if (timed) S2M_HIP(e, hipEventRecord(e->ev[1], e->stream));
@@ -1113,6 +1120,11 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
         }
         return S2M_OK;
     };
+    for (int i = 0; i < k; ++i) handles[i]->in_batch = k >= 4;
+    struct ClearHint {  // whatever way the call ends
+        s2m_engine *const *h; int k;
+        ~ClearHint() { for (int i = 0; i < k; ++i) h[i]->in_batch = false; }
+    } clear_hint{handles, k};
     for (int i = 0; i < k; ++i) {
         s2m_engine *e = handles[i];
         S2M_HIP(e, hipSetDevice(e->device));
