@@ -482,8 +482,10 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=8, leaf=0.5):
         torch.cuda.synchronize()
         batches.append((time.perf_counter() - t0) / 8 * 1e3)
     b2b = float(np.median(batches))
+    sys.stderr.write("[bench] frame leg: back-to-back batches %s ms per frame\n" % ", ".join("%.3f" % b for b in batches))
     return {"ms_per_frame": float(w.sum()), "frames_per_s": float(1e3 / w.sum()),
             "ms_per_frame_back_to_back": float(b2b), "frames_per_s_back_to_back": float(1e3 / b2b),
+            "back_to_back_batches_ms": [float(b) for b in batches],
             "stages_ms": {"raw_to_scan": float(w[0]), "iterated_update": float(w[1]), "map_incremental": float(w[2]),
                           "fov_segment": float(w[3])},
             "scan_points_raw": int(n), "scan_points_after_voxel_grid": int(nd), "map_points": int(eng.map_size()),
