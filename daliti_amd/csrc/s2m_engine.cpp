@@ -87,9 +87,9 @@ struct s2m_engine {
     int64_t rows_cap = 0;
 
     Pose last_pose{};
-    uint32_t *d_hard = nullptr;   // hard list (n entries) followed by its counter
+    uint32_t *d_hard = nullptr;   // the far-point lists' counters sit behind 3 x n_cap words (the words themselves are free)
     uint32_t *d_qheads = nullptr; // match_hard's dequeue heads (kQueueWords)
-    float *d_wq = nullptr;        // world-frame query points of the hard list (3 x n_cap)
+    HardRec *d_hrec = nullptr;    // the far points' records: 2 x n_cap (without / with a radius)
     uint32_t *d_dbg = nullptr;  // S2M_DEBUG_MATCH=1: per-point diagnostics of the match kernel
     bool dbg = false;
     bool nn_valid = false;
@@ -202,8 +202,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         m.grid = e->grid; m.pose = pose; m.gates = gates;
         m.sx = sx; m.sy = sy; m.sz = sz; m.n = n;
         m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
-        m.hard_list = e->d_hard; m.hard_count = e->d_hard + 3 * e->n_cap;
-        m.wq = e->d_wq;
+        m.hard_rec = e->d_hrec; m.hard_count = e->d_hard + 3 * e->n_cap;
         m.qheads = e->d_qheads;
         m.dbg = e->dbg ? e->d_dbg : nullptr;
         // Point batches per trip of the first-shell kernel (unless S2M_EASY_NB fixed it): three (24 loads in flight, 160
@@ -360,7 +359,7 @@ int s2m_destroy(s2m_engine *e)
     free_undist(e->und);
     comm_destroy(e->comm);
     void *ptrs[] = {e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
-                    e->d_nn_d2, e->d_hard, e->d_qheads, e->d_wq, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
+                    e->d_nn_d2, e->d_hard, e->d_qheads, e->d_hrec, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_block) (void)hipHostFree(e->h_block);
@@ -628,7 +627,7 @@ int scan_reserve(s2m_engine *e, int64_t n)
     rc = rc ? rc : grow(e, &e->d_partials, (int64_t)std::max(reduce_blocks((int)cap), 1) * kRedTerms);
     rc = rc ? rc : grow(e, &e->d_block_off, (int64_t)rows_blocks((int)cap) + 1);
     rc = rc ? rc : grow(e, &e->d_hard, 3 * cap + 16);
-    rc = rc ? rc : grow(e, &e->d_wq, 3 * cap);
+    rc = rc ? rc : grow(e, &e->d_hrec, 2 * cap);
     if (!rc) S2M_HIP(e, hipMemsetAsync(e->d_hard + 3 * cap, 0, 16 * sizeof(uint32_t), e->stream));
     if (e->dbg) rc = rc ? rc : grow(e, &e->d_dbg, cap * 4);
     if (rc) return rc;

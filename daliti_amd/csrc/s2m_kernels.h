@@ -162,6 +162,16 @@ hipError_t undistort(UndistBuffers &u, const float *pts, int64_t stride, int64_t
 constexpr int kQueueShards = 64;
 constexpr int kQueueStride = 32;  // words (128 B)
 constexpr int kQueueWords = kQueueShards * kQueueStride;
+// What the first-shell kernel hands to match_hard for a point it could not resolve -- everything that kernel needs to
+// start, in one 32-byte record (it used to follow an index into three more arrays: one dependent load level per point)
+struct HardRec {
+    float wx, wy, wz;   // world-frame query
+    uint32_t qi;        // scan point
+    float d5;           // squared distance of the first shell's 5th neighbour (valid when found == 5)
+    uint32_t found;     // neighbours the first shell held (0 = empty shell, 5 = radius known)
+    uint32_t pad[2];
+};
+static_assert(sizeof(HardRec) == 32, "HardRec is two 16-byte loads");
 struct MatchArgs {
     Grid grid;
     Pose pose;
@@ -170,10 +180,9 @@ struct MatchArgs {
     int n;
     int32_t *nn_idx;     // n x 5, index into the caller's map array, -1 = missing
     float *nn_d2;        // n x 5 ascending, INFINITY = missing
-    uint32_t *hard_list; // 2 x n entries of scratch: the points the first-shell kernel could not resolve, without / with a radius
+    HardRec *hard_rec;   // 2 x n records of scratch: the points the first-shell kernel could not resolve, without / with a radius
     uint32_t *hard_count; // the two lengths (device counters, reset by every reduce launch)
     uint32_t *qheads = nullptr;  // kQueueShards dequeue heads of match_hard's work queue, kQueueStride words apart
-    float *wq = nullptr;      // 3 x n scratch: world-frame query point of every unresolved scan point (SoA)
     uint32_t *dbg = nullptr;  // optional diagnostics, 4 words per scan point
 };
 void launch_match(const MatchArgs &a, int group, hipStream_t st);

@@ -64,8 +64,9 @@ constexpr int kHardBatch = S2M_HARD_BATCH;  // same for the one-cell-per-lane ke
 #define S2M_HARD_BAND 1.7f  // first band of match_hard in cells (measured sweeps in DESIGN.md)
 #endif
 
-__device__ __forceinline__ void append_list(uint32_t *__restrict__ list, uint32_t *__restrict__ counter, bool want,
-                                            uint32_t value);
+struct Query;
+__device__ __forceinline__ void append_rec(HardRec *__restrict__ list, uint32_t *__restrict__ counter, bool want,
+                                           const HardRec &rec);
 __device__ __forceinline__ u64 make_key(float d2, uint32_t orig)
 {
     return ((u64)__float_as_uint(d2) << 32) | (u64)orig;
@@ -454,13 +455,18 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
     // atomics serialise in L2 (~90 per microsecond), ten thousand per-lane atomics would cost > 100 us.
     // unresolved: match_hard's list, in two parts -- the points without a radius (fewer than five neighbours in the
     // shell: two rounds there, ~11 us against ~5.5 us) are handed out first so that they do not form the launch's tail
-    append_list(a.hard_list, a.hard_count, j == 0 && !done && !found5, (uint32_t)qi);
-    append_list(a.hard_list + (int64_t)a.n, a.hard_count + 1, j == 0 && !done && found5, (uint32_t)qi);
+    {
+        uint32_t found = 0;
+#pragma unroll
+        for (int k = 0; k < kK; ++k) found += is_empty(best[k]) ? 0u : 1u;
+        const HardRec rec = {q.wx, q.wy, q.wz, (uint32_t)qi, d5, found, {0u, 0u}};
+        append_rec(a.hard_rec, a.hard_count, j == 0 && !done && !found5, rec);
+        append_rec(a.hard_rec + (int64_t)a.n, a.hard_count + 1, j == 0 && !done && found5, rec);
+    }
     if (j == 0) {
         // unresolved points keep their first-shell list too: match_hard takes its radius from it, and its
         // query point from here (the pose alone is 48 SGPRs that kernel would spill around every point)
         store_result(best, qi, a.nn_idx, a.nn_d2);
-        if (!done) { a.wq[qi] = q.wx; a.wq[(int64_t)a.n + qi] = q.wy; a.wq[2 * (int64_t)a.n + qi] = q.wz; }
         if (a.dbg) {
             a.dbg[4 * (int64_t)qi + 0] = (uint32_t)(wall_clock64() - t0);
             a.dbg[4 * (int64_t)qi + 1] = done ? 1u : 0u;
@@ -702,11 +708,16 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
     const bool done = found5 && d5 <= cube_bound2(g, q, 1);
     // unresolved: match_hard's list, in two parts -- the points without a radius (fewer than five neighbours in the
     // shell: two rounds there, ~11 us against ~5.5 us) are handed out first so that they do not form the launch's tail
-    append_list(a.hard_list, a.hard_count, j == 0 && !done && !found5, (uint32_t)qi);
-    append_list(a.hard_list + (int64_t)a.n, a.hard_count + 1, j == 0 && !done && found5, (uint32_t)qi);
+    {
+        uint32_t found = 0;
+#pragma unroll
+        for (int k = 0; k < kK; ++k) found += is_empty(best[k]) ? 0u : 1u;
+        const HardRec rec = {q.wx, q.wy, q.wz, (uint32_t)qi, d5, found, {0u, 0u}};
+        append_rec(a.hard_rec, a.hard_count, j == 0 && !done && !found5, rec);
+        append_rec(a.hard_rec + (int64_t)a.n, a.hard_count + 1, j == 0 && !done && found5, rec);
+    }
     if (j == 0) {
         store_result(best, qi, a.nn_idx, a.nn_d2);
-        if (!done) { a.wq[qi] = q.wx; a.wq[(int64_t)a.n + qi] = q.wy; a.wq[2 * (int64_t)a.n + qi] = q.wz; }
         if (a.dbg) {
             a.dbg[4 * (int64_t)qi + 0] = (uint32_t)(wall_clock64() - t0);
             a.dbg[4 * (int64_t)qi + 1] = done ? 1u : 0u;
@@ -723,8 +734,8 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
 
 // one atomic per wave for a list append: same-address atomics serialise in L2 (~90 per microsecond), ten thousand
 // per-lane atomics would cost > 100 us
-__device__ __forceinline__ void append_list(uint32_t *__restrict__ list, uint32_t *__restrict__ counter, bool want,
-                                            uint32_t value)
+__device__ __forceinline__ void append_rec(HardRec *__restrict__ list, uint32_t *__restrict__ counter, bool want,
+                                           const HardRec &rec)
 {
     const unsigned long long mask = __ballot(want);
     if (mask == 0ull) return;  // wave-uniform
@@ -733,7 +744,11 @@ __device__ __forceinline__ void append_list(uint32_t *__restrict__ list, uint32_
     uint32_t base = 0;
     if (lane64 == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
     base = __shfl(base, leader, 64);
-    if (want) list[base + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull))] = value;
+    if (want) {
+        uint4 *dst = reinterpret_cast<uint4 *>(list + (base + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull))));
+        dst[0] = make_uint4(__float_as_uint(rec.wx), __float_as_uint(rec.wy), __float_as_uint(rec.wz), rec.qi);
+        dst[1] = make_uint4(__float_as_uint(rec.d5), rec.found, 0u, 0u);
+    }
 }
 
 // ---- the rest: one wave per hard scan point, occupied rows only ------------------------------------
@@ -805,14 +820,14 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
     uint32_t h = (uint32_t)wave;
     while (h < count) {
         const long long t0 = a.dbg ? wall_clock64() : 0;
-        const int qi = (int)(h < c0 ? a.hard_list[h] : a.hard_list[(int64_t)a.n + (h - c0)]);
-        const Query q = query_at(g, a.wq[qi], a.wq[(int64_t)a.n + qi], a.wq[2 * (int64_t)a.n + qi]);
+        // the point's record: query, index, and the radius when the first shell found five (then one round is exact)
+        const uint4 *rp = reinterpret_cast<const uint4 *>(h < c0 ? a.hard_rec + h : a.hard_rec + ((int64_t)a.n + (h - c0)));
+        const uint4 r0 = rp[0], r1 = rp[1];
+        const int qi = (int)r0.w;
+        const Query q = query_at(g, __uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
         const float fxq = (float)q.cx + q.frx;  // query x in cell units
-        // radius: the first shell's 5th-best distance when it found five (then one round is exact)
-        const int32_t ci4 = a.nn_idx[(int64_t)qi * kK + (kK - 1)];
-        const float cd4 = a.nn_d2[(int64_t)qi * kK + (kK - 1)];
-        bool have_tau = ci4 >= 0;
-        float tau = have_tau ? cd4 : 0.0f;  // squared
+        bool have_tau = r1.y == (uint32_t)kK;
+        float tau = have_tau ? __uint_as_float(r1.x) : 0.0f;  // squared
         u64 t[kK], best[kK];
 #pragma unroll
         for (int k = 0; k < kK; ++k) { t[k] = kEmptyKey; best[k] = kEmptyKey; }
@@ -824,7 +839,7 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
         // successor is the gate.  Measured with the gate clamps in place, search kernels per rematch pass, 1.7 -> 2.8
         // cells for these points: C3 38.0 -> 37.7 us, C4 77.4 -> 65.6, R1 24.1 -> 23.8, C2 27.2 -> 27.3; 3.1 cells (the
         // general path) 41.3 / 74.2 / 24.0 / 29.9.
-        if (!have_tau && a.nn_idx[(int64_t)qi * kK] < 0) band = S2M_HARD_BAND_EMPTY * g.c;
+        if (r1.y == 0u) band = S2M_HARD_BAND_EMPTY * g.c;
         band = fminf(band, sqrtf(a.gates.knn_d2_gate * 1.0001f));  // no first band beyond the gate either (coarse grids)
         uint32_t rounds = 0;
         const int hbx = q.cx >> 3, hby = q.cy >> 3, hbz = q.cz >> 3;
