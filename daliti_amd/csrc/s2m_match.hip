@@ -860,12 +860,40 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
         };
         auto flush_cells = [&]() {
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // list stores before the loads below
-            for (int jb = 0; jb < nc; jb += 64) {  // wave-uniform trip count
+            // Pass 1: the two prefix words of EVERY listed cell, four chunks of 64 cells per round trip; only the cells
+            // that hold points stay, compacted in place as point runs {start, end} (a compacted entry never lands beyond
+            // the entries already read).  Most listed cells of a wide band are empty -- the point is far from every
+            // surface, that is why it is here -- and each chunk of 64 cells used to cost a dependent table-then-points
+            // round trip whether or not it held anything.
+            int no = 0;
+            for (int jb = 0; jb < nc; jb += 256) {  // wave-uniform trip count
+                uint32_t rs[4], re[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = jb + u * 64 + lane;
+                    rs[u] = 0u; re[u] = 0u;
+                    if (j < nc) {
+                        const uint2 ce = cells[j];
+                        const uint32_t *tb = g.tab + (int64_t)(ce.x - 1) * kBrickStride + ce.y;
+                        rs[u] = tb[0]; re[u] = tb[1];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the reads above before the in-place writes
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool holds = rs[u] < re[u];
+                    const unsigned long long m = __ballot(holds);
+                    if (holds) cells[no + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(rs[u], re[u]);
+                    no += __popcll(m);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            // Pass 2: the runs, one per lane and trip
+            for (int jb = 0; jb < no; jb += 64) {  // wave-uniform trip count
                 const int j = jb + lane;
-                if (j < nc) {
-                    const uint2 ce = cells[j];
-                    const uint32_t *tb = g.tab + (int64_t)(ce.x - 1) * kBrickStride + ce.y;
-                    scan_points<kHardBatch, WIDE>(g, tb[0], tb[1], q.wx, q.wy, q.wz, t);
+                if (j < no) {
+                    const uint2 run = cells[j];
+                    scan_points<kHardBatch, WIDE>(g, run.x, run.y, q.wx, q.wy, q.wz, t);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // loads above before the next stores
