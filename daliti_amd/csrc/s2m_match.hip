@@ -782,6 +782,9 @@ __device__ __forceinline__ int kth_set_bit(uint64_t m, int k)
 // of 4 vs 8 make no difference -- the kernel is VALU-issue bound at ~58 %, TA ~27 % busy).
 constexpr int kPairSlots = 6;  // (brick,row) pairs a lane can hold per chunk of 64 bricks
 
+#ifndef S2M_HARD_CHUNKS
+#define S2M_HARD_CHUNKS 4  // chunks of 64 listed cells whose table words are fetched per round trip
+#endif
 #ifndef S2M_HARD_BAND_EMPTY
 #define S2M_HARD_BAND_EMPTY 2.8f  // first band (cells) of a far point whose first shell held nothing
 #endif
@@ -866,10 +869,10 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
             // surface, that is why it is here -- and each chunk of 64 cells used to cost a dependent table-then-points
             // round trip whether or not it held anything.
             int no = 0;
-            for (int jb = 0; jb < nc; jb += 256) {  // wave-uniform trip count
-                uint32_t rs[4], re[4];
+            for (int jb = 0; jb < nc; jb += 64 * S2M_HARD_CHUNKS) {  // wave-uniform trip count
+                uint32_t rs[S2M_HARD_CHUNKS], re[S2M_HARD_CHUNKS];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < S2M_HARD_CHUNKS; ++u) {
                     const int j = jb + u * 64 + lane;
                     rs[u] = 0u; re[u] = 0u;
                     if (j < nc) {
@@ -880,7 +883,7 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the reads above before the in-place writes
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < S2M_HARD_CHUNKS; ++u) {
                     const bool holds = rs[u] < re[u];
                     const unsigned long long m = __ballot(holds);
                     if (holds) cells[no + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(rs[u], re[u]);
