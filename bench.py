@@ -17,21 +17,38 @@ Workloads (``--config``; daliti_amd/synth.py):
            ikd_Tree.cpp:489-521) and the scan through s2m_scan_set_downsampled(0.5)
            (laserMapping.cpp:775-776)
 
-N > 1 (launched by torch.distributed.run), ``--mode sharded``: the scan points are split over the
-ranks, the map is replicated, the 158-double normal block is summed with one RCCL all-reduce per
-iteration.  ``--scaling strong`` (default for C4 = BASELINE configs[3]): ONE scan of the config's
-size, shard_range() per rank (131,072 / 8 = 16,384 points per GPU at N = 8).  ``--scaling weak``
-(default otherwise, so that the driver's `--gpus N` sweep keeps the per-GPU work fixed): the scan
-grows to N x beams, one config-sized shard per rank.
+Launching.  ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N
+ranks itself: before torch is imported or the GPU touched it runs ``python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>`` as a CHILD process,
+relays the child's output with rank 0's JSON line last, and exits with the child's return code.  Launched
+by torch.distributed.run directly (the driver's form) it reads RANK / LOCAL_RANK / WORLD_SIZE.  A run whose
+world size differs from ``--gpus`` is refused.
 
-Extra objects on the JSON line: ``roofline`` (the rematch pass: search kernels + reduce<FIT>,
-88 algorithmic bytes per eval; HIP-event timed inside the engine on its stream, every 17th pass (default run length) of
-the timed region sampled), ``roofline_reuse`` (the reduce kernel of a reuse pass, 28 B/eval) and
-``cpu_baseline`` (the CPU oracle, 1 thread, rank 0 at N = 1 only).
+N > 1, ``--mode sharded`` (default except C5): ONE scan of the config's size is split over the ranks with
+shard_range() (north star: "a single scan's points shard across GPUs"; 65,536 / 8 = 8,192 points per GPU
+at N = 8 for C3), the map is replicated, and the 158-double normal block is summed once per iteration --
+``--collective rccl`` (default): one RCCL all-reduce issued from the engine's C++ loop; that is
+``"scaling": "strong"``.  ``--scaling weak`` grows the scan to N x beams instead (one config-sized shard
+per rank); the strong run also reports it as the side object ``weak_scaling``.
+``--collective host --shards S`` is the single-process form (one rank drives S handles -- S devices, or S
+shards on one device -- and sums the S pinned blocks on the host, no collective library).
+
+The timed region is K calls of the C ABI from a C++ loop (tools/bench_loop.cpp: the reference's caller is
+C++) bracketed by barrier + device synchronise; nothing inside it is instrumented.  The HIP-event samples
+behind ``roofline`` are taken in a SEPARATE untimed loop afterwards (every pass of 40 more steps).
+
+Extra objects on the JSON line: ``roofline`` (the rematch pass: match_rows + match_hard + reduce<FIT>,
+88 algorithmic bytes per eval) with ``roofline.issue`` (the issue-side reading of the same pass from the
+committed SQ counters), ``roofline_reuse`` (the reduce kernel of a reuse pass, 28 B/eval), ``cpu_baseline``
+(the CPU oracle, 1 thread, rank 0 at N = 1 only), ``c5_batch`` (BASELINE configs[4] on this one GPU: 8
+scans in flight through s2m_iterated_update_batch against the map already built) and ``frame_pipeline``
+(raw sweep -> undistort + voxel grid -> update -> map update -> FOV trim, 64 frames, median / p99 / max).
 """
 import argparse
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -43,11 +60,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 BYTES_REMATCH = 88              # 12 B scan point + 5 x 12 B neighbours + 16 B plane
 BYTES_REUSE = 28                # 12 B scan point + 16 B cached plane
-TIMING_STRIDE = 17              # coprime to the 5 passes of a step: every kind of pass gets sampled (~60 samples in 200 steps;
-                                # a sampled pass costs ~10 us of event calls, so the stride keeps that under 2 % of a step)
+SAMPLE_STEPS = 40               # untimed steps of the HIP-event sampling loop (every pass is timed there)
+SIMDS = 1024                    # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md)
+CLOCK_HZ = 2.4e9
+VALU_CYCLES = 2                 # a wave64 VALU instruction issues over 2 cycles on a SIMD-32
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -56,12 +75,19 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "sharded", "replicas"],
                     help="auto: replicas for C5, sharded otherwise")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
-                    help="sharded mode only; auto: strong for C4 (BASELINE configs[3]), weak otherwise")
+                    help="sharded mode only; auto = strong: ONE scan of the config's size split over the ranks")
+    ap.add_argument("--collective", default="rccl", choices=["rccl", "host"],
+                    help="rccl: one rank per GPU, RCCL all-reduce of the block; host: ONE process drives --shards "
+                         "handles and sums their pinned blocks itself (s2m_iterated_update_multi)")
+    ap.add_argument("--shards", type=int, default=0,
+                    help="--collective host: number of handles (default: the visible devices); handle i uses device "
+                         "i %% device_count, so more shards than devices puts several shards on one device")
     ap.add_argument("--max-iter", type=int, default=5)
     ap.add_argument("--cell", type=float, default=0.0)
     ap.add_argument("--cpu-steps", type=int, default=32,
                     help="CPU baseline sample: iterated updates of the same scan, 1 thread (0 = skip); 32 is ~7 s at C3")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline and every side leg")
+    ap.add_argument("--no-side", action="store_true", help="skip the side legs (c5_batch, frame_pipeline, weak_scaling)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU testing)")
     ap.add_argument("--all-on-device0", action="store_true", help="test hook: every rank uses GPU 0")
@@ -74,11 +100,48 @@ def parse():
     ap.add_argument("--force-collective", action="store_true",
                     help="run the sharded/all-reduce code path even with one rank (test hook)")
     ap.add_argument("--replicas", type=int, default=0, help="C5: number of independent scans (default 8)")
-    ap.add_argument("--sort-scan", default="none", choices=["none", "morton"],
-                    help="experiment: hand the scan over in Morton order of 0.5 m body-frame cells instead of ring order")
     ap.add_argument("--sequential", action="store_true",
                     help="C5 on one GPU: serve the scans one after the other instead of through s2m_iterated_update_batch")
-    return ap.parse_args()
+    ap.add_argument("--py-loop", action="store_true",
+                    help="drive the timed steps from Python (one ctypes call per step) instead of tools/bench_loop.cpp")
+    ap.add_argument("--frames", type=int, default=64, help="frames of the frame_pipeline side leg")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = pick a free one)")
+    return ap.parse_args(argv)
+
+
+# ---- self-launch: `python bench.py --gpus N` without a launcher ----------------------------------------
+def needs_self_launch(a, env):
+    """N > 1 ranks are wanted and nobody has started them: no torch.distributed.run environment."""
+    return a.gpus > 1 and a.collective == "rccl" and "WORLD_SIZE" not in env and "RANK" not in env
+
+
+def self_launch_argv(a, argv, port):
+    """Command line of the child launcher (one rank per GPU on this node, loopback rendezvous)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a, argv):
+    """Start the ranks as a child process (never exec: this process may not be replaced once anything has
+    touched the GPU, and nothing here has), relay its output with the JSON line last, return its code."""
+    cmd = self_launch_argv(a, argv, a.master_port or free_port())
+    sys.stderr.write("[bench] --gpus %d without WORLD_SIZE: launching %s\n" % (a.gpus, " ".join(cmd)))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = p.stdout.splitlines()
+    js = [l for l in lines if l.startswith("{") and l.rstrip().endswith("}")]
+    for l in lines:
+        if not js or l is not js[-1]:
+            print(l)
+    if js:
+        print(js[-1], flush=True)
+    return p.returncode if p.returncode != 0 or js else 1
 
 
 def build_reference_density_map(eng, cloud, leaf=0.5, chunk=1 << 20):
@@ -89,15 +152,59 @@ def build_reference_density_map(eng, cloud, leaf=0.5, chunk=1 << 20):
     return eng.map_size()
 
 
+class CLoop:
+    """tools/bench_loop.cpp (a C++ caller of the C ABI) bound with ctypes; one call runs `steps` steps."""
+
+    def __init__(self, engs, x_prop, P0, mode):
+        from daliti_amd.engine import IterLog, library_path
+        path = os.path.join(os.path.dirname(library_path()), "libs2m_benchloop.so")
+        if not os.path.exists(path):
+            raise SystemExit("%s is missing: run __graft_entry__.build()" % path)
+        C.CDLL(library_path(), mode=C.RTLD_GLOBAL)
+        self.fn = C.CDLL(path).s2m_bench_loop
+        self.fn.restype = C.c_int
+        k = len(engs)
+        ns = 1 if mode == 2 else k
+        self.engs, self.k, self.ns, self.mode = engs, k, ns, mode
+        self.hs = (C.c_void_p * k)(*[e.h for e in engs])
+        self.xp = np.ascontiguousarray(np.stack(x_prop[:ns]), np.float64)
+        self.P0 = np.ascontiguousarray(np.stack(P0[:ns]), np.float64)
+        self.x = np.zeros((ns, 36))
+        self.P = np.zeros((ns, 24, 24))
+        self.logs = (IterLog * k)()
+        self.step0 = 0
+
+    def run(self, steps):
+        it, rm = C.c_int64(0), C.c_int64(0)
+        rc = self.fn(self.hs, C.c_int32(self.k), C.c_int32(steps), C.c_int32(self.step0), C.c_int32(self.mode),
+                     C.c_void_p(self.xp.ctypes.data), C.c_void_p(self.P0.ctypes.data), C.c_void_p(self.x.ctypes.data),
+                     C.c_void_p(self.P.ctypes.data), self.logs, C.byref(it), C.byref(rm))
+        self.step0 += steps
+        if rc != 0:
+            msgs = [e.lib.s2m_last_error(e.h).decode() for e in self.engs]
+            raise SystemExit("s2m_bench_loop failed: %d (%s)" % (rc, "; ".join(m for m in msgs if m)))
+        return it.value, rm.value
+
+    def result(self):
+        log = self.logs[0]
+        return dict(x=self.x[0].copy(), P=self.P[0].copy(), iters=log.iters, effct=np.array(log.effct[:log.iters]))
+
+
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if needs_self_launch(a, os.environ):
+        sys.exit(self_launch(a, argv))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.all_on_device0:
         local_rank = 0
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if a.collective == "rccl" and world != a.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d (start one rank per GPU, or let bench.py launch "
+                         "them: run it without WORLD_SIZE in the environment)" % (a.gpus, world))
+    if a.collective == "host" and world != 1:
+        raise SystemExit("--collective host is a single-process form: run it without torch.distributed.run")
     import torch
     import torch.distributed as dist
     from daliti_amd import Engine, synth
@@ -117,24 +224,38 @@ def main():
 
     cfgd = synth.CONFIGS[a.config]
     mode = a.mode if a.mode != "auto" else ("replicas" if a.config == "C5" else "sharded")
+    host_multi = a.collective == "host" and mode == "sharded"
+    n_dev = torch.cuda.device_count()
+    n_shards = (a.shards or max(a.gpus, 1)) if host_multi else 1
     sharded = (world > 1 or a.force_collective) and mode == "sharded"
-    scaling = a.scaling if a.scaling != "auto" else ("strong" if a.config == "C4" else "weak")
-    if not sharded:
+    scaling = a.scaling if a.scaling != "auto" else "strong"
+    if not sharded and not host_multi:
         scaling = "weak"   # replicas / one GPU: per-GPU work is fixed by construction
+    parts = n_shards if host_multi else world   # pieces one scan is split into
     # ---- workload -------------------------------------------------------------------------------
     t0 = time.time()
     map_xyz = synth.make_map(cfgd["M"], cfgd["L"], seed=1)
-    scans = []            # one entry per independent scan this rank serves: (body points, sensor position)
-    if sharded:
-        if scaling == "strong":   # ONE scan of the config's size, split over the ranks
+    scans = []            # one entry per handle of this rank: (body points, sensor position)
+
+    def sharded_scan(kind, piece):
+        """piece `piece` of `parts` of the sharded workload: strong = ONE scan of the config's size split with
+        shard_range; weak = the scan grows to parts x beams, one config-sized piece each."""
+        if kind == "strong":
             scan_all = synth.make_scan(cfgd["beams"], cfgd["az"], cfgd["L"], seed=2)
-            lo, hi = shard_range(len(scan_all), rank, world)
-        else:                     # the scan grows with the job: one config-sized shard per rank
-            scan_all = synth.make_scan(cfgd["beams"] * world, cfgd["az"], cfgd["L"], seed=2)
+            lo, hi = shard_range(len(scan_all), piece, parts)
+        else:
+            scan_all = synth.make_scan(cfgd["beams"] * parts, cfgd["az"], cfgd["L"], seed=2)
             per = cfgd["beams"] * cfgd["az"]
-            lo, hi = rank * per, (rank + 1) * per
-        scans.append((scan_all[lo:hi], synth.SENSOR_POS))
-        n_scan_total = len(scan_all)
+            lo, hi = piece * per, (piece + 1) * per
+        return scan_all[lo:hi], len(scan_all)
+
+    if sharded:
+        sc, n_scan_total = sharded_scan(scaling, rank)
+        scans.append((sc, synth.SENSOR_POS))
+    elif host_multi:
+        for i in range(n_shards):
+            sc, n_scan_total = sharded_scan(scaling, i)
+            scans.append((sc, synth.SENSOR_POS))
     elif mode == "replicas" and (a.config == "C5" or world > 1):
         nrep = a.replicas or cfgd.get("replicas", world)
         for k in range(rank, nrep, world):   # SURVEY 8d: seeds 2..9, sensor offsets (k - 3.5) * 2 m in x
@@ -146,15 +267,6 @@ def main():
         n_scan_total = len(scans[0][0])
     if not scans:
         raise SystemExit("rank %d has no scan to serve (more ranks than replicas)" % rank)
-    if a.sort_scan == "morton":
-        def morton_order(pts, cell=0.5):
-            q = np.floor((pts - pts.min(0)) / cell).astype(np.uint64)
-            code = np.zeros(len(pts), np.uint64)
-            for b in range(16):
-                for ax in range(3):
-                    code |= ((q[:, ax] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + ax)
-            return np.argsort(code, kind="stable")
-        scans = [(s[morton_order(s.astype(np.float64))], pos) for s, pos in scans]
     filt = [synth.filter_inputs(pos) for _, pos in scans]
     t_gen = time.time() - t0
 
@@ -166,37 +278,53 @@ def main():
     assert stream.cuda_stream != 0
     engs = []
     d_keep = []   # device tensors handed to the engine as raw pointers stay alive until the end
-    for k, (scan, _pos) in enumerate(scans):
-        e = Engine(max_iter=a.max_iter, cell_size=a.cell, device=local_rank, feat_threshold=100,
+    for k in range(len(scans)):
+        dev = (k % n_dev) if host_multi else local_rank
+        e = Engine(max_iter=a.max_iter, cell_size=a.cell, device=dev, feat_threshold=100,
                    extrinsic_est_en=int(a.extrinsic))
-        if k == 0:
+        if k == 0 and not host_multi:
             e.set_stream(stream.cuda_stream)
         engs.append(e)
     eng = engs[0]
     # inputs resident in HBM before the timed region: hand the engine device pointers
     torch.cuda.synchronize()
     t0 = time.time()
+    owners = {}           # device -> the handle that owns that device's copy of the map
     if a.config == "R1":
         m_map = build_reference_density_map(eng, map_xyz)
+        owners[eng.cfg.device] = eng
     else:
-        d_map = torch.from_numpy(map_xyz).cuda()
-        d_keep.append(d_map)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        eng.map_build_device(d_map.data_ptr(), 3, len(map_xyz))
+        for e in engs:
+            dev = e.cfg.device
+            if dev in owners:
+                continue
+            with torch.cuda.device(dev):
+                d_map = torch.from_numpy(map_xyz).cuda()
+                d_keep.append(d_map)
+                torch.cuda.synchronize(dev)
+                if e is eng:
+                    t0 = time.time()
+                e.map_build_device(d_map.data_ptr(), 3, len(map_xyz))
+                torch.cuda.synchronize(dev)
+                if e is eng:
+                    t_build = time.time() - t0
+            owners[dev] = e
         m_map = len(map_xyz)
-    torch.cuda.synchronize()
-    t_build = time.time() - t0
-    for e in engs[1:]:
-        e.map_share(eng)   # several scans in flight search ONE HBM-resident map
+    if a.config == "R1":
+        torch.cuda.synchronize()
+        t_build = time.time() - t0
+    for e in engs:
+        if owners[e.cfg.device] is not e:
+            e.map_share(owners[e.cfg.device])   # several handles on a device search ONE HBM-resident map
     n_local = 0
     for e, (scan, _pos) in zip(engs, scans):
         if a.config == "R1":
             n_local += e.scan_set_downsampled(scan, 0.5)
         else:
-            d_scan = torch.from_numpy(np.ascontiguousarray(scan)).cuda()
-            d_keep.append(d_scan)
-            e.scan_set_device(d_scan.data_ptr(), 3, len(scan))
+            with torch.cuda.device(e.cfg.device):
+                d_scan = torch.from_numpy(np.ascontiguousarray(scan)).cuda()
+                d_keep.append(d_scan)
+                e.scan_set_device(d_scan.data_ptr(), 3, len(scan))
             n_local += len(scan)
     info = eng.map_info()
 
@@ -231,119 +359,135 @@ def main():
     from daliti_amd.engine import IterLog
     x_prop0, P0 = filt[0][1], filt[0][2]
     use_callback = sharded and not builtin_comm
-    if use_callback:
-        from daliti_amd.sharding import allreduce_block
-
-        def reduce_cb():
-            allreduce_block(blk)
-
-    # preallocated per-scan buffers: lean calls, no per-step conversions
-    bufs = [dict(x=np.zeros(36), xp=np.ascontiguousarray(f[1], np.float64), P=np.zeros((24, 24)), P0=f[2],
-                 log=IterLog()) for f in filt]
+    batched = len(engs) > 1 and not use_callback and not a.sequential and not host_multi
+    loop_mode = 2 if host_multi else (1 if batched else 0)
     last = {}
 
-    batched = len(engs) > 1 and not use_callback and not a.sequential
-    if batched:  # all of this rank's scans in flight at once, one host thread (s2m_iterated_update_batch)
-        from daliti_amd.engine import IterLog as _IL
-        bx = np.zeros((len(engs), 36)); bxp = np.ascontiguousarray(np.stack([b["xp"] for b in bufs]))
-        bP = np.zeros((len(engs), 24, 24)); blogs = (_IL * len(engs))()
+    if use_callback or a.py_loop:
+        # Python-driven steps: the torch.distributed callback form needs the interpreter anyway
+        if use_callback:
+            from daliti_amd.sharding import allreduce_block
 
-    def step_batched(k_step):
-        for e in engs:
-            e.set_feat_queue(())
-        bx[:] = bxp
-        for i, b in enumerate(bufs):
-            bP[i] = b["P0"]
-            bP[i, 0, 0] += (k_step & 1) * 1e-15
-        Engine.iterated_update_batch(engs, bx, bxp, bP, blogs)
-        bufs[0]["x"][:] = bx[0]; bufs[0]["P"][:] = bP[0]
-        bufs[0]["log"] = blogs[0]
-        return sum(l.iters for l in blogs), sum(l.rematch_passes for l in blogs)
+            def reduce_cb():
+                allreduce_block(blk)
+        bufs = [dict(x=np.zeros(36), xp=np.ascontiguousarray(f[1], np.float64), P=np.zeros((24, 24)), P0=f[2],
+                     log=IterLog()) for f in filt]
+        if batched or host_multi:
+            ns = 1 if host_multi else len(engs)
+            bx = np.zeros((ns, 36)); bxp = np.ascontiguousarray(np.stack([b["xp"] for b in bufs[:ns]]))
+            bP = np.zeros((ns, 24, 24)); blogs = (IterLog * len(engs))()
+        step_no = [0]
 
-    def step(k_step):
-        """One iterated update per scan this rank serves.  The degeneracy queue is cleared so that every step
-        is the same scan arriving fresh.  P differs from the previous step's P in its last bit: in a real
-        stream the covariance changes every scan, so the engine's per-distinct-P cache of (P/R)^-1 must MISS
-        once per scan -- that 24x24 inverse is part of the step (round-1 bench skipped it)."""
-        it = rm = 0
-        for e, b in zip(engs, bufs):
-            e.set_feat_queue(())
-            b["x"][:] = b["xp"]
-            b["P"][:] = b["P0"]
-            b["P"][0, 0] += (k_step & 1) * 1e-15
+        def run_steps(steps):
+            it = rm = 0
+            for _ in range(steps):
+                k_step = step_no[0]
+                step_no[0] += 1
+                for e in engs:
+                    e.set_feat_queue(())
+                if batched or host_multi:
+                    bx[:] = bxp
+                    for i in range(len(bx)):
+                        bP[i] = bufs[i]["P0"]
+                        bP[i, 0, 0] += (k_step & 1) * 1e-15
+                    if host_multi:
+                        Engine.iterated_update_multi(engs, bx[0], bxp[0], bP[0], blogs)
+                    else:
+                        Engine.iterated_update_batch(engs, bx, bxp, bP, blogs)
+                    bufs[0]["x"][:] = bx[0]; bufs[0]["P"][:] = bP[0]; bufs[0]["log"] = blogs[0]
+                    it += sum(l.iters for l in blogs[:len(bx)])
+                    rm += sum(l.rematch_passes for l in blogs[:len(bx)])
+                    continue
+                for e, b in zip(engs, bufs):
+                    b["x"][:] = b["xp"]
+                    b["P"][:] = b["P0"]
+                    b["P"][0, 0] += (k_step & 1) * 1e-15
+                    if use_callback:
+                        r = e.iterated_update_sharded(b["x"], b["xp"], b["P"], blk.data_ptr(), reduce_cb)
+                        b["x"][:], b["P"][:] = r["x"], r["P"]
+                        it += r["iters"]
+                        rm += r["rematch_passes"]
+                        last[id(e)] = (r["iters"], r["effct"])
+                    else:
+                        if "call" not in b:  # ctypes arguments built once (harness overhead, not the product's)
+                            b["call"] = e.iterated_update_bound(b["x"], b["xp"], b["P"], b["log"])
+                        b["call"]()
+                        it += b["log"].iters
+                        rm += b["log"].rematch_passes
+            return it, rm
+
+        def result():
+            b0 = bufs[0]
             if use_callback:
-                r = e.iterated_update_sharded(b["x"], b["xp"], b["P"], blk.data_ptr(), reduce_cb)
-                b["x"][:], b["P"][:] = r["x"], r["P"]
-                it += r["iters"]
-                rm += r["rematch_passes"]
-                last[id(e)] = (r["iters"], r["effct"])
-            else:
-                if "call" not in b:  # ctypes arguments built once (harness overhead, not the product's)
-                    b["call"] = e.iterated_update_bound(b["x"], b["xp"], b["P"], b["log"])
-                b["call"]()
-                it += b["log"].iters
-                rm += b["log"].rematch_passes
-        return it, rm
+                return dict(x=b0["x"].copy(), P=b0["P"].copy(), iters=last[id(eng)][0], effct=np.array(last[id(eng)][1]))
+            return dict(x=b0["x"].copy(), P=b0["P"].copy(), iters=b0["log"].iters,
+                        effct=np.array(b0["log"].effct[:b0["log"].iters]))
+        timed_loop = "Python (one ctypes call per step)"
+    else:
+        cl = CLoop(engs, [f[1] for f in filt], [f[2] for f in filt], loop_mode)
+        run_steps, result = cl.run, cl.result
+        timed_loop = "C++ caller (tools/bench_loop.cpp), one ctypes call for all steps"
 
     def fence():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
+        for d in owners:
+            torch.cuda.synchronize(d)
 
-    if batched:
-        step = step_batched
-    for k in range(a.warmup):
-        step(k)
-    # sampling stride of the HIP-event timing: the largest of these (all coprime to the 5 passes of a step) that
-    # still leaves ~40 sampled passes in the timed region
-    stride = 3
-    for cand in (7, 11, 13, TIMING_STRIDE):
-        if a.steps * 5 // cand >= 40:
-            stride = cand
-    eng.set_timing(stride)
-    import gc
-    gc.disable()  # no collector pauses inside the timed region (harness hygiene)
-    fence()
-    t0 = time.perf_counter()
-    iters = rematch = 0
-    for k in range(a.steps):
-        it, rm = step(k)
-        iters += it
-        rematch += rm
-    fence()
-    dt = time.perf_counter() - t0
-    gc.enable()
+    def timed(steps):
+        """EXACTLY `steps` steps between barrier + synchronise on both sides; MAX over ranks."""
+        import gc
+        gc.disable()  # no collector pauses inside the timed region (harness hygiene)
+        fence()
+        t0 = time.perf_counter()
+        it, rm = run_steps(steps)
+        fence()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, it, rm
+
+    run_steps(a.warmup)
+    dt, iters, rematch = timed(a.steps)
+    res = result()
+    # ---- HIP-event samples: a separate, untimed loop (every pass timed; three event records + a sync each) ----
+    for e in engs:
+        e.set_timing(1)
+    run_steps(SAMPLE_STEPS)
     tstats = eng.timing_stats()
-    eng.set_timing(False)
-    b0 = bufs[0]
-    if use_callback:
-        res = dict(x=b0["x"].copy(), P=b0["P"].copy(), iters=last[id(eng)][0], effct=np.array(last[id(eng)][1]))
-    else:
-        res = dict(x=b0["x"].copy(), P=b0["P"].copy(), iters=b0["log"].iters,
-                   effct=np.array(b0["log"].effct[:b0["log"].iters]))
+    for e in engs:
+        e.set_timing(0)
+
+    n_indep = 1 if (sharded or host_multi) else len(scans)      # independent scans per step on this rank
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tot = torch.tensor([float(n_local) * iters / max(len(scans), 1), float(iters), float(len(scans) * a.steps)],
+        tot = torch.tensor([float(n_local) * iters / max(n_indep, 1), float(iters), float(n_indep * a.steps)],
                            dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         # evals: every rank's points x its passes; iterations / scans: summed over independent scans only
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         evals_total, iters_all, scans_all = [float(v) for v in tot.tolist()]
     else:
-        evals_total = float(n_local) * iters / max(len(scans), 1)
-        iters_all, scans_all = float(iters), float(len(scans) * a.steps)
+        evals_total = float(n_local) * iters / max(n_indep, 1)
+        iters_all, scans_all = float(iters), float(n_indep * a.steps)
     if sharded:  # the ranks iterate one and the same scan together
         iters_all, scans_all = float(iters), float(a.steps)
     value = evals_total / dt
     x_true = filt[0][0]
     pose_err = float(np.abs(res["x"][9:12] - x_true[9:12]).max())
-    n_per_scan = n_local // max(len(scans), 1)
+    n_per_scan = n_scan_total if (sharded or host_multi) else n_local // max(len(scans), 1)
 
     if sharded:
         par = ("scan points sharded x%d (%s scaling: %d-pt scan, %d per rank), map replicated, RCCL all-reduce of 158 f64 "
                "per iteration (%s)" % (world, scaling, n_scan_total, n_local,
                                        "engine-owned communicator" if builtin_comm else "torch.distributed callback"))
+    elif host_multi:
+        par = ("single process, %d handles on %d device(s) (%s scaling: %d-pt scan, %d per handle), one map per device, "
+               "the %d pinned 160-double blocks summed on the host in handle order, ONE fp64 update; no collective "
+               "library (s2m_iterated_update_multi)" % (n_shards, min(n_shards, n_dev), scaling, n_scan_total,
+                                                        n_local // n_shards, n_shards))
     elif len(scans) > 1 or world > 1:
         par = "replicas: %d independent scans on %d GPU(s), one shared map per GPU, no collective; %s" % (
             int(scans_all / a.steps), world,
@@ -354,7 +498,7 @@ def main():
         "metric": "residual+Jacobian evals/sec",
         "value": value,
         "unit": "evals/s",
-        "n_gpus": world,
+        "n_gpus": world if not host_multi else min(n_shards, n_dev),
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps,
@@ -366,11 +510,11 @@ def main():
         "config": {
             "workload": "%s: full iterated ESKF (max_iter %d%s), %d-pt scan%s vs %d-pt map%s" % (
                 a.config, a.max_iter, ", extrinsic_est_en" if a.extrinsic else "", n_per_scan,
-                " shard" if sharded else "", m_map,
+                " in %d shards" % parts if (sharded or host_multi) else "", m_map,
                 " (reference density: map through Add_Points(downsample 0.5 m), scan through VoxelGrid 0.5 m)"
                 if a.config == "R1" else ""),
-            "scan_points_per_gpu": n_local,
-            "scans_per_gpu": len(scans),
+            "scan_points_per_gpu": n_local if not host_multi else n_local // max(min(n_shards, n_dev), 1),
+            "scans_per_gpu": len(scans) if not host_multi else 1,
             "map_points": m_map,
             "parallelism": par,
             "cell_size_m": info["cell"],
@@ -378,24 +522,26 @@ def main():
         },
         "eskf_iters_per_sec": iters_all / dt,
         "scans_per_sec": scans_all / dt,
-        "iters_per_step": iters / a.steps / max(len(scans), 1),
-        "rematch_passes_per_step": rematch / a.steps / max(len(scans), 1),
+        "iters_per_step": iters / a.steps / max(n_indep, 1),
+        "rematch_passes_per_step": rematch / a.steps / max(n_indep, 1),
         "pose_error_vs_truth_m": pose_err,
         "final_pos": [float(v) for v in res["x"][9:12]],
         "map_build_s": t_build,
+        "timed_loop": timed_loop,
         "host_inverse_per_step": "included (P perturbed in its last bit every step: the (P/R)^-1 cache misses once per scan)",
     }
-    # ---- rooflines (engine 0's scan; HIP events on the engine's stream, sampled passes) -----------
+    # ---- rooflines (handle 0's scan; HIP events on the engine's stream, the separate sampling loop) ----------
     n0 = len(scans[0][0]) if a.config != "R1" else eng.n
+    single = world == 1 and not host_multi and len(scans) == 1
     if tstats["match_launches"] > 0 and tstats["fit_launches"] > 0:
         ms_match = tstats["match_ms"] / tstats["match_launches"]
         ms_fit = tstats["fit_ms"] / tstats["fit_launches"]
         ms = ms_match + ms_fit
         achieved = n0 * BYTES_REMATCH / (ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic() if (a.config == "C3" and world == 1) else (None, None)
+        traffic, traffic_src = pmc_traffic() if (a.config == "C3" and single) else (None, None)
         copy_peak = measured_copy_peak(torch) if (rank == 0 and not a.no_cpu) else None  # --no-cpu: no side legs
         out["roofline"] = {
-            "kernel": "rematch pass = match_easy + match_hard (exact 5-NN on the brick grid) + reduce_kernel<FIT> "
+            "kernel": "rematch pass = match_rows + match_hard (exact 5-NN on the brick grid) + reduce_kernel<FIT> "
                       "(neighbour gate, plane fit, residual, Jacobian row, normal block)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
@@ -413,8 +559,13 @@ def main():
             "peak_measured_copy": copy_peak,
             "frac_of_measured_peak": (achieved / copy_peak) if copy_peak else None,
             "note": "one launch = the three kernels of one rematch pass (HIP events on the engine's stream around "
-                    "the search kernels and around reduce<FIT>; every %dth pass of the timed region sampled)" % stride,
+                    "the search kernels and around reduce<FIT>), sampled in a separate untimed loop of %d steps "
+                    "after the timed region" % SAMPLE_STEPS,
         }
+        if a.config == "C3" and single:
+            issue = pmc_issue(ms)
+            if issue:
+                out["roofline"]["issue"] = issue
     if tstats["reduce_launches"] > 0:
         ms_r = tstats["reduce_ms"] / tstats["reduce_launches"]
         ach_r = n0 * BYTES_REUSE / (ms_r * 1e-3) / 1e9
@@ -425,31 +576,87 @@ def main():
             "avg_launch_ms": ms_r, "launches": tstats["reduce_launches"],
             "note": "latency-bound at this size: 1.8 MB per launch is 0.23 us at 8 TB/s",
         }
-    if rank == 0 and world == 1 and not a.no_cpu and a.cpu_steps > 0:
+    side = not a.no_cpu and not a.no_side
+    if sharded and scaling == "strong" and world > 1 and not a.no_side and a.config != "R1":
+        # side number: the weak form of the same job (the scan grows to N x beams, one config-sized shard per
+        # rank); every rank takes part (the collective is inside the update)
+        sc, n_weak = sharded_scan("weak", rank)
+        d_scan = torch.from_numpy(np.ascontiguousarray(sc)).cuda()
+        d_keep.append(d_scan)
+        eng.scan_set_device(d_scan.data_ptr(), 3, len(sc))
+        run_steps(max(a.warmup // 2, 2))
+        wsteps = max(a.steps // 4, 5)
+        wdt, wit, _ = timed(wsteps)
+        wtot = torch.tensor([float(len(sc)) * wit], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(wtot, op=dist.ReduceOp.SUM)
+        out["weak_scaling"] = {"value": float(wtot.item()) / wdt, "unit": "evals/s", "ms_per_step": 1e3 * wdt / wsteps,
+                               "steps": wsteps, "scan_points_total": int(n_weak), "scan_points_per_gpu": int(len(sc)),
+                               "note": "side leg after the timed region: the same job with the scan grown to N x beams"}
+    if rank == 0 and single and not a.no_cpu and a.cpu_steps > 0:
         cpu_map = eng.map_points() if a.config == "R1" else map_xyz
         cpu_scan = eng.scan_get() if a.config == "R1" else scans[0][0]
         out["cpu_baseline"] = cpu_baseline(a, cpu_map, cpu_scan, x_prop0, P0, res)
         out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
-    if rank == 0 and world == 1 and not a.no_cpu and a.config in ("C1", "C2", "C3", "C4") and not a.sequential:
+    if rank == 0 and single and side and a.config == "C3" and not a.extrinsic:
+        # BASELINE configs[4] on this one device, against the map that is already resident
+        out["c5_batch"] = c5_batch(torch, Engine, synth, eng, a)
+    if rank == 0 and single and side and a.config in ("C1", "C2", "C3", "C4") and not a.sequential:
         # side leg, after everything that is timed or compared: what one LiDAR frame costs on the device when the
         # stages either side of the hot path run too.  It changes the engine's map (the scan is merged
         # in), which is why it comes last.
-        out["frame_pipeline"] = frame_pipeline(torch, eng, scans[0][0], x_prop0, P0)
+        out["frame_pipeline"] = frame_pipeline(torch, eng, scans[0][0], x_prop0, P0, frames=a.frames)
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
         sys.stderr.write("[bench] gen %.1fs, map build %.3fs, cell %.3f m (%.2f pts/cell), %d bricks\n" % (
             t_gen, t_build, info["cell"], info["mean_per_cell"], info["bricks"]))
         # RCCL prints a version banner through C stdio; flush it first so the JSON is the last line
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
+        C.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
 
 
-def frame_pipeline(torch, eng, scan, x_prop, P0, frames=8, leaf=0.5):
+def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5):
+    """BASELINE configs[4] on ONE GPU: k independent 65,536-point scans (seeds 2.., sensor offsets (i - 3.5) * 2 m)
+    in flight through s2m_iterated_update_batch from one host thread, searching the map `owner` already holds."""
+    engs, keep, filt = [], [], []
+    for i in range(k):
+        sc, pos = synth.replica_scan("C5", i)
+        e = Engine(max_iter=a.max_iter, cell_size=a.cell, device=owner.cfg.device, feat_threshold=100)
+        e.map_share(owner)
+        d = torch.from_numpy(np.ascontiguousarray(sc)).cuda()
+        keep.append(d)
+        e.scan_set_device(d.data_ptr(), 3, len(sc))
+        engs.append(e)
+        filt.append(synth.filter_inputs(pos))
+    cl = CLoop(engs, [f[1] for f in filt], [f[2] for f in filt], 1)
+    cl.run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    it, rm = cl.run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = 65536
+    reuse = it - rm
+    algo_bytes = float(n) * (rm * BYTES_REMATCH + reuse * BYTES_REUSE)
+    errs = [float(np.abs(cl.x[i][9:12] - filt[i][0][9:12]).max()) for i in range(k)]
+    for e in engs:
+        e.close()
+    return {"scans_in_flight": k, "steps": steps, "scans_per_sec": k * steps / dt, "value": n * it / dt, "unit": "evals/s",
+            "ms_per_batch": 1e3 * dt / steps, "eskf_iters_per_sec": it / dt,
+            "algorithmic_GBps": algo_bytes / dt / 1e9, "frac": algo_bytes / dt / 1e9 / HBM_PEAK_GBS,
+            "pose_error_vs_truth_m_max": max(errs),
+            "note": "BASELINE configs[4] on one device: %d scans (seeds 2..%d) vs the resident 5M-pt map, one host "
+                    "thread, s2m_iterated_update_batch driven by tools/bench_loop.cpp; algorithmic bytes = 88 B per "
+                    "eval of a rematch pass + 28 B per eval of a reuse pass" % (k, 1 + k)}
+
+
+def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
     """Raw sweep (48-byte PointXYZINormal records on the host) -> undistort + voxel grid -> iterated update ->
-    map_incremental -> field-of-view trim, each stage ended by a device sync; mean over the warm frames."""
+    map_incremental -> field-of-view trim.  First `frames` frames one by one with a device sync after every stage
+    (stage times), then `frames` frames back to back, each frame timed on its own (median / p99 / max: a
+    real-time consumer cares about the worst frame, the reference hides its rebuilds behind a thread,
+    ikd_Tree.cpp:192-203)."""
     n = len(scan)
     rec = np.zeros((n, 12), np.float32)
     rec[:, :3] = scan
@@ -459,39 +666,49 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=8, leaf=0.5):
     poses = np.zeros((K, 22)); poses[:, 0] = np.linspace(0.0, 0.102, K)
     poses[:, 13:22] = np.eye(3).ravel()                       # sensor at rest: undistortion is the identity up to rounding
     end = np.zeros(36); end[0:9] = np.eye(3).ravel(); end[12:21] = np.eye(3).ravel()
-    rows, merged = [], []
-    for _ in range(frames):
+    rows = []
+    staged = min(frames, 8)
+    for _ in range(staged):
         t = [time.perf_counter()]
         nd = eng.scan_set_from_raw(rec, 4, 6, poses, end, leaf); torch.cuda.synchronize(); t.append(time.perf_counter())
         r = eng.iterated_update(x_prop, x_prop, P0); torch.cuda.synchronize(); t.append(time.perf_counter())
         eng.map_incremental(r["x"], 0.5); torch.cuda.synchronize(); t.append(time.perf_counter())
         eng.fov_segment(r["x"][9:12], 1000.0); torch.cuda.synchronize(); t.append(time.perf_counter())
         rows.append(np.diff(t) * 1e3)
-        merged.append(eng.map_last_update_merged())
     w = np.array(rows[2:]).mean(0)
-    # the same frames back to back, synchronised only at the end: a stage's asynchronous tail (the table build of a
-    # merged update) overlaps the host side of the next stage
-    batches = []
-    for _ in range(3):  # three batches of eight frames, the median batch is reported (one slow allocation does not count)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(8):
-            eng.scan_set_from_raw(rec, 4, 6, poses, end, leaf)
-            r = eng.iterated_update(x_prop, x_prop, P0)
-            eng.map_incremental(r["x"], 0.5)
-            eng.fov_segment(r["x"][9:12], 1000.0)
-        torch.cuda.synchronize()
-        batches.append((time.perf_counter() - t0) / 8 * 1e3)
-    b2b = float(np.median(batches))
-    sys.stderr.write("[bench] frame leg: back-to-back batches %s ms per frame\n" % ", ".join("%.3f" % b for b in batches))
+    # the same frames back to back (no device sync between the stages: a stage's asynchronous tail -- the table
+    # build of a merged update -- overlaps the host side of the next stage), every frame timed on its own
+    st0 = eng.map_update_stats()
+    per, how = [], []
+    torch.cuda.synchronize()
+    for _ in range(frames):
+        t0 = time.perf_counter()
+        eng.scan_set_from_raw(rec, 4, 6, poses, end, leaf)
+        r = eng.iterated_update(x_prop, x_prop, P0)
+        eng.map_incremental(r["x"], 0.5)
+        eng.fov_segment(r["x"][9:12], 1000.0)
+        per.append((time.perf_counter() - t0) * 1e3)
+        how.append(eng.map_last_update_merged())
+    torch.cuda.synchronize()
+    st1 = eng.map_update_stats()
+    per = np.array(per)
+    med = float(np.median(per))
+    worst = int(np.argmax(per))
+    sys.stderr.write("[bench] frame leg: %d frames back to back, median %.3f p99 %.3f max %.3f ms (frame %d, %s)\n" % (
+        frames, med, float(np.percentile(per, 99)), float(per.max()), worst, "merged" if how[worst] else "rebuilt"))
     return {"ms_per_frame": float(w.sum()), "frames_per_s": float(1e3 / w.sum()),
-            "ms_per_frame_back_to_back": float(b2b), "frames_per_s_back_to_back": float(1e3 / b2b),
-            "back_to_back_batches_ms": [float(b) for b in batches],
+            "ms_per_frame_back_to_back": med, "frames_per_s_back_to_back": float(1e3 / med),
+            "median_ms": med, "p99_ms": float(np.percentile(per, 99)), "max_ms": float(per.max()),
+            "max_over_median": float(per.max() / med), "worst_frame": worst,
+            "frames_back_to_back": int(frames),
+            "updates": {k: int(st1[k] - st0[k]) for k in st1},
+            "rebuilt_frames": [i for i, m in enumerate(how) if not m],
             "stages_ms": {"raw_to_scan": float(w[0]), "iterated_update": float(w[1]), "map_incremental": float(w[2]),
                           "fov_segment": float(w[3])},
             "scan_points_raw": int(n), "scan_points_after_voxel_grid": int(nd), "map_points": int(eng.map_size()),
-            "updates_merged": int(sum(merged[2:])), "frames": int(frames - 2),
             "note": "host-timed, one frame in flight, host input (3 MB of records cross PCIe in raw_to_scan); "
-                    "not part of `value`"}
+                    "not part of `value`; `updates` counts how the map updates of the back-to-back frames were "
+                    "produced (merged into the grid / rebuilt / re-gridded) and how often a device buffer grew"}
 
 
 def measured_copy_peak(torch, nbytes=1 << 30, reps=10):
@@ -512,27 +729,70 @@ def measured_copy_peak(torch, nbytes=1 << 30, reps=10):
         return None
 
 
-def pmc_traffic():
-    """Fabric traffic of one rematch pass (search kernels + reduce<FIT>) from the newest COMMITTED counter
-    summary that holds FETCH_SIZE / WRITE_SIZE for those kernels (profiles/*_pmc.json, made by
-    scripts/profile_round.sh + summarize_profile.py: separate rocprofv3 --pmc passes of this same command).
-    This is a STATIC figure of the profiled build, not something measured in this run -- the label says so.
-    Read side doubled as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE tallies 128-B requests at
-    64 B), so it is an upper bound; at C3 every structure sits in the Infinity Cache, so this is fabric
-    (L2 <-> Infinity Cache) traffic rather than HBM traffic."""
+REMATCH_KERNELS = ("match_rows", "match_hard", "reduce_kernel<false, true>")
+
+
+def newest_pmc():
+    """The newest COMMITTED counter summary (profiles/*_pmc.json, made by scripts/profile_round.sh +
+    summarize_profile.py from separate rocprofv3 --pmc passes of this same command) that holds the rematch
+    pass's kernels."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
             doc = json.load(open(path))
-            k = doc["kernels"]
-            tot = 0.0
-            for name in ("match_rows", "match_hard", "reduce_kernel<false, true>"):
-                tot += (2.0 * k[name]["FETCH_SIZE_avg"] + k[name]["WRITE_SIZE_avg"]) * 1024.0
-            return tot, "%s (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the profiled build '%s', " \
-                        "read side x2; not measured in this run)" % (os.path.relpath(path, ROOT), doc.get("tag", "?"))
+            if all(name in doc["kernels"] for name in REMATCH_KERNELS):
+                return path, doc
         except (KeyError, ValueError, OSError):
             continue
     return None, None
+
+
+def pmc_traffic():
+    """Fabric traffic of one rematch pass (search kernels + reduce<FIT>) from FETCH_SIZE / WRITE_SIZE.
+    This is a STATIC figure of the profiled build, not something measured in this run -- the label says so.
+    Read side doubled as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE tallies 128-B requests at
+    64 B), so it is an upper bound; at C3 every structure sits in the Infinity Cache, so this is fabric
+    (L2 <-> Infinity Cache) traffic rather than HBM traffic."""
+    path, doc = newest_pmc()
+    if not doc:
+        return None, None
+    try:
+        k = doc["kernels"]
+        tot = sum((2.0 * k[name]["FETCH_SIZE_avg"] + k[name]["WRITE_SIZE_avg"]) * 1024.0 for name in REMATCH_KERNELS)
+    except KeyError:
+        return None, None
+    return tot, "%s (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the profiled build '%s', " \
+                "read side x2; not measured in this run)" % (os.path.relpath(path, ROOT), doc.get("tag", "?"))
+
+
+def pmc_issue(pass_ms):
+    """Issue-side reading of the rematch pass from the committed SQ counters (static, like `traffic`):
+    VALU wave-instructions x 2 cycles / (1,024 SIMD-32s x 2.4 GHz) = the time the pass would take if VALU issue
+    were the only limit, as a fraction of the measured pass; and the share of wave-cycles parked in s_waitcnt
+    (SQ_WAIT_ANY / SQ_WAVE_CYCLES).  Low issue fraction + high wait share = latency-bound, not issue- or
+    bandwidth-bound."""
+    path, doc = newest_pmc()
+    if not doc:
+        return None
+    try:
+        k = doc["kernels"]
+        valu = sum(k[name]["SQ_INSTS_VALU_avg"] for name in REMATCH_KERNELS)
+        wait = sum(k[name]["SQ_WAIT_ANY_avg"] for name in REMATCH_KERNELS)
+        cyc = sum(k[name]["SQ_WAVE_CYCLES_avg"] for name in REMATCH_KERNELS)
+        act = sum(k[name]["SQ_ACTIVE_INST_ANY_avg"] for name in REMATCH_KERNELS)
+    except KeyError:
+        return None
+    floor_ms = valu * VALU_CYCLES / (SIMDS * CLOCK_HZ) * 1e3
+    o = {"valu_wave_instructions": valu, "valu_issue_floor_ms": floor_ms, "frac_of_pass": floor_ms / pass_ms,
+         "wait_share_of_wave_cycles": wait / cyc, "active_share_of_wave_cycles": act / cyc,
+         "source": "%s (static: SQ counters of the profiled build '%s')" % (os.path.relpath(path, ROOT), doc.get("tag", "?")),
+         "note": "VALU wave-instructions x %d cycles / (%d SIMDs x %.1f GHz) / measured pass; fp64 min/max and the "
+                 "fp64 Jacobian row issue at half rate, so the true issue floor is up to 2x this figure" % (
+                     VALU_CYCLES, SIMDS, CLOCK_HZ / 1e9)}
+    b = doc.get("batched")
+    if b:   # the same reading for the batched launch (K scans per grid), when the profile holds it
+        o["batched"] = b
+    return o
 
 
 def cpu_baseline(a, map_xyz, scan, x_prop, P0, gpu_res):

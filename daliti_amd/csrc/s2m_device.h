@@ -1,12 +1,17 @@
 // s2m_device.h -- data layout shared by the HIP kernels of the scan-to-map engine (gfx950).
 //
 // Map layout in HBM ("brick grid", replaces the ikd-Tree of eskf_lio/include/ikd-Tree/):
-//   pts   : M x float4 {x, y, bitcast(original index), z} (make_map_point), sorted by (brick, cell-in-brick),
-//           followed by 8 sentinel points (padding targets of the search kernels' batches);
+//   pts   : M x float4 {x, y, bitcast(sorted position), z} (make_map_point), sorted by (brick, cell-in-brick,
+//           caller index), followed by 8 sentinel points (padding targets of the search kernels' batches);
 //           one 16-byte load per candidate, a cell's points are contiguous, the cells of one
-//           x-row of a brick are contiguous.
-//   porig : M x float4 {x, y, z, 0} in the caller's original order; neighbour indices returned by
-//           the search refer to it (plane fit gathers 5 points from it).
+//           x-row of a brick are contiguous.  A neighbour is identified by its SORTED POSITION on the whole
+//           per-iteration path: the plane fit gathers its five points from this array (the five neighbours of a
+//           query sit in the same or adjacent cells, i.e. in a few cache lines), so nothing in caller order is
+//           touched between two map updates.
+//   pidx  : M x uint32, the caller's index of every sorted position (the index into the array handed to
+//           s2m_map_build, renumbered by updates: survivors in index order, then the added points).  Read only
+//           when somebody asks for caller indices or caller order (s2m_get_neighbors, s2m_map_get_points) and by
+//           the map update; 4 B/point instead of the 16 B/point copy in caller order that round 2 kept.
 //   top   : dense nbx*nby*nbz array of 16-byte entries over the map bounding box:
 //           {brick id + 1 (0 = empty), position of the brick's first point + 1, 64-bit mask of the (y,z)
 //           rows of the brick that hold points}.  A brick is 8x8x8 cells; at c = 0.5 m this array is 7 K entries (0.1 MB) for
@@ -37,28 +42,30 @@ struct Grid {
     const uint4 *top;      // {id + 1, first point + 1 (used by the table builder only), rowmask lo, rowmask hi}
     const uint32_t *tab;
     const float4 *pts;
-    const float4 *porig;
+    const uint32_t *pidx;
     int64_t m;
     uint32_t sent_off;  // byte offset of the sentinel block pts[m..m+8) (valid while it fits 32 bits), else 0
 };
 
-// Element of the sorted point array Grid::pts: {x, y, bitcast(original index), z}.  The index sits in the
-// third word so that a search key (index, d2) is formed in place: the 64-bit key needs an even-aligned
-// register pair, the index already is in one, and d2 is written over z once dz has been taken -- no
-// register moves per candidate (three with the natural {x, y, z, index} order).
-__host__ __device__ inline float4 make_map_point(float x, float y, float z, uint32_t idx)
+// Element of the sorted point array Grid::pts: {x, y, bitcast(sorted position), z}.  The position sits in the
+// third word so that a search key (position, d2) is formed in place: the 64-bit key needs an even-aligned
+// register pair, the position already is in one, and d2 is written over z once dz has been taken -- no
+// register moves per candidate (three with the natural {x, y, z, w} order, one more if the position had to be
+// derived from the load address).  Candidates tied at exactly the same float d2 are therefore ranked by sorted
+// position = (brick, cell, caller index): a total order both this engine and the oracle can compute.
+__host__ __device__ inline float4 make_map_point(float x, float y, float z, uint32_t pos)
 {
     float4 p;
     p.x = x; p.y = y; p.w = z;
 #if defined(__HIP_DEVICE_COMPILE__)
-    p.z = __uint_as_float(idx);
+    p.z = __uint_as_float(pos);
 #else
-    __builtin_memcpy(&p.z, &idx, 4);
+    __builtin_memcpy(&p.z, &pos, 4);
 #endif
     return p;
 }
 __device__ __forceinline__ float map_point_z(const float4 &p) { return p.w; }
-__device__ __forceinline__ uint32_t map_point_index(const float4 &p) { return __float_as_uint(p.z); }
+__device__ __forceinline__ uint32_t map_point_pos(const float4 &p) { return __float_as_uint(p.z); }
 
 // rot_end, pos_end, R_L_I, T_L_I of StatesGroup (eskf_lio/include/common_lib.h:219-222)
 struct Pose {

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -55,6 +56,8 @@ struct s2m_engine {
     bool in_batch = false;          // set while the handle is served by s2m_iterated_update_batch with several scans
     bool no_merge = false;          // S2M_NO_MERGE=1: every update rebuilds the grid from scratch (A/B and tests)
     bool last_update_merged = false;
+    int64_t n_merged = 0, n_rebuilt = 0, n_regrid = 0;  // how this handle's map updates were produced (s2m_map_update_stats)
+    std::mutex stats_mu;            // the lazily fetched counts of a merged update may be asked for by borrowers' threads
     Grid grid{};
     MapStats stats;
     bool map_ready = false;
@@ -87,6 +90,7 @@ struct s2m_engine {
     int64_t rows_cap = 0;
 
     Pose last_pose{};
+    Pose rematch_pose{};          // pose of the last rematch pass: the world-frame queries Nearest_Points belong to
     uint32_t *d_hard = nullptr;   // the far-point lists' counters sit behind 3 x n_cap words (the words themselves are free)
     uint32_t *d_qheads = nullptr; // match_hard's dequeue heads (kQueueWords)
     HardRec *d_hrec = nullptr;    // the far points' records: 2 x n_cap (without / with a radius)
@@ -213,13 +217,14 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         if (((group >> 8) & 0xf) == 0 && ((int64_t)n * 2 > 3072 * 64 || e->in_batch)) group |= 2 << 8;
         launch_match(m, group, e->stream);  // hard_count is zero: reset by every reduce launch
         e->nn_valid = true;
+        e->rematch_pose = pose;
     }
     if (timed) S2M_HIP(e, hipEventRecord(e->ev[1], e->stream));
     ReduceArgs r;
     r.pose = pose; r.gates = gates;
     r.sx = sx; r.sy = sy; r.sz = sz; r.n = n;
     r.fit = rematch ? 1 : 0;
-    r.nn_idx = e->d_nn_idx; r.nn_d2 = e->d_nn_d2; r.porig = e->grid.porig;
+    r.nn_idx = e->d_nn_idx; r.nn_d2 = e->d_nn_d2; r.pts = e->grid.pts;
     r.plane = e->d_plane; r.flags = e->d_flags; r.sel = e->d_sel; r.eff = e->d_eff; r.pd2 = e->d_pd2;
     r.partials = e->d_partials; r.block = d_out;
     r.ticket = e->d_ticket; r.hard_count = e->d_hard + 3 * e->n_cap;
@@ -423,9 +428,13 @@ int s2m_map_share(s2m_engine *e, const s2m_engine *owner)
     S2M_HIP(e, hipSetDevice(e->device));
     S2M_HIP(e, hipStreamSynchronize(e->stream));
     S2M_HIP(e, hipStreamSynchronize(owner->stream));  // the owner's build has finished
-    (void)resolve_stats(const_cast<s2m_engine *>(owner)->map, const_cast<s2m_engine *>(owner)->stats);
+    {   // the counts of the owner's last merged update arrive lazily; several borrowers may ask at once
+        s2m_engine *o = const_cast<s2m_engine *>(owner);
+        std::lock_guard<std::mutex> lk(o->stats_mu);
+        (void)resolve_stats(o->map, o->stats);
+        e->stats = o->stats;
+    }
     e->grid = owner->grid;
-    e->stats = owner->stats;
     e->built_cell = owner->built_cell;
     e->map_ready = true;
     e->map_borrowed = true;
@@ -440,7 +449,11 @@ int commit_update(s2m_engine *e)
 {
     bool merged = false;
     e->map_ready = false;
-    hipError_t he = resolve_stats(e->map, e->stats);  // counts of the previous build / merge
+    hipError_t he;
+    {
+        std::lock_guard<std::mutex> lk(e->stats_mu);
+        he = resolve_stats(e->map, e->stats);  // counts of the previous build / merge
+    }
     if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "resolve_stats", he);
     // The cell size is kept across updates (a stable grid) unless the density has drifted by more than 2x from
     // the ~11 points per occupied cell it was chosen for -- e.g. a map seeded from a handful of points and then
@@ -457,6 +470,7 @@ int commit_update(s2m_engine *e)
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "merge_update", he);
     }
     e->last_update_merged = merged;
+    if (merged) ++e->n_merged; else ++e->n_rebuilt;
     if (!merged) {
         int64_t m_new = 0;
         bool too_large = false;
@@ -475,6 +489,7 @@ int commit_update(s2m_engine *e)
             if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
             if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
             e->built_cell = e->grid.c;
+            ++e->n_regrid;
         }
     }
     e->map_ready = true;
@@ -550,6 +565,10 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     const Pose pose = pose_of(state);
     float4 *la = nullptr, *lb = nullptr;
     int64_t na = 0, nb = 0;
+    if (e->nn_valid && ekf_inited != 0) {  // Nearest_Points[i] of the reference is never short (unbounded search)
+        int rc = s2m_complete_neighbors(e, nullptr);
+        if (rc) return rc;
+    }
     S2M_HIP(e, incr_classify(e->upd, pose, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, (int)e->n,
                              e->d_nn_idx, e->grid, e->nn_valid && ekf_inited != 0, filter_size_map, &la, &na, &lb, &nb, e->stream));
     if (n_to_add) *n_to_add = na;
@@ -575,7 +594,7 @@ int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity, int64_t *m)
         if (rc) return rc;
         e->stage_cap = floats;
     }
-    launch_float4_to_xyz(e->grid.porig, e->grid.m, e->d_stage, e->stream);
+    launch_map_to_xyz(e->grid.pts, e->grid.pidx, e->grid.m, e->d_stage, e->stream);  // caller order
     S2M_HIP(e, hipMemcpyAsync(xyz, e->d_stage, (size_t)floats * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     S2M_HIP(e, hipStreamSynchronize(e->stream));
     return S2M_OK;
@@ -600,7 +619,10 @@ int s2m_map_info(const s2m_engine *ce, double info[8])
     if (!ce || !info) return S2M_ERR_ARG;
     if (!ce->map_ready) return S2M_ERR_STATE;
     s2m_engine *e = const_cast<s2m_engine *>(ce);  // the counts of a merged update are fetched on demand
-    if (!e->map_borrowed && resolve_stats(e->map, e->stats) != hipSuccess) return S2M_ERR_HIP;
+    if (!e->map_borrowed) {
+        std::lock_guard<std::mutex> lk(e->stats_mu);
+        if (resolve_stats(e->map, e->stats) != hipSuccess) return S2M_ERR_HIP;
+    }
     info[0] = e->grid.c;
     info[1] = e->grid.ox; info[2] = e->grid.oy; info[3] = e->grid.oz;
     info[4] = (double)e->stats.bricks;
@@ -897,8 +919,98 @@ int s2m_get_neighbors(s2m_engine *e, int32_t *idx, float *d2)
     S2M_HIP(e, hipStreamSynchronize(e->stream));
     const size_t n = (size_t)e->n;
     if (n == 0) return S2M_OK;
-    if (idx) S2M_HIP(e, hipMemcpy(idx, e->d_nn_idx, n * S2M_K * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (idx) {  // the engine identifies a neighbour by its sorted position; the caller's indices are looked up on request
+        const int64_t words = (int64_t)n * S2M_K;
+        if (words > e->stage_cap) {
+            int rc = grow(e, &e->d_stage, words);
+            if (rc) return rc;
+            e->stage_cap = words;
+        }
+        int32_t *tmp = reinterpret_cast<int32_t *>(e->d_stage);
+        launch_positions_to_indices(e->d_nn_idx, e->grid.pidx, words, tmp, e->stream);
+        S2M_HIP(e, hipMemcpyAsync(idx, tmp, (size_t)words * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        S2M_HIP(e, hipStreamSynchronize(e->stream));
+    }
     if (d2) S2M_HIP(e, hipMemcpy(d2, e->d_nn_d2, n * S2M_K * sizeof(float), hipMemcpyDeviceToHost));
+    return S2M_OK;
+}
+
+int s2m_map_get_order(s2m_engine *e, uint32_t *order, int64_t capacity, int64_t *m)
+{
+    if (!e || !m) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map");
+    *m = e->grid.m;
+    if (!order || e->grid.m == 0) return S2M_OK;
+    if (capacity < e->grid.m) return fail(e, S2M_ERR_CAPACITY, "order buffer too small");
+    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    S2M_HIP(e, hipMemcpy(order, e->grid.pidx, (size_t)e->grid.m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return S2M_OK;
+}
+
+int s2m_map_grid(const s2m_engine *e, int32_t cells[3])
+{
+    if (!e || !cells) return S2M_ERR_ARG;
+    if (!e->map_ready) return S2M_ERR_STATE;
+    cells[0] = e->grid.ncx; cells[1] = e->grid.ncy; cells[2] = e->grid.ncz;
+    return S2M_OK;
+}
+
+int s2m_map_update_stats(const s2m_engine *e, int64_t stats[4])
+{
+    if (!e || !stats) return S2M_ERR_ARG;
+    stats[0] = e->n_merged;
+    stats[1] = e->n_rebuilt;
+    stats[2] = e->n_regrid;
+    stats[3] = map_allocations();
+    return S2M_OK;
+}
+
+// Nearest_Points beyond the gate.  ikdtree.Nearest_Search is unbounded (max_dist = INFINITY, ikd_Tree.cpp:425): every
+// scan point gets its five nearest map points however far they are, and map_incremental reads points_near[0] of
+// exactly those far points when the sensor enters new territory (laserMapping.cpp:593-607).  The per-iteration search
+// stops at the d2 <= 5 gate (:853) -- nothing beyond it can enter the update -- so a point whose neighbourhood is
+// emptier than that ends the pass with a list that is short, or not proven beyond the gate.  This call completes those
+// lists: the points whose 5th distance is not inside the radius searched so far are collected and handed to the
+// far-point kernel again with the radius doubled per round, until every one has its exact five (or the radius exceeds
+// the grid).  Cold path: nothing to do for a scan inside the mapped area.
+int s2m_complete_neighbors(s2m_engine *e, int64_t *n_completed)
+{
+    if (n_completed) *n_completed = 0;
+    if (!e) return S2M_ERR_ARG;
+    if (!e->map_ready || !e->nn_valid) return fail(e, S2M_ERR_STATE, "no rematch pass yet");
+    S2M_HIP(e, hipSetDevice(e->device));
+    const int n = (int)e->n;
+    if (n == 0 || e->grid.m == 0) return S2M_OK;
+    MatchArgs m;
+    m.grid = e->grid; m.pose = e->rematch_pose; m.gates = gates_of(e->cfg);
+    m.sx = e->d_scan; m.sy = e->d_scan + e->n_cap; m.sz = e->d_scan + 2 * e->n_cap; m.n = n;
+    m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
+    m.hard_rec = e->d_hrec; m.hard_count = e->d_hard + 3 * e->n_cap;
+    m.qheads = e->d_qheads;
+    m.dbg = nullptr;
+    const double ext = (double)std::max(std::max(e->grid.ncx, e->grid.ncy), e->grid.ncz) * e->grid.c;
+    const double reach2 = 3.0 * ext * ext;  // squared diagonal of the grid: nothing lies farther from a point inside it
+    int64_t first = -1;
+    for (int round = 0; round < 24; ++round) {
+        // hard_count / qheads are zero here: every reduce launch and every round below leaves them so
+        launch_collect_short(m, e->stream);
+        const uint32_t *src[1] = {m.hard_count};
+        uint32_t cnt = 0;
+        S2M_HIP(e, mail_fetch(e->mail, src, 1, &cnt, e->stream));
+        if (first < 0) first = cnt;
+        bool last = cnt == 0;
+        if (!last) {
+            m.gates.knn_d2_gate *= 4.0f;  // radius x 2
+            launch_match_hard_only(m, e->stream);
+            last = (double)m.gates.knn_d2_gate > reach2;  // the whole grid has been inside the radius
+        }
+        S2M_HIP(e, hipMemsetAsync(m.hard_count, 0, 4 * sizeof(uint32_t), e->stream));
+        S2M_HIP(e, hipMemsetAsync(e->d_qheads, 0, kQueueWords * sizeof(uint32_t), e->stream));
+        if (last) break;
+    }
+    S2M_HIP(e, hipGetLastError());
+    if (n_completed) *n_completed = first < 0 ? 0 : first;
     return S2M_OK;
 }
 
@@ -1170,6 +1282,72 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
                 if (slots[i].active) S2M_HIP(handles[i], hipStreamSynchronize(handles[i]->stream));
             return fail(handles[0], S2M_ERR_HIP, "s2m_iterated_update_batch: a pass did not publish its block");
         }
+    }
+    return S2M_OK;
+}
+
+// ONE scan split over n handles, driven by ONE host thread, no collective library ("a single-process
+// peer-copy gather ... whichever measures lower"): handles[i] holds shard i (contiguous ranges in handle order) and
+// the map, on any mix of devices -- n GPUs of a node, or n shards on one GPU.  Every pass is launched on all handles;
+// each reduce kernel publishes its 160-double block straight into that handle's pinned host page (as in the
+// single-handle loop: no D2H copy, no driver sync, no publish kernel); the host picks the n blocks up as they land,
+// sums them in handle order (fixed order: the result is deterministic for a given n) and runs ONE fp64 update.
+// The degeneracy queue and the Kalman work area are those of handles[0].
+int s2m_iterated_update_multi(s2m_engine *const *handles, int32_t n, double x[S2M_STATE_DOUBLES],
+                              const double x_prop[S2M_STATE_DOUBLES], double P[S2M_DIM * S2M_DIM], s2m_iter_log *log)
+{
+    if (!handles || n < 1 || n > 256 || !x || !x_prop || !P) return S2M_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        s2m_engine *e = handles[i];
+        if (!e) return S2M_ERR_ARG;
+        for (int j = 0; j < i; ++j)
+            if (handles[j] == e) return fail(e, S2M_ERR_ARG, "s2m_iterated_update_multi: a handle appears twice");
+        if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
+        if (e->comm.handle || !e->host_poll)
+            return fail(e, S2M_ERR_STATE, "s2m_iterated_update_multi: handles without a communicator, host-polled block only");
+        e->nn_valid = false;
+    }
+    s2m_engine *e0 = handles[0];
+    const int max_iter = e0->cfg.max_iter;
+    reset_log(log, max_iter);
+    IterCtl c{0, 1, 0, 0, 0, 0};
+    int passes = 0, it = 0;
+    double sum[S2M_BLOCK_DOUBLES];
+    for (it = 0; it < max_iter; ++it) {
+        c.it = it;
+        c.rematch = (it == 0) || c.rematch_en;  // :847
+        passes += c.rematch;
+        for (int i = 0; i < n; ++i) {
+            int rc = run_pass(handles[i], x, c.rematch, handles[i]->d_block);
+            if (rc) return rc;
+        }
+        if (it == 0) {  // (P/R)^-1 behind the launches of the first pass, see s2m_iterated_update_sharded
+            Mat24 Pm;
+            std::memcpy(Pm.data(), P, sizeof(double) * S2M_DIM * S2M_DIM);
+            EskfParams prm;
+            prm.laser_point_cov = e0->cfg.laser_point_cov;
+            (void)eskf_prepare(prm, Pm, e0->work);
+        }
+        for (int i = 0; i < n; ++i) {  // handle order: the sum below must not depend on the arrival order
+            const double *hb = nullptr;
+            int rc = wait_block(handles[i], handles[i]->d_block, &hb);
+            if (rc) return rc;
+            rc = finish_timing(handles[i]);
+            if (rc) return rc;
+            if (i == 0) std::memcpy(sum, hb, sizeof(sum));
+            else
+                for (int k = 0; k < S2M_BLOCK_DOUBLES; ++k) sum[k] += hb[k];
+        }
+        bool finished = false;
+        int rc = consume_block(e0, sum, c, x, x_prop, P, log, finished, nullptr);
+        if (rc) return rc;
+        if (finished) { ++it; break; }
+    }
+    if (log) {
+        log->iters = it;
+        log->rematch_passes = passes;
+        log->converged = c.conv;
+        log->ekf_stop = c.stop;
     }
     return S2M_OK;
 }

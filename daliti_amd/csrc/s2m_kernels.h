@@ -34,11 +34,12 @@ constexpr int kSentinelPoints = 8;  // pts[m .. m+8): padding targets of the sea
 struct MapBuffers {
     // owned by the engine, (re)allocated by build_map
     float4 *pts = nullptr;
-    float4 *porig = nullptr;
-    float4 *pts2 = nullptr, *porig2 = nullptr;  // the other halves of the double buffers a merge update writes into
+    uint32_t *pidx = nullptr;                   // caller index of every sorted position
+    float4 *pts2 = nullptr;
+    uint32_t *pidx2 = nullptr;                  // the other halves of the double buffers a merge update writes into
     uint4 *top = nullptr;
     uint32_t *tab = nullptr;
-    int64_t pts_cap = 0, porig_cap = 0, pts2_cap = 0, porig2_cap = 0, top_cap = 0, tab_cap = 0;
+    int64_t pts_cap = 0, pidx_cap = 0, pts2_cap = 0, pidx2_cap = 0, top_cap = 0, tab_cap = 0;
     // per-point arrays of scratch_cap + 1 elements.  keys_alt holds the SORTED keys of the current map (it stays
     // valid between updates: the merge update reads it); keys is the unsorted input of a build or the output of a
     // merge; vals / vals_alt are the build sort's payload
@@ -75,6 +76,8 @@ struct MapStats {
 hipError_t build_map(const float *xyz_dev, int64_t stride, int64_t m, float cell, MapBuffers &buf, Grid &grid,
                      MapStats &stats, bool &too_large, hipStream_t st, bool with_margin = false);
 void free_map(MapBuffers &buf);
+int64_t map_allocations();  // device (re)allocations by the map build / merge / update code so far (all handles; diagnostic)
+void note_allocation();
 // bricks / occupied_cells of the last build or merge (a merge does not wait for them: they arrive behind it)
 hipError_t resolve_stats(MapBuffers &buf, MapStats &stats);
 // The map after an update without a new sort (s2m_map.hip, "merge update"): alive[caller index] and alive_s[sorted
@@ -95,7 +98,7 @@ struct UpdateBuffers {
     uint32_t deleted_reported = 0;  // box deletes already reported to the caller within this update
     // per-batch scratch
     uint64_t *key = nullptr, *key2 = nullptr;
-    uint32_t *val = nullptr, *val2 = nullptr, *cnt = nullptr, *best_idx = nullptr, *add_flag = nullptr, *pos = nullptr;
+    uint32_t *val = nullptr, *val2 = nullptr, *cnt = nullptr, *best_idx = nullptr, *best_pos = nullptr, *add_flag = nullptr, *pos = nullptr;
     float *dnew = nullptr, *best_d = nullptr;
     int64_t batch_cap = 0;
     // compaction of the old points
@@ -122,7 +125,10 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
                          const int32_t *nn_idx, const Grid &g, bool have_nn, double fs, float4 **to_add, int64_t *n_add,
                          float4 **no_down, int64_t *n_no_down, hipStream_t st);
 hipError_t xyz_to_float4(UpdateBuffers &u, const float *xyz_dev, int64_t stride, int64_t n, float4 **out, hipStream_t st);
-void launch_float4_to_xyz(const float4 *in, int64_t n, float *xyz, hipStream_t st);
+// the map in CALLER order as packed xyz (ikdtree.flatten's counterpart): xyz[3 * pidx[j]] = pts[j]
+void launch_map_to_xyz(const float4 *pts, const uint32_t *pidx, int64_t m, float *xyz, hipStream_t st);
+// caller indices of a neighbour list: out[i] = nn[i] >= 0 ? pidx[nn[i]] : -1
+void launch_positions_to_indices(const int32_t *nn, const uint32_t *pidx, int64_t count, int32_t *out, hipStream_t st);
 
 // ---- s2m_voxel.hip : scan voxel down-sampling (pcl::VoxelGrid, laserMapping.cpp:775-776) ------------
 struct VoxelBuffers {
@@ -178,7 +184,7 @@ struct MatchArgs {
     Gates gates;
     const float *sx, *sy, *sz;
     int n;
-    int32_t *nn_idx;     // n x 5, index into the caller's map array, -1 = missing
+    int32_t *nn_idx;     // n x 5, sorted position of the neighbour in Grid::pts, -1 = missing
     float *nn_d2;        // n x 5 ascending, INFINITY = missing
     HardRec *hard_rec;   // 2 x n records of scratch: the points the first-shell kernel could not resolve, without / with a radius
     uint32_t *hard_count; // the two lengths (device counters, reset by every reduce launch)
@@ -186,6 +192,11 @@ struct MatchArgs {
     uint32_t *dbg = nullptr;  // optional diagnostics, 4 words per scan point
 };
 void launch_match(const MatchArgs &a, int group, hipStream_t st);
+// completion of the lists that ended short at the gate (s2m_complete_neighbors): the scan points with fewer than five
+// neighbours appended to hard list 0 (a.pose = the pose of the rematch pass that produced the lists), and the far-point
+// kernel on its own (a.gates.knn_d2_gate = the radius^2 of this round)
+void launch_collect_short(const MatchArgs &a, hipStream_t st);
+void launch_match_hard_only(const MatchArgs &a, hipStream_t st);
 
 // ---- s2m_reduce.hip : [plane fit +] residual + Jacobian + normal block ----------------------------
 constexpr int kRedBlock = 512;   // 8 waves per workgroup: 128 partial rows at 65k points for the in-kernel final sum
@@ -202,7 +213,7 @@ struct ReduceArgs {
     int fit;             // rematch pass: fit the plane from the fresh neighbours first
     const int32_t *nn_idx;
     const float *nn_d2;
-    const float4 *porig;
+    const float4 *pts;   // the sorted map points {x, y, position, z}: nn_idx holds sorted positions
     float4 *plane;
     uint8_t *flags;
     uint8_t *sel;

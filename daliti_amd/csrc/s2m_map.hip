@@ -3,7 +3,8 @@
 // Replaces the map seed of the reference: ikdtree.Build(feats_down_world->points)
 // (eskf_lio/src/laserMapping.cpp:784-790; KD_TREE::Build / BuildTree,
 // eskf_lio/include/ikd-Tree/ikd_Tree.cpp:408-423, 678-733).  Instead of a pointer tree of 176-byte
-// nodes the points are radix-sorted by (brick, cell-in-brick) into one float4 array; a dense
+// nodes the points are radix-sorted by (brick, cell-in-brick; stable, i.e. then by caller index) into one float4
+// array whose third word is the sorted position itself, with the caller indices beside it (pidx); a dense
 // top-level array over the bounding box and a 513-entry prefix table per occupied brick locate
 // any run of cells along x with two 4-byte loads.
 //
@@ -127,14 +128,14 @@ __global__ __launch_bounds__(256) void key_kernel(const float *__restrict__ xyz,
 
 __global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ xyz, int64_t stride, int64_t m,
                                                      const uint32_t *__restrict__ vals, float4 *__restrict__ pts,
-                                                     float4 *__restrict__ porig)
+                                                     uint32_t *__restrict__ pidx)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const uint32_t src = vals[j];
     pts[j] = make_map_point(xyz[(int64_t)src * stride], xyz[(int64_t)src * stride + 1], xyz[(int64_t)src * stride + 2],
-                            src);
-    porig[j] = make_float4(xyz[j * stride], xyz[j * stride + 1], xyz[j * stride + 2], 0.0f);
+                            (uint32_t)j);
+    pidx[j] = src;
 }
 
 // ---- top entries and per-brick prefix tables from the SORTED keys -------------------------------------------
@@ -241,20 +242,29 @@ __global__ __launch_bounds__(256) void brick_table_kernel(int64_t bricks, const 
     }
 }
 
-static hipError_t ensure(void **p, int64_t *cap, int64_t need, size_t elem)
+// `need` is the bare requirement; a (re)allocation adds `headroom` elements on top, so that a map that grows a
+// little with every scan does not reallocate -- two device-wide syncs and ~100 MB of hipMalloc at 5 M points --
+// on every update (round 2 compared the stored capacity against need + headroom: the headroom was never usable)
+static int64_t g_map_allocations = 0;  // diagnostic only (s2m_map_update_stats); racy increments are harmless
+static hipError_t ensure(void **p, int64_t *cap, int64_t need, size_t elem, int64_t headroom = 0)
 {
     if (*cap >= need && *p) return hipSuccess;
     if (*p) S2M_TRY(hipFree(*p));
     *p = nullptr;
     *cap = 0;
-    S2M_TRY(hipMalloc(p, (size_t)std::max<int64_t>(need, 1) * elem));
-    *cap = need;
+    const int64_t c = std::max<int64_t>(need + headroom, 1);
+    S2M_TRY(hipMalloc(p, (size_t)c * elem));
+    *cap = c;
+    ++g_map_allocations;
     return hipSuccess;
 }
+int64_t map_allocations() { return g_map_allocations; }
+void note_allocation() { ++g_map_allocations; }
+static inline int64_t headroom_for(int64_t m) { return m / 4 + 65536; }
 
 void free_map(MapBuffers &b)
 {
-    void *ptrs[] = {b.pts, b.porig, b.pts2, b.porig2, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.work_a, b.work_b,
+    void *ptrs[] = {b.pts, b.pidx, b.pts2, b.pidx2, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.work_a, b.work_b,
                     b.work_c, b.rank, b.bstart, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -279,7 +289,7 @@ static hipError_t ensure_sort_tmp(MapBuffers &buf, size_t bytes)
 static hipError_t ensure_scratch(MapBuffers &buf, int64_t m)
 {
     if (buf.scratch_cap >= m) return hipSuccess;
-    const int64_t cap = m + m / 4 + 65536;
+    const int64_t cap = m + headroom_for(m);
     void **ps[] = {(void **)&buf.keys, (void **)&buf.keys_alt, (void **)&buf.vals, (void **)&buf.vals_alt,
                    (void **)&buf.work_a, (void **)&buf.work_b, (void **)&buf.work_c};
     const size_t es[] = {8, 8, 4, 4, 4, 4, 4};
@@ -350,10 +360,8 @@ static hipError_t build_tables(MapBuffers &buf, const uint64_t *keys, int64_t m,
         S2M_TRY(mail_fetch(buf.mail, src, 1, &b32, st));
         bricks = b32;
     }
-    if (buf.tab_cap < bricks * kBrickStride || !buf.tab)
-        S2M_TRY(ensure((void **)&buf.tab, &buf.tab_cap, (bricks + bricks / 4 + 64) * kBrickStride, sizeof(uint32_t)));
-    if (buf.bstart_cap < bricks || !buf.bstart)
-        S2M_TRY(ensure((void **)&buf.bstart, &buf.bstart_cap, bricks + bricks / 4 + 64, sizeof(uint32_t)));
+    S2M_TRY(ensure((void **)&buf.tab, &buf.tab_cap, bricks * kBrickStride, sizeof(uint32_t), (bricks / 4 + 64) * kBrickStride));
+    S2M_TRY(ensure((void **)&buf.bstart, &buf.bstart_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
     hipLaunchKernelGGL(brick_assign_kernel, dim3((unsigned)((top_entries + 255) / 256)), dim3(256), 0, st, top_entries,
                        buf.top, buf.rank, buf.bstart, buf.counters + 64);
     if (bricks > 0)
@@ -415,9 +423,9 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     const float max_cells = (float)std::max(std::max(nc[0], nc[1]), nc[2]);
     g.slop = std::max(1.0e-4f, 16.0f * max_cells * 1.1920929e-7f);
 
-    S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m + m / 4 + 65536 + kSentinelPoints, sizeof(float4)));
+    S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m + kSentinelPoints, sizeof(float4), headroom_for(m)));
     S2M_TRY(put_sentinels(buf.pts, m, st));
-    S2M_TRY(ensure((void **)&buf.porig, &buf.porig_cap, m + m / 4 + 65536, sizeof(float4)));
+    S2M_TRY(ensure((void **)&buf.pidx, &buf.pidx_cap, m + 1, sizeof(uint32_t), headroom_for(m)));
     S2M_TRY(ensure((void **)&buf.top, &buf.top_cap, top_entries + 1, sizeof(uint4)));
     S2M_TRY(ensure_scratch(buf, m));
     if (!buf.counters) S2M_TRY(hipMalloc((void **)&buf.counters, (64 + kOccShards * 32) * sizeof(uint32_t)));
@@ -426,7 +434,7 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     stats = MapStats();
     stats.top_entries = top_entries;
     if (m == 0) {
-        g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.porig = buf.porig;
+        g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
         return hipStreamSynchronize(st);
     }
 
@@ -442,10 +450,10 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     size_t t1 = buf.sort_tmp_bytes;
     S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t1, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m,
                                       0, (unsigned)bits, st));
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, buf.vals_alt, buf.pts, buf.porig);
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, buf.vals_alt, buf.pts, buf.pidx);
     S2M_TRY(build_tables(buf, buf.keys_alt, m, top_entries, stats, st));
     stats.top_entries = top_entries;
-    g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.porig = buf.porig;
+    g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
     return hipSuccess;
 }
 
@@ -484,14 +492,17 @@ hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, Ma
 }
 
 // ---- merge update: the map after an incremental update WITHOUT a new sort ----------------------------------
-// Input: the current map (sorted points with their caller indices, their sorted keys keys_alt), the update's
+// Input: the current map (sorted points, their caller indices pidx, their sorted keys keys_alt), the update's
 // verdicts (alive[caller index] of every old point) and its staged new points (caller order of the new map:
 // survivors in index order, then the staged points -- the same list update_finish would hand to a full build).
 // The new points are sorted by their key in the CURRENT grid (tens of thousands, not millions), every one finds
-// its place among the old keys by binary search and announces itself there (v[lb] += 1); one scan over
+// its place among the old keys by binary search -- BEHIND the old points of its own cell (upper bound): the new
+// points carry the highest caller indices, so the merged array is ordered by (brick, cell, caller index) exactly
+// like a fresh build of the same list, and the search's tie order (sorted position) does not depend on which of
+// the two ways the map was produced -- and announces itself there (v[ub] += 1); one scan over
 // v[j] = alive(j) + announcements(j) then gives every surviving old point and every new point its position in
 // the merged order.  Old points move with one coalesced read and one scattered-but-monotone write; caller
-// indices are renumbered on the way (exclusive scan of alive).  ~0.6 GB of traffic at 5 M points instead of a
+// indices are renumbered on the way (exclusive scan of alive).  ~0.3 GB of traffic at 5 M points instead of a
 // 5 M-key radix sort, a bounding-box pass and a gather.
 // rank of the dead among the caller indices: a bit mask of the dead per 64 indices and the number of dead before
 // every word (312 KB + 625 KB at 5 M points: L2-resident, so renumbering a caller index costs two cache hits
@@ -556,17 +567,18 @@ __global__ __launch_bounds__(256) void merge_newkey_kernel(const float4 *__restr
     if (__syncthreads_or(out ? 1 : 0) && threadIdx.x == 0) atomicOr(outside, 1u);
 }
 
-// lower bound of every new key among the old keys; the new point announces itself there
+// upper bound of every new key among the old keys (the first old point of a LATER cell); the new point announces
+// itself there
 __global__ __launch_bounds__(256) void merge_lb_kernel(int n, const uint64_t *__restrict__ nkeys, const uint64_t *__restrict__ okeys,
                                                        int64_t m, uint32_t *__restrict__ lb, uint32_t *__restrict__ c)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = nkeys[i];
-    int64_t lo = 0, hi = m;  // first j with okeys[j] >= k
+    int64_t lo = 0, hi = m;  // first j with okeys[j] > k
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (okeys[mid] < k) lo = mid + 1; else hi = mid;
+        if (okeys[mid] <= k) lo = mid + 1; else hi = mid;
     }
     lb[i] = (uint32_t)lo;
     atomicAdd(&c[lo], 1u);
@@ -574,17 +586,20 @@ __global__ __launch_bounds__(256) void merge_lb_kernel(int n, const uint64_t *__
 
 // surviving old points to their merged positions: S = exclusive scan of alive_s[j] + c[j]; the c[j] new points that
 // announced themselves at j go first
-__global__ __launch_bounds__(256) void merge_old_kernel(int64_t m, const float4 *__restrict__ pts, const uint64_t *__restrict__ okeys,
+__global__ __launch_bounds__(256) void merge_old_kernel(int64_t m, const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
+                                                        const uint64_t *__restrict__ okeys,
                                                         const uint8_t *__restrict__ alive_s, const DeadRank *__restrict__ rank,
                                                         const uint32_t *__restrict__ c, const uint32_t *__restrict__ S,
-                                                        float4 *__restrict__ npts, uint64_t *__restrict__ nkeys_out)
+                                                        float4 *__restrict__ npts, uint32_t *__restrict__ npidx,
+                                                        uint64_t *__restrict__ nkeys_out)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m || !alive_s[j]) return;
     const uint32_t pos = S[j] + c[j];
     const float4 p = pts[j];
-    const uint32_t ci = map_point_index(p);
-    npts[pos] = make_map_point(p.x, p.y, map_point_z(p), ci - dead_before(ci, rank));
+    const uint32_t ci = pidx[j];
+    npts[pos] = make_map_point(p.x, p.y, map_point_z(p), pos);
+    npidx[pos] = ci - dead_before(ci, rank);
     nkeys_out[pos] = okeys[j];
 }
 
@@ -594,7 +609,7 @@ __global__ __launch_bounds__(256) void merge_new_kernel(int n, const uint64_t *_
                                                         const uint32_t *__restrict__ lb, const uint32_t *__restrict__ S,
                                                         const float4 *__restrict__ stage, uint32_t survivors,
                                                         float4 *__restrict__ npts, uint64_t *__restrict__ nkeys_out,
-                                                        float4 *__restrict__ nporig)
+                                                        uint32_t *__restrict__ npidx)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -607,16 +622,9 @@ __global__ __launch_bounds__(256) void merge_new_kernel(int n, const uint64_t *_
     const uint32_t pos = S[l] + (uint32_t)(i - lo);
     const uint32_t t = nvals[i];
     const float4 p = stage[t];
-    npts[pos] = make_map_point(p.x, p.y, p.z, survivors + t);
+    npts[pos] = make_map_point(p.x, p.y, p.z, pos);
     nkeys_out[pos] = nkeys[i];
-    nporig[survivors + t] = make_float4(p.x, p.y, p.z, 0.0f);
-}
-
-__global__ __launch_bounds__(256) void merge_porig_kernel(int64_t m, const float4 *__restrict__ porig, const uint8_t *__restrict__ alive,
-                                                          const DeadRank *__restrict__ rank, float4 *__restrict__ nporig)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m && alive[i]) nporig[(uint32_t)i - dead_before((uint32_t)i, rank)] = porig[i];
+    npidx[pos] = survivors + t;
 }
 
 hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive, const uint8_t *alive_s,
@@ -629,7 +637,7 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     const int n = (int)n_new;
     const int64_t words = (m + 63) / 64;
     // work_c: [dead counts per word | their exclusive prefix]; mv: [stage positions | lower bounds] of the new points
-    S2M_TRY(ensure((void **)&buf.dword, &buf.dword_cap, 3 * (words + 2), sizeof(unsigned long long)));  // masks, then the packed records
+    S2M_TRY(ensure((void **)&buf.dword, &buf.dword_cap, 3 * (words + 2), sizeof(unsigned long long), 3 * (words / 4 + 1024)));  // masks, then the packed records
     DeadRank *rank = reinterpret_cast<DeadRank *>(buf.dword + 2 * ((words + 2) / 2));  // 16-byte aligned
     uint32_t *dcnt = buf.work_c, *dprefix = buf.work_c + (words + 1);
     uint32_t *c = buf.work_a, *S = buf.work_b;
@@ -647,8 +655,8 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
         S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, buf.keys, buf.keys, buf.vals, buf.vals, (size_t)n_new, 0, kbits, st));
     S2M_TRY(ensure_sort_tmp(buf, std::max(std::max(tmp, tmp2), tmp3)));
     if (n > 0) {
-        S2M_TRY(ensure((void **)&buf.mk, &buf.mk_cap, n_new, sizeof(uint64_t)));
-        S2M_TRY(ensure((void **)&buf.mv, &buf.mv_cap, 2 * n_new, sizeof(uint32_t)));
+        S2M_TRY(ensure((void **)&buf.mk, &buf.mk_cap, n_new, sizeof(uint64_t), n_new / 2 + 4096));
+        S2M_TRY(ensure((void **)&buf.mv, &buf.mv_cap, 2 * n_new, sizeof(uint32_t), n_new + 8192));
     }
 
     // dead rank over the caller indices (element `words` of the counts is zero: the prefix there is the total)
@@ -687,19 +695,17 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     const int64_t survivors = m - (int64_t)dead;
     const int64_t m_new = survivors + n_new;
     if (m_new > buf.scratch_cap || m_new >= ((int64_t)1 << 31) || m_new == 0) return hipSuccess;
-    S2M_TRY(ensure((void **)&buf.pts2, &buf.pts2_cap, m_new + m_new / 4 + 65536 + kSentinelPoints, sizeof(float4)));
-    S2M_TRY(ensure((void **)&buf.porig2, &buf.porig2_cap, m_new + m_new / 4 + 65536, sizeof(float4)));
-    hipLaunchKernelGGL(merge_old_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.pts, buf.keys_alt,
-                       alive_s, rank, c, S, buf.pts2, buf.keys);
-    hipLaunchKernelGGL(merge_porig_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.porig, alive, rank,
-                       buf.porig2);
+    S2M_TRY(ensure((void **)&buf.pts2, &buf.pts2_cap, m_new + kSentinelPoints, sizeof(float4), headroom_for(m_new)));
+    S2M_TRY(ensure((void **)&buf.pidx2, &buf.pidx2_cap, m_new + 1, sizeof(uint32_t), headroom_for(m_new)));
+    hipLaunchKernelGGL(merge_old_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.pts, buf.pidx, buf.keys_alt,
+                       alive_s, rank, c, S, buf.pts2, buf.pidx2, buf.keys);
     if (n > 0)
         hipLaunchKernelGGL(merge_new_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, nv_sorted, lb, S, stage,
-                           (uint32_t)survivors, buf.pts2, buf.keys, buf.porig2);
+                           (uint32_t)survivors, buf.pts2, buf.keys, buf.pidx2);
     S2M_TRY(put_sentinels(buf.pts2, m_new, st));
     // the merged arrays become the map
     std::swap(buf.pts, buf.pts2); std::swap(buf.pts_cap, buf.pts2_cap);
-    std::swap(buf.porig, buf.porig2); std::swap(buf.porig_cap, buf.porig2_cap);
+    std::swap(buf.pidx, buf.pidx2); std::swap(buf.pidx_cap, buf.pidx2_cap);
     std::swap(buf.keys, buf.keys_alt);
     const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
     S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(top_entries + 1) * sizeof(uint4), st));
@@ -709,7 +715,7 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     const int64_t brick_bound = std::min<int64_t>(stats.bricks + n_new, std::min<int64_t>(top_entries, m_new));
     S2M_TRY(build_tables(buf, buf.keys_alt, m_new, top_entries, stats, st, brick_bound));
     stats.top_entries = top_entries;
-    g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.porig = buf.porig;
+    g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
     merged = true;
     return hipSuccess;
 }

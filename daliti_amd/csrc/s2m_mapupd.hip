@@ -15,7 +15,8 @@
 //   probe    eight lanes per new point: count / best old point inside its voxel via the brick grid
 //   sort     radix sort of the new points by voxel key (stable: batch order inside a voxel)
 //   resolve  eight lanes per voxel: winner among the new points, verdict against the best old point, and the old
-//            points of a rewritten voxel (except the keeper) marked dead -- by caller index and by sorted position
+//            points of a rewritten voxel (except the keeper) marked dead -- by caller index (Grid::pidx) and by
+//            sorted position
 //   stage    the winning new points in batch order
 // The new map is "survivors in index order, then the staged points": merged into the sorted arrays of the current
 // grid (s2m_map.hip, merge_update) or, when a new point lies outside the grid, compacted here (update_finish) and
@@ -109,9 +110,9 @@ __device__ __forceinline__ void for_points_in_box(const Grid &g, const float (&m
                 const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + (rowbit << 3);
                 const uint32_t e = tb[l1 + 1];
                 for (uint32_t i = tb[l0] + sub; i < e; i += stride) {
-                    const float4 q = g.pts[i];  // {x, y, index, z}
+                    const float4 q = g.pts[i];  // {x, y, position, z}
                     const float4 p = make_float4(q.x, q.y, map_point_z(q), 0.0f);
-                    if (in_box(p, mn, mx)) f(p, map_point_index(q), i);
+                    if (in_box(p, mn, mx)) f(p, g.pidx[i], i);  // caller index (4-byte read beside the point), position
                 }
             }
         }
@@ -122,7 +123,8 @@ constexpr int kBoxLanes = 8;  // lanes that share one voxel box
 __global__ __launch_bounds__(256) void add_probe_kernel(Grid g, const float4 *__restrict__ np, int n, float ds,
                                                         uint64_t *__restrict__ key, uint32_t *__restrict__ val,
                                                         float *__restrict__ dnew, uint32_t *__restrict__ cnt,
-                                                        uint32_t *__restrict__ best_idx, float *__restrict__ best_d)
+                                                        uint32_t *__restrict__ best_idx, uint32_t *__restrict__ best_pos,
+                                                        float *__restrict__ best_d)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = tid / kBoxLanes;
@@ -130,21 +132,22 @@ __global__ __launch_bounds__(256) void add_probe_kernel(Grid g, const float4 *__
     const bool live = i < n;
     const float4 p = np[live ? i : 0];
     const Voxel v = voxel_of(p.x, p.y, p.z, ds);
-    uint32_t c = 0, bi = 0xffffffffu;
+    uint32_t c = 0, bi = 0xffffffffu, bp = 0u;
     float bd = INFINITY;
     if (live)
-        for_points_in_box(g, v.mn, v.mx, [&](const float4 &q, uint32_t idx, uint32_t) {
+        for_points_in_box(g, v.mn, v.mx, [&](const float4 &q, uint32_t idx, uint32_t pos) {
             ++c;
             const float d = dist2(q.x, q.y, q.z, v.mid);
-            if (d < bd || (d == bd && idx < bi)) { bd = d; bi = idx; }
+            if (d < bd || (d == bd && idx < bi)) { bd = d; bi = idx; bp = pos; }
         }, sub, kBoxLanes);
-    // group result: counts add up; the best old point is the smallest (distance, index) pair
+    // group result: counts add up; the best old point is the smallest (distance, caller index) pair
 #pragma unroll
     for (int off = kBoxLanes / 2; off > 0; off >>= 1) {
         c += __shfl_xor(c, off, kBoxLanes);
         const float od = __shfl_xor(bd, off, kBoxLanes);
         const uint32_t oi = __shfl_xor(bi, off, kBoxLanes);
-        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+        const uint32_t op = __shfl_xor(bp, off, kBoxLanes);
+        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; bp = op; }
     }
     if (!live || sub != 0) return;
     key[i] = voxel_key(p.x, p.y, p.z, ds);
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(256) void add_probe_kernel(Grid g, const float4 *__
     dnew[i] = dist2(p.x, p.y, p.z, v.mid);
     cnt[i] = c;
     best_idx[i] = bi;
+    best_pos[i] = bp;
     best_d[i] = bd;
 }
 
@@ -162,6 +166,7 @@ __global__ __launch_bounds__(256) void add_resolve_kernel(Grid g, const float4 *
                                                           const float *__restrict__ dnew,
                                                           const uint32_t *__restrict__ cnt,
                                                           const uint32_t *__restrict__ best_idx,
+                                                          const uint32_t *__restrict__ best_pos,
                                                           const float *__restrict__ best_d,
                                                           uint8_t *__restrict__ alive, uint8_t *__restrict__ alive_s,
                                                           uint32_t *__restrict__ add_flag, uint32_t *__restrict__ counters)
@@ -196,9 +201,9 @@ __global__ __launch_bounds__(256) void add_resolve_kernel(Grid g, const float4 *
         } else {
             // an old point stays the closest.  The reference rewrites the voxel when it held several points
             // or when the result "is" the new point within EPSS (ikd_Tree.cpp:514, 1676-1680)
-            const float4 pe = g.porig[bi];
+            const float4 pe = g.pts[best_pos[w]];
             const bool same = fabs((double)(pw.x - pe.x)) < 1e-6 && fabs((double)(pw.y - pe.y)) < 1e-6 &&
-                              fabs((double)(pw.z - pe.z)) < 1e-6;
+                              fabs((double)(pw.z - map_point_z(pe))) < 1e-6;
             keep = bi;
             rewrite = (c > 1) || same;
         }
@@ -215,8 +220,8 @@ __global__ __launch_bounds__(256) void add_resolve_kernel(Grid g, const float4 *
     }
 }
 
-// over the SORTED array (it holds the coordinates and the caller index): both alive arrays are written without a gather
-__global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restrict__ pts, int64_t m,
+// over the SORTED array (coordinates and, beside it, the caller indices): both alive arrays are written without a gather
+__global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx, int64_t m,
                                                            const float *__restrict__ boxes, int nb,
                                                            uint8_t *__restrict__ alive, uint8_t *__restrict__ alive_s,
                                                            uint32_t *__restrict__ counters)
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restr
             const float mn[3] = {bx[0], bx[1], bx[2]}, mx[3] = {bx[3], bx[4], bx[5]};
             hit = in_box(p, mn, mx);
         }
-        if (hit) { alive_s[j] = 0; alive[map_point_index(q)] = 0; }
+        if (hit) { alive_s[j] = 0; alive[pidx[j]] = 0; }
     }
     // one atomic per workgroup: a field-of-view trim deletes 1e5..1e6 points, per-point atomics on one
     // address would take milliseconds
@@ -244,6 +249,20 @@ __global__ __launch_bounds__(256) void flags_to_u32_kernel(const uint8_t *__rest
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) out[i] = a[i] ? 1u : 0u;
+}
+
+// survivors of the map in CALLER order: sorted position j holds caller index ci = pidx[j]; it goes to pos[ci]
+// (exclusive scan of the alive flags over the caller indices)
+__global__ __launch_bounds__(256) void scatter_survivors_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
+                                                                const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
+                                                                int64_t m, float4 *__restrict__ out)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint32_t ci = pidx[j];
+    if (!flag[ci]) return;
+    const float4 q = pts[j];
+    out[pos[ci]] = make_float4(q.x, q.y, map_point_z(q), 0.0f);
 }
 
 // out[pos[i]] = src[i] for flagged i (pos = exclusive scan of the flags), shifted by base
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
                                                             const float *__restrict__ sy,
                                                             const float *__restrict__ sz, int n,
                                                             const int32_t *__restrict__ nn_idx,
-                                                            const float4 *__restrict__ porig, int have_nn, double fs,
+                                                            const float4 *__restrict__ pts, int have_nn, double fs,
                                                             float4 *__restrict__ pw_out,
                                                             unsigned long long *__restrict__ cls_out)
 {
@@ -283,17 +302,17 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
         const float mid[3] = {(float)(floor((double)wx / fs) * fs + 0.5 * fs), (float)(floor((double)wy / fs) * fs + 0.5 * fs),
                               (float)(floor((double)wz / fs) * fs + 0.5 * fs)};  // :599-601
         const float dist = dist2(wx, wy, wz, mid);                              // :602
-        const float4 n0 = porig[nn_idx[(int64_t)i * kK]];
+        const float4 n0 = pts[nn_idx[(int64_t)i * kK]];  // Nearest_Points as sorted positions
         if (fabs((double)(n0.x - mid[0])) > 0.5 * fs && fabs((double)(n0.y - mid[1])) > 0.5 * fs &&
-            fabs((double)(n0.z - mid[2])) > 0.5 * fs) {                         // :603
+            fabs((double)(map_point_z(n0) - mid[2])) > 0.5 * fs) {              // :603
             cls = 2;
         } else {
             bool need_add = true;
             if (cnt >= kK) {                                                    // :610
 #pragma unroll
                 for (int r = 0; r < kK; ++r) {
-                    const float4 q = porig[nn_idx[(int64_t)i * kK + r]];
-                    if (need_add && dist2(q.x, q.y, q.z, mid) < dist) need_add = false;  // :612-616
+                    const float4 q = pts[nn_idx[(int64_t)i * kK + r]];
+                    if (need_add && dist2(q.x, q.y, map_point_z(q), mid) < dist) need_add = false;  // :612-616
                 }
             }
             cls = need_add ? 1 : 0;
@@ -325,12 +344,25 @@ __global__ __launch_bounds__(256) void xyz_to_float4_kernel(const float *__restr
     if (i < n) out[i] = make_float4(xyz[i * stride], xyz[i * stride + 1], xyz[i * stride + 2], 0.0f);
 }
 
-__global__ __launch_bounds__(256) void float4_to_xyz_kernel(const float4 *__restrict__ in, int64_t n, float *__restrict__ xyz)
+// ikdtree.flatten's counterpart: the map in the caller's index order, packed xyz
+__global__ __launch_bounds__(256) void map_to_xyz_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
+                                                         int64_t m, float *__restrict__ xyz)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) {
+        const float4 p = pts[j];
+        const int64_t i = pidx[j];
+        xyz[3 * i] = p.x; xyz[3 * i + 1] = p.y; xyz[3 * i + 2] = map_point_z(p);
+    }
+}
+
+__global__ __launch_bounds__(256) void positions_to_indices_kernel(const int32_t *__restrict__ nn, const uint32_t *__restrict__ pidx,
+                                                                   int64_t count, int32_t *__restrict__ out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const float4 p = in[i];
-        xyz[3 * i] = p.x; xyz[3 * i + 1] = p.y; xyz[3 * i + 2] = p.z;
+    if (i < count) {
+        const int32_t p = nn[i];
+        out[i] = p >= 0 ? (int32_t)pidx[p] : -1;
     }
 }
 
@@ -409,6 +441,7 @@ static hipError_t grow(T **p, int64_t *cap, int64_t need, bool keep = false, hip
     const int64_t c = std::max<int64_t>(need + need / 4, 1024);
     T *q = nullptr;
     S2M_TRY(hipMalloc((void **)&q, (size_t)c * sizeof(T)));
+    note_allocation();
     if (*p) {
         if (keep && *cap > 0) {
             S2M_TRY(hipMemcpyAsync(q, *p, (size_t)*cap * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -423,7 +456,7 @@ static hipError_t grow(T **p, int64_t *cap, int64_t need, bool keep = false, hip
 
 void free_update(UpdateBuffers &u)
 {
-    void *ptrs[] = {u.alive, u.alive_s, u.counters, u.stage, u.key, u.key2, u.val, u.val2, u.dnew, u.cnt, u.best_idx, u.best_d,
+    void *ptrs[] = {u.alive, u.alive_s, u.counters, u.stage, u.key, u.key2, u.val, u.val2, u.dnew, u.cnt, u.best_idx, u.best_pos, u.best_d,
                     u.add_flag, u.pos, u.flag32, u.pos_old, u.list, u.tmp, u.boxes, u.cvt};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -496,6 +529,7 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
         c = u.batch_cap; S2M_TRY(grow(&u.dnew, &c, n));
         c = u.batch_cap; S2M_TRY(grow(&u.cnt, &c, n));
         c = u.batch_cap; S2M_TRY(grow(&u.best_idx, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_pos, &c, n));
         c = u.batch_cap; S2M_TRY(grow(&u.best_d, &c, n));
         c = u.batch_cap; S2M_TRY(grow(&u.add_flag, &c, n));
         c = u.batch_cap; S2M_TRY(grow(&u.pos, &c, n));
@@ -503,7 +537,7 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
     }
     const int in = (int)n;
     hipLaunchKernelGGL(add_probe_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, u.key, u.val, u.dnew, u.cnt,
-                       u.best_idx, u.best_d);
+                       u.best_idx, u.best_pos, u.best_d);
     size_t bytes = 0;
     S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 63, st));
     S2M_TRY(ensure_tmp(u, bytes));
@@ -516,7 +550,7 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
         S2M_TRY(mail_fetch(u.mail, src, 1, &before, st));
     }
     hipLaunchKernelGGL(add_resolve_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, u.key2, u.val2, u.dnew,
-                       u.cnt, u.best_idx, u.best_d, u.alive, u.alive_s, u.add_flag, u.counters);
+                       u.cnt, u.best_idx, u.best_pos, u.best_d, u.alive, u.alive_s, u.add_flag, u.counters);
     // winners, in batch order, go to the staging list
     S2M_TRY(scan_u32(u, u.add_flag, u.pos, n, st));
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage);
@@ -537,7 +571,7 @@ hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_hos
     S2M_TRY(hipMemcpyAsync(u.boxes, boxes_host, (size_t)nb * 6 * sizeof(float), hipMemcpyHostToDevice, st));
     // counters[2] is zero at update_begin and only this entry point adds to it: the count after the launch, minus
     // what earlier calls of the same update reported
-    hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.pts, g.m, u.boxes, nb, u.alive,
+    hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.pts, g.pidx, g.m, u.boxes, nb, u.alive,
                        u.alive_s, u.counters);
     const uint32_t *src[1] = {u.counters + 2};
     uint32_t after = 0;
@@ -564,8 +598,8 @@ hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStr
     }
     S2M_TRY(grow(&u.list, &u.list_cap, survivors + u.stage_n));
     if (g.m > 0)
-        hipLaunchKernelGGL(scatter_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.porig, u.flag32, u.pos_old, g.m,
-                           (int64_t)0, u.list);
+        hipLaunchKernelGGL(scatter_survivors_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.pts, g.pidx, u.flag32, u.pos_old, g.m,
+                           u.list);
     if (u.stage_n > 0)
         S2M_TRY(hipMemcpyAsync(u.list + survivors, u.stage, (size_t)u.stage_n * sizeof(float4), hipMemcpyDeviceToDevice, st));
     *m_out = survivors + u.stage_n;
@@ -592,6 +626,7 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
         c = u.batch_cap; S2M_TRY(grow(&u.dnew, &c, n));
         c = u.batch_cap; S2M_TRY(grow(&u.cnt, &c, n));
         c = u.batch_cap; S2M_TRY(grow(&u.best_idx, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_pos, &c, n));
         c = u.batch_cap; S2M_TRY(grow(&u.best_d, &c, n));
         c = u.batch_cap; S2M_TRY(grow(&u.add_flag, &c, n));
         c = u.batch_cap; S2M_TRY(grow(&u.pos, &c, n));
@@ -599,7 +634,7 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
     }
     float4 *pw = u.cvt, *la = u.cvt + n, *lb = u.cvt + 2 * (int64_t)n;
     unsigned long long *fl = reinterpret_cast<unsigned long long *>(u.key), *ps = reinterpret_cast<unsigned long long *>(u.key2);
-    hipLaunchKernelGGL(incr_classify_kernel, dim3(nblk(n)), dim3(256), 0, st, pose, sx, sy, sz, n, nn_idx, g.porig,
+    hipLaunchKernelGGL(incr_classify_kernel, dim3(nblk(n)), dim3(256), 0, st, pose, sx, sy, sz, n, nn_idx, g.pts,
                        have_nn ? 1 : 0, fs, pw, fl);
     {
         size_t bytes = 0;
@@ -630,9 +665,14 @@ hipError_t xyz_to_float4(UpdateBuffers &u, const float *xyz_dev, int64_t stride,
     return hipGetLastError();
 }
 
-void launch_float4_to_xyz(const float4 *in, int64_t n, float *xyz, hipStream_t st)
+void launch_map_to_xyz(const float4 *pts, const uint32_t *pidx, int64_t m, float *xyz, hipStream_t st)
 {
-    if (n > 0) hipLaunchKernelGGL(float4_to_xyz_kernel, dim3(nblk(n)), dim3(256), 0, st, in, n, xyz);
+    if (m > 0) hipLaunchKernelGGL(map_to_xyz_kernel, dim3(nblk(m)), dim3(256), 0, st, pts, pidx, m, xyz);
+}
+
+void launch_positions_to_indices(const int32_t *nn, const uint32_t *pidx, int64_t count, int32_t *out, hipStream_t st)
+{
+    if (count > 0) hipLaunchKernelGGL(positions_to_indices_kernel, dim3(nblk(count)), dim3(256), 0, st, nn, pidx, count, out);
 }
 
 }  // namespace s2m

@@ -7,10 +7,12 @@
 // neighbour gate (:852-854) and esti_plane (:863) run in the thread-per-point kernel of
 // s2m_reduce.hip, where one wave instruction serves 64 scan points instead of 4.
 //
-// Candidates are ranked by the 64-bit key (float bits of d2) << 32 | original index: d2 >= 0 so the
-// bit pattern orders like the value, the index makes keys unique, and a top-5 insertion is a
-// handful of 64-bit compare/selects with no tie branches (ikd-Tree ranks by d2, then x,
-// ikd_Tree.h:102-108; exact ties are ~1e-7 of queries and either choice is a valid exact 5-NN).
+// Candidates are ranked by the 64-bit key (float bits of d2) << 32 | sorted position: d2 >= 0 so the
+// bit pattern orders like the value, the position makes keys unique, and a top-5 insertion is a
+// handful of 64-bit compare/selects with no tie branches.  Sorted position = (brick, cell, caller index), a
+// total order the oracle computes from s2m_map_info (ikd-Tree ranks by d2, then x, ikd_Tree.h:102-108, with
+// a traversal-dependent choice at the 5th place; exact ties are ~1e-7 of queries and every choice is a valid
+// exact 5-NN).  The position doubles as the gather address of the plane fit (s2m_reduce.hip).
 //
 // Two kernels, because measured cost is a long tail of far queries on top of the first-shell work:
 //   match_rows<G> : G lanes (default 2) per scan point scan the 3x3x3 cells around it as nine x-ROWS: the three
@@ -184,7 +186,7 @@ __device__ __forceinline__ void scan_points(const Grid &g, uint32_t s, uint32_t 
             const float dz = wz - map_point_z(p[u]);
             float d = sq.x + sq.y;
             d = d + dz * dz;
-            key[u] = make_key(d, map_point_index(p[u]));
+            key[u] = make_key(d, map_point_pos(p[u]));
         }
         if (S2M_BATCH_SORT && S2M_INSERT_F64 && B == 8) {
             u64 k8[8];
@@ -533,7 +535,7 @@ __device__ __forceinline__ void consume_batch(const float4 (&p)[8], float wx, fl
         const float dz = wz - map_point_z(p[u]);
         float d = sq.x + sq.y;
         d = d + dz * dz;
-        key[u] = make_key(d, map_point_index(p[u]));
+        key[u] = make_key(d, map_point_pos(p[u]));
     }
 #ifdef S2M_EXP_BATCH_REJECT
     // experiment (DESIGN, rejected table): skip the 48-operation network when no lane of the wave holds a candidate
@@ -791,7 +793,11 @@ constexpr int kPairSlots = 6;  // (brick,row) pairs a lane can hold per chunk of
 #ifndef S2M_HARD_OCC
 #define S2M_HARD_OCC 4  // waves per SIMD match_hard is compiled for (116 VGPRs at 4; 5 needs spills) = resident waves / 1024
 #endif
-template <bool WIDE>
+// FAR: the instantiation behind s2m_complete_neighbors.  Its radius is not the gate but whatever it takes to find
+// five points, so the brick neighbourhood is intersected with the grid per point (a 100 m radius would otherwise
+// enumerate millions of bricks that do not exist); the per-iteration instantiation keeps the unclamped cube, whose
+// lane -> brick mapping is computed once per wave.
+template <bool WIDE, bool FAR = false>
 __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
 {
     constexpr int G = 64;
@@ -805,8 +811,8 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
     const uint32_t c0 = a.hard_count[0], count = c0 + a.hard_count[1];  // [no radius yet | radius known]
     // brick rings needed so that the neighbourhood covers the gate radius from anywhere in the home brick
     const float gate_r = sqrtf(a.gates.knn_d2_gate);
-    const int NB = max(1, (int)ceilf(gate_r * g.inv_c * 0.125f + 1e-3f));
-    const int bside = 2 * NB + 1, nbricks = bside * bside * bside;
+    const int NB = max(1, (int)fminf(ceilf(gate_r * g.inv_c * 0.125f + 1e-3f), 1048576.0f));
+    const int bside = 2 * NB + 1, nbricks = FAR ? 0 : bside * bside * bside;  // FAR clips the cube to the grid per point
     // the brick this lane inspects in the first chunk of 64 bricks, relative to the home brick (the common
     // case NB = 1 has 27 bricks, one chunk): computed once, not per point
     const int ob0 = lane < nbricks ? lane : 0;
@@ -937,15 +943,23 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) append_cells(nid[k], nrow, nxa[k], ncl[k]);  // <= 2 x 49 x 7 cells
-            } else
-            for (int bbase = 0; bbase < nbricks; bbase += 64) {
+            } else {
+            // FAR: the neighbourhood clipped to the grid (empty when the point lies further outside than the radius)
+            const int flx = max(hbx - NB, 0), fly = max(hby - NB, 0), flz = max(hbz - NB, 0);
+            const int fsx = FAR ? max(min(hbx + NB, g.nbx - 1) - flx + 1, 0) : 0;
+            const int fsy = FAR ? max(min(hby + NB, g.nby - 1) - fly + 1, 0) : 0;
+            const int fsz = FAR ? max(min(hbz + NB, g.nbz - 1) - flz + 1, 0) : 0;
+            const int nbr = FAR ? (int)min((long long)fsx * fsy * fsz, 0x7fffffc0ll) : nbricks;
+            for (int bbase = 0; bbase < nbr; bbase += 64) {
                 // 1. top entries of up to 64 bricks, one per lane
                 const int b = bbase + lane;
                 uint32_t my_id = 0;
                 uint64_t my_mask = 0;
                 int bx = 0, by = 0, bz = 0;
-                if (b < nbricks) {
-                    if (bbase == 0) {
+                if (b < nbr) {
+                    if (FAR) {
+                        bx = flx + b % fsx; by = fly + (b / fsx) % fsy; bz = flz + b / (fsx * fsy);
+                    } else if (bbase == 0) {
                         bx = hbx + odx0; by = hby + ody0; bz = hbz + odz0;
                     } else {
                         bx = hbx + (b % bside) - NB;
@@ -1009,6 +1023,7 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
                     }
                 }
             }
+            }
             flush_cells();
             ++rounds;
             merge_lists<G>(t, best);
@@ -1070,6 +1085,53 @@ static void launch_easy(const MatchArgs &a, bool wide, bool cells, int nb, hipSt
     }
 }
 
+// ---- completion of the lists that ended short at the gate (s2m_complete_neighbors) -------------------------
+// A list is the exact, final answer when it holds five neighbours whose 5th distance is inside the radius the search
+// was allowed (a.gates.knn_d2_gate: the gate, or the larger radius of the last completion round) -- both search
+// kernels guarantee that much and no more: beyond it a list may be short, or full of whatever the last band happened
+// to see.  Every other scan point goes to the far-point list again, as a point without a radius (its world-frame
+// query is the one of the rematch pass that produced the list).
+__global__ __launch_bounds__(256) void collect_short_kernel(MatchArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool want = false;
+    HardRec rec = {0.f, 0.f, 0.f, 0u, 0.f, 0u, {0u, 0u}};
+    if (i < a.n && !(a.nn_idx[(int64_t)i * kK + (kK - 1)] >= 0 && a.nn_d2[(int64_t)i * kK + (kK - 1)] <= a.gates.knn_d2_gate)) {
+        want = true;
+        body_to_world(a.pose, a.sx[i], a.sy[i], a.sz[i], rec.wx, rec.wy, rec.wz);
+        rec.qi = (uint32_t)i;
+    }
+    append_rec(a.hard_rec, a.hard_count, want, rec);
+}
+
+void launch_collect_short(const MatchArgs &a, hipStream_t st)
+{
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(collect_short_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+}
+
+static void launch_hard(const MatchArgs &a, bool wide, hipStream_t st)
+{
+    // the rest: one wave per point (narrower groups measured slower: the far tail is latency-bound)
+    const int hg = 64;
+    // as many waves as stay resident together (116 VGPRs: 4 per SIMD, 4,096 on the chip); the rest of the list is
+    // pulled through the queue heads
+    const int64_t groups = std::min<int64_t>(a.n, (a.qheads ? 1024 * S2M_HARD_OCC : 8192) * (64 / hg));
+    const int blocks = (int)((groups * hg + 255) / 256);
+    if (!wide) hipLaunchKernelGGL(match_hard<false>, dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(match_hard<true>, dim3(blocks), dim3(256), 0, st, a);
+}
+
+void launch_match_hard_only(const MatchArgs &a, hipStream_t st)
+{
+    if (a.n <= 0) return;
+    const bool wide = a.grid.sent_off == 0 && a.grid.m != 0;
+    const int64_t groups = std::min<int64_t>(a.n, 1024 * S2M_HARD_OCC);
+    const int blocks = (int)((groups * 64 + 255) / 256);
+    if (!wide) hipLaunchKernelGGL((match_hard<false, true>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((match_hard<true, true>), dim3(blocks), dim3(256), 0, st, a);
+}
+
 void launch_match(const MatchArgs &a, int group, hipStream_t st)
 {
     if (a.n <= 0) return;
@@ -1084,14 +1146,7 @@ void launch_match(const MatchArgs &a, int group, hipStream_t st)
         case 8: launch_easy<8>(a, wide, cells, nb, st); break;
         default: launch_easy<2>(a, wide, cells, nb, st); break;
     }
-    // the rest: one wave per point (narrower groups measured slower: the far tail is latency-bound)
-    const int hg = 64;
-    // as many waves as stay resident together (116 VGPRs: 4 per SIMD, 4,096 on the chip); the rest of the list is
-    // pulled through the queue heads
-    const int64_t groups = std::min<int64_t>(a.n, (a.qheads ? 1024 * S2M_HARD_OCC : 8192) * (64 / hg));
-    const int blocks = (int)((groups * hg + 255) / 256);
-    if (!wide) hipLaunchKernelGGL(match_hard<false>, dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(match_hard<true>, dim3(blocks), dim3(256), 0, st, a);
+    launch_hard(a, wide, st);
 }
 
 }  // namespace s2m

@@ -3,7 +3,7 @@
 //
 // On a rematch pass (FIT) each lane first applies the neighbour gate (laserMapping.cpp:852-854) to
 // the fresh Nearest_Points of its scan point and fits the plane (esti_plane, :863;
-// common_lib.h:267-299) from the five neighbours gathered by index; the plane only depends on the
+// common_lib.h:267-299) from the five neighbours gathered by sorted position; the plane only depends on the
 // (world-frame, constant) neighbours, so it is cached and the reuse passes skip the fit -- the
 // reference re-fits the identical plane every iteration.
 //
@@ -224,14 +224,11 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
                 float nx[kK], ny[kK], nz[kK];
 #pragma unroll
                 for (int k = 0; k < kK; ++k) {
-#ifdef S2M_EXP_FIT_COALESCED
-                    // experiment (timing only, results are wrong): consecutive instead of gathered neighbours, to
-                    // bound what the five random 16-byte reads per point cost
-                    const float4 p = a.porig[(int64_t)i * kK + k + (ni[k] & 0)];
-#else
-                    const float4 p = a.porig[ni[k]];
-#endif
-                    nx[k] = p.x; ny[k] = p.y; nz[k] = p.z;
+                    // neighbours are sorted positions: the five of a query sit in the same or adjacent cells of
+                    // the cell-ordered array, i.e. in a few cache lines (round 2 gathered from a copy in caller
+                    // order: five random lines per point, 2 x 12.6 MB fetched per pass to read 5.2 MB)
+                    const float4 p = a.pts[ni[k]];
+                    nx[k] = p.x; ny[k] = p.y; nz[k] = map_point_z(p);
                 }
                 plane_ok = fit_plane(nx, ny, nz, a.gates.plane_thr, pl);
             }

@@ -23,7 +23,8 @@ ABI_SYMBOLS = [
     "s2m_fov_segment", "s2m_fov_reset",
     "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
-    "s2m_iterated_update", "s2m_iterated_update_batch", "s2m_iterated_update_sharded", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
+    "s2m_iterated_update", "s2m_iterated_update_batch", "s2m_iterated_update_multi", "s2m_iterated_update_sharded",
+    "s2m_complete_neighbors", "s2m_map_get_order", "s2m_map_grid", "s2m_map_update_stats", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
     "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats",
 ]
 
@@ -192,6 +193,39 @@ class Engine:
         m = C.c_int32()
         self._ck(self.lib.s2m_map_last_update(self.h, C.byref(m)))
         return bool(m.value)
+
+    def map_update_stats(self):
+        """Running counts: updates merged / rebuilt / re-gridded, device buffer (re)allocations (process-wide)."""
+        st = (C.c_int64 * 4)()
+        self._ck(self.lib.s2m_map_update_stats(self.h, st))
+        return dict(merged=st[0], rebuilt=st[1], regridded=st[2], allocations=st[3])
+
+    def map_order(self):
+        """order[j] = caller index of the point at sorted position j (the engine's tie order)."""
+        m = C.c_int64()
+        self._ck(self.lib.s2m_map_get_order(self.h, None, C.c_int64(0), C.byref(m)))
+        out = np.zeros(max(m.value, 1), np.uint32)
+        self._ck(self.lib.s2m_map_get_order(self.h, _p(out), C.c_int64(len(out)), C.byref(m)))
+        return out[:m.value]
+
+    def map_grid(self):
+        """Cells per axis of the current grid."""
+        c = (C.c_int32 * 3)()
+        self._ck(self.lib.s2m_map_grid(self.h, c))
+        return tuple(c)
+
+    def map_rank(self):
+        """rank[i] = sorted position of caller index i: what the oracle takes as the tie order of equal distances."""
+        order = self.map_order()
+        rank = np.empty(len(order), np.uint32)
+        rank[order] = np.arange(len(order), dtype=np.uint32)
+        return rank
+
+    def complete_neighbors(self):
+        """Nearest_Points beyond the gate (unbounded ikd-Tree search); returns the number of lists that were short."""
+        c = C.c_int64()
+        self._ck(self.lib.s2m_complete_neighbors(self.h, C.byref(c)))
+        return c.value
 
     def map_add(self, xyz, downsample_on, downsample_size=0.5):
         """ikdtree.Add_Points(points, downsample_on); returns voxels rewritten (or n)."""
@@ -387,6 +421,23 @@ class Engine:
             msgs = [e.lib.s2m_last_error(e.h).decode() for e in engines]
             raise S2MError(rc, "%s (%s)" % (engines[0].lib.s2m_strerror(rc).decode(), "; ".join(m for m in msgs if m)))
         return logs
+
+    @staticmethod
+    def iterated_update_multi(engines, x, x_prop, P, logs=None):
+        """ONE scan whose shards sit in `engines` (handle order = index order), summed on the host.  x (36,),
+        x_prop (36,), P (24, 24) float64 C-contiguous arrays updated in place; returns the IterLog."""
+        k = len(engines)
+        assert x.shape == (STATE_DOUBLES,) and x_prop.shape == (STATE_DOUBLES,) and P.shape == (DIM, DIM)
+        assert x.flags.c_contiguous and x_prop.flags.c_contiguous and P.flags.c_contiguous
+        hs = (C.c_void_p * k)(*[e.h for e in engines])
+        if logs is None:
+            logs = (IterLog * 1)()
+        rc = engines[0].lib.s2m_iterated_update_multi(hs, C.c_int32(k), C.c_void_p(x.ctypes.data),
+                                                      C.c_void_p(x_prop.ctypes.data), C.c_void_p(P.ctypes.data), logs)
+        if rc != 0:
+            msgs = [e.lib.s2m_last_error(e.h).decode() for e in engines]
+            raise S2MError(rc, "%s (%s)" % (engines[0].lib.s2m_strerror(rc).decode(), "; ".join(m for m in msgs if m)))
+        return logs[0]
 
     def iterated_update_sharded(self, x, x_prop, P, d_block_ptr, reduce_cb):
         """reduce_cb() must sum the device block across ranks on this handle's stream."""

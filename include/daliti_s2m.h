@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define S2M_ABI_VERSION 1
+/* 2: s2m_map_incremental gained `ekf_inited`, s2m_get_timing_stats writes 6 doubles, s2m_set_timing(n > 2) samples
+ * (all round 2, which forgot to bump it); new in round 3: s2m_iterated_update_multi, s2m_complete_neighbors,
+ * s2m_map_get_order, s2m_map_update_stats.  A caller built against version 1 must be recompiled. */
+#define S2M_ABI_VERSION 2
 #define S2M_K 5            /* NUM_MATCH_POINTS, laserMapping.cpp:77 */
 #define S2M_DIM 24         /* DIM_OF_STATES, common_lib.h:23 */
 #define S2M_STATE_DOUBLES 36
@@ -132,12 +135,28 @@ int s2m_fov_reset(s2m_engine *e);
 int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], double filter_size_map,
                         int32_t ekf_inited, int64_t *n_to_add, int64_t *n_no_downsample);
 /* ikdtree.flatten(Root_Node, PCL_Storage) (laserMapping.cpp:1170-1175): the current map points,
- * packed xyz, in the engine's index order (the order neighbour indices refer to). */
+ * packed xyz, in the caller's index order (the order the indices of s2m_get_neighbors refer to: the array given to
+ * s2m_map_build; after updates the survivors in index order followed by the added points). */
 int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity_points, int64_t *m);
 /* How the last map_add / map_delete_boxes / fov_segment / map_incremental produced the new map (design, not
  * reference): *merged = 1 when the update was merged into the sorted arrays of the current grid, 0 when the grid
  * was rebuilt (a new point outside the grid and its margin, a density drift, an empty map). */
 int s2m_map_last_update(const s2m_engine *e, int32_t *merged);
+/* Running counts for latency diagnosis (design, not reference; the reference hides the same events behind ikd-Tree's
+ * rebuild thread, ikd_Tree.cpp:192-203, 229-367): stats[0] = updates merged into the grid, stats[1] = updates that
+ * rebuilt it, stats[2] = rebuilds that also chose a new cell size (density drift), stats[3] = device buffer
+ * (re)allocations made by map builds and updates so far (process-wide). */
+int s2m_map_update_stats(const s2m_engine *e, int64_t stats[4]);
+/* The engine's internal point order (design, not reference): order[j] = the caller's index of the point at sorted
+ * position j.  Positions are ordered by (brick of 8x8x8 cells, cell within the brick, caller index), the cell of a
+ * coordinate v being floor((v - origin) * (1 / cell_size)) in float arithmetic with the origin and cell size of
+ * s2m_map_info -- after a full build and after a merged update alike.  Candidates tied at exactly the same float
+ * squared distance are ranked by this position (tests hand it to the oracle as the tie order). */
+int s2m_map_get_order(s2m_engine *e, uint32_t *order, int64_t capacity_points, int64_t *m);
+/* cells[3] = cells per axis of the current grid (multiples of 8: a brick is 8x8x8 cells; bricks are numbered
+ * x fastest, then y, then z, and so are the cells inside a brick); a coordinate's cell index is clamped to
+ * [0, cells - 1].  Together with s2m_map_info this determines the order of s2m_map_get_order. */
+int s2m_map_grid(const s2m_engine *e, int32_t cells[3]);
 
 /* The down-sampled body-frame scan feats_down (laserMapping.cpp:775-778).  Resets the per-scan
  * state: point_selected_surf := true (:812), Nearest_Points cleared (:810).  Coordinates must be finite -- the
@@ -214,8 +233,17 @@ int s2m_get_rows(s2m_engine *e, double *h_x, double *h, int32_t *scan_index, int
 int s2m_get_point_state(s2m_engine *e, uint8_t *selected, uint8_t *effective, float *plane,
                         float *pd2);
 /* Nearest_Points of the last rematch pass (:845-850): idx[n*5] indexes the array given to
- * s2m_map_build (-1 = missing), d2[n*5] ascending (INFINITY = missing). */
+ * s2m_map_build (-1 = missing), d2[n*5] ascending (INFINITY = missing); exact ties in d2 are ordered by the engine's
+ * sorted position (s2m_map_get_order).  The per-iteration search stops at the d2 <= 5 gate (:853): a list is the exact
+ * answer of ikdtree.Nearest_Search for every neighbour within the gate radius and ends there -- a scan point whose
+ * surroundings are emptier than that has fewer than five entries until s2m_complete_neighbors has run. */
 int s2m_get_neighbors(s2m_engine *e, int32_t *idx, float *d2);
+/* Completes the lists that ended short at the gate to the unbounded result of ikdtree.Nearest_Search (max_dist =
+ * INFINITY, ikd-Tree/ikd_Tree.cpp:425): five nearest map points however far away (fewer only when the map holds
+ * fewer).  map_incremental reads points_near[0] of exactly such points when the sensor enters new territory
+ * (laserMapping.cpp:593-607); s2m_map_incremental therefore calls this first.  Cold path: a scan inside the mapped
+ * area has nothing to complete.  *n_completed (optional) = lists that were short. */
+int s2m_complete_neighbors(s2m_engine *e, int64_t *n_completed);
 
 /* Kalman update of laserMapping.cpp:1012-1046 from the normal block:
  * K_1 = (H_T_H + (P/R)^-1)^-1; solution = K z + vec - K H vec[0:12]; x [+]= solution.
@@ -255,6 +283,14 @@ int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES],
  * must be distinct, on one device, without a communicator. */
 int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, const double *x_prop,
                               double *P, s2m_iter_log *logs);
+/* ONE scan split over n handles, driven by one host thread, without a collective library (design, not reference;
+ * SURVEY.md 8e "single-process peer-copy gather"): handles[i] holds shard i of the scan (contiguous ranges, handle
+ * order = index order) and the map -- on n devices of one node, or several shards per device.  Every pass is launched
+ * on all handles, each handle's block lands in its own pinned host page, the host sums the n blocks in handle order
+ * and runs ONE fp64 update (degeneracy queue and Kalman work area of handles[0]).  x, P as in s2m_iterated_update.
+ * Deterministic for a given n; agrees with the single-handle result to summation order (~1e-13 in the pose). */
+int s2m_iterated_update_multi(s2m_engine *const *handles, int32_t n, double x[S2M_STATE_DOUBLES],
+                              const double x_prop[S2M_STATE_DOUBLES], double P[S2M_DIM * S2M_DIM], s2m_iter_log *log);
 /* Multi-GPU form: this handle holds a contiguous shard of the scan's points and the whole map.
  * After every pass the shard's block (S2M_BLOCK_DOUBLES doubles, layout as in
  * s2m_residual_pass_device) is in d_block, a DEVICE buffer the caller owns; reduce(user) must

@@ -75,7 +75,8 @@ static inline int s2m_wire_bytes(const uint8_t **p, const uint8_t *end, uint32_t
 static inline int s2m_pc2_parse(const uint8_t *buf, size_t len, s2m_pc2_view *v, size_t *consumed)
 {
     const uint8_t *p = buf, *end = buf + len, *s = NULL;
-    uint32_t nfields = 0, n = 0;
+    uint32_t nfields = 0;
+    uint64_t n = 0;
     int rc;
     if (!buf || !v) return S2M_WIRE_BAD;
     memset(v, 0, sizeof(*v));
@@ -113,9 +114,17 @@ static inline int s2m_pc2_parse(const uint8_t *buf, size_t len, s2m_pc2_view *v,
         (rc = s2m_wire_bytes(&p, end, 1, &s)))
         return rc;
     v->is_dense = *s;
-    n = v->width * v->height;
-    if (v->point_step == 0 ? n != 0 : (uint64_t)n * v->point_step > v->data_len) return S2M_WIRE_BAD;
-    v->n_points = n;
+    n = (uint64_t)v->width * (uint64_t)v->height;          /* 64-bit: width * height may not wrap */
+    if (n > 0xffffffffull) return S2M_WIRE_BAD;
+    if (v->point_step == 0 ? n != 0 : n * v->point_step > v->data_len) return S2M_WIRE_BAD;
+    {   /* every named float32 field lies inside a record: the offsets come from the message and are handed on as
+         * pointers (s2m_pc2_scan_args), so a field that sticks out of point_step would read past the blob */
+        const int32_t offs[8] = {v->off_x, v->off_y, v->off_z, v->off_normal_x, v->off_normal_y, v->off_normal_z,
+                                 v->off_intensity, v->off_curvature};
+        for (int k = 0; k < 8; ++k)
+            if (offs[k] >= 0 && (uint64_t)(uint32_t)offs[k] + 4u > (uint64_t)v->point_step) return S2M_WIRE_BAD;
+    }
+    v->n_points = (uint32_t)n;
     if (consumed) *consumed = (size_t)(p - buf);
     return S2M_WIRE_OK;
 }

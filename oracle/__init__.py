@@ -126,6 +126,17 @@ class KdTree:
             lib().orc_kdtree_free(C.c_void_p(self.h))
             self.h = None
 
+    def set_rank(self, rank):
+        """rank[i] = place of map point i in the total order that breaks ties between candidates at exactly the
+        same d2 (None = index order).  Tests pass the GPU engine's sorted position."""
+        if rank is None:
+            lib().orc_kdtree_set_rank(C.c_void_p(self.h), None)
+            return self
+        rank = np.ascontiguousarray(rank, np.uint32)
+        assert len(rank) == len(self.xyz)
+        lib().orc_kdtree_set_rank(C.c_void_p(self.h), _p(rank))
+        return self
+
     def knn5(self, q, nthreads=1):
         q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
         n = len(q)
@@ -136,15 +147,40 @@ class KdTree:
         return idx, d2, cnt
 
 
-def knn5_brute(map_xyz, q):
+def knn5_brute(map_xyz, q, rank=None):
     m = np.ascontiguousarray(map_xyz, np.float32).reshape(-1, 3)
     q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
     n = len(q)
     idx = np.empty((n, K), np.int32)
     d2 = np.empty((n, K), np.float32)
     cnt = np.empty(n, np.int32)
-    lib().orc_knn5_brute(_p(m), C.c_int64(len(m)), _p(q), C.c_int64(n), _p(idx), _p(d2), _p(cnt))
+    if rank is not None:
+        rank = np.ascontiguousarray(rank, np.uint32)
+        assert len(rank) == len(m)
+    lib().orc_knn5_brute_ranked(_p(m), C.c_int64(len(m)), _p(rank), _p(q), C.c_int64(n), _p(idx), _p(d2), _p(cnt))
     return idx, d2, cnt
+
+
+def grid_rank(map_xyz, cell, origin, cells):
+    """The GPU engine's documented point order, computed independently of it (include/daliti_s2m.h,
+    s2m_map_get_order): points sorted by (brick of 8x8x8 cells, cell within the brick, caller index), the cell of a
+    coordinate v being floor((v - origin) * (1 / cell)) in float arithmetic, clamped to the grid; bricks and the
+    cells inside a brick are numbered x fastest, then y, then z.  Returns rank[i] = sorted position of point i."""
+    p = np.ascontiguousarray(map_xyz, np.float32).reshape(-1, 3)
+    inv_c = np.float32(1.0) / np.float32(cell)
+    key = np.zeros(len(p), np.uint64)
+    c = []
+    for k in range(3):
+        v = np.floor((p[:, k] - np.float32(origin[k])) * inv_c)
+        c.append(np.clip(v, 0, cells[k] - 1).astype(np.int64))
+    nbx, nby = cells[0] // 8, cells[1] // 8
+    brick = ((c[2] >> 3) * nby + (c[1] >> 3)) * nbx + (c[0] >> 3)
+    local = (((c[2] & 7) << 3) | (c[1] & 7)) << 3 | (c[0] & 7)
+    key = (brick << 9) | local
+    order = np.argsort(key, kind="stable")
+    rank = np.empty(len(p), np.uint32)
+    rank[order] = np.arange(len(p), dtype=np.uint32)
+    return rank
 
 
 def esti_plane(nb, thr=0.1):

@@ -203,6 +203,7 @@ struct orc_kdtree {
     int64_t m;
     float *x, *y, *z;  /* points in tree order: node of range [l,r] is (l+r)>>1 */
     int32_t *orig;     /* original index of each tree-order point */
+    uint32_t *rank;    /* tie order of each tree-order point among candidates at exactly the same d2 (default: orig) */
     float *box;        /* 6 floats per node: xmin xmax ymin ymax zmin zmax of its subtree */
 };
 
@@ -214,10 +215,12 @@ static inline void kd_swap(orc_kdtree *t, int64_t a, int64_t b)
 {
     float f;
     int32_t o;
+    uint32_t r;
     f = t->x[a]; t->x[a] = t->x[b]; t->x[b] = f;
     f = t->y[a]; t->y[a] = t->y[b]; t->y[b] = f;
     f = t->z[a]; t->z[a] = t->z[b]; t->z[b] = f;
     o = t->orig[a]; t->orig[a] = t->orig[b]; t->orig[b] = o;
+    r = t->rank[a]; t->rank[a] = t->rank[b]; t->rank[b] = r;
 }
 /* nth_element on [l, r] by one coordinate (ikd_Tree.cpp:707-722) */
 static void kd_select(orc_kdtree *t, int axis, int64_t l, int64_t r, int64_t k)
@@ -276,20 +279,29 @@ orc_kdtree *orc_kdtree_build(const float *xyz, int64_t m)
     t->y = (float *)malloc(sizeof(float) * mm);
     t->z = (float *)malloc(sizeof(float) * mm);
     t->orig = (int32_t *)malloc(sizeof(int32_t) * mm);
+    t->rank = (uint32_t *)malloc(sizeof(uint32_t) * mm);
     t->box = (float *)malloc(sizeof(float) * 6 * mm);
     for (int64_t i = 0; i < m; ++i) {
         t->x[i] = xyz[3 * i + 0];
         t->y[i] = xyz[3 * i + 1];
         t->z[i] = xyz[3 * i + 2];
         t->orig[i] = (int32_t)i;
+        t->rank[i] = (uint32_t)i;
     }
     kd_build(t, 0, m - 1);
     return t;
 }
+/* rank[i] = position of original index i in the total order that breaks ties between candidates at exactly the same
+ * float d2 (a permutation of 0..m-1).  The GPU engine ranks such candidates by its sorted position -- (brick, cell,
+ * caller index), s2m_map_get_order -- which tests compute independently from s2m_map_info and hand over here. */
+void orc_kdtree_set_rank(orc_kdtree *t, const uint32_t *rank)
+{
+    for (int64_t i = 0; i < t->m; ++i) t->rank[i] = rank ? rank[t->orig[i]] : (uint32_t)t->orig[i];
+}
 void orc_kdtree_free(orc_kdtree *t)
 {
     if (!t) return;
-    free(t->x); free(t->y); free(t->z); free(t->orig); free(t->box);
+    free(t->x); free(t->y); free(t->z); free(t->orig); free(t->rank); free(t->box);
     free(t);
 }
 int64_t orc_kdtree_size(const orc_kdtree *t) { return t->m; }
@@ -297,28 +309,30 @@ int64_t orc_kdtree_size(const orc_kdtree *t) { return t->m; }
 typedef struct {
     float d2[ORC_K], x[ORC_K], y[ORC_K], z[ORC_K];
     int32_t idx[ORC_K];
+    uint32_t rank[ORC_K];
     int n;
 } top5;
 
-/* strict total order on candidates: (d2, original index).  The reference orders by d2 and breaks
- * d2 ties by x (ikd_Tree.h:102-108); which of two candidates tied at the 5th place survives there
- * depends on its traversal order.  Index order is an equally valid, layout-independent choice that
- * the GPU path reproduces with a single 64-bit compare. */
-static inline int cand_less(float d2a, int32_t ia, float d2b, int32_t ib)
+/* strict total order on candidates: (d2, rank).  The reference orders by d2 and breaks d2 ties by x
+ * (ikd_Tree.h:102-108); which of two candidates tied at the 5th place survives there depends on its
+ * traversal order.  Any fixed total order on the map points is an equally valid choice; the rank is the
+ * original index unless orc_kdtree_set_rank installed another one (the GPU engine's sorted position, which
+ * it carries in the low half of a 64-bit search key: one compare per candidate). */
+static inline int cand_less(float d2a, uint32_t ra, float d2b, uint32_t rb)
 {
     if (d2a != d2b) return d2a < d2b;
-    return ia < ib;
+    return ra < rb;
 }
-static inline void top5_offer(top5 *h, float d2, float x, float y, float z, int32_t idx)
+static inline void top5_offer(top5 *h, float d2, float x, float y, float z, int32_t idx, uint32_t rank)
 {
-    if (h->n == ORC_K && !cand_less(d2, idx, h->d2[ORC_K - 1], h->idx[ORC_K - 1])) return;
+    if (h->n == ORC_K && !cand_less(d2, rank, h->d2[ORC_K - 1], h->rank[ORC_K - 1])) return;
     int p = (h->n < ORC_K) ? h->n : ORC_K - 1;
-    while (p > 0 && cand_less(d2, idx, h->d2[p - 1], h->idx[p - 1])) {
+    while (p > 0 && cand_less(d2, rank, h->d2[p - 1], h->rank[p - 1])) {
         h->d2[p] = h->d2[p - 1]; h->x[p] = h->x[p - 1]; h->y[p] = h->y[p - 1]; h->z[p] = h->z[p - 1];
-        h->idx[p] = h->idx[p - 1];
+        h->idx[p] = h->idx[p - 1]; h->rank[p] = h->rank[p - 1];
         --p;
     }
-    h->d2[p] = d2; h->x[p] = x; h->y[p] = y; h->z[p] = z; h->idx[p] = idx;
+    h->d2[p] = d2; h->x[p] = x; h->y[p] = y; h->z[p] = z; h->idx[p] = idx; h->rank[p] = rank;
     if (h->n < ORC_K) h->n++;
 }
 /* float squared L2, ((dx*dx + dy*dy) + dz*dz)   (ikd_Tree.cpp:1682-1688) */
@@ -350,7 +364,7 @@ static void kd_search(const orc_kdtree *t, int64_t l, int64_t r, float qx, float
     if (l > r) return;
     int64_t mid = (l + r) >> 1;
     top5_offer(h, dist2f(qx, qy, qz, t->x[mid], t->y[mid], t->z[mid]), t->x[mid], t->y[mid],
-               t->z[mid], t->orig[mid]);
+               t->z[mid], t->orig[mid], t->rank[mid]);
     int64_t ll = l, lr = mid - 1, rl = mid + 1, rr = r;
     float dl = (ll <= lr) ? box_dist2f(t->box + 6 * ((ll + lr) >> 1), qx, qy, qz) : INFINITY;
     float dr = (rl <= rr) ? box_dist2f(t->box + 6 * ((rl + rr) >> 1), qx, qy, qz) : INFINITY;
@@ -386,15 +400,22 @@ void orc_knn5(const orc_kdtree *t, const float *q, int64_t n, int32_t *idx, floa
     }
 }
 
+void orc_knn5_brute_ranked(const float *xyz, int64_t m, const uint32_t *rank, const float *q, int64_t n, int32_t *idx,
+                           float *d2, int32_t *cnt);
 void orc_knn5_brute(const float *xyz, int64_t m, const float *q, int64_t n, int32_t *idx, float *d2,
                     int32_t *cnt)
+{
+    orc_knn5_brute_ranked(xyz, m, NULL, q, n, idx, d2, cnt);
+}
+void orc_knn5_brute_ranked(const float *xyz, int64_t m, const uint32_t *rank, const float *q, int64_t n, int32_t *idx,
+                           float *d2, int32_t *cnt)
 {
     for (int64_t i = 0; i < n; ++i) {
         top5 h;
         h.n = 0;
         for (int64_t j = 0; j < m; ++j)
             top5_offer(&h, dist2f(q[3 * i], q[3 * i + 1], q[3 * i + 2], xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2]),
-                       xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2], (int32_t)j);
+                       xyz[3 * j], xyz[3 * j + 1], xyz[3 * j + 2], (int32_t)j, rank ? rank[j] : (uint32_t)j);
         top5_store(&h, idx + ORC_K * i, d2 + ORC_K * i, cnt + i);
     }
 }

@@ -66,11 +66,14 @@ void orc_state_boxminus(const orc_state *a, const orc_state *b, double out[ORC_D
  * Replaces KD_TREE::Build / Nearest_Search (eskf_lio/include/ikd-Tree/ikd_Tree.cpp:408-461,
  * 678-733, 1061-1244).  Same tree shape rule (median on the longest-extent axis, one point per
  * node, per-node AABB pruning in float) and the same float squared-L2 (ikd_Tree.cpp:1682-1688).
- * Result order: ascending (d2, original index) -- the reference orders by d2 and breaks d2 ties
- * by x (ikd_Tree.h:102-108) with a traversal-dependent choice at the 5th place; the index makes
- * the order total and independent of the search structure. */
+ * Result order: ascending (d2, rank) -- the reference orders by d2 and breaks d2 ties
+ * by x (ikd_Tree.h:102-108) with a traversal-dependent choice at the 5th place; a fixed rank makes
+ * the order total and independent of the search structure.  rank = original index unless
+ * orc_kdtree_set_rank installs another permutation (tests pass the GPU engine's sorted position,
+ * computed independently from its grid parameters: (brick, cell, caller index)). */
 typedef struct orc_kdtree orc_kdtree;
 orc_kdtree *orc_kdtree_build(const float *xyz, int64_t m);   /* xyz: m x 3 floats, AoS */
+void        orc_kdtree_set_rank(orc_kdtree *t, const uint32_t *rank); /* rank[original index]; NULL = index order */
 void        orc_kdtree_free(orc_kdtree *t);
 int64_t     orc_kdtree_size(const orc_kdtree *t);
 /* queries: n x 3 floats.  idx: n x 5 (index into the caller's xyz, -1 = missing), d2: n x 5
@@ -79,6 +82,8 @@ void orc_knn5(const orc_kdtree *t, const float *q, int64_t n, int32_t *idx, floa
               int32_t *cnt, int nthreads);
 void orc_knn5_brute(const float *xyz, int64_t m, const float *q, int64_t n, int32_t *idx,
                     float *d2, int32_t *cnt);
+void orc_knn5_brute_ranked(const float *xyz, int64_t m, const uint32_t *rank, const float *q, int64_t n,
+                           int32_t *idx, float *d2, int32_t *cnt);
 
 /* ---- plane fit: esti_plane<float> (common_lib.h:267-299) -------------------------------- */
 int orc_esti_plane(const float nb[15], float thr, float pabcd[4]);

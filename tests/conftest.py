@@ -31,6 +31,16 @@ def small_tree(oracle, small_scene):
     return oracle.KdTree(small_scene["map"])
 
 
+def ranked_tree(oracle, eng, map_xyz):
+    """The oracle's k-d tree over `map_xyz` with the tie order of the GPU engine `eng` (sorted position = brick, cell,
+    caller index).  The order is computed here from the grid parameters alone (oracle.grid_rank) and must equal what
+    the engine reports -- that pins the documented order, not only consistency between the two sides."""
+    info = eng.map_info()
+    rank = oracle.grid_rank(map_xyz, info["cell"], info["origin"], eng.map_grid())
+    assert np.array_equal(rank, eng.map_rank()), "the engine's point order differs from the documented one"
+    return oracle.KdTree(map_xyz).set_rank(rank)
+
+
 def bits(a):
     """View a float array as integers so that equality is bit-exact (and NaN == NaN)."""
     a = np.ascontiguousarray(a)

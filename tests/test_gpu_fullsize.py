@@ -9,7 +9,7 @@ shard additivity, and registration accuracy against the known true pose.
 import numpy as np
 import pytest
 
-from conftest import bits
+from conftest import bits, ranked_tree
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +35,7 @@ def test_fullsize_first_pass_matches_oracle(eng3, c3, oracle):
     out = eng3.residual_pass(x, True)
     idx, d2 = eng3.get_neighbors()
     st = eng3.get_point_state()
-    tree = oracle.KdTree(c3["map"])
+    tree = ranked_tree(oracle, eng3, c3["map"])     # also pins the documented point order at 5 M points
     cfg = oracle.default_cfg(nthreads=16)
     ps = oracle.residual_pass(cfg, tree, c3["scan"], x, True, oracle.PassState(len(c3["scan"])))
     near = ps.nn_d2[:, 4] <= 5.0
@@ -110,7 +110,7 @@ def test_c1_one_iteration_matches_oracle(oracle):
     e.scan_set(c["scan"])
     got = e.iterated_update(c["x_prop"], c["x_prop"], c["P"])
     idx, d2 = e.get_neighbors()
-    tree = oracle.KdTree(c["map"])
+    tree = ranked_tree(oracle, e, c["map"])
     ref = oracle.iterated_update(oracle.default_cfg(max_iter=1), tree, c["scan"], c["x_prop"], c["x_prop"], c["P"])
     oi, od, oc = tree.knn5(oracle.body_to_world(c["x_prop"], c["scan"]))
     near = (oc == 5) & (od[:, 4] <= 5.0)
@@ -129,15 +129,50 @@ def test_c2_single_pass_matches_oracle(oracle):
     e.scan_set(c["scan"])
     out = e.residual_pass(c["x_prop"], True)
     st = e.get_point_state()
-    tree = oracle.KdTree(c["map"])
+    idx, d2 = e.get_neighbors()
+    tree = ranked_tree(oracle, e, c["map"])
     ps = oracle.residual_pass(oracle.default_cfg(nthreads=16), tree, c["scan"], c["x_prop"], True,
                               oracle.PassState(len(c["scan"])))
+    near = (ps.nn_cnt == 5) & (ps.nn_d2[:, 4] <= 5.0)
+    assert near.mean() > 0.99
+    assert (idx[near] == ps.nn_idx[near]).all() and (bits(d2[near]) == bits(ps.nn_d2[near])).all()
     assert (st["selected"] == ps.selected).all() and (st["eff"] == ps.eff).all()
     ok = ps.plane_ok.astype(bool)
     assert (bits(st["plane"][ok]) == bits(ps.plane[ok])).all() and (bits(st["pd2"][ok]) == bits(ps.pd2[ok])).all()
     assert out["effct"] == ps.effct
     assert np.abs(out["HtH"] - ps.HtH).max() <= 1e-11 * np.abs(ps.HtH).max()
     assert np.abs(out["Htz"] - ps.Htz).max() <= 1e-11 * max(np.abs(ps.Htz).max(), 1.0)
+    e.close()
+
+
+def test_c2_extrinsic_estimation_at_full_size(oracle):
+    """extrinsic_est_en = 1 at 65 536 points (C2): the 12-column rows (laserMapping.cpp:968-972) bit for bit on a
+    4 096-row sample, the 92-term block to summation order, and the whole iterated update against the oracle."""
+    from daliti_amd import Engine, synth
+    c = synth.make_config("C2")
+    x = c["x_prop"].copy()
+    x[12:21] = oracle.so3_exp([0.02, -0.01, 0.03]).ravel()     # a non-trivial extrinsic: the B, C columns matter
+    x[21:24] = [0.05, -0.02, 0.1]
+    e = Engine(max_iter=5, extrinsic_est_en=1)
+    e.map_build(c["map"])
+    e.scan_set(c["scan"])
+    out = e.residual_pass(x, True)
+    hx, h, ridx = e.get_rows()
+    tree = ranked_tree(oracle, e, c["map"])
+    cfg = oracle.default_cfg(nthreads=16, extrinsic_est_en=1, max_iter=5)
+    ps = oracle.residual_pass(cfg, tree, c["scan"], x, True, oracle.PassState(len(c["scan"])), want_rows=True)
+    assert out["effct"] == ps.effct and (ridx == np.nonzero(ps.eff)[0]).all()
+    pick = np.sort(np.random.RandomState(5).choice(ps.effct, 4096, replace=False))
+    assert (bits(hx[pick]) == bits(ps.Hsub[pick])).all() and (bits(h[pick]) == bits(ps.meas[pick])).all()
+    assert np.abs(hx[:, 6:]).max() > 0                           # the extrinsic columns are really filled
+    assert np.abs(out["HtH"] - ps.HtH).max() <= 1e-11 * np.abs(ps.HtH).max()
+    assert np.abs(out["Htz"] - ps.Htz).max() <= 1e-11 * max(np.abs(ps.Htz).max(), 1.0)
+    r = e.iterated_update(x, x, c["P"])
+    ro = oracle.iterated_update(cfg, tree, c["scan"], x, x, c["P"])
+    assert r["iters"] == ro["iters"] and (r["effct"] == ro["effct"]).all()
+    assert np.abs(r["x"] - ro["x"]).max() < 1e-9
+    assert np.abs(oracle.so3_log(ro["x"][:9].reshape(3, 3).T @ r["x"][:9].reshape(3, 3))).max() < 1e-9
+    assert np.abs(oracle.so3_log(ro["x"][12:21].reshape(3, 3).T @ r["x"][12:21].reshape(3, 3))).max() < 1e-9
     e.close()
 
 
@@ -154,7 +189,7 @@ def test_c4_sharded_scan_against_20m_map(oracle):
     idx, d2 = e.get_neighbors()
     rs = np.random.RandomState(3)
     pick = np.sort(rs.choice(len(c["scan"]), 4096, replace=False))
-    oi, od, oc = oracle.KdTree(c["map"]).knn5(oracle.body_to_world(x, c["scan"][pick]), 8)
+    oi, od, oc = ranked_tree(oracle, e, c["map"]).knn5(oracle.body_to_world(x, c["scan"][pick]), 8)
     near = (oc == 5) & (od[:, 4] <= 5.0)
     assert near.mean() > 0.95
     assert (idx[pick][near] == oi[near]).all() and (bits(d2[pick][near]) == bits(od[near])).all()
@@ -220,7 +255,7 @@ def test_r1_reference_density_matches_oracle(c3, oracle):
     out = e.residual_pass(x, True)
     idx, d2 = e.get_neighbors()
     st = e.get_point_state()
-    tree = oracle.KdTree(m)
+    tree = ranked_tree(oracle, e, m)
     ps = oracle.residual_pass(oracle.default_cfg(nthreads=16), tree, scan, x, True, oracle.PassState(n))
     near = (ps.nn_cnt == 5) & (ps.nn_d2[:, 4] <= 5.0)
     assert near.mean() > 0.5
@@ -234,12 +269,13 @@ def test_r1_reference_density_matches_oracle(c3, oracle):
     e.close()
 
 
-def test_c5_batch_call_equals_one_by_one(c3, eng3):
-    """s2m_iterated_update_batch: four C5 replicas in flight from one host thread give, scan for scan, the very
-    bits that s2m_iterated_update gives one after the other (same kernels, same launch shapes, same host solve)."""
+def test_c5_batch_call_equals_one_by_one(c3, eng3, oracle):
+    """s2m_iterated_update_batch: all eight C5 replicas (BASELINE configs[4]) in flight from one host thread -- one
+    grid per pass for all of them -- give, scan for scan, the very bits that s2m_iterated_update gives one after the
+    other (same per-point code, same partial-sum shapes, same host solve), and every one of them matches the oracle."""
     from daliti_amd import Engine, synth
     from daliti_amd.engine import IterLog
-    K = 4
+    K = 8
     engs, xs, Ps = [], [], []
     for k in range(K):
         scan, pos = synth.replica_scan("C5", k)
@@ -259,6 +295,14 @@ def test_c5_batch_call_equals_one_by_one(c3, eng3):
         assert (bits(x[k]) == bits(one[k]["x"])).all() and (bits(P[k]) == bits(one[k]["P"])).all()
     with pytest.raises(Exception):
         Engine.iterated_update_batch([engs[0], engs[0]], x[:2].copy(), xp[:2].copy(), P[:2].copy())
+    tree = oracle.KdTree(c3["map"])
+    cfg = oracle.default_cfg(max_iter=5, nthreads=16)
+    for k in range(K):
+        scan, pos = synth.replica_scan("C5", k)
+        ro = oracle.iterated_update(cfg, tree, scan, xs[k], xs[k], Ps[k])
+        assert logs[k].iters == ro["iters"] and list(logs[k].effct[:logs[k].iters]) == list(ro["effct"]), k
+        assert np.abs(x[k][9:12] - ro["x"][9:12]).max() < 1e-9
+        assert np.abs(oracle.so3_log(ro["x"][:9].reshape(3, 3).T @ x[k][:9].reshape(3, 3))).max() < 1e-9
     for e in engs:
         e.close()
 

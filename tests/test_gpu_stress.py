@@ -5,7 +5,7 @@ inside, at the rim of and far outside the map."""
 import numpy as np
 import pytest
 
-from conftest import bits
+from conftest import bits, ranked_tree
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,7 @@ def _check(oracle, m, q, cell, x=None):
     e.residual_pass(x, True)
     idx, d2 = e.get_neighbors()
     st = e.get_point_state()
-    oi, od, oc = oracle.KdTree(m).knn5(oracle.body_to_world(x, q))
+    oi, od, oc = ranked_tree(oracle, e, m).knn5(oracle.body_to_world(x, q))
     near = (oc == 5) & (od[:, 4] <= 5.0)
     assert (bits(d2[near]) == bits(od[near])).all(), "d2 mismatch at cell %g" % cell
     assert (idx[near] == oi[near]).all(), "index mismatch at cell %g" % cell
@@ -59,6 +59,34 @@ def test_tiny_and_degenerate_maps(oracle):
               rs.uniform(-1, 1, (6, 3)), np.c_[np.linspace(-1, 1, 50), np.zeros(50), np.zeros(50)]):
         for cell in (0.05, 0.5, 4.0):
             _check(oracle, m.astype(np.float32), q, cell)
+
+
+def test_exact_ties_follow_the_documented_order(oracle):
+    """A lattice map (coordinates exactly representable) and queries on lattice points, edge and cell centres: most
+    queries see several candidates at exactly the same float d2, also across the 5th place.  The engine ranks them by
+    sorted position = (brick, cell, caller index) -- s2m_map_get_order -- and the oracle, given that order computed
+    independently from the grid parameters, must return the identical lists, whatever the cell size."""
+    g = np.arange(-8, 9) * 0.25
+    m = np.stack(np.meshgrid(g, g, g[:9], indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    rs = np.random.RandomState(3)
+    m = m[rs.permutation(len(m))]                         # caller order unrelated to position
+    q = np.r_[m[:600], m[600:1200] + np.float32(0.125), m[1200:1800] + np.float32([0.125, 0.0, 0.0])].astype(np.float32)
+    tied = 0
+    for cell in (0.11, 0.5, 0.8, 0.0):
+        from daliti_amd import Engine, synth
+        e = Engine(cell_size=cell)
+        e.map_build(m)
+        e.scan_set(q)
+        e.residual_pass(synth.make_state(), True)
+        idx, d2 = e.get_neighbors()
+        oi, od, oc = ranked_tree(oracle, e, m).knn5(q)
+        assert (bits(d2) == bits(od)).all() and (idx == oi).all(), "cell %g" % cell
+        # the scene does what it is for: with the plain index order the lists differ
+        pi, pd, _ = oracle.KdTree(m).knn5(q)
+        assert (bits(pd) == bits(od)).all()
+        tied += int((pi != oi).any(axis=1).sum())
+        e.close()
+    assert tied > 100
 
 
 def test_rotated_far_pose(oracle):

@@ -4,7 +4,7 @@ sides keep different insertion orders); poses of a multi-frame run must still ag
 import numpy as np
 import pytest
 
-from conftest import bits
+from conftest import bits, ranked_tree
 
 
 def _rows(a):
@@ -198,6 +198,62 @@ def test_map_incremental_after_ekf_stop(oracle, small_scene, small_tree):
     assert e.map_size() == om.size()
     assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cell", [0.5, 0.0, 1.3])
+def test_new_territory_points_enter_the_map_like_the_reference(oracle, small_scene, cell):
+    """Scan points farther than sqrt(5) m from every map point (the sensor enters unmapped ground).  The reference's
+    Nearest_Search is unbounded (ikd_Tree.cpp:425), so Nearest_Points[i] always holds five points and map_incremental
+    decides PointNoNeedDownsample from points_near[0] (laserMapping.cpp:603).  The per-iteration search ends at the
+    gate; s2m_complete_neighbors (called by s2m_map_incremental) finishes those lists.  All lists then equal the
+    oracle's unbounded 5-NN, and both sides send the same points to the same list."""
+    from daliti_amd import Engine, synth
+    m = small_scene["map"]
+    x = synth.make_state()
+    rs = np.random.RandomState(11)
+    L = small_scene["L"]
+    near = (m[rs.choice(len(m), 1500)] + rs.normal(0, 0.05, (1500, 3))).astype(np.float32)
+    # shells around the box: 3 .. 60 m outside, all directions, some just beyond the gate radius
+    d = rs.normal(size=(900, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    far = (d * (L * 0.75 + rs.uniform(2.3, 60.0, (900, 1)))).astype(np.float32) + np.float32([0, 0, 5.0])
+    rim = (m[rs.choice(len(m), 300)] + d[:300] * rs.uniform(2.0, 2.6, (300, 1))).astype(np.float32)
+    q = np.r_[near, far, rim].astype(np.float32)
+    e = Engine(cell_size=cell)
+    e.map_build(m)
+    e.scan_set(q)
+    out = e.residual_pass(x, True)
+    tree = ranked_tree(oracle, e, m)
+    oi, od, oc = tree.knn5(q)                          # identity pose: world = body
+    assert (oc == 5).all()
+    beyond = od[:, 4] > 5.0
+    assert beyond.sum() > 600 and (~beyond).sum() > 1500
+    idx0, d0 = e.get_neighbors()
+    assert (idx0[~beyond] == oi[~beyond]).all() and (bits(d0[~beyond]) == bits(od[~beyond])).all()
+    n_short = e.complete_neighbors()
+    assert n_short >= beyond.sum()
+    idx, d2 = e.get_neighbors()
+    assert (idx == oi).all() and (bits(d2) == bits(od)).all()      # every list, however far
+    assert e.complete_neighbors() == 0                              # nothing left to do
+    st = e.get_point_state()
+    assert (st["selected"][beyond] == 0).all()                      # the gate still rejected them in the pass
+    # map_incremental: the lists of laserMapping.cpp:593-624 from the unbounded Nearest_Points, on both sides
+    e2 = Engine(cell_size=cell)
+    e2.map_build(m)
+    e2.scan_set(q)
+    e2.residual_pass(x, True)
+    na, nb = e2.map_incremental(x, 0.5)                             # completes the lists itself
+    to_add, no_down = oracle.map_incremental_lists(q, x, m[oi], oc, 0.5)
+    assert (na, nb) == (len(to_add), len(no_down))
+    assert nb > 100                                                 # new territory goes in without down-sampling
+    om = oracle.Map(m)
+    om.add(to_add, True, 0.5)
+    om.add(no_down, False)
+    assert e2.map_size() == om.size()
+    assert (bits(_rows(e2.map_points())) == bits(_rows(om.points()))).all()
+    assert out["effct"] > 0
+    e.close()
+    e2.close()
 
 
 @pytest.mark.gpu

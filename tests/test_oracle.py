@@ -43,6 +43,40 @@ def test_kdtree_ties_and_small_maps(oracle):
     assert c4[0] == 0 and (i4 == -1).all()
 
 
+def test_ranked_tie_order(oracle):
+    """orc_kdtree_set_rank: candidates at exactly the same float d2 are ordered by the installed rank (the GPU
+    engine's sorted position); tree and brute force agree under any rank, the d2 lists never depend on it, and
+    grid_rank is the documented (brick, cell, caller index) order."""
+    g = np.arange(-6, 7) * 0.25
+    m = np.stack(np.meshgrid(g, g, g[:5], indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    rs = np.random.RandomState(1)
+    m = m[rs.permutation(len(m))]
+    q = np.r_[m[:200], m[200:400] + np.float32(0.125)].astype(np.float32)
+    base_i, base_d, _ = oracle.KdTree(m).knn5(q)
+    differs = 0
+    for rank in (rs.permutation(len(m)).astype(np.uint32),
+                 oracle.grid_rank(m, 0.5, (-2.0, -2.0, -1.0), (16, 16, 8)),
+                 oracle.grid_rank(m, 0.11, (-1.7, -1.9, -0.3), (40, 40, 16))):
+        assert sorted(rank.tolist()) == list(range(len(m)))            # a permutation
+        ti, td, _ = oracle.KdTree(m).set_rank(rank).knn5(q)
+        bi, bd, _ = oracle.knn5_brute(m, q, rank)
+        assert (ti == bi).all() and (bits(td) == bits(bd)).all() and (bits(td) == bits(base_d)).all()
+        # inside a run of equal d2 the ranks ascend
+        rk = rank[ti].astype(np.int64)
+        same = td[:, 1:] == td[:, :-1]
+        assert (rk[:, 1:][same] > rk[:, :-1][same]).all()
+        differs += int((ti != base_i).any(axis=1).sum())
+    assert differs > 50                                                # the rank really decides something here
+    # back to the default
+    t = oracle.KdTree(m).set_rank(rs.permutation(len(m)).astype(np.uint32)).set_rank(None)
+    assert (t.knn5(q)[0] == base_i).all()
+    # grid_rank: stable in the caller index inside a cell, cells ordered x fastest inside a brick, bricks x fastest
+    pts = np.float32([[0.1, 0.1, 0.1], [0.6, 0.1, 0.1], [0.1, 0.6, 0.1], [0.1, 0.1, 0.6], [4.1, 0.1, 0.1],
+                      [0.2, 0.2, 0.2], [0.1, 4.1, 0.1]])
+    r = oracle.grid_rank(pts, 0.5, (0.0, 0.0, 0.0), (16, 16, 8))
+    assert list(np.argsort(r)) == [0, 5, 1, 2, 3, 4, 6]
+
+
 def test_plane_fit_matches_lstsq(oracle):
     rs = np.random.RandomState(1)
     for _ in range(200):

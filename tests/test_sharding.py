@@ -5,6 +5,8 @@ import os
 import sys
 
 import numpy as np
+
+from conftest import bits
 import pytest
 import torch
 import torch.multiprocessing as mp
@@ -149,7 +151,7 @@ def test_two_process_sharded_bench_equals_single_rank():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--config", "C1", "--steps", "3", "--warmup", "1", "--no-cpu",
+                          "--gpus", "2", "--config", "C1", "--scaling", "weak", "--steps", "3", "--warmup", "1", "--no-cpu",
                           "--backend", "gloo", "--all-on-device0"], env=env, capture_output=True, text=True,
                          timeout=900)
     assert two.returncode == 0, two.stderr[-3000:]
@@ -162,6 +164,51 @@ def test_two_process_sharded_bench_equals_single_rank():
     assert l2["n_gpus"] == 2 and l2["scaling"] == "weak"
     assert l2["config"]["scan_points_per_gpu"] * 2 == l1["config"]["scan_points_per_gpu"]
     assert np.abs(np.array(l2["final_pos"]) - np.array(l1["final_pos"])).max() < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 8])
+def test_single_process_multi_handle_update_equals_single_handle(n):
+    """s2m_iterated_update_multi: ONE scan in n shard_range pieces on n handles (here all on one GPU, sharing one map),
+    the n pinned blocks summed by the host in handle order, one fp64 update -- no collective library.  Same iterations
+    and effective counts as the single handle, pose within 1e-12 (summation order), and deterministic: a second run
+    gives the same bits."""
+    from daliti_amd import Engine, synth
+    from daliti_amd.sharding import shard_range
+    sc = synth.make_small()
+    one = Engine(max_iter=5)
+    one.map_build(sc["map"])
+    one.scan_set(sc["scan"])
+    ref = one.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
+    engs = []
+    for r in range(n):
+        lo, hi = shard_range(len(sc["scan"]), r, n)
+        e = Engine(max_iter=5)
+        e.map_share(one)
+        e.scan_set(sc["scan"][lo:hi])
+        engs.append(e)
+    runs = []
+    for _ in range(2):
+        for e in engs:
+            e.set_feat_queue(())
+        x = sc["x_prop"].copy(); P = sc["P"].copy()
+        log = Engine.iterated_update_multi(engs, x, np.ascontiguousarray(sc["x_prop"]), P)
+        runs.append((x, P, log.iters, list(log.effct[:log.iters]), log.rematch_passes))
+    x, P, iters, effct, rematch = runs[0]
+    assert iters == ref["iters"] and effct == list(ref["effct"]) and rematch == ref["rematch_passes"]
+    assert np.abs(x - ref["x"]).max() < 1e-12 and np.abs(P - ref["P"]).max() < 1e-14
+    assert (bits(runs[1][0]) == bits(x)).all() and (bits(runs[1][1]) == bits(P)).all()
+    # the shards' neighbour lists are the single handle's, piece by piece
+    ri, rd = one.get_neighbors()
+    for r, e in enumerate(engs):
+        lo, hi = shard_range(len(sc["scan"]), r, n)
+        i, d = e.get_neighbors()
+        assert (i == ri[lo:hi]).all() and (bits(d) == bits(rd[lo:hi])).all()
+    with pytest.raises(Exception):
+        Engine.iterated_update_multi([engs[0], engs[0]], x, np.ascontiguousarray(sc["x_prop"]), P)
+    for e in engs:
+        e.close()
+    one.close()
 
 
 @pytest.mark.gpu
@@ -206,19 +253,21 @@ def test_empty_first_scan():
 
 @pytest.mark.gpu
 def test_two_process_strong_scaling_bench_equals_single_rank():
-    """`--scaling strong` (BASELINE configs[3] form): ONE scan split by shard_range over two ranks (gloo on CUDA
-    tensors, both on GPU 0) registers to the same pose as one rank over the same scan."""
+    """The default for N > 1 (north star: "a single scan's points shard across GPUs"): ONE scan split by shard_range
+    over two ranks (gloo on CUDA tensors, both on GPU 0) registers to the same pose as one rank over the same scan.
+    The two ranks are started by bench.py ITSELF: `python bench.py --gpus 2` with no WORLD_SIZE in the environment --
+    the driver's single-GPU command form -- must launch them as a child process and relay rank 0's line last."""
     import json
     import subprocess
-    port = str(29900 + os.getpid() % 90)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--config", "C1", "--scaling", "strong", "--steps", "3", "--warmup", "1",
-                          "--no-cpu", "--backend", "gloo", "--all-on-device0"], env=env, capture_output=True,
-                         text=True, timeout=900)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C1", "--steps", "3",
+                          "--warmup", "1", "--no-cpu", "--backend", "gloo", "--all-on-device0"], env=env,
+                         capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-3000:]
-    l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "launching" in two.stderr and "torch.distributed.run" in two.stderr
+    assert two.stdout.rstrip().splitlines()[-1].startswith("{")          # the JSON line is the last line
+    l2 = json.loads(two.stdout.rstrip().splitlines()[-1])
+    assert "weak_scaling" in l2 and l2["weak_scaling"]["scan_points_total"] == 20000
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
                           "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
@@ -229,15 +278,47 @@ def test_two_process_strong_scaling_bench_equals_single_rank():
 
 
 def test_bench_defaults_follow_baseline_configs():
-    """CPU-side check of bench.py's argument logic: C4 defaults to strong scaling (one 131,072-point scan,
-    16,384 points per GPU at N = 8), C5 to replicas with the survey's seeds and offsets."""
+    """CPU-side check of bench.py's argument logic: N > 1 defaults to strong scaling (C4: one 131,072-point scan,
+    16,384 points per GPU at N = 8; C3: 8,192), C5 to replicas with the survey's seeds and offsets."""
     from daliti_amd import synth
     from daliti_amd.sharding import shard_range
     c4 = synth.CONFIGS["C4"]
     n = c4["beams"] * c4["az"]
     assert n == 131072 and [shard_range(n, r, 8) for r in (0, 7)] == [(0, 16384), (114688, 131072)]
+    assert shard_range(65536, 3, 8) == (24576, 32768)
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert '"strong" if a.config == "C4" else "weak"' in src and '"replicas" if a.config == "C5"' in src
+    assert 'a.scaling if a.scaling != "auto" else "strong"' in src and '"replicas" if a.config == "C5"' in src
     c5 = synth.CONFIGS["C5"]
     assert c5["replicas"] == 8 and (c5["M"], c5["beams"] * c5["az"]) == (5_000_000, 65536)
     assert [synth.replica_offset(k) for k in (0, 7)] == [-7.0, 7.0]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with N > 1 and no launcher environment (the driver's single-GPU command form with a
+    larger N) must not silently run one rank: it starts N ranks as a CHILD process -- never exec, never after touching
+    the GPU -- with a loopback rendezvous; under torch.distributed.run it does not launch again; a world size that
+    differs from --gpus is refused.  No GPU needed: only the argument logic runs here."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert "torch" not in bench.__dict__                                   # nothing GPU-side is imported at load time
+    argv = ["--gpus", "2", "--steps", "7", "--config", "C1"]
+    a = bench.parse(argv)
+    assert bench.needs_self_launch(a, {})
+    assert not bench.needs_self_launch(a, {"WORLD_SIZE": "2", "RANK": "0"})   # already under a launcher
+    assert not bench.needs_self_launch(bench.parse(["--gpus", "1"]), {})
+    assert not bench.needs_self_launch(bench.parse(["--gpus", "2", "--collective", "host"]), {})   # one process by design
+    cmd = bench.self_launch_argv(a, argv, 29511)
+    assert cmd == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                   "--master-addr", "127.0.0.1", "--master-port", "29511", os.path.join(ROOT, "bench.py")] + argv
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os.exec" not in src and "execv" not in src.replace("never exec", "")
+    assert src.index("if needs_self_launch(a, os.environ)") < src.index("import torch\n")
+    # a mismatch between --gpus and the world size is an error, not a silent single-rank run
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK")}
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr

@@ -24,6 +24,15 @@ static int check(const uint8_t *buf, size_t len)
     if (rs == 0 && v.n_points) {
         /* the offsets handed to the C ABI address floats inside one record */
         if (oa < 0 || ob < 0 || (uint32_t)(oa + 1) * 4u > v.point_step || (uint32_t)(ob + 1) * 4u > v.point_step) return 5;
+        /* ... and the pointers themselves: read what s2m_scan_set_from_raw / s2m_undistort would read of the FIRST and
+         * the LAST record (x, y, z and the two time fields) -- an offset that sticks out of the blob is an ASan report */
+        volatile float sink = 0.0f;
+        const int64_t recs[2] = {0, (int64_t)v.n_points - 1};
+        for (int r = 0; r < 2; ++r) {
+            const float *rec = pts + recs[r] * stride;
+            sink += rec[0]; sink += rec[1]; sink += rec[2]; sink += rec[oa]; sink += rec[ob];
+        }
+        (void)sink;
     }
     return 0;
 }
