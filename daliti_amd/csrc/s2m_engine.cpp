@@ -97,6 +97,14 @@ struct s2m_engine {
     uint32_t *d_dbg = nullptr;  // S2M_DEBUG_MATCH=1: per-point diagnostics of the match kernel
     bool dbg = false;
     bool nn_valid = false;
+    bool nn_complete = false;     // s2m_complete_neighbors has run on the current lists
+
+    // far-point lists, counters and queue heads shared by the scans of a batched launch; owned by the first handle of
+    // a launch group of s2m_iterated_update_batch
+    HardRec *d_brec = nullptr;
+    int64_t brec_cap = 0;          // records per list
+    uint32_t *d_bcnt = nullptr;    // two sets of {16 counter words, kQueueWords queue heads}, used alternately
+    unsigned long long bwave = 0;  // launches so far (selects the set)
 
     EskfWork work;
     Comm comm;  // attached RCCL communicator (multi-GPU form), handle == nullptr when single GPU
@@ -206,7 +214,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         m.grid = e->grid; m.pose = pose; m.gates = gates;
         m.sx = sx; m.sy = sy; m.sz = sz; m.n = n;
         m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
-        m.hard_rec = e->d_hrec; m.hard_count = e->d_hard + 3 * e->n_cap;
+        m.hard_rec = e->d_hrec; m.hard_off1 = n; m.hard_count = e->d_hard + 3 * e->n_cap;
         m.qheads = e->d_qheads;
         m.dbg = e->dbg ? e->d_dbg : nullptr;
         // Point batches per trip of the first-shell kernel (unless S2M_EASY_NB fixed it): three (24 loads in flight, 160
@@ -217,6 +225,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         if (((group >> 8) & 0xf) == 0 && ((int64_t)n * 2 > 3072 * 64 || e->in_batch)) group |= 2 << 8;
         launch_match(m, group, e->stream);  // hard_count is zero: reset by every reduce launch
         e->nn_valid = true;
+        e->nn_complete = false;
         e->rematch_pose = pose;
     }
     if (timed) S2M_HIP(e, hipEventRecord(e->ev[1], e->stream));
@@ -363,7 +372,7 @@ int s2m_destroy(s2m_engine *e)
     free_voxel(e->vox);
     free_undist(e->und);
     comm_destroy(e->comm);
-    void *ptrs[] = {e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
+    void *ptrs[] = {e->d_brec, e->d_bcnt, e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
                     e->d_nn_d2, e->d_hard, e->d_qheads, e->d_hrec, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -981,35 +990,43 @@ int s2m_complete_neighbors(s2m_engine *e, int64_t *n_completed)
     if (!e->map_ready || !e->nn_valid) return fail(e, S2M_ERR_STATE, "no rematch pass yet");
     S2M_HIP(e, hipSetDevice(e->device));
     const int n = (int)e->n;
-    if (n == 0 || e->grid.m == 0) return S2M_OK;
+    if (n == 0 || e->grid.m == 0 || e->nn_complete) return S2M_OK;
     MatchArgs m;
     m.grid = e->grid; m.pose = e->rematch_pose; m.gates = gates_of(e->cfg);
     m.sx = e->d_scan; m.sy = e->d_scan + e->n_cap; m.sz = e->d_scan + 2 * e->n_cap; m.n = n;
     m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
-    m.hard_rec = e->d_hrec; m.hard_count = e->d_hard + 3 * e->n_cap;
+    m.hard_rec = e->d_hrec; m.hard_off1 = n; m.hard_count = e->d_hard + 3 * e->n_cap;
     m.qheads = e->d_qheads;
     m.dbg = nullptr;
-    const double ext = (double)std::max(std::max(e->grid.ncx, e->grid.ncy), e->grid.ncz) * e->grid.c;
-    const double reach2 = 3.0 * ext * ext;  // squared diagonal of the grid: nothing lies farther from a point inside it
+    const double c = e->grid.c;
+    const double half_diag = 0.5 * c * std::sqrt((double)e->grid.ncx * e->grid.ncx + (double)e->grid.ncy * e->grid.ncy +
+                                                 (double)e->grid.ncz * e->grid.ncz);
     int64_t first = -1;
-    for (int round = 0; round < 24; ++round) {
+    for (int round = 0; round < 64; ++round) {
         // hard_count / qheads are zero here: every reduce launch and every round below leaves them so
         launch_collect_short(m, e->stream);
-        const uint32_t *src[1] = {m.hard_count};
-        uint32_t cnt = 0;
-        S2M_HIP(e, mail_fetch(e->mail, src, 1, &cnt, e->stream));
+        const uint32_t *src[2] = {m.hard_count, m.hard_count + 2};
+        uint32_t v[2] = {0, 0};
+        S2M_HIP(e, mail_fetch(e->mail, src, 2, v, e->stream));
+        const uint32_t cnt = v[0];
         if (first < 0) first = cnt;
         bool last = cnt == 0;
         if (!last) {
+            // the farthest of the open queries from the grid centre, plus half the grid's diagonal: a radius beyond
+            // that has seen every map point (a list still short then belongs to a map of fewer than five points)
+            float far2;
+            std::memcpy(&far2, &v[1], sizeof(far2));
+            const double reach = std::sqrt((double)far2) + half_diag + c;
             m.gates.knn_d2_gate *= 4.0f;  // radius x 2
             launch_match_hard_only(m, e->stream);
-            last = (double)m.gates.knn_d2_gate > reach2;  // the whole grid has been inside the radius
+            last = (double)m.gates.knn_d2_gate > reach * reach || !(m.gates.knn_d2_gate < 1.0e37f);
         }
         S2M_HIP(e, hipMemsetAsync(m.hard_count, 0, 4 * sizeof(uint32_t), e->stream));
         S2M_HIP(e, hipMemsetAsync(e->d_qheads, 0, kQueueWords * sizeof(uint32_t), e->stream));
         if (last) break;
     }
     S2M_HIP(e, hipGetLastError());
+    e->nn_complete = true;
     if (n_completed) *n_completed = first < 0 ? 0 : first;
     return S2M_OK;
 }
@@ -1188,10 +1205,41 @@ int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double
 // wait -- it goes round the handles, picks up whichever block has arrived, solves, and launches that handle's next
 // pass, so the kernels of different scans fill each other's latency gaps (a single scan in flight leaves the GPU
 // idle during every host turn-around and most of every latency-bound kernel).
+namespace {
+int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *x_prop, double *P, s2m_iter_log *logs);
+
+// the K scans can go through ONE grid per pass when they search the same map on the same device with the same gates
+bool batch_can_fuse(s2m_engine *const *handles, int32_t k)
+{
+    static const bool off = std::getenv("S2M_BATCH_STREAMS") != nullptr;  // A/B: the per-handle-stream form of round 2
+    if (off || k < 2) return false;
+    const s2m_engine *a = handles[0];
+    for (int i = 0; i < k; ++i) {
+        const s2m_engine *e = handles[i];
+        if (!e->map_ready || e->grid.pts != a->grid.pts || e->grid.tab != a->grid.tab || e->grid.m != a->grid.m) return false;
+        if (e->timing || e->dbg || (e->match_group & ~0xff) != 0) return false;
+        if (e->cfg.max_iter != a->cfg.max_iter || e->cfg.extrinsic_est_en != a->cfg.extrinsic_est_en ||
+            e->cfg.plane_thr != a->cfg.plane_thr || e->cfg.knn_d2_gate != a->cfg.knn_d2_gate ||
+            e->cfg.s_gate != a->cfg.s_gate || e->cfg.res_gate != a->cfg.res_gate)
+            return false;
+    }
+    return true;
+}
+}  // namespace
+
 int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, const double *x_prop, double *P,
                               s2m_iter_log *logs)
 {
     if (!handles || k < 1 || k > 256 || !x || !x_prop || !P) return S2M_ERR_ARG;
+    {
+        bool ok = true;
+        for (int i = 0; i < k && ok; ++i) {
+            ok = handles[i] != nullptr && handles[i]->scan_ready && !handles[i]->comm.handle && handles[i]->host_poll &&
+                 handles[i]->device == handles[0]->device;
+            for (int j = 0; j < i && ok; ++j) ok = handles[j] != handles[i];
+        }
+        if (ok && batch_can_fuse(handles, k)) return batch_fused(handles, k, x, x_prop, P, logs);
+    }
     struct Slot {
         IterCtl c{0, 1, 0, 0, 0, 0};
         int passes = 0;
@@ -1351,6 +1399,189 @@ int s2m_iterated_update_multi(s2m_engine *const *handles, int32_t n, double x[S2
     }
     return S2M_OK;
 }
+
+namespace {
+// One grid per pass for all scans of a launch group (s2m_kernels.h, BatchArgs).  The K scans are dealt to G groups of
+// at most kBatchMax; every group runs its scans in lock step -- pass w of all its active scans is one set of launches
+// on the group's stream -- while the host consumes the blocks as they land (one fp64 solve each) and launches the
+// group's next pass once the last of them is in.  With two groups the kernels of one cover the host turn-around of the
+// other.  Per scan the loop is exactly that of s2m_iterated_update: results are bit-identical.
+int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *x_prop, double *P, s2m_iter_log *logs)
+{
+    struct Slot {
+        IterCtl c{0, 1, 0, 0, 0, 0};
+        int passes = 0;
+        bool active = true, waiting = false;
+        unsigned long long seq = 0;
+    };
+    struct Group {
+        int first = 0, count = 0;   // slots [first, first + count)
+        int waiting = 0, active = 0;
+        s2m_engine *lead = nullptr;
+        BatchArgs args;
+    };
+    Slot slots[256];
+    Group groups[64];
+    int ng = k >= 4 ? 2 : 1;
+    while ((k + ng - 1) / ng > kBatchMax) ++ng;
+    auto xk = [&](int i) { return x + (size_t)i * S2M_STATE_DOUBLES; };
+    auto xpk = [&](int i) { return x_prop + (size_t)i * S2M_STATE_DOUBLES; };
+    auto Pk = [&](int i) { return P + (size_t)i * S2M_DIM * S2M_DIM; };
+    s2m_engine *e0 = handles[0];
+    S2M_HIP(e0, hipSetDevice(e0->device));
+    for (int g = 0, at = 0; g < ng; ++g) {
+        Group &G = groups[g];
+        G.first = at;
+        G.count = (k - at + (ng - g) - 1) / (ng - g);
+        at += G.count;
+        G.active = G.count;
+        G.lead = handles[G.first];
+        // the group's shared far-point lists: room for every scan's points in each of the two lists
+        int64_t total = 0;
+        int n_max = 0;
+        for (int i = G.first; i < G.first + G.count; ++i) {
+            total += handles[i]->n;
+            n_max = std::max<int>(n_max, (int)handles[i]->n);
+        }
+        s2m_engine *L = G.lead;
+        if (L->brec_cap < total || !L->d_brec) {
+            int rc = grow(L, &L->d_brec, 2 * total);
+            if (rc) return rc;
+            L->brec_cap = total;
+        }
+        if (!L->d_bcnt) {
+            const size_t words = 2 * (16 + kQueueWords);
+            S2M_HIP(L, hipMalloc((void **)&L->d_bcnt, words * sizeof(uint32_t)));
+            S2M_HIP(L, hipMemsetAsync(L->d_bcnt, 0, words * sizeof(uint32_t), L->stream));
+        }
+        BatchArgs &b = G.args;
+        b.grid = L->grid;
+        b.gates = gates_of(L->cfg);
+        b.k = G.count;
+        b.n_max = n_max;
+        b.hard_rec = L->d_brec;
+        b.hard_off1 = L->brec_cap;
+        for (int j = 0; j < kBatchMax; ++j) std::memset(&b.d[j], 0, sizeof(ScanDesc));
+        for (int j = 0; j < G.count; ++j) {
+            s2m_engine *e = handles[G.first + j];
+            ScanDesc &d = b.d[j];
+            d.sx = e->d_scan; d.sy = e->d_scan + e->n_cap; d.sz = e->d_scan + 2 * e->n_cap;
+            d.nn_idx = e->d_nn_idx; d.nn_d2 = e->d_nn_d2;
+            d.plane = e->d_plane; d.flags = e->d_flags; d.sel = e->d_sel; d.eff = e->d_eff; d.pd2 = e->d_pd2;
+            d.partials = e->d_partials; d.block = e->d_block; d.ticket = e->d_ticket;
+            d.host_block = e->h_block_dev;
+            d.host_flag = reinterpret_cast<unsigned long long *>(e->h_block_dev + S2M_BLOCK_DOUBLES);
+            d.n = (int32_t)e->n;
+            d.active = 1;
+            e->nn_valid = false;
+            reset_log(logs ? logs + G.first + j : nullptr, e->cfg.max_iter);
+            // the handle's own stream may still hold its scan hand-over: the group's launches go to the lead's stream
+            if (e != L && e->stream != L->stream) S2M_HIP(e, hipStreamSynchronize(e->stream));
+        }
+    }
+    // one pass of every active scan of the group: the table's poses and flags, then the launches
+    auto launch = [&](Group &G) -> int {
+        s2m_engine *L = G.lead;
+        BatchArgs &b = G.args;
+        uint32_t *set0 = L->d_bcnt, *set1 = L->d_bcnt + (16 + kQueueWords);
+        const bool odd = (L->bwave++ & 1ull) != 0;
+        b.hard_count = odd ? set1 : set0;            b.qheads = b.hard_count + 16;
+        b.hard_count_next = odd ? set0 : set1;       b.qheads_next = b.hard_count_next + 16;
+        bool any_rematch = false, any_plain = false;
+        G.waiting = 0;
+        for (int j = 0; j < G.count; ++j) {
+            const int i = G.first + j;
+            Slot &s = slots[i];
+            ScanDesc &d = b.d[j];
+            d.active = s.active ? 1 : 0;
+            if (!s.active) continue;
+            s2m_engine *e = handles[i];
+            s.c.rematch = (s.c.it == 0) || s.c.rematch_en;  // :847
+            s.passes += s.c.rematch;
+            d.rematch = s.c.rematch;
+            d.pose = pose_of(xk(i));
+            d.seq = s.seq = ++e->seq;
+            any_rematch = any_rematch || s.c.rematch;
+            any_plain = any_plain || !s.c.rematch;
+            s.waiting = true;
+            ++G.waiting;
+            e->last_rematch = s.c.rematch != 0;
+            e->last_pose = d.pose;
+            if (s.c.rematch) { e->nn_valid = true; e->nn_complete = false; e->rematch_pose = d.pose; }
+            e->pass_done = true;
+            e->timed_this_pass = false;
+        }
+        if (any_rematch) launch_match_batch(b, L->stream);
+        launch_reduce_batch(b, any_rematch, any_plain, L->stream);
+        S2M_HIP(L, hipGetLastError());
+        for (int j = 0; j < G.count; ++j) {  // (P/R)^-1 behind the launches of the first pass
+            const int i = G.first + j;
+            if (!slots[i].active || slots[i].c.it != 0) continue;
+            Mat24 Pm;
+            std::memcpy(Pm.data(), Pk(i), sizeof(double) * S2M_DIM * S2M_DIM);
+            EskfParams prm;
+            prm.laser_point_cov = handles[i]->cfg.laser_point_cov;
+            (void)eskf_prepare(prm, Pm, handles[i]->work);
+        }
+        return S2M_OK;
+    };
+    for (int g = 0; g < ng; ++g) {
+        int rc = launch(groups[g]);
+        if (rc) return rc;
+    }
+    int groups_left = ng;
+    long idle_spins = 0;
+    while (groups_left > 0) {
+        bool progress = false;
+        for (int g = 0; g < ng; ++g) {
+            Group &G = groups[g];
+            if (G.active == 0) continue;
+            for (int j = 0; j < G.count; ++j) {
+                const int i = G.first + j;
+                Slot &s = slots[i];
+                if (!s.waiting) continue;
+                s2m_engine *e = handles[i];
+                volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(e->h_block + S2M_BLOCK_DOUBLES);
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != s.seq) continue;
+                progress = true;
+                s.waiting = false;
+                --G.waiting;
+                bool finished = false;
+                int rc = consume_block(e, e->h_block, s.c, xk(i), xpk(i), Pk(i), logs ? logs + i : nullptr, finished, nullptr);
+                if (rc) return rc;
+                ++s.c.it;
+                if (finished) {
+                    s.active = false;
+                    --G.active;
+                    if (logs) {
+                        logs[i].iters = s.c.it;
+                        logs[i].rematch_passes = s.passes;
+                        logs[i].converged = s.c.conv;
+                        logs[i].ekf_stop = s.c.stop;
+                    }
+                }
+            }
+            if (G.waiting == 0) {
+                if (G.active > 0) {
+                    int rc = launch(G);
+                    if (rc) return rc;
+                } else {
+                    --groups_left;
+                    G.active = 0;
+                    G.waiting = -1;  // done: never looked at again
+                }
+            }
+        }
+        if (progress) { idle_spins = 0; continue; }
+        __builtin_ia32_pause();
+        if (++idle_spins > 200000000L) {  // a kernel failed: let the runtime say which
+            for (int g = 0; g < ng; ++g) S2M_HIP(groups[g].lead, hipStreamSynchronize(groups[g].lead->stream));
+            return fail(handles[0], S2M_ERR_HIP, "s2m_iterated_update_batch: a pass did not publish its block");
+        }
+    }
+    return S2M_OK;
+}
+}  // namespace
 
 int s2m_comm_unique_id(uint8_t id[S2M_COMM_ID_BYTES])
 {

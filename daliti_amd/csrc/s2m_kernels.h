@@ -175,7 +175,8 @@ struct HardRec {
     uint32_t qi;        // scan point
     float d5;           // squared distance of the first shell's 5th neighbour (valid when found == 5)
     uint32_t found;     // neighbours the first shell held (0 = empty shell, 5 = radius known)
-    uint32_t pad[2];
+    uint32_t slot;      // scan of a batched launch (0 otherwise)
+    uint32_t pad;
 };
 static_assert(sizeof(HardRec) == 32, "HardRec is two 16-byte loads");
 struct MatchArgs {
@@ -186,7 +187,9 @@ struct MatchArgs {
     int n;
     int32_t *nn_idx;     // n x 5, sorted position of the neighbour in Grid::pts, -1 = missing
     float *nn_d2;        // n x 5 ascending, INFINITY = missing
-    HardRec *hard_rec;   // 2 x n records of scratch: the points the first-shell kernel could not resolve, without / with a radius
+    HardRec *hard_rec;   // records of scratch: the points the first-shell kernel could not resolve, without / with a radius
+    int64_t hard_off1 = 0;  // where the second list (radius known) starts inside hard_rec (n for one scan; the sum of all scans' n in a batch)
+    uint32_t slot = 0;   // which scan of a batched launch this is (travels in the record so that match_hard finds the outputs)
     uint32_t *hard_count; // the two lengths (device counters, reset by every reduce launch)
     uint32_t *qheads = nullptr;  // kQueueShards dequeue heads of match_hard's work queue, kQueueStride words apart
     uint32_t *dbg = nullptr;  // optional diagnostics, 4 words per scan point
@@ -228,6 +231,50 @@ struct ReduceArgs {
     unsigned long long *host_flag;   // optional: set to seq (system scope) after host_block is written
     unsigned long long seq;
 };
+// ---- one grid for K scans (s2m_iterated_update_batch, BASELINE configs[4] on one device) -----------------------
+// Every pass of the K scans that are ready is ONE launch per kernel: blockIdx.y selects the scan, whose pose, flags
+// and buffers sit in a table that travels in the kernel arguments (K <= 8 per launch: 2.9 KB of the 4 KB a launch may
+// carry); the far points of all scans share one list and one set of queue heads, so the resident waves of match_hard
+// balance over 8x the points.  The per-point code and the partial-sum shapes are those of the single-scan kernels:
+// results are bit-identical to s2m_iterated_update.
+constexpr int kBatchMax = 8;
+struct ScanDesc {
+    Pose pose;
+    const float *sx, *sy, *sz;
+    int32_t *nn_idx;
+    float *nn_d2;
+    float4 *plane;
+    uint8_t *flags, *sel, *eff;
+    float *pd2;
+    double *partials, *block;
+    uint32_t *ticket;
+    double *host_block;
+    unsigned long long *host_flag;
+    unsigned long long seq;
+    int32_t n;
+    int32_t rematch;   // this pass runs the search (and the plane fit) for this scan
+    int32_t active;    // 0: the scan has finished (or is not part of this launch)
+    int32_t pad;
+};
+struct BatchArgs {
+    Grid grid;
+    Gates gates;
+    int32_t k;
+    int32_t n_max;               // largest n of the table (grid size of the per-point kernels)
+    HardRec *hard_rec;           // unified far-point lists of all scans: [no radius | radius known], hard_off1 apart
+    int64_t hard_off1;
+    uint32_t *hard_count;        // this launch's counters / queue heads ...
+    uint32_t *qheads;
+    uint32_t *hard_count_next;   // ... and the other set, which the reduce kernels zero for the next launch
+    uint32_t *qheads_next;
+    ScanDesc d[kBatchMax];
+};
+static_assert(sizeof(BatchArgs) <= 4096, "the table must fit the kernel-argument segment");
+// the kernels of one pass for the active scans of the table: search (for the scans with rematch set), then the reduce
+// kernels (FIT for the rematching scans, plain for the others: the host issues whichever the table needs)
+void launch_match_batch(const BatchArgs &b, hipStream_t st);
+void launch_reduce_batch(const BatchArgs &b, bool any_fit, bool any_plain, hipStream_t st);
+
 int reduce_blocks(int n);
 int rows_blocks(int n);
 void launch_publish(const double *block, double *host_block, unsigned long long *host_flag, unsigned long long seq,

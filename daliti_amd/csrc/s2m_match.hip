@@ -461,9 +461,9 @@ __global__ __launch_bounds__(256) void match_easy(MatchArgs a)
         uint32_t found = 0;
 #pragma unroll
         for (int k = 0; k < kK; ++k) found += is_empty(best[k]) ? 0u : 1u;
-        const HardRec rec = {q.wx, q.wy, q.wz, (uint32_t)qi, d5, found, {0u, 0u}};
+        const HardRec rec = {q.wx, q.wy, q.wz, (uint32_t)qi, d5, found, a.slot, 0u};
         append_rec(a.hard_rec, a.hard_count, j == 0 && !done && !found5, rec);
-        append_rec(a.hard_rec + (int64_t)a.n, a.hard_count + 1, j == 0 && !done && found5, rec);
+        append_rec(a.hard_rec + a.hard_off1, a.hard_count + 1, j == 0 && !done && found5, rec);
     }
     if (j == 0) {
         // unresolved points keep their first-shell list too: match_hard takes its radius from it, and its
@@ -563,9 +563,8 @@ struct RunCursor {
 #endif
 
 template <int G, bool WIDE, int NB>
-__global__ __launch_bounds__(256) void match_rows(MatchArgs a)
+__device__ __forceinline__ void match_rows_body(const MatchArgs &a, uint2 *__restrict__ runs)
 {
-    __shared__ uint2 runs[kRunSlots * 256];  // [slot][thread]: conflict-free whatever the per-lane fill
     const long long t0 = a.dbg ? wall_clock64() : 0;
 #ifdef S2M_EXP_ROWS_TIMELINE
     long long st_[4] = {0, 0, 0, 0};
@@ -714,9 +713,9 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
         uint32_t found = 0;
 #pragma unroll
         for (int k = 0; k < kK; ++k) found += is_empty(best[k]) ? 0u : 1u;
-        const HardRec rec = {q.wx, q.wy, q.wz, (uint32_t)qi, d5, found, {0u, 0u}};
+        const HardRec rec = {q.wx, q.wy, q.wz, (uint32_t)qi, d5, found, a.slot, 0u};
         append_rec(a.hard_rec, a.hard_count, j == 0 && !done && !found5, rec);
-        append_rec(a.hard_rec + (int64_t)a.n, a.hard_count + 1, j == 0 && !done && found5, rec);
+        append_rec(a.hard_rec + a.hard_off1, a.hard_count + 1, j == 0 && !done && found5, rec);
     }
     if (j == 0) {
         store_result(best, qi, a.nn_idx, a.nn_d2);
@@ -734,6 +733,36 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
     }
 }
 
+template <int G, bool WIDE, int NB>
+__global__ __launch_bounds__(256) void match_rows(MatchArgs a)
+{
+    __shared__ uint2 runs[kRunSlots * 256];  // [slot][thread]: conflict-free whatever the per-lane fill
+    match_rows_body<G, WIDE, NB>(a, runs);
+}
+
+// the search arguments of scan blockIdx.y of a batched launch (everything uniform: scalar loads from the table)
+__device__ __forceinline__ MatchArgs batch_match_args(const BatchArgs &b, uint32_t slot)
+{
+    const ScanDesc &d = b.d[slot];
+    MatchArgs m;
+    m.grid = b.grid; m.pose = d.pose; m.gates = b.gates;
+    m.sx = d.sx; m.sy = d.sy; m.sz = d.sz; m.n = d.n;
+    m.nn_idx = d.nn_idx; m.nn_d2 = d.nn_d2;
+    m.hard_rec = b.hard_rec; m.hard_off1 = b.hard_off1; m.slot = slot;
+    m.hard_count = b.hard_count; m.qheads = b.qheads; m.dbg = nullptr;
+    return m;
+}
+// K scans, one grid: blockIdx.y = scan.  The scans that do not search in this pass leave at once.
+template <int G, bool WIDE, int NB>
+__global__ __launch_bounds__(256) void match_rows_batch(BatchArgs b)
+{
+    __shared__ uint2 runs[kRunSlots * 256];
+    const ScanDesc &d = b.d[blockIdx.y];
+    if (!d.active || !d.rematch) return;
+    const MatchArgs a = batch_match_args(b, blockIdx.y);
+    match_rows_body<G, WIDE, NB>(a, runs);
+}
+
 // one atomic per wave for a list append: same-address atomics serialise in L2 (~90 per microsecond), ten thousand
 // per-lane atomics would cost > 100 us
 __device__ __forceinline__ void append_rec(HardRec *__restrict__ list, uint32_t *__restrict__ counter, bool want,
@@ -749,7 +778,7 @@ __device__ __forceinline__ void append_rec(HardRec *__restrict__ list, uint32_t 
     if (want) {
         uint4 *dst = reinterpret_cast<uint4 *>(list + (base + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull))));
         dst[0] = make_uint4(__float_as_uint(rec.wx), __float_as_uint(rec.wy), __float_as_uint(rec.wz), rec.qi);
-        dst[1] = make_uint4(__float_as_uint(rec.d5), rec.found, 0u, 0u);
+        dst[1] = make_uint4(__float_as_uint(rec.d5), rec.found, rec.slot, 0u);
     }
 }
 
@@ -797,13 +826,13 @@ constexpr int kPairSlots = 6;  // (brick,row) pairs a lane can hold per chunk of
 // five points, so the brick neighbourhood is intersected with the grid per point (a 100 m radius would otherwise
 // enumerate millions of bricks that do not exist); the per-iteration instantiation keeps the unclamped cube, whose
 // lane -> brick mapping is computed once per wave.
-template <bool WIDE, bool FAR = false>
-__global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
+constexpr int kMaxCells = 1024;  // an append adds at most 64 rows x 8 cells
+// `out(slot, idx, d2)` names the neighbour arrays of the scan a record belongs to: the launch's own arrays for one scan,
+// a look-up in the table for a batched launch
+template <bool WIDE, bool FAR, class Out>
+__device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__restrict__ cells, Out &&out)
 {
     constexpr int G = 64;
-    constexpr int kMaxCells = 1024;  // an append adds at most 64 rows x 8 cells
-    __shared__ uint2 cells_all[4][kMaxCells];  // one cell list per wave of the workgroup
-    uint2 *cells = cells_all[threadIdx.x >> 6];
     const Grid &g = a.grid;
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -830,7 +859,7 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
     while (h < count) {
         const long long t0 = a.dbg ? wall_clock64() : 0;
         // the point's record: query, index, and the radius when the first shell found five (then one round is exact)
-        const uint4 *rp = reinterpret_cast<const uint4 *>(h < c0 ? a.hard_rec + h : a.hard_rec + ((int64_t)a.n + (h - c0)));
+        const uint4 *rp = reinterpret_cast<const uint4 *>(h < c0 ? a.hard_rec + h : a.hard_rec + (a.hard_off1 + (h - c0)));
         const uint4 r0 = rp[0], r1 = rp[1];
         const int qi = (int)r0.w;
         const Query q = query_at(g, __uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
@@ -1045,7 +1074,10 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
             for (int k = 0; k < kK; ++k) t[k] = kEmptyKey;
         }
         if (lane == 0) {
-            store_result(best, qi, a.nn_idx, a.nn_d2);
+            int32_t *o_idx;
+            float *o_d2;
+            out(r1.z, o_idx, o_d2);
+            store_result(best, qi, o_idx, o_d2);
             if (a.dbg) {
                 a.dbg[4 * (int64_t)qi + 0] += (uint32_t)(wall_clock64() - t0);
                 a.dbg[4 * (int64_t)qi + 2] = (uint32_t)t0;  // absolute start tick (100 MHz) of the hard part
@@ -1062,6 +1094,34 @@ __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
             h += (uint32_t)nwaves;
         }
     }
+}
+
+template <bool WIDE, bool FAR = false>
+__global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
+{
+    __shared__ uint2 cells_all[4][kMaxCells];  // one cell list per wave of the workgroup
+    match_hard_body<WIDE, FAR>(a, cells_all[threadIdx.x >> 6], [&](uint32_t, int32_t *&idx, float *&d2) {
+        idx = a.nn_idx;
+        d2 = a.nn_d2;
+    });
+}
+
+// the far points of ALL scans of a batched launch, from one list through one set of queue heads
+template <bool WIDE>
+__global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard_batch(BatchArgs b)
+{
+    __shared__ uint2 cells_all[4][kMaxCells];
+    MatchArgs a;
+    a.grid = b.grid; a.gates = b.gates;
+    a.sx = a.sy = a.sz = nullptr; a.n = b.n_max;
+    a.nn_idx = nullptr; a.nn_d2 = nullptr;
+    a.hard_rec = b.hard_rec; a.hard_off1 = b.hard_off1; a.slot = 0;
+    a.hard_count = b.hard_count; a.qheads = b.qheads; a.dbg = nullptr;
+    match_hard_body<WIDE, false>(a, cells_all[threadIdx.x >> 6], [&](uint32_t slot, int32_t *&idx, float *&d2) {
+        const uint32_t s_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);  // one point per wave: uniform
+        idx = b.d[s_].nn_idx;
+        d2 = b.d[s_].nn_d2;
+    });
 }
 
 template <int G>
@@ -1085,6 +1145,20 @@ static void launch_easy(const MatchArgs &a, bool wide, bool cells, int nb, hipSt
     }
 }
 
+// maximum over the ACTIVE lanes of the wave (cold path: plain shuffles; inactive lanes contribute 0)
+__device__ __forceinline__ uint32_t wave_max_u32_slow(uint32_t v)
+{
+    const unsigned long long act = __ballot(1);
+    uint32_t m = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int src = (int)(threadIdx.x & 63) ^ off;
+        const uint32_t o = (uint32_t)__shfl((int)m, src, 64);
+        if ((act >> src) & 1ull) m = max(m, o);
+    }
+    return m;
+}
+
 // ---- completion of the lists that ended short at the gate (s2m_complete_neighbors) -------------------------
 // A list is the exact, final answer when it holds five neighbours whose 5th distance is inside the radius the search
 // was allowed (a.gates.knn_d2_gate: the gate, or the larger radius of the last completion round) -- both search
@@ -1095,11 +1169,21 @@ __global__ __launch_bounds__(256) void collect_short_kernel(MatchArgs a)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool want = false;
-    HardRec rec = {0.f, 0.f, 0.f, 0u, 0.f, 0u, {0u, 0u}};
+    HardRec rec = {0.f, 0.f, 0.f, 0u, 0.f, 0u, 0u, 0u};
     if (i < a.n && !(a.nn_idx[(int64_t)i * kK + (kK - 1)] >= 0 && a.nn_d2[(int64_t)i * kK + (kK - 1)] <= a.gates.knn_d2_gate)) {
-        want = true;
         body_to_world(a.pose, a.sx[i], a.sy[i], a.sz[i], rec.wx, rec.wy, rec.wz);
         rec.qi = (uint32_t)i;
+        // squared distance to the centre of the grid: the host derives from its maximum the radius at which every
+        // map point has been seen (a query may lie far outside the grid).  A non-finite query can have no neighbours:
+        // it is left as it is.
+        const Grid &g = a.grid;
+        const float cx = g.ox + 0.5f * (float)g.ncx * g.c, cy = g.oy + 0.5f * (float)g.ncy * g.c, cz = g.oz + 0.5f * (float)g.ncz * g.c;
+        const float d2c = ((rec.wx - cx) * (rec.wx - cx) + (rec.wy - cy) * (rec.wy - cy)) + (rec.wz - cz) * (rec.wz - cz);
+        want = d2c < 3.0e38f;  // false for NaN and +inf
+        if (want) {
+            uint32_t mx = wave_max_u32_slow(__float_as_uint(d2c));
+            if ((threadIdx.x & 63) == 0) atomicMax(a.hard_count + 2, mx);
+        }
     }
     append_rec(a.hard_rec, a.hard_count, want, rec);
 }
@@ -1130,6 +1214,20 @@ void launch_match_hard_only(const MatchArgs &a, hipStream_t st)
     const int blocks = (int)((groups * 64 + 255) / 256);
     if (!wide) hipLaunchKernelGGL((match_hard<false, true>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((match_hard<true, true>), dim3(blocks), dim3(256), 0, st, a);
+}
+
+// search kernels of one batched pass (G = 2 lanes per point, two point batches per trip: the chip is shared by K scans)
+void launch_match_batch(const BatchArgs &b, hipStream_t st)
+{
+    if (b.n_max <= 0 || b.k <= 0) return;
+    const bool wide = b.grid.sent_off == 0 && b.grid.m != 0;
+    const int64_t threads = (int64_t)b.n_max * 2;
+    const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)b.k);
+    if (!wide) hipLaunchKernelGGL((match_rows_batch<2, false, 2>), grid, dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((match_rows_batch<2, true, 2>), grid, dim3(256), 0, st, b);
+    const int blocks = 1024 * S2M_HARD_OCC * 64 / 256;  // the resident waves; the rest of the list comes through the heads
+    if (!wide) hipLaunchKernelGGL(match_hard_batch<false>, dim3(blocks), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL(match_hard_batch<true>, dim3(blocks), dim3(256), 0, st, b);
 }
 
 void launch_match(const MatchArgs &a, int group, hipStream_t st)

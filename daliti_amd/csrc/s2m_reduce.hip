@@ -184,8 +184,10 @@ __device__ __forceinline__ void pin(T &v)
 #define S2M_STAMP(k) do { } while (0)
 #endif
 
+// bx / nblk: this workgroup's index among the workgroups of ITS scan and their number (blockIdx.x / gridDim.x for one
+// scan per launch; in a batched launch the grid is sized for the largest scan)
 template <bool EXT, bool FIT>
-__global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
+__device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t bx, const uint32_t nblk)
 {
 #ifdef S2M_EXP_REDUCE_TIMELINE
     long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
     constexpr int NC = EXT ? 12 : 6;
     using T = Terms<NC>;
     __shared__ double red[kRedBlock / 64][T::kSlots];
-    const int i = blockIdx.x * kRedBlock + threadIdx.x;
+    const int i = (int)bx * kRedBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
     bool eff = false;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < kRedBlock / 64; ++w) s += red[w][t];
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.partials) + (int64_t)blockIdx.x * T::kSlots + t,
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.partials) + (int64_t)bx * T::kSlots + t,
                            (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
@@ -311,9 +313,9 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
         // Two-level arrival count: same-address atomics serialise in L2 (~11 ns each), so 128 workgroups on
         // one counter keep the last one waiting 1.4 us.  Sixteen group counters on separate cache lines take
         // the arrivals in parallel; the last of each group takes the top-level ticket.
-        const uint32_t groups = min(gridDim.x, (uint32_t)kTicketGroups);
-        const uint32_t grp = blockIdx.x % groups;
-        const uint32_t gsize = (gridDim.x - grp + groups - 1) / groups;
+        const uint32_t groups = min(nblk, (uint32_t)kTicketGroups);
+        const uint32_t grp = bx % groups;
+        const uint32_t gsize = (nblk - grp + groups - 1) / groups;
         uint32_t *gt = a.ticket + kTicketStride * (1 + grp);
         uint32_t last = 0;
         if (__hip_atomic_fetch_add(gt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) {
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
     constexpr int kDepth = 8;                       // independent loads in flight per lane
     __shared__ double part[kChunks][T::kSlots];
     __shared__ double tot[T::kSlots];
-    const int blocks = gridDim.x;
+    const int blocks = (int)nblk;
     if (threadIdx.x < kChunks * T::kSlots) {
         const int t = threadIdx.x % T::kSlots, ch = threadIdx.x / T::kSlots;
         const unsigned long long *pp = reinterpret_cast<const unsigned long long *>(a.partials) + t;
@@ -395,6 +397,49 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
         a.block[159] = (double)hi;
     }
 #endif
+}
+
+template <bool EXT, bool FIT>
+__global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
+{
+    reduce_body<EXT, FIT>(a, blockIdx.x, gridDim.x);
+}
+
+// K scans, one grid: blockIdx.y = scan; FIT serves the scans that searched in this pass, the plain form the others
+// (two launches when a pass holds both kinds).  Same per-point code, same workgroup -> points mapping and the same
+// fixed-order final sum per scan as the single-scan kernel: every scan's block is bit-identical to what
+// s2m_iterated_update produces.  The last workgroup of every scan also zeroes the OTHER set of far-point counters and
+// queue heads (the set the next launch will use; the current one may still be read by nobody -- match_hard is done --
+// but the next launch's search kernels must find theirs zero).
+template <bool EXT, bool FIT>
+__global__ __launch_bounds__(kRedBlock) void reduce_kernel_batch(BatchArgs b)
+{
+    const ScanDesc &d = b.d[blockIdx.y];
+    if (!d.active || (d.rematch != 0) != FIT) return;
+    const uint32_t nblk = (uint32_t)max((d.n + kRedBlock - 1) / kRedBlock, 1);
+    if (blockIdx.x >= nblk) return;
+    ReduceArgs a;
+    a.pose = d.pose; a.gates = b.gates;
+    a.sx = d.sx; a.sy = d.sy; a.sz = d.sz; a.n = d.n;
+    a.fit = FIT ? 1 : 0;
+    a.nn_idx = d.nn_idx; a.nn_d2 = d.nn_d2; a.pts = b.grid.pts;
+    a.plane = d.plane; a.flags = d.flags; a.sel = d.sel; a.eff = d.eff; a.pd2 = d.pd2;
+    a.partials = d.partials; a.block = d.block; a.ticket = d.ticket;
+    a.hard_count = b.hard_count_next; a.qheads = b.qheads_next;
+    a.host_block = d.host_block; a.host_flag = d.host_flag; a.seq = d.seq;
+    reduce_body<EXT, FIT>(a, blockIdx.x, nblk);
+}
+
+void launch_reduce_batch(const BatchArgs &b, bool any_fit, bool any_plain, hipStream_t st)
+{
+    const dim3 grid((unsigned)std::max(reduce_blocks(b.n_max), 1), (unsigned)b.k);
+    if (b.gates.extrinsic) {
+        if (any_fit) hipLaunchKernelGGL((reduce_kernel_batch<true, true>), grid, dim3(kRedBlock), 0, st, b);
+        if (any_plain) hipLaunchKernelGGL((reduce_kernel_batch<true, false>), grid, dim3(kRedBlock), 0, st, b);
+    } else {
+        if (any_fit) hipLaunchKernelGGL((reduce_kernel_batch<false, true>), grid, dim3(kRedBlock), 0, st, b);
+        if (any_plain) hipLaunchKernelGGL((reduce_kernel_batch<false, false>), grid, dim3(kRedBlock), 0, st, b);
+    }
 }
 
 // after a collective: copy the summed block to pinned host memory and raise the sequence flag
