@@ -176,9 +176,10 @@ class CLoop:
 
     def run(self, steps):
         it, rm = C.c_int64(0), C.c_int64(0)
+        self.step_us = np.zeros(max(steps, 1))
         rc = self.fn(self.hs, C.c_int32(self.k), C.c_int32(steps), C.c_int32(self.step0), C.c_int32(self.mode),
                      C.c_void_p(self.xp.ctypes.data), C.c_void_p(self.P0.ctypes.data), C.c_void_p(self.x.ctypes.data),
-                     C.c_void_p(self.P.ctypes.data), self.logs, C.byref(it), C.byref(rm))
+                     C.c_void_p(self.P.ctypes.data), self.logs, C.byref(it), C.byref(rm), C.c_void_p(self.step_us.ctypes.data))
         self.step0 += steps
         if rc != 0:
             msgs = [e.lib.s2m_last_error(e.h).decode() for e in self.engs]
@@ -433,7 +434,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         for d in owners:
-            torch.cuda.synchronize(d)
+            if d != torch.cuda.current_device():
+                torch.cuda.synchronize(d)
 
     def timed(steps):
         """EXACTLY `steps` steps between barrier + synchronise on both sides; MAX over ranks."""
@@ -451,9 +453,14 @@ def main():
             dt = float(t.item())
         return dt, it, rm
 
+    # the box's own copy peak (second denominator of the roofline): measured here, before the timed region, because it
+    # is independent of it and because ~40 ms of streaming copies also bring the device clocks up -- with the driver's
+    # --steps 20 --warmup 5 the whole timed region is 3 ms and would otherwise run on a chip that has just left idle
+    copy_peak = measured_copy_peak(torch) if (rank == 0 and not a.no_cpu) else None  # --no-cpu: no side legs
     run_steps(a.warmup)
     dt, iters, rematch = timed(a.steps)
     res = result()
+    step_us = getattr(cl, "step_us", None) if not (use_callback or a.py_loop) else None
     # ---- HIP-event samples: a separate, untimed loop (every pass timed; three event records + a sync each) ----
     for e in engs:
         e.set_timing(1)
@@ -528,8 +535,17 @@ def main():
         "final_pos": [float(v) for v in res["x"][9:12]],
         "map_build_s": t_build,
         "timed_loop": timed_loop,
+        "timed_region_ms": 1e3 * dt,
         "host_inverse_per_step": "included (P perturbed in its last bit every step: the (P/R)^-1 cache misses once per scan)",
     }
+    if step_us is not None and len(step_us) == a.steps and a.steps > 0:
+        # the steps as the C++ loop saw them (one steady-clock read per step): separates the steps themselves from the
+        # fixed cost of the bracket (two device synchronisations + the ctypes call), which a 20-step run spreads over 3 ms
+        out["step_times"] = {"mean_ms": float(step_us.mean() * 1e-3), "median_ms": float(np.median(step_us) * 1e-3),
+                             "max_ms": float(step_us.max() * 1e-3), "first_ms": float(step_us[0] * 1e-3),
+                             "bracket_overhead_ms": float(1e3 * dt - step_us.sum() * 1e-3),
+                             "note": "host steady clock inside tools/bench_loop.cpp; ms_per_step above is the "
+                                     "bracketed wall time / steps and includes bracket_overhead_ms / steps"}
     # ---- rooflines (handle 0's scan; HIP events on the engine's stream, the separate sampling loop) ----------
     n0 = len(scans[0][0]) if a.config != "R1" else eng.n
     single = world == 1 and not host_multi and len(scans) == 1
@@ -539,7 +555,6 @@ def main():
         ms = ms_match + ms_fit
         achieved = n0 * BYTES_REMATCH / (ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic() if (a.config == "C3" and single) else (None, None)
-        copy_peak = measured_copy_peak(torch) if (rank == 0 and not a.no_cpu) else None  # --no-cpu: no side legs
         out["roofline"] = {
             "kernel": "rematch pass = match_rows + match_hard (exact 5-NN on the brick grid) + reduce_kernel<FIT> "
                       "(neighbour gate, plane fit, residual, Jacobian row, normal block)",

@@ -190,6 +190,23 @@ def esti_plane(nb, thr=0.1):
     return bool(ok), out
 
 
+def esti_plane_qr(nb, thr=0.1):
+    """(ok, pabcd, perm, rdiag, rank) of the column-pivoted Householder QR behind the fit."""
+    nb = np.ascontiguousarray(nb, np.float32).reshape(15)
+    out = np.zeros(4, np.float32)
+    perm = np.zeros(3, np.int32)
+    rdiag = np.zeros(3, np.float32)
+    rank = C.c_int32(0)
+    ok = lib().orc_esti_plane_qr(_p(nb), C.c_float(thr), _p(out), _p(perm), _p(rdiag), C.byref(rank))
+    return bool(ok), out, perm, rdiag, rank.value
+
+
+def set_sum_order(mask):
+    """Test instrument: evaluate the assumed Eigen reductions as halving trees (bit 0: 3-term double dot products,
+    bit 1: normvec.norm(), bit 2: QR column norms).  0 = the default left-to-right order the product follows."""
+    lib().orc_set_sum_order(C.c_int(int(mask)))
+
+
 def body_to_world(x, pb):
     x = np.ascontiguousarray(x, float)
     pb = np.ascontiguousarray(pb, np.float32).reshape(-1, 3)

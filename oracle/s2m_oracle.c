@@ -58,16 +58,35 @@ static void mat3_tmul(const double A[9], const double B[9], double C[9]) /* A^T 
                            A[2 * 3 + i] * B[2 * 3 + j];
     memcpy(C, T, sizeof(T));
 }
+/* ---- ASSUMED evaluation orders (parity unpinned) ------------------------------------------------------------
+ * Three kinds of sums on the per-point path are Eigen fixed-size reductions whose order is decided inside Eigen
+ * (3.3.7's Redux.h / ProductEvaluators.h), which is not installed here: the default below is left to right
+ * ((a0 + a1) + a2); Eigen's non-vectorised complete unroller (redux_novec_unroller) is a halving tree
+ * (a0 + (a1 + a2) for three terms, (a0 + a1) + (a2 + (a3 + a4)) for five).  orc_set_sum_order switches each kind to
+ * the tree form so that tests can MEASURE how many gates the unverifiable choice can flip
+ * (tests/test_oracle.py::test_assumed_summation_orders_flip_no_gate); the product follows the default.
+ *   bit 0: the 3-term double dot products of rot_end * (R_L_I * p + T_L_I), rot_end^T * n, (. ) * C
+ *          (laserMapping.cpp:836, 954, 966-971)
+ *   bit 1: normvec.norm() of esti_plane (common_lib.h:285), three floats
+ *   bit 2: the column norms of colPivHouseholderQr (colwise().norm(), five floats; common_lib.h:283) */
+static int g_sum_order = 0;
+void orc_set_sum_order(int mask) { g_sum_order = mask; }
+int orc_get_sum_order(void) { return g_sum_order; }
+static inline double dot3(double a0, double b0, double a1, double b1, double a2, double b2)
+{
+    if (g_sum_order & 1) return a0 * b0 + (a1 * b1 + a2 * b2);
+    return a0 * b0 + a1 * b1 + a2 * b2;
+}
 static void mat3_vec(const double A[9], const double v[3], double o[3])
 {
     double t[3];
-    for (int i = 0; i < 3; ++i) t[i] = A[i * 3 + 0] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2];
+    for (int i = 0; i < 3; ++i) t[i] = dot3(A[i * 3 + 0], v[0], A[i * 3 + 1], v[1], A[i * 3 + 2], v[2]);
     o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
 }
 static void mat3_tvec(const double A[9], const double v[3], double o[3]) /* A^T v */
 {
     double t[3];
-    for (int i = 0; i < 3; ++i) t[i] = A[0 * 3 + i] * v[0] + A[1 * 3 + i] * v[1] + A[2 * 3 + i] * v[2];
+    for (int i = 0; i < 3; ++i) t[i] = dot3(A[0 * 3 + i], v[0], A[1 * 3 + i], v[1], A[2 * 3 + i], v[2]);
     o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
 }
 /* SKEW_SYM_MATRX(v) * w   (so3_math.h:9) */
@@ -428,7 +447,20 @@ void orc_knn5_brute_ranked(const float *xyz, int64_t m, const uint32_t *rank, co
  * Eigen's ColPivHouseholderQR: pivot on the largest remaining column norm with LAPACK-style
  * norm downdating, Householder reflectors, rank threshold), then n = x/|x|, d = 1/|x| and the
  * 5-point inlier check. */
+static int esti_plane_impl(const float nb[15], float thr, float pabcd[4], int32_t *perm_out, float *rdiag_out,
+                           int32_t *rank_out);
 int orc_esti_plane(const float nb[15], float thr, float pabcd[4])
+{
+    return esti_plane_impl(nb, thr, pabcd, NULL, NULL, NULL);
+}
+/* the factorisation behind the fit, for cross-checks against LAPACK's sgeqp3 (tests): perm[k] = original column in
+ * position k, rdiag[k] = R(k,k), *rank = Eigen's rank decision */
+int orc_esti_plane_qr(const float nb[15], float thr, float pabcd[4], int32_t perm[3], float rdiag[3], int32_t *rank)
+{
+    return esti_plane_impl(nb, thr, pabcd, perm, rdiag, rank);
+}
+static int esti_plane_impl(const float nb[15], float thr, float pabcd[4], int32_t *perm_out, float *rdiag_out,
+                           int32_t *rank_out)
 {
     enum { R = ORC_K, C = 3 };
     float A[R][C], c[R];
@@ -440,7 +472,11 @@ int orc_esti_plane(const float nb[15], float thr, float pabcd[4])
     }
     for (int k = 0; k < C; ++k) {
         float s = 0.0f;
-        for (int i = 0; i < R; ++i) s = s + A[i][k] * A[i][k];
+        if (g_sum_order & 4) {  /* halving tree of five terms: (a0 + a1) + (a2 + (a3 + a4)) */
+            s = (A[0][k] * A[0][k] + A[1][k] * A[1][k]) + (A[2][k] * A[2][k] + (A[3][k] * A[3][k] + A[4][k] * A[4][k]));
+        } else {
+            for (int i = 0; i < R; ++i) s = s + A[i][k] * A[i][k];
+        }
         nrm_dir[k] = sqrtf(s);
         nrm_upd[k] = nrm_dir[k];
     }
@@ -530,7 +566,11 @@ int orc_esti_plane(const float nb[15], float thr, float pabcd[4])
         }
         for (int i = 0; i < nonzero; ++i) xs[perm[i]] = c[i];
     }
-    float n = sqrtf((xs[0] * xs[0] + xs[1] * xs[1]) + xs[2] * xs[2]);
+    if (perm_out) for (int k = 0; k < C; ++k) perm_out[k] = perm[k];
+    if (rdiag_out) for (int k = 0; k < C; ++k) rdiag_out[k] = A[k][k];
+    if (rank_out) *rank_out = nonzero;
+    float n = (g_sum_order & 2) ? sqrtf(xs[0] * xs[0] + (xs[1] * xs[1] + xs[2] * xs[2]))
+                                : sqrtf((xs[0] * xs[0] + xs[1] * xs[1]) + xs[2] * xs[2]);
     pabcd[0] = xs[0] / n;
     pabcd[1] = xs[1] / n;
     pabcd[2] = xs[2] / n;

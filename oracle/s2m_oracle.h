@@ -87,6 +87,13 @@ void orc_knn5_brute_ranked(const float *xyz, int64_t m, const uint32_t *rank, co
 
 /* ---- plane fit: esti_plane<float> (common_lib.h:267-299) -------------------------------- */
 int orc_esti_plane(const float nb[15], float thr, float pabcd[4]);
+/* the same fit plus the factorisation behind it: perm[k] = original column in position k of the column-pivoted QR,
+ * rdiag[k] = R(k,k), *rank = the rank decision (tests compare them with LAPACK's sgeqp3 through scipy) */
+int orc_esti_plane_qr(const float nb[15], float thr, float pabcd[4], int32_t perm[3], float rdiag[3], int32_t *rank);
+/* ASSUMED summation orders (s2m_oracle.c): bit 0 = 3-term double dot products, bit 1 = normvec.norm(), bit 2 = QR
+ * column norms evaluated as Eigen's halving tree instead of left to right.  Default 0.  Test instrument only. */
+void orc_set_sum_order(int mask);
+int  orc_get_sum_order(void);
 
 /* ---- body -> world transform (laserMapping.cpp:835-841), double math, float result ------ */
 void orc_body_to_world(const orc_state *x, const float pb[3], float pw[3]);

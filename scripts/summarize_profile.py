@@ -14,6 +14,10 @@ dst = os.path.join(root, "profiles")
 
 
 def short(name):
+    for k in ("match_rows_batch", "match_hard_batch", "reduce_kernel_batch<false, true>", "reduce_kernel_batch<false, false>",
+              "reduce_kernel_batch<true, true>", "reduce_kernel_batch<true, false>"):
+        if k in name:
+            return k
     for k in ("match_rows", "match_easy", "match_hard", "reduce_kernel<false, true>", "reduce_kernel<false, false>",
               "reduce_kernel<true, true>", "reduce_kernel<true, false>"):
         if k in name:

@@ -266,3 +266,69 @@ def test_kdtree_matches_scipy_ckdtree_at_scale(oracle):
     assert distinct.mean() > 0.99
     assert (np.sort(i1[distinct], 1) == np.sort(ii[distinct], 1)).all()
     assert np.abs(np.sqrt(d1.astype(np.float64)) - dd).max() < 1e-5
+
+
+def test_assumed_summation_orders_flip_no_gate(oracle):
+    """Size of the unpinned index risk.  Three kinds of sums on the per-point path are Eigen
+    fixed-size reductions whose order is decided inside Eigen 3.3.7 (not installed here): the oracle assumes left to
+    right, Eigen's non-vectorised unroller is a halving tree.  Evaluate the first rematch pass of the FULL C3 workload
+    (65,536 points vs 5 M map) under every combination of the two orders and count the points whose gates
+    (selected / effective) change: that number, not an argument, is what the assumption can cost."""
+    from daliti_amd import synth
+    c = synth.make_config("C3")
+    tree = oracle.KdTree(c["map"])
+    cfg = oracle.default_cfg(nthreads=8)
+    n = len(c["scan"])
+    try:
+        oracle.set_sum_order(0)
+        base = oracle.residual_pass(cfg, tree, c["scan"], c["x_prop"], True, oracle.PassState(n))
+        report = {}
+        for mask in (1, 2, 4, 7):
+            oracle.set_sum_order(mask)
+            ps = oracle.residual_pass(cfg, tree, c["scan"], c["x_prop"], True, oracle.PassState(n))
+            flips = int(((ps.selected != base.selected) | (ps.eff != base.eff)).sum())
+            ok = base.plane_ok.astype(bool) & ps.plane_ok.astype(bool)
+            dplane = float(np.abs(ps.plane[ok].astype(np.float64) - base.plane[ok]).max())
+            dnn = int((ps.nn_idx != base.nn_idx).any(axis=1).sum())
+            report[mask] = (flips, dnn, dplane, abs(ps.effct - base.effct))
+    finally:
+        oracle.set_sum_order(0)
+    print("gate flips / changed neighbour lists / max plane delta / effct delta per order mask:", report)
+    for mask, (flips, dnn, dplane, deff) in report.items():
+        assert flips <= 2 and deff <= 2, (mask, flips)        # 0-1 expected of 65,536; nowhere near the 1e-4 pose bar
+        assert dplane < 4e-5                                   # one float ulp of a plane offset d of 128..256 m
+    assert report[2][1] == 0 and report[4][1] == 0             # plane-side orders cannot touch the search
+
+
+def test_plane_qr_matches_lapack_sgeqp3(oracle, small_scene, small_tree):
+    """orc_esti_plane's factorisation against LAPACK's sgeqp3 (scipy.linalg.qr(pivoting=True) in float32 -- the
+    algorithm Eigen's ColPivHouseholderQR comments cite) on 10^5 real 5-point neighbourhoods: same pivot order
+    (except where two column norms tie to a few ulps) and the same |R(k,k)| to float round-off."""
+    from scipy.linalg import qr
+    rs = np.random.RandomState(4)
+    m = small_scene["map"]
+    q = (m[rs.choice(len(m), 100_000)] + rs.normal(0, 0.05, (100_000, 3))).astype(np.float32)
+    idx, d2, cnt = small_tree.knn5(q, 8)
+    assert (cnt == 5).all()
+    nbs = m[idx]                                               # (n, 5, 3) float32
+    piv_diff = 0
+    worst = 0.0
+    for k in range(len(nbs)):
+        A = nbs[k]
+        ok, pl, perm, rdiag, rank = oracle.esti_plane_qr(A)
+        R, P = qr(A, mode="r", pivoting=True)                  # float32 in, sgeqp3
+        assert R.dtype == np.float32
+        if not (P == perm).all():
+            # LAPACK and the restatement may order two columns of (nearly) equal norm differently
+            nrm = np.linalg.norm(A.astype(np.float64), axis=0)
+            a, b = np.sort(nrm)[-2:]
+            piv_diff += 1
+            if abs(a - b) > 1e-4 * b and rank == 3:
+                # a real difference: only acceptable in the trailing (already reduced) columns
+                assert P[0] == perm[0], (k, P, perm, nrm)
+            continue
+        rel = np.abs(np.abs(np.diag(R)) - np.abs(rdiag)) / np.abs(np.diag(R)).max()
+        worst = max(worst, float(rel.max()))
+    print("pivot orders differing: %d of %d; worst |R(k,k)| deviation %.2e of the largest diagonal" % (piv_diff, len(nbs), worst))
+    assert piv_diff < 0.01 * len(nbs)
+    assert worst < 2e-5
