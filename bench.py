@@ -173,10 +173,16 @@ class CLoop:
         self.P = np.zeros((ns, 24, 24))
         self.logs = (IterLog * k)()
         self.step0 = 0
+        self.step_us = np.zeros(1)
+
+    def reserve(self, steps):
+        """allocate the per-step clock array before the timed region"""
+        self.step_us = np.zeros(max(steps, 1))
 
     def run(self, steps):
         it, rm = C.c_int64(0), C.c_int64(0)
-        self.step_us = np.zeros(max(steps, 1))
+        if len(self.step_us) != max(steps, 1):
+            self.step_us = np.zeros(max(steps, 1))
         rc = self.fn(self.hs, C.c_int32(self.k), C.c_int32(steps), C.c_int32(self.step0), C.c_int32(self.mode),
                      C.c_void_p(self.xp.ctypes.data), C.c_void_p(self.P0.ctypes.data), C.c_void_p(self.x.ctypes.data),
                      C.c_void_p(self.P.ctypes.data), self.logs, C.byref(it), C.byref(rm), C.c_void_p(self.step_us.ctypes.data))
@@ -458,6 +464,8 @@ def main():
     # --steps 20 --warmup 5 the whole timed region is 3 ms and would otherwise run on a chip that has just left idle
     copy_peak = measured_copy_peak(torch) if (rank == 0 and not a.no_cpu) else None  # --no-cpu: no side legs
     run_steps(a.warmup)
+    if not (use_callback or a.py_loop):
+        cl.reserve(a.steps)
     dt, iters, rematch = timed(a.steps)
     res = result()
     step_us = getattr(cl, "step_us", None) if not (use_callback or a.py_loop) else None
@@ -747,14 +755,22 @@ def measured_copy_peak(torch, nbytes=1 << 30, reps=10):
 REMATCH_KERNELS = ("match_rows", "match_hard", "reduce_kernel<false, true>")
 
 
-def newest_pmc():
+def newest_pmc(batched=False):
     """The newest COMMITTED counter summary (profiles/*_pmc.json, made by scripts/profile_round.sh +
     summarize_profile.py from separate rocprofv3 --pmc passes of this same command) that holds the rematch
-    pass's kernels."""
+    pass's kernels of the C3 run (tags ending in C3, or the untagged summaries of earlier rounds) -- or, with
+    `batched`, the summary of the C5 run that carries the whole-run sums of the K-scan kernels."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
             doc = json.load(open(path))
+            tag = str(doc.get("tag", ""))
+            if batched:
+                if doc.get("batched"):
+                    return path, doc
+                continue
+            if tag[-3:-1] == "_C" and not tag.endswith("_C3"):
+                continue
             if all(name in doc["kernels"] for name in REMATCH_KERNELS):
                 return path, doc
         except (KeyError, ValueError, OSError):
@@ -804,9 +820,9 @@ def pmc_issue(pass_ms):
          "note": "VALU wave-instructions x %d cycles / (%d SIMDs x %.1f GHz) / measured pass; fp64 min/max and the "
                  "fp64 Jacobian row issue at half rate, so the true issue floor is up to 2x this figure" % (
                      VALU_CYCLES, SIMDS, CLOCK_HZ / 1e9)}
-    b = doc.get("batched")
-    if b:   # the same reading for the batched launch (K scans per grid), when the profile holds it
-        o["batched"] = b
+    bpath, bdoc = newest_pmc(batched=True)
+    if bdoc:   # the same reading for the batched launches (one grid for K scans), from the C5 profile
+        o["batched"] = dict(bdoc["batched"], source=os.path.relpath(bpath, ROOT))
     return o
 
 

@@ -38,6 +38,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "s2m_device.h"
 #include "s2m_kernels.h"
@@ -1223,8 +1224,11 @@ void launch_match_batch(const BatchArgs &b, hipStream_t st)
     const bool wide = b.grid.sent_off == 0 && b.grid.m != 0;
     const int64_t threads = (int64_t)b.n_max * 2;
     const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)b.k);
-    if (!wide) hipLaunchKernelGGL((match_rows_batch<2, false, 2>), grid, dim3(256), 0, st, b);
-    else hipLaunchKernelGGL((match_rows_batch<2, true, 2>), grid, dim3(256), 0, st, b);
+    static const int nb_env = std::getenv("S2M_BATCH_NB") ? std::atoi(std::getenv("S2M_BATCH_NB")) : 0;  // dev knob
+    if (wide) hipLaunchKernelGGL((match_rows_batch<2, true, 2>), grid, dim3(256), 0, st, b);
+    else if (nb_env == 1) hipLaunchKernelGGL((match_rows_batch<2, false, 1>), grid, dim3(256), 0, st, b);
+    else if (nb_env == 3) hipLaunchKernelGGL((match_rows_batch<2, false, 3>), grid, dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((match_rows_batch<2, false, 2>), grid, dim3(256), 0, st, b);
     const int blocks = 1024 * S2M_HARD_OCC * 64 / 256;  // the resident waves; the rest of the list comes through the heads
     if (!wide) hipLaunchKernelGGL(match_hard_batch<false>, dim3(blocks), dim3(256), 0, st, b);
     else hipLaunchKernelGGL(match_hard_batch<true>, dim3(blocks), dim3(256), 0, st, b);

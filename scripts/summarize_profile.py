@@ -47,7 +47,41 @@ for sub in ("fetch", "write", "sq", "tcc"):
                 summary[k][c + "_avg"] = sum(x) / len(x)
                 if c in ("FETCH_SIZE", "WRITE_SIZE"):
                     summary[k][c + "_max"] = max(x)
-out = dict(tag=tag, note="FETCH_SIZE / WRITE_SIZE in KiB per launch as reported by rocprofv3 (separate --pmc passes); "
+# whole-run sums of the batched kernels (one grid for K scans): per-scan VALU work and the wait / active shares of
+# the wave-cycles, for the issue-side reading of the throughput regime (bench.py: roofline.issue.batched)
+batched = None
+sq_files = glob.glob(os.path.join(src, "sq", "**", "*counter_collection.csv"), recursive=True)
+bj = os.path.join(src, "bench_under_stats.json")
+if sq_files and os.path.exists(bj) and os.path.getsize(bj):
+    tot = collections.defaultdict(float)
+    seen = False
+    for r in csv.DictReader(open(sq_files[0])):
+        k = short(r["Kernel_Name"])
+        if k and "_batch" in k:
+            tot[r["Counter_Name"]] += float(r["Counter_Value"])
+            seen = True
+    if seen:
+        try:
+            b = json.loads(open(bj).read().strip().splitlines()[-1])
+            scans = (b["steps"] + b["warmup"] + 40) * b["config"]["scans_per_gpu"]   # warm-up + timed + HIP-event sampling loop
+            valu = tot["SQ_INSTS_VALU"] / scans
+            batched = dict(scans_profiled=scans, scans_per_launch_group=b["config"]["scans_per_gpu"],
+                           valu_wave_instructions_per_scan=valu,
+                           valu_issue_floor_us_per_scan=valu * 2 / (1024 * 2.4e9) * 1e6,
+                           wait_share_of_wave_cycles=tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"],
+                           active_share_of_wave_cycles=tot["SQ_ACTIVE_INST_ANY"] / tot["SQ_WAVE_CYCLES"],
+                           scans_per_sec_unprofiled=None,
+                           note="sums over every dispatch of match_rows_batch / match_hard_batch / reduce_kernel_batch of the "
+                                "profiled run divided by the scans it registered; issue floor = VALU x 2 cycles / (1024 SIMDs x 2.4 GHz)")
+            ub = os.path.join(src, "bench.json")
+            if os.path.exists(ub) and os.path.getsize(ub):
+                u = json.loads(open(ub).read().strip().splitlines()[-1])
+                batched["scans_per_sec_unprofiled"] = u["scans_per_sec"]
+                batched["gpu_us_per_scan_at_that_rate"] = 1e6 / u["scans_per_sec"]
+                batched["issue_utilisation"] = batched["valu_issue_floor_us_per_scan"] / batched["gpu_us_per_scan_at_that_rate"]
+        except (KeyError, ValueError, IndexError):
+            batched = None
+out = dict(tag=tag, batched=batched, note="FETCH_SIZE / WRITE_SIZE in KiB per launch as reported by rocprofv3 (separate --pmc passes); "
            "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so read bytes are up to 2x "
            "the reported figure", kernels=summary)
 for name in ("bench.json", "bench_under_stats.json"):
