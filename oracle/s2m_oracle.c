@@ -660,8 +660,8 @@ void orc_residual_pass(const orc_cfg *cfg, const orc_kdtree *tree, const float *
         if (orc_esti_plane(nb, cfg->plane_thr, pl)) {
             plane_ok[i] = 1;
             float r = ((pl[0] * pw[0] + pl[1] * pw[1]) + pl[2] * pw[2]) + pl[3];        /* :866 */
-            double pbn = sqrt(((double)pb[0] * (double)pb[0] + (double)pb[1] * (double)pb[1]) +
-                              (double)pb[2] * (double)pb[2]);
+            /* p_body.norm(): a 3-term double reduction inside Eigen (order assumed: dot3 / orc_set_sum_order bit 0) */
+            double pbn = sqrt(dot3((double)pb[0], (double)pb[0], (double)pb[1], (double)pb[1], (double)pb[2], (double)pb[2]));
             /* "float s = 1 - 0.9 * fabs(pd2) / sqrt(p_body.norm())" (:868): the double expression is ROUNDED
              * TO FLOAT before "s > 0.9" (:870) promotes it back, so s_double in (0.9, 0.9000000059604645] --
              * which rounds to float(0.9) = 0.89999997615... -- is rejected */
