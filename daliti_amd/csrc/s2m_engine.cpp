@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/daliti_s2m.h"
 #include "s2m_comm.h"
@@ -1360,7 +1361,13 @@ int s2m_iterated_update_multi(s2m_engine *const *handles, int32_t n, double x[S2
     reset_log(log, max_iter);
     IterCtl c{0, 1, 0, 0, 0, 0};
     int passes = 0, it = 0;
-    double sum[S2M_BLOCK_DOUBLES];
+    // the n blocks are combined pairwise over the handle index (a perfect binary tree, missing handles count as
+    // +0.0): with the tree-shaped final sum of the reduce kernel, n aligned power-of-two pieces of a scan give the
+    // single-handle block bit for bit
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    std::vector<double> tree((size_t)np2 * S2M_BLOCK_DOUBLES);
+    double *sum = tree.data();
     for (it = 0; it < max_iter; ++it) {
         c.it = it;
         c.rematch = (it == 0) || c.rematch_en;  // :847
@@ -1382,10 +1389,12 @@ int s2m_iterated_update_multi(s2m_engine *const *handles, int32_t n, double x[S2
             if (rc) return rc;
             rc = finish_timing(handles[i]);
             if (rc) return rc;
-            if (i == 0) std::memcpy(sum, hb, sizeof(sum));
-            else
-                for (int k = 0; k < S2M_BLOCK_DOUBLES; ++k) sum[k] += hb[k];
+            std::memcpy(sum + (size_t)i * S2M_BLOCK_DOUBLES, hb, S2M_BLOCK_DOUBLES * sizeof(double));
         }
+        std::fill(tree.begin() + (size_t)n * S2M_BLOCK_DOUBLES, tree.end(), 0.0);
+        for (int w = 1; w < np2; w <<= 1)
+            for (int i = 0; i + w < np2; i += 2 * w)
+                for (int k = 0; k < S2M_BLOCK_DOUBLES; ++k) sum[(size_t)i * S2M_BLOCK_DOUBLES + k] += sum[(size_t)(i + w) * S2M_BLOCK_DOUBLES + k];
         bool finished = false;
         int rc = consume_block(e0, sum, c, x, x_prop, P, log, finished, nullptr);
         if (rc) return rc;

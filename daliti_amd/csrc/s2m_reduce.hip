@@ -299,9 +299,10 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
     // workgroup to arrive can read every row without a release/acquire fence pair
     if (threadIdx.x < T::kSlots) {
         const int t = threadIdx.x;
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < kRedBlock / 64; ++w) s += red[w][t];
+        static_assert(kRedBlock / 64 == 8, "the wave sums of a workgroup go through a three-level tree");
+        // a tree over the wave index too (not a running sum): the partition-consistency of the final sum below then
+        // reaches down to aligned 64-point pieces of the scan
+        const double s = ((red[0][t] + red[1][t]) + (red[2][t] + red[3][t])) + ((red[4][t] + red[5][t]) + (red[6][t] + red[7][t]));
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(a.partials) + (int64_t)bx * T::kSlots + t,
                            (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -329,37 +330,74 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
     S2M_STAMP(5);
 
     // ---- last workgroup: fixed-order sum of the rows (independent of arrival order) -----------------
-    constexpr int kChunks = kRedBlock / T::kSlots;  // lanes per term: 16 (NC = 6) or 5 (NC = 12)
-    constexpr int kDepth = 8;                       // independent loads in flight per lane
-    __shared__ double part[kChunks][T::kSlots];
+    // The order is a perfect BINARY TREE over the workgroup index (rows beyond the last one count as +0.0): lane ch
+    // of kTree takes the contiguous rows [ch * R, (ch + 1) * R), R = P / kTree with P the power of two >= blocks,
+    // eight at a time through a three-level tree, the groups of eight through a binary counter (the carry chain of
+    // pairwise summation), and the kTree lane sums go through the same tree in LDS.  A tree over the index is what
+    // makes the sum PARTITION-CONSISTENT: a handle that holds an aligned power-of-two piece of the scan (rows
+    // [r * S, (r + 1) * S) of the whole) computes exactly the node of this tree that covers those rows, so n such
+    // blocks combined pairwise by the host (s2m_iterated_update_multi) reproduce the single-handle block bit for bit.
+    constexpr int kLanes = kRedBlock / T::kSlots;       // lanes available per term: 16 (NC = 6) or 5 (NC = 12)
+    constexpr int kTree = kLanes >= 16 ? 16 : 4;        // ... of which a power of two takes part
+    constexpr int kDepth = 8;                           // independent loads in flight per lane
+    __shared__ double part[kTree][T::kSlots];
     __shared__ double tot[T::kSlots];
     const int blocks = (int)nblk;
-    if (threadIdx.x < kChunks * T::kSlots) {
+    int P = kTree;
+    while (P < blocks) P <<= 1;
+    const int R = P / kTree;                            // rows per lane: a power of two
+    if (threadIdx.x < kTree * T::kSlots) {
         const int t = threadIdx.x % T::kSlots, ch = threadIdx.x / T::kSlots;
         const unsigned long long *pp = reinterpret_cast<const unsigned long long *>(a.partials) + t;
-        double acc[kDepth];
-#pragma unroll
-        for (int k = 0; k < kDepth; ++k) acc[k] = 0.0;
-        for (int b0 = ch; b0 < blocks; b0 += kChunks * kDepth) {
+        // binary counter of pending subtree sums: level l holds the sum of 8 * 2^l rows, or nothing
+        constexpr int kLevels = 14;  // 8 * 2^14 rows per lane: more than a 2^28-point scan has
+        double stack[kLevels];
+        uint32_t occupied = 0u;
+        double lane_sum = 0.0;
+        for (int r0 = 0; r0 < R; r0 += kDepth) {
             unsigned long long raw[kDepth];
 #pragma unroll
             for (int k = 0; k < kDepth; ++k) {
-                const int b = b0 + k * kChunks;
-                raw[k] = (b < blocks) ? __hip_atomic_load(pp + (int64_t)b * T::kSlots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                      : 0ull;  // +0.0
+                const int b = ch * R + r0 + k;
+                raw[k] = (r0 + k < R && b < blocks) ? __hip_atomic_load(pp + (int64_t)b * T::kSlots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                    : 0ull;  // +0.0
             }
+            double v[kDepth];
 #pragma unroll
-            for (int k = 0; k < kDepth; ++k) acc[k] += __longlong_as_double((long long)raw[k]);
+            for (int k = 0; k < kDepth; ++k) v[k] = __longlong_as_double((long long)raw[k]);
+            // R < 8: the rows sit in the first R slots and the rest are +0.0 -- ((a0 + a1) + (0 + 0)) + ... is the tree over R
+            double s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            if (R <= kDepth) {
+                lane_sum = s;
+            } else {
+                // push: merge with the pending sums of equal size, older (lower rows) on the left
+#pragma unroll
+                for (int l = 0; l < kLevels; ++l) {
+                    const bool carry = (occupied >> l) & 1u;
+                    const bool low_all = (occupied & ((1u << l) - 1u)) == ((1u << l) - 1u);  // every level below carried
+                    if (carry && low_all) s = stack[l] + s;
+                    else if (!carry && low_all) stack[l] = s;
+                }
+                occupied += 1u;  // the counter itself: bit l set <=> level l pending
+                lane_sum = s;    // after the last group every level has carried: s is the whole tree
+            }
         }
-        double s01 = acc[0] + acc[1], s23 = acc[2] + acc[3], s45 = acc[4] + acc[5], s67 = acc[6] + acc[7];
-        part[ch][t] = (s01 + s23) + (s45 + s67);
+        part[ch][t] = lane_sum;
     }
     __syncthreads();
     if (threadIdx.x < T::kSlots) {
-        double s = 0.0;
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) s += part[c][threadIdx.x];
-        tot[threadIdx.x] = s;
+        const int t = threadIdx.x;
+        double s;
+        if (kTree == 16) {
+            const double q0 = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+            const double q1 = (part[4 % kTree][t] + part[5 % kTree][t]) + (part[6 % kTree][t] + part[7 % kTree][t]);
+            const double q2 = (part[8 % kTree][t] + part[9 % kTree][t]) + (part[10 % kTree][t] + part[11 % kTree][t]);
+            const double q3 = (part[12 % kTree][t] + part[13 % kTree][t]) + (part[14 % kTree][t] + part[15 % kTree][t]);
+            s = (q0 + q1) + (q2 + q3);
+        } else {
+            s = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+        }
+        tot[t] = s;
     }
     __syncthreads();
     S2M_STAMP(6);

@@ -288,7 +288,10 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
  * order = index order) and the map -- on n devices of one node, or several shards per device.  Every pass is launched
  * on all handles, each handle's block lands in its own pinned host page, the host sums the n blocks in handle order
  * and runs ONE fp64 update (degeneracy queue and Kalman work area of handles[0]).  x, P as in s2m_iterated_update.
- * Deterministic for a given n; agrees with the single-handle result to summation order (~1e-13 in the pose). */
+ * The sums are binary trees -- over the point index inside the reduce kernel, over the handle index on the host -- so
+ * when the shards are aligned power-of-two pieces of the scan (n a power of two, shard sizes 64 * 2^k: shard_range of a
+ * 65,536-point scan over 2, 4 or 8 handles) the result is BIT-IDENTICAL to s2m_iterated_update on the whole scan,
+ * whatever n; otherwise it agrees to summation order (~1e-13 in the pose) and is deterministic for a given n. */
 int s2m_iterated_update_multi(s2m_engine *const *handles, int32_t n, double x[S2M_STATE_DOUBLES],
                               const double x_prop[S2M_STATE_DOUBLES], double P[S2M_DIM * S2M_DIM], s2m_iter_log *log);
 /* Multi-GPU form: this handle holds a contiguous shard of the scan's points and the whole map.

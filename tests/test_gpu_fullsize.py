@@ -307,6 +307,32 @@ def test_c5_batch_call_equals_one_by_one(c3, eng3, oracle):
         e.close()
 
 
+def test_c3_scan_in_eight_shards_is_bit_identical(c3, eng3):
+    """north star's split at full size on one GPU: the 65 536-point C3 scan in 8 shard_range pieces (8 192 points
+    each) on 8 handles sharing the map, blocks summed by the host (s2m_iterated_update_multi).  The sums are trees
+    over the point index on the device and over the handle index on the host, so the result equals the single
+    handle's bit for bit -- the same would hold for 8 GPUs, whatever their number (2, 4, 8)."""
+    from daliti_amd import Engine
+    from daliti_amd.sharding import shard_range
+    eng3.scan_set(c3["scan"])
+    eng3.set_feat_queue(())
+    ref = eng3.iterated_update(c3["x_prop"], c3["x_prop"], c3["P"])
+    for n in (2, 8):
+        engs = []
+        for r in range(n):
+            lo, hi = shard_range(len(c3["scan"]), r, n)
+            e = Engine(max_iter=5)
+            e.map_share(eng3)
+            e.scan_set(c3["scan"][lo:hi])
+            engs.append(e)
+        x = c3["x_prop"].copy(); P = c3["P"].copy()
+        log = Engine.iterated_update_multi(engs, x, np.ascontiguousarray(c3["x_prop"]), P)
+        assert log.iters == ref["iters"] and list(log.effct[:log.iters]) == list(ref["effct"])
+        assert (bits(x) == bits(ref["x"])).all() and (bits(P) == bits(ref["P"])).all(), n
+        for e in engs:
+            e.close()
+
+
 def test_fullsize_merge_update_equals_rebuild(c3, monkeypatch):
     """Two frames of register + map_incremental on the 5 M-point map: the merged map (default) and the rebuilt
     one (S2M_NO_MERGE=1) hold the same points in the same order, and the next scan's update is bit-identical."""
