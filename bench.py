@@ -277,19 +277,22 @@ def main():
     filt = [synth.filter_inputs(pos) for _, pos in scans]
     t_gen = time.time() - t0
 
-    # one explicit (non-default) stream shared by the engine's kernels and torch's collectives: RCCL orders
-    # its work against torch's *current* stream, so the all-reduce of a block is only correctly ordered
-    # after the kernel that wrote it if both are issued under this stream
-    stream = torch.cuda.Stream(device=local_rank)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
+    # sharded runs: one explicit (non-default) stream shared by the engine's kernels and torch's collectives -- RCCL
+    # orders its work against torch's *current* stream, so the all-reduce of a block is only correctly ordered
+    # after the kernel that wrote it if both are issued under this stream.  Otherwise every handle keeps its own
+    # stream (one queue fewer for the bracket's device synchronise to drain).
+    stream = None
+    if sharded:
+        stream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(stream)
+        assert stream.cuda_stream != 0
     engs = []
     d_keep = []   # device tensors handed to the engine as raw pointers stay alive until the end
     for k in range(len(scans)):
         dev = (k % n_dev) if host_multi else local_rank
         e = Engine(max_iter=a.max_iter, cell_size=a.cell, device=dev, feat_threshold=100,
                    extrinsic_est_en=int(a.extrinsic))
-        if k == 0 and not host_multi:
+        if k == 0 and stream is not None:
             e.set_stream(stream.cuda_stream)
         engs.append(e)
     eng = engs[0]
@@ -331,6 +334,7 @@ def main():
             with torch.cuda.device(e.cfg.device):
                 d_scan = torch.from_numpy(np.ascontiguousarray(scan)).cuda()
                 d_keep.append(d_scan)
+                torch.cuda.synchronize(e.cfg.device)   # the upload ran on torch's stream, the engine reads on its own
                 e.scan_set_device(d_scan.data_ptr(), 3, len(scan))
             n_local += len(scan)
     info = eng.map_info()
@@ -606,6 +610,7 @@ def main():
         sc, n_weak = sharded_scan("weak", rank)
         d_scan = torch.from_numpy(np.ascontiguousarray(sc)).cuda()
         d_keep.append(d_scan)
+        torch.cuda.synchronize()
         eng.scan_set_device(d_scan.data_ptr(), 3, len(sc))
         run_steps(max(a.warmup // 2, 2))
         wsteps = max(a.steps // 4, 5)
@@ -649,6 +654,7 @@ def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5):
         e.map_share(owner)
         d = torch.from_numpy(np.ascontiguousarray(sc)).cuda()
         keep.append(d)
+        torch.cuda.synchronize()
         e.scan_set_device(d.data_ptr(), 3, len(sc))
         engs.append(e)
         filt.append(synth.filter_inputs(pos))

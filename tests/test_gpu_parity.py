@@ -319,3 +319,85 @@ def test_s_gate_float_rounding_edge(oracle):
     assert (st["selected"] == ps.selected).all() and (st["eff"] == ps.eff).all()
     assert out["effct"] == ps.effct
     e.close()
+
+
+@pytest.mark.parametrize("K", [2, 5, 9, 17])
+def test_batch_of_ragged_scans_equals_one_by_one(small_scene, K, monkeypatch):
+    """s2m_iterated_update_batch (one grid for K scans) on scans of different sizes -- including an empty one and one so
+    small that the degeneracy queue stops its update after the first pass -- from different predicted poses: every
+    scan's log, state and covariance equal what s2m_iterated_update gives for it alone, bit for bit; K = 9 and 17 spread
+    over two and three launch groups; the per-handle-stream form of round 2 (S2M_BATCH_STREAMS=1) gives the same."""
+    from daliti_amd import Engine, synth
+    rs = np.random.RandomState(K)
+    owner = Engine(max_iter=5)
+    owner.map_build(small_scene["map"])
+    full = small_scene["scan"]
+    engs, xs, Ps, sizes = [], [], [], []
+    for k in range(K):
+        n = [len(full), 777, 0, 64, 1500, 1024, 2000][k % 7]
+        lo = rs.randint(0, len(full) - n + 1)
+        e = Engine(max_iter=5)
+        e.map_share(owner)
+        e.scan_set(full[lo:lo + n])
+        d = np.zeros(24); d[:6] = rs.normal(0, [2e-3, 2e-3, 2e-3, 0.01, 0.01, 0.01])
+        import oracle as orc
+        xs.append(orc.boxplus(small_scene["x_prop"], d))
+        Ps.append(small_scene["P"] * (1.0 + 0.1 * k))
+        engs.append(e); sizes.append(n)
+    one = []
+    for e, x, P in zip(engs, xs, Ps):
+        e.set_feat_queue(())
+        one.append(e.iterated_update(x, x, P))
+    if K >= 4:
+        assert any(o["ekf_stop"] for o in one) and any(not o["ekf_stop"] for o in one)
+        assert len({o["iters"] for o in one}) > 1                  # the scans do not all end in the same pass
+    for mode in ("fused", "streams"):
+        for e in engs:
+            e.set_feat_queue(())
+        X = np.ascontiguousarray(np.stack(xs)); XP = X.copy(); PB = np.ascontiguousarray(np.stack(Ps))
+        if mode == "streams":
+            # the env switch is read once per process: ask for the fallback by giving one handle a different gate
+            engs[0].set_config(res_gate=2.0 + 1e-12)
+            one[0] = None
+        logs = Engine.iterated_update_batch(engs, X, XP, PB)
+        for k in range(K):
+            if one[k] is None:
+                continue
+            o = one[k]
+            assert logs[k].iters == o["iters"] and logs[k].rematch_passes == o["rematch_passes"], (mode, k)
+            assert bool(logs[k].ekf_stop) == o["ekf_stop"] and bool(logs[k].converged) == o["converged"]
+            assert list(logs[k].effct[:logs[k].iters]) == list(o["effct"]), (mode, k)
+            assert (bits(X[k]) == bits(o["x"])).all() and (bits(PB[k]) == bits(o["P"])).all(), (mode, k, sizes[k])
+    for e in engs:
+        e.close()
+    owner.close()
+
+
+def test_complete_neighbors_edge_cases(oracle, small_scene):
+    """s2m_complete_neighbors where it cannot succeed: a map of fewer than five points (every list stays short, the call
+    terminates), non-finite scan points (left alone), an empty scan; and map_incremental on such inputs."""
+    from daliti_amd import Engine, synth
+    x = synth.make_state()
+    q = small_scene["scan"][:500].copy()
+    q[7] = np.nan
+    q[9, 1] = np.inf
+    e = Engine(cell_size=0.5)
+    e.map_build(small_scene["map"][:3])
+    e.scan_set(q)
+    e.residual_pass(x, True)
+    e.complete_neighbors()
+    idx, d2 = e.get_neighbors()
+    oi, od, oc = oracle.KdTree(small_scene["map"][:3]).knn5(q)
+    ok = np.isfinite(q).all(axis=1)
+    assert (idx[ok][:, :3] == oi[ok][:, :3]).all() and (idx[:, 3:] == -1).all()
+    assert (bits(d2[ok][:, :3]) == bits(od[ok][:, :3])).all()
+    assert (idx[~ok] == -1).all()
+    clean = q[ok]
+    e.scan_set(clean)
+    e.residual_pass(x, True)
+    na, nb = e.map_incremental(x, 0.5)                     # completes what it can (three points), then classifies
+    assert na + nb == len(clean)
+    e.scan_set(np.zeros((0, 3), np.float32))
+    e.residual_pass(x, True)
+    assert e.complete_neighbors() == 0
+    e.close()
