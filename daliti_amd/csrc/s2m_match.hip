@@ -1097,6 +1097,305 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
     }
 }
 
+// ---- the same search with 32 lanes per point: two points per wave (round 3) ---------------------------------------
+// A far point is ~6.5 us of DEPENDENT load round trips whatever the lane count.  With 32 lanes per point every resident
+// wave carries two points that advance independently (each half of the wave runs its own sequence of points and
+// rounds; all primitives below are half-local: DPP scans and minima that do not cross lane 31|32, ballots split in
+// two, width-32 shuffles), so 8,192 points are in flight at the same register and LDS budget.  The halves share one
+// instruction stream: a half idles while the other fetches its next record, and their rounds issue one after the
+// other, so a single point takes longer -- this form is for the batched launches, where the list is long and only
+// throughput counts (hard_half_waves below has the measurements).
+__device__ __forceinline__ int half_incl_scan(int x)
+{
+    int v = x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3: stays inside a half
+    return v;
+}
+// the value lane 31 (half 0) / lane 63 (half 1) holds
+__device__ __forceinline__ int half_last(int v, int half)
+{
+    const int a = __builtin_amdgcn_readlane(v, 31), b = __builtin_amdgcn_readlane(v, 63);
+    return half ? b : a;
+}
+__device__ __forceinline__ int half_first(int v, int half)
+{
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 32);
+    return half ? b : a;
+}
+__device__ __forceinline__ uint32_t half_ballot(bool p, int half)
+{
+    const unsigned long long m = __ballot(p);
+    return half ? (uint32_t)(m >> 32) : (uint32_t)m;
+}
+__device__ __forceinline__ uint32_t half_min_u32(uint32_t v, int half)
+{
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v = dpp_min_step(v, k);  // row_shr 1, 2, 4, 8, row_bcast:15: lane 31 / 63 hold their half's minimum
+    return (uint32_t)half_last((int)v, half);
+}
+__device__ __forceinline__ u64 half_min_u64(u64 v, int half)
+{
+    const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    const uint32_t mh = half_min_u32(hi, half);
+    const uint32_t ml = half_min_u32((hi == mh) ? lo : 0xffffffffu, half);
+    return ((u64)mh << 32) | (u64)ml;
+}
+// sorted top-5 of the 32 private lists of a half (as merge_lists)
+__device__ __forceinline__ void merge_lists_half(const u64 (&priv)[kK], u64 (&best)[kK], int half)
+{
+    u64 t[kK];
+#pragma unroll
+    for (int k = 0; k < kK; ++k) t[k] = priv[k];
+#pragma unroll
+    for (int k = 0; k < kK; ++k) {
+        const u64 m = half_min_u64(t[0], half);
+        best[k] = m;
+        if (t[0] == m && !is_empty(m)) {
+#pragma unroll
+            for (int s = 0; s < kK - 1; ++s) t[s] = t[s + 1];
+            t[kK - 1] = kEmptyKey;
+        }
+    }
+}
+
+constexpr int kHalfCells = 512;  // cell list of one half; an append adds at most 32 rows x 8 cells
+template <bool WIDE, class Out>
+__device__ __forceinline__ void match_hard32_body(const MatchArgs &a, uint2 *__restrict__ cells, Out &&out)
+{
+    constexpr int GL = 32;
+    const Grid &g = a.grid;
+    const int lane = threadIdx.x & 31;         // lane inside the half
+    const int half = (threadIdx.x >> 5) & 1;
+    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int ngrp = (gridDim.x * blockDim.x) >> 5;
+    const uint32_t c0 = a.hard_count[0], count = c0 + a.hard_count[1];  // [no radius yet | radius known]
+    const float gate_r = sqrtf(a.gates.knn_d2_gate);
+    const int NB = max(1, (int)fminf(ceilf(gate_r * g.inv_c * 0.125f + 1e-3f), 1048576.0f));
+    const int bside = 2 * NB + 1, nbricks = bside * bside * bside;
+    const int ob0 = lane < nbricks ? lane : 0;
+    const int odx0 = (ob0 % bside) - NB, ody0 = ((ob0 / bside) % bside) - NB, odz0 = (ob0 / (bside * bside)) - NB;
+    const float near_r = (3.0f - g.slop) * g.c * 0.9999f;
+    const float near_r2 = near_r * near_r;
+    const float gate2_up = a.gates.knn_d2_gate * 1.0001f;
+    const uint32_t shard = (uint32_t)grp % kQueueShards;
+    uint32_t h = (uint32_t)grp;
+    bool fresh = true;
+    // state of the half's current point
+    uint32_t qi = 0, slot = 0, found = 0;
+    Query q = {};
+    float fxq = 0.0f, tau = 0.0f, band = 0.0f;
+    bool have_tau = false;
+    int hbx = 0, hby = 0, hbz = 0;
+    u64 t[kK], best[kK];
+#pragma unroll
+    for (int k = 0; k < kK; ++k) { t[k] = kEmptyKey; best[k] = kEmptyKey; }
+    while (h < count) {  // divergent between the halves: each runs its own sequence of points, one ROUND per trip
+        if (fresh) {
+            const uint4 *rp = reinterpret_cast<const uint4 *>(h < c0 ? a.hard_rec + h : a.hard_rec + (a.hard_off1 + (h - c0)));
+            const uint4 r0 = rp[0], r1 = rp[1];
+            qi = r0.w; found = r1.y; slot = r1.z;
+            q = query_at(g, __uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+            fxq = (float)q.cx + q.frx;
+            have_tau = found == (uint32_t)kK;
+            tau = have_tau ? __uint_as_float(r1.x) : 0.0f;
+            band = (found == 0u ? S2M_HARD_BAND_EMPTY : S2M_HARD_BAND) * g.c;   // as in match_hard_body
+            band = fminf(band, sqrtf(gate2_up));
+            hbx = q.cx >> 3; hby = q.cy >> 3; hbz = q.cz >> 3;
+#pragma unroll
+            for (int k = 0; k < kK; ++k) { t[k] = kEmptyKey; best[k] = kEmptyKey; }
+            fresh = false;
+        }
+        int nc = 0;  // cells waiting in the half's list (uniform inside the half)
+        auto append_cells = [&](uint32_t id, int rowbit, int xa, int ncell) {
+            const int incl = half_incl_scan(ncell);
+            const int total = half_last(incl, half);
+            if (total == 0) return;
+            const int at = nc + incl - ncell;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < ncell) cells[at + c] = make_uint2(id, (uint32_t)((rowbit << 3) + ((xa + c) & 7)));
+            nc += total;
+        };
+        auto flush_cells = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            int no = 0;
+            for (int jb = 0; jb < nc; jb += GL * S2M_HARD_CHUNKS) {
+                uint32_t rs[S2M_HARD_CHUNKS], re[S2M_HARD_CHUNKS];
+#pragma unroll
+                for (int u = 0; u < S2M_HARD_CHUNKS; ++u) {
+                    const int j = jb + u * GL + lane;
+                    rs[u] = 0u; re[u] = 0u;
+                    if (j < nc) {
+                        const uint2 ce = cells[j];
+                        const uint32_t *tb = g.tab + (int64_t)(ce.x - 1) * kBrickStride + ce.y;
+                        rs[u] = tb[0]; re[u] = tb[1];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll
+                for (int u = 0; u < S2M_HARD_CHUNKS; ++u) {
+                    const bool holds = rs[u] < re[u];
+                    const uint32_t m = half_ballot(holds, half);
+                    if (holds) cells[no + __popc(m & ((1u << lane) - 1u))] = make_uint2(rs[u], re[u]);
+                    no += __popc(m);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            for (int jb = 0; jb < no; jb += GL) {
+                const int j = jb + lane;
+                if (j < no) {
+                    const uint2 run = cells[j];
+                    scan_points<kHardBatch, WIDE>(g, run.x, run.y, q.wx, q.wy, q.wz, t);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            nc = 0;
+        };
+        const float r2 = have_tau ? tau : band * band;
+        if (r2 <= near_r2) {
+            // the 7x7 x-rows around the home row, 32 + 17 of them per half
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int rl = lane + 32 * sub;
+                const int ndy = (rl % 7) - 3, ndz = (rl / 7) - 3;
+                uint32_t nid[2] = {0u, 0u};
+                int nxa[2] = {0, 0}, ncl[2] = {0, 0}, nrow = 0;
+                const int yy = q.cy + ndy, zz = q.cz + ndz;
+                if (rl < 49 && yy >= 0 && yy < g.ncy && zz >= 0 && zz < g.ncz) {
+                    const float gy = ndy > 0 ? (float)ndy - q.fry : (ndy < 0 ? q.fry - (float)(ndy + 1) : 0.0f);
+                    const float gz = ndz > 0 ? (float)ndz - q.frz : (ndz < 0 ? q.frz - (float)(ndz + 1) : 0.0f);
+                    const float ay = fmaxf(gy - g.slop, 0.0f), az = fmaxf(gz - g.slop, 0.0f);
+                    const float b2 = (ay * ay + az * az) * (g.c * g.c) * 0.99999f;
+                    if (b2 <= r2) {
+                        const float reach = sqrtf(fmaxf(r2 - b2, 0.0f)) * g.inv_c * 1.00001f + g.slop;
+                        const int xa = max((int)floorf(fxq - reach), 0), xb = min((int)floorf(fxq + reach), g.ncx - 1);
+                        nrow = ((zz & 7) << 3) | (yy & 7);
+                        const int64_t toprow = ((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx;
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int bx = (xa >> 3) + k;
+                            if (xa > xb || bx > (xb >> 3)) continue;
+                            const uint4 te = g.top[toprow + bx];
+                            const uint32_t mword = (nrow & 32) ? te.w : te.z;
+                            if (te.x == 0 || ((mword >> (nrow & 31)) & 1u) == 0) continue;
+                            nid[k] = te.x;
+                            nxa[k] = max(xa, bx << 3);
+                            ncl[k] = min(xb, (bx << 3) + 7) - nxa[k] + 1;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (nc + GL * 8 > kHalfCells) flush_cells();
+                    append_cells(nid[k], nrow, nxa[k], ncl[k]);
+                }
+            }
+        } else {
+            for (int bbase = 0; bbase < nbricks; bbase += GL) {
+                const int b = bbase + lane;
+                uint32_t my_id = 0;
+                uint64_t my_mask = 0;
+                int bx = 0, by = 0, bz = 0;
+                if (b < nbricks) {
+                    if (bbase == 0) {
+                        bx = hbx + odx0; by = hby + ody0; bz = hbz + odz0;
+                    } else {
+                        bx = hbx + (b % bside) - NB;
+                        by = hby + ((b / bside) % bside) - NB;
+                        bz = hbz + (b / (bside * bside)) - NB;
+                    }
+                    if (bx >= 0 && bx < g.nbx && by >= 0 && by < g.nby && bz >= 0 && bz < g.nbz) {
+                        const uint4 te = g.top[((int64_t)bz * g.nby + by) * g.nbx + bx];
+                        my_id = te.x;
+                        my_mask = te.x ? ((uint64_t)te.w << 32 | te.z) : 0ull;
+                    }
+                }
+                const int cnt = __popcll(my_mask);
+                const int incl = half_incl_scan(cnt);
+                const int excl = incl - cnt;
+                const int total = half_last(incl, half);
+                for (int pbase = 0; pbase < total; pbase += GL * kPairSlots) {
+#pragma unroll
+                    for (int sl = 0; sl < kPairSlots; ++sl) {
+                        if (pbase + sl * GL >= total) break;  // uniform inside the half
+                        const int p = pbase + sl * GL + lane;
+                        int o = 0;
+#pragma unroll
+                        for (int step = 16; step >= 1; step >>= 1) {
+                            const int cand = o + step;
+                            const int pc = __shfl(excl, min(cand, GL - 1), GL);
+                            if (cand < GL && pc <= p) o = cand;
+                        }
+                        const uint32_t mlo = __shfl((uint32_t)my_mask, o, GL), mhi = __shfl((uint32_t)(my_mask >> 32), o, GL);
+                        const uint32_t oid = __shfl(my_id, o, GL);
+                        const int obx = __shfl(bx, o, GL), oby = __shfl(by, o, GL), obz = __shfl(bz, o, GL);
+                        const int oex = __shfl(excl, o, GL);
+                        int rowbit = 0, xa = 0, ncell = 0;
+                        if (p < total) {
+                            const uint64_t om = ((uint64_t)mhi << 32) | mlo;
+                            rowbit = kth_set_bit(om, p - oex);
+                            const int yy = (oby << 3) + (rowbit & 7), zz = (obz << 3) + (rowbit >> 3);
+                            const int dy = yy - q.cy, dz = zz - q.cz;
+                            const float gy = dy > 0 ? (float)dy - q.fry : (dy < 0 ? q.fry - (float)(dy + 1) : 0.0f);
+                            const float gz = dz > 0 ? (float)dz - q.frz : (dz < 0 ? q.frz - (float)(dz + 1) : 0.0f);
+                            const float ay = fmaxf(gy - g.slop, 0.0f), az = fmaxf(gz - g.slop, 0.0f);
+                            const float b2 = (ay * ay + az * az) * (g.c * g.c) * 0.99999f;
+                            if (b2 <= r2) {
+                                const float reach = sqrtf(fmaxf(r2 - b2, 0.0f)) * g.inv_c * 1.00001f + g.slop;
+                                xa = max((int)floorf(fxq - reach), obx << 3);
+                                const int xb = min((int)floorf(fxq + reach), (obx << 3) + 7);
+                                ncell = max(xb - xa + 1, 0);
+                            }
+                        }
+                        if (nc + GL * 8 > kHalfCells) flush_cells();
+                        append_cells(oid, rowbit, xa, min(ncell, 8));
+                    }
+                }
+            }
+        }
+        flush_cells();
+        merge_lists_half(t, best, half);
+        const bool found5 = !is_empty(best[kK - 1]);
+        const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
+        // the decisions of match_hard_body, one round at a time
+        bool done = have_tau;                                             // every point within tau was visited: exact
+        done = done || (found5 && d5 <= band * band);                     // five found inside the fully scanned band
+        done = done || (band * band > a.gates.knn_d2_gate);               // beyond the gate: "not five within it"
+        if (!done) {
+            if (found5) { have_tau = true; tau = fminf(d5, gate2_up); }   // radius known now: one exact round
+            else band = fminf(band * 2.0f, sqrtf(gate2_up));
+#pragma unroll
+            for (int k = 0; k < kK; ++k) t[k] = kEmptyKey;
+        } else {
+            if (lane == 0) {
+                int32_t *o_idx;
+                float *o_d2;
+                out(slot, o_idx, o_d2);
+                store_result(best, (int64_t)qi, o_idx, o_d2);
+            }
+            uint32_t ticket = 0;
+            if (lane == 0) ticket = atomicAdd(a.qheads + shard * kQueueStride, 1u);
+            ticket = (uint32_t)half_first((int)ticket, half);
+            h = (uint32_t)ngrp + ticket * kQueueShards + shard;
+            fresh = true;
+        }
+    }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard32(MatchArgs a)
+{
+    __shared__ uint2 cells_all[8][kHalfCells];  // one cell list per half-wave of the workgroup
+    match_hard32_body<WIDE>(a, cells_all[threadIdx.x >> 5], [&](uint32_t, int32_t *&idx, float *&d2) {
+        idx = a.nn_idx;
+        d2 = a.nn_d2;
+    });
+}
+
 template <bool WIDE, bool FAR = false>
 __global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard(MatchArgs a)
 {
@@ -1144,6 +1443,18 @@ static void launch_easy(const MatchArgs &a, bool wide, bool cells, int nb, hipSt
         if (!wide) hipLaunchKernelGGL((match_rows<G, false, 3>), dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((match_rows<G, true, 3>), dim3(blocks), dim3(256), 0, st, a);
     }
+}
+
+// Lanes per far point.  Measured (gpurun_out/r03g): with ONE scan in flight a wave per point is faster (C3 0.150 vs
+// 0.159 ms/step, C4 0.208 vs 0.212: the two halves of a wave share one instruction stream, so their load chains run one
+// after the other and a point's latency nearly doubles -- and a single scan's launch is as long as its slowest points);
+// with K scans in one grid the half-wave form wins (18.7 -> 20.4 k scans/s at K = 8, 21.1 -> 23.3 k at K = 16: the list
+// is long, only throughput counts, and 8,192 points in flight hide more of each other's waits).  So: half-waves in
+// batched launches, waves otherwise; S2M_HARD_LANES=32|64 forces one form everywhere (A/B).
+static bool hard_half_waves(bool batched)
+{
+    static const int v = std::getenv("S2M_HARD_LANES") ? std::atoi(std::getenv("S2M_HARD_LANES")) : 0;
+    return v == 32 ? true : (v == 64 ? false : batched);
 }
 
 // maximum over the ACTIVE lanes of the wave (cold path: plain shuffles; inactive lanes contribute 0)
@@ -1201,6 +1512,14 @@ static void launch_hard(const MatchArgs &a, bool wide, hipStream_t st)
     const int hg = 64;
     // as many waves as stay resident together (116 VGPRs: 4 per SIMD, 4,096 on the chip); the rest of the list is
     // pulled through the queue heads
+    if (a.qheads && !a.dbg && hard_half_waves(false)) {
+        // two points per wave: as many half-waves as stay resident together (8,192), at most one per scan point
+        const int64_t halves = std::min<int64_t>(a.n, 1024 * S2M_HARD_OCC * 2);
+        const int blocks = (int)((halves * 32 + 255) / 256);
+        if (!wide) hipLaunchKernelGGL(match_hard32<false>, dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(match_hard32<true>, dim3(blocks), dim3(256), 0, st, a);
+        return;
+    }
     const int64_t groups = std::min<int64_t>(a.n, (a.qheads ? 1024 * S2M_HARD_OCC : 8192) * (64 / hg));
     const int blocks = (int)((groups * hg + 255) / 256);
     if (!wide) hipLaunchKernelGGL(match_hard<false>, dim3(blocks), dim3(256), 0, st, a);
@@ -1217,6 +1536,22 @@ void launch_match_hard_only(const MatchArgs &a, hipStream_t st)
     else hipLaunchKernelGGL((match_hard<true, true>), dim3(blocks), dim3(256), 0, st, a);
 }
 
+template <bool WIDE>
+__global__ __launch_bounds__(256, S2M_HARD_OCC) void match_hard32_batch(BatchArgs b)
+{
+    __shared__ uint2 cells_all[8][kHalfCells];
+    MatchArgs a;
+    a.grid = b.grid; a.gates = b.gates;
+    a.sx = a.sy = a.sz = nullptr; a.n = b.n_max;
+    a.nn_idx = nullptr; a.nn_d2 = nullptr;
+    a.hard_rec = b.hard_rec; a.hard_off1 = b.hard_off1; a.slot = 0;
+    a.hard_count = b.hard_count; a.qheads = b.qheads; a.dbg = nullptr;
+    match_hard32_body<WIDE>(a, cells_all[threadIdx.x >> 5], [&](uint32_t slot, int32_t *&idx, float *&d2) {
+        idx = b.d[slot].nn_idx;   // the two halves of a wave may serve different scans: a per-lane look-up in the table
+        d2 = b.d[slot].nn_d2;
+    });
+}
+
 // search kernels of one batched pass (G = 2 lanes per point, two point batches per trip: the chip is shared by K scans)
 void launch_match_batch(const BatchArgs &b, hipStream_t st)
 {
@@ -1230,7 +1565,10 @@ void launch_match_batch(const BatchArgs &b, hipStream_t st)
     else if (nb_env == 3) hipLaunchKernelGGL((match_rows_batch<2, false, 3>), grid, dim3(256), 0, st, b);
     else hipLaunchKernelGGL((match_rows_batch<2, false, 2>), grid, dim3(256), 0, st, b);
     const int blocks = 1024 * S2M_HARD_OCC * 64 / 256;  // the resident waves; the rest of the list comes through the heads
-    if (!wide) hipLaunchKernelGGL(match_hard_batch<false>, dim3(blocks), dim3(256), 0, st, b);
+    if (hard_half_waves(true)) {
+        if (!wide) hipLaunchKernelGGL(match_hard32_batch<false>, dim3(blocks), dim3(256), 0, st, b);
+        else hipLaunchKernelGGL(match_hard32_batch<true>, dim3(blocks), dim3(256), 0, st, b);
+    } else if (!wide) hipLaunchKernelGGL(match_hard_batch<false>, dim3(blocks), dim3(256), 0, st, b);
     else hipLaunchKernelGGL(match_hard_batch<true>, dim3(blocks), dim3(256), 0, st, b);
 }
 
