@@ -14,7 +14,7 @@ dst = os.path.join(root, "profiles")
 
 
 def short(name):
-    for k in ("match_rows_batch", "match_hard_batch", "reduce_kernel_batch<false, true>", "reduce_kernel_batch<false, false>",
+    for k in ("match_rows_batch", "match_hard32_batch", "match_hard_batch", "match_hard32", "reduce_kernel_batch<false, true>", "reduce_kernel_batch<false, false>",
               "reduce_kernel_batch<true, true>", "reduce_kernel_batch<true, false>"):
         if k in name:
             return k
