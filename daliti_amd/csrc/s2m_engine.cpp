@@ -1429,12 +1429,12 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
         s2m_engine *lead = nullptr;
         BatchArgs args;
     };
-    Slot slots[256];
-    Group groups[64];
     int ng = k >= 4 ? 2 : 1;
     static const int ng_env = std::getenv("S2M_BATCH_GROUPS") ? std::atoi(std::getenv("S2M_BATCH_GROUPS")) : 0;  // dev knob
     if (ng_env > 0) ng = std::min(ng_env, (int)k);
     while ((k + ng - 1) / ng > kBatchMax) ++ng;
+    std::vector<Slot> slots((size_t)k);
+    std::vector<Group> groups((size_t)ng);  // a group carries its kernel-argument table (2.9 KB): not on the stack
     auto xk = [&](int i) { return x + (size_t)i * S2M_STATE_DOUBLES; };
     auto xpk = [&](int i) { return x_prop + (size_t)i * S2M_STATE_DOUBLES; };
     auto Pk = [&](int i) { return P + (size_t)i * S2M_DIM * S2M_DIM; };
