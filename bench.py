@@ -158,8 +158,11 @@ class CLoop:
     def __init__(self, engs, x_prop, P0, mode):
         from daliti_amd.engine import IterLog, library_path
         path = os.path.join(os.path.dirname(library_path()), "libs2m_benchloop.so")
-        if not os.path.exists(path):
-            raise SystemExit("%s is missing: run __graft_entry__.build()" % path)
+        if not os.path.exists(path):   # normally built by __graft_entry__.build(); plain g++ against the C ABI
+            lib_dir = os.path.dirname(library_path())
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                                   os.path.join(ROOT, "tools", "bench_loop.cpp"), "-L", lib_dir, "-ldaliti_s2m",
+                                   "-Wl,-rpath," + lib_dir, "-o", path])
         C.CDLL(library_path(), mode=C.RTLD_GLOBAL)
         self.fn = C.CDLL(path).s2m_bench_loop
         self.fn.restype = C.c_int
