@@ -157,9 +157,9 @@ class CLoop:
 
     def __init__(self, engs, x_prop, P0, mode):
         from daliti_amd.engine import IterLog, library_path
-        path = os.path.join(os.path.dirname(library_path()), "libs2m_benchloop.so")
+        lib_dir = os.path.join(ROOT, "daliti_amd", "_lib")   # next to the product library (S2M_LIB may point elsewhere)
+        path = os.path.join(lib_dir, "libs2m_benchloop.so")
         if not os.path.exists(path):   # normally built by __graft_entry__.build(); plain g++ against the C ABI
-            lib_dir = os.path.dirname(library_path())
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"),
                                    os.path.join(ROOT, "tools", "bench_loop.cpp"), "-L", lib_dir, "-ldaliti_s2m",
                                    "-Wl,-rpath," + lib_dir, "-o", path])

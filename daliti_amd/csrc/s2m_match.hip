@@ -820,6 +820,9 @@ constexpr int kPairSlots = 6;  // (brick,row) pairs a lane can hold per chunk of
 #ifndef S2M_HARD_BAND_EMPTY
 #define S2M_HARD_BAND_EMPTY 2.8f  // first band (cells) of a far point whose first shell held nothing
 #endif
+#ifndef S2M_HARD_PIECES
+#define S2M_HARD_PIECES 1  // idle lanes of the far-point kernel take the later 8-point pieces of the listed cells (0: one run per lane)
+#endif
 #ifndef S2M_HARD_OCC
 #define S2M_HARD_OCC 4  // waves per SIMD match_hard is compiled for (116 VGPRs at 4; 5 needs spills) = resident waves / 1024
 #endif
@@ -927,7 +930,22 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             }
-            // Pass 2: the runs, one per lane and trip
+            // Pass 2: the runs.  A run is one cell -- 12 points on average at the tuned density, i.e. usually TWO batches
+            // of eight -- and a lane that walks its run alone pays one dependent load trip per batch while most lanes of
+            // the wave hold no run at all (a far point lists 10-30 non-empty cells).  With few runs the idle lanes take
+            // the later pieces of the same runs instead: lane l serves piece l / no of run l % no (the last piece takes
+            // whatever is left), so a cell of up to 32 points (16 with more than 16 runs) is read in ONE trip.  Same
+            // candidates, same top-5 (the merge of the private lists does not depend on who scanned what).
+            if (S2M_HARD_PIECES && no > 0 && no <= 32) {  // wave-uniform
+                const int P = no <= 16 ? 4 : 2;
+                const int piece = lane / no;
+                if (piece < P) {
+                    const uint2 run = cells[lane - piece * no];
+                    const uint32_t s0 = run.x + 8u * (uint32_t)piece;
+                    const uint32_t e0 = (piece == P - 1) ? run.y : min(s0 + 8u, run.y);
+                    if (s0 < e0) scan_points<kHardBatch, WIDE>(g, s0, e0, q.wx, q.wy, q.wz, t);
+                }
+            } else
             for (int jb = 0; jb < no; jb += 64) {  // wave-uniform trip count
                 const int j = jb + lane;
                 if (j < no) {
@@ -1245,6 +1263,16 @@ __device__ __forceinline__ void match_hard32_body(const MatchArgs &a, uint2 *__r
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             }
+            if (S2M_HARD_PIECES && no > 0 && no <= 16) {  // idle lanes take the later pieces of the runs (see match_hard_body)
+                const int P = no <= 8 ? 4 : 2;
+                const int piece = lane / no;
+                if (piece < P) {
+                    const uint2 run = cells[lane - piece * no];
+                    const uint32_t s0 = run.x + 8u * (uint32_t)piece;
+                    const uint32_t e0 = (piece == P - 1) ? run.y : min(s0 + 8u, run.y);
+                    if (s0 < e0) scan_points<kHardBatch, WIDE>(g, s0, e0, q.wx, q.wy, q.wz, t);
+                }
+            } else
             for (int jb = 0; jb < no; jb += GL) {
                 const int j = jb + lane;
                 if (j < no) {
