@@ -705,9 +705,105 @@ __device__ __forceinline__ void match_rows_body(const MatchArgs &a, uint2 *__res
     S2M_ROWS_STAMP(3, nr);
     walk_runs();
     merge_lists<G>(t, best);
-    const bool found5 = !is_empty(best[kK - 1]);
-    const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
-    const bool done = found5 && d5 <= cube_bound2(g, q, 1);
+    bool found5 = !is_empty(best[kK - 1]);
+    float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
+    bool done = found5 && d5 <= cube_bound2(g, q, 1);
+#if S2M_ROWS_EXT
+    // ---- phase 4 (round 3 experiment, off by default: measured slower, see DESIGN): the second / third shell, in place,
+    // for the points whose radius is already known ------
+    // A point that holds five neighbours but not provably the nearest five used to go to match_hard -- a second kernel,
+    // its own dependent-load chain of ~6 us per point, and a launch as long as its busiest wave.  Measured on the first
+    // pass (predicted pose off by 1 deg / 5 cm: far returns sit 0.5-3 m off their surface): these points come in WHOLE
+    // WAVES -- 21 % of this kernel's waves hold any at C3 (23 % at C4), and those hold 23-25 of 32 -- and for 96 % of
+    // them (75 % at C4) the 5th distance is within three cells.  So the waves that hold such points (wave-uniform
+    // branch; the others leave as before) finish them here: the x-rows within R cells of the home row whose (y,z)
+    // bound is inside the radius, minus what the first shell has already read, listed per lane (the G lanes of a point
+    // split the rows), top entries of all listed pieces in one trip, their prefix words in a second, then the point
+    // runs through the walk above.  Every cell within the radius has then been read: the list is exact and final.
+    // A lane with more pieces than slots gives up and the point takes the old route.
+    {
+        constexpr int R = S2M_ROWS_EXT;  // rows |dy|, |dz| <= R
+        constexpr int W = 2 * R + 1;
+        const float lim = ((float)R - g.slop) * g.c * 0.9999f;  // a row R + 1 cells away is bounded below by (R - slop) cells
+        const bool ext = !done && found5 && d5 <= lim * lim;
+        if (__any(ext)) {
+            nr = 0;
+            bool over = false;
+            if (ext) {
+                const float fxq = (float)q.cx + q.frx;
+                for (int rr = j; rr < W * W; rr += G) {
+                    const int dy = rr % W - R, dz = rr / W - R;
+                    const int yy = q.cy + dy, zz = q.cz + dz;
+                    if (yy < 0 || yy >= g.ncy || zz < 0 || zz >= g.ncz) continue;
+                    const float gy = dy > 0 ? (float)dy - q.fry : (dy < 0 ? q.fry - (float)(dy + 1) : 0.0f);
+                    const float gz = dz > 0 ? (float)dz - q.frz : (dz < 0 ? q.frz - (float)(dz + 1) : 0.0f);
+                    const float ay = fmaxf(gy - g.slop, 0.0f), az = fmaxf(gz - g.slop, 0.0f);
+                    const float b2 = (ay * ay + az * az) * (g.c * g.c) * 0.99999f;
+                    if (b2 > d5) continue;
+                    const float reach = sqrtf(fmaxf(d5 - b2, 0.0f)) * g.inv_c * 1.00001f + g.slop;
+                    const int xa = max((int)floorf(fxq - reach), 0), xb = min((int)floorf(fxq + reach), g.ncx - 1);
+                    // the nine inner rows: cells x_lo .. x_hi were read by the first shell, or skipped there because their
+                    // box bound exceeds a 5th distance that was already no smaller than today's radius
+                    const bool inner = xok && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+                    const int plo[2] = {xa, inner ? x_hi + 1 : 1}, phi[2] = {inner ? x_lo - 1 : xb, inner ? xb : 0};
+                    const int rowb = ((zz & 7) << 3) | (yy & 7);
+                    const int64_t toprow = ((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx;
+#pragma unroll
+                    for (int pc = 0; pc < 2; ++pc) {
+                        const int lo = plo[pc], hi = phi[pc];
+                        if (lo > hi) continue;
+                        for (int b = lo >> 3; b <= (hi >> 3); ++b) {  // a piece spans at most 2 R + 1 cells: two bricks
+                            const int sl = max(lo, b << 3) & 7, sh = min(hi, (b << 3) + 7) & 7;
+                            if (nr == (uint32_t)kRunSlots) { over = true; break; }
+                            runs[nr * 256 + threadIdx.x] = make_uint2((uint32_t)(toprow + b), (uint32_t)((rowb << 8) | (sl << 4) | sh));
+                            ++nr;
+                        }
+                    }
+                    if (over) break;
+                }
+            }
+            // the G lanes of a point stand or fall together
+            bool over_g = over;
+#pragma unroll
+            for (int off = G / 2; off > 0; off >>= 1) over_g = over_g || (__shfl_xor((int)over_g, off, G) != 0);
+            if (over_g) nr = 0;
+            // trip 1: the top entries of all listed pieces; trip 2: their two prefix words
+            uint32_t ids[kRunSlots];
+#pragma unroll
+            for (int k = 0; k < kRunSlots; ++k) {
+                ids[k] = 0u;
+                if ((uint32_t)k < nr) {
+                    const uint2 dsc = runs[k * 256 + threadIdx.x];
+                    const uint4 te = g.top[dsc.x];
+                    const uint32_t rowb = dsc.y >> 8;
+                    const uint32_t mword = (rowb & 32u) ? te.w : te.z;
+                    if (te.x != 0u && ((mword >> (rowb & 31u)) & 1u)) ids[k] = te.x;
+                }
+            }
+            uint32_t rs[kRunSlots], re[kRunSlots];
+#pragma unroll
+            for (int k = 0; k < kRunSlots; ++k) {
+                rs[k] = 0u; re[k] = 0u;
+                if ((uint32_t)k < nr && ids[k] != 0u) {
+                    const uint32_t w = runs[k * 256 + threadIdx.x].y;
+                    const uint32_t *tb = g.tab + (int64_t)(ids[k] - 1) * kBrickStride + ((w >> 8) << 3);
+                    rs[k] = tb[(w >> 4) & 7u];
+                    re[k] = tb[(w & 7u) + 1u];
+                }
+            }
+            uint32_t nr2 = 0;
+#pragma unroll
+            for (int k = 0; k < kRunSlots; ++k)
+                if ((uint32_t)k < nr && rs[k] < re[k]) { runs[nr2 * 256 + threadIdx.x] = make_uint2(rs[k], re[k]); ++nr2; }
+            nr = nr2;
+            walk_runs();
+            merge_lists<G>(t, best);
+            found5 = !is_empty(best[kK - 1]);
+            d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
+            done = done || (ext && !over_g);
+        }
+    }
+#endif
     // unresolved: match_hard's list, in two parts -- the points without a radius (fewer than five neighbours in the
     // shell: two rounds there, ~11 us against ~5.5 us) are handed out first so that they do not form the launch's tail
     {
@@ -819,6 +915,10 @@ constexpr int kPairSlots = 6;  // (brick,row) pairs a lane can hold per chunk of
 #endif
 #ifndef S2M_HARD_BAND_EMPTY
 #define S2M_HARD_BAND_EMPTY 2.8f  // first band (cells) of a far point whose first shell held nothing
+#endif
+#ifndef S2M_ROWS_EXT
+#define S2M_ROWS_EXT 0  // experiment (round 3, DESIGN "tried and rejected"): 2 or 3 = the first-shell kernel finishes the points whose
+                        // 5th distance is within that many cells itself; 0 = every unresolved point goes to match_hard
 #endif
 #ifndef S2M_HARD_PIECES
 #define S2M_HARD_PIECES 1  // idle lanes of the far-point kernel take the later 8-point pieces of the listed cells (0: one run per lane)
