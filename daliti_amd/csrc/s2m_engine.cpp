@@ -99,6 +99,11 @@ struct s2m_engine {
     bool dbg = false;
     bool nn_valid = false;
     bool nn_complete = false;     // s2m_complete_neighbors has run on the current lists
+    // far points (scan points the first-shell kernel could not resolve) of the last FIRST rematch pass of a scan and of
+    // the last LATER one; -1 = unknown.  A pass whose predecessor in the same position had none runs without the
+    // far-point kernel on that bet (spec_mode: 0 never, 1 by history, 2 always -- the last two for tests)
+    int64_t far_first = -1, far_later = -1;
+    int spec_mode = 1;
 
     // far-point lists, counters and queue heads shared by the scans of a batched launch; owned by the first handle of
     // a launch group of s2m_iterated_update_batch
@@ -192,7 +197,8 @@ int stage_cloud(s2m_engine *e, const float *xyz, int64_t stride, int64_t count, 
 // defer_publish: the caller sums d_out over the ranks first and publishes the result itself (launch_publish);
 // every other caller gets the block and the flag in pinned host memory straight from the reduce kernel, with or
 // without a communicator attached to the handle.
-int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, double *d_out, bool defer_publish = false)
+int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, double *d_out, bool defer_publish = false,
+             bool skip_far = false)
 {
     if (!e || !state) return fail(e, S2M_ERR_ARG, "null argument");
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
@@ -224,6 +230,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         // C4 0.225 -> 0.214 ms/step, C5 batch 13.3 -> 14.2 k scans/s, against C3 20.3 -> 21.1 us the other way.
         int group = e->match_group;
         if (((group >> 8) & 0xf) == 0 && ((int64_t)n * 2 > 3072 * 64 || e->in_batch)) group |= 2 << 8;
+        if (skip_far) group |= 0x40000;     // the first-shell kernel only: the reduce kernel reports whether the bet held
         launch_match(m, group, e->stream);  // hard_count is zero: reset by every reduce launch
         e->nn_valid = true;
         e->nn_complete = false;
@@ -239,6 +246,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     r.partials = e->d_partials; r.block = d_out;
     r.ticket = e->d_ticket; r.hard_count = e->d_hard + 3 * e->n_cap;
     r.qheads = e->d_qheads;
+    r.spec = (rematch && skip_far) ? 1 : 0;
     const bool publish = e->host_poll && d_out == e->d_block && !defer_publish;
     r.host_block = publish ? e->h_block_dev : nullptr;
     r.host_flag = publish ? reinterpret_cast<unsigned long long *>(e->h_block_dev + S2M_BLOCK_DOUBLES) : nullptr;
@@ -248,6 +256,41 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     S2M_HIP(e, hipGetLastError());
     e->last_pose = pose;
     e->pass_done = true;
+    return S2M_OK;
+}
+
+// The pass just waited for ran without the far-point kernel and its list turned out not to be empty: run that kernel
+// now (the list and its counters are still in place) and the reduce kernel again -- every per-point output of a rematch
+// pass is a function of the neighbour lists alone, so the second run overwrites the first completely.
+int redo_with_far_points(s2m_engine *e, const double state[S2M_STATE_DOUBLES], double *d_out)
+{
+    const Pose pose = pose_of(state);
+    const Gates gates = gates_of(e->cfg);
+    const int n = (int)e->n;
+    float *sx = e->d_scan, *sy = e->d_scan + e->n_cap, *sz = e->d_scan + 2 * e->n_cap;
+    MatchArgs m;
+    m.grid = e->grid; m.pose = pose; m.gates = gates;
+    m.sx = sx; m.sy = sy; m.sz = sz; m.n = n;
+    m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
+    m.hard_rec = e->d_hrec; m.hard_off1 = n; m.hard_count = e->d_hard + 3 * e->n_cap;
+    m.qheads = e->d_qheads;
+    m.dbg = nullptr;
+    launch_match_far_points(m, e->match_group, e->stream);
+    ReduceArgs r;
+    r.pose = pose; r.gates = gates;
+    r.sx = sx; r.sy = sy; r.sz = sz; r.n = n;
+    r.fit = 1;
+    r.nn_idx = e->d_nn_idx; r.nn_d2 = e->d_nn_d2; r.pts = e->grid.pts;
+    r.plane = e->d_plane; r.flags = e->d_flags; r.sel = e->d_sel; r.eff = e->d_eff; r.pd2 = e->d_pd2;
+    r.partials = e->d_partials; r.block = d_out;
+    r.ticket = e->d_ticket; r.hard_count = e->d_hard + 3 * e->n_cap;
+    r.qheads = e->d_qheads;
+    const bool publish = e->host_poll && d_out == e->d_block;
+    r.host_block = publish ? e->h_block_dev : nullptr;
+    r.host_flag = publish ? reinterpret_cast<unsigned long long *>(e->h_block_dev + S2M_BLOCK_DOUBLES) : nullptr;
+    r.seq = ++e->seq;
+    launch_reduce(r, e->stream);
+    S2M_HIP(e, hipGetLastError());
     return S2M_OK;
 }
 
@@ -341,6 +384,10 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
         if (v >= 1 && v <= 3) e->match_group |= v << 8;
     }
     e->dbg = std::getenv("S2M_DEBUG_MATCH") != nullptr;
+    if (const char *g = std::getenv("S2M_SPEC")) {  // 0: always launch the far-point kernel; 2: always bet on an empty list (tests)
+        const int v = std::atoi(g);
+        if (v >= 0 && v <= 2) e->spec_mode = v;
+    }
     e->no_merge = std::getenv("S2M_NO_MERGE") != nullptr;
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&e->ev[i]) == hipSuccess;
@@ -1141,7 +1188,14 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         passes += rematch;
         const auto t_a = now();
         const bool collective = !reduce && e->comm.handle;  // built-in RCCL sum of the block before the hand-off
-        int rc = run_pass(e, x, rematch, d_block, collective);
+        // Bet on "no far points" when the last rematch pass in this position (first of a scan / later) had none: at a
+        // converged pose the first shell resolves every point (measured: 0 of 65,536 at C3, 0 of 131,072 at C4), and
+        // the far-point kernel -- a launch, a kernel boundary and 4,096 waves that find an empty list -- is ~4 us.
+        // Plain single-handle loop only (no collective: every rank would have to lose the bet together).
+        const int64_t hist = it == 0 ? e->far_first : e->far_later;
+        const bool spec = rematch && !reduce && !collective && !e->dbg && d_block == e->d_block && e->host_poll &&
+                          (e->spec_mode == 2 || (e->spec_mode == 1 && hist == 0));
+        int rc = run_pass(e, x, rematch, d_block, collective, spec);
         if (rc) return rc;
         if (it == 0) {
             // (state.cov / LASER_POINT_COV).inverse() (:1017) depends on the covariance alone: 8 us of host LU that
@@ -1173,10 +1227,20 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         } else {
             rc = wait_block(e, d_block, &hb);
         }
-        const auto t_c = now();
         if (rc) return rc;
         rc = finish_timing(e);
         if (rc) return rc;
+        if (rematch && !reduce && !collective) {
+            const int64_t far_points = (int64_t)hb[158];
+            if (it == 0) e->far_first = far_points; else e->far_later = far_points;
+            if (spec && far_points != 0) {  // the bet is lost: this block is void (s2m_reduce.hip)
+                rc = redo_with_far_points(e, x, d_block);
+                if (rc) return rc;
+                rc = wait_block(e, d_block, &hb);
+                if (rc) return rc;
+            }
+        }
+        const auto t_c = now();
         IterCtl ctl{it, rematch, rematch_num, rematch_en, conv, stop};
         bool finished = false;
         rc = consume_block(e, hb, ctl, x, x_prop, P, log, finished, tl ? &t_solve_us : nullptr);

@@ -198,6 +198,8 @@ void launch_match(const MatchArgs &a, int group, hipStream_t st);
 // completion of the lists that ended short at the gate (s2m_complete_neighbors): the scan points with fewer than five
 // neighbours appended to hard list 0 (a.pose = the pose of the rematch pass that produced the lists), and the far-point
 // kernel on its own (a.gates.knn_d2_gate = the radius^2 of this round)
+// the far-point kernel on its own, in its per-iteration form (the redo of a pass whose speculation "no far points" failed)
+void launch_match_far_points(const MatchArgs &a, int group, hipStream_t st);
 void launch_collect_short(const MatchArgs &a, hipStream_t st);
 void launch_match_hard_only(const MatchArgs &a, hipStream_t st);
 
@@ -225,8 +227,10 @@ struct ReduceArgs {
     double *partials;  // blocks x kRedTerms
     double *block;     // S2M_BLOCK_DOUBLES output (device)
     uint32_t *ticket;  // arrival counters of the in-kernel final sum (kTicketWords words, zero before the first launch)
-    uint32_t *hard_count;            // reset to 0 for the next rematch pass
+    uint32_t *hard_count;            // reset to 0 for the next rematch pass; its sum is published as block[158]
     uint32_t *qheads = nullptr;      // match_hard's dequeue heads, reset likewise
+    int spec = 0;                    // the far-point kernel was NOT launched for this pass (the host bet on an empty list):
+                                     // if the list is not empty the block is void and the counters are left for the redo
     double *host_block;              // optional: pinned host copy of block, device-visible pointer
     unsigned long long *host_flag;   // optional: set to seq (system scope) after host_block is written
     unsigned long long seq;

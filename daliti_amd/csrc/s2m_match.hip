@@ -1705,6 +1705,13 @@ void launch_match_batch(const BatchArgs &b, hipStream_t st)
     else hipLaunchKernelGGL(match_hard_batch<true>, dim3(blocks), dim3(256), 0, st, b);
 }
 
+void launch_match_far_points(const MatchArgs &a, int group, hipStream_t st)
+{
+    if (a.n <= 0) return;
+    launch_hard(a, (a.grid.sent_off == 0 && a.grid.m != 0) || (group & 0x10000), st);
+}
+
+// group bit 0x40000: the first-shell kernel only (the host bets that it resolves every point; s2m_engine.cpp, run_pass)
 void launch_match(const MatchArgs &a, int group, hipStream_t st)
 {
     if (a.n <= 0) return;
@@ -1719,7 +1726,7 @@ void launch_match(const MatchArgs &a, int group, hipStream_t st)
         case 8: launch_easy<8>(a, wide, cells, nb, st); break;
         default: launch_easy<2>(a, wide, cells, nb, st); break;
     }
-    launch_hard(a, wide, st);
+    if (!(group & 0x40000)) launch_hard(a, wide, st);
 }
 
 }  // namespace s2m

@@ -401,6 +401,10 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
     }
     __syncthreads();
     S2M_STAMP(6);
+    // far points of this pass (the two list lengths): published as block[158]; a pass that ran WITHOUT the far-point
+    // kernel on the host's bet that the list would be empty is void when it is not -- the counters then stay for the redo
+    const uint32_t far_points = a.hard_count ? a.hard_count[0] + a.hard_count[1] : 0u;
+    const bool void_pass = a.spec != 0 && far_points != 0u;
     if (threadIdx.x < 160) {
         const int o = threadIdx.x;
         double v = 0.0;
@@ -414,15 +418,18 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
             v = tot[T::kCnt];
         } else if (o == 157) {
             v = tot[T::kRes];
+        } else if (o == 158) {
+            v = (double)far_points;
         }
         a.block[o] = v;
         if (a.host_block) publish_store(a.host_block + o, v);
     }
     if (threadIdx.x == 0) {
         __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-        if (a.hard_count) { a.hard_count[0] = 0u; a.hard_count[1] = 0u; a.hard_count[2] = 0u; }
     }
-    if (a.qheads && threadIdx.x < kQueueShards) a.qheads[threadIdx.x * kQueueStride] = 0u;
+    __syncthreads();  // every thread has read the list lengths before they are reset
+    if (threadIdx.x == 0 && a.hard_count && !void_pass) { a.hard_count[0] = 0u; a.hard_count[1] = 0u; a.hard_count[2] = 0u; }
+    if (a.qheads && threadIdx.x < kQueueShards && !void_pass) a.qheads[threadIdx.x * kQueueStride] = 0u;
     if (a.host_flag) publish_flag(a.host_flag, a.seq);
 #ifdef S2M_EXP_REDUCE_TIMELINE
     if (threadIdx.x == 0) {

@@ -36,7 +36,7 @@ extern "C" {
 #define S2M_K 5            /* NUM_MATCH_POINTS, laserMapping.cpp:77 */
 #define S2M_DIM 24         /* DIM_OF_STATES, common_lib.h:23 */
 #define S2M_STATE_DOUBLES 36
-#define S2M_BLOCK_DOUBLES 160 /* HtH[144] Htz[12] effct total_res pad[2] */
+#define S2M_BLOCK_DOUBLES 160 /* HtH[144] Htz[12] effct total_res far_points pad */
 #define S2M_FEAT_QUEUE 10  /* QUEUE_SIZE, laserMapping.cpp:192 */
 
 enum {
@@ -217,7 +217,8 @@ typedef struct {
 int s2m_residual_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch,
                       s2m_pass_out *out);
 /* Same pass, result left on the device for a collective: d_block is a DEVICE pointer to
- * S2M_BLOCK_DOUBLES doubles laid out HtH[144] Htz[12] effct total_res 0 0 (effct as a double).
+ * S2M_BLOCK_DOUBLES doubles laid out HtH[144] Htz[12] effct total_res far_points 0 (effct as a double; far_points =
+ * scan points this pass handed to the far-point kernel, a diagnostic).
  * No host synchronisation; ordered on the handle's stream. */
 int s2m_residual_pass_device(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch,
                              double *d_block);

@@ -157,3 +157,50 @@ def test_both_far_point_kernels_pass_the_stress_suite():
                             os.path.join(here, "test_map_update.py")], env=env, capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, "S2M_HARD_LANES=%s\n%s" % (lanes, r.stdout[-3000:])
         assert " passed" in r.stdout
+
+
+def test_bet_on_no_far_points_is_exact_whether_won_or_lost(oracle):
+    """A rematch pass whose predecessor in the same position (first pass of a scan / later pass) reported no far points
+    runs WITHOUT the far-point kernel; the reduce kernel reports the list length, and a lost bet is repaired by running
+    the far-point kernel and the reduce kernel again.  (1) History: the first update on a handle bets on nothing, the
+    second one bets on the later pass -- same bits.  (2) In child processes: S2M_SPEC=2 (always bet, i.e. the first pass
+    of C3 with its 9,981 far points LOSES every time) and S2M_SPEC=0 (never bet) give the oracle-checked results."""
+    import os
+    import subprocess
+    import sys
+    from daliti_amd import Engine, synth
+    c = synth.make_config("C2")
+    e = Engine(max_iter=5)
+    e.map_build(c["map"])
+    e.scan_set(c["scan"])
+    runs = []
+    for _ in range(3):
+        e.set_feat_queue(())
+        runs.append(e.iterated_update(c["x_prop"], c["x_prop"], c["P"]))
+    for r in runs[1:]:
+        assert r["iters"] == runs[0]["iters"] and (r["effct"] == runs[0]["effct"]).all()
+        assert (bits(r["x"]) == bits(runs[0]["x"])).all() and (bits(r["P"]) == bits(runs[0]["P"])).all()
+    # a different scan on the same handle whose LATER pass does have far points: far outliers that no pose can fix
+    rs = np.random.RandomState(5)
+    bad = c["scan"].copy()
+    pick = rs.choice(len(bad), 4000, replace=False)
+    bad[pick] *= np.float32(0.93)                       # pulled 7 % towards the sensor: 0.5-7 m off their surface
+    e.scan_set(bad)
+    e.set_feat_queue(())
+    lost = e.iterated_update(c["x_prop"], c["x_prop"], c["P"])        # bets on the later pass (history 0) and loses
+    e.set_feat_queue(())
+    again = e.iterated_update(c["x_prop"], c["x_prop"], c["P"])       # history now says: do not bet
+    assert lost["iters"] == again["iters"] and (lost["effct"] == again["effct"]).all()
+    assert (bits(lost["x"]) == bits(again["x"])).all() and (bits(lost["P"]) == bits(again["P"])).all()
+    ro = oracle.iterated_update(oracle.default_cfg(max_iter=5, nthreads=8), oracle.KdTree(c["map"]), bad, c["x_prop"], c["x_prop"], c["P"])
+    assert lost["iters"] == ro["iters"] and (lost["effct"] == ro["effct"]).all() and np.abs(lost["x"] - ro["x"]).max() < 1e-9
+    e.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "iterated_update_matches_oracle or fullsize_registration or c1_one_iteration or multi_frame_odometry or ragged"
+    for mode in ("2", "0"):
+        env = dict(os.environ, S2M_SPEC=mode)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-k", sel,
+                            os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_fullsize.py"),
+                            os.path.join(here, "test_map_update.py")], env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, "S2M_SPEC=%s\n%s" % (mode, r.stdout[-3000:])
+        assert " passed" in r.stdout
