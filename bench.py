@@ -631,6 +631,10 @@ def main():
     if rank == 0 and single and side and a.config == "C3" and not a.extrinsic:
         # BASELINE configs[4] on this one device, against the map that is already resident
         out["c5_batch"] = c5_batch(torch, Engine, synth, eng, a)
+        # the same entry point at saturation (24 scans in flight: replicas 0..23, three launch groups of eight)
+        sat = c5_batch(torch, Engine, synth, eng, a, k=24, steps=20, warmup=3)
+        out["c5_batch"]["at_24_in_flight"] = {q: sat[q] for q in ("scans_in_flight", "scans_per_sec", "value", "unit",
+                                                                  "algorithmic_GBps", "frac", "pose_error_vs_truth_m_max")}
     if rank == 0 and single and side and a.config in ("C1", "C2", "C3", "C4") and not a.sequential:
         # side leg, after everything that is timed or compared: what one LiDAR frame costs on the device when the
         # stages either side of the hot path run too.  It changes the engine's map (the scan is merged
@@ -678,7 +682,7 @@ def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5):
             "ms_per_batch": 1e3 * dt / steps, "eskf_iters_per_sec": it / dt,
             "algorithmic_GBps": algo_bytes / dt / 1e9, "frac": algo_bytes / dt / 1e9 / HBM_PEAK_GBS,
             "pose_error_vs_truth_m_max": max(errs),
-            "note": "BASELINE configs[4] on one device: %d scans (seeds 2..%d) vs the resident 5M-pt map, one host "
+            "note": "BASELINE configs[4] shape on one device: %d scans (seeds 2..%d) vs the resident 5M-pt map, one host "
                     "thread, s2m_iterated_update_batch driven by tools/bench_loop.cpp; algorithmic bytes = 88 B per "
                     "eval of a rematch pass + 28 B per eval of a reuse pass" % (k, 1 + k)}
 
