@@ -104,6 +104,7 @@ struct s2m_engine {
     // far-point kernel on that bet (spec_mode: 0 never, 1 by history, 2 always -- the last two for tests)
     int64_t far_first = -1, far_later = -1;
     int spec_mode = 1;
+    bool spec_env = false;  // S2M_SPEC set: the environment overrides the config (A/B runs)
 
     // far-point lists, counters and queue heads shared by the scans of a batched launch; owned by the first handle of
     // a launch group of s2m_iterated_update_batch
@@ -335,7 +336,7 @@ int s2m_config_default(s2m_config *c)
     c->feat_threshold = 100;
     c->cell_size = 0.0f;
     c->device = -1;
-    c->keep_neighbors = 0;
+    c->far_point_bet = 1;
     return S2M_OK;
 }
 
@@ -384,9 +385,10 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
         if (v >= 1 && v <= 3) e->match_group |= v << 8;
     }
     e->dbg = std::getenv("S2M_DEBUG_MATCH") != nullptr;
-    if (const char *g = std::getenv("S2M_SPEC")) {  // 0: always launch the far-point kernel; 2: always bet on an empty list (tests)
+    if (cfg->far_point_bet >= 0 && cfg->far_point_bet <= 2) e->spec_mode = cfg->far_point_bet;
+    if (const char *g = std::getenv("S2M_SPEC")) {  // overrides the config: 0 never bet, 1 by history, 2 always (A/B runs, tests)
         const int v = std::atoi(g);
-        if (v >= 0 && v <= 2) e->spec_mode = v;
+        if (v >= 0 && v <= 2) { e->spec_mode = v; e->spec_env = true; }
     }
     e->no_merge = std::getenv("S2M_NO_MERGE") != nullptr;
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
@@ -441,11 +443,10 @@ int s2m_set_config(s2m_engine *e, const s2m_config *cfg)
     if (rc) return fail(e, rc, "invalid config");
     const float cell = e->cfg.cell_size;
     const int dev = e->cfg.device;
-    const int keep = e->cfg.keep_neighbors;
     e->cfg = *cfg;
     e->cfg.cell_size = cell;
     e->cfg.device = dev;
-    e->cfg.keep_neighbors = keep;
+    if (e->cfg.far_point_bet >= 0 && e->cfg.far_point_bet <= 2 && !e->spec_env) e->spec_mode = e->cfg.far_point_bet;
     return S2M_OK;
 }
 

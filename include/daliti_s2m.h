@@ -65,7 +65,10 @@ typedef struct {
     int32_t feat_threshold;  /* dynamic_effect_featurepoints_threshold, laserMapping.cpp:97 */
     float  cell_size;        /* voxel edge of the GPU map in metres; <= 0 = choose from density */
     int32_t device;          /* HIP device ordinal; < 0 = current device                   */
-    int32_t keep_neighbors;  /* reserved (Nearest_Points are always kept); set 0               */
+    int32_t far_point_bet;   /* 1 (default): a rematch pass whose predecessor in the same position (first pass of a
+                              * scan / later pass) left no point to the far-point kernel runs without that kernel;
+                              * the reduce kernel reports whether the bet held and a lost bet is repaired (results
+                              * are identical either way).  0: never bet.  2: always bet (tests)             */
 } s2m_config;
 
 int s2m_abi_version(void);

@@ -41,7 +41,7 @@ def test_oracle_reproduces_golden(oracle, gold, ext):
 def test_gpu_reproduces_golden(gold, ext):
     from daliti_amd import Engine
     k = "e%d_" % ext
-    e = Engine(max_iter=5, extrinsic_est_en=ext, keep_neighbors=1)
+    e = Engine(max_iter=5, extrinsic_est_en=ext)
     e.map_build(gold["map"])
     e.scan_set(gold["scan"])
     out = e.residual_pass(gold[k + "x0"], True)

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def eng(small_scene):
     from daliti_amd import Engine
-    e = Engine(max_iter=5, keep_neighbors=1, cell_size=0.0)
+    e = Engine(max_iter=5, cell_size=0.0)
     e.map_build(small_scene["map"])
     e.scan_set(small_scene["scan"])
     yield e
@@ -118,7 +118,7 @@ def test_cell_size_invariance(eng, small_scene, cell):
     eng.residual_pass(x, True)
     ref_idx, ref_d2 = eng.get_neighbors()
     ref = eng.get_point_state()
-    e = Engine(keep_neighbors=1, cell_size=cell)
+    e = Engine(cell_size=cell)
     e.map_build(small_scene["map"])
     e.scan_set(small_scene["scan"])
     e.residual_pass(x, True)
@@ -139,7 +139,7 @@ def test_group_width_invariance(eng, small_scene, group):
     ref_idx, ref_d2 = eng.get_neighbors()
     os.environ["S2M_MATCH_GROUP"] = str(group)
     try:
-        e = Engine(keep_neighbors=1)
+        e = Engine()
     finally:
         del os.environ["S2M_MATCH_GROUP"]
     e.map_build(small_scene["map"])
@@ -185,7 +185,7 @@ def test_wide_address_path(eng, small_scene):
     ref_idx, ref_d2 = eng.get_neighbors()
     os.environ["S2M_WIDE_ADDR"] = "1"
     try:
-        e = Engine(keep_neighbors=1)
+        e = Engine()
     finally:
         del os.environ["S2M_WIDE_ADDR"]
     e.map_build(small_scene["map"])
@@ -204,7 +204,7 @@ def test_map_share(eng, small_scene):
     eng.scan_set(small_scene["scan"])
     ref_out = eng.residual_pass(x, True)
     ref_idx, ref_d2 = eng.get_neighbors()
-    e = Engine(keep_neighbors=1)
+    e = Engine()
     e.map_share(eng)
     assert e.map_size() == eng.map_size()
     e.scan_set(small_scene["scan"][::-1].copy())          # its own scan (reversed order)
@@ -223,7 +223,7 @@ def test_map_share(eng, small_scene):
 
 def test_edge_cases(oracle, small_scene):
     from daliti_amd import Engine, S2MError
-    e = Engine(keep_neighbors=1, cell_size=0.25)
+    e = Engine(cell_size=0.25)
     x = small_scene["x_prop"]
     with pytest.raises(S2MError):          # no map yet
         e.residual_pass(x, True)
@@ -284,7 +284,7 @@ def test_map_permutation_invariance(small_scene):
     x = small_scene["x_prop"]
     res = []
     for m in (small_scene["map"], small_scene["map"][perm]):
-        e = Engine(keep_neighbors=1)
+        e = Engine()
         e.map_build(m)
         e.scan_set(small_scene["scan"])
         out = e.residual_pass(x, True)

@@ -180,6 +180,15 @@ def test_bet_on_no_far_points_is_exact_whether_won_or_lost(oracle):
     for r in runs[1:]:
         assert r["iters"] == runs[0]["iters"] and (r["effct"] == runs[0]["effct"]).all()
         assert (bits(r["x"]) == bits(runs[0]["x"])).all() and (bits(r["P"]) == bits(runs[0]["P"])).all()
+    # the same through the config field: never bet / always bet (every pass of this scan with far points loses)
+    for bet in (0, 2):
+        h = Engine(max_iter=5, far_point_bet=bet)
+        h.map_share(e)
+        h.scan_set(c["scan"])
+        r = h.iterated_update(c["x_prop"], c["x_prop"], c["P"])
+        assert r["iters"] == runs[0]["iters"] and (r["effct"] == runs[0]["effct"]).all(), bet
+        assert (bits(r["x"]) == bits(runs[0]["x"])).all() and (bits(r["P"]) == bits(runs[0]["P"])).all(), bet
+        h.close()
     # a different scan on the same handle whose LATER pass does have far points: far outliers that no pose can fix
     rs = np.random.RandomState(5)
     bad = c["scan"].copy()
