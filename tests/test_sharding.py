@@ -327,3 +327,24 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_host_collective_form_equals_single_handle():
+    """`bench.py --collective host --shards 4`: one process, four handles holding the shard_range pieces of ONE C1 scan
+    on one GPU, blocks summed on the host -- the registered pose equals the plain single-handle run bit for bit (aligned
+    power-of-two shards: 2 500 points each are NOT multiples of 64, so here only to summation order) and the line says
+    what ran."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    outs = []
+    for extra in (["--collective", "host", "--shards", "4"], []):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3", "--warmup", "1",
+                            "--no-cpu"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(json.loads(r.stdout.rstrip().splitlines()[-1]))
+    multi, one = outs
+    assert "s2m_iterated_update_multi" in multi["config"]["parallelism"] and multi["scaling"] == "strong"
+    assert multi["iters_per_step"] == one["iters_per_step"]
+    assert np.abs(np.array(multi["final_pos"]) - np.array(one["final_pos"])).max() < 1e-12
