@@ -833,6 +833,12 @@ def newest_pmc(batched=False):
     return None, None
 
 
+def per_pass(k, name):
+    """launches of kernel `name` per rematch pass (= per launch of match_rows) in the profiled run"""
+    calls, rows = k[name].get("calls"), k["match_rows"].get("calls")
+    return (calls / rows) if (calls and rows) else 1.0
+
+
 def pmc_traffic():
     """Fabric traffic of one rematch pass (search kernels + reduce<FIT>) from FETCH_SIZE / WRITE_SIZE.
     This is a STATIC figure of the profiled build, not something measured in this run -- the label says so.
@@ -844,7 +850,10 @@ def pmc_traffic():
         return None, None
     try:
         k = doc["kernels"]
-        tot = sum((2.0 * k[name]["FETCH_SIZE_avg"] + k[name]["WRITE_SIZE_avg"]) * 1024.0 for name in REMATCH_KERNELS)
+        # per rematch PASS: the far-point kernel does not run in every pass (the bet on an empty list), so every
+        # kernel's per-launch average is weighted with its launches per first-shell launch
+        tot = sum((2.0 * k[name]["FETCH_SIZE_avg"] + k[name]["WRITE_SIZE_avg"]) * 1024.0 * per_pass(k, name)
+                  for name in REMATCH_KERNELS)
     except KeyError:
         return None, None
     return tot, "%s (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the profiled build '%s', " \
@@ -862,10 +871,10 @@ def pmc_issue(pass_ms):
         return None
     try:
         k = doc["kernels"]
-        valu = sum(k[name]["SQ_INSTS_VALU_avg"] for name in REMATCH_KERNELS)
-        wait = sum(k[name]["SQ_WAIT_ANY_avg"] for name in REMATCH_KERNELS)
-        cyc = sum(k[name]["SQ_WAVE_CYCLES_avg"] for name in REMATCH_KERNELS)
-        act = sum(k[name]["SQ_ACTIVE_INST_ANY_avg"] for name in REMATCH_KERNELS)
+        valu = sum(k[name]["SQ_INSTS_VALU_avg"] * per_pass(k, name) for name in REMATCH_KERNELS)
+        wait = sum(k[name]["SQ_WAIT_ANY_avg"] * per_pass(k, name) for name in REMATCH_KERNELS)
+        cyc = sum(k[name]["SQ_WAVE_CYCLES_avg"] * per_pass(k, name) for name in REMATCH_KERNELS)
+        act = sum(k[name]["SQ_ACTIVE_INST_ANY_avg"] * per_pass(k, name) for name in REMATCH_KERNELS)
     except KeyError:
         return None
     floor_ms = valu * VALU_CYCLES / (SIMDS * CLOCK_HZ) * 1e3
