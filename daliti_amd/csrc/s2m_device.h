@@ -2,7 +2,7 @@
 //
 // Map layout in HBM ("brick grid", replaces the ikd-Tree of eskf_lio/include/ikd-Tree/):
 //   pts   : M x float4 {x, y, bitcast(sorted position), z} (make_map_point), sorted by (brick, cell-in-brick,
-//           caller index), followed by 8 sentinel points (padding targets of the search kernels' batches);
+//           caller index), followed by 32 sentinel points (padding targets of the search kernels' batches);
 //           one 16-byte load per candidate, a cell's points are contiguous, the cells of one
 //           x-row of a brick are contiguous.  A neighbour is identified by its SORTED POSITION on the whole
 //           per-iteration path: the plane fit gathers its five points from this array (the five neighbours of a
@@ -44,7 +44,7 @@ struct Grid {
     const float4 *pts;
     const uint32_t *pidx;
     int64_t m;
-    uint32_t sent_off;  // byte offset of the sentinel block pts[m..m+8) (valid while it fits 32 bits), else 0
+    uint32_t sent_off;  // byte offset of the sentinel block pts[m..m+32) (valid while it fits 32 bits), else 0
 };
 
 // Element of the sorted point array Grid::pts: {x, y, bitcast(sorted position), z}.  The position sits in the

@@ -30,7 +30,8 @@ constexpr int kBboxScratchFloats = (kBboxBlocks + 1) * 6;
 hipError_t cloud_bbox(const float *xyz, int64_t stride, int64_t n, float *scratch, Mailbox &mail, float lo[3], float hi[3],
                       hipStream_t st);
 
-constexpr int kSentinelPoints = 8;  // pts[m .. m+8): padding targets of the search kernels' point batches
+constexpr int kSentinelPoints = 32;  // pts[m .. m+32): padding targets of the search kernels' point batches (8 slots x up to 4 lanes
+                                     // that share a run point by point)
 struct MapBuffers {
     // owned by the engine, (re)allocated by build_map
     float4 *pts = nullptr;

@@ -305,7 +305,7 @@ static hipError_t ensure_scratch(MapBuffers &buf, int64_t m)
 
 static hipError_t put_sentinels(float4 *pts, int64_t m, hipStream_t st)
 {
-    // eight extra elements: the sentinel points the search kernels load for the padding slots of a batch
+    // kSentinelPoints extra elements: the sentinel points the search kernels load for the padding slots of a batch
     // (far enough for the squared distance to overflow to +inf; index word 0xffffffff)
     struct Block {
         uint32_t w[kSentinelPoints][4];

@@ -15,7 +15,8 @@
 // exact 5-NN).  The position doubles as the gather address of the plane fit (s2m_reduce.hip).
 //
 // Two kernels, because measured cost is a long tail of far queries on top of the first-shell work:
-//   match_rows<G> : G lanes (default 2) per scan point scan the 3x3x3 cells around it as nine x-ROWS: the three
+//   match_rows<G> : G lanes (default 2) per scan point scan the 3x3x3 cells around it as nine x-ROWS (the G lanes read
+//                   adjacent points of every run): the three
 //                   cells of a row are one contiguous run of points (two when the row straddles a brick), the
 //                   home row first, the other rows trimmed by its 5th-best distance, all of a lane's runs walked
 //                   as one flat sequence of 8-point batches, three batches (24 loads) in flight per trip.  If the
@@ -506,25 +507,48 @@ __device__ __forceinline__ void seg_run(const TabQuad &q, int sx0, int sx1, int 
     if (lo <= hi) { s = sel4(q, lo - sx0); e = sel4(q, hi - sx0 + 1); }
 }
 
-// eight candidates pts[i .. i+8) clipped to e; slots beyond e (all of them when i >= e) read the sentinel block
-template <bool WIDE>
-__device__ __forceinline__ void load_batch(const Grid &g, uint32_t i, uint32_t e, float4 (&p)[8])
+// eight candidates of the run [i, e) for lane j of the S lanes that share it: pts[i + S u + j], u = 0..7 -- the S lanes
+// of a query read ADJACENT points in every load instruction, so a pair's two 16-byte requests fall into one cache line
+// (the texture addresser spends a cycle per distinct line and instruction: with a chunk per lane every request was its
+// own line, and at saturation that unit was the busiest one, TA_BUSY 63 % of the batched first-shell kernel).  Slots
+// beyond e (all of them when i >= e) read the sentinel block.  S = 1, j = 0: eight consecutive points.
+#ifndef S2M_ROWS_PRED
+#define S2M_ROWS_PRED 0  // padding slots of match_rows' batches: 1 = the load is skipped (exec-masked), 0 = it reads the sentinel block
+#endif
+template <bool WIDE, int S = 1, bool PRED = false>
+__device__ __forceinline__ void load_batch(const Grid &g, uint32_t i, uint32_t e, float4 (&p)[8], uint32_t j = 0)
 {
+    static_assert(8 * S <= kSentinelPoints, "sentinel block too short");
     const float4 *__restrict__ pts = g.pts;
-    const uint32_t left = e > i ? e - i : 0u;
+    const uint32_t left = e > i + j ? e - i - j : 0u;  // slot u is real iff S u < left
+    if (PRED) {
+        // padding slots issue no request at all (four slots in ten are padding, and the texture addresser moves 64 bytes a
+        // clock whatever they hold); their registers keep whatever was there and consume_batch sets the distance to +inf
+        const uint32_t off = (i + j) << 4;
+        const char *base = reinterpret_cast<const char *>(pts);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            asm volatile("" : "=v"(p[u].x), "=v"(p[u].y), "=v"(p[u].z), "=v"(p[u].w));  // unspecified, not undefined
+            if ((uint32_t)(S * u) < left)
+                p[u] = WIDE ? pts[i + j + S * u] : *reinterpret_cast<const float4 *>(base + (size_t)off + 16 * S * u);
+        }
+        return;
+    }
     if (WIDE) {
         const uint32_t sent = (uint32_t)g.m;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) p[u] = pts[((uint32_t)u < left) ? i + u : sent + u];
+        for (int u = 0; u < 8; ++u) p[u] = pts[((uint32_t)(S * u) < left) ? i + j + S * u : sent + S * u];
     } else {
-        const uint32_t off = i << 4, soff = g.sent_off;
+        const uint32_t off = (i + j) << 4, soff = g.sent_off;
         const char *base = reinterpret_cast<const char *>(pts);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            p[u] = *reinterpret_cast<const float4 *>(base + (size_t)(((uint32_t)u < left) ? off : soff) + 16 * u);
+            p[u] = *reinterpret_cast<const float4 *>(base + (size_t)(((uint32_t)(S * u) < left) ? off : soff) + 16 * S * u);
     }
 }
-__device__ __forceinline__ void consume_batch(const float4 (&p)[8], float wx, float wy, float wz, u64 (&t)[kK])
+// `left` (PRED): slots u with S u >= left hold no point
+template <int S = 1, bool PRED = false>
+__device__ __forceinline__ void consume_batch(const float4 (&p)[8], float wx, float wy, float wz, u64 (&t)[kK], uint32_t left = 0)
 {
     typedef float f2 __attribute__((ext_vector_type(2)));
     const f2 wxy = {wx, wy};
@@ -536,6 +560,7 @@ __device__ __forceinline__ void consume_batch(const float4 (&p)[8], float wx, fl
         const float dz = wz - map_point_z(p[u]);
         float d = sq.x + sq.y;
         d = d + dz * dz;
+        if (PRED) d = ((uint32_t)(S * u) < left) ? d : INFINITY;
         key[u] = make_key(d, map_point_pos(p[u]));
     }
 #ifdef S2M_EXP_BATCH_REJECT
@@ -550,6 +575,13 @@ __device__ __forceinline__ void consume_batch(const float4 (&p)[8], float wx, fl
 }
 
 constexpr int kRunSlots = 16;  // 8 rows x 2 segments besides the home row
+#ifndef S2M_ROWS_EXT
+#define S2M_ROWS_EXT 0  // experiment (round 3, DESIGN "tried and rejected"): 2 or 3 = the first-shell kernel finishes the points whose
+                        // radius is known in place
+#endif
+#ifndef S2M_ROWS_SHARE
+#define S2M_ROWS_SHARE 1  // the G lanes of a query read adjacent points of the same run (0: a chunk of the run each)
+#endif
 
 // position in a lane's chain of runs: run k of nr, next batch at i, run end e (i = e = 0 once exhausted)
 struct RunCursor {
@@ -575,6 +607,8 @@ __device__ __forceinline__ void match_rows_body(const MatchArgs &a, uint2 *__res
     const int qi = tid / G;
     const int j = tid % G;
     if (qi >= a.n) return;  // group-uniform
+    constexpr int kShare = (S2M_ROWS_SHARE && !S2M_ROWS_EXT && G <= 4) ? G : 1;  // lanes that share a run point by point
+    constexpr bool kPred = S2M_ROWS_PRED != 0;
     const Query q = make_query(g, a.pose, a.sx[qi], a.sy[qi], a.sz[qi]);
     S2M_ROWS_STAMP(0, q.cx);
     // x extent of the neighbourhood inside the grid; segment A lies in brick bA, segment B (if any) in bA + 1
@@ -616,9 +650,15 @@ __device__ __forceinline__ void match_rows_body(const MatchArgs &a, uint2 *__res
 #pragma unroll
     for (int k = 0; k < kK; ++k) t[k] = kEmptyKey;
     uint32_t nr = 0;
-    // this lane's contiguous share of the run [s, e): ceil(len / G) rounded up to whole batches
+    // the G lanes of a query share every run point by point (load_batch): all of them list the whole run and walk it
+    // in steps of 8 G points.  (S2M_ROWS_SHARE=0, the round-2 form: a contiguous chunk of ceil(len / G) points, rounded up
+    // to whole batches, per lane.)
     auto push_run = [&](uint32_t s, uint32_t e) {
         if (s >= e) return;
+        if (kShare > 1) {
+            runs[nr * 256 + threadIdx.x] = make_uint2(s, e); ++nr;
+            return;
+        }
         const uint32_t chunk = (((e - s) + 8u * G - 1u) / (8u * G)) * 8u;
         const uint32_t ms = s + (uint32_t)j * chunk, me = min(ms + chunk, e);
         if (ms < me) { runs[nr * 256 + threadIdx.x] = make_uint2(ms, me); ++nr; }
@@ -631,7 +671,7 @@ __device__ __forceinline__ void match_rows_body(const MatchArgs &a, uint2 *__res
         c.k = 0;
         { const uint2 r0 = runs[threadIdx.x]; c.i = r0.x; c.e = r0.y; }
         auto advance = [&]() {
-            c.i += 8u;
+            c.i += 8u * kShare;
             if (c.i >= c.e) {
                 ++c.k;
                 c.i = 0u; c.e = 0u;
@@ -640,13 +680,16 @@ __device__ __forceinline__ void match_rows_body(const MatchArgs &a, uint2 *__res
         };
         while (c.k < nr) {
             float4 p[NB][8];
+            uint32_t left[NB];
+            const uint32_t jj = kShare > 1 ? (uint32_t)j : 0u;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
-                load_batch<WIDE>(g, c.i, c.e, p[b]);
+                left[b] = c.e > c.i + jj ? c.e - c.i - jj : 0u;
+                load_batch<WIDE, kShare, kPred>(g, c.i, c.e, p[b], jj);
                 advance();
             }
 #pragma unroll
-            for (int b = 0; b < NB; ++b) consume_batch(p[b], q.wx, q.wy, q.wz, t);
+            for (int b = 0; b < NB; ++b) consume_batch<kShare, kPred>(p[b], q.wx, q.wy, q.wz, t, left[b]);
         }
     };
     // phase 3a: the home row (r = 4), all G lanes of the group on it
