@@ -1730,13 +1730,15 @@ void launch_match_batch(const BatchArgs &b, hipStream_t st)
     const bool wide = b.grid.sent_off == 0 && b.grid.m != 0;
     static const int nb_env = std::getenv("S2M_BATCH_NB") ? std::atoi(std::getenv("S2M_BATCH_NB")) : 0;  // dev knobs
     static const int g_env = std::getenv("S2M_BATCH_G") ? std::atoi(std::getenv("S2M_BATCH_G")) : 0;
-    const int G = g_env == 1 ? 1 : 2;
+    const int G = g_env == 1 ? 1 : (g_env == 4 ? 4 : 2);
     const int64_t threads = (int64_t)b.n_max * G;
     const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)b.k);
     if (wide) hipLaunchKernelGGL((match_rows_batch<2, true, 2>), dim3((unsigned)(((int64_t)b.n_max * 2 + 255) / 256), (unsigned)b.k), dim3(256), 0, st, b);
     else if (G == 1 && nb_env == 1) hipLaunchKernelGGL((match_rows_batch<1, false, 1>), grid, dim3(256), 0, st, b);
     else if (G == 1 && nb_env == 3) hipLaunchKernelGGL((match_rows_batch<1, false, 3>), grid, dim3(256), 0, st, b);
     else if (G == 1) hipLaunchKernelGGL((match_rows_batch<1, false, 2>), grid, dim3(256), 0, st, b);
+    else if (G == 4 && nb_env == 1) hipLaunchKernelGGL((match_rows_batch<4, false, 1>), grid, dim3(256), 0, st, b);
+    else if (G == 4) hipLaunchKernelGGL((match_rows_batch<4, false, 2>), grid, dim3(256), 0, st, b);
     else if (nb_env == 1) hipLaunchKernelGGL((match_rows_batch<2, false, 1>), grid, dim3(256), 0, st, b);
     else if (nb_env == 3) hipLaunchKernelGGL((match_rows_batch<2, false, 3>), grid, dim3(256), 0, st, b);
     else hipLaunchKernelGGL((match_rows_batch<2, false, 2>), grid, dim3(256), 0, st, b);
