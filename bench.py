@@ -884,6 +884,14 @@ def pmc_issue(pass_ms):
          "note": "VALU wave-instructions x %d cycles / (%d SIMDs x %.1f GHz) / measured pass; fp64 min/max and the "
                  "fp64 Jacobian row issue at half rate, so the true issue floor is up to 2x this figure" % (
                      VALU_CYCLES, SIMDS, CLOCK_HZ / 1e9)}
+    try:   # busiest unit: share of the search kernels' run time in which the texture addressers (L1 request path) are busy
+        ta = sum(k[name]["TA_BUSY_avr_avg"] * per_pass(k, name) for name in REMATCH_KERNELS)
+        gui = sum(k[name]["GRBM_GUI_ACTIVE_avg"] * per_pass(k, name) for name in REMATCH_KERNELS)
+        o["ta_busy_share"] = ta * 288 / 256 / (gui / 8)
+        o["ta_note"] = ("TA_BUSY_avr (average over the 288 addresser instances of the counter, 256 of them on active CUs) / "
+                        "(GRBM_GUI_ACTIVE / 8 XCDs), kernels weighted by launches per pass")
+    except KeyError:
+        pass
     bpath, bdoc = newest_pmc(batched=True)
     if bdoc:   # the same reading for the batched launches (one grid for K scans), from the C5 profile
         o["batched"] = dict(bdoc["batched"], source=os.path.relpath(bpath, ROOT))

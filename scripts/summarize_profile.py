@@ -13,6 +13,11 @@ src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 
 
+# TA_BUSY_avr averages the 9 x 4 x 8 = 288 addresser instances the counter is defined over; 256 of them belong to active
+# CUs.  GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+TA_INSTANCES, CUS, XCDS = 288, 256, 8
+
+
 def short(name):
     for k in ("match_rows_batch", "match_hard32_batch", "match_hard_batch", "match_hard32", "reduce_kernel_batch<false, true>", "reduce_kernel_batch<false, false>",
               "reduce_kernel_batch<true, true>", "reduce_kernel_batch<true, false>"):
@@ -35,7 +40,7 @@ if stats:
         if k:
             summary[k].update(calls=int(r["Calls"]), avg_ns=float(r["AverageNs"]), min_ns=float(r["MinNs"]),
                               max_ns=float(r["MaxNs"]))
-for sub in ("fetch", "write", "sq", "tcc"):
+for sub in ("fetch", "write", "sq", "tcc", "ta", "tcp"):
     for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
@@ -73,6 +78,15 @@ if sq_files and os.path.exists(bj) and os.path.getsize(bj):
                            scans_per_sec_unprofiled=None,
                            note="sums over every dispatch of match_rows_batch / match_hard_batch / reduce_kernel_batch of the "
                                 "profiled run divided by the scans it registered; issue floor = VALU x 2 cycles / (1024 SIMDs x 2.4 GHz)")
+            ta_files = glob.glob(os.path.join(src, "ta", "**", "*counter_collection.csv"), recursive=True)
+            if ta_files:   # share of the batched kernels' run time in which the texture addressers are busy
+                ta = collections.defaultdict(float)
+                for r in csv.DictReader(open(ta_files[0])):
+                    k = short(r["Kernel_Name"])
+                    if k and "_batch" in k:
+                        ta[r["Counter_Name"]] += float(r["Counter_Value"])
+                if ta.get("GRBM_GUI_ACTIVE"):
+                    batched["ta_busy_share"] = ta["TA_BUSY_avr"] * TA_INSTANCES / CUS / (ta["GRBM_GUI_ACTIVE"] / XCDS)
             ub = os.path.join(src, "bench.json")
             if os.path.exists(ub) and os.path.getsize(ub):
                 u = json.loads(open(ub).read().strip().splitlines()[-1])
