@@ -579,6 +579,9 @@ constexpr int kRunSlots = 16;  // 8 rows x 2 segments besides the home row
 #define S2M_ROWS_EXT 0  // experiment (round 3, DESIGN "tried and rejected"): 2 or 3 = the first-shell kernel finishes the points whose
                         // radius is known in place
 #endif
+#ifndef S2M_ROWS_QUADS
+#define S2M_ROWS_QUADS 0  // experiment: the two prefix words of an outer-row piece as ONE 4-byte-aligned dwordx4 (half the requests)
+#endif
 #ifndef S2M_ROWS_SHARE
 #define S2M_ROWS_SHARE 1  // the G lanes of a query read adjacent points of the same run (0: a chunk of the run each)
 #endif
@@ -731,12 +734,22 @@ __device__ __forceinline__ void match_rows_body(const MatchArgs &a, uint2 *__res
         const int la = max(xa, x_lo), ha = min(xb, ax1);  // piece inside segment A
         if (idA[r] && la <= ha) {
             const uint32_t *tb = g.tab + (int64_t)(idA[r] - 1) * kBrickStride + (rowbit[r] << 3);
+#if S2M_ROWS_QUADS
+            const TabQuad qd = *reinterpret_cast<const TabQuad *>(tb + (la & 7));
+            sA[r] = qd.w[0]; eA[r] = sel4(qd, ha - la + 1);
+#else
             sA[r] = tb[la & 7]; eA[r] = tb[(ha & 7) + 1];
+#endif
         }
         const int lb = max(xa, bx0), hb = min(xb, x_hi);  // piece inside segment B
         if (idB[r] && lb <= hb) {
             const uint32_t *tb = g.tab + (int64_t)(idB[r] - 1) * kBrickStride + (rowbit[r] << 3);
+#if S2M_ROWS_QUADS
+            const TabQuad qd = *reinterpret_cast<const TabQuad *>(tb + (lb & 7));
+            sB[r] = qd.w[0]; eB[r] = sel4(qd, hb - lb + 1);
+#else
             sB[r] = tb[lb & 7]; eB[r] = tb[(hb & 7) + 1];
+#endif
         }
     }
 #pragma unroll
