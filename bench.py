@@ -26,10 +26,15 @@ world size differs from ``--gpus`` is refused.
 
 N > 1, ``--mode sharded`` (default except C5): ONE scan of the config's size is split over the ranks with
 shard_range() (north star: "a single scan's points shard across GPUs"; 65,536 / 8 = 8,192 points per GPU
-at N = 8 for C3), the map is replicated, and the 158-double normal block is summed once per iteration --
-``--collective rccl`` (default): one RCCL all-reduce issued from the engine's C++ loop; that is
-``"scaling": "strong"``.  ``--scaling weak`` grows the scan to N x beams instead (one config-sized shard
-per rank); the strong run also reports it as the side object ``weak_scaling``.
+at N = 8 for C3), the map is replicated, and the 158-double normal block is summed once per iteration; that is
+``"scaling": "strong"``.  Two forms of the sum are built into the engine's C++ loop: ``--collective rccl`` (north
+star: one RCCL all-reduce per iteration on the engine's stream, then a one-block publish kernel) and ``--collective
+shm`` (every rank's reduce kernel publishes into that rank's pinned page as on one GPU; the ranks' host threads
+exchange the 1.3 KB through POSIX shared memory and sum pairwise over the rank index: no collective launch).  The
+default ``--collective auto`` attaches both, times ten steps of each before the timed region, uses the lower one
+("whichever measures lower") and prints both figures in ``config.collective_probe_ms_per_step``.
+``--scaling weak`` grows the scan to N x beams instead (one config-sized shard per rank); the strong run also
+reports it as the side object ``weak_scaling``.
 ``--collective host --shards S`` is the single-process form (one rank drives S handles -- S devices, or S
 shards on one device -- and sums the S pinned blocks on the host, no collective library).
 
@@ -77,9 +82,12 @@ def parse(argv=None):
                     help="auto: replicas for C5, sharded otherwise")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
                     help="sharded mode only; auto = strong: ONE scan of the config's size split over the ranks")
-    ap.add_argument("--collective", default="rccl", choices=["rccl", "host"],
-                    help="rccl: one rank per GPU, RCCL all-reduce of the block; host: ONE process drives --shards "
-                         "handles and sums their pinned blocks itself (s2m_iterated_update_multi)")
+    ap.add_argument("--collective", default="auto", choices=["auto", "rccl", "shm", "host"],
+                    help="one rank per GPU: rccl = RCCL all-reduce of the block from the engine's loop; shm = the ranks' "
+                         "host threads exchange the blocks through POSIX shared memory (one node, no collective library); "
+                         "auto = both are attached and timed for a few steps before the timed region and the lower one "
+                         "is used (both numbers are printed).  host: ONE process drives --shards handles and sums their "
+                         "pinned blocks itself (s2m_iterated_update_multi)")
     ap.add_argument("--shards", type=int, default=0,
                     help="--collective host: number of handles (default: the visible devices); handle i uses device "
                          "i %% device_count, so more shards than devices puts several shards on one device")
@@ -113,7 +121,7 @@ def parse(argv=None):
 # ---- self-launch: `python bench.py --gpus N` without a launcher ----------------------------------------
 def needs_self_launch(a, env):
     """N > 1 ranks are wanted and nobody has started them: no torch.distributed.run environment."""
-    return a.gpus > 1 and a.collective == "rccl" and "WORLD_SIZE" not in env and "RANK" not in env
+    return a.gpus > 1 and a.collective != "host" and "WORLD_SIZE" not in env and "RANK" not in env
 
 
 def self_launch_argv(a, argv, port):
@@ -211,7 +219,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.all_on_device0:
         local_rank = 0
-    if a.collective == "rccl" and world != a.gpus:
+    if a.collective != "host" and world != a.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d (start one rank per GPU, or let bench.py launch "
                          "them: run it without WORLD_SIZE in the environment)" % (a.gpus, world))
     if a.collective == "host" and world != 1:
@@ -345,31 +353,68 @@ def main():
 
     blk = torch.zeros(160, dtype=torch.float64, device="cuda")
     builtin_comm = False
-    if sharded and a.backend == "nccl" and not a.torch_collective:
+    exchange = None        # "shm" | "rccl" once one of the engine's own exchanges is attached
+    exchange_probe = {}    # --collective auto: ms/step of each form over a few steps before the timed region
+
+    def all_ok(flag):      # every rank, or nobody
+        if not dist.is_initialized():
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def try_shm():
+        """The ranks' host threads exchange the blocks through a POSIX shared-memory segment (one node)."""
+        import secrets
+        tok = [secrets.token_hex(4) if rank == 0 else None]
+        if dist.is_initialized():
+            dist.broadcast_object_list(tok, src=0)
+        name = "/s2m_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tok[0])
+        try:
+            eng.comm_init_shm(name, world, rank)
+            ok = True
+        except Exception as ex:  # noqa: BLE001 - reported, then another form is taken
+            ok = False
+            sys.stderr.write("rank %d: s2m_comm_init_shm failed (%s)\n" % (rank, ex))
+        ok = all_ok(ok)
+        if not ok:
+            eng.comm_destroy()
+        return ok
+
+    def try_rccl():
         # the engine's own RCCL communicator: the all-reduce is issued from the C++ loop on the engine's
         # stream; torch.distributed only ships the 128-byte unique id.  Every rank first proves it can reach
         # RCCL (a rank that cannot must not leave the others blocked inside ncclCommInitRank); any failure
-        # sends all ranks to the torch.distributed callback instead
-        def all_ok(flag):
-            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(t.item())
-
+        # sends all ranks to another form
+        if a.backend != "nccl":
+            return False
         try:
             probe = Engine.comm_unique_id()
         except Exception as ex:  # noqa: BLE001 - reported, then the fallback path is taken
             probe = None
             sys.stderr.write("rank %d: engine RCCL communicator unavailable (%s)\n" % (rank, ex))
-        if all_ok(probe is not None):
-            ids = [probe if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            try:
-                eng.comm_init(ids[0], world, rank)
-                ok = True
-            except Exception as ex:  # noqa: BLE001
-                ok = False
-                sys.stderr.write("rank %d: s2m_comm_init failed (%s)\n" % (rank, ex))
-            builtin_comm = all_ok(ok)
+        if not all_ok(probe is not None):
+            return False
+        ids = [probe if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        try:
+            eng.comm_init(ids[0], world, rank)
+            ok = True
+        except Exception as ex:  # noqa: BLE001
+            ok = False
+            sys.stderr.write("rank %d: s2m_comm_init failed (%s)\n" % (rank, ex))
+        ok = all_ok(ok)
+        if not ok:
+            eng.comm_destroy()
+        return ok
+
+    if sharded and not a.torch_collective:
+        order = {"auto": ("shm", "rccl"), "shm": ("shm", "rccl"), "rccl": ("rccl", "shm")}[a.collective]
+        for form in order:   # the first form every rank can attach; `auto` weighs the two against each other further down
+            if (try_shm if form == "shm" else try_rccl)():
+                exchange = form
+                break
+        builtin_comm = exchange is not None
 
     from daliti_amd.engine import IterLog
     x_prop0, P0 = filt[0][1], filt[0][2]
@@ -467,6 +512,24 @@ def main():
             dt = float(t.item())
         return dt, it, rm
 
+    if sharded and a.collective == "auto" and exchange == "shm" and a.backend == "nccl" and world > 1:
+        # "pick RCCL or a host-side gather, whichever measures lower" -- a few steps of each, the maximum over
+        # the ranks decides (the same number on every rank), the loser is detached
+        def probe_ms():
+            run_steps(3)
+            d, _, _ = timed(10)
+            return 1e3 * d / 10
+        exchange_probe["shm"] = probe_ms()
+        eng.comm_destroy()
+        if try_rccl():
+            exchange_probe["rccl"] = probe_ms()
+            if exchange_probe["rccl"] < exchange_probe["shm"]:
+                exchange = "rccl"
+            else:
+                eng.comm_destroy()
+        if exchange == "shm" and not try_shm():
+            raise SystemExit("the shared-memory exchange could not be re-attached")
+
     # the box's own copy peak (second denominator of the roofline): measured here, before the timed region, because it
     # is independent of it and because ~40 ms of streaming copies also bring the device clocks up -- with the driver's
     # --steps 20 --warmup 5 the whole timed region is 3 ms and would otherwise run on a chip that has just left idle
@@ -503,9 +566,12 @@ def main():
     n_per_scan = n_scan_total if (sharded or host_multi) else n_local // max(len(scans), 1)
 
     if sharded:
-        par = ("scan points sharded x%d (%s scaling: %d-pt scan, %d per rank), map replicated, RCCL all-reduce of 158 f64 "
-               "per iteration (%s)" % (world, scaling, n_scan_total, n_local,
-                                       "engine-owned communicator" if builtin_comm else "torch.distributed callback"))
+        how = {"rccl": "RCCL all-reduce of 158 f64 per iteration (engine-owned communicator)",
+               "shm": "the ranks' 160-double blocks exchanged through POSIX shared memory by the host threads and summed "
+                      "pairwise over the rank index on every rank (no collective library)",
+               None: "all-reduce of 158 f64 per iteration through the torch.distributed callback"}[exchange]
+        par = "scan points sharded x%d (%s scaling: %d-pt scan, %d per rank), map replicated, %s" % (
+            world, scaling, n_scan_total, n_local, how)
     elif host_multi:
         par = ("single process, %d handles on %d device(s) (%s scaling: %d-pt scan, %d per handle), one map per device, "
                "the %d pinned 160-double blocks summed on the host in handle order, ONE fp64 update; no collective "
@@ -540,6 +606,8 @@ def main():
             "scans_per_gpu": len(scans) if not host_multi else 1,
             "map_points": m_map,
             "parallelism": par,
+            "collective": (exchange or "torch.distributed callback") if sharded else None,
+            "collective_probe_ms_per_step": exchange_probe or None,
             "cell_size_m": info["cell"],
             "mean_points_per_cell": info["mean_per_cell"],
         },

@@ -7,9 +7,15 @@
 // RCCL is resolved at run time (dlopen) so that single-GPU users carry no dependency on it; inside a
 // PyTorch process the already loaded librccl is reused.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
+#include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -89,6 +95,69 @@ void comm_destroy(Comm &c)
 {
     if (c.handle && g_api.CommDestroy) (void)g_api.CommDestroy((ncclComm_t)c.handle);
     c = Comm();
+}
+
+// ---- host shared-memory exchange (s2m_comm.h) --------------------------------------------------------------------
+bool shm_exchange_init(ShmExchange &x, const char *name, int nranks, int rank, std::string &err)
+{
+    shm_exchange_destroy(x);
+    if (!name || name[0] != '/' || std::strlen(name) >= sizeof(x.name) || std::strchr(name + 1, '/')) {
+        err = "shared-memory name must look like \"/something\"";
+        return false;
+    }
+    const size_t bytes = (size_t)2 * nranks * kShmSlotDoubles * sizeof(double);
+    // every rank may be the first to arrive: create-or-open, size it (a fresh segment is zero-filled: sequence 0 = nothing
+    // published; the first exchange carries sequence 1).  The name must be unique per job: a stale segment of a crashed
+    // job with the same name would carry old sequence words.
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) { err = std::string("shm_open: ") + std::strerror(errno); return false; }
+    if (ftruncate(fd, (off_t)bytes) != 0) { err = std::string("ftruncate: ") + std::strerror(errno); close(fd); return false; }
+    void *base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) { err = std::string("mmap: ") + std::strerror(errno); return false; }
+    x.base = base;
+    x.bytes = bytes;
+    x.nranks = nranks;
+    x.rank = rank;
+    x.seq = 0;
+    std::snprintf(x.name, sizeof(x.name), "%s", name);
+    return true;
+}
+
+bool shm_exchange(ShmExchange &x, const double *block, int count, double *out, std::string &err)
+{
+    if (!x.base || count < 1 || count >= kShmSlotDoubles) { err = "shared-memory exchange not initialised"; return false; }
+    const unsigned long long seq = ++x.seq;
+    double *slots = static_cast<double *>(x.base) + (size_t)(seq & 1ull) * x.nranks * kShmSlotDoubles;
+    double *mine = slots + (size_t)x.rank * kShmSlotDoubles;
+    std::memcpy(mine, block, (size_t)count * sizeof(double));
+    __atomic_store_n(reinterpret_cast<unsigned long long *>(mine + kShmSlotDoubles - 1), seq, __ATOMIC_RELEASE);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < x.nranks; ++r) {
+        const double *slot = slots + (size_t)r * kShmSlotDoubles;
+        const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(slot + kShmSlotDoubles - 1);
+        for (long spin = 0;; ++spin) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+            __builtin_ia32_pause();
+            if ((spin & 0xfffff) == 0xfffff &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) {
+                err = "shared-memory exchange: rank " + std::to_string(r) + " did not publish sequence " + std::to_string(seq) +
+                      " within 60 s";
+                return false;
+            }
+        }
+        std::memcpy(out + (size_t)r * count, slot, (size_t)count * sizeof(double));
+    }
+    return true;
+}
+
+void shm_exchange_destroy(ShmExchange &x)
+{
+    if (x.base) {
+        munmap(x.base, x.bytes);
+        if (x.name[0]) shm_unlink(x.name);  // the name goes with the first rank that leaves; mappings of the others stay valid
+    }
+    x = ShmExchange();
 }
 
 }  // namespace s2m

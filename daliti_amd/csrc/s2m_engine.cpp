@@ -115,6 +115,8 @@ struct s2m_engine {
 
     EskfWork work;
     Comm comm;  // attached RCCL communicator (multi-GPU form), handle == nullptr when single GPU
+    ShmExchange shm;               // or: host shared-memory exchange between the processes of one node (s2m_comm_init_shm)
+    std::vector<double> shm_blocks;  // the ranks' blocks of one exchange, padded to a power of two for the tree sum
     int32_t queue[S2M_FEAT_QUEUE + 1] = {0};
     int32_t queue_len = 0;
 };
@@ -422,6 +424,7 @@ int s2m_destroy(s2m_engine *e)
     free_voxel(e->vox);
     free_undist(e->und);
     comm_destroy(e->comm);
+    shm_exchange_destroy(e->shm);
     void *ptrs[] = {e->d_brec, e->d_bcnt, e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
                     e->d_nn_d2, e->d_hard, e->d_qheads, e->d_hrec, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
@@ -1162,6 +1165,26 @@ void reset_log(s2m_iter_log *log, int max_iter)
 }
 }  // namespace
 
+// Publish this rank's block to the shared segment, collect everybody's and sum them pairwise over the rank index (the
+// same perfect binary tree as s2m_iterated_update_multi: with aligned power-of-two shards the sum equals the unsplit
+// scan's block bit for bit, and every rank computes the identical sum, so the redundant fp64 updates stay in step).
+static int shm_sum(s2m_engine *e, const double **hb)
+{
+    const int n = e->shm.nranks;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    e->shm_blocks.resize((size_t)np2 * S2M_BLOCK_DOUBLES);
+    double *sum = e->shm_blocks.data();
+    std::string err;
+    if (!shm_exchange(e->shm, *hb, S2M_BLOCK_DOUBLES, sum, err)) return fail(e, S2M_ERR_HIP, err.c_str());
+    std::fill(e->shm_blocks.begin() + (size_t)n * S2M_BLOCK_DOUBLES, e->shm_blocks.end(), 0.0);
+    for (int w = 1; w < np2; w <<= 1)
+        for (int i = 0; i + w < np2; i += 2 * w)
+            for (int k = 0; k < S2M_BLOCK_DOUBLES; ++k) sum[(size_t)i * S2M_BLOCK_DOUBLES + k] += sum[(size_t)(i + w) * S2M_BLOCK_DOUBLES + k];
+    *hb = sum;
+    return S2M_OK;
+}
+
 int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double x_prop[S2M_STATE_DOUBLES],
                                 double P[S2M_DIM * S2M_DIM], s2m_iter_log *log, double *d_block,
                                 s2m_allreduce_fn reduce, void *user)
@@ -1189,6 +1212,7 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         passes += rematch;
         const auto t_a = now();
         const bool collective = !reduce && e->comm.handle;  // built-in RCCL sum of the block before the hand-off
+        const bool shm = !reduce && !collective && e->shm.base && d_block == e->d_block;  // host shared-memory sum after it
         // Bet on "no far points" when the last rematch pass in this position (first of a scan / later) had none: at a
         // converged pose the first shell resolves every point (measured: 0 of 65,536 at C3, 0 of 131,072 at C4), and
         // the far-point kernel -- a launch, a kernel boundary and 4,096 waves that find an empty list -- is ~4 us.
@@ -1231,14 +1255,22 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         if (rc) return rc;
         rc = finish_timing(e);
         if (rc) return rc;
+        if (shm) {  // every rank's block, summed in rank order: the far-point count below is then the job's, not the rank's
+            rc = shm_sum(e, &hb);
+            if (rc) return rc;
+        }
         if (rematch && !reduce && !collective) {
             const int64_t far_points = (int64_t)hb[158];
             if (it == 0) e->far_first = far_points; else e->far_later = far_points;
-            if (spec && far_points != 0) {  // the bet is lost: this block is void (s2m_reduce.hip)
+            if (spec && far_points != 0) {  // the bet is lost: this block is void (s2m_reduce.hip); with shm, for every rank alike
                 rc = redo_with_far_points(e, x, d_block);
                 if (rc) return rc;
                 rc = wait_block(e, d_block, &hb);
                 if (rc) return rc;
+                if (shm) {
+                    rc = shm_sum(e, &hb);
+                    if (rc) return rc;
+                }
             }
         }
         const auto t_c = now();
@@ -1300,7 +1332,7 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
     {
         bool ok = true;
         for (int i = 0; i < k && ok; ++i) {
-            ok = handles[i] != nullptr && handles[i]->scan_ready && !handles[i]->comm.handle && handles[i]->host_poll &&
+            ok = handles[i] != nullptr && handles[i]->scan_ready && !handles[i]->comm.handle && !handles[i]->shm.base && handles[i]->host_poll &&
                  handles[i]->device == handles[0]->device;
             for (int j = 0; j < i && ok; ++j) ok = handles[j] != handles[i];
         }
@@ -1324,7 +1356,7 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
         for (int j = 0; j < i; ++j)
             if (handles[j] == e) return fail(e, S2M_ERR_ARG, "s2m_iterated_update_batch: a handle appears twice");
         if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
-        if (e->comm.handle || !e->host_poll) return fail(e, S2M_ERR_STATE, "s2m_iterated_update_batch: single-GPU handles with the host-polled block only");
+        if (e->comm.handle || e->shm.base || !e->host_poll) return fail(e, S2M_ERR_STATE, "s2m_iterated_update_batch: single-GPU handles with the host-polled block only");
         if (e->device != handles[0]->device) return fail(e, S2M_ERR_ARG, "s2m_iterated_update_batch: handles on different devices");
     }
     auto launch = [&](int i) -> int {
@@ -1417,7 +1449,7 @@ int s2m_iterated_update_multi(s2m_engine *const *handles, int32_t n, double x[S2
         for (int j = 0; j < i; ++j)
             if (handles[j] == e) return fail(e, S2M_ERR_ARG, "s2m_iterated_update_multi: a handle appears twice");
         if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
-        if (e->comm.handle || !e->host_poll)
+        if (e->comm.handle || e->shm.base || !e->host_poll)
             return fail(e, S2M_ERR_STATE, "s2m_iterated_update_multi: handles without a communicator, host-polled block only");
         e->nn_valid = false;
     }
@@ -1680,10 +1712,21 @@ int s2m_comm_init(s2m_engine *e, const uint8_t id[S2M_COMM_ID_BYTES], int32_t nr
     return S2M_OK;
 }
 
+int s2m_comm_init_shm(s2m_engine *e, const char *name, int32_t nranks, int32_t rank)
+{
+    if (!e || !name || nranks < 1 || nranks > 256 || rank < 0 || rank >= nranks) return fail(e, S2M_ERR_ARG, "s2m_comm_init_shm: bad argument");
+    if (!e->host_poll) return fail(e, S2M_ERR_STATE, "s2m_comm_init_shm: needs the host-polled block");
+    comm_destroy(e->comm);
+    std::string err;
+    if (!shm_exchange_init(e->shm, name, nranks, rank, err)) return fail(e, S2M_ERR_HIP, err.c_str());
+    return S2M_OK;
+}
+
 int s2m_comm_destroy(s2m_engine *e)
 {
     if (!e) return S2M_ERR_ARG;
     comm_destroy(e->comm);
+    shm_exchange_destroy(e->shm);
     return S2M_OK;
 }
 

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
     "s2m_iterated_update", "s2m_iterated_update_batch", "s2m_iterated_update_multi", "s2m_iterated_update_sharded",
-    "s2m_complete_neighbors", "s2m_map_get_order", "s2m_map_grid", "s2m_map_update_stats", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
+    "s2m_complete_neighbors", "s2m_map_get_order", "s2m_map_grid", "s2m_map_update_stats", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_init_shm", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
     "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats",
 ]
 
@@ -471,6 +471,10 @@ class Engine:
         if rc != 0:
             raise S2MError(rc, "s2m_comm_unique_id failed (is librccl available?)")
         return bytes(buf)
+
+    def comm_init_shm(self, name, nranks, rank):
+        """Host shared-memory exchange between the processes of one node (s2m_comm_init_shm)."""
+        self._ck(self.lib.s2m_comm_init_shm(self.h, C.c_char_p(name.encode()), C.c_int32(nranks), C.c_int32(rank)))
 
     def comm_init(self, uid, nranks, rank):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)

@@ -319,6 +319,14 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES],
 #define S2M_COMM_ID_BYTES 128
 int s2m_comm_unique_id(uint8_t id[S2M_COMM_ID_BYTES]);
 int s2m_comm_init(s2m_engine *e, const uint8_t id[S2M_COMM_ID_BYTES], int32_t nranks, int32_t rank);
+/* The same for the processes of ONE node without a collective library: the exchange goes through a POSIX shared-
+ * memory segment `name` ("/something", unique per job, the same string on every rank).  Every rank's reduce kernel
+ * publishes its block into that rank's pinned page exactly as in the single-GPU loop; the rank's host thread copies the
+ * 1.3 KB into its slot of the segment and reads everybody's -- no collective launch, no publish kernel, no GPU
+ * peer access.  The blocks are summed pairwise over the rank index on every rank alike, so aligned power-of-two shards
+ * give the unsplit scan's result bit for bit (as s2m_iterated_update_multi does inside one process).  All ranks must
+ * have called this before the first of them enters s2m_iterated_update. */
+int s2m_comm_init_shm(s2m_engine *e, const char *name, int32_t nranks, int32_t rank);
 int s2m_comm_destroy(s2m_engine *e);
 
 /* Degeneracy queue access (effct_feat_numQueue, laserMapping.cpp:193). */

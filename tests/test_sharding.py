@@ -123,16 +123,18 @@ def test_bench_collective_path_single_rank():
     import subprocess
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300))
     lines = []
-    for extra in ([], ["--torch-collective"]):   # the engine-owned RCCL communicator, then the torch callback
+    # the engine-owned RCCL communicator, the host shared-memory exchange, then the torch callback
+    for extra in (["--collective", "rccl"], ["--collective", "shm"], ["--torch-collective"]):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
                               "--warmup", "1", "--no-cpu", "--force-collective"] + extra, env=env,
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
         assert lines[-1]["n_gpus"] == 1 and lines[-1]["value"] > 0 and lines[-1]["pose_error_vs_truth_m"] < 0.05
-    assert "engine-owned communicator" in lines[0]["config"]["parallelism"]
-    assert "torch.distributed callback" in lines[1]["config"]["parallelism"]
-    assert lines[0]["final_pos"] == lines[1]["final_pos"]
+    assert "engine-owned communicator" in lines[0]["config"]["parallelism"] and lines[0]["config"]["collective"] == "rccl"
+    assert "POSIX shared memory" in lines[1]["config"]["parallelism"] and lines[1]["config"]["collective"] == "shm"
+    assert "torch.distributed callback" in lines[2]["config"]["parallelism"]
+    assert lines[0]["final_pos"] == lines[1]["final_pos"] == lines[2]["final_pos"]
     line = lines[0]
     ref = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
                           "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
@@ -152,10 +154,11 @@ def test_two_process_sharded_bench_equals_single_rank():
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
                           "--gpus", "2", "--config", "C1", "--scaling", "weak", "--steps", "3", "--warmup", "1", "--no-cpu",
-                          "--backend", "gloo", "--all-on-device0"], env=env, capture_output=True, text=True,
+                          "--backend", "gloo", "--all-on-device0", "--torch-collective"], env=env, capture_output=True, text=True,
                          timeout=900)
     assert two.returncode == 0, two.stderr[-3000:]
     l2 = json.loads([ln for ln in two.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "torch.distributed callback" in l2["config"]["parallelism"]   # gloo all-reduce of the block through the C callback
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
                           "--warmup", "1", "--no-cpu", "--beams-mult", "2"], env=env, capture_output=True,
                          text=True, timeout=900)
@@ -278,6 +281,7 @@ def test_two_process_strong_scaling_bench_equals_single_rank():
     assert one.returncode == 0, one.stderr[-3000:]
     l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert l2["n_gpus"] == 2 and l2["scaling"] == "strong"
+    assert l2["config"]["collective"] == "shm"   # gloo cannot carry the engine's RCCL communicator: the host exchange it is
     assert l2["config"]["scan_points_per_gpu"] * 2 == l1["config"]["scan_points_per_gpu"] == 10000
     assert np.abs(np.array(l2["final_pos"]) - np.array(l1["final_pos"])).max() < 1e-10
 
@@ -348,3 +352,42 @@ def test_bench_host_collective_form_equals_single_handle():
     assert "s2m_iterated_update_multi" in multi["config"]["parallelism"] and multi["scaling"] == "strong"
     assert multi["iters_per_step"] == one["iters_per_step"]
     assert np.abs(np.array(multi["final_pos"]) - np.array(one["final_pos"])).max() < 1e-12
+
+
+def test_shared_memory_exchange_protocol():
+    """The host side of --collective shm on its own (no GPU): forked ranks exchange blocks through the POSIX segment
+    with jittered timing; every rank must read every rank's block of the same sequence (two slots per rank by sequence
+    parity: a rank cannot overwrite a slot somebody is still reading)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(tempfile.mkdtemp(prefix="s2m_shm_"), "shm_exchange_test")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "c++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__",
+                           "-I", os.path.join(ROOT, "daliti_amd", "csrc"), "-I", "/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "shm_exchange_test.cpp"), os.path.join(ROOT, "daliti_amd", "csrc", "s2m_comm.cpp"),
+                           "-ldl", "-lrt", "-pthread", "-o", exe])
+    for ranks, rounds in ((2, 4000), (4, 3000), (7, 1500)):
+        out = subprocess.run([exe, str(ranks), str(rounds)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_two_process_shared_memory_exchange_is_bit_identical_to_one_rank():
+    """--collective shm: two ranks (both on GPU 0) split the C2 scan into two aligned halves, publish their blocks into
+    their own pinned pages, exchange them through POSIX shared memory on the host and sum them pairwise over the rank
+    index -- the registered pose must equal the single rank's BIT FOR BIT (tree-shaped sums)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C2", "--steps", "3",
+                          "--warmup", "1", "--no-cpu", "--backend", "gloo", "--all-on-device0", "--collective", "shm"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    l2 = json.loads(two.stdout.rstrip().splitlines()[-1])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C2", "--steps", "3",
+                          "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    l1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert l2["config"]["collective"] == "shm" and l2["n_gpus"] == 2
+    assert l2["config"]["scan_points_per_gpu"] == 32768
+    assert l2["final_pos"] == l1["final_pos"]
+    assert l2["iters_per_step"] == l1["iters_per_step"]
