@@ -522,8 +522,14 @@ def main():
         exchange_probe["shm"] = probe_ms()
         eng.comm_destroy()
         if try_rccl():
-            exchange_probe["rccl"] = probe_ms()
-            if exchange_probe["rccl"] < exchange_probe["shm"]:
+            try:
+                ms_rccl = probe_ms()
+            except Exception as ex:  # noqa: BLE001 - a rank whose all-reduce failed: everybody returns to the host exchange
+                ms_rccl = None
+                sys.stderr.write("rank %d: RCCL probe failed (%s)\n" % (rank, ex))
+            if all_ok(ms_rccl is not None):
+                exchange_probe["rccl"] = ms_rccl
+            if "rccl" in exchange_probe and exchange_probe["rccl"] < exchange_probe["shm"]:
                 exchange = "rccl"
             else:
                 eng.comm_destroy()
