@@ -512,7 +512,7 @@ def main():
             dt = float(t.item())
         return dt, it, rm
 
-    if sharded and a.collective == "auto" and exchange == "shm" and a.backend == "nccl" and world > 1:
+    if sharded and a.collective == "auto" and exchange == "shm" and a.backend == "nccl":
         # "pick RCCL or a host-side gather, whichever measures lower" -- a few steps of each, the maximum over
         # the ranks decides (the same number on every rank), the loser is detached
         def probe_ms():
