@@ -1168,15 +1168,28 @@ void reset_log(s2m_iter_log *log, int max_iter)
 // Publish this rank's block to the shared segment, collect everybody's and sum them pairwise over the rank index (the
 // same perfect binary tree as s2m_iterated_update_multi: with aligned power-of-two shards the sum equals the unsplit
 // scan's block bit for bit, and every rank computes the identical sum, so the redundant fp64 updates stay in step).
-static int shm_sum(s2m_engine *e, const double **hb)
+// `bet`: this rank skipped the far-point kernel in this pass (word 159 of the published copy says so); *any_void =
+// some rank bet and found far points, i.e. published a void block -- every rank learns it from the same data, so all of
+// them enter the second exchange together even if their bets differed (handles with different histories).
+static int shm_sum(s2m_engine *e, const double **hb, bool bet, bool *any_void)
 {
     const int n = e->shm.nranks;
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
     e->shm_blocks.resize((size_t)np2 * S2M_BLOCK_DOUBLES);
     double *sum = e->shm_blocks.data();
+    double mine[S2M_BLOCK_DOUBLES];
+    std::memcpy(mine, *hb, sizeof(mine));
+    mine[159] = bet ? 1.0 : 0.0;
     std::string err;
-    if (!shm_exchange(e->shm, *hb, S2M_BLOCK_DOUBLES, sum, err)) return fail(e, S2M_ERR_HIP, err.c_str());
+    if (!shm_exchange(e->shm, mine, S2M_BLOCK_DOUBLES, sum, err)) return fail(e, S2M_ERR_HIP, err.c_str());
+    bool v = false;
+    for (int r = 0; r < n; ++r) {
+        double *b = sum + (size_t)r * S2M_BLOCK_DOUBLES;
+        v = v || (b[159] != 0.0 && b[158] != 0.0);
+        b[159] = 0.0;
+    }
+    if (any_void) *any_void = v;
     std::fill(e->shm_blocks.begin() + (size_t)n * S2M_BLOCK_DOUBLES, e->shm_blocks.end(), 0.0);
     for (int w = 1; w < np2; w <<= 1)
         for (int i = 0; i + w < np2; i += 2 * w)
@@ -1255,22 +1268,27 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         if (rc) return rc;
         rc = finish_timing(e);
         if (rc) return rc;
+        const double *own = hb;  // this rank's block in its pinned page
+        bool any_void = false;
         if (shm) {  // every rank's block, summed in rank order: the far-point count below is then the job's, not the rank's
-            rc = shm_sum(e, &hb);
+            rc = shm_sum(e, &hb, spec, &any_void);
             if (rc) return rc;
         }
         if (rematch && !reduce && !collective) {
             const int64_t far_points = (int64_t)hb[158];
             if (it == 0) e->far_first = far_points; else e->far_later = far_points;
-            if (spec && far_points != 0) {  // the bet is lost: this block is void (s2m_reduce.hip); with shm, for every rank alike
+            const bool lost = spec && (int64_t)own[158] != 0;  // this rank's bet is lost: its block is void (s2m_reduce.hip)
+            if (lost) {
                 rc = redo_with_far_points(e, x, d_block);
                 if (rc) return rc;
                 rc = wait_block(e, d_block, &hb);
                 if (rc) return rc;
-                if (shm) {
-                    rc = shm_sum(e, &hb);
-                    if (rc) return rc;
-                }
+                own = hb;
+            }
+            if (shm && any_void) {  // somebody's block was void: everybody publishes again (the unchanged block where it was valid)
+                hb = own;
+                rc = shm_sum(e, &hb, false, nullptr);
+                if (rc) return rc;
             }
         }
         const auto t_c = now();

@@ -399,3 +399,27 @@ def test_two_process_shared_memory_exchange_is_bit_identical_to_one_rank():
     assert l2["config"]["scan_points_per_gpu"] == 32768
     assert l2["final_pos"] == l1["final_pos"]
     assert l2["iters_per_step"] == l1["iters_per_step"]
+
+
+@pytest.mark.gpu
+def test_shared_memory_exchange_survives_ranks_that_bet_differently():
+    """Two processes on GPU 0, each with half of the C2 scan, exchange their blocks through POSIX shared memory.  Rank
+    0 ALWAYS bets that its far-point list is empty (and loses on the first pass of every scan), rank 1 never bets: every rank
+    learns from the exchanged blocks that one of them was void, all of them publish a second time, and the result equals
+    one engine over the whole scan bit for bit -- over three scans in a row."""
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="s2m_shm_")
+    helper = os.path.join(ROOT, "tests", "shm_rank_helper.py")
+    name = "/s2m_t_%d" % os.getpid()
+    procs = [subprocess.Popen([sys.executable, helper, name, "2", str(r), "2" if r == 0 else "0",
+                               os.path.join(tmp, "r%d.npy" % r)], stderr=subprocess.PIPE, text=True) for r in range(2)]
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+    one = subprocess.run([sys.executable, helper, name, "1", "0", "1", os.path.join(tmp, "one.npy")], capture_output=True,
+                         text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a, b, ref = (np.load(os.path.join(tmp, f)) for f in ("r0.npy", "r1.npy", "one.npy"))
+    assert np.array_equal(a, b)       # the redundant updates stay in step
+    assert np.array_equal(a, ref)     # 32,768-point shards are aligned: bit-identical to the unsplit scan
