@@ -63,4 +63,37 @@ int s2m_bench_loop(s2m_engine *const *handles, int32_t k, int32_t steps, int32_t
     return S2M_OK;
 }
 
+// The frame leg of bench.py as a C++ caller: `frames` whole frames back to back, one in flight -- raw sweep records on
+// the host -> s2m_scan_set_from_raw (undistort + voxel grid) -> s2m_iterated_update -> s2m_map_incremental ->
+// s2m_fov_segment, i.e. what the reference's node does per scan (laserMapping.cpp:731-1175) with the engine in place of
+// its CPU stages.  frame_us[f] = wall time of frame f on the host's steady clock, merged[f] = how its map update was
+// produced (s2m_map_last_update).  x (36) holds the last frame's state on return.
+int s2m_bench_frames(s2m_engine *e, int32_t frames, const float *records, int64_t stride_floats, int64_t n,
+                     int32_t time_off_a, int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses,
+                     const double *state_end, float leaf, const double *x_prop, const double *P0, double filter_size_map,
+                     double cube_len, double *x, double *frame_us, int32_t *merged)
+{
+    if (!e || frames < 0 || !records || !poses || !state_end || !x_prop || !P0 || !x || !frame_us || !merged) return S2M_ERR_ARG;
+    double P[S2M_DIM * S2M_DIM];
+    s2m_iter_log log;
+    for (int f = 0; f < frames; ++f) {
+        const auto t0 = std::chrono::steady_clock::now();
+        int64_t n_out = 0, na = 0, nb = 0;
+        int rc = s2m_scan_set_from_raw(e, records, stride_floats, n, time_off_a, time_off_b, poses, n_poses, state_end, leaf, 0, &n_out);
+        if (rc) return rc;
+        std::memcpy(x, x_prop, S2M_STATE_DOUBLES * sizeof(double));
+        std::memcpy(P, P0, sizeof(P));
+        rc = s2m_iterated_update(e, x, x_prop, P, &log);
+        if (rc) return rc;
+        rc = s2m_map_incremental(e, x, filter_size_map, 1, &na, &nb);
+        if (rc) return rc;
+        rc = s2m_fov_segment(e, x + 9, cube_len, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        frame_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        rc = s2m_map_last_update(e, &merged[f]);
+        if (rc) return rc;
+    }
+    return S2M_OK;
+}
+
 }  // extern "C"
