@@ -25,6 +25,10 @@
 #include "s2m_plane.h"
 #include "s2m_point.h"
 
+#ifndef S2M_EXT_MFMA
+#define S2M_EXT_MFMA 1  // twelve Jacobian columns (extrinsic_est_en): the wave's sums by v_mfma_f64_16x16x4 (0: three butterflies)
+#endif
+
 namespace s2m {
 
 // Term layout of a partial row for NC Jacobian columns (NC = 6 without extrinsic estimation, 12
@@ -265,9 +269,51 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
         }
         a.eff[i] = eff ? 1 : 0;
     }
-    // ineffective lanes carry h = 0, z = 0 and contribute exact zeros.  Terms are reduced 32 at a
-    // time; term index within a chunk = compile-time slot, so everything stays in registers.
+    // ineffective lanes carry h = 0, z = 0 and contribute exact zeros.
     S2M_STAMP(2);
+#if S2M_EXT_MFMA
+    if constexpr (EXT) {
+        // Twelve Jacobian columns: the wave's 92 sums as ONE matrix product.  The 64 x 16 matrix [h | z | |r| | eff | 0]
+        // goes through LDS and is multiplied with its own transpose by sixteen v_mfma_f64_16x16x4_f64 (four points per
+        // instruction; the same register is the A and the B operand: A[i][k] = B[k][i] = M[point 4 s + lane / 16][column
+        // lane % 16]); H^T H, H^T z, sum |r| and the count are entries of the 16 x 16 result, of which lane l holds
+        // D[l / 16 + 4 r][l % 16], r = 0..3.  Measured against three halving butterflies over 96 terms
+        // (scripts/hth_mfma_probe.hip, two waves per SIMD as here): 1.10 vs 2.08 us per wave -- and 0.72 us for the ONE
+        // butterfly of the six-column case, which therefore keeps the shuffle form (north star: "MFMA ... taken only if
+        // rocprof shows it beating the shuffle reduce").  Still a fixed function of the wave's 64 points: the
+        // partition-consistency of the sums above the wave level is untouched.
+        typedef double double4_t __attribute__((ext_vector_type(4)));
+        __shared__ double stage[kRedBlock / 64][64 * 17];  // rows padded to 17 doubles: conflict-free column reads
+        double *my = stage[wave];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) my[lane * 17 + k] = h[k];
+        my[lane * 17 + 12] = z;
+        my[lane * 17 + 13] = absr;
+        my[lane * 17 + 14] = eff ? 1.0 : 0.0;
+        my[lane * 17 + 15] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const double m = my[(4 * s + (lane >> 4)) * 17 + (lane & 15)];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(m, m, acc, 0, 0, 0);
+        }
+        const int j = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = (lane >> 4) + 4 * r;
+            int slot = -1;
+            if (i <= j && j < 12) slot = T::tri(i, j);
+            else if (j == 12 && i < 12) slot = T::kHtz + i;
+            else if (i == 13 && j == 14) slot = T::kRes;
+            else if (i == 14 && j == 14) slot = T::kCnt;
+            if (slot >= 0) red[wave][slot] = acc[r];
+        }
+        if (lane < T::kSlots - T::kUsed) red[wave][T::kUsed + lane] = 0.0;  // padding slots of the row
+    } else
+#endif
+    {
     double hz[12];
 #pragma unroll
     for (int r = 0; r < 12; ++r) hz[r] = h[r] * z;
@@ -292,6 +338,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
         }
         wave_sum32(v, lane);
         if ((lane & 1) == 0) red[wave][chunk * 32 + ((lane >> 1) & 31)] = v[0];
+    }
     }
     __syncthreads();
     S2M_STAMP(3);
