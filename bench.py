@@ -42,7 +42,8 @@ The timed region is K calls of the C ABI from a C++ loop (tools/bench_loop.cpp: 
 C++) bracketed by barrier + device synchronise; nothing inside it is instrumented.  The HIP-event samples
 behind ``roofline`` are taken in a SEPARATE untimed loop afterwards (every pass of 40 more steps).
 
-Extra objects on the JSON line: ``roofline`` (the rematch pass: match_rows + match_hard + reduce<FIT>,
+Extra objects on the JSON line: ``job_roofline`` (algorithmic bytes of the whole timed region against N x 8 TB/s: the
+figure to compare across N), ``roofline`` (the rematch pass: match_rows + match_hard + reduce<FIT>,
 88 algorithmic bytes per eval) with ``roofline.issue`` (the issue-side reading of the same pass from the
 committed SQ counters), ``roofline_reuse`` (the reduce kernel of a reuse pass, 28 B/eval), ``cpu_baseline``
 (the CPU oracle, 1 thread, rank 0 at N = 1 only), ``c5_batch`` (BASELINE configs[4] on this one GPU: 8
@@ -626,6 +627,14 @@ def main():
         },
         "eskf_iters_per_sec": iters_all / dt,
         "scans_per_sec": scans_all / dt,
+        # the whole timed region against the roof of all N GPUs: algorithmic bytes (88 B per eval of a rematch pass, 28 B of a
+        # reuse pass) / wall time -- the figure to compare across N (`roofline` below is one rematch pass on rank 0)
+        "job_roofline": {
+            "achieved": evals_total * (BYTES_REUSE + (BYTES_REMATCH - BYTES_REUSE) * rematch / max(iters, 1)) / dt / 1e9,
+            "peak": HBM_PEAK_GBS * max(world if not host_multi else min(n_shards, n_dev), 1), "unit": "GB/s",
+            "frac": evals_total * (BYTES_REUSE + (BYTES_REMATCH - BYTES_REUSE) * rematch / max(iters, 1)) / dt / 1e9 /
+                    (HBM_PEAK_GBS * max(world if not host_multi else min(n_shards, n_dev), 1)),
+            "note": "algorithmic bytes of every pass of the timed region / its wall time, against N x 8 TB/s"},
         "iters_per_step": iters / a.steps / max(n_indep, 1),
         "rematch_passes_per_step": rematch / a.steps / max(n_indep, 1),
         "pose_error_vs_truth_m": pose_err,
