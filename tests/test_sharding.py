@@ -423,3 +423,14 @@ def test_shared_memory_exchange_survives_ranks_that_bet_differently():
     a, b, ref = (np.load(os.path.join(tmp, f)) for f in ("r0.npy", "r1.npy", "one.npy"))
     assert np.array_equal(a, b)       # the redundant updates stay in step
     assert np.array_equal(a, ref)     # 32,768-point shards are aligned: bit-identical to the unsplit scan
+    # three ranks (always / never / by history), shards that are not aligned: the ranks still agree bit for bit with each
+    # other, and with the unsplit scan to rounding
+    name3 = name + "_3"
+    procs = [subprocess.Popen([sys.executable, helper, name3, "3", str(r), str((2, 0, 1)[r]),
+                               os.path.join(tmp, "t%d.npy" % r)], stderr=subprocess.PIPE, text=True) for r in range(3)]
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+    t = [np.load(os.path.join(tmp, "t%d.npy" % r)) for r in range(3)]
+    assert np.array_equal(t[0], t[1]) and np.array_equal(t[0], t[2])
+    assert np.abs(t[0][:, :36] - ref[:, :36]).max() < 1e-10 and np.array_equal(t[0][:, 612:621], ref[:, 612:621])
