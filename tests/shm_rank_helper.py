@@ -21,7 +21,7 @@ e.scan_set(sc["scan"][lo:hi])
 if nranks > 1:
     e.comm_init_shm(name, nranks, rank)
 res = []
-for _ in range(3):   # three scans in a row: the bet's history moves between them
+for _ in range(int(os.environ.get("S2M_HELPER_SCANS", "3"))):   # scans in a row: the bet's history moves between them
     e.set_feat_queue(())
     r = e.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
     eff = np.zeros(8)
