@@ -1036,7 +1036,8 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
         // 2.8 cells is the widest band that still takes the direct 7x7-row path below (radius within 3 cells), and its
         // successor is the gate.  Measured with the gate clamps in place, search kernels per rematch pass, 1.7 -> 2.8
         // cells for these points: C3 38.0 -> 37.7 us, C4 77.4 -> 65.6, R1 24.1 -> 23.8, C2 27.2 -> 27.3; 3.1 cells (the
-        // general path) 41.3 / 74.2 / 24.0 / 29.9.
+        // general path) 41.3 / 74.2 / 24.0 / 29.9.  Re-checked at the end of round 3 (search kernels per rematch pass): 2.2 cells
+        // C3 32.6 / C4 59.7, 2.5 cells 32.5 / 53.9, against 31.7 / 53.0 with 2.8.
         if (r1.y == 0u) band = S2M_HARD_BAND_EMPTY * g.c;
         band = fminf(band, sqrtf(a.gates.knn_d2_gate * 1.0001f));  // no first band beyond the gate either (coarse grids)
         uint32_t rounds = 0;
