@@ -34,7 +34,8 @@ exchange the 1.3 KB through POSIX shared memory and sum pairwise over the rank i
 default ``--collective auto`` attaches both, times ten steps of each before the timed region, uses the lower one
 ("whichever measures lower") and prints both figures in ``config.collective_probe_ms_per_step``.
 ``--scaling weak`` grows the scan to N x beams instead (one config-sized shard per rank); the strong run also
-reports it as the side object ``weak_scaling``.
+reports it as the side object ``weak_scaling``, and ``sector_sharding`` (the same scan dealt out in azimuth sectors
+instead of contiguous ranges: balanced ranks).
 ``--collective host --shards S`` is the single-process form (one rank drives S handles -- S devices, or S
 shards on one device -- and sums the S pinned blocks on the host, no collective library).
 
@@ -714,6 +715,30 @@ def main():
         out["weak_scaling"] = {"value": float(wtot.item()) / wdt, "unit": "evals/s", "ms_per_step": 1e3 * wdt / wsteps,
                                "steps": wsteps, "scan_points_total": int(n_weak), "scan_points_per_gpu": int(len(sc)),
                                "note": "side leg after the timed region: the same job with the scan grown to N x beams"}
+    if sharded and scaling == "strong" and world > 1 and not a.no_side and a.config != "R1" and cfgd["az"] % world == 0:
+        # second side number: the same scan dealt out in azimuth SECTORS (rank r takes azimuths [r, r + 1) * az / N of every
+        # beam) instead of contiguous index ranges (whole beams per rank).  The near-horizontal beams hold the long-range
+        # returns and nearly all far points of the first pass, so with whole beams per rank one rank is as slow as the whole
+        # scan (scripts/shard_balance.py); sectors balance the ranks at the price of the bit-identity with
+        # the unsplit scan.  The headline keeps the contiguous ranges SURVEY 8e prescribes.
+        scan_all = synth.make_scan(cfgd["beams"], cfgd["az"], cfgd["L"], seed=2)
+        wsec = cfgd["az"] // world
+        sc = np.ascontiguousarray(scan_all.reshape(cfgd["beams"], cfgd["az"], 3)[:, rank * wsec:(rank + 1) * wsec].reshape(-1, 3))
+        d_scan = torch.from_numpy(sc).cuda()
+        d_keep.append(d_scan)
+        torch.cuda.synchronize()
+        eng.scan_set_device(d_scan.data_ptr(), 3, len(sc))
+        run_steps(max(a.warmup // 2, 2))
+        ssteps = max(a.steps // 4, 5)
+        sdt, sit, _ = timed(ssteps)
+        stot = torch.tensor([float(len(sc)) * sit], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(stot, op=dist.ReduceOp.SUM)
+        sres = result()
+        out["sector_sharding"] = {"value": float(stot.item()) / sdt, "unit": "evals/s", "ms_per_step": 1e3 * sdt / ssteps,
+                                  "steps": ssteps, "scan_points_per_gpu": int(len(sc)),
+                                  "pose_delta_vs_range_sharding_m": float(np.abs(sres["x"][9:12] - res["x"][9:12]).max()),
+                                  "note": "side leg after the timed region: the same scan, rank r holding azimuth sector r of "
+                                          "every beam instead of a contiguous index range"}
     if rank == 0 and single and not a.no_cpu and a.cpu_steps > 0:
         cpu_map = eng.map_points() if a.config == "R1" else map_xyz
         cpu_scan = eng.scan_get() if a.config == "R1" else scans[0][0]

@@ -284,6 +284,7 @@ def test_two_process_strong_scaling_bench_equals_single_rank():
     assert two.stdout.rstrip().splitlines()[-1].startswith("{")          # the JSON line is the last line
     l2 = json.loads(two.stdout.rstrip().splitlines()[-1])
     assert "weak_scaling" in l2 and l2["weak_scaling"]["scan_points_total"] == 20000
+    # (C1 has 625 azimuths: no sector leg with two ranks; test_two_process_shared_memory_exchange... covers it on C2)
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--steps", "3",
                           "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
@@ -399,6 +400,9 @@ def test_two_process_shared_memory_exchange_is_bit_identical_to_one_rank():
     assert l2["config"]["scan_points_per_gpu"] == 32768
     assert l2["final_pos"] == l1["final_pos"]
     assert l2["iters_per_step"] == l1["iters_per_step"]
+    # side legs of an N > 1 run: the weak form and the sector-sharded form of the same scan (same pose to rounding)
+    assert l2["weak_scaling"]["scan_points_per_gpu"] == 65536
+    assert l2["sector_sharding"]["scan_points_per_gpu"] == 32768 and l2["sector_sharding"]["pose_delta_vs_range_sharding_m"] < 1e-10
 
 
 @pytest.mark.gpu
