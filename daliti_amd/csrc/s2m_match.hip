@@ -1666,6 +1666,7 @@ __global__ __launch_bounds__(256) void collect_short_kernel(MatchArgs a)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool want = false;
+    uint32_t far_bits = 0u;
     HardRec rec = {0.f, 0.f, 0.f, 0u, 0.f, 0u, 0u, 0u};
     if (i < a.n && !(a.nn_idx[(int64_t)i * kK + (kK - 1)] >= 0 && a.nn_d2[(int64_t)i * kK + (kK - 1)] <= a.gates.knn_d2_gate)) {
         body_to_world(a.pose, a.sx[i], a.sy[i], a.sz[i], rec.wx, rec.wy, rec.wz);
@@ -1677,11 +1678,12 @@ __global__ __launch_bounds__(256) void collect_short_kernel(MatchArgs a)
         const float cx = g.ox + 0.5f * (float)g.ncx * g.c, cy = g.oy + 0.5f * (float)g.ncy * g.c, cz = g.oz + 0.5f * (float)g.ncz * g.c;
         const float d2c = ((rec.wx - cx) * (rec.wx - cx) + (rec.wy - cy) * (rec.wy - cy)) + (rec.wz - cz) * (rec.wz - cz);
         want = d2c < 3.0e38f;  // false for NaN and +inf
-        if (want) {
-            uint32_t mx = wave_max_u32_slow(__float_as_uint(d2c));
-            if ((threadIdx.x & 63) == 0) atomicMax(a.hard_count + 2, mx);
-        }
+        if (want) far_bits = __float_as_uint(d2c);  // >= 0: the bit pattern orders like the value
     }
+    // the wave's maximum, taken by ALL lanes (a lane with a complete list contributes 0) and reported by whichever lane
+    // comes first: short lists are sparse, so the wave's lane 0 usually is not one of them
+    const uint32_t mx = wave_max_u32_slow(far_bits);
+    if (mx != 0u && (threadIdx.x & 63) == 0) atomicMax(a.hard_count + 2, mx);
     append_rec(a.hard_rec, a.hard_count, want, rec);
 }
 

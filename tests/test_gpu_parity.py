@@ -373,6 +373,68 @@ def test_batch_of_ragged_scans_equals_one_by_one(small_scene, K, monkeypatch):
     owner.close()
 
 
+def test_batch_and_multi_with_extrinsic_estimation(oracle, small_scene, small_tree):
+    """extrinsic_est_en = 1 (twelve Jacobian columns: the MFMA contraction, laserMapping.cpp:968-972) through the two
+    multi-scan entry points, which until round 4 only ever ran the six-column default: K = 5 ragged scans from
+    different predicted poses with a non-trivial R_L_I / T_L_I through s2m_iterated_update_batch
+    (reduce_kernel_batch<true, .>) == one by one bit for bit, one by one == oracle <= 1e-9; and ONE scan in two aligned
+    shards through s2m_iterated_update_multi == the single handle bit for bit."""
+    from daliti_amd import Engine
+    from daliti_amd.sharding import shard_range
+    rs = np.random.RandomState(5)
+    owner = Engine(max_iter=5, extrinsic_est_en=1)
+    owner.map_build(small_scene["map"])
+    full = small_scene["scan"]
+    base = small_scene["x_prop"].copy()
+    base[12:21] = oracle.so3_exp([0.02, -0.01, 0.03]).ravel()
+    base[21:24] = [0.05, -0.02, 0.1]
+    # the body-frame points that give the same LiDAR-frame cloud under this extrinsic: p_b = R_LI^T (p_l - T_LI)
+    R_LI = base[12:21].reshape(3, 3)
+    body = ((full.astype(np.float64) - base[21:24]) @ R_LI).astype(np.float32)
+    engs, xs, Ps, scans = [], [], [], []
+    for k, n in enumerate([len(body), 777, 1500, 1024, 2000]):
+        lo = rs.randint(0, len(body) - n + 1)
+        e = Engine(max_iter=5, extrinsic_est_en=1)
+        e.map_share(owner)
+        e.scan_set(body[lo:lo + n])
+        d = np.zeros(24); d[:6] = rs.normal(0, [2e-3, 2e-3, 2e-3, 0.01, 0.01, 0.01])
+        xs.append(oracle.boxplus(base, d))
+        Ps.append(small_scene["P"] * (1.0 + 0.1 * k))
+        engs.append(e); scans.append(body[lo:lo + n])
+    cfg = oracle.default_cfg(extrinsic_est_en=1, max_iter=5)
+    one = []
+    for e, x, P, sc in zip(engs, xs, Ps, scans):
+        e.set_feat_queue(())
+        o = e.iterated_update(x, x, P)
+        ref = oracle.iterated_update(cfg, small_tree, sc, x, x, P)
+        assert o["iters"] == ref["iters"] and (o["effct"] == ref["effct"]).all()
+        assert np.abs(o["x"] - ref["x"]).max() < 1e-9 and np.abs(o["P"] - ref["P"]).max() < 1e-11
+        assert np.abs(o["x"][21:24] - x[21:24]).max() > 0.0         # the extrinsic columns did move the extrinsic
+        one.append(o)
+    for e in engs:
+        e.set_feat_queue(())
+    X = np.ascontiguousarray(np.stack(xs)); XP = X.copy(); PB = np.ascontiguousarray(np.stack(Ps))
+    logs = Engine.iterated_update_batch(engs, X, XP, PB)
+    for k, o in enumerate(one):
+        assert logs[k].iters == o["iters"] and list(logs[k].effct[:logs[k].iters]) == list(o["effct"]), k
+        assert (bits(X[k]) == bits(o["x"])).all() and (bits(PB[k]) == bits(o["P"])).all(), k
+    # one scan (the whole cloud, 2 048 points) in two aligned shards, host-summed
+    shards = []
+    for r in range(2):
+        lo, hi = shard_range(len(body), r, 2)
+        e = Engine(max_iter=5, extrinsic_est_en=1)
+        e.map_share(owner)
+        e.scan_set(body[lo:hi])
+        shards.append(e)
+    x = xs[0].copy(); P = Ps[0].copy()
+    log = Engine.iterated_update_multi(shards, x, np.ascontiguousarray(xs[0]), P)
+    assert log.iters == one[0]["iters"] and list(log.effct[:log.iters]) == list(one[0]["effct"])
+    assert (bits(x) == bits(one[0]["x"])).all() and (bits(P) == bits(one[0]["P"])).all()
+    for e in engs + shards:
+        e.close()
+    owner.close()
+
+
 def test_complete_neighbors_edge_cases(oracle, small_scene):
     """s2m_complete_neighbors where it cannot succeed: a map of fewer than five points (every list stays short, the call
     terminates), non-finite scan points (left alone), an empty scan; and map_incremental on such inputs."""

@@ -257,6 +257,37 @@ def test_new_territory_points_enter_the_map_like_the_reference(oracle, small_sce
 
 
 @pytest.mark.gpu
+def test_isolated_far_points_complete_their_lists(oracle, small_scene):
+    """the completion rounds end at the radius derived from the FARTHEST open query.  collect_short used to
+    report a wave's maximum only when lane 0 of that wave had a short list itself -- with isolated far points (here one
+    per 64 scan points, never at a multiple of 64, the farthest ones hundreds of metres outside the grid) most waves
+    reported nothing, the radius was too small and far lists ended short or inexact.  Every list must equal the
+    oracle's unbounded 5-NN."""
+    from daliti_amd import Engine, synth
+    m = small_scene["map"]
+    x = synth.make_state()
+    rs = np.random.RandomState(23)
+    L = small_scene["L"]
+    n = 64 * 40
+    q = (m[rs.choice(len(m), n)] + rs.normal(0, 0.05, (n, 3))).astype(np.float32)   # inside the map: full lists
+    d = rs.normal(size=(40, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    far = (d * (L * 0.75 + rs.uniform(30.0, 400.0, (40, 1)))).astype(np.float32)
+    slots = 64 * np.arange(40) + rs.randint(1, 64, 40)                               # never lane 0 of a wave
+    q[slots] = far
+    e = Engine(cell_size=0.5)
+    e.map_build(m)
+    e.scan_set(q)
+    e.residual_pass(x, True)
+    oi, od, oc = ranked_tree(oracle, e, m).knn5(q)
+    assert (oc == 5).all() and (od[slots, 4] > 5.0).all() and (od[np.setdiff1d(np.arange(n), slots)][:, 4] <= 5.0).mean() > 0.99
+    n_short = e.complete_neighbors()
+    assert n_short >= 40
+    idx, d2 = e.get_neighbors()
+    assert (idx == oi).all() and (bits(d2) == bits(od)).all()
+    e.close()
+
+
+@pytest.mark.gpu
 def test_merge_update_equals_rebuild(oracle, small_scene, monkeypatch):
     """An update merged into the sorted arrays of the current grid (s2m_map.hip, merge_update) and the same update
     through a full rebuild give the same map in the same caller order, and the same exact neighbours afterwards."""
