@@ -42,7 +42,7 @@ struct s2m_engine {
     double last_ms[3] = {0, 0, 0};
     double tstats[6] = {0, 0, 0, 0, 0, 0};     // {match ms, n, reduce<FIT> ms, n, reduce (reuse pass) ms, n}
     bool last_rematch = false;
-    int match_group = 2;  // lanes per scan point in the first-shell search (measured best with 3 batches per trip)
+    int match_group = 0;  // launch_match flags (s2m_kernels.h): wide addresses, point batches per trip
     std::string err;
 
     MapBuffers map;
@@ -83,7 +83,7 @@ struct s2m_engine {
     double *h_block_dev = nullptr;          // the same memory as seen from the device
     unsigned long long seq = 0;             // pass sequence number published through the flag
     uint32_t *d_ticket = nullptr;
-    bool host_poll = true;                  // S2M_NO_HOST_POLL=1: use a D2H copy + stream sync instead
+    bool host_poll = true;                  // the reduce kernel publishes the block to pinned host memory (else: D2H copy + sync)
     // rows on request
     uint32_t *d_block_off = nullptr;
     double *d_hx = nullptr, *d_h = nullptr;
@@ -95,8 +95,6 @@ struct s2m_engine {
     uint32_t *d_hard = nullptr;   // the far-point lists' counters sit behind 3 x n_cap words (the words themselves are free)
     uint32_t *d_qheads = nullptr; // match_hard's dequeue heads (kQueueWords)
     HardRec *d_hrec = nullptr;    // the far points' records: 2 x n_cap (without / with a radius)
-    uint32_t *d_dbg = nullptr;  // S2M_DEBUG_MATCH=1: per-point diagnostics of the match kernel
-    bool dbg = false;
     bool nn_valid = false;
     bool nn_complete = false;     // s2m_complete_neighbors has run on the current lists
     // far points (scan points the first-shell kernel could not resolve) of the last FIRST rematch pass of a scan and of
@@ -226,7 +224,6 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
         m.hard_rec = e->d_hrec; m.hard_off1 = n; m.hard_count = e->d_hard + 3 * e->n_cap;
         m.qheads = e->d_qheads;
-        m.dbg = e->dbg ? e->d_dbg : nullptr;
         // Point batches per trip of the first-shell kernel (unless S2M_EASY_NB fixed it): three (24 loads in flight, 160
         // VGPRs, 3 waves/SIMD) is fastest while all of the launch's waves are resident anyway -- up to 98 k points; beyond
         // that, or when several scans are in flight on the chip (the batch entry), two (128 VGPRs, 4 waves/SIMD) wins:
@@ -277,7 +274,6 @@ int redo_with_far_points(s2m_engine *e, const double state[S2M_STATE_DOUBLES], d
     m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
     m.hard_rec = e->d_hrec; m.hard_off1 = n; m.hard_count = e->d_hard + 3 * e->n_cap;
     m.qheads = e->d_qheads;
-    m.dbg = nullptr;
     launch_match_far_points(m, e->match_group, e->stream);
     ReduceArgs r;
     r.pose = pose; r.gates = gates;
@@ -374,19 +370,12 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
     if (!e) return S2M_ERR_CAPACITY;
     e->cfg = *cfg;
     e->device = dev;
-    if (const char *g = std::getenv("S2M_MATCH_GROUP")) {
-        const int v = std::atoi(g);
-        if (v == 1 || v == 2 || v == 4 || v == 8) e->match_group = v;
-    }
-    if (const char *g = std::getenv("S2M_WIDE_ADDR"))
+    if (const char *g = std::getenv("S2M_WIDE_ADDR"))  // test hook: 64-bit point addresses on a small map
         if (std::atoi(g) != 0) e->match_group |= 0x10000;
-    if (const char *g = std::getenv("S2M_EASY_CELLS"))
-        if (std::atoi(g) != 0) e->match_group |= 0x20000;
-    if (const char *g = std::getenv("S2M_EASY_NB")) {
+    if (const char *g = std::getenv("S2M_EASY_NB")) {  // test hook: both first-shell instantiations on any scan size
         const int v = std::atoi(g);
-        if (v >= 1 && v <= 3) e->match_group |= v << 8;
+        if (v == 2 || v == 3) e->match_group |= v << 8;
     }
-    e->dbg = std::getenv("S2M_DEBUG_MATCH") != nullptr;
     if (cfg->far_point_bet >= 0 && cfg->far_point_bet <= 2) e->spec_mode = cfg->far_point_bet;
     if (const char *g = std::getenv("S2M_SPEC")) {  // overrides the config: 0 never bet, 1 by history, 2 always (A/B runs, tests)
         const int v = std::atoi(g);
@@ -403,7 +392,6 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
     ok = ok && hipMalloc((void **)&e->d_qheads, kQueueWords * sizeof(uint32_t)) == hipSuccess &&
          hipMemset(e->d_qheads, 0, kQueueWords * sizeof(uint32_t)) == hipSuccess;
     if (ok) std::memset(e->h_block, 0, (S2M_BLOCK_DOUBLES + 8) * sizeof(double));
-    e->host_poll = std::getenv("S2M_NO_HOST_POLL") == nullptr;
     if (!ok) {
         s2m_destroy(e);
         return S2M_ERR_HIP;
@@ -426,7 +414,7 @@ int s2m_destroy(s2m_engine *e)
     comm_destroy(e->comm);
     shm_exchange_destroy(e->shm);
     void *ptrs[] = {e->d_brec, e->d_bcnt, e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
-                    e->d_nn_d2, e->d_hard, e->d_qheads, e->d_hrec, e->d_dbg, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
+                    e->d_nn_d2, e->d_hard, e->d_qheads, e->d_hrec, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_block) (void)hipHostFree(e->h_block);
@@ -712,7 +700,6 @@ int scan_reserve(s2m_engine *e, int64_t n)
     rc = rc ? rc : grow(e, &e->d_hard, 3 * cap + 16);
     rc = rc ? rc : grow(e, &e->d_hrec, 2 * cap);
     if (!rc) S2M_HIP(e, hipMemsetAsync(e->d_hard + 3 * cap, 0, 16 * sizeof(uint32_t), e->stream));
-    if (e->dbg) rc = rc ? rc : grow(e, &e->d_dbg, cap * 4);
     if (rc) return rc;
     e->n_cap = cap;
     e->rows_cap = 0;
@@ -1049,7 +1036,6 @@ int s2m_complete_neighbors(s2m_engine *e, int64_t *n_completed)
     m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
     m.hard_rec = e->d_hrec; m.hard_off1 = n; m.hard_count = e->d_hard + 3 * e->n_cap;
     m.qheads = e->d_qheads;
-    m.dbg = nullptr;
     const double c = e->grid.c;
     const double half_diag = 0.5 * c * std::sqrt((double)e->grid.ncx * e->grid.ncx + (double)e->grid.ncy * e->grid.ncy +
                                                  (double)e->grid.ncz * e->grid.ncz);
@@ -1121,10 +1107,8 @@ namespace {
 // Everything the reference does with the result of one pass (:899-918, 1012-1101): degeneracy queue, Kalman update,
 // log row, rematch judgement, exit test + covariance update.  finished = the loop ends after this iteration.
 int consume_block(s2m_engine *e, const double *hb, IterCtl &c, double x[S2M_STATE_DOUBLES],
-                  const double x_prop[S2M_STATE_DOUBLES], double P[S2M_DIM * S2M_DIM], s2m_iter_log *log, bool &finished,
-                  double *solve_us)
+                  const double x_prop[S2M_STATE_DOUBLES], double P[S2M_DIM * S2M_DIM], s2m_iter_log *log, bool &finished)
 {
-    const auto t0 = std::chrono::steady_clock::now();
     const int max_iter = e->cfg.max_iter;
     const double *HtH = hb, *Htz = hb + 144;
     const int32_t effct = (int32_t)hb[156];
@@ -1135,7 +1119,6 @@ int consume_block(s2m_engine *e, const double *hb, IterCtl &c, double x[S2M_STAT
         int rc = s2m_eskf_update(e, x, x_prop, P, HtH, Htz, sol, &c.conv);
         if (rc) return rc;
     }
-    if (solve_us) *solve_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     if (log) {
         log->effct[c.it] = effct;
         log->rematch[c.it] = c.rematch;
@@ -1214,16 +1197,9 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
     int rematch_num = 0, rematch_en = 0, it = 0, passes = 0;
     int32_t conv = 0, stop = 0;
     reset_log(log, max_iter);
-    static const bool tl = std::getenv("S2M_HOST_TIMELINE") != nullptr;  // dev probe: host-side timings
-    double t_solve_us = 0.0;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<double, std::micro>(b - a).count();
-    };
     for (it = 0; it < max_iter; ++it) {
         const int rematch = (it == 0) || rematch_en;  // :847
         passes += rematch;
-        const auto t_a = now();
         const bool collective = !reduce && e->comm.handle;  // built-in RCCL sum of the block before the hand-off
         const bool shm = !reduce && !collective && e->shm.base && d_block == e->d_block;  // host shared-memory sum after it
         // Bet on "no far points" when the last rematch pass in this position (first of a scan / later) had none: at a
@@ -1231,7 +1207,7 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         // the far-point kernel -- a launch, a kernel boundary and 4,096 waves that find an empty list -- is ~4 us.
         // Plain single-handle loop only (no collective: every rank would have to lose the bet together).
         const int64_t hist = it == 0 ? e->far_first : e->far_later;
-        const bool spec = rematch && !reduce && !collective && !e->dbg && d_block == e->d_block && e->host_poll &&
+        const bool spec = rematch && !reduce && !collective && d_block == e->d_block && e->host_poll &&
                           (e->spec_mode == 2 || (e->spec_mode == 1 && hist == 0));
         int rc = run_pass(e, x, rematch, d_block, collective, spec);
         if (rc) return rc;
@@ -1244,7 +1220,6 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
             prm.laser_point_cov = e->cfg.laser_point_cov;
             (void)eskf_prepare(prm, Pm, e->work);  // a singular P is reported by the update itself
         }
-        const auto t_b = now();
         if (reduce && reduce(user) != 0) return fail(e, S2M_ERR_HIP, "all-reduce callback failed");
         const double *hb = nullptr;
         if (collective) {
@@ -1291,14 +1266,11 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
                 if (rc) return rc;
             }
         }
-        const auto t_c = now();
         IterCtl ctl{it, rematch, rematch_num, rematch_en, conv, stop};
         bool finished = false;
-        rc = consume_block(e, hb, ctl, x, x_prop, P, log, finished, tl ? &t_solve_us : nullptr);
+        rc = consume_block(e, hb, ctl, x, x_prop, P, log, finished);
         rematch_num = ctl.rematch_num; rematch_en = ctl.rematch_en; conv = ctl.conv; stop = ctl.stop;
         if (rc) return rc;
-        if (tl) std::fprintf(stderr, "[s2m timeline] it %d rematch %d: launch %.1f us, wait %.1f us, solve %.1f us\n", it,
-                             rematch, us(t_a, t_b), us(t_b, t_c), t_solve_us);
         if (finished) { ++it; break; }
     }
     if (log) {
@@ -1327,13 +1299,12 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
 // the K scans can go through ONE grid per pass when they search the same map on the same device with the same gates
 bool batch_can_fuse(s2m_engine *const *handles, int32_t k)
 {
-    static const bool off = std::getenv("S2M_BATCH_STREAMS") != nullptr;  // A/B: the per-handle-stream form of round 2
-    if (off || k < 2) return false;
+    if (k < 2) return false;
     const s2m_engine *a = handles[0];
     for (int i = 0; i < k; ++i) {
         const s2m_engine *e = handles[i];
         if (!e->map_ready || e->grid.pts != a->grid.pts || e->grid.tab != a->grid.tab || e->grid.m != a->grid.m) return false;
-        if (e->timing || e->dbg || (e->match_group & ~0xff) != 0) return false;
+        if (e->timing || e->match_group != 0) return false;
         if (e->cfg.max_iter != a->cfg.max_iter || e->cfg.extrinsic_est_en != a->cfg.extrinsic_est_en ||
             e->cfg.plane_thr != a->cfg.plane_thr || e->cfg.knn_d2_gate != a->cfg.knn_d2_gate ||
             e->cfg.s_gate != a->cfg.s_gate || e->cfg.res_gate != a->cfg.res_gate)
@@ -1422,7 +1393,7 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
             int rc = finish_timing(e);
             if (rc) return rc;
             bool finished = false;
-            rc = consume_block(e, e->h_block, s.c, xk(i), xpk(i), Pk(i), logs ? logs + i : nullptr, finished, nullptr);
+            rc = consume_block(e, e->h_block, s.c, xk(i), xpk(i), Pk(i), logs ? logs + i : nullptr, finished);
             if (rc) return rc;
             ++s.c.it;
             if (finished) {
@@ -1511,7 +1482,7 @@ int s2m_iterated_update_multi(s2m_engine *const *handles, int32_t n, double x[S2
             for (int i = 0; i + w < np2; i += 2 * w)
                 for (int k = 0; k < S2M_BLOCK_DOUBLES; ++k) sum[(size_t)i * S2M_BLOCK_DOUBLES + k] += sum[(size_t)(i + w) * S2M_BLOCK_DOUBLES + k];
         bool finished = false;
-        int rc = consume_block(e0, sum, c, x, x_prop, P, log, finished, nullptr);
+        int rc = consume_block(e0, sum, c, x, x_prop, P, log, finished);
         if (rc) return rc;
         if (finished) { ++it; break; }
     }
@@ -1549,8 +1520,6 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
     // as 2 x 6 19.1 k; K = 16 as 2 x 8 24.0 k, as 3 groups 22.4 k; K = 8 as 2 x 4 20.5 k, as 3 groups 19.0 k)
     for (int g : {8, 4})
         if (k % g == 0 && k / g >= 2) { ng = k / g; break; }
-    static const int ng_env = std::getenv("S2M_BATCH_GROUPS") ? std::atoi(std::getenv("S2M_BATCH_GROUPS")) : 0;  // dev knob
-    if (ng_env > 0) ng = std::min(ng_env, (int)k);
     while ((k + ng - 1) / ng > kBatchMax) ++ng;
     std::vector<Slot> slots((size_t)k);
     std::vector<Group> groups((size_t)ng);  // a group carries its kernel-argument table (2.9 KB): not on the stack
@@ -1677,7 +1646,7 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
                 s.waiting = false;
                 --G.waiting;
                 bool finished = false;
-                int rc = consume_block(e, e->h_block, s.c, xk(i), xpk(i), Pk(i), logs ? logs + i : nullptr, finished, nullptr);
+                int rc = consume_block(e, e->h_block, s.c, xk(i), xpk(i), Pk(i), logs ? logs + i : nullptr, finished);
                 if (rc) return rc;
                 ++s.c.it;
                 if (finished) {
@@ -1794,15 +1763,6 @@ int s2m_get_timing(const s2m_engine *e, double ms[3])
 {
     if (!e || !ms) return S2M_ERR_ARG;
     ms[0] = e->last_ms[0]; ms[1] = e->last_ms[1]; ms[2] = e->last_ms[2];
-    return S2M_OK;
-}
-
-// dev diagnostic (not part of the public header): per-point words written by the match kernel
-int s2m_debug_match(s2m_engine *e, uint32_t *out)
-{
-    if (!e || !out || !e->dbg || !e->d_dbg) return S2M_ERR_STATE;
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
-    S2M_HIP(e, hipMemcpy(out, e->d_dbg, (size_t)e->n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return S2M_OK;
 }
 

@@ -193,14 +193,16 @@ struct MatchArgs {
     uint32_t slot = 0;   // which scan of a batched launch this is (travels in the record so that match_hard finds the outputs)
     uint32_t *hard_count; // the two lengths (device counters, reset by every reduce launch)
     uint32_t *qheads = nullptr;  // kQueueShards dequeue heads of match_hard's work queue, kQueueStride words apart
-    uint32_t *dbg = nullptr;  // optional diagnostics, 4 words per scan point
 };
+// first shell (s2m_match.hip), then -- unless `group` carries bit 0x40000 -- the far-point kernel (s2m_match_far.hip)
 void launch_match(const MatchArgs &a, int group, hipStream_t st);
-// completion of the lists that ended short at the gate (s2m_complete_neighbors): the scan points with fewer than five
-// neighbours appended to hard list 0 (a.pose = the pose of the rematch pass that produced the lists), and the far-point
-// kernel on its own (a.gates.knn_d2_gate = the radius^2 of this round)
-// the far-point kernel on its own, in its per-iteration form (the redo of a pass whose speculation "no far points" failed)
+// the far-point kernel on its own, in its per-iteration form (the redo of a pass whose bet "no far points" was lost)
 void launch_match_far_points(const MatchArgs &a, int group, hipStream_t st);
+void launch_far_points(const MatchArgs &a, bool wide, hipStream_t st);
+// completion of the lists that ended short at the gate (s2m_complete_neighbors): the scan points with fewer than five
+// neighbours appended to far-point list 0 (a.pose = the pose of the rematch pass that produced the lists), and the
+// far-point kernel on its own with the brick neighbourhood clipped to the grid (a.gates.knn_d2_gate = the radius^2 of
+// this round)
 void launch_collect_short(const MatchArgs &a, hipStream_t st);
 void launch_match_hard_only(const MatchArgs &a, hipStream_t st);
 
@@ -278,6 +280,7 @@ static_assert(sizeof(BatchArgs) <= 4096, "the table must fit the kernel-argument
 // the kernels of one pass for the active scans of the table: search (for the scans with rematch set), then the reduce
 // kernels (FIT for the rematching scans, plain for the others: the host issues whichever the table needs)
 void launch_match_batch(const BatchArgs &b, hipStream_t st);
+void launch_far_points_batch(const BatchArgs &b, bool wide, hipStream_t st);
 void launch_reduce_batch(const BatchArgs &b, bool any_fit, bool any_plain, hipStream_t st);
 
 int reduce_blocks(int n);

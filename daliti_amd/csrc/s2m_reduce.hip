@@ -25,8 +25,8 @@
 #include "s2m_plane.h"
 #include "s2m_point.h"
 
-#ifndef S2M_EXT_MFMA
-#define S2M_EXT_MFMA 1  // twelve Jacobian columns (extrinsic_est_en): the wave's sums by v_mfma_f64_16x16x4 (0: three butterflies)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "s2m_reduce.hip is written for gfx950: v_permlane32_swap / v_permlane16_swap, f64 MFMA, 79 KB of LDS per workgroup"
 #endif
 
 namespace s2m {
@@ -47,20 +47,8 @@ struct Terms {
 
 // Sum of 32 values per lane across the 64 lanes of a wave with a halving butterfly: at each of
 // the five halving steps a lane keeps one half of its values and hands the other half to its
-// partner, so 32 + 1 shuffles replace 32 x 6.  On return v[0] of lane l is the wave-wide sum of
+// partner, so 32 + 1 exchanges replace 32 x 6.  On return v[0] of lane l is the wave-wide sum of
 // value (l >> 1) & 31 (both lanes of a pair hold it).  Fixed order, hence deterministic.
-template <int HALF>
-__device__ __forceinline__ void halve_step(double (&v)[32], int lane)
-{
-    constexpr int m = HALF * 2;
-    const bool hi = (lane & m) != 0;
-#pragma unroll
-    for (int i = 0; i < HALF; ++i) {
-        const double send = hi ? v[i] : v[i + HALF];
-        const double keep = hi ? v[i + HALF] : v[i];
-        v[i] = keep + __shfl_xor(send, m, 64);
-    }
-}
 // The two widest steps (partner lane ^ 32 and lane ^ 16: 24 of the 32 exchanges) with gfx950's v_permlane32_swap /
 // v_permlane16_swap: one VALU instruction exchanges the upper half (the odd 16-lane rows) of one register with the
 // lower half (the even rows) of another, which IS the keep / send pattern of a halving step -- no selects, no trip
@@ -128,21 +116,12 @@ __device__ __forceinline__ void halve_step_dpp(double (&v)[32], int lane)
 
 __device__ __forceinline__ void wave_sum32(double (&v)[32], int lane)
 {
-#ifdef S2M_EXP_SHUFFLE_BUTTERFLY
-    halve_step<16>(v, lane);
-    halve_step<8>(v, lane);
-    halve_step<4>(v, lane);
-    halve_step<2>(v, lane);
-    halve_step<1>(v, lane);
-    v[0] += __shfl_xor(v[0], 1, 64);
-#else
     halve_step_swap<16>(v);
     halve_step_swap<8>(v);
     halve_step_dpp<4>(v, lane);
     halve_step_dpp<2>(v, lane);
     halve_step_dpp<1>(v, lane);
     v[0] += dpp_xor<1>(v[0]);
-#endif
 }
 
 // compile-time (row, column) of upper-triangle slot t
@@ -180,23 +159,12 @@ __device__ __forceinline__ void pin(T &v)
     asm volatile("" : "+v"(v));
 }
 
-#ifdef S2M_EXP_REDUCE_TIMELINE
-// experiment: stage stamps (100 MHz wall clock) of thread 0 of the LAST workgroup, packed 12 bits each into the two
-// free slots of the block (read with s2m_residual_pass_device; scripts/reduce_timeline.py)
-#define S2M_STAMP(k) do { if (threadIdx.x == 0) tl_[k] = wall_clock64(); } while (0)
-#else
-#define S2M_STAMP(k) do { } while (0)
-#endif
 
 // bx / nblk: this workgroup's index among the workgroups of ITS scan and their number (blockIdx.x / gridDim.x for one
 // scan per launch; in a batched launch the grid is sized for the largest scan)
 template <bool EXT, bool FIT>
 __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t bx, const uint32_t nblk)
 {
-#ifdef S2M_EXP_REDUCE_TIMELINE
-    long long tl_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    S2M_STAMP(0);
     constexpr int NC = EXT ? 12 : 6;
     using T = Terms<NC>;
     __shared__ double red[kRedBlock / 64][T::kSlots];
@@ -250,7 +218,6 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
             sel = (uint8_t)s32;
             fl = (uint8_t)f32;
         }
-        S2M_STAMP(1);
         if (sel) {
             uint8_t sel_new = 0;  // sticky: only fit-ok + s-gate re-selects (:862,:873)
             if (fl & kFlagPlane) {
@@ -270,8 +237,6 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
         a.eff[i] = eff ? 1 : 0;
     }
     // ineffective lanes carry h = 0, z = 0 and contribute exact zeros.
-    S2M_STAMP(2);
-#if S2M_EXT_MFMA
     if constexpr (EXT) {
         // Twelve Jacobian columns: the wave's 92 sums as ONE matrix product.  The 64 x 16 matrix [h | z | |r| | eff | 0]
         // goes through LDS and is multiplied with its own transpose by sixteen v_mfma_f64_16x16x4_f64 (four points per
@@ -311,9 +276,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
             if (slot >= 0) red[wave][slot] = acc[r];
         }
         if (lane < T::kSlots - T::kUsed) red[wave][T::kUsed + lane] = 0.0;  // padding slots of the row
-    } else
-#endif
-    {
+    } else {
     double hz[12];
 #pragma unroll
     for (int r = 0; r < 12; ++r) hz[r] = h[r] * z;
@@ -341,7 +304,6 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
     }
     }
     __syncthreads();
-    S2M_STAMP(3);
     // one fp64 row per workgroup, published write-through (agent-scope 8-byte stores) so the last
     // workgroup to arrive can read every row without a release/acquire fence pair
     if (threadIdx.x < T::kSlots) {
@@ -355,7 +317,6 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
     __syncthreads();
-    S2M_STAMP(4);
     __shared__ uint32_t s_last;
     if (threadIdx.x == 0) {
         // Two-level arrival count: same-address atomics serialise in L2 (~11 ns each), so 128 workgroups on
@@ -374,7 +335,6 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
     }
     __syncthreads();
     if (!s_last) return;
-    S2M_STAMP(5);
 
     // ---- last workgroup: fixed-order sum of the rows (independent of arrival order) -----------------
     // The order is a perfect BINARY TREE over the workgroup index (rows beyond the last one count as +0.0): lane ch
@@ -447,7 +407,6 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
         tot[t] = s;
     }
     __syncthreads();
-    S2M_STAMP(6);
     // far points of this pass (the two list lengths): published as block[158]; a pass that ran WITHOUT the far-point
     // kernel on the host's bet that the list would be empty is void when it is not -- the counters then stay for the redo
     const uint32_t far_points = a.hard_count ? a.hard_count[0] + a.hard_count[1] : 0u;
@@ -478,17 +437,6 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
     if (threadIdx.x == 0 && a.hard_count && !void_pass) { a.hard_count[0] = 0u; a.hard_count[1] = 0u; a.hard_count[2] = 0u; }
     if (a.qheads && threadIdx.x < kQueueShards && !void_pass) a.qheads[threadIdx.x * kQueueStride] = 0u;
     if (a.host_flag) publish_flag(a.host_flag, a.seq);
-#ifdef S2M_EXP_REDUCE_TIMELINE
-    if (threadIdx.x == 0) {
-        const long long t7 = wall_clock64();
-        unsigned long long lo = 0, hi = 0;
-        for (int k = 1; k <= 4; ++k) lo |= (unsigned long long)((tl_[k] - tl_[k - 1]) & 0xfff) << (12 * (k - 1));
-        hi = (unsigned long long)((tl_[5] - tl_[4]) & 0xfff) | ((unsigned long long)((tl_[6] - tl_[5]) & 0xfff) << 12) |
-             ((unsigned long long)((t7 - tl_[6]) & 0xfff) << 24);
-        a.block[158] = (double)lo;
-        a.block[159] = (double)hi;
-    }
-#endif
 }
 
 template <bool EXT, bool FIT>
