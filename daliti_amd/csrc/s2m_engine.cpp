@@ -111,6 +111,14 @@ struct s2m_engine {
     uint32_t *d_bcnt = nullptr;    // two sets of {16 counter words, kQueueWords queue heads}, used alternately
     unsigned long long bwave = 0;  // launches so far (selects the set)
 
+    // device-resident loop (s2m_loop.h): state on the device, init record and result record in pinned host memory
+    LoopState *d_loop = nullptr;
+    LoopInit *h_init = nullptr, *h_init_dev = nullptr;
+    LoopRecord *h_rec = nullptr, *h_rec_dev = nullptr;
+    unsigned long long loop_seq = 0;   // one per enqueued chunk: the value the record's flag takes
+    int32_t loop_gen = 0;              // generation of the enqueued plan (a re-plan after a wrong prediction takes a new one)
+    std::vector<int8_t> sched_hist;    // which iterations of the last scan searched: the plan for the next one
+
     EskfWork work;
     Comm comm;  // attached RCCL communicator (multi-GPU form), handle == nullptr when single GPU
     ShmExchange shm;               // or: host shared-memory exchange between the processes of one node (s2m_comm_init_shm)
@@ -335,6 +343,7 @@ int s2m_config_default(s2m_config *c)
     c->cell_size = 0.0f;
     c->device = -1;
     c->far_point_bet = 1;
+    c->device_loop = 1;
     return S2M_OK;
 }
 
@@ -413,7 +422,9 @@ int s2m_destroy(s2m_engine *e)
     free_undist(e->und);
     comm_destroy(e->comm);
     shm_exchange_destroy(e->shm);
-    void *ptrs[] = {e->d_brec, e->d_bcnt, e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
+    if (e->h_init) (void)hipHostFree(e->h_init);
+    if (e->h_rec) (void)hipHostFree(e->h_rec);
+    void *ptrs[] = {e->d_loop, e->d_brec, e->d_bcnt, e->d_stage, e->d_scan, e->d_plane, e->d_flags, e->d_sel, e->d_eff, e->d_pd2, e->d_nn_idx,
                     e->d_nn_d2, e->d_hard, e->d_qheads, e->d_hrec, e->d_ticket, e->d_partials, e->d_block, e->d_block_off, e->d_hx, e->d_h, e->d_rowidx};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1181,6 +1192,219 @@ static int shm_sum(s2m_engine *e, const double **hb, bool bet, bool *any_void)
     return S2M_OK;
 }
 
+namespace {
+constexpr int kLoopChunk = 6;  // iterations enqueued ahead (the reference's yaml runs 10 at most and leaves after ~5)
+
+int ensure_loop(s2m_engine *e)
+{
+    if (e->d_loop) return S2M_OK;
+    S2M_HIP(e, hipMalloc((void **)&e->d_loop, sizeof(LoopState)));
+    S2M_HIP(e, hipMemsetAsync(e->d_loop, 0, sizeof(LoopState), e->stream));
+    S2M_HIP(e, hipHostMalloc((void **)&e->h_init, sizeof(LoopInit), hipHostMallocMapped));
+    S2M_HIP(e, hipHostGetDevicePointer((void **)&e->h_init_dev, e->h_init, 0));
+    S2M_HIP(e, hipHostMalloc((void **)&e->h_rec, sizeof(LoopRecord), hipHostMallocMapped));
+    S2M_HIP(e, hipHostGetDevicePointer((void **)&e->h_rec_dev, e->h_rec, 0));
+    std::memset(e->h_rec, 0, sizeof(LoopRecord));
+    return S2M_OK;
+}
+
+// can this handle's update run with the state on the device?
+bool loop_eligible(const s2m_engine *e)
+{
+    return e->cfg.device_loop != 0 && !e->comm.handle && !e->shm.base && e->host_poll && !e->timing && e->scan_ready &&
+           e->cfg.max_iter <= kLoopMaxIter;
+}
+
+// the init record of a scan: state, G and C^-1 (s2m_loop.h), thresholds, degeneracy queue.  false: P[0:nc, 0:nc] is not
+// positive definite -- the caller takes the host-stepped loop, whose LU form does not need that
+bool loop_fill_init(s2m_engine *e, const double *x, const double *x_prop, const double *P)
+{
+    LoopInit &in = *e->h_init;
+    const int nc = e->cfg.extrinsic_est_en ? 12 : 6;
+    if (!loop_prepare(e->cfg.laser_point_cov, P, nc, in.G, in.Cinv)) return false;
+    std::memcpy(in.x, x, sizeof(in.x));
+    std::memcpy(in.x_prop, x_prop, sizeof(in.x_prop));
+    in.conv_rot_deg = e->cfg.conv_rot_deg;
+    in.conv_pos_cm = e->cfg.conv_pos_cm;
+    in.max_iter = e->cfg.max_iter;
+    in.feat_threshold = e->cfg.feat_threshold;
+    in.nc = nc;
+    in.queue_len = e->queue_len;
+    std::memset(in.queue, 0, sizeof(in.queue));
+    std::memcpy(in.queue, e->queue, sizeof(int32_t) * (S2M_FEAT_QUEUE + 1));
+    return true;
+}
+
+int loop_wait(s2m_engine *e, unsigned long long seq)
+{
+    volatile unsigned long long *flag = &e->h_rec->flag;
+    for (long spin = 0; spin < 40000000L; ++spin) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return S2M_OK;
+        __builtin_ia32_pause();
+    }
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(e, S2M_ERR_HIP, "the device-resident loop did not publish its record");
+    return S2M_OK;
+}
+
+// what the host does with the record of a finished loop: state, log, degeneracy queue, covariance update (:1084-1085),
+// and the handle's bookkeeping of the last pass
+int loop_finish(s2m_engine *e, double *x, double *P, s2m_iter_log *log)
+{
+    const LoopRecord &rec = *e->h_rec;
+    if (rec.numeric) return fail(e, S2M_ERR_NUMERIC, "singular matrix in eskf update");
+    const int iters = rec.iters;
+    std::memcpy(x, rec.x, sizeof(rec.x));
+    if (log) {
+        log->iters = iters;
+        log->rematch_passes = rec.passes;
+        log->converged = rec.conv;
+        log->ekf_stop = rec.stop;
+        for (int i = 0; i < iters && i < 64; ++i) {
+            log->effct[i] = rec.effct[i];
+            log->rematch[i] = rec.rematch[i];
+            log->conv[i] = rec.conv_it[i];
+            log->total_residual[i] = rec.total_residual[i];
+            std::memcpy(log->solution[i], rec.solution[i], sizeof(rec.solution[i]));
+        }
+    }
+    std::memcpy(e->queue, rec.queue, sizeof(int32_t) * (S2M_FEAT_QUEUE + 1));
+    e->queue_len = rec.queue_len;
+    if (rec.update_cov && !loop_cov_update(e->h_init->G, e->h_init->Cinv, rec.block, e->h_init->nc, P))
+        return fail(e, S2M_ERR_NUMERIC, "singular matrix in the covariance update");
+    double st[S2M_STATE_DOUBLES] = {0};
+    std::memcpy(st, rec.pose_last, sizeof(rec.pose_last));
+    e->last_pose = pose_of(st);
+    std::memcpy(st, rec.pose_rematch, sizeof(rec.pose_rematch));
+    e->rematch_pose = pose_of(st);
+    e->last_rematch = iters > 0 && rec.rematch[iters - 1] != 0;
+    e->nn_valid = true;
+    e->nn_complete = false;
+    e->pass_done = true;
+    e->sched_hist.assign((size_t)e->cfg.max_iter, 0);
+    for (int i = 0; i < iters; ++i) {
+        e->sched_hist[i] = (int8_t)(rec.rematch[i] != 0);
+        if (rec.rematch[i]) { if (i == 0) e->far_first = rec.far_points[i]; else e->far_later = rec.far_points[i]; }
+    }
+    return S2M_OK;
+}
+
+// One scan's device-resident update as three steps, so that several handles can have their chains in flight at once:
+// loop_begin (init record, plan), then loop_enqueue (the kernels of up to kLoopChunk iterations, following the schedule
+// of the previous scan on this handle: which iterations searched) and loop_collect (wait for the record; finish, or go on
+// from where the chunk ended or the plan did not hold) until run.done.  Every kernel looks at the control words the
+// previous pass left and leaves at once when it is not due; a pass that needs a search the host did not enqueue stops
+// the chain and reports.
+struct LoopRun {
+    std::vector<int8_t> kinds;
+    Pose pose0;
+    int it0 = 0;
+    bool first = true, done = false;
+    unsigned long long seq = 0;
+    int guard = 0;
+};
+
+int loop_begin(s2m_engine *e, const double *x, const double *x_prop, const double *P, s2m_iter_log *log, LoopRun &run, bool &used)
+{
+    used = false;
+    if (!loop_eligible(e)) return S2M_OK;
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
+    S2M_HIP(e, hipSetDevice(e->device));
+    int rc = ensure_loop(e);
+    if (rc) return rc;
+    if (!loop_fill_init(e, x, x_prop, P)) return S2M_OK;
+    used = true;
+    const int max_iter = e->cfg.max_iter;
+    reset_log(log, max_iter);
+    e->nn_valid = false;
+    run.kinds.assign((size_t)max_iter, 1);   // no history: search kernels in front of every pass (never wrong)
+    if ((int)e->sched_hist.size() == max_iter) run.kinds = e->sched_hist;
+    run.kinds[0] = 1;
+    run.pose0 = pose_of(x);
+    return S2M_OK;
+}
+
+int loop_enqueue(s2m_engine *e, LoopRun &run)
+{
+    S2M_HIP(e, hipSetDevice(e->device));
+    const int max_iter = e->cfg.max_iter;
+    const Gates gates = gates_of(e->cfg);
+    const int n = (int)e->n;
+    float *sx = e->d_scan, *sy = e->d_scan + e->n_cap, *sz = e->d_scan + 2 * e->n_cap;
+    run.seq = ++e->loop_seq;
+    if (++e->loop_gen <= 0) e->loop_gen = 1;
+    const int it_end = std::min(max_iter, run.it0 + kLoopChunk);
+    for (int it = run.it0; it < it_end; ++it) {
+        LoopLaunch l;
+        l.state = e->d_loop; l.record = e->h_rec_dev; l.seq = run.seq;
+        l.expect_it = it; l.kind = run.kinds[it]; l.gen = e->loop_gen; l.last_of_chunk = it == it_end - 1 ? 1 : 0;
+        l.init = (run.first && it == run.it0) ? e->h_init_dev : nullptr;
+        if (run.kinds[it]) {
+            MatchArgs m;
+            m.grid = e->grid; m.pose = run.pose0; m.gates = gates;
+            m.sx = sx; m.sy = sy; m.sz = sz; m.n = n;
+            m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
+            m.hard_rec = e->d_hrec; m.hard_off1 = n; m.hard_count = e->d_hard + 3 * e->n_cap;
+            m.qheads = e->d_qheads;
+            m.loop = l;
+            // few far points expected (the pass in this position of the last scan had none): a small far-point grid -- the
+            // queue serves any number, a wrong guess only costs time
+            const int64_t hist = it == 0 ? e->far_first : e->far_later;
+            m.far_waves = (e->spec_mode != 0 && hist == 0) ? 256 : 0;
+            int group = e->match_group;
+            if (((group >> 8) & 0xf) == 0 && ((int64_t)n * 2 > 3072 * 64 || e->in_batch)) group |= 2 << 8;
+            launch_match(m, group, e->stream);
+        }
+        ReduceArgs r;
+        r.pose = run.pose0; r.gates = gates;
+        r.sx = sx; r.sy = sy; r.sz = sz; r.n = n;
+        r.fit = 0;
+        r.nn_idx = e->d_nn_idx; r.nn_d2 = e->d_nn_d2; r.pts = e->grid.pts;
+        r.plane = e->d_plane; r.flags = e->d_flags; r.sel = e->d_sel; r.eff = e->d_eff; r.pd2 = e->d_pd2;
+        r.partials = e->d_partials; r.block = e->d_block;
+        r.ticket = e->d_ticket; r.hard_count = e->d_hard + 3 * e->n_cap;
+        r.qheads = e->d_qheads;
+        r.spec = 0;
+        r.host_block = nullptr; r.host_flag = nullptr; r.seq = 0;
+        r.loop = l;
+        launch_reduce(r, e->stream);
+    }
+    S2M_HIP(e, hipGetLastError());
+    run.first = false;
+    return S2M_OK;
+}
+
+int loop_collect(s2m_engine *e, LoopRun &run, double *x, double *P, s2m_iter_log *log)
+{
+    int rc = loop_wait(e, run.seq);
+    if (rc) return rc;
+    const LoopRecord &rec = *e->h_rec;
+    if (rec.finished) {
+        run.done = true;
+        return loop_finish(e, x, P, log);
+    }
+    run.it0 = rec.iters;                 // the chunk ended, or the plan did not hold at this iteration: go on from here
+    if (run.it0 < 0 || run.it0 >= e->cfg.max_iter || ++run.guard > 4 * kLoopMaxIter)
+        return fail(e, S2M_ERR_HIP, "the device-resident loop did not end");
+    if (rec.abort) run.kinds[run.it0] = 1;
+    return S2M_OK;
+}
+
+int iterated_update_loop(s2m_engine *e, double *x, const double *x_prop, double *P, s2m_iter_log *log, bool &used)
+{
+    LoopRun run;
+    int rc = loop_begin(e, x, x_prop, P, log, run, used);
+    if (rc || !used) return rc;
+    while (!run.done) {
+        rc = loop_enqueue(e, run);
+        if (rc) return rc;
+        rc = loop_collect(e, run, x, P, log);
+        if (rc) return rc;
+    }
+    return S2M_OK;
+}
+}  // namespace
+
 int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double x_prop[S2M_STATE_DOUBLES],
                                 double P[S2M_DIM * S2M_DIM], s2m_iter_log *log, double *d_block,
                                 s2m_allreduce_fn reduce, void *user)
@@ -1188,6 +1412,11 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
     if (!e || !x || !x_prop || !P) return fail(e, S2M_ERR_ARG, "null argument");
     if (reduce && !d_block) return fail(e, S2M_ERR_ARG, "sharded update needs a device block");
     if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
+    if (!reduce && (!d_block || d_block == e->d_block)) {  // state on the device where the form allows it (s2m_loop.h)
+        bool used = false;
+        int rc = iterated_update_loop(e, x, x_prop, P, log, used);
+        if (rc || used) return rc;
+    }
     if (!d_block) d_block = e->d_block;
     // a new scan starts with every point selected and no neighbours (laserMapping.cpp:810-818);
     // iteration 0 is always a rematch pass, whose gate rewrites point_selected_surf for every point
@@ -1295,6 +1524,8 @@ int s2m_iterated_update(s2m_engine *e, double x[S2M_STATE_DOUBLES], const double
 // idle during every host turn-around and most of every latency-bound kernel).
 namespace {
 int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *x_prop, double *P, s2m_iter_log *logs);
+int batch_fused_loop(s2m_engine *const *handles, int32_t k, double *x, const double *x_prop, double *P, s2m_iter_log *logs,
+                     bool &used);
 
 // the K scans can go through ONE grid per pass when they search the same map on the same device with the same gates
 bool batch_can_fuse(s2m_engine *const *handles, int32_t k)
@@ -1325,7 +1556,50 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
                  handles[i]->device == handles[0]->device;
             for (int j = 0; j < i && ok; ++j) ok = handles[j] != handles[i];
         }
-        if (ok && batch_can_fuse(handles, k)) return batch_fused(handles, k, x, x_prop, P, logs);
+        if (ok && batch_can_fuse(handles, k)) {
+            bool used = false;
+            int rc = batch_fused_loop(handles, k, x, x_prop, P, logs, used);   // state on the device where every scan allows it
+            if (rc || used) return rc;
+            return batch_fused(handles, k, x, x_prop, P, logs);
+        }
+    }
+    {   // handles that cannot share a launch (different maps or gates): every handle's chain on its own stream, state on the
+        // device, all K in flight at once; the host only collects.  (Handles that cannot take the device-resident loop
+        // fall through to the host-stepped form below.)
+        bool all = true;
+        for (int i = 0; i < k && all; ++i) all = handles[i] != nullptr && loop_eligible(handles[i]) && handles[i]->map_ready;
+        for (int i = 0; i < k && all; ++i)
+            for (int j = 0; j < i && all; ++j) all = handles[j] != handles[i];
+        if (all) {
+            std::vector<LoopRun> runs((size_t)k);
+            std::vector<char> used((size_t)k, 0);
+            bool every = true;
+            for (int i = 0; i < k; ++i) {
+                bool u = false;
+                handles[i]->in_batch = k >= 4;
+                int rc = loop_begin(handles[i], x + (size_t)i * S2M_STATE_DOUBLES, x_prop + (size_t)i * S2M_STATE_DOUBLES,
+                                    P + (size_t)i * S2M_DIM * S2M_DIM, logs ? logs + i : nullptr, runs[i], u);
+                if (rc) { for (int j = 0; j <= i; ++j) handles[j]->in_batch = false; return rc; }
+                used[i] = u;
+                every = every && u;
+            }
+            if (every) {
+                int left = k, rc = S2M_OK;
+                while (left > 0 && rc == S2M_OK) {
+                    for (int i = 0; i < k && rc == S2M_OK; ++i)
+                        if (!runs[i].done) rc = loop_enqueue(handles[i], runs[i]);
+                    for (int i = 0; i < k && rc == S2M_OK; ++i)
+                        if (!runs[i].done) {
+                            rc = loop_collect(handles[i], runs[i], x + (size_t)i * S2M_STATE_DOUBLES, P + (size_t)i * S2M_DIM * S2M_DIM,
+                                              logs ? logs + i : nullptr);
+                            if (runs[i].done) --left;
+                        }
+                }
+                for (int i = 0; i < k; ++i) handles[i]->in_batch = false;
+                return rc;
+            }
+            for (int i = 0; i < k; ++i) handles[i]->in_batch = false;   // nothing was enqueued: the host-stepped form takes over
+        }
     }
     struct Slot {
         IterCtl c{0, 1, 0, 0, 0, 0};
@@ -1677,6 +1951,149 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
             for (int g = 0; g < ng; ++g) S2M_HIP(groups[g].lead, hipStreamSynchronize(groups[g].lead->stream));
             return fail(handles[0], S2M_ERR_HIP, "s2m_iterated_update_batch: a pass did not publish its block");
         }
+    }
+    return S2M_OK;
+}
+}  // namespace
+
+namespace {
+// The batched form with the loops on the device: the K scans are dealt to launch groups as in batch_fused, but a group's
+// passes are enqueued kLoopChunk iterations ahead -- search kernels in front of every pass (the scans of a group do not
+// rematch in the same iterations; a scan that does not search leaves those kernels at once), ONE reduce launch per pass
+// for the rematching and the reusing scans alike -- and the host only collects the K records at the end.  No host turn-
+// around between the passes, no lock step with the host: the groups' chains fill the chip side by side.
+int batch_fused_loop(s2m_engine *const *handles, int32_t k, double *x, const double *x_prop, double *P, s2m_iter_log *logs,
+                     bool &used)
+{
+    used = false;
+    bool any_points = false;
+    for (int i = 0; i < k; ++i) {
+        if (!loop_eligible(handles[i])) return S2M_OK;
+        any_points = any_points || handles[i]->n > 0;
+    }
+    if (!any_points) return S2M_OK;
+    struct Group {
+        int first = 0, count = 0;
+        s2m_engine *lead = nullptr;
+        BatchArgs args;
+    };
+    int ng = k >= 4 ? 2 : 1;
+    for (int g : {8, 4})
+        if (k % g == 0 && k / g >= 2) { ng = k / g; break; }
+    while ((k + ng - 1) / ng > kBatchMax) ++ng;
+    std::vector<Group> groups((size_t)ng);
+    auto xk = [&](int i) { return x + (size_t)i * S2M_STATE_DOUBLES; };
+    auto xpk = [&](int i) { return x_prop + (size_t)i * S2M_STATE_DOUBLES; };
+    auto Pk = [&](int i) { return P + (size_t)i * S2M_DIM * S2M_DIM; };
+    s2m_engine *e0 = handles[0];
+    S2M_HIP(e0, hipSetDevice(e0->device));
+    for (int i = 0; i < k; ++i) {
+        int rc = ensure_loop(handles[i]);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < k; ++i)   // before anything is enqueued: a covariance the Cholesky form cannot take sends the call back
+        if (!loop_fill_init(handles[i], xk(i), xpk(i), Pk(i))) return S2M_OK;
+    used = true;
+    const int max_iter = e0->cfg.max_iter;
+    for (int g = 0, at = 0; g < ng; ++g) {
+        Group &G = groups[g];
+        G.first = at;
+        G.count = (k - at + (ng - g) - 1) / (ng - g);
+        at += G.count;
+        G.lead = handles[G.first];
+        int64_t total = 0;
+        int n_max = 0;
+        for (int i = G.first; i < G.first + G.count; ++i) {
+            total += handles[i]->n;
+            n_max = std::max<int>(n_max, (int)handles[i]->n);
+        }
+        s2m_engine *L = G.lead;
+        if (L->brec_cap < total || !L->d_brec) {
+            int rc = grow(L, &L->d_brec, 2 * total);
+            if (rc) return rc;
+            L->brec_cap = total;
+        }
+        if (!L->d_bcnt) {
+            const size_t words = 2 * (16 + kQueueWords);
+            S2M_HIP(L, hipMalloc((void **)&L->d_bcnt, words * sizeof(uint32_t)));
+            S2M_HIP(L, hipMemsetAsync(L->d_bcnt, 0, words * sizeof(uint32_t), L->stream));
+        }
+        BatchArgs &b = G.args;
+        b.grid = L->grid;
+        b.gates = gates_of(L->cfg);
+        b.k = G.count;
+        b.n_max = n_max;
+        b.hard_rec = L->d_brec;
+        b.hard_off1 = L->brec_cap;
+        for (int j = 0; j < kBatchMax; ++j) b.d[j] = ScanDesc{};
+        for (int j = 0; j < G.count; ++j) {
+            s2m_engine *e = handles[G.first + j];
+            ScanDesc &d = b.d[j];
+            d.pose = pose_of(xk(G.first + j));
+            d.sx = e->d_scan; d.sy = e->d_scan + e->n_cap; d.sz = e->d_scan + 2 * e->n_cap;
+            d.nn_idx = e->d_nn_idx; d.nn_d2 = e->d_nn_d2;
+            d.plane = e->d_plane; d.flags = e->d_flags; d.sel = e->d_sel; d.eff = e->d_eff; d.pd2 = e->d_pd2;
+            d.partials = e->d_partials; d.block = e->d_block; d.ticket = e->d_ticket;
+            d.host_block = nullptr; d.host_flag = nullptr; d.seq = 0;
+            d.n = (int32_t)e->n;
+            d.rematch = 1;
+            d.active = 1;
+            d.loop.state = e->d_loop;
+            d.loop.record = e->h_rec_dev;
+            e->nn_valid = false;
+            reset_log(logs ? logs + G.first + j : nullptr, e->cfg.max_iter);
+            if (e != L && e->stream != L->stream) S2M_HIP(e, hipStreamSynchronize(e->stream));
+        }
+    }
+    std::vector<char> done((size_t)k, 0);
+    int left = k, it0 = 0;
+    bool first = true;
+    while (left > 0) {
+        if (it0 >= max_iter) return fail(e0, S2M_ERR_HIP, "s2m_iterated_update_batch: a device-resident loop did not end");
+        const int it_end = std::min(max_iter, it0 + kLoopChunk);
+        for (int i = 0; i < k; ++i) {
+            s2m_engine *e = handles[i];
+            ++e->loop_seq;
+            if (++e->loop_gen <= 0) e->loop_gen = 1;
+        }
+        for (int it = it0; it < it_end; ++it)
+            for (int g = 0; g < ng; ++g) {
+                Group &G = groups[g];
+                s2m_engine *L = G.lead;
+                BatchArgs &b = G.args;
+                uint32_t *set0 = L->d_bcnt, *set1 = L->d_bcnt + (16 + kQueueWords);
+                const bool odd = (L->bwave++ & 1ull) != 0;
+                b.hard_count = odd ? set1 : set0;            b.qheads = b.hard_count + 16;
+                b.hard_count_next = odd ? set0 : set1;       b.qheads_next = b.hard_count_next + 16;
+                for (int j = 0; j < G.count; ++j) {
+                    s2m_engine *e = handles[G.first + j];
+                    LoopLaunch &l = b.d[j].loop;
+                    b.d[j].active = done[G.first + j] ? 0 : 1;
+                    l.seq = e->loop_seq; l.gen = e->loop_gen;
+                    l.expect_it = it; l.kind = 1; l.last_of_chunk = it == it_end - 1 ? 1 : 0;
+                    l.init = (first && it == it0) ? e->h_init_dev : nullptr;
+                }
+                launch_match_batch(b, L->stream);
+                launch_reduce_batch_loop(b, L->stream);
+                S2M_HIP(L, hipGetLastError());
+            }
+        first = false;
+        int next_it = max_iter;
+        for (int i = 0; i < k; ++i) {
+            if (done[i]) continue;
+            s2m_engine *e = handles[i];
+            int rc = loop_wait(e, e->loop_seq);
+            if (rc) return rc;
+            if (e->h_rec->finished) {
+                rc = loop_finish(e, xk(i), Pk(i), logs ? logs + i : nullptr);
+                if (rc) return rc;
+                done[i] = 1;
+                --left;
+            } else {
+                next_it = std::min<int>(next_it, e->h_rec->iters);
+            }
+        }
+        it0 = left > 0 ? next_it : max_iter;
     }
     return S2M_OK;
 }

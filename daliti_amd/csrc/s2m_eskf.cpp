@@ -225,6 +225,91 @@ bool eskf_update(const EskfParams &p, State &x, const State &x_prop, const Mat24
     return true;
 }
 
+namespace {
+// Cholesky factor of the symmetric positive definite n x n matrix M (row-major, n <= 12) in place, lower triangle
+bool chol_factor(double *M, int n)
+{
+    for (int j = 0; j < n; ++j) {
+        double d = M[j * n + j];
+        for (int k = 0; k < j; ++k) d -= M[j * n + k] * M[j * n + k];
+        if (!(d > 0.0)) return false;
+        d = std::sqrt(d);
+        M[j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double v = M[i * n + j];
+            for (int k = 0; k < j; ++k) v -= M[i * n + k] * M[j * n + k];
+            M[i * n + j] = v / d;
+        }
+    }
+    return true;
+}
+// x <- (L L^T)^-1 x
+void chol_solve(const double *L, int n, double *x)
+{
+    for (int i = 0; i < n; ++i) {
+        double v = x[i];
+        for (int k = 0; k < i; ++k) v -= L[i * n + k] * x[k];
+        x[i] = v / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double v = x[i];
+        for (int k = i + 1; k < n; ++k) v -= L[k * n + i] * x[k];
+        x[i] = v / L[i * n + i];
+    }
+}
+}  // namespace
+
+bool loop_prepare(double laser_point_cov, const double *P, int nc, double *G, double *Cinv)
+{
+    constexpr int N = kDim;
+    double L[144];
+    for (int r = 0; r < nc; ++r)
+        for (int c = 0; c < nc; ++c) L[r * nc + c] = P[r * N + c] / laser_point_cov;
+    if (!chol_factor(L, nc)) return false;
+    for (int c = 0; c < nc; ++c) {  // C^-1 column by column (symmetric: stored as is)
+        double e[12];
+        for (int r = 0; r < nc; ++r) e[r] = r == c ? 1.0 : 0.0;
+        chol_solve(L, nc, e);
+        for (int r = 0; r < nc; ++r) Cinv[r * nc + c] = e[r];
+    }
+    for (int r = 0; r < nc; ++r)    // exactly symmetric (the device adds it to the symmetric H^T H and factors the sum)
+        for (int c = r + 1; c < nc; ++c) Cinv[r * nc + c] = Cinv[c * nc + r] = 0.5 * (Cinv[r * nc + c] + Cinv[c * nc + r]);
+    for (int r = 0; r < N; ++r)
+        for (int c = 0; c < nc; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < nc; ++k) s += (P[r * N + k] / laser_point_cov) * Cinv[k * nc + c];
+            G[r * nc + c] = s;
+        }
+    return true;
+}
+
+bool loop_cov_update(const double *G, const double *Cinv, const double *HtH, int nc, double *P)
+{
+    constexpr int N = kDim;
+    double M[144];
+    for (int r = 0; r < nc; ++r)
+        for (int c = 0; c < nc; ++c) M[r * nc + c] = Cinv[r * nc + c] + HtH[r * 12 + c];
+    if (!chol_factor(M, nc)) return false;
+    double Y[12 * N];  // M^-1 (A P[0:nc, :]), column by column
+    for (int c = 0; c < N; ++c) {
+        double y[12];
+        for (int r = 0; r < nc; ++r) {
+            double s = 0.0;
+            for (int k = 0; k < nc; ++k) s += HtH[r * 12 + k] * P[k * N + c];
+            y[r] = s;
+        }
+        chol_solve(M, nc, y);
+        for (int r = 0; r < nc; ++r) Y[r * N + c] = y[r];
+    }
+    for (int r = 0; r < N; ++r)
+        for (int c = 0; c < N; ++c) {
+            double s = 0.0;
+            for (int k = 0; k < nc; ++k) s += G[r * nc + k] * Y[k * N + c];
+            P[r * N + c] -= s;
+        }
+    return true;
+}
+
 S2M_CPU_CLONES void cov_update(const EskfWork &work, Mat24 &P)
 {
     constexpr int N = kDim;

@@ -57,4 +57,11 @@ bool eskf_update(const EskfParams &p, State &x, const State &x_prop, const Mat24
 // P <- (I - K_1[:, :12] * HtH (+) 0) * P
 void cov_update(const EskfWork &work, Mat24 &P);
 
+// ---- the same update in the form the device-resident loop uses (s2m_loop.h): with P' = P / R, C = P'[0:nc, 0:nc],
+// K_1[:, 0:nc] = G M^-1, G = P'[:, 0:nc] C^-1 (24 x nc, row-major), M = C^-1 + H^T H.
+// G and C^-1 (nc x nc) for the scan; false when C is not positive definite (the caller falls back to the LU form)
+bool loop_prepare(double laser_point_cov, const double *P, int nc, double *G, double *Cinv);
+// P <- P - G M^-1 (A P[0:nc, :]) with A = HtH (12 x 12 layout); false when M is not positive definite
+bool loop_cov_update(const double *G, const double *Cinv, const double *HtH, int nc, double *P);
+
 }  // namespace s2m

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "s2m_device.h"
+#include "s2m_loop.h"
 
 namespace s2m {
 
@@ -193,6 +194,8 @@ struct MatchArgs {
     uint32_t slot = 0;   // which scan of a batched launch this is (travels in the record so that match_hard finds the outputs)
     uint32_t *hard_count; // the two lengths (device counters, reset by every reduce launch)
     uint32_t *qheads = nullptr;  // kQueueShards dequeue heads of match_hard's work queue, kQueueStride words apart
+    LoopLaunch loop;             // device-resident loop (s2m_loop.h): state == nullptr for a host-stepped pass
+    int32_t far_waves = 0;       // > 0: waves of the far-point launch (few far points expected); 0: as many as stay resident
 };
 // first shell (s2m_match.hip), then -- unless `group` carries bit 0x40000 -- the far-point kernel (s2m_match_far.hip)
 void launch_match(const MatchArgs &a, int group, hipStream_t st);
@@ -237,6 +240,8 @@ struct ReduceArgs {
     double *host_block;              // optional: pinned host copy of block, device-visible pointer
     unsigned long long *host_flag;   // optional: set to seq (system scope) after host_block is written
     unsigned long long seq;
+    LoopLaunch loop;                 // device-resident loop: pose and pass kind come from loop.state, the last workgroup
+                                     // runs the Kalman update and the judgement (s2m_loop.h)
 };
 // ---- one grid for K scans (s2m_iterated_update_batch, BASELINE configs[4] on one device) -----------------------
 // Every pass of the K scans that are ready is ONE launch per kernel: blockIdx.y selects the scan, whose pose, flags
@@ -262,6 +267,7 @@ struct ScanDesc {
     int32_t rematch;   // this pass runs the search (and the plane fit) for this scan
     int32_t active;    // 0: the scan has finished (or is not part of this launch)
     int32_t pad;
+    LoopLaunch loop;   // device-resident loop: pose / rematch / active come from loop.state instead
 };
 struct BatchArgs {
     Grid grid;
@@ -282,6 +288,7 @@ static_assert(sizeof(BatchArgs) <= 4096, "the table must fit the kernel-argument
 void launch_match_batch(const BatchArgs &b, hipStream_t st);
 void launch_far_points_batch(const BatchArgs &b, bool wide, hipStream_t st);
 void launch_reduce_batch(const BatchArgs &b, bool any_fit, bool any_plain, hipStream_t st);
+void launch_reduce_batch_loop(const BatchArgs &b, hipStream_t st);  // every scan of the table runs the device-resident loop
 
 int reduce_blocks(int n);
 int rows_blocks(int n);

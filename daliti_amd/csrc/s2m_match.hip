@@ -243,6 +243,22 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
     match_rows_body<G, WIDE, NB>(a, runs);
 }
 
+// the same inside the device-resident loop (s2m_loop.h): the first kernel of a scan runs at the pose in its arguments
+// and has workgroup 0 bring the init record over; a later one runs only if the device decided to search again, at the
+// pose the last update left
+template <int G, bool WIDE, int NB>
+__global__ __launch_bounds__(256) void match_rows_loop(MatchArgs a)
+{
+    __shared__ uint2 runs[kRunSlots * 256];
+    if (a.loop.init) {
+        if (blockIdx.x == 0) loop_copy_init(a.loop);
+    } else {
+        if (!loop_launch_due(a.loop) || !a.loop.state->rematch_now) return;
+        a.pose = loop_pose(a.loop.state);
+    }
+    match_rows_body<G, WIDE, NB>(a, runs);
+}
+
 // the search arguments of scan blockIdx.y of a batched launch (everything uniform: scalar loads from the table)
 __device__ __forceinline__ MatchArgs batch_match_args(const BatchArgs &b, uint32_t slot)
 {
@@ -261,8 +277,18 @@ __global__ __launch_bounds__(256) void match_rows_batch(BatchArgs b)
 {
     __shared__ uint2 runs[kRunSlots * 256];
     const ScanDesc &d = b.d[blockIdx.y];
-    if (!d.active || !d.rematch) return;
-    const MatchArgs a = batch_match_args(b, blockIdx.y);
+    if (!d.active) return;
+    MatchArgs a = batch_match_args(b, blockIdx.y);
+    if (d.loop.state) {  // device-resident loop: the device knows whether this scan searches in this pass
+        if (d.loop.init) {
+            if (blockIdx.x == 0) loop_copy_init(d.loop);
+        } else {
+            if (!loop_launch_due(d.loop) || !d.loop.state->rematch_now) return;
+            a.pose = loop_pose(d.loop.state);
+        }
+    } else if (!d.rematch) {
+        return;
+    }
     match_rows_body<G, WIDE, NB>(a, runs);
 }
 
@@ -275,7 +301,15 @@ void launch_match(const MatchArgs &a, int group, hipStream_t st)
     const bool wide = (a.grid.sent_off == 0 && a.grid.m != 0) || (group & 0x10000);
     const int nb = (group >> 8) & 0xf;
     const int blocks = (int)(((int64_t)a.n * 2 + 255) / 256);
-    if (nb == 2) {
+    if (a.loop.state) {
+        if (nb == 2) {
+            if (!wide) hipLaunchKernelGGL((match_rows_loop<2, false, 2>), dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((match_rows_loop<2, true, 2>), dim3(blocks), dim3(256), 0, st, a);
+        } else {
+            if (!wide) hipLaunchKernelGGL((match_rows_loop<2, false, 3>), dim3(blocks), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((match_rows_loop<2, true, 3>), dim3(blocks), dim3(256), 0, st, a);
+        }
+    } else if (nb == 2) {
         if (!wide) hipLaunchKernelGGL((match_rows<2, false, 2>), dim3(blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((match_rows<2, true, 2>), dim3(blocks), dim3(256), 0, st, a);
     } else {  // default: three batches (24 point loads) per trip

@@ -637,6 +637,9 @@ template <bool WIDE, bool FAR = false>
 __global__ __launch_bounds__(256, kHardOcc) void match_hard(MatchArgs a)
 {
     __shared__ uint2 cells_all[4][kMaxCells];  // one cell list per wave of the workgroup
+    // device-resident loop: a launch of an iteration in which the device did not search finds an empty list anyway (every
+    // reduce launch zeroes the counters); leaving here saves the waves the look
+    if (!FAR && a.loop.state && (!loop_launch_due(a.loop) || !a.loop.state->rematch_now)) return;
     match_hard_body<WIDE, FAR>(a, cells_all[threadIdx.x >> 6], [&](uint32_t, int32_t *&idx, float *&d2) {
         idx = a.nn_idx;
         d2 = a.nn_d2;
@@ -748,7 +751,8 @@ void launch_far_points(const MatchArgs &a, bool wide, hipStream_t st)
     }
     // as many waves as stay resident together (4 per SIMD, 4,096 on the chip); the rest of the list is pulled through
     // the queue heads
-    const int64_t groups = std::min<int64_t>(a.n, a.qheads ? 1024 * kHardOcc : 8192);
+    int64_t groups = std::min<int64_t>(a.n, a.qheads ? 1024 * kHardOcc : 8192);
+    if (a.far_waves > 0 && a.qheads) groups = std::min<int64_t>(groups, a.far_waves);
     const int blocks = (int)((groups * 64 + 255) / 256);
     if (!wide) hipLaunchKernelGGL(match_hard<false>, dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(match_hard<true>, dim3(blocks), dim3(256), 0, st, a);

@@ -22,6 +22,7 @@
 
 #include "s2m_device.h"
 #include "s2m_kernels.h"
+#include "s2m_loop.h"
 #include "s2m_plane.h"
 #include "s2m_point.h"
 
@@ -160,14 +161,37 @@ __device__ __forceinline__ void pin(T &v)
 }
 
 
+// the workgroup's shared memory, declared once per kernel so that the two per-pass forms of a device-loop launch
+// (rematch / reuse, chosen at run time by a uniform branch) use the same storage
+template <bool EXT>
+struct ReduceShared {
+    using T = Terms<EXT ? 12 : 6>;
+    static constexpr int kLanes = kRedBlock / T::kSlots;  // lanes available per term in the final sum: 16 (NC = 6) or 5 (NC = 12)
+    static constexpr int kTree = kLanes >= 16 ? 16 : 4;   // ... of which a power of two takes part
+    double red[kRedBlock / 64][T::kSlots];
+    double part[kTree][T::kSlots];
+    double tot[T::kSlots];
+    double stage[EXT ? kRedBlock / 64 : 1][EXT ? 64 * 17 : 1];  // MFMA operand staging; rows padded to 17 doubles: conflict-free column reads
+    LoopScratch loop;
+    uint32_t last;
+};
+
+// system-scope store of a 32-bit word into the pinned record
+__device__ __forceinline__ void publish_word(int32_t *dst, int32_t v)
+{
+    __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // bx / nblk: this workgroup's index among the workgroups of ITS scan and their number (blockIdx.x / gridDim.x for one
-// scan per launch; in a batched launch the grid is sized for the largest scan)
-template <bool EXT, bool FIT>
-__device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t bx, const uint32_t nblk)
+// scan per launch; in a batched launch the grid is sized for the largest scan).  FIT: rematch pass (gate + plane fit
+// first); LOOP: device-resident loop -- the last workgroup goes on with the Kalman update and the judgement (s2m_loop.h)
+template <bool EXT, bool FIT, bool LOOP>
+__device__ __forceinline__ void reduce_body(const ReduceArgs &a, ReduceShared<EXT> &sh, const uint32_t bx, const uint32_t nblk)
 {
     constexpr int NC = EXT ? 12 : 6;
     using T = Terms<NC>;
-    __shared__ double red[kRedBlock / 64][T::kSlots];
+    auto &red = sh.red;
+    LoopScratch &loop_scratch = sh.loop;
     const int i = (int)bx * kRedBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -248,8 +272,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
         // rocprof shows it beating the shuffle reduce").  Still a fixed function of the wave's 64 points: the
         // partition-consistency of the sums above the wave level is untouched.
         typedef double double4_t __attribute__((ext_vector_type(4)));
-        __shared__ double stage[kRedBlock / 64][64 * 17];  // rows padded to 17 doubles: conflict-free column reads
-        double *my = stage[wave];
+        double *my = sh.stage[wave];
 #pragma unroll
         for (int k = 0; k < 12; ++k) my[lane * 17 + k] = h[k];
         my[lane * 17 + 12] = z;
@@ -317,7 +340,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
     __syncthreads();
-    __shared__ uint32_t s_last;
+    uint32_t &s_last = sh.last;
     if (threadIdx.x == 0) {
         // Two-level arrival count: same-address atomics serialise in L2 (~11 ns each), so 128 workgroups on
         // one counter keep the last one waiting 1.4 us.  Sixteen group counters on separate cache lines take
@@ -344,11 +367,10 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
     // makes the sum PARTITION-CONSISTENT: a handle that holds an aligned power-of-two piece of the scan (rows
     // [r * S, (r + 1) * S) of the whole) computes exactly the node of this tree that covers those rows, so n such
     // blocks combined pairwise by the host (s2m_iterated_update_multi) reproduce the single-handle block bit for bit.
-    constexpr int kLanes = kRedBlock / T::kSlots;       // lanes available per term: 16 (NC = 6) or 5 (NC = 12)
-    constexpr int kTree = kLanes >= 16 ? 16 : 4;        // ... of which a power of two takes part
+    constexpr int kTree = ReduceShared<EXT>::kTree;     // lanes per term that take part: 16 (NC = 6) or 4 (NC = 12)
     constexpr int kDepth = 8;                           // independent loads in flight per lane
-    __shared__ double part[kTree][T::kSlots];
-    __shared__ double tot[T::kSlots];
+    auto &part = sh.part;
+    auto &tot = sh.tot;
     const int blocks = (int)nblk;
     int P = kTree;
     while (P < blocks) P <<= 1;
@@ -429,6 +451,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
         }
         a.block[o] = v;
         if (a.host_block) publish_store(a.host_block + o, v);
+        if (LOOP) loop_scratch.blk[o] = v;
     }
     if (threadIdx.x == 0) {
         __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
@@ -437,12 +460,90 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, const uint32_t 
     if (threadIdx.x == 0 && a.hard_count && !void_pass) { a.hard_count[0] = 0u; a.hard_count[1] = 0u; a.hard_count[2] = 0u; }
     if (a.qheads && threadIdx.x < kQueueShards && !void_pass) a.qheads[threadIdx.x * kQueueStride] = 0u;
     if (a.host_flag) publish_flag(a.host_flag, a.seq);
+    if constexpr (LOOP) {
+        // ---- device-resident loop: the Kalman update, the judgement and the hand-over to the next pass (s2m_loop.h) ----
+        LoopState *ls = a.loop.state;
+        LoopRecord *rec = a.loop.record;
+        const int it = ls->it;
+        loop_step(ls, loop_scratch, rec, FIT);
+        const int t = threadIdx.x;
+        // this iteration's log row, straight into the pinned record (what Log/mat_out.txt records, :936-937)
+        if (t < S2M_DIM) publish_store(&rec->solution[it][t], loop_scratch.sol[t]);
+        if (t == 32) {
+            publish_store(&rec->total_residual[it], loop_scratch.blk[157]);
+            publish_word(&rec->effct[it], (int32_t)loop_scratch.blk[156]);
+            publish_word(&rec->rematch[it], FIT ? 1 : 0);
+            publish_word(&rec->conv_it[it], ls->conv);
+            publish_word(&rec->far_points[it], (int32_t)loop_scratch.blk[158]);
+        }
+        if (!loop_scratch.finished && a.loop.last_of_chunk) {  // the host enqueued no further: tell it where the loop stands
+            if (t == 448) {
+                publish_word(&rec->iters, ls->it);
+                publish_word(&rec->finished, 0);
+                publish_word(&rec->abort, 0);
+            }
+            publish_flag(&rec->flag, a.loop.seq);
+        }
+        if (loop_scratch.finished) {
+            if (t < S2M_STATE_DOUBLES) publish_store(&rec->x[t], ls->in.x[t]);
+            if (t >= 64 && t < 64 + S2M_BLOCK_DOUBLES) publish_store(&rec->block[t - 64], loop_scratch.blk[t - 64]);
+            if (t >= 256 && t < 256 + 24) publish_store(&rec->pose_last[t - 256], ls->pose_last[t - 256]);
+            if (t >= 320 && t < 320 + 24) publish_store(&rec->pose_rematch[t - 320], ls->pose_rematch[t - 320]);
+            if (t >= 384 && t < 384 + S2M_FEAT_QUEUE + 2) publish_word(&rec->queue[t - 384], ls->in.queue[t - 384]);
+            if (t == 448) {
+                publish_word(&rec->queue_len, ls->in.queue_len);
+                publish_word(&rec->iters, ls->it);
+                publish_word(&rec->passes, ls->passes);
+                publish_word(&rec->conv, ls->conv);
+                publish_word(&rec->stop, ls->stop);
+                publish_word(&rec->finished, 1);
+                publish_word(&rec->abort, 0);
+                publish_word(&rec->numeric, ls->numeric);
+                publish_word(&rec->update_cov, ls->update_cov);
+            }
+            publish_flag(&rec->flag, a.loop.seq);
+        }
+    }
 }
 
 template <bool EXT, bool FIT>
 __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
 {
-    reduce_body<EXT, FIT>(a, blockIdx.x, gridDim.x);
+    __shared__ ReduceShared<EXT> sh;
+    reduce_body<EXT, FIT, false>(a, sh, blockIdx.x, gridDim.x);
+}
+
+// A reduce launch that finds the device wanting a rematch pass although the host enqueued no search kernels in front of
+// it (the schedule the host predicted from the previous scan did not hold): nothing is computed, the record tells the
+// host where to resume.  (The opposite mismatch is harmless: the search kernels left at once and this pass reuses.)
+__device__ __forceinline__ void loop_abort(const LoopLaunch &l, uint32_t bx)
+{
+    if (bx != 0) return;
+    if (threadIdx.x == 0) {
+        l.state->abort = l.gen;
+        publish_word(&l.record->iters, l.state->it);
+        publish_word(&l.record->finished, 0);
+        publish_word(&l.record->abort, 1);
+    }
+    publish_flag(&l.record->flag, l.seq);
+}
+
+template <bool EXT>
+__global__ __launch_bounds__(kRedBlock, EXT ? 2 : 8) void reduce_kernel_loop(ReduceArgs a)
+{
+    if (a.loop.init && a.n == 0) {  // an empty scan has no search kernel in front: its one workgroup brings the init record over
+        loop_copy_init(a.loop);
+        __threadfence();
+        __syncthreads();
+    }
+    if (!loop_launch_due(a.loop)) return;
+    const LoopState *ls = a.loop.state;
+    if (ls->rematch_now && !a.loop.kind) { loop_abort(a.loop, blockIdx.x); return; }
+    a.pose = loop_pose(ls);
+    a.fit = ls->rematch_now;
+    __shared__ ReduceShared<EXT> sh;
+    if (a.fit) reduce_body<EXT, true, true>(a, sh, blockIdx.x, gridDim.x);
+    else reduce_body<EXT, false, true>(a, sh, blockIdx.x, gridDim.x);
 }
 
 // K scans, one grid: blockIdx.y = scan; FIT serves the scans that searched in this pass, the plain form the others
@@ -451,6 +552,21 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel(ReduceArgs a)
 // s2m_iterated_update produces.  The last workgroup of every scan also zeroes the OTHER set of far-point counters and
 // queue heads (the set the next launch will use; the current one may still be read by nobody -- match_hard is done --
 // but the next launch's search kernels must find theirs zero).
+__device__ __forceinline__ ReduceArgs batch_reduce_args(const BatchArgs &b, const ScanDesc &d)
+{
+    ReduceArgs a;
+    a.pose = d.pose; a.gates = b.gates;
+    a.sx = d.sx; a.sy = d.sy; a.sz = d.sz; a.n = d.n;
+    a.fit = d.rematch;
+    a.nn_idx = d.nn_idx; a.nn_d2 = d.nn_d2; a.pts = b.grid.pts;
+    a.plane = d.plane; a.flags = d.flags; a.sel = d.sel; a.eff = d.eff; a.pd2 = d.pd2;
+    a.partials = d.partials; a.block = d.block; a.ticket = d.ticket;
+    a.hard_count = b.hard_count_next; a.qheads = b.qheads_next;
+    a.host_block = d.host_block; a.host_flag = d.host_flag; a.seq = d.seq;
+    a.loop = d.loop;
+    return a;
+}
+
 template <bool EXT, bool FIT>
 __global__ __launch_bounds__(kRedBlock) void reduce_kernel_batch(BatchArgs b)
 {
@@ -458,16 +574,48 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel_batch(BatchArgs b)
     if (!d.active || (d.rematch != 0) != FIT) return;
     const uint32_t nblk = (uint32_t)max((d.n + kRedBlock - 1) / kRedBlock, 1);
     if (blockIdx.x >= nblk) return;
-    ReduceArgs a;
-    a.pose = d.pose; a.gates = b.gates;
-    a.sx = d.sx; a.sy = d.sy; a.sz = d.sz; a.n = d.n;
-    a.fit = FIT ? 1 : 0;
-    a.nn_idx = d.nn_idx; a.nn_d2 = d.nn_d2; a.pts = b.grid.pts;
-    a.plane = d.plane; a.flags = d.flags; a.sel = d.sel; a.eff = d.eff; a.pd2 = d.pd2;
-    a.partials = d.partials; a.block = d.block; a.ticket = d.ticket;
-    a.hard_count = b.hard_count_next; a.qheads = b.qheads_next;
-    a.host_block = d.host_block; a.host_flag = d.host_flag; a.seq = d.seq;
-    reduce_body<EXT, FIT>(a, blockIdx.x, nblk);
+    const ReduceArgs a = batch_reduce_args(b, d);
+    __shared__ ReduceShared<EXT> sh;
+    reduce_body<EXT, FIT, false>(a, sh, blockIdx.x, nblk);
+}
+
+// the same with the loop on the device: ONE launch per pass serves the rematching and the reusing scans alike
+template <bool EXT>
+__global__ __launch_bounds__(kRedBlock, EXT ? 2 : 8) void reduce_kernel_batch_loop(BatchArgs b)
+{
+    const ScanDesc &d = b.d[blockIdx.y];
+    if (!d.active) return;
+    const uint32_t nblk = (uint32_t)max((d.n + kRedBlock - 1) / kRedBlock, 1);
+    if (blockIdx.x >= nblk) return;
+    if (d.loop.init && b.n_max <= 0) {  // a group of empty scans: no search kernel ran in front to bring the init records over
+        loop_copy_init(d.loop);
+        __threadfence();
+        __syncthreads();
+    }
+    if (!loop_launch_due(d.loop)) {
+        // a scan whose loop has ended still keeps the hand-over of the far-point counters going: the set the NEXT launch
+        // will use must be zero whoever is left to run (every scan does it, redundantly)
+        if (blockIdx.x == 0) {
+            if (threadIdx.x < 3) b.hard_count_next[threadIdx.x] = 0u;
+            if (threadIdx.x < kQueueShards) b.qheads_next[threadIdx.x * kQueueStride] = 0u;
+        }
+        return;
+    }
+    ReduceArgs a = batch_reduce_args(b, d);
+    const LoopState *ls = d.loop.state;
+    a.pose = loop_pose(ls);
+    a.fit = ls->rematch_now;
+    a.host_block = nullptr; a.host_flag = nullptr;
+    __shared__ ReduceShared<EXT> sh;
+    if (a.fit) reduce_body<EXT, true, true>(a, sh, blockIdx.x, nblk);
+    else reduce_body<EXT, false, true>(a, sh, blockIdx.x, nblk);
+}
+
+void launch_reduce_batch_loop(const BatchArgs &b, hipStream_t st)
+{
+    const dim3 grid((unsigned)std::max(reduce_blocks(b.n_max), 1), (unsigned)b.k);
+    if (b.gates.extrinsic) hipLaunchKernelGGL((reduce_kernel_batch_loop<true>), grid, dim3(kRedBlock), 0, st, b);
+    else hipLaunchKernelGGL((reduce_kernel_batch_loop<false>), grid, dim3(kRedBlock), 0, st, b);
 }
 
 void launch_reduce_batch(const BatchArgs &b, bool any_fit, bool any_plain, hipStream_t st)
@@ -502,6 +650,11 @@ void launch_reduce(const ReduceArgs &a, hipStream_t st)
 {
     // an empty scan still produces a (zero) block: one workgroup with no points
     const int blocks = std::max(reduce_blocks(a.n), 1);
+    if (a.loop.state) {
+        if (a.gates.extrinsic) hipLaunchKernelGGL((reduce_kernel_loop<true>), dim3(blocks), dim3(kRedBlock), 0, st, a);
+        else hipLaunchKernelGGL((reduce_kernel_loop<false>), dim3(blocks), dim3(kRedBlock), 0, st, a);
+        return;
+    }
     if (a.gates.extrinsic) {
         if (a.fit) hipLaunchKernelGGL((reduce_kernel<true, true>), dim3(blocks), dim3(kRedBlock), 0, st, a);
         else hipLaunchKernelGGL((reduce_kernel<true, false>), dim3(blocks), dim3(kRedBlock), 0, st, a);

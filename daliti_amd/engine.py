@@ -41,7 +41,7 @@ class Config(C.Structure):
                 ("conv_rot_deg", C.c_double), ("conv_pos_cm", C.c_double),
                 ("extrinsic_est_en", C.c_int32), ("max_iter", C.c_int32),
                 ("feat_threshold", C.c_int32), ("cell_size", C.c_float), ("device", C.c_int32),
-                ("far_point_bet", C.c_int32)]
+                ("far_point_bet", C.c_int32), ("device_loop", C.c_int32)]
 
 
 class PassOut(C.Structure):

@@ -31,8 +31,9 @@ extern "C" {
 
 /* 2: s2m_map_incremental gained `ekf_inited`, s2m_get_timing_stats writes 6 doubles, s2m_set_timing(n > 2) samples
  * (all round 2, which forgot to bump it); new in round 3: s2m_iterated_update_multi, s2m_complete_neighbors,
- * s2m_map_get_order, s2m_map_update_stats.  A caller built against version 1 must be recompiled. */
-#define S2M_ABI_VERSION 2
+ * s2m_map_get_order, s2m_map_update_stats.  3 (round 4): s2m_config gained `device_loop`.  A caller built against an
+ * older version must be recompiled. */
+#define S2M_ABI_VERSION 3
 #define S2M_K 5            /* NUM_MATCH_POINTS, laserMapping.cpp:77 */
 #define S2M_DIM 24         /* DIM_OF_STATES, common_lib.h:23 */
 #define S2M_STATE_DOUBLES 36
@@ -69,6 +70,14 @@ typedef struct {
                               * scan / later pass) left no point to the far-point kernel runs without that kernel;
                               * the reduce kernel reports whether the bet held and a lost bet is repaired (results
                               * are identical either way).  0: never bet.  2: always bet (tests)             */
+    int32_t device_loop;     /* 1 (default): s2m_iterated_update and s2m_iterated_update_batch keep the state on the
+                              * device between the passes of a scan -- the last workgroup of every pass applies the
+                              * Kalman update, the convergence test and the rematch / exit judgement
+                              * (laserMapping.cpp:899-918, 1012-1101), the kernels of the following iterations are already
+                              * enqueued, and the host reads one record at the end and updates the covariance.  0: the
+                              * host-stepped loop (one round trip per pass).  Forms that sum blocks over ranks or
+                              * handles (communicator, shared-memory exchange, _multi, _sharded) are always host-stepped.
+                              * Both evaluate the same update; they agree to ~1e-12 in the pose. */
 } s2m_config;
 
 int s2m_abi_version(void);

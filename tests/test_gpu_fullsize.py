@@ -341,7 +341,13 @@ def test_c3_scan_in_eight_shards_is_bit_identical(c3, eng3):
     from daliti_amd.sharding import shard_range
     eng3.scan_set(c3["scan"])
     eng3.set_feat_queue(())
+    dev = eng3.iterated_update(c3["x_prop"], c3["x_prop"], c3["P"])     # state on the device (the default)
+    eng3.set_config(device_loop=0)                                       # host-stepped, like the multi-handle form
+    eng3.set_feat_queue(())
     ref = eng3.iterated_update(c3["x_prop"], c3["x_prop"], c3["P"])
+    eng3.set_config(device_loop=1)
+    assert dev["iters"] == ref["iters"] and (dev["effct"] == ref["effct"]).all()
+    assert np.abs(dev["x"] - ref["x"]).max() < 1e-11 and np.abs(dev["P"] - ref["P"]).max() < 1e-13
     for n in (2, 8):
         engs = []
         for r in range(n):

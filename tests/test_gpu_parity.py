@@ -33,7 +33,7 @@ def _oracle_pass(oracle, tree, scan, x, rematch, ps=None, ext=0):
 def test_library_is_native():
     from daliti_amd import library_path, load_library
     assert os.path.exists(library_path())
-    assert load_library().s2m_abi_version() == 2
+    assert load_library().s2m_abi_version() == 3
 
 
 def test_knn_exact(eng, oracle, small_scene):
@@ -406,11 +406,75 @@ def test_batch_and_multi_with_extrinsic_estimation(oracle, small_scene, small_tr
         shards.append(e)
     x = xs[0].copy(); P = Ps[0].copy()
     log = Engine.iterated_update_multi(shards, x, np.ascontiguousarray(xs[0]), P)
-    assert log.iters == one[0]["iters"] and list(log.effct[:log.iters]) == list(one[0]["effct"])
-    assert (bits(x) == bits(one[0]["x"])).all() and (bits(P) == bits(one[0]["P"])).all()
+    host = Engine(max_iter=5, extrinsic_est_en=1, device_loop=0)   # the multi-handle form is host-stepped: compare like with like
+    host.map_share(owner)
+    host.scan_set(scans[0])
+    href = host.iterated_update(xs[0], xs[0], Ps[0])
+    assert log.iters == href["iters"] and list(log.effct[:log.iters]) == list(href["effct"])
+    assert (bits(x) == bits(href["x"])).all() and (bits(P) == bits(href["P"])).all()
+    assert np.abs(href["x"] - one[0]["x"]).max() < 1e-11 and np.abs(href["P"] - one[0]["P"]).max() < 1e-13
+    host.close()
     for e in engs + shards:
         e.close()
     owner.close()
+
+
+@pytest.mark.parametrize("ext", [0, 1])
+def test_device_loop_equals_host_loop(oracle, small_scene, small_tree, ext):
+    """The iterated update with the state on the device (the last workgroup of every pass applies the Kalman update in the
+    matrix-inversion-lemma form, the convergence test and the rematch / exit judgement; the host reads one record) against
+    the host-stepped loop (two 24x24 LU inverses per iteration, laserMapping.cpp:1017-1018): identical schedules and
+    effective counts, states within 1e-11, covariances within 1e-13 -- with max_iter = 5 (one chunk), with the yaml's 10
+    (the loop leaves early; the plan of the second scan follows the first one's schedule) and from a perturbed start
+    whose schedule differs from the previous scan's (the plan does not hold: the chain stops and is resumed)."""
+    from daliti_amd import Engine
+    for max_iter in (5, 10, 2, 1):
+        dev = Engine(max_iter=max_iter, extrinsic_est_en=ext)
+        host = Engine(max_iter=max_iter, extrinsic_est_en=ext, device_loop=0)
+        for e in (dev, host):
+            e.map_build(small_scene["map"])
+            e.scan_set(small_scene["scan"])
+        xp, P = small_scene["x_prop"], small_scene["P"]
+        starts = [xp, xp, oracle.boxplus(xp, np.r_[-9e-3, 7e-3, -1.4e-2, -0.045, 0.035, -0.025, np.zeros(18)]), xp,
+                  oracle.boxplus(xp, np.r_[2e-2, 1e-2, -2e-2, 0.1, -0.1, 0.05, np.zeros(18)])]
+        scheds = set()
+        for x0 in starts:      # the third start is (nearly) the true pose: it converges at once and rematches early
+            for e in (dev, host):
+                e.set_feat_queue(())
+            a = dev.iterated_update(x0, xp, P)
+            b = host.iterated_update(x0, xp, P)
+            assert a["iters"] == b["iters"] and a["rematch_passes"] == b["rematch_passes"], max_iter
+            assert (a["effct"] == b["effct"]).all() and (a["rematch"] == b["rematch"]).all() and (a["conv"] == b["conv"]).all()
+            assert a["converged"] == b["converged"] and a["ekf_stop"] == b["ekf_stop"]
+            assert np.abs(a["x"] - b["x"]).max() < 1e-11 and np.abs(a["P"] - b["P"]).max() < 1e-13
+            assert np.abs(a["solution"] - b["solution"]).max() < 1e-11
+            assert np.abs(a["total_res"] - b["total_res"]).max() <= 1e-12 * max(1.0, np.abs(b["total_res"]).max())
+            assert list(dev.feat_queue()) == list(host.feat_queue())
+            # what the handle serves after the update is the last pass's, whichever side ran the loop
+            sa, sb = dev.get_point_state(), host.get_point_state()
+            assert (sa["selected"] == sb["selected"]).all() and (sa["eff"] == sb["eff"]).all()
+            ha, hb = dev.get_rows(), host.get_rows()
+            assert (ha[2] == hb[2]).all() and np.abs(ha[0] - hb[0]).max() < 1e-9
+            scheds.add(tuple(a["rematch"]))
+        if max_iter >= 5:
+            assert len(scheds) > 1          # the plan taken from the previous scan did not always hold
+        ref = oracle.iterated_update(oracle.default_cfg(extrinsic_est_en=ext, max_iter=max_iter), small_tree,
+                                     small_scene["scan"], xp, xp, P)
+        for e in (dev, host):
+            e.set_feat_queue(())
+        a = dev.iterated_update(xp, xp, P)
+        assert a["iters"] == ref["iters"] and (a["effct"] == ref["effct"]).all() and np.abs(a["x"] - ref["x"]).max() < 1e-9
+        dev.close(); host.close()
+    # a degenerate scan: the degeneracy queue stops the update on the device exactly as on the host
+    dev = Engine(max_iter=5); host = Engine(max_iter=5, device_loop=0)
+    for e in (dev, host):
+        e.map_build(small_scene["map"])
+        e.scan_set(small_scene["scan"][:64])
+    a = dev.iterated_update(xp, xp, P); b = host.iterated_update(xp, xp, P)
+    assert a["ekf_stop"] and b["ekf_stop"] and a["iters"] == b["iters"] == 1
+    assert (bits(a["x"]) == bits(b["x"])).all() and (bits(a["P"]) == bits(b["P"])).all()      # untouched on both sides
+    assert list(dev.feat_queue()) == list(host.feat_queue())
+    dev.close(); host.close()
 
 
 def test_complete_neighbors_edge_cases(oracle, small_scene):

@@ -188,7 +188,7 @@ def test_single_process_multi_handle_update_equals_single_handle(n):
     from daliti_amd import Engine, synth
     from daliti_amd.sharding import shard_range
     sc = synth.make_small()
-    one = Engine(max_iter=5)
+    one = Engine(max_iter=5, device_loop=0)    # host-stepped like the multi-handle form: bit-identity compares like with like
     one.map_build(sc["map"])
     one.scan_set(sc["scan"])
     ref = one.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
@@ -233,7 +233,7 @@ def test_single_pass_entry_points_with_communicator_attached():
     sharded loop defers the host hand-off of the block until after its collective."""
     from daliti_amd import Engine, synth
     sc = synth.make_small()
-    plain = Engine(max_iter=5)
+    plain = Engine(max_iter=5, device_loop=0)  # a handle with a communicator is host-stepped
     plain.map_build(sc["map"])
     plain.scan_set(sc["scan"])
     ref = plain.residual_pass(sc["x_prop"], True)
