@@ -116,8 +116,8 @@ def parse(argv=None):
     ap.add_argument("--py-loop", action="store_true",
                     help="drive the timed steps from Python (one ctypes call per step) instead of tools/bench_loop.cpp")
     ap.add_argument("--frames", type=int, default=64, help="frames of the frame_pipeline side leg")
-    ap.add_argument("--host-loop", action="store_true",
-                    help="A/B: the host-stepped iteration loop (s2m_config.device_loop = 0) instead of the device-resident one")
+    ap.add_argument("--device-loop", action="store_true",
+                    help="A/B: the device-resident iteration loop (s2m_config.device_loop = 1) instead of the host-stepped one")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = pick a free one)")
     return ap.parse_args(argv)
 
@@ -314,7 +314,7 @@ def main():
     for k in range(len(scans)):
         dev = (k % n_dev) if host_multi else local_rank
         e = Engine(max_iter=a.max_iter, cell_size=a.cell, device=dev, feat_threshold=100,
-                   extrinsic_est_en=int(a.extrinsic), device_loop=0 if a.host_loop else 1)
+                   extrinsic_est_en=int(a.extrinsic), device_loop=1 if a.device_loop else 0)
         if k == 0 and stream is not None:
             e.set_stream(stream.cuda_stream)
         engs.append(e)
@@ -784,7 +784,7 @@ def other_configs(torch, Engine, synth, a, c3_map, steps=50, warmup=5):
         try:
             c = synth.CONFIGS[name]
             e = Engine(max_iter=a.max_iter, cell_size=a.cell, device=torch.cuda.current_device(), feat_threshold=100,
-                       device_loop=0 if a.host_loop else 1)
+                       device_loop=1 if a.device_loop else 0)
             scan = synth.make_scan(c["beams"], c["az"], c["L"], seed=2)
             if name == "R1":
                 m_pts = build_reference_density_map(e, c3_map)
@@ -821,7 +821,7 @@ def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5):
     for i in range(k):
         sc, pos = synth.replica_scan("C5", i)
         e = Engine(max_iter=a.max_iter, cell_size=a.cell, device=owner.cfg.device, feat_threshold=100,
-                   device_loop=0 if a.host_loop else 1)
+                   device_loop=1 if a.device_loop else 0)
         e.map_share(owner)
         d = torch.from_numpy(np.ascontiguousarray(sc)).cuda()
         keep.append(d)

@@ -343,7 +343,7 @@ int s2m_config_default(s2m_config *c)
     c->cell_size = 0.0f;
     c->device = -1;
     c->far_point_bet = 1;
-    c->device_loop = 1;
+    c->device_loop = 0;
     return S2M_OK;
 }
 
@@ -1973,7 +1973,7 @@ int batch_fused_loop(s2m_engine *const *handles, int32_t k, double *x, const dou
     }
     if (!any_points) return S2M_OK;
     struct Group {
-        int first = 0, count = 0;
+        int first = 0, count = 0, passes = 0;
         s2m_engine *lead = nullptr;
         BatchArgs args;
     };
@@ -2045,55 +2045,82 @@ int batch_fused_loop(s2m_engine *const *handles, int32_t k, double *x, const dou
             if (e != L && e->stream != L->stream) S2M_HIP(e, hipStreamSynchronize(e->stream));
         }
     }
+    // A group's search kernels are enqueued in front of a pass only where some scan of the group is expected to search:
+    // every scan's plan is the schedule of the previous scan on its handle (all passes, without one).  A scan that wants
+    // to search where nothing was enqueued stops its own chain and reports (loop_abort); it is resumed in the next round
+    // from that iteration -- the scans of a group need not be at the same iteration.
     std::vector<char> done((size_t)k, 0);
-    int left = k, it0 = 0;
+    std::vector<int> it0((size_t)k, 0);
+    std::vector<std::vector<int8_t>> kinds((size_t)k);
+    for (int i = 0; i < k; ++i) {
+        kinds[i].assign((size_t)max_iter, 1);
+        if ((int)handles[i]->sched_hist.size() == max_iter) kinds[i] = handles[i]->sched_hist;
+        kinds[i][0] = 1;
+    }
+    int left = k;
     bool first = true;
-    while (left > 0) {
-        if (it0 >= max_iter) return fail(e0, S2M_ERR_HIP, "s2m_iterated_update_batch: a device-resident loop did not end");
-        const int it_end = std::min(max_iter, it0 + kLoopChunk);
+    for (int round = 0; left > 0; ++round) {
+        if (round > 4 * kLoopMaxIter) return fail(e0, S2M_ERR_HIP, "s2m_iterated_update_batch: a device-resident loop did not end");
         for (int i = 0; i < k; ++i) {
             s2m_engine *e = handles[i];
             ++e->loop_seq;
             if (++e->loop_gen <= 0) e->loop_gen = 1;
         }
-        for (int it = it0; it < it_end; ++it)
+        for (int g = 0; g < ng; ++g) {
+            Group &G = groups[g];
+            G.passes = 0;
+            for (int j = 0; j < G.count; ++j)
+                if (!done[G.first + j]) G.passes = std::max(G.passes, std::min(kLoopChunk, max_iter - it0[G.first + j]));
+        }
+        for (int p = 0; p < kLoopChunk; ++p)
             for (int g = 0; g < ng; ++g) {
                 Group &G = groups[g];
+                if (p >= G.passes) continue;
                 s2m_engine *L = G.lead;
                 BatchArgs &b = G.args;
-                uint32_t *set0 = L->d_bcnt, *set1 = L->d_bcnt + (16 + kQueueWords);
-                const bool odd = (L->bwave++ & 1ull) != 0;
-                b.hard_count = odd ? set1 : set0;            b.qheads = b.hard_count + 16;
-                b.hard_count_next = odd ? set0 : set1;       b.qheads_next = b.hard_count_next + 16;
+                bool search = false;
                 for (int j = 0; j < G.count; ++j) {
-                    s2m_engine *e = handles[G.first + j];
-                    LoopLaunch &l = b.d[j].loop;
-                    b.d[j].active = done[G.first + j] ? 0 : 1;
-                    l.seq = e->loop_seq; l.gen = e->loop_gen;
-                    l.expect_it = it; l.kind = 1; l.last_of_chunk = it == it_end - 1 ? 1 : 0;
-                    l.init = (first && it == it0) ? e->h_init_dev : nullptr;
+                    const int i = G.first + j, it = it0[i] + p;
+                    if (!done[i] && it < max_iter) search = search || kinds[i][it] != 0;
                 }
-                launch_match_batch(b, L->stream);
+                for (int j = 0; j < G.count; ++j) {
+                    const int i = G.first + j, it = it0[i] + p;
+                    s2m_engine *e = handles[i];
+                    LoopLaunch &l = b.d[j].loop;
+                    b.d[j].active = (!done[i] && it < max_iter) ? 1 : 0;
+                    l.seq = e->loop_seq; l.gen = e->loop_gen;
+                    l.expect_it = it; l.kind = search ? 1 : 0;
+                    l.last_of_chunk = (p == std::min(kLoopChunk, max_iter - it0[i]) - 1) ? 1 : 0;
+                    l.init = (first && p == 0) ? e->h_init_dev : nullptr;
+                }
+                if (search) {
+                    uint32_t *set0 = L->d_bcnt, *set1 = L->d_bcnt + (16 + kQueueWords);
+                    const bool odd = (L->bwave++ & 1ull) != 0;
+                    b.hard_count = odd ? set1 : set0;            b.qheads = b.hard_count + 16;
+                    b.hard_count_next = odd ? set0 : set1;       b.qheads_next = b.hard_count_next + 16;
+                    launch_match_batch(b, L->stream);
+                }
                 launch_reduce_batch_loop(b, L->stream);
                 S2M_HIP(L, hipGetLastError());
             }
         first = false;
-        int next_it = max_iter;
         for (int i = 0; i < k; ++i) {
             if (done[i]) continue;
             s2m_engine *e = handles[i];
             int rc = loop_wait(e, e->loop_seq);
             if (rc) return rc;
-            if (e->h_rec->finished) {
+            const LoopRecord &rec = *e->h_rec;
+            if (rec.finished) {
                 rc = loop_finish(e, xk(i), Pk(i), logs ? logs + i : nullptr);
                 if (rc) return rc;
                 done[i] = 1;
                 --left;
             } else {
-                next_it = std::min<int>(next_it, e->h_rec->iters);
+                it0[i] = rec.iters;   // the chunk ended, or this scan's plan did not hold at this iteration
+                if (it0[i] < 0 || it0[i] >= max_iter) return fail(e, S2M_ERR_HIP, "a device-resident loop reported an impossible iteration");
+                if (rec.abort) kinds[i][it0[i]] = 1;
             }
         }
-        it0 = left > 0 ? next_it : max_iter;
     }
     return S2M_OK;
 }

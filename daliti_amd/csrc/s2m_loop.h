@@ -55,6 +55,11 @@ struct LoopState {
     int32_t numeric;           // the nc x nc system was not positive definite
     int32_t update_cov;        // the loop ended through the exit test without EKF_stop: the covariance is updated (:1084)
     int32_t pad;
+    // per-iteration log rows, kept here until the loop ends (a store to pinned host memory holds the kernel's end back by
+    // a PCIe round trip: once per scan, not once per pass)
+    double log_res[kLoopMaxIter];
+    double log_sol[kLoopMaxIter][S2M_DIM];
+    int32_t log_effct[kLoopMaxIter], log_rematch[kLoopMaxIter], log_conv[kLoopMaxIter], log_far[kLoopMaxIter];
 };
 
 // the record the host reads at the end (pinned host memory; the flag is written last)
@@ -92,21 +97,33 @@ __device__ __forceinline__ bool loop_launch_due(const LoopLaunch &l)
     const LoopState *ls = l.state;
     return !(ls->finished || ls->abort == l.gen || ls->it != l.expect_it);
 }
-// The pose the device left for this pass, into scalar registers: the state is written by this very kernel's last
-// workgroup, so the compiler must treat the loads as divergent (48 VGPRs for a value every lane shares) unless told
-__device__ __forceinline__ Pose loop_pose(const LoopState *ls)
+// What a launch of the chain needs to know, requested in ONE round trip: the control words the previous reduce launch
+// left and the pose it left (the loads are issued before the first branch; the state is written by this very kernel's
+// last workgroup, so the compiler must treat them as divergent -- 48 VGPRs for a value every lane shares -- unless the
+// values are moved to scalar registers by hand).  Returns whether the launch is due; rematch_now: the pass searches.
+__device__ __forceinline__ bool loop_enter(const LoopLaunch &l, Pose &pose, int &rematch_now)
 {
-    Pose p;
-    double *o = reinterpret_cast<double *>(&p);
-    const double *x = ls->in.x;
+    const LoopState *ls = l.state;
+    int fin = ls->finished, ab = ls->abort, it = ls->it, rn = ls->rematch_now;
+    double px[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) px[i] = ls->in.x[i];
+    asm volatile("" : "+v"(fin), "+v"(ab), "+v"(it), "+v"(rn));
+#pragma unroll
+    for (int i = 0; i < 24; ++i) asm volatile("" : "+v"(px[i]));
+    fin = __builtin_amdgcn_readfirstlane(fin); ab = __builtin_amdgcn_readfirstlane(ab);
+    it = __builtin_amdgcn_readfirstlane(it); rn = __builtin_amdgcn_readfirstlane(rn);
+    rematch_now = rn;
+    if (fin || ab == l.gen || it != l.expect_it) return false;
+    double *o = reinterpret_cast<double *>(&pose);
 #pragma unroll
     for (int i = 0; i < 24; ++i) {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(x[i]);
+        const unsigned long long b = (unsigned long long)__double_as_longlong(px[i]);
         const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
         o[i] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
     }
-    return p;
+    return true;
 }
 // First kernel of a scan's chain, workgroup 0: the init record from pinned host memory into the device state.  The
 // kernel itself runs at the pose in its arguments; everything later in the stream reads the state.
@@ -150,9 +167,24 @@ __device__ inline void loop_log_atb(const double *A, const double *B, double *ou
 {
     auto el = [&](int r, int c) { return (A[0 * 3 + r] * B[0 * 3 + c] + A[1 * 3 + r] * B[1 * 3 + c]) + A[2 * 3 + r] * B[2 * 3 + c]; };
     const double tr = el(0, 0) + el(1, 1) + el(2, 2);
-    const double theta = (tr > 3.0 - 1e-6) ? 0.0 : trig_acos(0.5 * (tr - 1));
     const double k0 = el(2, 1) - el(1, 2), k1 = el(0, 2) - el(2, 0), k2 = el(1, 0) - el(0, 1);
-    const double f = (fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / trig_sin(theta));
+    // The reference: theta = acos((tr - 1) / 2) (0 when tr > 3 - 1e-6), factor 0.5 when |theta| < 0.001, else
+    // 0.5 theta / sin(theta).  The vector (k0, k1, k2) / 2 has length sin(theta): for the small rotations this is called
+    // with (the state against its own prediction) theta / sin(theta) = asin(s) / s is a short series in s^2 -- no acos, no
+    // square root, no division in the chain of the one wave that runs this (each costs ~150 cycles there); agreement with
+    // the acos form ~1e-16 (theta / sin(theta) is flat in theta).  Larger rotations take the reference's form as written.
+    const double s2 = 0.25 * ((k0 * k0 + k1 * k1) + k2 * k2);
+    double f;
+    if (tr > 2.8 && s2 < 0.01) {                      // cos(theta) > 0.9, sin^2(theta) < 0.01
+        const double lim = 9.999996666667e-07;         // sin^2(0.001)
+        f = 0.5;
+        if (!(s2 < lim))
+            f = 0.5 * (1.0 + s2 * (1.0 / 6 + s2 * (3.0 / 40 + s2 * (5.0 / 112 + s2 * (35.0 / 1152 + s2 * (63.0 / 2816 +
+                       s2 * (231.0 / 13312 + s2 * (143.0 / 10240))))))));
+    } else {
+        const double theta = (tr > 3.0 - 1e-6) ? 0.0 : trig_acos(0.5 * (tr - 1));
+        f = (fabs(theta) < 0.001) ? 0.5 : (0.5 * theta / trig_sin(theta));
+    }
     out[0] = f * k0; out[1] = f * k1; out[2] = f * k2;
 }
 // offset in the 36-double state of the linear block that error-state entries e .. e + 2 belong to (common_lib.h:146-157)
@@ -160,147 +192,170 @@ __device__ inline int loop_linear_offset(int e) { return e == 3 ? 9 : (e == 9 ? 
 
 // shared-memory work area of the step
 struct LoopScratch {
-    double blk[S2M_BLOCK_DOUBLES];
+    double blk[S2M_BLOCK_DOUBLES];   // the pass's block
+    LoopInit in;                     // the scan's state, staged from device memory by the whole workgroup (one round trip)
     double vec[S2M_DIM], sol[S2M_DIM];
-    double b[12], w[12];
-    double M[144];
-    int32_t stop, ok, finished;
+    int32_t finished;
 };
+constexpr int kLoopInitDoubles = (int)(sizeof(LoopInit) / 8);
 
-// What the reference does with the result of one pass (laserMapping.cpp:899-918, 1012-1101), by the last workgroup of
-// the reduce kernel; s.blk holds the pass's block.  Every thread of the workgroup calls it (barriers inside); the
-// serial parts run on thread 0, the 24-wide parts on a lane per row.  On return the control words in *ls describe
-// the next pass and s.finished says whether the loop has ended.
-__device__ inline void loop_step(LoopState *ls, LoopScratch &s, LoopRecord *rec, bool was_rematch)
+__device__ __forceinline__ double loop_readlane(double v, int lane)  // lane: compile-time constant after unrolling
 {
-    const int t = threadIdx.x;
-    LoopInit &in = ls->in;
-    const int nc = in.nc;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// LDS writes of this wave before LDS reads by other lanes of the same wave
+__device__ __forceinline__ void loop_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// What the reference does with the result of one pass (laserMapping.cpp:899-918, 1012-1101), by ONE WAVE of the last
+// workgroup of the reduce kernel (threadIdx.x < 64); s.blk holds the pass's block and s.in the staged state.  The
+// nc x nc system M w = b (M = C^-1 + H^T H, symmetric positive definite: elimination without pivoting) is solved with a
+// row per lane in registers and v_readlane broadcasts of the pivot row -- no shared-memory round trips in the chain; the
+// 24-wide parts take a lane per row, the two rotations a lane each.  On return the state and the control words in *ls
+// describe the next pass, s.sol / s.finished are set, and `old` holds the pose this pass ran at (lanes < 24).
+template <int NC>
+__device__ inline void loop_step_wave(LoopState *ls, LoopScratch &s, bool was_rematch, double &old)
+{
+    const int lane = threadIdx.x;
+    LoopInit &in = s.in;
     const double *A = s.blk, *Htz = s.blk + 144;  // 12 x 12 block layout, zeros beyond nc
+    // control words of the previous pass (one round trip, overlapped with everything up to the judgement)
     const int it = ls->it;
-    if (t == 0) {
-        // effct_feat_numQueue / EKF_stop_flg (:899-918)
-        const int32_t effct = (int32_t)s.blk[156];
-        int32_t len = in.queue_len;
-        in.queue[len++] = effct;
-        if (len > S2M_FEAT_QUEUE) {
-            for (int q = 0; q < S2M_FEAT_QUEUE; ++q) in.queue[q] = in.queue[q + 1];
-            len = S2M_FEAT_QUEUE;
-        }
-        in.queue_len = len;
-        int32_t stop = 0;
-        for (int q = 0; q < len; ++q)
-            if (in.queue[q] <= in.feat_threshold) stop = 1;
-        s.stop = stop;
-        s.ok = 1;
+    int rematch_num = ls->rematch_num, conv = ls->conv;
+    const int passes = ls->passes;
+    old = lane < 24 ? in.x[lane] : 0.0;
+    // effct_feat_numQueue / EKF_stop_flg (:899-918): the queue entry a lane holds after the push
+    const int32_t effct = (int32_t)s.blk[156];
+    int len = in.queue_len;
+    int32_t qv = 0x7fffffff;
+    if (len < S2M_FEAT_QUEUE) {
+        if (lane < len) qv = in.queue[lane];
+        if (lane == len) qv = effct;
+        len += 1;
+    } else {
+        if (lane < S2M_FEAT_QUEUE - 1) qv = in.queue[lane + 1];
+        if (lane == S2M_FEAT_QUEUE - 1) qv = effct;
+        len = S2M_FEAT_QUEUE;
     }
-    if (t < S2M_DIM) s.sol[t] = 0.0;
-    if (t < 24) {  // the pose this pass ran at
-        ls->pose_last[t] = in.x[t];
-        if (was_rematch) ls->pose_rematch[t] = in.x[t];
-    }
-    __syncthreads();
-    const bool stop = s.stop != 0;
-    if (!stop) {
+    const bool stop = __ballot(lane < len && qv <= in.feat_threshold) != 0ull;
+    loop_wave_sync();  // every lane has read its old entry
+    if (lane < S2M_FEAT_QUEUE + 1) in.queue[lane] = lane < len ? qv : 0;
+    if (lane == 0) in.queue_len = len;
+    double sol = 0.0;
+    bool ok = true;
+    if (!stop) {  // wave-uniform
+        // lane i < NC: row i of M = C^-1 + A (requested before the chain below needs it)
+        const int i = lane < NC ? lane : 0;
+        double Mr[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) Mr[c] = in.Cinv[i * NC + c] + A[i * 12 + c];
+        const double hz = Htz[i];
         // vec = x_prop [-] x (:1028; common_lib.h:173-187)
-        if (t < 2) {
-            const int o = t == 0 ? 0 : 12;
-            loop_log_atb(in.x + o, in.x_prop + o, s.vec + (t == 0 ? 0 : 6));
-        } else if (t >= 8 && t < 8 + 18) {
-            const int k = t - 8, e = (k < 3) ? 3 + k : ((k < 6) ? 9 + (k - 3) : 12 + (k - 6));
+        if (lane < 2) {
+            const int o = lane == 0 ? 0 : 12;
+            loop_log_atb(in.x + o, in.x_prop + o, s.vec + (lane == 0 ? 0 : 6));
+        } else if (lane >= 8 && lane < 8 + 18) {
+            const int k = lane - 8, e = (k < 3) ? 3 + k : ((k < 6) ? 9 + (k - 3) : 12 + (k - 6));
             const int base = e - (e % 3);
             s.vec[e] = in.x_prop[loop_linear_offset(base) + e % 3] - in.x[loop_linear_offset(base) + e % 3];
         }
-        __syncthreads();
-        // b = H^T z - A vec[0:nc];  M = C^-1 + A
-        if (t < nc) {
+        loop_wave_sync();
+        // b_i = (H^T z)_i - (A vec[0:nc])_i
+        double bi;
+        {
             double acc = 0.0;
-            for (int j = 0; j < nc; ++j) acc += A[t * 12 + j] * s.vec[j];
-            s.b[t] = Htz[t] - acc;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc += A[i * 12 + c] * s.vec[c];
+            bi = hz - acc;
         }
-        if (t >= 64 && t < 64 + nc * nc) {
-            const int r = (t - 64) / nc, c = (t - 64) % nc;
-            s.M[r * nc + c] = in.Cinv[r * nc + c] + A[r * 12 + c];
+        const double vr = lane < S2M_DIM ? s.vec[lane] : 0.0;
+        // forward elimination, pivot row broadcast from lane k (one reciprocal per pivot, reused by the back substitution)
+        double rp[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const double pk = loop_readlane(Mr[k], k);
+            ok = ok && (pk > 0.0);
+            rp[k] = 1.0 / pk;
+            const double f = Mr[k] * rp[k];
+            const double bk = loop_readlane(bi, k);
+#pragma unroll
+            for (int c = k + 1; c < NC; ++c) {
+                const double rkc = loop_readlane(Mr[c], k);
+                if (lane > k) Mr[c] -= f * rkc;
+            }
+            if (lane > k) bi -= f * bk;
         }
-        __syncthreads();
-        if (t == 0) {
-            // Cholesky M = L L^T in place (lower triangle), then L y = b, L^T w = y
-            bool ok = true;
-            for (int j = 0; j < nc; ++j) {
-                double d = s.M[j * nc + j];
-                for (int k = 0; k < j; ++k) d -= s.M[j * nc + k] * s.M[j * nc + k];
-                if (!(d > 0.0)) { ok = false; break; }
-                d = sqrt(d);
-                s.M[j * nc + j] = d;
-                for (int i = j + 1; i < nc; ++i) {
-                    double v = s.M[i * nc + j];
-                    for (int k = 0; k < j; ++k) v -= s.M[i * nc + k] * s.M[j * nc + k];
-                    s.M[i * nc + j] = v / d;
-                }
-            }
-            if (ok) {
-                for (int i = 0; i < nc; ++i) {
-                    double v = s.b[i];
-                    for (int k = 0; k < i; ++k) v -= s.M[i * nc + k] * s.w[k];
-                    s.w[i] = v / s.M[i * nc + i];
-                }
-                for (int i = nc - 1; i >= 0; --i) {
-                    double v = s.w[i];
-                    for (int k = i + 1; k < nc; ++k) v -= s.M[k * nc + i] * s.w[k];
-                    s.w[i] = v / s.M[i * nc + i];
-                }
-            }
-            s.ok = ok ? 1 : 0;
+        // back substitution: w_k from lane k, every lane above folds it into its own right-hand side
+        double w[NC];
+#pragma unroll
+        for (int k = NC - 1; k >= 0; --k) {
+            const double wk = loop_readlane(bi, k) * rp[k];
+            w[k] = wk;
+            if (lane < k) bi -= Mr[k] * wk;
         }
-        __syncthreads();
-        if (s.ok) {
-            // solution = vec + G w (:1032)
-            if (t < S2M_DIM) {
-                double acc = 0.0;
-                for (int j = 0; j < nc; ++j) acc += in.G[t * nc + j] * s.w[j];
-                s.sol[t] = s.vec[t] + acc;
-            }
-            __syncthreads();
-            // x [+]= solution (:1033; common_lib.h:146-157)
-            if (t < 2) {
-                const int o = t == 0 ? 0 : 12, e = t == 0 ? 0 : 6;
-                loop_rot_times_exp(in.x + o, s.sol[e], s.sol[e + 1], s.sol[e + 2]);
-            } else if (t >= 8 && t < 8 + 18) {
-                const int k = t - 8, e = (k < 3) ? 3 + k : ((k < 6) ? 9 + (k - 3) : 12 + (k - 6));
-                const int base = e - (e % 3);
-                in.x[loop_linear_offset(base) + e % 3] += s.sol[e];
-            }
+        if (ok) {
+            // solution = vec + G w (:1032), a lane per row
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc += in.G[(lane < S2M_DIM ? lane : 0) * NC + c] * w[c];
+            sol = lane < S2M_DIM ? vr + acc : 0.0;
         }
-        __syncthreads();
     }
-    if (t == 0) {
-        int32_t conv = ls->conv;
-        if (!stop && s.ok) {
+    if (lane < S2M_DIM) s.sol[lane] = sol;
+    loop_wave_sync();
+    if (!stop && ok) {
+        // x [+]= solution (:1033; common_lib.h:146-157), on the staged copy
+        if (lane < 2) {
+            const int o = lane == 0 ? 0 : 12, e = lane == 0 ? 0 : 6;
+            loop_rot_times_exp(in.x + o, s.sol[e], s.sol[e + 1], s.sol[e + 2]);
+        } else if (lane >= 8 && lane < 8 + 18) {
+            const int k = lane - 8, e = (k < 3) ? 3 + k : ((k < 6) ? 9 + (k - 3) : 12 + (k - 6));
+            const int base = e - (e % 3);
+            in.x[loop_linear_offset(base) + e % 3] += s.sol[e];
+        }
+        loop_wave_sync();
+    }
+    // back to device memory: the state the next pass runs at, the queue, this pass's poses
+    if (lane < S2M_STATE_DOUBLES) ls->in.x[lane] = in.x[lane];
+    if (lane < S2M_FEAT_QUEUE + 1) ls->in.queue[lane] = in.queue[lane];
+    if (lane < 24) {
+        ls->pose_last[lane] = old;
+        if (was_rematch) ls->pose_rematch[lane] = old;
+    }
+    if (lane == 0) {
+        ls->in.queue_len = len;
+        if (!stop && ok) {
             const double rn = sqrt(s.sol[0] * s.sol[0] + s.sol[1] * s.sol[1] + s.sol[2] * s.sol[2]);
             const double tn = sqrt(s.sol[3] * s.sol[3] + s.sol[4] * s.sol[4] + s.sol[5] * s.sol[5]);
             conv = ((rn * 57.3 < in.conv_rot_deg) && (tn * 100 < in.conv_pos_cm)) ? 1 : 0;  // :1040
         }
         // rematch judgement and exit test (:1070-1101; s2m_iterctl.h)
-        int32_t rematch_en = 0, rematch_num = ls->rematch_num;
+        int32_t rematch_en = 0;
         if (conv || (rematch_num == 0 && it == in.max_iter - 2)) { rematch_en = 1; rematch_num++; }
         bool finished = false, update_cov = false;
         if (rematch_num >= 2 || it == in.max_iter - 1) { finished = true; update_cov = !stop; }
         else if (stop) finished = true;
-        if (!s.ok) { finished = true; update_cov = false; }
-        ls->update_cov = update_cov ? 1 : 0;
+        if (!ok) { finished = true; update_cov = false; }
         ls->conv = conv;
         ls->stop = stop ? 1 : 0;
         ls->rematch_en = rematch_en;
         ls->rematch_num = rematch_num;
-        ls->passes += was_rematch ? 1 : 0;
+        ls->passes = passes + (was_rematch ? 1 : 0);
         ls->it = it + 1;
         ls->rematch_now = rematch_en;
         ls->finished = finished ? 1 : 0;
-        ls->numeric = s.ok ? 0 : 1;
+        ls->numeric = ok ? 0 : 1;
+        ls->update_cov = update_cov ? 1 : 0;
         s.finished = finished ? 1 : 0;
     }
-    __syncthreads();
-    (void)rec;
+    loop_wave_sync();
 }
 #endif  // __HIPCC__
 

@@ -253,8 +253,8 @@ __global__ __launch_bounds__(256) void match_rows_loop(MatchArgs a)
     if (a.loop.init) {
         if (blockIdx.x == 0) loop_copy_init(a.loop);
     } else {
-        if (!loop_launch_due(a.loop) || !a.loop.state->rematch_now) return;
-        a.pose = loop_pose(a.loop.state);
+        int rematch_now = 0;
+        if (!loop_enter(a.loop, a.pose, rematch_now) || !rematch_now) return;
     }
     match_rows_body<G, WIDE, NB>(a, runs);
 }
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void match_rows_batch(BatchArgs b)
         if (d.loop.init) {
             if (blockIdx.x == 0) loop_copy_init(d.loop);
         } else {
-            if (!loop_launch_due(d.loop) || !d.loop.state->rematch_now) return;
-            a.pose = loop_pose(d.loop.state);
+            int rematch_now = 0;
+            if (!loop_enter(d.loop, a.pose, rematch_now) || !rematch_now) return;
         }
     } else if (!d.rematch) {
         return;

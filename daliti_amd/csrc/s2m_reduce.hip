@@ -358,6 +358,14 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, ReduceShared<EX
     }
     __syncthreads();
     if (!s_last) return;
+    // device-resident loop: the scan's state (4 KB) is requested now and lands in shared memory after the final sum -- its
+    // round trip overlaps that of the partial rows
+    double pre0 = 0.0, pre1 = 0.0;
+    if constexpr (LOOP) {
+        const double *src = reinterpret_cast<const double *>(&a.loop.state->in);
+        pre0 = src[threadIdx.x];
+        if (threadIdx.x + kRedBlock < kLoopInitDoubles) pre1 = src[threadIdx.x + kRedBlock];
+    }
 
     // ---- last workgroup: fixed-order sum of the rows (independent of arrival order) -----------------
     // The order is a perfect BINARY TREE over the workgroup index (rows beyond the last one count as +0.0): lane ch
@@ -464,35 +472,66 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, ReduceShared<EX
         // ---- device-resident loop: the Kalman update, the judgement and the hand-over to the next pass (s2m_loop.h) ----
         LoopState *ls = a.loop.state;
         LoopRecord *rec = a.loop.record;
-        const int it = ls->it;
-        loop_step(ls, loop_scratch, rec, FIT);
-        const int t = threadIdx.x;
-        // this iteration's log row, straight into the pinned record (what Log/mat_out.txt records, :936-937)
-        if (t < S2M_DIM) publish_store(&rec->solution[it][t], loop_scratch.sol[t]);
-        if (t == 32) {
-            publish_store(&rec->total_residual[it], loop_scratch.blk[157]);
-            publish_word(&rec->effct[it], (int32_t)loop_scratch.blk[156]);
-            publish_word(&rec->rematch[it], FIT ? 1 : 0);
-            publish_word(&rec->conv_it[it], ls->conv);
-            publish_word(&rec->far_points[it], (int32_t)loop_scratch.blk[158]);
+        {   // the scan's state into shared memory (its loads have been in flight since before the final sum)
+            double *dst = reinterpret_cast<double *>(&loop_scratch.in);
+            dst[threadIdx.x] = pre0;
+            if (threadIdx.x + kRedBlock < kLoopInitDoubles) dst[threadIdx.x + kRedBlock] = pre1;
         }
-        if (!loop_scratch.finished && a.loop.last_of_chunk) {  // the host enqueued no further: tell it where the loop stands
-            if (t == 448) {
-                publish_word(&rec->iters, ls->it);
+        __syncthreads();
+        if (threadIdx.x >= 64) return;  // one wave goes on
+        const int t = threadIdx.x;
+        const int it = ls->it;
+        double old;
+        loop_step_wave<NC>(ls, loop_scratch, FIT, old);
+        // this iteration's log row (what Log/mat_out.txt records, :936-937): kept on the device until the loop ends
+        const int32_t conv_now = ls->conv;
+        if (t < S2M_DIM) ls->log_sol[it][t] = loop_scratch.sol[t];
+        if (t == 32) {
+            ls->log_res[it] = loop_scratch.blk[157];
+            ls->log_effct[it] = (int32_t)loop_scratch.blk[156];
+            ls->log_rematch[it] = FIT ? 1 : 0;
+            ls->log_conv[it] = conv_now;
+            ls->log_far[it] = (int32_t)loop_scratch.blk[158];
+        }
+        const bool finished = loop_scratch.finished != 0;
+        if (!finished && a.loop.last_of_chunk) {  // the host enqueued no further: tell it where the loop stands
+            if (t == 0) {
+                publish_word(&rec->iters, it + 1);
                 publish_word(&rec->finished, 0);
                 publish_word(&rec->abort, 0);
             }
-            publish_flag(&rec->flag, a.loop.seq);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t == 0) __hip_atomic_store(&rec->flag, a.loop.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        if (loop_scratch.finished) {
-            if (t < S2M_STATE_DOUBLES) publish_store(&rec->x[t], ls->in.x[t]);
-            if (t >= 64 && t < 64 + S2M_BLOCK_DOUBLES) publish_store(&rec->block[t - 64], loop_scratch.blk[t - 64]);
-            if (t >= 256 && t < 256 + 24) publish_store(&rec->pose_last[t - 256], ls->pose_last[t - 256]);
-            if (t >= 320 && t < 320 + 24) publish_store(&rec->pose_rematch[t - 320], ls->pose_rematch[t - 320]);
-            if (t >= 384 && t < 384 + S2M_FEAT_QUEUE + 2) publish_word(&rec->queue[t - 384], ls->in.queue[t - 384]);
-            if (t == 448) {
-                publish_word(&rec->queue_len, ls->in.queue_len);
-                publish_word(&rec->iters, ls->it);
+        if (finished) {
+            for (int q = 0; q < it; ++q) {  // the earlier passes' rows (written by earlier launches), then this pass's
+                if (t < S2M_DIM) publish_store(&rec->solution[q][t], ls->log_sol[q][t]);
+                if (t == 32) {
+                    publish_store(&rec->total_residual[q], ls->log_res[q]);
+                    publish_word(&rec->effct[q], ls->log_effct[q]);
+                    publish_word(&rec->rematch[q], ls->log_rematch[q]);
+                    publish_word(&rec->conv_it[q], ls->log_conv[q]);
+                    publish_word(&rec->far_points[q], ls->log_far[q]);
+                }
+            }
+            if (t < S2M_DIM) publish_store(&rec->solution[it][t], loop_scratch.sol[t]);
+            if (t == 32) {
+                publish_store(&rec->total_residual[it], loop_scratch.blk[157]);
+                publish_word(&rec->effct[it], (int32_t)loop_scratch.blk[156]);
+                publish_word(&rec->rematch[it], FIT ? 1 : 0);
+                publish_word(&rec->conv_it[it], conv_now);
+                publish_word(&rec->far_points[it], (int32_t)loop_scratch.blk[158]);
+            }
+            if (t < S2M_STATE_DOUBLES) publish_store(&rec->x[t], loop_scratch.in.x[t]);
+            for (int o = t; o < S2M_BLOCK_DOUBLES; o += 64) publish_store(&rec->block[o], loop_scratch.blk[o]);
+            if (t < 24) {
+                publish_store(&rec->pose_last[t], old);
+                publish_store(&rec->pose_rematch[t], FIT ? old : ls->pose_rematch[t]);
+            }
+            if (t < S2M_FEAT_QUEUE + 2) publish_word(&rec->queue[t], loop_scratch.in.queue[t]);
+            if (t == 0) {
+                publish_word(&rec->queue_len, loop_scratch.in.queue_len);
+                publish_word(&rec->iters, it + 1);
                 publish_word(&rec->passes, ls->passes);
                 publish_word(&rec->conv, ls->conv);
                 publish_word(&rec->stop, ls->stop);
@@ -501,7 +540,8 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, ReduceShared<EX
                 publish_word(&rec->numeric, ls->numeric);
                 publish_word(&rec->update_cov, ls->update_cov);
             }
-            publish_flag(&rec->flag, a.loop.seq);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t == 0) __hip_atomic_store(&rec->flag, a.loop.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -529,18 +569,17 @@ __device__ __forceinline__ void loop_abort(const LoopLaunch &l, uint32_t bx)
 }
 
 template <bool EXT>
-__global__ __launch_bounds__(kRedBlock, EXT ? 2 : 8) void reduce_kernel_loop(ReduceArgs a)
+__global__ __launch_bounds__(kRedBlock, EXT ? 2 : 6) void reduce_kernel_loop(ReduceArgs a)
 {
     if (a.loop.init && a.n == 0) {  // an empty scan has no search kernel in front: its one workgroup brings the init record over
         loop_copy_init(a.loop);
         __threadfence();
         __syncthreads();
     }
-    if (!loop_launch_due(a.loop)) return;
-    const LoopState *ls = a.loop.state;
-    if (ls->rematch_now && !a.loop.kind) { loop_abort(a.loop, blockIdx.x); return; }
-    a.pose = loop_pose(ls);
-    a.fit = ls->rematch_now;
+    int rematch_now = 0;
+    if (!loop_enter(a.loop, a.pose, rematch_now)) return;
+    if (rematch_now && !a.loop.kind) { loop_abort(a.loop, blockIdx.x); return; }
+    a.fit = rematch_now;
     __shared__ ReduceShared<EXT> sh;
     if (a.fit) reduce_body<EXT, true, true>(a, sh, blockIdx.x, gridDim.x);
     else reduce_body<EXT, false, true>(a, sh, blockIdx.x, gridDim.x);
@@ -581,7 +620,7 @@ __global__ __launch_bounds__(kRedBlock) void reduce_kernel_batch(BatchArgs b)
 
 // the same with the loop on the device: ONE launch per pass serves the rematching and the reusing scans alike
 template <bool EXT>
-__global__ __launch_bounds__(kRedBlock, EXT ? 2 : 8) void reduce_kernel_batch_loop(BatchArgs b)
+__global__ __launch_bounds__(kRedBlock, EXT ? 2 : 6) void reduce_kernel_batch_loop(BatchArgs b)
 {
     const ScanDesc &d = b.d[blockIdx.y];
     if (!d.active) return;
@@ -592,7 +631,9 @@ __global__ __launch_bounds__(kRedBlock, EXT ? 2 : 8) void reduce_kernel_batch_lo
         __threadfence();
         __syncthreads();
     }
-    if (!loop_launch_due(d.loop)) {
+    ReduceArgs a = batch_reduce_args(b, d);
+    int rematch_now = 0;
+    if (!loop_enter(d.loop, a.pose, rematch_now)) {
         // a scan whose loop has ended still keeps the hand-over of the far-point counters going: the set the NEXT launch
         // will use must be zero whoever is left to run (every scan does it, redundantly)
         if (blockIdx.x == 0) {
@@ -601,10 +642,8 @@ __global__ __launch_bounds__(kRedBlock, EXT ? 2 : 8) void reduce_kernel_batch_lo
         }
         return;
     }
-    ReduceArgs a = batch_reduce_args(b, d);
-    const LoopState *ls = d.loop.state;
-    a.pose = loop_pose(ls);
-    a.fit = ls->rematch_now;
+    if (rematch_now && !d.loop.kind) { loop_abort(d.loop, blockIdx.x); return; }
+    a.fit = rematch_now;
     a.host_block = nullptr; a.host_flag = nullptr;
     __shared__ ReduceShared<EXT> sh;
     if (a.fit) reduce_body<EXT, true, true>(a, sh, blockIdx.x, nblk);

@@ -70,14 +70,17 @@ typedef struct {
                               * scan / later pass) left no point to the far-point kernel runs without that kernel;
                               * the reduce kernel reports whether the bet held and a lost bet is repaired (results
                               * are identical either way).  0: never bet.  2: always bet (tests)             */
-    int32_t device_loop;     /* 1 (default): s2m_iterated_update and s2m_iterated_update_batch keep the state on the
-                              * device between the passes of a scan -- the last workgroup of every pass applies the
-                              * Kalman update, the convergence test and the rematch / exit judgement
+    int32_t device_loop;     /* 0 (default): the host-stepped loop -- after every pass the block lands in pinned host memory,
+                              * the host runs the 24x24 update and launches the next pass.  1: s2m_iterated_update and
+                              * s2m_iterated_update_batch keep the state on the device between the passes of a scan: the
+                              * last workgroup of every pass applies the Kalman update (matrix-inversion-lemma form, one
+                              * nc x nc solve), the convergence test and the rematch / exit judgement
                               * (laserMapping.cpp:899-918, 1012-1101), the kernels of the following iterations are already
-                              * enqueued, and the host reads one record at the end and updates the covariance.  0: the
-                              * host-stepped loop (one round trip per pass).  Forms that sum blocks over ranks or
-                              * handles (communicator, shared-memory exchange, _multi, _sharded) are always host-stepped.
-                              * Both evaluate the same update; they agree to ~1e-12 in the pose. */
+                              * enqueued, the host reads one record at the end and updates the covariance.  Both forms
+                              * evaluate the same update (poses agree to ~1e-12); measured on MI355X the device form is
+                              * the slower one (C3 0.161 vs 0.145 ms/step, 22.8 k vs 25.9 k scans/s at 24 in flight:
+                              * NOTEBOOK.md, round 4), hence opt-in.  Forms that sum blocks over ranks or handles
+                              * (communicator, shared-memory exchange, _multi, _sharded) are always host-stepped. */
 } s2m_config;
 
 int s2m_abi_version(void);

@@ -7,7 +7,8 @@
 #       runs every leg alternately with the in-tree library ("base") and with each variant, `reps` times (default 2),
 #       and prints one line per run; JSON lines under gpurun_out/<tag>/.
 #       legs: C1 C2 C3 C4 R1 (one scan in flight), K8 K16 K24 ... (C5 with that many scans in flight), FRAME (C3 with
-#       the frame_pipeline side leg); a variant named "-" means "base only" (with the given env: environment A/B)
+#       the frame_pipeline side leg); a variant named "-" means "the in-tree library again" with the given env and with the
+#       extra bench.py arguments in $AB_ARGS (e.g. AB_ARGS=--device-loop: an A/B of two forms inside one library)
 #   scripts/ab.sh counters <tag> "<variants>" "<leg>"    (GPU box) SQ / TA / TCP counters of one leg, base and variants
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -34,8 +35,8 @@ run)
   tag=${1:?tag}; variants=${2:-}; legs=${3:-"C3 K8 K24"}; reps=${4:-2}; venv=${5:-}
   O=gpurun_out/$tag; mkdir -p $O
   one() {  # name leg env...
-    local name=$1 leg=$2; shift 2
-    env "$@" timeout 900 python3 bench.py $(leg_args $leg) > $O/$name.json 2> $O/$name.err
+    local name=$1 leg=$2 extra=$3; shift 3
+    env "$@" timeout 900 python3 bench.py $(leg_args $leg) $extra > $O/$name.json 2> $O/$name.err
     python3 - "$O/$name.json" "$name" <<'PY'
 import json, sys
 try:
@@ -48,9 +49,9 @@ PY
   }
   for rep in $(seq 1 $reps); do
     for leg in $legs; do
-      one ${leg}_base_$rep $leg S2M_AB=base
+      one ${leg}_base_$rep $leg "" S2M_AB=base
       for v in $variants; do
-        if [ "$v" = "-" ]; then one ${leg}_env_$rep $leg $venv; else one ${leg}_${v}_$rep $leg S2M_LIB=$(lib_of $v) $venv; fi
+        if [ "$v" = "-" ]; then one ${leg}_alt_$rep $leg "${AB_ARGS:-}" ${venv:-S2M_AB=alt}; else one ${leg}_${v}_$rep $leg "" S2M_LIB=$(lib_of $v) $venv; fi
       done
     done
   done

@@ -299,22 +299,24 @@ def test_s_gate_float_rounding_edge(oracle):
     e.close()
 
 
+@pytest.mark.parametrize("loop", [0, 1])
 @pytest.mark.parametrize("K", [2, 5, 9, 17])
-def test_batch_of_ragged_scans_equals_one_by_one(small_scene, K, monkeypatch):
+def test_batch_of_ragged_scans_equals_one_by_one(small_scene, K, loop, monkeypatch):
     """s2m_iterated_update_batch (one grid for K scans) on scans of different sizes -- including an empty one and one so
     small that the degeneracy queue stops its update after the first pass -- from different predicted poses: every
     scan's log, state and covariance equal what s2m_iterated_update gives for it alone, bit for bit; K = 9 and 17 spread
-    over two and three launch groups; the per-handle-stream form of round 2 (S2M_BATCH_STREAMS=1) gives the same."""
+    over two and three launch groups; the per-handle-stream form (handles that cannot share a launch) gives the same.  loop = 1: all of it
+    with the state on the device (s2m_config.device_loop)."""
     from daliti_amd import Engine, synth
     rs = np.random.RandomState(K)
-    owner = Engine(max_iter=5)
+    owner = Engine(max_iter=5, device_loop=loop)
     owner.map_build(small_scene["map"])
     full = small_scene["scan"]
     engs, xs, Ps, sizes = [], [], [], []
     for k in range(K):
         n = [len(full), 777, 0, 64, 1500, 1024, 2000][k % 7]
         lo = rs.randint(0, len(full) - n + 1)
-        e = Engine(max_iter=5)
+        e = Engine(max_iter=5, device_loop=loop)
         e.map_share(owner)
         e.scan_set(full[lo:lo + n])
         d = np.zeros(24); d[:6] = rs.normal(0, [2e-3, 2e-3, 2e-3, 0.01, 0.01, 0.01])
@@ -429,7 +431,7 @@ def test_device_loop_equals_host_loop(oracle, small_scene, small_tree, ext):
     whose schedule differs from the previous scan's (the plan does not hold: the chain stops and is resumed)."""
     from daliti_amd import Engine
     for max_iter in (5, 10, 2, 1):
-        dev = Engine(max_iter=max_iter, extrinsic_est_en=ext)
+        dev = Engine(max_iter=max_iter, extrinsic_est_en=ext, device_loop=1)
         host = Engine(max_iter=max_iter, extrinsic_est_en=ext, device_loop=0)
         for e in (dev, host):
             e.map_build(small_scene["map"])
@@ -466,7 +468,7 @@ def test_device_loop_equals_host_loop(oracle, small_scene, small_tree, ext):
         assert a["iters"] == ref["iters"] and (a["effct"] == ref["effct"]).all() and np.abs(a["x"] - ref["x"]).max() < 1e-9
         dev.close(); host.close()
     # a degenerate scan: the degeneracy queue stops the update on the device exactly as on the host
-    dev = Engine(max_iter=5); host = Engine(max_iter=5, device_loop=0)
+    dev = Engine(max_iter=5, device_loop=1); host = Engine(max_iter=5, device_loop=0)
     for e in (dev, host):
         e.map_build(small_scene["map"])
         e.scan_set(small_scene["scan"][:64])
