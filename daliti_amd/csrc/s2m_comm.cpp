@@ -98,6 +98,34 @@ void comm_destroy(Comm &c)
 }
 
 // ---- host shared-memory exchange (s2m_comm.h) --------------------------------------------------------------------
+namespace {
+// Header of the segment (the slots follow kShmHeaderDoubles doubles in).  Rank 0 OWNS the name: it removes whatever sits
+// under it (the leftover of a crashed job carries old sequence words), creates the segment exclusively -- fresh, zero-
+// filled -- and writes the magic word; the other ranks open it, count themselves in, and everybody starts when rank 0
+// has seen all of them (`go`).  A rank that finds a segment already fully attached, or whose name has moved to another
+// inode while it waits, has caught the previous generation of the name (re-attach under the same name without a
+// barrier in between) and starts over on the new one.
+struct ShmHeader {
+    unsigned long long magic, nranks, attached, go;
+};
+constexpr unsigned long long kShmMagic = 0x5332'4d45'5843'4831ull;  // "S2MEXCH1"
+constexpr double kShmAttachTimeout = 60.0;
+
+double since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+bool same_inode(const char *name, const struct stat &mine)
+{
+    const int fd = shm_open(name, O_RDWR, 0600);
+    if (fd < 0) return false;
+    struct stat st;
+    const bool same = fstat(fd, &st) == 0 && st.st_ino == mine.st_ino && st.st_dev == mine.st_dev;
+    close(fd);
+    return same;
+}
+}  // namespace
+
 bool shm_exchange_init(ShmExchange &x, const char *name, int nranks, int rank, std::string &err)
 {
     shm_exchange_destroy(x);
@@ -105,16 +133,63 @@ bool shm_exchange_init(ShmExchange &x, const char *name, int nranks, int rank, s
         err = "shared-memory name must look like \"/something\"";
         return false;
     }
-    const size_t bytes = (size_t)2 * nranks * kShmSlotDoubles * sizeof(double);
-    // every rank may be the first to arrive: create-or-open, size it (a fresh segment is zero-filled: sequence 0 = nothing
-    // published; the first exchange carries sequence 1).  The name must be unique per job: a stale segment of a crashed
-    // job with the same name would carry old sequence words.
-    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0) { err = std::string("shm_open: ") + std::strerror(errno); return false; }
-    if (ftruncate(fd, (off_t)bytes) != 0) { err = std::string("ftruncate: ") + std::strerror(errno); close(fd); return false; }
-    void *base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (base == MAP_FAILED) { err = std::string("mmap: ") + std::strerror(errno); return false; }
+    const size_t bytes = ((size_t)kShmHeaderDoubles + (size_t)2 * nranks * kShmSlotDoubles) * sizeof(double);
+    const auto t0 = std::chrono::steady_clock::now();
+    void *base = MAP_FAILED;
+    if (rank == 0) {
+        (void)shm_unlink(name);
+        const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) { err = std::string("shm_open: ") + std::strerror(errno); return false; }
+        if (ftruncate(fd, (off_t)bytes) != 0) { err = std::string("ftruncate: ") + std::strerror(errno); close(fd); shm_unlink(name); return false; }
+        base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (base == MAP_FAILED) { err = std::string("mmap: ") + std::strerror(errno); shm_unlink(name); return false; }
+        ShmHeader *h = static_cast<ShmHeader *>(base);
+        h->nranks = (unsigned long long)nranks;
+        __atomic_store_n(&h->attached, 1ull, __ATOMIC_RELAXED);
+        __atomic_store_n(&h->magic, kShmMagic, __ATOMIC_RELEASE);
+        while (__atomic_load_n(&h->attached, __ATOMIC_ACQUIRE) < (unsigned long long)nranks) {
+            if (since(t0) > kShmAttachTimeout) {
+                err = "shared-memory exchange: not every rank attached within 60 s";
+                munmap(base, bytes); shm_unlink(name);
+                return false;
+            }
+            usleep(50);
+        }
+        __atomic_store_n(&h->go, 1ull, __ATOMIC_RELEASE);
+    } else {
+        for (;;) {
+            if (since(t0) > kShmAttachTimeout) { err = "shared-memory exchange: rank 0 did not create the segment within 60 s"; return false; }
+            const int fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) {  // not there yet, or not sized yet
+                if (fd >= 0) close(fd);
+                usleep(100);
+                continue;
+            }
+            base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (base == MAP_FAILED) { err = std::string("mmap: ") + std::strerror(errno); return false; }
+            ShmHeader *h = static_cast<ShmHeader *>(base);
+            bool stale = false;
+            while (__atomic_load_n(&h->magic, __ATOMIC_ACQUIRE) != kShmMagic && !stale) {
+                if (since(t0) > kShmAttachTimeout || !same_inode(name, st)) stale = true;
+                else usleep(50);
+            }
+            if (!stale && h->nranks != (unsigned long long)nranks) { err = "shared-memory exchange: the segment was created for another rank count"; munmap(base, bytes); return false; }
+            // count in; a segment that is already full is the previous generation of this name
+            if (!stale && __atomic_add_fetch(&h->attached, 1ull, __ATOMIC_ACQ_REL) > (unsigned long long)nranks) stale = true;
+            while (!stale && __atomic_load_n(&h->go, __ATOMIC_ACQUIRE) == 0ull) {
+                if (since(t0) > kShmAttachTimeout) { err = "shared-memory exchange: not every rank attached within 60 s"; munmap(base, bytes); return false; }
+                if (!same_inode(name, st)) stale = true;   // rank 0 has replaced the segment under this name
+                else usleep(50);
+            }
+            if (!stale) break;
+            munmap(base, bytes);
+            base = MAP_FAILED;
+            usleep(200);
+        }
+    }
     x.base = base;
     x.bytes = bytes;
     x.nranks = nranks;
@@ -128,7 +203,7 @@ bool shm_exchange(ShmExchange &x, const double *block, int count, double *out, s
 {
     if (!x.base || count < 1 || count >= kShmSlotDoubles) { err = "shared-memory exchange not initialised"; return false; }
     const unsigned long long seq = ++x.seq;
-    double *slots = static_cast<double *>(x.base) + (size_t)(seq & 1ull) * x.nranks * kShmSlotDoubles;
+    double *slots = static_cast<double *>(x.base) + kShmHeaderDoubles + (size_t)(seq & 1ull) * x.nranks * kShmSlotDoubles;
     double *mine = slots + (size_t)x.rank * kShmSlotDoubles;
     std::memcpy(mine, block, (size_t)count * sizeof(double));
     __atomic_store_n(reinterpret_cast<unsigned long long *>(mine + kShmSlotDoubles - 1), seq, __ATOMIC_RELEASE);
@@ -155,7 +230,7 @@ void shm_exchange_destroy(ShmExchange &x)
 {
     if (x.base) {
         munmap(x.base, x.bytes);
-        if (x.name[0]) shm_unlink(x.name);  // the name goes with the first rank that leaves; mappings of the others stay valid
+        if (x.name[0] && x.rank == 0) shm_unlink(x.name);  // the name belongs to rank 0; mappings of the others stay valid
     }
     x = ShmExchange();
 }

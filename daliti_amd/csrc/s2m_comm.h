@@ -27,7 +27,10 @@ struct ShmExchange {
     char name[96] = {0};
 };
 constexpr int kShmSlotDoubles = 256;  // 160-double block + sequence word, padded to 2 KB (no line shared between slots)
+constexpr int kShmHeaderDoubles = 16;  // attach header in front of the slots: magic, rank count, ranks attached, go
 
+// Collective over the ranks: rank 0 creates the segment under `name` (removing a leftover), the others wait for it, and
+// every rank returns once all have attached (or fails after 60 s).  Re-attaching under the same name is safe.
 bool shm_exchange_init(ShmExchange &x, const char *name, int nranks, int rank, std::string &err);
 // publish `block` (count doubles) as this rank's contribution, wait for all ranks, return the per-rank blocks in rank order
 // in `out` (nranks x count).  false on time-out (a rank died or left the loop).

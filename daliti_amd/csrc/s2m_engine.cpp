@@ -101,6 +101,10 @@ struct s2m_engine {
     // the last LATER one; -1 = unknown.  A pass whose predecessor in the same position had none runs without the
     // far-point kernel on that bet (spec_mode: 0 never, 1 by history, 2 always -- the last two for tests)
     int64_t far_first = -1, far_later = -1;
+    int64_t bets_won = 0, bets_lost = 0;   // passes that ran without the far-point kernel and were right / had to be redone
+    // neighbour lists of the last rematch pass that did not fill inside the gate (block[159]); -1 = not known for this
+    // handle (forms that only see the sum over shards, the device-resident loop): s2m_map_incremental then asks the device
+    int64_t short_lists = -1;
     int spec_mode = 1;
     bool spec_env = false;  // S2M_SPEC set: the environment overrides the config (A/B runs)
 
@@ -625,7 +629,9 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     const Pose pose = pose_of(state);
     float4 *la = nullptr, *lb = nullptr;
     int64_t na = 0, nb = 0;
-    if (e->nn_valid && ekf_inited != 0) {  // Nearest_Points[i] of the reference is never short (unbounded search)
+    // Nearest_Points[i] of the reference is never short (unbounded search): finish the lists that ended at the gate -- when
+    // the last rematch pass reported any (block[159]; a scan inside the mapped area has none: no launch, no round trip)
+    if (e->nn_valid && ekf_inited != 0 && e->short_lists != 0) {
         int rc = s2m_complete_neighbors(e, nullptr);
         if (rc) return rc;
     }
@@ -910,6 +916,7 @@ int s2m_residual_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int 
     if (rc) return rc;
     rc = finish_timing(e);
     if (rc) return rc;
+    if (rematch) e->short_lists = (int64_t)hb[159];
     std::memcpy(out->HtH, hb, 144 * sizeof(double));
     std::memcpy(out->Htz, hb + 144, 12 * sizeof(double));
     out->effct_feat_num = (int32_t)hb[156];
@@ -921,6 +928,7 @@ int s2m_residual_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int 
 int s2m_residual_pass_device(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, double *d_block)
 {
     if (!d_block) return fail(e, S2M_ERR_ARG, "null device block");
+    if (e && rematch) e->short_lists = -1;  // the block stays on the device
     return run_pass(e, state, rematch, d_block);
 }
 
@@ -1041,6 +1049,7 @@ int s2m_complete_neighbors(s2m_engine *e, int64_t *n_completed)
     S2M_HIP(e, hipSetDevice(e->device));
     const int n = (int)e->n;
     if (n == 0 || e->grid.m == 0 || e->nn_complete) return S2M_OK;
+    if (e->short_lists == 0) { e->nn_complete = true; return S2M_OK; }  // the last rematch pass counted them: none
     MatchArgs m;
     m.grid = e->grid; m.pose = e->rematch_pose; m.gates = gates_of(e->cfg);
     m.sx = e->d_scan; m.sy = e->d_scan + e->n_cap; m.sz = e->d_scan + 2 * e->n_cap; m.n = n;
@@ -1281,6 +1290,7 @@ int loop_finish(s2m_engine *e, double *x, double *P, s2m_iter_log *log)
     e->nn_valid = true;
     e->nn_complete = false;
     e->pass_done = true;
+    e->short_lists = -1;
     e->sched_hist.assign((size_t)e->cfg.max_iter, 0);
     for (int i = 0; i < iters; ++i) {
         e->sched_hist[i] = (int8_t)(rec.rematch[i] != 0);
@@ -1478,16 +1488,19 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
             rc = shm_sum(e, &hb, spec, &any_void);
             if (rc) return rc;
         }
+        if (rematch) e->short_lists = (!reduce && !collective) ? (int64_t)own[159] : -1;
         if (rematch && !reduce && !collective) {
             const int64_t far_points = (int64_t)hb[158];
             if (it == 0) e->far_first = far_points; else e->far_later = far_points;
             const bool lost = spec && (int64_t)own[158] != 0;  // this rank's bet is lost: its block is void (s2m_reduce.hip)
+            if (spec) { if (lost) ++e->bets_lost; else ++e->bets_won; }
             if (lost) {
                 rc = redo_with_far_points(e, x, d_block);
                 if (rc) return rc;
                 rc = wait_block(e, d_block, &hb);
                 if (rc) return rc;
                 own = hb;
+                e->short_lists = (int64_t)own[159];
             }
             if (shm && any_void) {  // somebody's block was void: everybody publishes again (the unchanged block where it was valid)
                 hb = own;
@@ -1667,6 +1680,7 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
             int rc = finish_timing(e);
             if (rc) return rc;
             bool finished = false;
+            if (s.c.rematch) e->short_lists = (int64_t)e->h_block[159];
             rc = consume_block(e, e->h_block, s.c, xk(i), xpk(i), Pk(i), logs ? logs + i : nullptr, finished);
             if (rc) return rc;
             ++s.c.it;
@@ -1736,6 +1750,8 @@ int s2m_iterated_update_multi(s2m_engine *const *handles, int32_t n, double x[S2
             int rc = run_pass(handles[i], x, c.rematch, handles[i]->d_block);
             if (rc) return rc;
         }
+        if (c.rematch)
+            for (int i = 0; i < n; ++i) handles[i]->short_lists = -1;  // (each handle's own count is in its block; not tracked here)
         if (it == 0) {  // (P/R)^-1 behind the launches of the first pass, see s2m_iterated_update_sharded
             Mat24 Pm;
             std::memcpy(Pm.data(), P, sizeof(double) * S2M_DIM * S2M_DIM);
@@ -1920,6 +1936,7 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
                 s.waiting = false;
                 --G.waiting;
                 bool finished = false;
+                if (s.c.rematch) e->short_lists = (int64_t)e->h_block[159];
                 int rc = consume_block(e, e->h_block, s.c, xk(i), xpk(i), Pk(i), logs ? logs + i : nullptr, finished);
                 if (rc) return rc;
                 ++s.c.it;
@@ -2138,6 +2155,7 @@ int s2m_comm_init(s2m_engine *e, const uint8_t id[S2M_COMM_ID_BYTES], int32_t nr
     if (!e || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(e, S2M_ERR_ARG, "s2m_comm_init: bad argument");
     S2M_HIP(e, hipSetDevice(e->device));
     comm_destroy(e->comm);
+    shm_exchange_destroy(e->shm);   // one exchange at a time
     std::string err;
     if (!comm_init(e->comm, id, nranks, rank, err)) return fail(e, S2M_ERR_HIP, err.c_str());
     return S2M_OK;
@@ -2207,6 +2225,14 @@ int s2m_get_timing(const s2m_engine *e, double ms[3])
 {
     if (!e || !ms) return S2M_ERR_ARG;
     ms[0] = e->last_ms[0]; ms[1] = e->last_ms[1]; ms[2] = e->last_ms[2];
+    return S2M_OK;
+}
+
+int s2m_bet_stats(const s2m_engine *e, int64_t stats[2])
+{
+    if (!e || !stats) return S2M_ERR_ARG;
+    stats[0] = e->bets_won;
+    stats[1] = e->bets_lost;
     return S2M_OK;
 }
 

@@ -34,14 +34,16 @@ namespace s2m {
 
 // Term layout of a partial row for NC Jacobian columns (NC = 6 without extrinsic estimation, 12
 // with): [0, NC(NC+1)/2) upper triangle of H^T H (row-major, r <= c), then NC terms of H^T z, then
-// total_residual and the effective count; padded to a multiple of 32 (32 or 96 slots).
+// total_residual, the effective count and (rematch passes) the number of neighbour lists that did not fill inside the
+// gate; padded to a multiple of 32 (32 or 96 slots).
 template <int NC>
 struct Terms {
     static constexpr int kTri = NC * (NC + 1) / 2;
     static constexpr int kHtz = kTri;
     static constexpr int kRes = kTri + NC;
     static constexpr int kCnt = kTri + NC + 1;
-    static constexpr int kUsed = kTri + NC + 2;             // 29 or 92
+    static constexpr int kShort = kTri + NC + 2;            // rematch pass: lists that did not fill inside the gate
+    static constexpr int kUsed = kTri + NC + 3;             // 30 or 93
     static constexpr int kSlots = ((kUsed + 31) / 32) * 32;  // 32 or 96
     __host__ __device__ static constexpr int tri(int r, int c) { return r * NC - (r * (r - 1)) / 2 + (c - r); }
 };
@@ -195,7 +197,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, ReduceShared<EX
     const int i = (int)bx * kRedBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    bool eff = false;
+    bool eff = false, short_list = false;
     double h[12], z = 0.0, absr = 0.0;
 #pragma unroll
     for (int k = 0; k < 12; ++k) h[k] = 0.0;
@@ -230,6 +232,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, ReduceShared<EX
                 }
                 plane_ok = fit_plane(nx, ny, nz, a.gates.plane_thr, pl);
             }
+            short_list = !gate;  // the unbounded search of the reference would go on for this point (s2m_complete_neighbors)
             sel = gate ? 1 : 0;  // point_selected_surf after the gate
             fl = (uint8_t)((gate ? kFlagGate : 0) | (plane_ok ? kFlagPlane : 0));
             a.plane[i] = pl;
@@ -278,7 +281,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, ReduceShared<EX
         my[lane * 17 + 12] = z;
         my[lane * 17 + 13] = absr;
         my[lane * 17 + 14] = eff ? 1.0 : 0.0;
-        my[lane * 17 + 15] = 0.0;
+        my[lane * 17 + 15] = short_list ? 1.0 : 0.0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -296,6 +299,7 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, ReduceShared<EX
             else if (j == 12 && i < 12) slot = T::kHtz + i;
             else if (i == 13 && j == 14) slot = T::kRes;
             else if (i == 14 && j == 14) slot = T::kCnt;
+            else if (i == 15 && j == 15) slot = T::kShort;
             if (slot >= 0) red[wave][slot] = acc[r];
         }
         if (lane < T::kSlots - T::kUsed) red[wave][T::kUsed + lane] = 0.0;  // padding slots of the row
@@ -319,6 +323,8 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, ReduceShared<EX
                 val = absr;
             } else if (t == T::kCnt) {
                 val = eff ? 1.0 : 0.0;
+            } else if (t == T::kShort) {
+                val = short_list ? 1.0 : 0.0;
             }
             v[k] = val;
         }
@@ -456,6 +462,8 @@ __device__ __forceinline__ void reduce_body(const ReduceArgs &a, ReduceShared<EX
             v = tot[T::kRes];
         } else if (o == 158) {
             v = (double)far_points;
+        } else if (o == 159) {
+            v = tot[T::kShort];  // rematch passes: neighbour lists short of the gate (0 on a reuse pass)
         }
         a.block[o] = v;
         if (a.host_block) publish_store(a.host_block + o, v);

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
     "s2m_iterated_update", "s2m_iterated_update_batch", "s2m_iterated_update_multi", "s2m_iterated_update_sharded",
     "s2m_complete_neighbors", "s2m_map_get_order", "s2m_map_grid", "s2m_map_update_stats", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_init_shm", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
-    "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats",
+    "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats", "s2m_bet_stats",
 ]
 
 
@@ -156,6 +156,12 @@ class Engine:
         ms = (C.c_double * 3)()
         self._ck(self.lib.s2m_get_timing(self.h, ms))
         return list(ms)
+
+    def bet_stats(self):
+        """(passes that bet on an empty far-point list and won, passes whose bet was lost and redone)"""
+        st = (C.c_int64 * 2)()
+        self._ck(self.lib.s2m_bet_stats(self.h, st))
+        return int(st[0]), int(st[1])
 
     def timing_stats(self):
         st = (C.c_double * 6)()

@@ -32,6 +32,7 @@ extern "C" {
 /* 2: s2m_map_incremental gained `ekf_inited`, s2m_get_timing_stats writes 6 doubles, s2m_set_timing(n > 2) samples
  * (all round 2, which forgot to bump it); new in round 3: s2m_iterated_update_multi, s2m_complete_neighbors,
  * s2m_map_get_order, s2m_map_update_stats.  3 (round 4): s2m_config gained `device_loop`.  A caller built against an
+ * s2m_bet_stats is new, block[159] carries the count of neighbour lists short of the gate.  A caller built against an
  * older version must be recompiled. */
 #define S2M_ABI_VERSION 3
 #define S2M_K 5            /* NUM_MATCH_POINTS, laserMapping.cpp:77 */
@@ -369,6 +370,12 @@ int s2m_h_share_model(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int 
  * choose n coprime to the passes per scan so that every kind of pass is visited); 0 switches it off. */
 int s2m_set_timing(s2m_engine *e, int enabled);
 int s2m_get_timing(const s2m_engine *e, double ms[3]);
+/* The bet of s2m_config.far_point_bet, counted (design, not reference): stats[0] = rematch passes that ran without the
+ * far-point kernel and were right, stats[1] = passes whose bet was lost (far-point kernel + reduce kernel run again).
+ * The rule: a pass bets only when the last pass in the same position (first pass of a scan / a later one) reported no
+ * far point at all; a lost bet therefore stops the betting in that position until a full pass reports zero again. */
+int s2m_bet_stats(const s2m_engine *e, int64_t stats[2]);
+
 /* Accumulated over the timed passes since the last s2m_set_timing call: stats[0] = sum of search-kernel
  * ms over rematch passes, stats[1] = their count, stats[2] = sum of the reduce kernel's ms on rematch
  * passes (gate + plane fit included), stats[3] = count, stats[4] = sum of the reduce kernel's ms on reuse

@@ -68,6 +68,33 @@ int s2m_bench_loop(s2m_engine *const *handles, int32_t k, int32_t steps, int32_t
 // s2m_fov_segment, i.e. what the reference's node does per scan (laserMapping.cpp:731-1175) with the engine in place of
 // its CPU stages.  frame_us[f] = wall time of frame f on the host's steady clock, merged[f] = how its map update was
 // produced (s2m_map_last_update).  x (36) holds the last frame's state on return.
+// A different scan every step through ONE handle (vary != 0: scan s % k; vary == 0: always scan 0): what a live stream
+// does to the handle's histories -- the bet on an empty far-point list (s2m_config.far_point_bet) is decided by what
+// the LAST scan's pass in the same position found, and a benchmark that replays one scan makes that a perfect predictor.
+// Every step hands the scan over with s2m_scan_set (device pointer), so both settings pay the same hand-over.
+int s2m_bench_loop_varying(s2m_engine *e, int32_t k, const float *const *scans_dev, const int64_t *n, int32_t steps,
+                           int32_t vary, const double *x_prop, const double *P0, double *x, double *P, s2m_iter_log *log,
+                           int64_t *iters, int64_t *rematch)
+{
+    if (!e || k < 1 || !scans_dev || !n || steps < 0 || !x_prop || !P0 || !x || !P || !log || !iters || !rematch) return S2M_ERR_ARG;
+    const size_t xs = S2M_STATE_DOUBLES, ps = (size_t)S2M_DIM * S2M_DIM;
+    for (int s = 0; s < steps; ++s) {
+        const int j = vary ? s % k : 0;
+        int rc = s2m_scan_set(e, scans_dev[j], 3, n[j], 1);
+        if (rc) return rc;
+        rc = s2m_feat_queue_set(e, nullptr, 0);
+        if (rc) return rc;
+        std::memcpy(x, x_prop + j * xs, xs * sizeof(double));
+        std::memcpy(P, P0 + j * ps, ps * sizeof(double));
+        P[0] += (double)(s & 1) * 1e-15;
+        rc = s2m_iterated_update(e, x, x_prop + j * xs, P, log);
+        if (rc) return rc;
+        *iters += log->iters;
+        *rematch += log->rematch_passes;
+    }
+    return S2M_OK;
+}
+
 int s2m_bench_frames(s2m_engine *e, int32_t frames, const float *records, int64_t stride_floats, int64_t n,
                      int32_t time_off_a, int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses,
                      const double *state_end, float leaf, const double *x_prop, const double *P0, double filter_size_map,
