@@ -523,30 +523,6 @@ def main():
             dt = float(t.item())
         return dt, it, rm
 
-    if sharded and a.collective == "auto" and exchange == "shm" and a.backend == "nccl":
-        # "pick RCCL or a host-side gather, whichever measures lower" -- a few steps of each, the maximum over
-        # the ranks decides (the same number on every rank), the loser is detached
-        def probe_ms():
-            run_steps(3)
-            d, _, _ = timed(10)
-            return 1e3 * d / 10
-        exchange_probe["shm"] = probe_ms()
-        eng.comm_destroy()
-        if try_rccl():
-            try:
-                ms_rccl = probe_ms()
-            except Exception as ex:  # noqa: BLE001 - a rank whose all-reduce failed: everybody returns to the host exchange
-                ms_rccl = None
-                sys.stderr.write("rank %d: RCCL probe failed (%s)\n" % (rank, ex))
-            if all_ok(ms_rccl is not None):
-                exchange_probe["rccl"] = ms_rccl
-            if "rccl" in exchange_probe and exchange_probe["rccl"] < exchange_probe["shm"]:
-                exchange = "rccl"
-            else:
-                eng.comm_destroy()
-        if exchange == "shm" and not try_shm():
-            raise SystemExit("the shared-memory exchange could not be re-attached")
-
     # the box's own copy peak (second denominator of the roofline): measured here, before the timed region, because it
     # is independent of it and because ~40 ms of streaming copies also bring the device clocks up -- with the driver's
     # --steps 20 --warmup 5 the whole timed region is 3 ms and would otherwise run on a chip that has just left idle
@@ -741,6 +717,89 @@ def main():
                                   "pose_delta_vs_range_sharding_m": float(np.abs(sres["x"][9:12] - res["x"][9:12]).max()),
                                   "note": "side leg after the timed region: the same scan, rank r holding azimuth sector r of "
                                           "every beam instead of a contiguous index range"}
+    if world > 1 and not a.no_side and a.config in ("C3", "C5"):
+        # side leg of every N > 1 run: the multi-GPU form that does scale -- every rank keeps 24 replica scans in flight on
+        # its own GPU through s2m_iterated_update_batch (no exchange at all), between two barriers; scans/s summed over ranks
+        try:
+            rb = c5_batch(torch, Engine, synth, eng, a, k=24, steps=12, warmup=3, fence=fence)
+            t = torch.tensor([rb["dt"]], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rdt = float(t.item())
+            n_scans = world * 24 * rb["steps"]
+            gbs = world * rb["algorithmic_bytes"] / rdt / 1e9
+            out["replicas_batched"] = {"scans_per_sec": n_scans / rdt, "value": world * rb["evals"] / rdt, "unit": "evals/s",
+                                       "scans_in_flight_per_gpu": 24, "steps": rb["steps"], "ms_per_batch": 1e3 * rdt / rb["steps"],
+                                       "job_roofline": {"achieved": gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                                        "frac": gbs / (HBM_PEAK_GBS * world)},
+                                       "note": "side leg: BASELINE configs[4] scaled out -- 24 independent 65,536-pt scans in "
+                                               "flight per GPU (s2m_iterated_update_batch), map replicated, no collective"}
+        except Exception as ex:  # noqa: BLE001 - a side leg never takes the headline down
+            out["replicas_batched"] = {"error": str(ex)[:300]}
+    if sharded and a.collective == "auto" and exchange == "shm" and world > 1 and not a.no_side:
+        # The other exchange forms, measured AFTER the headline (which ran on the shared-memory exchange) and under a
+        # watchdog: a hang inside ncclCommInitRank or the first all-reduce must not take the record down with it.  On expiry
+        # rank 0 prints what has been collected and every rank leaves with os._exit(0) (never a re-exec).
+        import threading
+
+        def expire():
+            if rank == 0:
+                out["config"]["collective_probe_ms_per_step"] = dict(exchange_probe, **{"rccl" if a.backend == "nccl" else "torch_callback": "timed out"})
+                out["rccl_probe"] = "timed out"
+                C.CDLL(None).fflush(None)
+                sys.stdout.write(json.dumps(out) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get("S2M_PROBE_TIMEOUT_S", "120")), expire)
+        dog.daemon = True
+        dog.start()
+
+        def probe_ms(run):
+            run(3)
+            fence()
+            t0 = time.perf_counter()
+            run(10)
+            fence()
+            d = time.perf_counter() - t0
+            t = torch.tensor([d], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return 1e3 * float(t.item()) / 10
+        sc0 = scans[0][0]                                   # the headline's shard again (the side legs changed the scan)
+        d_scan = torch.from_numpy(np.ascontiguousarray(sc0)).cuda()
+        d_keep.append(d_scan)
+        torch.cuda.synchronize()
+        eng.scan_set_device(d_scan.data_ptr(), 3, len(sc0))
+        exchange_probe["shm"] = probe_ms(run_steps)
+        eng.comm_destroy()
+        if a.backend == "nccl":
+            if try_rccl():
+                try:
+                    ms_other = probe_ms(run_steps)
+                except Exception as ex:  # noqa: BLE001
+                    ms_other = None
+                    sys.stderr.write("rank %d: RCCL probe failed (%s)\n" % (rank, ex))
+                if all_ok(ms_other is not None):
+                    exchange_probe["rccl"] = ms_other
+                eng.comm_destroy()
+            else:
+                exchange_probe["rccl"] = "unavailable"
+        else:
+            # gloo (the two-process test on one GPU): the torch.distributed callback form stands in for the second exchange, so
+            # that the detach -> other form -> re-attach sequence has run with world > 1 before a driver ever sees it
+            from daliti_amd.sharding import allreduce_block
+
+            def cb_steps(n_steps):
+                xb, Pb = np.zeros(36), np.zeros((24, 24))
+                for _ in range(n_steps):
+                    eng.set_feat_queue(())
+                    xb[:] = x_prop0
+                    Pb[:] = P0
+                    eng.iterated_update_sharded(xb, x_prop0, Pb, blk.data_ptr(), lambda: allreduce_block(blk))
+            exchange_probe["torch_callback"] = probe_ms(cb_steps)
+        if not try_shm():
+            raise SystemExit("the shared-memory exchange could not be re-attached")
+        exchange_probe["shm_reattached"] = probe_ms(run_steps)
+        dog.cancel()
+        out["config"]["collective_probe_ms_per_step"] = exchange_probe
     if rank == 0 and single and not a.no_cpu and a.cpu_steps > 0:
         cpu_map = eng.map_points() if a.config == "R1" else map_xyz
         cpu_scan = eng.scan_get() if a.config == "R1" else scans[0][0]
@@ -818,7 +877,7 @@ def other_configs(torch, Engine, synth, a, c3_map, steps=50, warmup=5):
     return res
 
 
-def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5):
+def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5, fence=None):
     """BASELINE configs[4] on ONE GPU: k independent 65,536-point scans (seeds 2.., sensor offsets (i - 3.5) * 2 m)
     in flight through s2m_iterated_update_batch from one host thread, searching the map `owner` already holds."""
     engs, keep, filt = [], [], []
@@ -835,10 +894,11 @@ def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5):
         filt.append(synth.filter_inputs(pos))
     cl = CLoop(engs, [f[1] for f in filt], [f[2] for f in filt], 1)
     cl.run(warmup)
-    torch.cuda.synchronize()
+    fence = fence or torch.cuda.synchronize   # N > 1: barrier + synchronise, so that every rank's batches run side by side
+    fence()
     t0 = time.perf_counter()
     it, rm = cl.run(steps)
-    torch.cuda.synchronize()
+    fence()
     dt = time.perf_counter() - t0
     n = 65536
     reuse = it - rm
@@ -846,7 +906,8 @@ def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5):
     errs = [float(np.abs(cl.x[i][9:12] - filt[i][0][9:12]).max()) for i in range(k)]
     for e in engs:
         e.close()
-    return {"scans_in_flight": k, "steps": steps, "scans_per_sec": k * steps / dt, "value": n * it / dt, "unit": "evals/s",
+    return {"scans_in_flight": k, "steps": steps, "dt": dt, "evals": float(n) * it, "algorithmic_bytes": algo_bytes,
+            "scans_per_sec": k * steps / dt, "value": n * it / dt, "unit": "evals/s",
             "ms_per_batch": 1e3 * dt / steps, "eskf_iters_per_sec": it / dt,
             "algorithmic_GBps": algo_bytes / dt / 1e9, "frac": algo_bytes / dt / 1e9 / HBM_PEAK_GBS,
             "pose_error_vs_truth_m_max": max(errs),

@@ -199,6 +199,13 @@ def test_bet_on_no_far_points_is_exact_whether_won_or_lost(oracle):
     again = e.iterated_update(c["x_prop"], c["x_prop"], c["P"])       # history now says: do not bet
     assert lost["iters"] == again["iters"] and (lost["effct"] == again["effct"]).all()
     assert (bits(lost["x"]) == bits(again["x"])).all() and (bits(lost["P"]) == bits(again["P"])).all()
+    # the rule, counted: a position bets only after a pass there reported NO far point; the lost bet above is the only one,
+    # and the scan after it did not bet again in that position (s2m_bet_stats)
+    won, n_lost = e.bet_stats()
+    assert n_lost == 1 and won >= 2, (won, n_lost)
+    e.set_feat_queue(())
+    e.iterated_update(c["x_prop"], c["x_prop"], c["P"])
+    assert e.bet_stats() == (won, n_lost)
     ro = oracle.iterated_update(oracle.default_cfg(max_iter=5, nthreads=8), oracle.KdTree(c["map"]), bad, c["x_prop"], c["x_prop"], c["P"])
     assert lost["iters"] == ro["iters"] and (lost["effct"] == ro["effct"]).all() and np.abs(lost["x"] - ro["x"]).max() < 1e-9
     e.close()

@@ -295,6 +295,34 @@ def test_two_process_strong_scaling_bench_equals_single_rank():
     assert np.abs(np.array(l2["final_pos"]) - np.array(l1["final_pos"])).max() < 1e-10
 
 
+@pytest.mark.gpu
+def test_two_process_default_bench_walks_every_exchange_form():
+    """`python bench.py --gpus 2` as the driver runs it (default config C3), two ranks on one GPU over gloo: the headline
+    on the shared-memory exchange, then -- after the headline, under the watchdog -- detach, the second exchange form (the
+    torch.distributed callback stands in for RCCL under gloo), re-attach; the side legs weak_scaling, sector_sharding and
+    replicas_batched (24 scans in flight per rank, summed).  With a watchdog of a millisecond the probe "hangs": rank 0
+    still prints the line collected so far and every rank leaves with exit code 0."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu",
+           "--backend", "gloo", "--all-on-device0"]
+    two = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert two.returncode == 0, two.stderr[-3000:]
+    l2 = json.loads(two.stdout.rstrip().splitlines()[-1])
+    assert l2["n_gpus"] == 2 and l2["scaling"] == "strong" and l2["config"]["collective"] == "shm"
+    probe = l2["config"]["collective_probe_ms_per_step"]
+    assert set(probe) == {"shm", "torch_callback", "shm_reattached"} and all(v > 0 for v in probe.values())
+    assert l2["weak_scaling"]["scan_points_total"] == 131072 and l2["sector_sharding"]["scan_points_per_gpu"] == 32768
+    rb = l2["replicas_batched"]
+    assert rb["scans_in_flight_per_gpu"] == 24 and rb["scans_per_sec"] > 1000 and 0 < rb["job_roofline"]["frac"] < 1
+    assert rb["job_roofline"]["peak"] == 2 * 8000.0
+    hung = subprocess.run(cmd, env=dict(env, S2M_PROBE_TIMEOUT_S="0.001"), capture_output=True, text=True, timeout=1500)
+    assert hung.returncode == 0, hung.stderr[-3000:]
+    lh = json.loads([ln for ln in hung.stdout.splitlines() if ln.startswith("{")][-1])
+    assert lh["rccl_probe"] == "timed out" and lh["ms_per_step"] > 0 and "replicas_batched" in lh
+
+
 def test_bench_defaults_follow_baseline_configs():
     """CPU-side check of bench.py's argument logic: N > 1 defaults to strong scaling (C4: one 131,072-point scan,
     16,384 points per GPU at N = 8; C3: 8,192), C5 to replicas with the survey's seeds and offsets."""
