@@ -735,7 +735,7 @@ def main():
                                                "flight per GPU (s2m_iterated_update_batch), map replicated, no collective"}
         except Exception as ex:  # noqa: BLE001 - a side leg never takes the headline down
             out["replicas_batched"] = {"error": str(ex)[:300]}
-    if sharded and a.collective == "auto" and exchange == "shm" and world > 1 and not a.no_side:
+    if sharded and a.collective == "auto" and exchange == "shm" and not a.no_side:
         # The other exchange forms, measured AFTER the headline (which ran on the shared-memory exchange) and under a
         # watchdog: a hang inside ncclCommInitRank or the first all-reduce must not take the record down with it.  On expiry
         # rank 0 prints what has been collected and every rank leaves with os._exit(0) (never a re-exec).
@@ -760,9 +760,11 @@ def main():
             run(10)
             fence()
             d = time.perf_counter() - t0
-            t = torch.tensor([d], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return 1e3 * float(t.item()) / 10
+            if dist.is_initialized():
+                t = torch.tensor([d], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d = float(t.item())
+            return 1e3 * d / 10
         sc0 = scans[0][0]                                   # the headline's shard again (the side legs changed the scan)
         d_scan = torch.from_numpy(np.ascontiguousarray(sc0)).cuda()
         d_keep.append(d_scan)
