@@ -1010,13 +1010,21 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
     x_out = np.zeros(36)
     frame_us = np.zeros(max(frames, 1))
     merged = np.zeros(max(frames, 1), np.int32)
-    rc = fn(eng.h, C.c_int32(frames), C.c_void_p(recs.ctypes.data), C.c_int64(recs.shape[1]), C.c_int64(recs.shape[0]),
-            C.c_int32(4), C.c_int32(6), C.c_void_p(pos_c.ctypes.data), C.c_int32(len(pos_c)), C.c_void_p(end_c.ctypes.data),
-            C.c_float(leaf), C.c_void_p(xp_c.ctypes.data), C.c_void_p(P0_c.ctypes.data), C.c_double(0.5), C.c_double(1000.0),
-            C.c_void_p(x_out.ctypes.data), C.c_void_p(frame_us.ctypes.data), C.c_void_p(merged.ctypes.data))
-    if rc != 0:
-        raise RuntimeError("s2m_bench_frames failed: %d (%s)" % (rc, eng.lib.s2m_last_error(eng.h).decode()))
-    torch.cuda.synchronize()
+    def run_frames(prefetch):
+        rc = fn(eng.h, C.c_int32(frames), C.c_void_p(recs.ctypes.data), C.c_int64(recs.shape[1]), C.c_int64(recs.shape[0]),
+                C.c_int32(4), C.c_int32(6), C.c_void_p(pos_c.ctypes.data), C.c_int32(len(pos_c)), C.c_void_p(end_c.ctypes.data),
+                C.c_float(leaf), C.c_void_p(xp_c.ctypes.data), C.c_void_p(P0_c.ctypes.data), C.c_double(0.5), C.c_double(1000.0),
+                C.c_int32(prefetch), C.c_void_p(x_out.ctypes.data), C.c_void_p(frame_us.ctypes.data), C.c_void_p(merged.ctypes.data))
+        if rc != 0:
+            raise RuntimeError("s2m_bench_frames failed: %d (%s)" % (rc, eng.lib.s2m_last_error(eng.h).decode()))
+        torch.cuda.synchronize()
+    # first without the prefetch (every frame's 3 MB of records cross PCIe inside s2m_scan_set_from_raw), then -- the figures
+    # reported -- with s2m_scan_prefetch_raw: the next sweep's records travel while the current one is registered
+    run_frames(0)
+    med_no_prefetch = float(np.median(frame_us[:frames] * 1e-3))
+    st0 = eng.map_update_stats()
+    eng.scan_prefetch_raw(recs)   # the side stream, its buffer and the worker thread exist before the timed frames
+    run_frames(1)
     st1 = eng.map_update_stats()
     per = frame_us[:frames] * 1e-3
     how = [bool(v) for v in merged[:frames]]
@@ -1026,7 +1034,8 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
         frames, med, float(np.percentile(per, 99)), float(per.max()), worst, "merged" if how[worst] else "rebuilt"))
     return {"ms_per_frame": float(w.sum()), "frames_per_s": float(1e3 / w.sum()),
             "ms_per_frame_back_to_back": med, "frames_per_s_back_to_back": float(1e3 / med),
-            "median_ms": med, "p99_ms": float(np.percentile(per, 99)), "max_ms": float(per.max()),
+            "median_ms": med, "median_ms_without_prefetch": med_no_prefetch,
+            "p99_ms": float(np.percentile(per, 99)), "max_ms": float(per.max()),
             "max_over_median": float(per.max() / med), "worst_frame": worst,
             "frames_back_to_back": int(frames),
             "updates": {k: int(st1[k] - st0[k]) for k in st1},

@@ -11,7 +11,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <vector>
@@ -67,6 +69,21 @@ struct s2m_engine {
     // staging for host inputs
     float *d_stage = nullptr;
     int64_t stage_cap = 0;  // floats
+    // s2m_scan_prefetch_raw: the NEXT sweep's records cross PCIe on a side stream, driven by a worker thread (a copy out of
+    // pageable memory blocks the thread that issues it), while the caller's thread registers the current sweep
+    struct Prefetch {
+        std::thread worker;
+        std::mutex mu;
+        std::condition_variable cv;
+        bool quit = false, busy = false, ready = false;
+        const float *src = nullptr;      // host records the job copies / the copy in d_buf belongs to
+        int64_t floats = 0;
+        hipError_t err = hipSuccess;
+        float *d_buf = nullptr;
+        int64_t cap = 0;                 // floats
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+    } pf;
 
     // scan + per-point state
     int64_t n = 0, n_cap = 0;
@@ -419,6 +436,14 @@ int s2m_destroy(s2m_engine *e)
     if (!e) return S2M_ERR_ARG;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->pf.worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(e->pf.mu); e->pf.quit = true; }
+        e->pf.cv.notify_all();
+        e->pf.worker.join();
+    }
+    if (e->pf.stream) { (void)hipStreamSynchronize(e->pf.stream); (void)hipStreamDestroy(e->pf.stream); }
+    if (e->pf.done) (void)hipEventDestroy(e->pf.done);
+    if (e->pf.d_buf) (void)hipFree(e->pf.d_buf);
     free_map(e->map);
     free_update(e->upd);
     free_mailbox(e->mail);
@@ -828,6 +853,59 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride, int64_t n,
     return S2M_OK;
 }
 
+namespace {
+void prefetch_worker(s2m_engine *e)
+{
+    auto &p = e->pf;
+    (void)hipSetDevice(e->device);
+    std::unique_lock<std::mutex> lk(p.mu);
+    for (;;) {
+        p.cv.wait(lk, [&] { return p.quit || p.busy; });
+        if (p.quit) return;
+        const float *src = p.src;
+        const int64_t floats = p.floats;
+        lk.unlock();
+        hipError_t he = hipMemcpyAsync(p.d_buf, src, (size_t)floats * sizeof(float), hipMemcpyHostToDevice, p.stream);
+        if (he == hipSuccess) he = hipEventRecord(p.done, p.stream);
+        lk.lock();
+        p.err = he;
+        p.busy = false;
+        p.ready = he == hipSuccess;
+        p.cv.notify_all();
+    }
+}
+}  // namespace
+
+int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride, int64_t n)
+{
+    if (!e || n < 0 || stride < 3 || (n > 0 && !points)) return fail(e, S2M_ERR_ARG, "s2m_scan_prefetch_raw: bad argument");
+    if (n == 0) return S2M_OK;
+    S2M_HIP(e, hipSetDevice(e->device));
+    auto &p = e->pf;
+    const int64_t floats = n * stride;
+    {   // one job at a time: a prefetch that is still running finishes first
+        std::unique_lock<std::mutex> lk(p.mu);
+        p.cv.wait(lk, [&] { return !p.busy; });
+        p.ready = false;
+    }
+    if (!p.stream) S2M_HIP(e, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    if (!p.done) S2M_HIP(e, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+    if (floats > p.cap) {
+        S2M_HIP(e, hipStreamSynchronize(p.stream));
+        if (p.d_buf) S2M_HIP(e, hipFree(p.d_buf));
+        p.d_buf = nullptr;
+        S2M_HIP(e, hipMalloc((void **)&p.d_buf, (size_t)floats * sizeof(float)));
+        p.cap = floats;
+    }
+    if (!p.worker.joinable()) p.worker = std::thread(prefetch_worker, e);
+    {
+        std::lock_guard<std::mutex> lk(p.mu);
+        p.src = points; p.floats = floats; p.busy = true;
+    }
+    p.cv.notify_all();
+    return S2M_OK;
+}
+
 int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, int64_t n, int32_t oa, int32_t ob,
                           const s2m_imu_pose *poses, int32_t np, const double state_end[S2M_STATE_DOUBLES], float leaf,
                           int on_device, int64_t *n_out)
@@ -839,7 +917,22 @@ int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, in
     if (rc) return rc;
     if (n > 0) {
         const float *dev = points;
-        if (!on_device) {
+        bool prefetched = false;
+        if (!on_device && e->pf.worker.joinable()) {  // has s2m_scan_prefetch_raw brought exactly these records over already?
+            auto &p = e->pf;
+            std::unique_lock<std::mutex> lk(p.mu);
+            if (p.src == points && p.floats == n * stride && (p.busy || p.ready)) {
+                p.cv.wait(lk, [&] { return !p.busy; });
+                if (p.ready) {
+                    p.ready = false;  // consumed
+                    lk.unlock();
+                    S2M_HIP(e, hipStreamWaitEvent(e->stream, p.done, 0));
+                    dev = p.d_buf;
+                    prefetched = true;
+                }
+            }
+        }
+        if (!on_device && !prefetched) {
             const int64_t floats = n * stride;
             if (floats > e->stage_cap) {
                 rc = grow(e, &e->d_stage, floats);

@@ -212,6 +212,12 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride_floats, int
                   int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses,
                   const double state_end[S2M_STATE_DOUBLES], int sort_by_time, int on_device, float *out_xyz,
                   uint32_t *perm);
+/* The NEXT sweep's records on their way while the current one is registered (the reference's node receives the next
+ * message while it works, laserMapping.cpp:726-731): starts the host-to-device copy of `points` (host memory, n records
+ * of stride_floats floats) on a side stream, driven by a worker thread of the handle, and returns at once.  A following
+ * s2m_scan_set_from_raw with the SAME pointer, stride and n uses that copy instead of copying itself (any other call
+ * ignores it).  The caller keeps the buffer alive and unchanged until then.  (Design, not reference.) */
+int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride_floats, int64_t n);
 /* The node's front half of a frame kept on the device: undistort (time-sorted) -> VoxelGrid(leaf)
  * -> current scan (IMU_Processing.hpp:333-370, laserMapping.cpp:775-778).  leaf <= 0 skips the
  * down-sampling.  *n_out = feats_down_size. */

@@ -138,3 +138,41 @@ def test_gpu_undistort_matches_oracle(oracle):
     if m == len(ref_ds):
         assert np.abs(got_ds - ref_ds).max() < 1e-3
     e.close()
+
+
+@pytest.mark.gpu
+def test_prefetched_records_give_the_same_scan(oracle):
+    """s2m_scan_prefetch_raw: the next sweep's records copied to the device by the handle's worker thread on a side stream;
+    s2m_scan_set_from_raw with the same buffer uses that copy -- same scan, bit for bit, as when it copies itself; a call
+    with another buffer ignores the prefetch; prefetching twice in a row, or never consuming, is harmless."""
+    from daliti_amd import Engine, synth
+    sc = synth.make_small()
+    n = len(sc["scan"])
+    rs = np.random.RandomState(3)
+    rec = np.zeros((n, 12), np.float32)
+    rec[:, :3] = sc["scan"]
+    rec[:, 4] = rs.permutation(n).astype(np.float32) / n
+    rec[:, 6] = 0.1
+    other = rec.copy(); other[:, :3] += np.float32(0.25)
+    K = 12
+    poses = np.zeros((K, 22)); poses[:, 0] = np.linspace(0.0, 0.101, K); poses[:, 13:22] = np.eye(3).ravel()
+    poses[:, 1:4] = rs.normal(0, 0.3, (K, 3)); poses[:, 4:7] = rs.normal(0, 0.2, (K, 3)); poses[:, 7:10] = rs.normal(0, 0.5, (K, 3))
+    end = np.zeros(36); end[0:9] = np.eye(3).ravel(); end[12:21] = np.eye(3).ravel()
+    e = Engine()
+    e.map_build(sc["map"])
+    e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3)
+    plain = e.scan_get()
+    e.scan_set_from_raw(other, 4, 6, poses, end, 0.3)
+    plain_other = e.scan_get()
+    for _ in range(3):
+        e.scan_prefetch_raw(rec)
+        e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3)
+        assert (bits(e.scan_get()) == bits(plain)).all()
+    e.scan_prefetch_raw(rec)
+    e.scan_prefetch_raw(rec)                                   # a second request while (or after) the first one runs
+    e.scan_set_from_raw(other, 4, 6, poses, end, 0.3)          # another buffer: the prefetch is ignored ...
+    assert (bits(e.scan_get()) == bits(plain_other)).all()
+    e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3)            # ... and still there for the buffer it was made from
+    assert (bits(e.scan_get()) == bits(plain)).all()
+    e.scan_prefetch_raw(other)                                 # never consumed: close() must not hang
+    e.close()

@@ -98,7 +98,7 @@ int s2m_bench_loop_varying(s2m_engine *e, int32_t k, const float *const *scans_d
 int s2m_bench_frames(s2m_engine *e, int32_t frames, const float *records, int64_t stride_floats, int64_t n,
                      int32_t time_off_a, int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses,
                      const double *state_end, float leaf, const double *x_prop, const double *P0, double filter_size_map,
-                     double cube_len, double *x, double *frame_us, int32_t *merged)
+                     double cube_len, int32_t prefetch, double *x, double *frame_us, int32_t *merged)
 {
     if (!e || frames < 0 || !records || !poses || !state_end || !x_prop || !P0 || !x || !frame_us || !merged) return S2M_ERR_ARG;
     double P[S2M_DIM * S2M_DIM];
@@ -108,6 +108,10 @@ int s2m_bench_frames(s2m_engine *e, int32_t frames, const float *records, int64_
         int64_t n_out = 0, na = 0, nb = 0;
         int rc = s2m_scan_set_from_raw(e, records, stride_floats, n, time_off_a, time_off_b, poses, n_poses, state_end, leaf, 0, &n_out);
         if (rc) return rc;
+        if (prefetch && f + 1 < frames) {  // the next sweep's records cross PCIe while this one is registered
+            rc = s2m_scan_prefetch_raw(e, records, stride_floats, n);
+            if (rc) return rc;
+        }
         std::memcpy(x, x_prop, S2M_STATE_DOUBLES * sizeof(double));
         std::memcpy(P, P0, sizeof(P));
         rc = s2m_iterated_update(e, x, x_prop, P, &log);
