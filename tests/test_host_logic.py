@@ -48,6 +48,47 @@ def test_host_eskf_matches_oracle(oracle, small_scene, small_tree, tmp_path):
     assert float(f["worst_x"]) < 1e-12 and float(f["worst_solution_rel"]) < 1e-9 and float(f["worst_P_rel"]) < 1e-11, r.stdout
 
 
+def test_loop_algebra_matches_the_two_inverse_form(oracle, small_scene, small_tree, tmp_path):
+    """The device-resident loop evaluates the Kalman update in the matrix-inversion-lemma form (s2m_loop.h: one nc x nc
+    solve, G = P'U C^-1) instead of the reference's two 24x24 inverses (laserMapping.cpp:1017-1032, 1084-1085).  Its host
+    half (loop_prepare, loop_cov_update) and a restatement of the device wave's elimination, on the CPU under sanitizers,
+    against the oracle's literal form -- six columns (the shipped default) and twelve (extrinsic estimation); plus the
+    loop's own sin / cos / acos against the C library."""
+    exe = str(tmp_path / "loop_algebra_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fsanitize=address,undefined",
+                           "-fno-omit-frame-pointer", "-Wall", "-I", CSRC, os.path.join(ROOT, "tests", "loop_algebra_check.cpp"),
+                           os.path.join(CSRC, "s2m_eskf.cpp"), "-o", exe])
+    rs = np.random.RandomState(7)
+    x0 = small_scene["x_prop"]
+    for nc, ext in ((6, 0), (12, 1)):
+        cfg = oracle.default_cfg(extrinsic_est_en=ext)
+        ps = oracle.residual_pass(cfg, small_tree, small_scene["scan"], x0, True, oracle.PassState(len(small_scene["scan"])))
+        cases = []
+        for k in range(30):
+            scale = [1e-1, 1e-3, 1e-6][k % 3]
+            xc = oracle.boxplus(x0, rs.normal(0, 1, 24) * scale)
+            xp = oracle.boxplus(x0, rs.normal(0, 1, 24) * scale * 0.5)
+            A = rs.normal(0, 1, (24, 24))
+            P = small_scene["P"] + 1e-5 * (A @ A.T) * (k % 2 == 0)     # the bench's diagonal P and dense SPD ones
+            HtH = np.zeros((12, 12)); Htz = np.zeros(12)
+            if k % 5 == 4:
+                H = rs.normal(0, 1, (200, nc)); z = rs.normal(0, 0.05, 200)
+                HtH[:nc, :nc] = H.T @ H; Htz[:nc] = H.T @ z
+            else:
+                HtH[:nc, :nc] = ps.HtH[:nc, :nc] * (1.0 + 0.1 * k); Htz[:nc] = ps.Htz[:nc] * (1.0 + 0.1 * k)
+            x1, sol, K1, conv = oracle.eskf_update(cfg, xc, xp, P, HtH, Htz)
+            Pn = oracle.cov_update(K1, HtH, P)
+            cases.append(np.r_[xc, xp, P.ravel(), HtH.ravel(), Htz, x1, sol, float(conv), Pn.ravel()])
+        path = tmp_path / ("loop_cases_%d.bin" % nc)
+        path.write_bytes(np.ascontiguousarray(np.array(cases), np.float64).tobytes())
+        r = subprocess.run([exe, str(path), str(len(cases)), str(nc)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        f = dict(zip(r.stdout.split()[::2], r.stdout.split()[1::2]))
+        assert int(f["failed"]) == 0, r.stdout
+        assert float(f["worst_solution_rel"]) < 1e-9 and float(f["worst_P_rel"]) < 1e-10, r.stdout
+        assert max(float(f["trig_sin"]), float(f["trig_cos"])) < 3e-16 and float(f["trig_acos"]) < 1e-15, r.stdout
+
+
 def test_host_loop_control_matches_oracle(oracle, small_scene, small_tree, tmp_path):
     """s2m_iterctl.h (degeneracy queue, rematch judgement, exit test) replayed over the oracle's per-iteration
     (effct_feat_num, converged) sequences: same number of iterations, same rematch flags, same stop flag and queue."""
