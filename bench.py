@@ -116,6 +116,8 @@ def parse(argv=None):
     ap.add_argument("--py-loop", action="store_true",
                     help="drive the timed steps from Python (one ctypes call per step) instead of tools/bench_loop.cpp")
     ap.add_argument("--frames", type=int, default=64, help="frames of the frame_pipeline side leg")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="skip the two child rocprofv3 --pmc passes that measure roofline.traffic in this run")
     ap.add_argument("--device-loop", action="store_true",
                     help="A/B: the device-resident iteration loop (s2m_config.device_loop = 1) instead of the host-stepped one")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (0 = pick a free one)")
@@ -640,6 +642,15 @@ def main():
         ms = ms_match + ms_fit
         achieved = n0 * BYTES_REMATCH / (ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic() if (a.config == "C3" and single) else (None, None)
+        if a.config == "C3" and single and rank == 0 and not a.no_cpu and not a.no_side and not a.no_live_pmc:
+            live, why = live_pmc_traffic(a)     # this run's own counters; the committed profile's figure stays beside it
+            if live is not None:
+                static_traffic, traffic, traffic_src = traffic, live, why
+            else:
+                static_traffic = None
+                traffic_src = "%s [live counter pass unavailable: %s]" % (traffic_src, why)
+        else:
+            static_traffic = None
         out["roofline"] = {
             "kernel": "rematch pass = match_rows + match_hard (exact 5-NN on the brick grid) + reduce_kernel<FIT> "
                       "(neighbour gate, plane fit, residual, Jacobian row, normal block)",
@@ -647,6 +658,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_src,
+            "traffic_of_committed_profile": static_traffic,
             "algorithmic_bytes_per_eval": BYTES_REMATCH, "evals_per_launch": n0,
             "avg_launch_ms": ms, "launches": tstats["match_launches"],
             "search_kernels_only": {"avg_ms": ms_match, "achieved": n0 * BYTES_REMATCH / (ms_match * 1e-3) / 1e9,
@@ -1098,6 +1110,64 @@ def per_pass(k, name):
     """launches of kernel `name` per rematch pass (= per launch of match_rows) in the profiled run"""
     calls, rows = k[name].get("calls"), k["match_rows"].get("calls")
     return (calls / rows) if (calls and rows) else 1.0
+
+
+def live_pmc_traffic(a):
+    """Fabric traffic of one rematch pass MEASURED IN THIS RUN (a regression in fetched bytes must
+    show in the driver's line): two short child runs of this same bench under `rocprofv3 --kernel-trace --pmc` -- FETCH_SIZE
+    and WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes -- each bounded by a timeout; the children are
+    started as child processes (never an exec) with the program itself after `--`.  Returns (bytes per pass, label) or
+    (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    per_kernel = {}
+    tmp = tempfile.mkdtemp(prefix="s2m_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(key, None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable,
+                   os.path.abspath(__file__), "--config", a.config, "--steps", "12", "--warmup", "3", "--no-cpu", "--no-side",
+                   "--max-iter", str(a.max_iter)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s child failed (rc %d)" % (counter, r.returncode)
+            acc = {}
+            for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    name = row["Kernel_Name"]
+                    short = next((s for s in REMATCH_KERNELS if ("s2m::" + s) in name.replace("void ", "")), None)
+                    if short == "match_rows" and "match_rows_batch" in name:
+                        short = None
+                    if short:
+                        acc.setdefault(short, []).append(float(row["Counter_Value"]))
+            for s, v in acc.items():
+                per_kernel.setdefault(s, {})[counter] = (sum(v) / len(v), len(v))
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as ex:
+        return None, "live counter pass failed: %s" % type(ex).__name__
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    try:
+        rows = per_kernel["match_rows"]["FETCH_SIZE"][1]
+        tot = 0.0
+        for s in REMATCH_KERNELS:
+            fetch, calls = per_kernel[s]["FETCH_SIZE"]
+            write, _ = per_kernel[s]["WRITE_SIZE"]
+            tot += (2.0 * fetch + write) * 1024.0 * (calls / rows)
+    except (KeyError, ZeroDivisionError):
+        return None, "live counter pass: kernels of the rematch pass not found in the counter output"
+    return tot, ("measured in this run: two child passes of this bench under rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
+                 "WRITE_SIZE (12 steps each), kernels weighted by launches per rematch pass, read side x2 "
+                 "(MI355X_MICROARCH.md, gfx950)")
 
 
 def pmc_traffic():
