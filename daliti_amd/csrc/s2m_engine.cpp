@@ -660,12 +660,14 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
         int rc = s2m_complete_neighbors(e, nullptr);
         if (rc) return rc;
     }
+    VoxBox vox;
     S2M_HIP(e, incr_classify(e->upd, pose, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, (int)e->n,
-                             e->d_nn_idx, e->grid, e->nn_valid && ekf_inited != 0, filter_size_map, &la, &na, &lb, &nb, e->stream));
+                             e->d_nn_idx, e->grid, e->nn_valid && ekf_inited != 0, filter_size_map, &la, &na, &lb, &nb, e->stream,
+                             &vox));
     if (n_to_add) *n_to_add = na;
     if (n_no_downsample) *n_no_downsample = nb;
     S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
-    S2M_HIP(e, update_add(e->upd, e->grid, la, na, true, (float)filter_size_map, nullptr, e->stream));   // :627
+    S2M_HIP(e, update_add(e->upd, e->grid, la, na, true, (float)filter_size_map, nullptr, e->stream, &vox));   // :627
     S2M_HIP(e, update_add(e->upd, e->grid, lb, nb, false, 0.0f, nullptr, e->stream));                    // :628
     return commit_update(e);
 }

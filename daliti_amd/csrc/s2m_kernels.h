@@ -116,16 +116,22 @@ struct UpdateBuffers {
     int64_t cvt_cap = 0;
     Mailbox mail;
 };
+// box of voxels (edge = the down-sampling size) that holds every point of a batch: lets the sort that groups the batch by voxel
+// use a linear index of `bits` bits instead of the 63-bit packed key; bits == 0: not available (use the packed key)
+struct VoxBox {
+    int lo[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+    int bits = 0;
+};
 void free_update(UpdateBuffers &u);
 hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st);
 hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t n, bool downsample, float ds,
-                      int64_t *n_added, hipStream_t st);
+                      int64_t *n_added, hipStream_t st, const VoxBox *vox = nullptr);
 hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_host, int nb, int64_t *n_deleted,
                          hipStream_t st);
 hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStream_t st);
 hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, const float *sy, const float *sz, int n,
                          const int32_t *nn_idx, const Grid &g, bool have_nn, double fs, float4 **to_add, int64_t *n_add,
-                         float4 **no_down, int64_t *n_no_down, hipStream_t st);
+                         float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox = nullptr);
 hipError_t xyz_to_float4(UpdateBuffers &u, const float *xyz_dev, int64_t stride, int64_t n, float4 **out, hipStream_t st);
 // the map in CALLER order as packed xyz (ikdtree.flatten's counterpart): xyz[3 * pidx[j]] = pts[j]
 void launch_map_to_xyz(const float4 *pts, const uint32_t *pidx, int64_t m, float *xyz, hipStream_t st);

@@ -509,10 +509,11 @@ hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, Ma
 // instead of a gather from a 20 MB array)
 __global__ __launch_bounds__(256) void dead_words_kernel(int64_t m, const uint8_t *__restrict__ alive,
                                                          unsigned long long *__restrict__ word, uint32_t *__restrict__ cnt,
-                                                         uint32_t *__restrict__ outside_flag)
+                                                         uint32_t *__restrict__ outside_flag, uint32_t *__restrict__ announce)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { cnt[(m + 63) >> 6] = 0u; *outside_flag = 0u; }  // the scan's spare element; merge_newkey_kernel's flag
+    if (i <= m) announce[i] = 0u;  // the new points' announcements among the old keys start from zero (was a 4 (m + 1)-byte memset)
     const bool dead = i < m && alive[i] == 0;
     const unsigned long long w = __ballot(dead);
     if ((threadIdx.x & 63) == 0 && (i >> 6) <= ((m - 1) >> 6)) {
@@ -660,14 +661,13 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     }
 
     // dead rank over the caller indices (element `words` of the counts is zero: the prefix there is the total)
-    hipLaunchKernelGGL(dead_words_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, alive, buf.dword, dcnt,
-                       buf.counters + 8);
+    hipLaunchKernelGGL(dead_words_kernel, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, st, m, alive, buf.dword, dcnt,
+                       buf.counters + 8, c);
     size_t t = buf.sort_tmp_bytes;
     S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
     uint32_t dead = 0, outside = 0;
     hipLaunchKernelGGL(dead_pack_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, words, buf.dword, dprefix, rank);
-    // announcements of the new points among the old keys
-    S2M_TRY(hipMemsetAsync(c, 0, (size_t)(m + 1) * sizeof(uint32_t), st));
+    // announcements of the new points among the old keys (c was zeroed by dead_words_kernel)
     uint64_t *nk_sorted = buf.mk;
     uint32_t *nv_sorted = buf.mv, *lb = buf.mv + n_new;
     if (n > 0) {

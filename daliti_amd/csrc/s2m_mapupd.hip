@@ -70,6 +70,14 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, const float
     d = d + (az - b[2]) * (az - b[2]);
     return d;
 }
+// the same voxel as a LINEAR index over a box of voxels known to hold every point of the batch (VoxBox, s2m_kernels.h):
+// the sort that groups a batch by voxel then runs over `bits` instead of 63 bits (five launches less per scan)
+__device__ __forceinline__ bool voxel_in_box(float x, float y, float z, float ds, const VoxBox &b, uint64_t &lin)
+{
+    const int64_t kx = (int64_t)floorf(x / ds) - b.lo[0], ky = (int64_t)floorf(y / ds) - b.lo[1], kz = (int64_t)floorf(z / ds) - b.lo[2];
+    lin = ((uint64_t)kz * (uint64_t)b.d[1] + (uint64_t)ky) * (uint64_t)b.d[0] + (uint64_t)kx;
+    return kx >= 0 && kx < b.d[0] && ky >= 0 && ky < b.d[1] && kz >= 0 && kz < b.d[2];
+}
 __device__ __forceinline__ uint64_t voxel_key(float x, float y, float z, float ds)
 {
     // 21 bits per axis of floor(p / ds), biased; identical floor() to the one that makes the box
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256) void add_probe_kernel(Grid g, const float4 *__
                                                         uint64_t *__restrict__ key, uint32_t *__restrict__ val,
                                                         float *__restrict__ dnew, uint32_t *__restrict__ cnt,
                                                         uint32_t *__restrict__ best_idx, uint32_t *__restrict__ best_pos,
-                                                        float *__restrict__ best_d)
+                                                        float *__restrict__ best_d, uint32_t *__restrict__ add_flag, VoxBox vb)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = tid / kBoxLanes;
@@ -150,8 +158,11 @@ __global__ __launch_bounds__(256) void add_probe_kernel(Grid g, const float4 *__
         if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; bp = op; }
     }
     if (!live || sub != 0) return;
-    key[i] = voxel_key(p.x, p.y, p.z, ds);
+    uint64_t lin = 0;
+    if (vb.bits > 0) (void)voxel_in_box(p.x, p.y, p.z, ds, vb, lin);  // (the caller has made sure every point is inside)
+    key[i] = vb.bits > 0 ? lin : voxel_key(p.x, p.y, p.z, ds);
     val[i] = (uint32_t)i;
+    add_flag[i] = 0u;  // set by add_resolve_kernel for the winners (was a memset of its own)
     dnew[i] = dist2(p.x, p.y, p.z, v.mid);
     cnt[i] = c;
     best_idx[i] = bi;
@@ -285,9 +296,11 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
                                                             const int32_t *__restrict__ nn_idx,
                                                             const float4 *__restrict__ pts, int have_nn, double fs,
                                                             float4 *__restrict__ pw_out,
-                                                            unsigned long long *__restrict__ cls_out)
+                                                            unsigned long long *__restrict__ cls_out, VoxBox vb,
+                                                            uint32_t *__restrict__ vox_outside)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && vb.bits == 0) *vox_outside = 1u;
     if (i >= n) return;
     float wx, wy, wz;
     body_to_world(pose, sx[i], sy[i], sz[i], wx, wy, wz);  // pointBodyToWorld, :591
@@ -320,6 +333,10 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
     }
     // both list flags in one word (low half: PointToAdd, high half: PointNoNeedDownsample): one scan gives both positions
     cls_out[i] = cls == 1 ? 1ull : (cls == 2 ? (1ull << 32) : 0ull);
+    if (cls == 1 && vb.bits > 0) {  // PointToAdd goes through the voxel rule: does its voxel lie in the box the short key covers?
+        uint64_t lin;
+        if (!voxel_in_box(wx, wy, wz, (float)fs, vb, lin)) *vox_outside = 1u;
+    }
 }
 
 // list A (low halves) and list B (high halves) of the packed flags / positions
@@ -495,21 +512,58 @@ static hipError_t count_flags(UpdateBuffers &u, const uint32_t *flag, const uint
     return hipSuccess;
 }
 
+// every old point alive (both orders), the update's counters zero: one launch (three memsets are six on this stack)
+__global__ __launch_bounds__(256) void update_reset_kernel(int64_t bytes, uint8_t *__restrict__ alive, uint8_t *__restrict__ alive_s,
+                                                           uint32_t *__restrict__ counters)
+{
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0u;
+    if (i + 16 <= bytes) {
+        const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+        *reinterpret_cast<uint4 *>(alive + i) = ones;
+        *reinterpret_cast<uint4 *>(alive_s + i) = ones;
+    } else {
+        for (int64_t k = i; k < bytes; ++k) { alive[k] = 1; alive_s[k] = 1; }
+    }
+}
+
 hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st)
 {
     S2M_TRY(grow(&u.alive, &u.alive_cap, g.m + 1));
     S2M_TRY(grow(&u.alive_s, &u.alive_s_cap, g.m + 1));
     if (!u.counters) S2M_TRY(hipMalloc((void **)&u.counters, 64));
-    S2M_TRY(hipMemsetAsync(u.alive, 1, (size_t)g.m + 1, st));
-    S2M_TRY(hipMemsetAsync(u.alive_s, 1, (size_t)g.m + 1, st));
-    S2M_TRY(hipMemsetAsync(u.counters, 0, 64, st));
+    {
+        const int64_t bytes = g.m + 1;
+        hipLaunchKernelGGL(update_reset_kernel, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, st, bytes, u.alive, u.alive_s,
+                           u.counters);
+    }
     u.stage_n = 0;
     u.deleted_reported = 0;
     return hipSuccess;
 }
 
+// the voxels (edge ds) that can hold a point of the grid's box, two to spare on every side; bits = 0 when that is no use
+VoxBox vox_box_of(const Grid &g, float ds)
+{
+    VoxBox b{};
+    const float o[3] = {g.ox, g.oy, g.oz};
+    const int nc[3] = {g.ncx, g.ncy, g.ncz};
+    double prod = 1.0;
+    for (int k = 0; k < 3; ++k) {
+        const double lo = std::floor((double)o[k] / ds) - 2.0, hi = std::floor(((double)o[k] + (double)nc[k] * g.c) / ds) + 2.0;
+        if (!(hi - lo < 2.0e6) || !(std::fabs(lo) < 1.0e9)) return VoxBox{};
+        b.lo[k] = (int)lo;
+        b.d[k] = (int)(hi - lo + 1.0);
+        prod *= (double)b.d[k];
+    }
+    if (prod >= 1.0e12) return VoxBox{};
+    b.bits = 1;
+    while (((uint64_t)1 << b.bits) < (uint64_t)prod) ++b.bits;
+    return b;
+}
+
 hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t n, bool downsample, float ds,
-                      int64_t *n_added, hipStream_t st)
+                      int64_t *n_added, hipStream_t st, const VoxBox *vox)
 {
     if (n_added) *n_added = 0;
     if (n <= 0) return hipSuccess;
@@ -537,13 +591,13 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
     }
     const int in = (int)n;
     hipLaunchKernelGGL(add_probe_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, u.key, u.val, u.dnew, u.cnt,
-                       u.best_idx, u.best_pos, u.best_d);
+                       u.best_idx, u.best_pos, u.best_d, u.add_flag, vox ? *vox : VoxBox{});
+    const unsigned kbits = (vox && vox->bits > 0) ? (unsigned)vox->bits : 63u;
     size_t bytes = 0;
-    S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 63, st));
+    S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, u.key, u.key2, u.val, u.val2, (size_t)n, 0, kbits, st));
     S2M_TRY(ensure_tmp(u, bytes));
     size_t b2 = u.tmp_bytes;
-    S2M_TRY(rocprim::radix_sort_pairs(u.tmp, b2, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 63, st));
-    S2M_TRY(hipMemsetAsync(u.add_flag, 0, (size_t)n * sizeof(uint32_t), st));
+    S2M_TRY(rocprim::radix_sort_pairs(u.tmp, b2, u.key, u.key2, u.val, u.val2, (size_t)n, 0, kbits, st));
     uint32_t before = 0;
     if (n_added) {  // tmp_counter of Add_Points before this batch (zero unless several batches share one update)
         const uint32_t *src[1] = {u.counters + 1};
@@ -608,8 +662,9 @@ hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStr
 
 hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, const float *sy, const float *sz, int n,
                          const int32_t *nn_idx, const Grid &g, bool have_nn, double fs, float4 **to_add, int64_t *n_add,
-                         float4 **no_down, int64_t *n_no_down, hipStream_t st)
+                         float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox)
 {
+    if (vox) *vox = VoxBox{};
     *n_add = 0;
     *n_no_down = 0;
     *to_add = nullptr;
@@ -634,8 +689,13 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
     }
     float4 *pw = u.cvt, *la = u.cvt + n, *lb = u.cvt + 2 * (int64_t)n;
     unsigned long long *fl = reinterpret_cast<unsigned long long *>(u.key), *ps = reinterpret_cast<unsigned long long *>(u.key2);
+    const VoxBox vb = vox ? vox_box_of(g, (float)fs) : VoxBox{};
+    if (!u.counters) {  // (word 15 is this call's flag: zero here, and zeroed again by every update_begin behind the read-back)
+        S2M_TRY(hipMalloc((void **)&u.counters, 64));
+        S2M_TRY(hipMemsetAsync(u.counters, 0, 64, st));
+    }
     hipLaunchKernelGGL(incr_classify_kernel, dim3(nblk(n)), dim3(256), 0, st, pose, sx, sy, sz, n, nn_idx, g.pts,
-                       have_nn ? 1 : 0, fs, pw, fl);
+                       have_nn ? 1 : 0, fs, pw, fl, vb, u.counters + 15);
     {
         size_t bytes = 0;
         S2M_TRY(rocprim::exclusive_scan(nullptr, bytes, fl, ps, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), st));
@@ -646,11 +706,12 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
     hipLaunchKernelGGL(scatter2_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fl, ps, (int64_t)n, la, lb);
     {   // both list lengths with one hand-back: last position + last flag, as four 32-bit words
         const uint32_t *p32 = reinterpret_cast<const uint32_t *>(ps + (n - 1)), *f32 = reinterpret_cast<const uint32_t *>(fl + (n - 1));
-        const uint32_t *src[4] = {p32, f32, p32 + 1, f32 + 1};
-        uint32_t h[4] = {0, 0, 0, 0};
-        S2M_TRY(mail_fetch(u.mail, src, 4, h, st));
+        const uint32_t *src[5] = {p32, f32, p32 + 1, f32 + 1, u.counters + 15};
+        uint32_t h[5] = {0, 0, 0, 0, 1};
+        S2M_TRY(mail_fetch(u.mail, src, 5, h, st));
         *n_add = (int64_t)h[0] + h[1];
         *n_no_down = (int64_t)h[2] + h[3];
+        if (vox && h[4] == 0u) *vox = vb;   // every PointToAdd lies in the box: the voxel sort can use the short key
     }
     *to_add = la;
     *no_down = lb;
