@@ -38,7 +38,7 @@ extern "C" {
 #define S2M_K 5            /* NUM_MATCH_POINTS, laserMapping.cpp:77 */
 #define S2M_DIM 24         /* DIM_OF_STATES, common_lib.h:23 */
 #define S2M_STATE_DOUBLES 36
-#define S2M_BLOCK_DOUBLES 160 /* HtH[144] Htz[12] effct total_res far_points pad */
+#define S2M_BLOCK_DOUBLES 160 /* HtH[144] Htz[12] effct total_res far_points short_lists */
 #define S2M_FEAT_QUEUE 10  /* QUEUE_SIZE, laserMapping.cpp:192 */
 
 enum {
