@@ -1021,42 +1021,53 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
     P0_c = np.ascontiguousarray(P0, np.float64)
     x_out = np.zeros(36)
     frame_us = np.zeros(max(frames, 1))
+    pose_us = np.zeros(max(frames, 1))
     merged = np.zeros(max(frames, 1), np.int32)
     def run_frames(prefetch):
         rc = fn(eng.h, C.c_int32(frames), C.c_void_p(recs.ctypes.data), C.c_int64(recs.shape[1]), C.c_int64(recs.shape[0]),
                 C.c_int32(4), C.c_int32(6), C.c_void_p(pos_c.ctypes.data), C.c_int32(len(pos_c)), C.c_void_p(end_c.ctypes.data),
                 C.c_float(leaf), C.c_void_p(xp_c.ctypes.data), C.c_void_p(P0_c.ctypes.data), C.c_double(0.5), C.c_double(1000.0),
-                C.c_int32(prefetch), C.c_void_p(x_out.ctypes.data), C.c_void_p(frame_us.ctypes.data), C.c_void_p(merged.ctypes.data))
+                C.c_int32(prefetch), C.c_void_p(x_out.ctypes.data), C.c_void_p(frame_us.ctypes.data), C.c_void_p(merged.ctypes.data),
+                C.c_void_p(pose_us.ctypes.data))
         if rc != 0:
             raise RuntimeError("s2m_bench_frames failed: %d (%s)" % (rc, eng.lib.s2m_last_error(eng.h).decode()))
         torch.cuda.synchronize()
-    # first without the prefetch (every frame's 3 MB of records cross PCIe inside s2m_scan_set_from_raw), then -- the figures
-    # reported -- with s2m_scan_prefetch_raw: the next sweep's records travel while the current one is registered
+    # three forms of the same frames: every frame on its own (3 MB of records cross PCIe inside s2m_scan_set_from_raw); with
+    # s2m_scan_prefetch_raw (the next sweep's records travel while the current one is registered); and -- the figures
+    # reported -- with s2m_scan_prepare_raw: the next frame's copy, undistortion and voxel grid run on the handle's side
+    # stream beside this frame's map update (a node that replays or catches up; the scans and poses are bit-identical,
+    # tests/test_undistort.py)
     run_frames(0)
     med_no_prefetch = float(np.median(frame_us[:frames] * 1e-3))
-    st0 = eng.map_update_stats()
+    pose_latency = float(np.median(pose_us[:frames] * 1e-3))
     eng.scan_prefetch_raw(recs)   # the side stream, its buffer and the worker thread exist before the timed frames
     run_frames(1)
+    med_prefetch = float(np.median(frame_us[:frames] * 1e-3))
+    st0 = eng.map_update_stats()
+    run_frames(2)
     st1 = eng.map_update_stats()
     per = frame_us[:frames] * 1e-3
     how = [bool(v) for v in merged[:frames]]
     med = float(np.median(per))
     worst = int(np.argmax(per))
+    sys.stderr.write("[bench] frame leg: first frames %s ms; sorted tail %s ms\n" % (
+        " ".join("%.3f" % v for v in per[:6]), " ".join("%.3f" % v for v in np.sort(per)[-6:])))
     sys.stderr.write("[bench] frame leg: %d frames back to back, median %.3f p99 %.3f max %.3f ms (frame %d, %s)\n" % (
         frames, med, float(np.percentile(per, 99)), float(per.max()), worst, "merged" if how[worst] else "rebuilt"))
     return {"ms_per_frame": float(w.sum()), "frames_per_s": float(1e3 / w.sum()),
             "ms_per_frame_back_to_back": med, "frames_per_s_back_to_back": float(1e3 / med),
-            "median_ms": med, "median_ms_without_prefetch": med_no_prefetch,
+            "median_ms": med, "median_ms_without_prefetch": med_no_prefetch, "median_ms_prefetch_only": med_prefetch,
+            "pose_latency_ms": pose_latency, "pipelining": "s2m_scan_prepare_raw: frame k+1's front half beside frame k's map update",
             "p99_ms": float(np.percentile(per, 99)), "max_ms": float(per.max()),
             "max_over_median": float(per.max() / med), "worst_frame": worst,
-            "frames_back_to_back": int(frames),
+            "frames_back_to_back": int(frames), "untimed_warmup_frames": 2,
             "updates": {k: int(st1[k] - st0[k]) for k in st1},
             "bets": dict(zip(("won", "lost"), eng.bet_stats())),
             "rebuilt_frames": [i for i, m in enumerate(how) if not m],
             "stages_ms": {"raw_to_scan": float(w[0]), "iterated_update": float(w[1]), "map_incremental": float(w[2]),
                           "fov_segment": float(w[3])},
             "scan_points_raw": int(n), "scan_points_after_voxel_grid": int(nd), "map_points": int(eng.map_size()),
-            "note": "host-timed, one frame in flight, host input (3 MB of records cross PCIe in raw_to_scan); the staged "
+            "note": "host-timed, host input (3 MB of records cross PCIe in raw_to_scan); pose_latency_ms = records in -> pose out of a frame on its own (no prefetch); the staged "
                     "frames (stages_ms, ms_per_frame) are Python calls with a device sync after every stage, the back-to-back "
                     "frames one C++ loop (tools/bench_loop.cpp, s2m_bench_frames); not part of `value`; `updates` counts how the map updates of the back-to-back frames were "
                     "produced (merged into the grid / rebuilt / re-gridded) and how often a device buffer grew"}

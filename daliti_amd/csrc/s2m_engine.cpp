@@ -83,7 +83,17 @@ struct s2m_engine {
         int64_t cap = 0;                 // floats
         hipStream_t stream = nullptr;
         hipEvent_t done = nullptr;
+        // s2m_scan_prepare_raw: the job also undistorts and down-samples into the spare scan arrays (d_scan_alt) on
+        // the side stream; what it was asked for is kept so that s2m_scan_set_from_raw can recognise the same call
+        bool prepare = false, prepared = false;
+        int64_t stride = 0, n = 0, m = 0;
+        int32_t oa = 0, ob = 0;
+        float leaf = 0.0f;
+        std::vector<double> poses;       // 22 doubles per pose
+        double state_end[S2M_STATE_DOUBLES] = {0};
     } pf;
+    float *d_scan_alt = nullptr;  // sx | sy | sz of the scan being prepared, laid out like d_scan (same n_cap)
+    int64_t scan_alt_cap = 0;     // the n_cap it was allocated for
 
     // scan + per-point state
     int64_t n = 0, n_cap = 0;
@@ -444,6 +454,7 @@ int s2m_destroy(s2m_engine *e)
     if (e->pf.stream) { (void)hipStreamSynchronize(e->pf.stream); (void)hipStreamDestroy(e->pf.stream); }
     if (e->pf.done) (void)hipEventDestroy(e->pf.done);
     if (e->pf.d_buf) (void)hipFree(e->pf.d_buf);
+    if (e->d_scan_alt) (void)hipFree(e->d_scan_alt);
     free_map(e->map);
     free_update(e->upd);
     free_mailbox(e->mail);
@@ -663,10 +674,9 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     VoxBox vox;
     S2M_HIP(e, incr_classify(e->upd, pose, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, (int)e->n,
                              e->d_nn_idx, e->grid, e->nn_valid && ekf_inited != 0, filter_size_map, &la, &na, &lb, &nb, e->stream,
-                             &vox));
+                             &vox, true));   // (update_begin runs inside, while the counts travel to the host)
     if (n_to_add) *n_to_add = na;
     if (n_no_downsample) *n_no_downsample = nb;
-    S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
     S2M_HIP(e, update_add(e->upd, e->grid, la, na, true, (float)filter_size_map, nullptr, e->stream, &vox));   // :627
     S2M_HIP(e, update_add(e->upd, e->grid, lb, nb, false, 0.0f, nullptr, e->stream));                    // :628
     return commit_update(e);
@@ -726,9 +736,12 @@ int s2m_map_info(const s2m_engine *ce, double info[8])
 }
 
 namespace {
+void pf_drain(s2m_engine *e);  // the side thread (s2m_scan_prefetch_raw / s2m_scan_prepare_raw) is idle
+
 int scan_reserve(s2m_engine *e, int64_t n)
 {
     if (n <= e->n_cap && e->n_cap > 0) return S2M_OK;
+    pf_drain(e);  // (a prepared scan was laid out for the old capacity: it is recognised as stale when it is picked up)
     const int64_t cap = ((std::max<int64_t>(n, 1) + 255) / 256) * 256;  // an empty first scan still gets buffers
     int rc = 0;
     rc = rc ? rc : grow(e, &e->d_scan, 3 * cap);
@@ -751,10 +764,10 @@ int scan_reserve(s2m_engine *e, int64_t n)
 }
 
 // point_selected_surf(feats_down_size, true) (:812); neighbours invalid until the first rematch
-int scan_reset(s2m_engine *e, int64_t n)
+int scan_reset(s2m_engine *e, int64_t n, bool wait = true)
 {
     launch_scan_reset(n, e->d_sel, e->d_eff, e->d_flags, e->stream);
-    S2M_HIP(e, mail_wait(e->mail, e->stream));  // the host buffer may be reused by the caller now
+    if (wait) S2M_HIP(e, mail_wait(e->mail, e->stream));  // the host buffer may be reused by the caller now
     e->n = n;
     e->scan_ready = true;
     e->pass_done = false;
@@ -783,6 +796,7 @@ int s2m_scan_set_downsampled(s2m_engine *e, const float *xyz, int64_t stride, in
     if (!e || n < 0 || stride < 3 || (n > 0 && !xyz) || !(leaf > 0.0f)) return fail(e, S2M_ERR_ARG, "s2m_scan_set_downsampled: bad argument");
     if (n > (int64_t)1 << 28) return fail(e, S2M_ERR_CAPACITY, "scan too large");
     S2M_HIP(e, hipSetDevice(e->device));
+    pf_drain(e);  // the voxel-grid buffers are shared with the side thread
     int rc = scan_reserve(e, n);  // the output cannot be larger than the input
     if (rc) return rc;
     const float *dev = nullptr;
@@ -819,6 +833,7 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride, int64_t n,
     if (n > 0 && !out_xyz) return fail(e, S2M_ERR_ARG, "undistort: null output");
     if (n == 0) return S2M_OK;
     S2M_HIP(e, hipSetDevice(e->device));
+    pf_drain(e);  // the undistortion buffers are shared with the side thread
     const float *dev = nullptr;
     // stage whole records (the time fields may sit anywhere in the record)
     if (on_device) {
@@ -856,6 +871,10 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride, int64_t n,
 }
 
 namespace {
+// The side thread of a handle: brings the next sweep's records over (s2m_scan_prefetch_raw) and, when asked
+// (s2m_scan_prepare_raw), also undistorts and down-samples them into the spare scan arrays -- on its own stream, with the
+// undistortion / voxel-grid buffers and mailboxes the main thread only touches through the scan_set entry points, which
+// wait for this thread first (pf_drain).
 void prefetch_worker(s2m_engine *e)
 {
     auto &p = e->pf;
@@ -866,30 +885,49 @@ void prefetch_worker(s2m_engine *e)
         if (p.quit) return;
         const float *src = p.src;
         const int64_t floats = p.floats;
+        const bool prepare = p.prepare;
         lk.unlock();
         hipError_t he = hipMemcpyAsync(p.d_buf, src, (size_t)floats * sizeof(float), hipMemcpyHostToDevice, p.stream);
+        int64_t m = p.n;
+        bool ok = he == hipSuccess;
+        if (ok && prepare) {
+            he = undistort(e->und, p.d_buf, p.stride, p.n, p.oa, p.ob, p.poses.data(), (int)(p.poses.size() / 22), pose_of(p.state_end),
+                           true, nullptr, p.stream);
+            ok = he == hipSuccess;
+            float *sx = e->d_scan_alt, *sy = e->d_scan_alt + e->scan_alt_cap, *sz = e->d_scan_alt + 2 * e->scan_alt_cap;
+            if (ok && p.leaf > 0.0f) {
+                bool too_fine = false;
+                he = voxel_downsample(e->vox, e->und.out, 3, p.n, p.leaf, sx, sy, sz, &m, &too_fine, p.stream);
+                ok = he == hipSuccess && !too_fine;  // a refusal is reported by the synchronous path, which runs instead
+            } else if (ok) {
+                launch_deinterleave(e->und.out, 3, p.n, sx, sy, sz, p.stream);
+            }
+        }
         if (he == hipSuccess) he = hipEventRecord(p.done, p.stream);
         lk.lock();
         p.err = he;
+        p.m = m;
         p.busy = false;
-        p.ready = he == hipSuccess;
+        p.ready = he == hipSuccess && !prepare;
+        p.prepared = ok && he == hipSuccess && prepare;
         p.cv.notify_all();
     }
 }
-}  // namespace
 
-int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride, int64_t n)
+// the side thread is idle (its buffers may be used / reallocated by the caller)
+void pf_drain(s2m_engine *e)
 {
-    if (!e || n < 0 || stride < 3 || (n > 0 && !points)) return fail(e, S2M_ERR_ARG, "s2m_scan_prefetch_raw: bad argument");
-    if (n == 0) return S2M_OK;
-    S2M_HIP(e, hipSetDevice(e->device));
+    if (!e->pf.worker.joinable()) return;
+    std::unique_lock<std::mutex> lk(e->pf.mu);
+    e->pf.cv.wait(lk, [&] { return !e->pf.busy; });
+}
+
+int pf_start(s2m_engine *e, const float *points, int64_t floats)
+{
     auto &p = e->pf;
-    const int64_t floats = n * stride;
-    {   // one job at a time: a prefetch that is still running finishes first
-        std::unique_lock<std::mutex> lk(p.mu);
-        p.cv.wait(lk, [&] { return !p.busy; });
-        p.ready = false;
-    }
+    pf_drain(e);
+    p.ready = false;
+    p.prepared = false;
     if (!p.stream) S2M_HIP(e, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     if (!p.done) S2M_HIP(e, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     if (floats > p.cap) {
@@ -900,9 +938,55 @@ int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride, in
         p.cap = floats;
     }
     if (!p.worker.joinable()) p.worker = std::thread(prefetch_worker, e);
+    p.src = points;
+    p.floats = floats;
+    return S2M_OK;
+}
+}  // namespace
+
+int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride, int64_t n)
+{
+    if (!e || n < 0 || stride < 3 || (n > 0 && !points)) return fail(e, S2M_ERR_ARG, "s2m_scan_prefetch_raw: bad argument");
+    if (n == 0) return S2M_OK;
+    S2M_HIP(e, hipSetDevice(e->device));
+    int rc = pf_start(e, points, n * stride);
+    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lk(e->pf.mu);
+        e->pf.prepare = false;
+        e->pf.busy = true;
+    }
+    e->pf.cv.notify_all();
+    return S2M_OK;
+}
+
+int s2m_scan_prepare_raw(s2m_engine *e, const float *points, int64_t stride, int64_t n, int32_t oa, int32_t ob,
+                         const s2m_imu_pose *poses, int32_t np, const double state_end[S2M_STATE_DOUBLES], float leaf)
+{
+    int rc = check_undistort_args(e, points, stride, n, oa, ob, poses, np, state_end);
+    if (rc) return rc;
+    if (n == 0) return S2M_OK;
+    S2M_HIP(e, hipSetDevice(e->device));
+    // the prepared scan must fit the arrays of the current one (they are swapped, not copied); a first or larger sweep is
+    // left to the synchronous call
+    if (e->n_cap < n) return S2M_OK;
+    rc = pf_start(e, points, n * stride);
+    if (rc) return rc;
+    if (e->scan_alt_cap != e->n_cap) {
+        if (e->d_scan_alt) S2M_HIP(e, hipFree(e->d_scan_alt));
+        e->d_scan_alt = nullptr;
+        e->scan_alt_cap = 0;
+        S2M_HIP(e, hipMalloc((void **)&e->d_scan_alt, (size_t)3 * e->n_cap * sizeof(float)));
+        e->scan_alt_cap = e->n_cap;
+    }
+    auto &p = e->pf;
+    p.stride = stride; p.n = n; p.oa = oa; p.ob = ob; p.leaf = leaf;
+    p.poses.assign(reinterpret_cast<const double *>(poses), reinterpret_cast<const double *>(poses) + (size_t)np * 22);
+    std::memcpy(p.state_end, state_end, sizeof(p.state_end));
     {
         std::lock_guard<std::mutex> lk(p.mu);
-        p.src = points; p.floats = floats; p.busy = true;
+        p.prepare = true;
+        p.busy = true;
     }
     p.cv.notify_all();
     return S2M_OK;
@@ -915,6 +999,20 @@ int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, in
     int rc = check_undistort_args(e, points, stride, n, oa, ob, poses, np, state_end);
     if (rc) return rc;
     S2M_HIP(e, hipSetDevice(e->device));
+    pf_drain(e);
+    if (n > 0 && !on_device && e->pf.prepared) {  // has s2m_scan_prepare_raw done exactly this call already?
+        auto &p = e->pf;
+        const bool same = p.src == points && p.stride == stride && p.n == n && p.oa == oa && p.ob == ob && p.leaf == leaf &&
+                          p.poses.size() == (size_t)np * 22 && std::memcmp(p.poses.data(), poses, p.poses.size() * sizeof(double)) == 0 &&
+                          std::memcmp(p.state_end, state_end, sizeof(p.state_end)) == 0 && e->scan_alt_cap == e->n_cap && p.m <= e->n_cap;
+        p.prepared = false;  // consumed or stale
+        if (same) {
+            S2M_HIP(e, hipStreamWaitEvent(e->stream, p.done, 0));
+            std::swap(e->d_scan, e->d_scan_alt);
+            if (n_out) *n_out = p.m;
+            return scan_reset(e, p.m, false);  // no host buffer is in flight: nothing to wait for
+        }
+    }
     rc = scan_reserve(e, n);
     if (rc) return rc;
     if (n > 0) {

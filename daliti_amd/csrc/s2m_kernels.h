@@ -22,6 +22,8 @@ void free_mailbox(Mailbox &mb);
 // stream before it -- has finished (the host polls the pinned sequence word instead of synchronising the stream)
 hipError_t mail_fetch(Mailbox &mb, const uint32_t *const *src, int k, uint32_t *out, hipStream_t st);
 // the same wait without a payload: returns when everything queued on the stream has finished
+hipError_t mail_post(Mailbox &mb, const uint32_t *const *src, int k, hipStream_t st);   // the two halves of mail_fetch
+hipError_t mail_collect(Mailbox &mb, int k, uint32_t *out, hipStream_t st);
 hipError_t mail_wait(Mailbox &mb, hipStream_t st);
 
 // ---- s2m_map.hip : map build (KD_TREE::Build, ikd-Tree/ikd_Tree.cpp:408-423) -------------------
@@ -131,7 +133,7 @@ hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_hos
 hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStream_t st);
 hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, const float *sy, const float *sz, int n,
                          const int32_t *nn_idx, const Grid &g, bool have_nn, double fs, float4 **to_add, int64_t *n_add,
-                         float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox = nullptr);
+                         float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox = nullptr, bool begin_update = false);
 hipError_t xyz_to_float4(UpdateBuffers &u, const float *xyz_dev, int64_t stride, int64_t n, float4 **out, hipStream_t st);
 // the map in CALLER order as packed xyz (ikdtree.flatten's counterpart): xyz[3 * pidx[j]] = pts[j]
 void launch_map_to_xyz(const float4 *pts, const uint32_t *pidx, int64_t m, float *xyz, hipStream_t st);

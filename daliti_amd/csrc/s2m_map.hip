@@ -507,29 +507,37 @@ hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, Ma
 // rank of the dead among the caller indices: a bit mask of the dead per 64 indices and the number of dead before
 // every word (312 KB + 625 KB at 5 M points: L2-resident, so renumbering a caller index costs two cache hits
 // instead of a gather from a 20 MB array)
-__global__ __launch_bounds__(256) void dead_words_kernel(int64_t m, const uint8_t *__restrict__ alive,
-                                                         unsigned long long *__restrict__ word, uint32_t *__restrict__ cnt,
-                                                         uint32_t *__restrict__ outside_flag, uint32_t *__restrict__ announce)
+__global__ __launch_bounds__(256) void dead_words_kernel(int64_t m, const uint8_t *__restrict__ alive, const uint8_t *__restrict__ alive_s,
+                                                         unsigned long long *__restrict__ word, unsigned long long *__restrict__ word_s,
+                                                         unsigned long long *__restrict__ cnt, uint32_t *__restrict__ outside_flag)
 {
+    // the removed points twice: by caller index (alive: renumbering) and by sorted position (alive_s: where a survivor
+    // lands); the two counts of a word travel as the halves of one 64-bit element, so ONE scan gives both prefixes
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { cnt[(m + 63) >> 6] = 0u; *outside_flag = 0u; }  // the scan's spare element; merge_newkey_kernel's flag
-    if (i <= m) announce[i] = 0u;  // the new points' announcements among the old keys start from zero (was a 4 (m + 1)-byte memset)
-    const bool dead = i < m && alive[i] == 0;
-    const unsigned long long w = __ballot(dead);
+    if (i == 0) { cnt[(m + 63) >> 6] = 0ull; *outside_flag = 0u; }  // the scan's spare element; merge_newkey_kernel's flag
+    const unsigned long long w = __ballot(i < m && alive[i] == 0);
+    const unsigned long long ws = __ballot(i < m && alive_s[i] == 0);
     if ((threadIdx.x & 63) == 0 && (i >> 6) <= ((m - 1) >> 6)) {
         word[i >> 6] = w;
-        cnt[i >> 6] = (uint32_t)__popcll(w);
+        word_s[i >> 6] = ws;
+        cnt[i >> 6] = (unsigned long long)__popcll(w) | ((unsigned long long)__popcll(ws) << 32);
     }
 }
-struct DeadRank {  // per 64 caller indices: mask of the removed ones, number removed before the word (one 16-byte gather)
+struct DeadRank {  // per 64 indices: mask of the removed ones, number removed before the word (one 16-byte gather)
     unsigned long long word;
     uint32_t prefix, pad;
 };
+// entry `words` (one past the last word) is an empty mask with the total as its prefix: a position may equal m
 __global__ __launch_bounds__(256) void dead_pack_kernel(int64_t words, const unsigned long long *__restrict__ word,
-                                                        const uint32_t *__restrict__ prefix, DeadRank *__restrict__ out)
+                                                        const unsigned long long *__restrict__ word_s,
+                                                        const unsigned long long *__restrict__ prefix, DeadRank *__restrict__ out,
+                                                        DeadRank *__restrict__ out_s)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < words) out[w] = DeadRank{word[w], prefix[w], 0u};
+    if (w > words) return;
+    const unsigned long long p = prefix[w];
+    out[w] = DeadRank{w < words ? word[w] : 0ull, (uint32_t)p, 0u};
+    out_s[w] = DeadRank{w < words ? word_s[w] : 0ull, (uint32_t)(p >> 32), 0u};
 }
 __device__ __forceinline__ uint32_t dead_before(uint32_t ci, const DeadRank *__restrict__ rank)
 {
@@ -537,13 +545,6 @@ __device__ __forceinline__ uint32_t dead_before(uint32_t ci, const DeadRank *__r
     const unsigned long long w = ((unsigned long long)r.y << 32) | r.x;
     return r.z + (uint32_t)__popcll(w & ((1ull << (ci & 63u)) - 1ull));
 }
-
-struct AlivePlusNew {
-    __host__ __device__ uint32_t operator()(const rocprim::tuple<uint8_t, uint32_t> &t) const
-    {
-        return (rocprim::get<0>(t) ? 1u : 0u) + rocprim::get<1>(t);
-    }
-};
 
 __global__ __launch_bounds__(256) void merge_newkey_kernel(const float4 *__restrict__ stage, int n, Grid g,
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
@@ -568,10 +569,10 @@ __global__ __launch_bounds__(256) void merge_newkey_kernel(const float4 *__restr
     if (__syncthreads_or(out ? 1 : 0) && threadIdx.x == 0) atomicOr(outside, 1u);
 }
 
-// upper bound of every new key among the old keys (the first old point of a LATER cell); the new point announces
-// itself there
+// upper bound of every new key among the old keys (the first old point of a LATER cell): the new point goes in front
+// of that old point, behind the old points of its own cell.  The keys are sorted, so lb is ascending.
 __global__ __launch_bounds__(256) void merge_lb_kernel(int n, const uint64_t *__restrict__ nkeys, const uint64_t *__restrict__ okeys,
-                                                       int64_t m, uint32_t *__restrict__ lb, uint32_t *__restrict__ c)
+                                                       int64_t m, uint32_t *__restrict__ lb)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -582,21 +583,31 @@ __global__ __launch_bounds__(256) void merge_lb_kernel(int n, const uint64_t *__
         if (okeys[mid] <= k) lo = mid + 1; else hi = mid;
     }
     lb[i] = (uint32_t)lo;
-    atomicAdd(&c[lo], 1u);
 }
 
-// surviving old points to their merged positions: S = exclusive scan of alive_s[j] + c[j]; the c[j] new points that
-// announced themselves at j go first
+// surviving old point j -> (survivors before j) + (new points that go in front of j or of an earlier old point): no
+// map-sized scan and no per-position counter array -- the survivors before j come from the removed-by-position rank, the
+// new points from one scalar binary search per wave in the sorted lb[] (a few thousand entries, L2-resident) plus the few
+// entries inside the wave's 64 positions
 __global__ __launch_bounds__(256) void merge_old_kernel(int64_t m, const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
                                                         const uint64_t *__restrict__ okeys,
                                                         const uint8_t *__restrict__ alive_s, const DeadRank *__restrict__ rank,
-                                                        const uint32_t *__restrict__ c, const uint32_t *__restrict__ S,
+                                                        const DeadRank *__restrict__ rank_s, const uint32_t *__restrict__ lb, int n_new,
                                                         float4 *__restrict__ npts, uint32_t *__restrict__ npidx,
                                                         uint64_t *__restrict__ nkeys_out)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // wave-uniform: number of new points with lb < the wave's first position
+    const uint32_t j0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(j - (threadIdx.x & 63)));
+    int lo = 0, hi = n_new;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (lb[mid] < j0) lo = mid + 1; else hi = mid;
+    }
     if (j >= m || !alive_s[j]) return;
-    const uint32_t pos = S[j] + c[j];
+    int k = lo;
+    while (k < n_new && lb[k] <= (uint32_t)j) ++k;
+    const uint32_t pos = ((uint32_t)j - dead_before((uint32_t)j, rank_s)) + (uint32_t)k;
     const float4 p = pts[j];
     const uint32_t ci = pidx[j];
     npts[pos] = make_map_point(p.x, p.y, map_point_z(p), pos);
@@ -604,23 +615,19 @@ __global__ __launch_bounds__(256) void merge_old_kernel(int64_t m, const float4 
     nkeys_out[pos] = okeys[j];
 }
 
-// new points: position S[lb] + rank among the new points with the same lower bound (they are sorted, so the rank is
-// the distance to the first of them)
+// new point i (sorted order) -> (survivors before its lb) + i
 __global__ __launch_bounds__(256) void merge_new_kernel(int n, const uint64_t *__restrict__ nkeys, const uint32_t *__restrict__ nvals,
-                                                        const uint32_t *__restrict__ lb, const uint32_t *__restrict__ S,
-                                                        const float4 *__restrict__ stage, uint32_t survivors,
+                                                        const uint32_t *__restrict__ lb, const DeadRank *__restrict__ rank_s,
+                                                        const float4 *__restrict__ stage, uint32_t m_old,
+                                                        const uint32_t *__restrict__ dead_total,
                                                         float4 *__restrict__ npts, uint64_t *__restrict__ nkeys_out,
                                                         uint32_t *__restrict__ npidx)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint32_t survivors = m_old - *dead_total;  // (the host learns the number while this kernel is in the queue)
     const uint32_t l = lb[i];
-    int lo = 0, hi = i;  // first i' with lb[i'] == l
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (lb[mid] < l) lo = mid + 1; else hi = mid;
-    }
-    const uint32_t pos = S[l] + (uint32_t)(i - lo);
+    const uint32_t pos = (l - dead_before(l, rank_s)) + (uint32_t)i;
     const uint32_t t = nvals[i];
     const float4 p = stage[t];
     npts[pos] = make_map_point(p.x, p.y, p.z, pos);
@@ -637,71 +644,83 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return hipSuccess;
     const int n = (int)n_new;
     const int64_t words = (m + 63) / 64;
-    // work_c: [dead counts per word | their exclusive prefix]; mv: [stage positions | lower bounds] of the new points
-    S2M_TRY(ensure((void **)&buf.dword, &buf.dword_cap, 3 * (words + 2), sizeof(unsigned long long), 3 * (words / 4 + 1024)));  // masks, then the packed records
-    DeadRank *rank = reinterpret_cast<DeadRank *>(buf.dword + 2 * ((words + 2) / 2));  // 16-byte aligned
-    uint32_t *dcnt = buf.work_c, *dprefix = buf.work_c + (words + 1);
-    uint32_t *c = buf.work_a, *S = buf.work_b;
-    auto merged_in = rocprim::make_transform_iterator(rocprim::make_zip_iterator(rocprim::make_tuple(alive_s, static_cast<const uint32_t *>(c))),
-                                                      AlivePlusNew());
+    // dword: [masks by caller index | masks by position | packed records by caller index | by position], words + 1 each;
+    // work_c: [the two dead counts of every word as one 64-bit element | their exclusive prefix]; mv: [stage positions |
+    // upper bounds] of the new points
+    const int64_t w1 = words + 2;  // (even offsets keep the 16-byte records aligned)
+    S2M_TRY(ensure((void **)&buf.dword, &buf.dword_cap, 6 * w1 + 2, sizeof(unsigned long long), 6 * (words / 4 + 1024)));
+    unsigned long long *word = buf.dword, *word_s = buf.dword + w1 + (w1 & 1);
+    DeadRank *rank = reinterpret_cast<DeadRank *>(buf.dword + 2 * (w1 + (w1 & 1)));
+    DeadRank *rank_s = rank + w1;
+    unsigned long long *dcnt = reinterpret_cast<unsigned long long *>(buf.work_c), *dprefix = dcnt + (words + 1);
+    if ((int64_t)(2 * (words + 1) * sizeof(unsigned long long)) > (buf.scratch_cap + 1) * (int64_t)sizeof(uint32_t)) return hipSuccess;
     unsigned kbits = 10;  // (brick << 9 | cell) of this grid
     {
         const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
         while (kbits < 64 && ((int64_t)1 << (kbits - 9)) < top_entries) ++kbits;
     }
-    size_t tmp = 0, tmp2 = 0, tmp3 = 0;
-    S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
-    S2M_TRY(rocprim::exclusive_scan(nullptr, tmp2, merged_in, S, 0u, (size_t)m + 1, rocprim::plus<uint32_t>(), st));
+    // capacity for the merged map before anything is enqueued (the exact size arrives with the hand-back below)
+    const int64_t m_bound = m + n_new;
+    if (m_bound > buf.scratch_cap || m_bound >= ((int64_t)1 << 31)) return hipSuccess;
+    size_t tmp = 0, tmp3 = 0;
+    S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, dcnt, dprefix, 0ull, (size_t)words + 1, rocprim::plus<unsigned long long>(), st));
     if (n > 0)
         S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, buf.keys, buf.keys, buf.vals, buf.vals, (size_t)n_new, 0, kbits, st));
-    S2M_TRY(ensure_sort_tmp(buf, std::max(std::max(tmp, tmp2), tmp3)));
+    S2M_TRY(ensure_sort_tmp(buf, std::max(tmp, tmp3)));
     if (n > 0) {
         S2M_TRY(ensure((void **)&buf.mk, &buf.mk_cap, n_new, sizeof(uint64_t), n_new / 2 + 4096));
         S2M_TRY(ensure((void **)&buf.mv, &buf.mv_cap, 2 * n_new, sizeof(uint32_t), n_new + 8192));
     }
+    S2M_TRY(ensure((void **)&buf.pts2, &buf.pts2_cap, m_bound + kSentinelPoints, sizeof(float4), headroom_for(m_bound)));
+    S2M_TRY(ensure((void **)&buf.pidx2, &buf.pidx2_cap, m_bound + 1, sizeof(uint32_t), headroom_for(m_bound)));
 
-    // dead rank over the caller indices (element `words` of the counts is zero: the prefix there is the total)
-    hipLaunchKernelGGL(dead_words_kernel, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, st, m, alive, buf.dword, dcnt,
-                       buf.counters + 8, c);
+    // the removed points' ranks, by caller index and by position (element `words` of the counts is zero: the prefix there
+    // is the total, in both halves)
+    hipLaunchKernelGGL(dead_words_kernel, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, st, m, alive, alive_s, word, word_s, dcnt,
+                       buf.counters + 8);
     size_t t = buf.sort_tmp_bytes;
-    S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
-    uint32_t dead = 0, outside = 0;
-    hipLaunchKernelGGL(dead_pack_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, words, buf.dword, dprefix, rank);
-    // announcements of the new points among the old keys (c was zeroed by dead_words_kernel)
+    S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, dcnt, dprefix, 0ull, (size_t)words + 1, rocprim::plus<unsigned long long>(), st));
+    hipLaunchKernelGGL(dead_pack_kernel, dim3((unsigned)((words + 256) / 256)), dim3(256), 0, st, words, word, word_s, dprefix, rank,
+                       rank_s);
     uint64_t *nk_sorted = buf.mk;
     uint32_t *nv_sorted = buf.mv, *lb = buf.mv + n_new;
-    if (n > 0) {
-        // keys in the CURRENT grid (keys / vals are free until the merge writes them), sorted into the small arrays
+    // keys of the new points in the CURRENT grid (keys / vals are free until the merge writes them); the kernel also says
+    // whether one of them lies outside the grid
+    if (n > 0)
         hipLaunchKernelGGL(merge_newkey_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals,
                            buf.counters + 8);
+    // the one hand-back -- number of dead, "a new point lies outside the grid" -- is posted here and collected after the
+    // merge kernels have been enqueued: they write into the spare arrays, which only become the map if the answer allows it
+    const uint32_t *dead_dev = reinterpret_cast<const uint32_t *>(dprefix + words);
+    {
+        const uint32_t *src[2] = {dead_dev, buf.counters + 8};
+        S2M_TRY(mail_post(buf.mail, src, 2, st));
+    }
+    if (n > 0) {
         t = buf.sort_tmp_bytes;
         S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, nk_sorted, buf.vals, nv_sorted, (size_t)n_new, 0, kbits, st));
-        hipLaunchKernelGGL(merge_lb_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, buf.keys_alt, m, lb, c);
+        hipLaunchKernelGGL(merge_lb_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, buf.keys_alt, m, lb);
     }
-    t = buf.sort_tmp_bytes;
-    S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, merged_in, S, 0u, (size_t)m + 1, rocprim::plus<uint32_t>(), st));
-    {   // the one hand-back: number of dead, "a new point lies outside the grid"
-        const uint32_t *src[2] = {dprefix + words, buf.counters + 8};
+    hipLaunchKernelGGL(merge_old_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.pts, buf.pidx, buf.keys_alt,
+                       alive_s, rank, rank_s, lb, n, buf.pts2, buf.pidx2, buf.keys);
+    if (n > 0)
+        hipLaunchKernelGGL(merge_new_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, nv_sorted, lb, rank_s, stage,
+                           (uint32_t)m, dead_dev, buf.pts2, buf.keys, buf.pidx2);
+    uint32_t dead = 0, outside = 0;
+    {
         uint32_t v[2] = {0, 0};
-        S2M_TRY(mail_fetch(buf.mail, src, 2, v, st));
+        S2M_TRY(mail_collect(buf.mail, 2, v, st));
         dead = v[0];
         outside = v[1];
     }
-    if (outside) return hipSuccess;     // full rebuild (with a fresh margin)
+    if (outside) return hipSuccess;     // full rebuild (with a fresh margin); what was written to the spare arrays is dropped
     if (dead == 0 && n_new == 0) {      // nothing was removed and nothing is added: the map stands as it is
         merged = true;
         return hipSuccess;
     }
     const int64_t survivors = m - (int64_t)dead;
     const int64_t m_new = survivors + n_new;
-    if (m_new > buf.scratch_cap || m_new >= ((int64_t)1 << 31) || m_new == 0) return hipSuccess;
-    S2M_TRY(ensure((void **)&buf.pts2, &buf.pts2_cap, m_new + kSentinelPoints, sizeof(float4), headroom_for(m_new)));
-    S2M_TRY(ensure((void **)&buf.pidx2, &buf.pidx2_cap, m_new + 1, sizeof(uint32_t), headroom_for(m_new)));
-    hipLaunchKernelGGL(merge_old_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.pts, buf.pidx, buf.keys_alt,
-                       alive_s, rank, c, S, buf.pts2, buf.pidx2, buf.keys);
-    if (n > 0)
-        hipLaunchKernelGGL(merge_new_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, nv_sorted, lb, S, stage,
-                           (uint32_t)survivors, buf.pts2, buf.keys, buf.pidx2);
+    if (m_new == 0) return hipSuccess;
     S2M_TRY(put_sentinels(buf.pts2, m_new, st));
     // the merged arrays become the map
     std::swap(buf.pts, buf.pts2); std::swap(buf.pts_cap, buf.pts2_cap);

@@ -405,7 +405,9 @@ void free_mailbox(Mailbox &mb)
     mb = Mailbox();
 }
 
-hipError_t mail_fetch(Mailbox &mb, const uint32_t *const *src, int k, uint32_t *out, hipStream_t st)
+// a hand-back in two halves: mail_post enqueues the kernel that copies the words and raises the sequence number,
+// mail_collect waits for it -- whatever the caller enqueues in between runs while the words travel
+hipError_t mail_post(Mailbox &mb, const uint32_t *const *src, int k, hipStream_t st)
 {
     if (k <= 0 || k > kMailSlots) return hipErrorInvalidValue;
     if (!mb.h) {
@@ -420,20 +422,32 @@ hipError_t mail_fetch(Mailbox &mb, const uint32_t *const *src, int k, uint32_t *
     if (++mb.seq == 0u) mb.seq = 1u;
     a.seq = mb.seq;
     hipLaunchKernelGGL(mail_kernel, dim3(1), dim3(64), 0, st, a, mb.dev);
-    // The kernel is the last thing on the stream: when its sequence number shows up in pinned memory everything
-    // before it has finished.  Polling it costs 2-3 us after the kernel ends; hipStreamSynchronize costs 10-20 us.
+    return hipSuccess;
+}
+
+hipError_t mail_collect(Mailbox &mb, int k, uint32_t *out, hipStream_t st)
+{
+    // When the kernel's sequence number shows up in pinned memory everything enqueued before it has finished.  Polling it
+    // costs 2-3 us after the kernel ends; hipStreamSynchronize costs 10-20 us.
     volatile uint32_t *flag = mb.h;
+    const uint32_t seq = mb.seq;
     bool seen = false;
     for (long spin = 0; spin < 20000000L; ++spin) {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == a.seq) { seen = true; break; }
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
         __builtin_ia32_pause();
     }
     if (!seen) {  // slow or failed: let the runtime tell us
         S2M_TRY(hipStreamSynchronize(st));
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != a.seq) return hipErrorUnknown;
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return hipErrorUnknown;
     }
     for (int i = 0; i < k; ++i) out[i] = mb.h[1 + i];
     return hipSuccess;
+}
+
+hipError_t mail_fetch(Mailbox &mb, const uint32_t *const *src, int k, uint32_t *out, hipStream_t st)
+{
+    S2M_TRY(mail_post(mb, src, k, st));
+    return mail_collect(mb, k, out, st);
 }
 
 hipError_t mail_wait(Mailbox &mb, hipStream_t st)
@@ -662,14 +676,14 @@ hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStr
 
 hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, const float *sy, const float *sz, int n,
                          const int32_t *nn_idx, const Grid &g, bool have_nn, double fs, float4 **to_add, int64_t *n_add,
-                         float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox)
+                         float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox, bool begin_update)
 {
     if (vox) *vox = VoxBox{};
     *n_add = 0;
     *n_no_down = 0;
     *to_add = nullptr;
     *no_down = nullptr;
-    if (n <= 0) return hipSuccess;
+    if (n <= 0) return begin_update ? update_begin(u, g, st) : hipSuccess;
     // scratch: cvt holds [pw (n) | list A (n) | list B (n)], flags in add_flag / cnt, positions in pos / best_idx
     S2M_TRY(grow(&u.cvt, &u.cvt_cap, (int64_t)3 * n));
     if (u.batch_cap < n) {
@@ -708,7 +722,11 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
         const uint32_t *p32 = reinterpret_cast<const uint32_t *>(ps + (n - 1)), *f32 = reinterpret_cast<const uint32_t *>(fl + (n - 1));
         const uint32_t *src[5] = {p32, f32, p32 + 1, f32 + 1, u.counters + 15};
         uint32_t h[5] = {0, 0, 0, 0, 1};
-        S2M_TRY(mail_fetch(u.mail, src, 5, h, st));
+        S2M_TRY(mail_post(u.mail, src, 5, st));
+        // the update this classification feeds begins while the counts travel (its reset kernel needs none of them and
+        // zeroes word 15 behind the read above, in stream order)
+        if (begin_update) S2M_TRY(update_begin(u, g, st));
+        S2M_TRY(mail_collect(u.mail, 5, h, st));
         *n_add = (int64_t)h[0] + h[1];
         *n_no_down = (int64_t)h[2] + h[3];
         if (vox && h[4] == 0u) *vox = vb;   // every PointToAdd lies in the box: the voxel sort can use the short key

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "s2m_last_error", "s2m_set_config", "s2m_set_stream", "s2m_map_build", "s2m_map_size",
     "s2m_map_info", "s2m_map_last_update", "s2m_map_share", "s2m_map_add", "s2m_map_delete_boxes", "s2m_map_incremental", "s2m_map_get_points",
     "s2m_fov_segment", "s2m_fov_reset",
-    "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_scan_prefetch_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
+    "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_scan_prefetch_raw", "s2m_scan_prepare_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
     "s2m_iterated_update", "s2m_iterated_update_batch", "s2m_iterated_update_multi", "s2m_iterated_update_sharded",
     "s2m_complete_neighbors", "s2m_map_get_order", "s2m_map_grid", "s2m_map_update_stats", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_init_shm", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
@@ -320,6 +320,16 @@ class Engine:
         hands to scan_set_from_raw unchanged)."""
         assert records.dtype == np.float32 and records.flags["C_CONTIGUOUS"]
         self._ck(self.lib.s2m_scan_prefetch_raw(self.h, _p(records), C.c_int64(records.shape[1]), C.c_int64(records.shape[0])))
+
+    def scan_prepare_raw(self, records, time_off_a, time_off_b, poses, state_end, leaf=0.5):
+        """The next frame's scan_set_from_raw on the handle's side stream (s2m_scan_prepare_raw); the same call of
+        scan_set_from_raw afterwards picks the prepared scan up.  `records` must stay alive and unchanged until then."""
+        assert records.dtype == np.float32 and records.flags["C_CONTIGUOUS"]
+        poses = np.ascontiguousarray(poses, np.float64)
+        state_end = np.ascontiguousarray(state_end, np.float64)
+        self._ck(self.lib.s2m_scan_prepare_raw(self.h, _p(records), C.c_int64(records.shape[1]), C.c_int64(records.shape[0]),
+                                               C.c_int32(time_off_a), C.c_int32(time_off_b), _p(poses), C.c_int32(len(poses)),
+                                               _p(state_end), C.c_float(leaf)))
 
     def scan_get(self):
         n = C.c_int64()

@@ -218,6 +218,18 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride_floats, int
  * s2m_scan_set_from_raw with the SAME pointer, stride and n uses that copy instead of copying itself (any other call
  * ignores it).  The caller keeps the buffer alive and unchanged until then.  (Design, not reference.) */
 int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride_floats, int64_t n);
+/* The whole front half of the NEXT frame while the map update of the current one runs: s2m_scan_set_from_raw's work (copy,
+ * undistortion, voxel grid) on the handle's side stream and worker thread, into spare scan arrays; returns at once.  A
+ * following s2m_scan_set_from_raw with the SAME arguments (pointer, layout, poses and state_end by value, leaf; host
+ * input) swaps the prepared scan in instead of computing it; any other call ignores it and computes as usual -- the result
+ * is the same scan either way.  Meant for a node that replays or catches up: the reference's loop has the next message's
+ * IMU poses as soon as the current update has produced the state they are propagated from (IMU_Processing.hpp:246-330),
+ * i.e. before map_incremental (laserMapping.cpp:1134) -- call it there.  The caller keeps `points` alive and unchanged
+ * until the matching s2m_scan_set_from_raw returns.  A sweep larger than the current scan's arrays is not prepared (the
+ * synchronous call handles it).  (Design, not reference.) */
+int s2m_scan_prepare_raw(s2m_engine *e, const float *points, int64_t stride_floats, int64_t n, int32_t time_off_a,
+                         int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses,
+                         const double state_end[S2M_STATE_DOUBLES], float leaf);
 /* The node's front half of a frame kept on the device: undistort (time-sorted) -> VoxelGrid(leaf)
  * -> current scan (IMU_Processing.hpp:333-370, laserMapping.cpp:775-778).  leaf <= 0 skips the
  * down-sampling.  *n_out = feats_down_size. */

@@ -32,3 +32,22 @@ print("window %.2f ms = %.1f frames; GPU busy %.1f %%; %.1f kernel launches per 
     span / 1e6, nf, 100.0 * busy / span, len(rows) / nf, sum(v[1] for v in per.values()) / nf / 1e3))
 for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:40]:
     print("%-62s %5.1f per frame  avg %7.2f us  %7.1f us per frame" % (k, c / nf, t / c / 1e3, t / nf / 1e3))
+
+# one frame as a sequence (optional 4th argument "seq"): from one incr_classify_kernel to the next, every kernel with its
+# queue, start relative to the frame, duration and the idle gap since the previous kernel END on any queue
+if len(sys.argv) > 4 and sys.argv[4] == "seq":
+    full = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            full.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
+    full.sort()
+    marks = [i for i, r in enumerate(full) if "incr_classify_kernel" in r[2]]
+    if len(marks) > 12:
+        a, b = marks[-10], marks[-9]
+        t0 = full[a][0]; last_end = t0
+        print("\none frame, classify to classify: %.1f us" % ((full[b][0] - t0) / 1e3))
+        for s, e, n, q in full[a:b]:
+            k = n.split("(")[0].replace("void ", "")
+            k = ("rocprim::" + k.split("::")[-1].split("<")[0]) if "rocprim" in k else k[:44]
+            print("  q%-3s +%7.1f us  %6.1f us  gap %5.1f  %s" % (q[-3:], (s - t0) / 1e3, (e - s) / 1e3, max(0, s - last_end) / 1e3, k))
+            last_end = max(last_end, e)

@@ -98,17 +98,23 @@ int s2m_bench_loop_varying(s2m_engine *e, int32_t k, const float *const *scans_d
 int s2m_bench_frames(s2m_engine *e, int32_t frames, const float *records, int64_t stride_floats, int64_t n,
                      int32_t time_off_a, int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses,
                      const double *state_end, float leaf, const double *x_prop, const double *P0, double filter_size_map,
-                     double cube_len, int32_t prefetch, double *x, double *frame_us, int32_t *merged)
+                     double cube_len, int32_t prefetch, double *x, double *frame_us, int32_t *merged, double *pose_us)
 {
+    // prefetch: 0 = every frame on its own; 1 = the next sweep's records cross PCIe while this one is registered
+    // (s2m_scan_prefetch_raw); 2 = the next frame's whole front half (copy, undistortion, voxel grid) runs beside this
+    // frame's map update (s2m_scan_prepare_raw, called where the reference's loop has the next message's IMU poses: after
+    // the update, before map_incremental).  pose_us[f] (optional) = records in -> pose out of frame f.
     if (!e || frames < 0 || !records || !poses || !state_end || !x_prop || !P0 || !x || !frame_us || !merged) return S2M_ERR_ARG;
     double P[S2M_DIM * S2M_DIM];
     s2m_iter_log log;
-    for (int f = 0; f < frames; ++f) {
+    // two untimed frames first (frame index < 0): the handle's side thread, its stream and the host's polling loops are
+    // warm when the timed frames start, as in any steady stream
+    for (int f = -2; f < frames; ++f) {
         const auto t0 = std::chrono::steady_clock::now();
         int64_t n_out = 0, na = 0, nb = 0;
         int rc = s2m_scan_set_from_raw(e, records, stride_floats, n, time_off_a, time_off_b, poses, n_poses, state_end, leaf, 0, &n_out);
         if (rc) return rc;
-        if (prefetch && f + 1 < frames) {  // the next sweep's records cross PCIe while this one is registered
+        if (prefetch == 1 && f + 1 < frames) {
             rc = s2m_scan_prefetch_raw(e, records, stride_floats, n);
             if (rc) return rc;
         }
@@ -116,10 +122,16 @@ int s2m_bench_frames(s2m_engine *e, int32_t frames, const float *records, int64_
         std::memcpy(P, P0, sizeof(P));
         rc = s2m_iterated_update(e, x, x_prop, P, &log);
         if (rc) return rc;
+        if (pose_us && f >= 0) pose_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (prefetch == 2 && f + 1 < frames) {
+            rc = s2m_scan_prepare_raw(e, records, stride_floats, n, time_off_a, time_off_b, poses, n_poses, state_end, leaf);
+            if (rc) return rc;
+        }
         rc = s2m_map_incremental(e, x, filter_size_map, 1, &na, &nb);
         if (rc) return rc;
         rc = s2m_fov_segment(e, x + 9, cube_len, nullptr, nullptr, nullptr);
         if (rc) return rc;
+        if (f < 0) continue;
         frame_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         rc = s2m_map_last_update(e, &merged[f]);
         if (rc) return rc;
