@@ -86,6 +86,7 @@ struct s2m_engine {
         // s2m_scan_prepare_raw: the job also undistorts and down-samples into the spare scan arrays (d_scan_alt) on
         // the side stream; what it was asked for is kept so that s2m_scan_set_from_raw can recognise the same call
         bool prepare = false, prepared = false;
+        bool copied = false;             // the records of this job are in d_buf already (a prefetch that was not consumed)
         int64_t stride = 0, n = 0, m = 0;
         int32_t oa = 0, ob = 0;
         float leaf = 0.0f;
@@ -887,7 +888,8 @@ void prefetch_worker(s2m_engine *e)
         const int64_t floats = p.floats;
         const bool prepare = p.prepare;
         lk.unlock();
-        hipError_t he = hipMemcpyAsync(p.d_buf, src, (size_t)floats * sizeof(float), hipMemcpyHostToDevice, p.stream);
+        hipError_t he = p.copied ? hipSuccess
+                                 : hipMemcpyAsync(p.d_buf, src, (size_t)floats * sizeof(float), hipMemcpyHostToDevice, p.stream);
         int64_t m = p.n;
         bool ok = he == hipSuccess;
         if (ok && prepare) {
@@ -954,6 +956,7 @@ int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride, in
     {
         std::lock_guard<std::mutex> lk(e->pf.mu);
         e->pf.prepare = false;
+        e->pf.copied = false;
         e->pf.busy = true;
     }
     e->pf.cv.notify_all();
@@ -970,6 +973,9 @@ int s2m_scan_prepare_raw(s2m_engine *e, const float *points, int64_t stride, int
     // the prepared scan must fit the arrays of the current one (they are swapped, not copied); a first or larger sweep is
     // left to the synchronous call
     if (e->n_cap < n) return S2M_OK;
+    pf_drain(e);
+    // the records may be on the device already: s2m_scan_prefetch_raw at the start of the frame, this call once the poses exist
+    const bool have = e->pf.ready && e->pf.src == points && e->pf.floats == n * stride;
     rc = pf_start(e, points, n * stride);
     if (rc) return rc;
     if (e->scan_alt_cap != e->n_cap) {
@@ -986,6 +992,7 @@ int s2m_scan_prepare_raw(s2m_engine *e, const float *points, int64_t stride, int
     {
         std::lock_guard<std::mutex> lk(p.mu);
         p.prepare = true;
+        p.copied = have;
         p.busy = true;
     }
     p.cv.notify_all();

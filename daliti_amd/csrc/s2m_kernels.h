@@ -116,10 +116,13 @@ struct UpdateBuffers {
     int64_t boxes_cap = 0;
     float4 *cvt = nullptr;         // conversion / classification scratch
     int64_t cvt_cap = 0;
+    unsigned long long *vtab = nullptr;  // direct-address table over a batch's voxel box (winner per voxel), all ~0 between batches
+    int64_t vtab_cap = 0;                // slots
     Mailbox mail;
 };
 // box of voxels (edge = the down-sampling size) that holds every point of a batch: lets the sort that groups the batch by voxel
 // use a linear index of `bits` bits instead of the 63-bit packed key; bits == 0: not available (use the packed key)
+constexpr int kVoxTableBits = 25;  // a voxel box of up to 2^25 voxels gets a winner table (256 MB at most; 45 MB at C3)
 struct VoxBox {
     int lo[3] = {0, 0, 0}, d[3] = {0, 0, 0};
     int bits = 0;

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void add_probe_kernel(Grid g, const float4 *__
                                                         uint64_t *__restrict__ key, uint32_t *__restrict__ val,
                                                         float *__restrict__ dnew, uint32_t *__restrict__ cnt,
                                                         uint32_t *__restrict__ best_idx, uint32_t *__restrict__ best_pos,
-                                                        float *__restrict__ best_d, uint32_t *__restrict__ add_flag, VoxBox vb)
+                                                        float *__restrict__ best_d, uint32_t *__restrict__ add_flag, VoxBox vb,
+                                                        unsigned long long *__restrict__ vtab)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = tid / kBoxLanes;
@@ -163,7 +164,12 @@ __global__ __launch_bounds__(256) void add_probe_kernel(Grid g, const float4 *__
     key[i] = vb.bits > 0 ? lin : voxel_key(p.x, p.y, p.z, ds);
     val[i] = (uint32_t)i;
     add_flag[i] = 0u;  // set by add_resolve_kernel for the winners (was a memset of its own)
-    dnew[i] = dist2(p.x, p.y, p.z, v.mid);
+    const float dn = dist2(p.x, p.y, p.z, v.mid);
+    dnew[i] = dn;
+    // winner of the voxel among the batch -- smallest centre distance, the LAST one on ties -- without a sort: one 64-bit
+    // atomic minimum of (distance bits, ~batch index) into the voxel's slot of a direct-address table over the voxel box
+    // (all slots ~0 between batches: add_stage_kernel puts them back)
+    if (vtab) atomicMin(vtab + lin, ((unsigned long long)__float_as_uint(dn) << 32) | (unsigned long long)(~(uint32_t)i));
     cnt[i] = c;
     best_idx[i] = bi;
     best_pos[i] = bp;
@@ -180,25 +186,41 @@ __global__ __launch_bounds__(256) void add_resolve_kernel(Grid g, const float4 *
                                                           const uint32_t *__restrict__ best_pos,
                                                           const float *__restrict__ best_d,
                                                           uint8_t *__restrict__ alive, uint8_t *__restrict__ alive_s,
-                                                          uint32_t *__restrict__ add_flag, uint32_t *__restrict__ counters)
+                                                          uint32_t *__restrict__ add_flag, uint32_t *__restrict__ counters,
+                                                          const unsigned long long *__restrict__ vtab)
 {
     // kBoxLanes lanes per sorted position: all of them take the (cheap) decision, the walk that marks the voxel's old
     // points is shared between them
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int s = tid / kBoxLanes;
     const uint32_t sub = (uint32_t)(tid % kBoxLanes);
-    const bool head = s < n && !(s > 0 && skey[s - 1] == skey[s]);  // first position of a voxel segment
+    // table form (vtab): s is a batch index, and the point decides for its voxel when the table names it the winner;
+    // sorted form: s is a sorted position, and the first position of a voxel segment decides
+    bool head = false;
     bool add_new = false, rewrite = false;
     uint32_t keep = 0xffffffffu, w = 0, c = 0;
+    float wd = 0.0f;
     float4 pw = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (head) {
-        // winner among the new points of this voxel: smallest centre distance, the last one on ties
-        w = sval[s];
-        float wd = dnew[w];
-        for (int t = s + 1; t < n && skey[t] == skey[s]; ++t) {
-            const uint32_t i = sval[t];
-            if (dnew[i] <= wd) { wd = dnew[i]; w = i; }
+    if (vtab) {
+        if (s < n) {
+            const unsigned long long e = vtab[skey[s]];  // (skey = the unsorted linear voxel indices)
+            head = (uint32_t)s == ~(uint32_t)e;
+            w = (uint32_t)s;
+            wd = __uint_as_float((uint32_t)(e >> 32));
         }
+    } else {
+        head = s < n && !(s > 0 && skey[s - 1] == skey[s]);
+        if (head) {
+            // winner among the new points of this voxel: smallest centre distance, the last one on ties
+            w = sval[s];
+            wd = dnew[w];
+            for (int t = s + 1; t < n && skey[t] == skey[s]; ++t) {
+                const uint32_t i = sval[t];
+                if (dnew[i] <= wd) { wd = dnew[i]; w = i; }
+            }
+        }
+    }
+    if (head) {
         c = cnt[w];
         const uint32_t bi = best_idx[w];
         const float bd = best_d[w];
@@ -276,12 +298,15 @@ __global__ __launch_bounds__(256) void scatter_survivors_kernel(const float4 *__
     out[pos[ci]] = make_float4(q.x, q.y, map_point_z(q), 0.0f);
 }
 
-// out[pos[i]] = src[i] for flagged i (pos = exclusive scan of the flags), shifted by base
+// out[pos[i]] = src[i] for flagged i (pos = exclusive scan of the flags), shifted by base; with a winner table, every
+// point also puts its voxel's slot back to "empty" (all points of a voxel write the same value)
 __global__ __launch_bounds__(256) void scatter_kernel(const float4 *__restrict__ src, const uint32_t *__restrict__ flag,
                                                       const uint32_t *__restrict__ pos, int64_t m, int64_t base,
-                                                      float4 *__restrict__ out)
+                                                      float4 *__restrict__ out, const uint64_t *__restrict__ vkey,
+                                                      unsigned long long *__restrict__ vtab)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m && vtab) vtab[vkey[i]] = ~0ull;
     if (i < m && flag[i]) {
         float4 p = src[i];
         p.w = 0.0f;
@@ -488,7 +513,7 @@ static hipError_t grow(T **p, int64_t *cap, int64_t need, bool keep = false, hip
 void free_update(UpdateBuffers &u)
 {
     void *ptrs[] = {u.alive, u.alive_s, u.counters, u.stage, u.key, u.key2, u.val, u.val2, u.dnew, u.cnt, u.best_idx, u.best_pos, u.best_d,
-                    u.add_flag, u.pos, u.flag32, u.pos_old, u.list, u.tmp, u.boxes, u.cvt};
+                    u.add_flag, u.pos, u.flag32, u.pos_old, u.list, u.tmp, u.boxes, u.cvt, u.vtab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_mailbox(u.mail);
@@ -604,24 +629,46 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
         u.batch_cap = c;
     }
     const int in = (int)n;
+    // with the batch inside a known box of voxels (map_incremental: VoxBox) whose direct-address table fits, the batch's
+    // voxel winners come from 64-bit atomic minima in that table; otherwise the batch is sorted by voxel key
+    unsigned long long *vtab = nullptr;
+    if (vox && vox->bits > 0 && vox->bits <= kVoxTableBits) {
+        const int64_t slots = (int64_t)vox->d[0] * vox->d[1] * vox->d[2];
+        if (u.vtab_cap < slots) {
+            if (u.vtab) S2M_TRY(hipFree(u.vtab));
+            u.vtab = nullptr;
+            u.vtab_cap = 0;
+            S2M_TRY(hipMalloc((void **)&u.vtab, (size_t)slots * sizeof(unsigned long long)));
+            note_allocation();
+            S2M_TRY(hipMemsetAsync(u.vtab, 0xff, (size_t)slots * sizeof(unsigned long long), st));
+            u.vtab_cap = slots;
+        }
+        vtab = u.vtab;
+    }
     hipLaunchKernelGGL(add_probe_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, u.key, u.val, u.dnew, u.cnt,
-                       u.best_idx, u.best_pos, u.best_d, u.add_flag, vox ? *vox : VoxBox{});
-    const unsigned kbits = (vox && vox->bits > 0) ? (unsigned)vox->bits : 63u;
-    size_t bytes = 0;
-    S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, u.key, u.key2, u.val, u.val2, (size_t)n, 0, kbits, st));
-    S2M_TRY(ensure_tmp(u, bytes));
-    size_t b2 = u.tmp_bytes;
-    S2M_TRY(rocprim::radix_sort_pairs(u.tmp, b2, u.key, u.key2, u.val, u.val2, (size_t)n, 0, kbits, st));
+                       u.best_idx, u.best_pos, u.best_d, u.add_flag, vox ? *vox : VoxBox{}, vtab);
+    const uint64_t *rkey = u.key;   // what add_resolve_kernel reads as keys / values: unsorted with the table
+    const uint32_t *rval = u.val;
+    if (!vtab) {
+        const unsigned kbits = (vox && vox->bits > 0) ? (unsigned)vox->bits : 63u;
+        size_t bytes = 0;
+        S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, u.key, u.key2, u.val, u.val2, (size_t)n, 0, kbits, st));
+        S2M_TRY(ensure_tmp(u, bytes));
+        size_t b2 = u.tmp_bytes;
+        S2M_TRY(rocprim::radix_sort_pairs(u.tmp, b2, u.key, u.key2, u.val, u.val2, (size_t)n, 0, kbits, st));
+        rkey = u.key2;
+        rval = u.val2;
+    }
     uint32_t before = 0;
     if (n_added) {  // tmp_counter of Add_Points before this batch (zero unless several batches share one update)
         const uint32_t *src[1] = {u.counters + 1};
         S2M_TRY(mail_fetch(u.mail, src, 1, &before, st));
     }
-    hipLaunchKernelGGL(add_resolve_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, u.key2, u.val2, u.dnew,
-                       u.cnt, u.best_idx, u.best_pos, u.best_d, u.alive, u.alive_s, u.add_flag, u.counters);
+    hipLaunchKernelGGL(add_resolve_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, rkey, rval, u.dnew,
+                       u.cnt, u.best_idx, u.best_pos, u.best_d, u.alive, u.alive_s, u.add_flag, u.counters, vtab);
     // winners, in batch order, go to the staging list
     S2M_TRY(scan_u32(u, u.add_flag, u.pos, n, st));
-    hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage, u.key, vtab);
     const uint32_t *src[3] = {u.pos + (n - 1), u.add_flag + (n - 1), u.counters + 1};
     uint32_t v[3] = {0, 0, 0};
     S2M_TRY(mail_fetch(u.mail, src, 3, v, st));

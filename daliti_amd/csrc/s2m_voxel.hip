@@ -66,12 +66,38 @@ __global__ __launch_bounds__(256) void vx_centroid_kernel(const float *__restric
     if (s >= n || !head[s]) return;
     float cx = 0.0f, cy = 0.0f, cz = 0.0f;
     int cnt = 0;
-    for (int64_t t = s; t < n && skey[t] == skey[s]; ++t) {
-        const int64_t i = sval[t];
-        cx = cx + xyz[i * stride];
-        cy = cy + xyz[i * stride + 1];
-        cz = cz + xyz[i * stride + 2];
-        ++cnt;
+    // four positions per trip: their keys, indices and points are requested together and added in order (a near-field
+    // voxel holds dozens of points; one dependent key -> index -> point chain per point made this the longest kernel of
+    // the front half)
+    const uint64_t k0 = skey[s];
+    for (int64_t t = s; t < n; t += 4) {
+        uint64_t kk[4];
+        uint32_t ii[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t tu = t + u < n ? t + u : n - 1;
+            kk[u] = skey[tu];
+            ii[u] = sval[tu];
+        }
+        float px[4], py[4], pz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            px[u] = xyz[(int64_t)ii[u] * stride];
+            py[u] = xyz[(int64_t)ii[u] * stride + 1];
+            pz[u] = xyz[(int64_t)ii[u] * stride + 2];
+        }
+        bool more = true;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            more = more && t + u < n && kk[u] == k0;
+            if (more) {
+                cx = cx + px[u];
+                cy = cy + py[u];
+                cz = cz + pz[u];
+                ++cnt;
+            }
+        }
+        if (!more) break;
     }
     const float fn = (float)cnt;
     const uint32_t o = pos[s];

@@ -226,7 +226,8 @@ int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride_flo
  * IMU poses as soon as the current update has produced the state they are propagated from (IMU_Processing.hpp:246-330),
  * i.e. before map_incremental (laserMapping.cpp:1134) -- call it there.  The caller keeps `points` alive and unchanged
  * until the matching s2m_scan_set_from_raw returns.  A sweep larger than the current scan's arrays is not prepared (the
- * synchronous call handles it).  (Design, not reference.) */
+ * synchronous call handles it).  Records that s2m_scan_prefetch_raw has already brought over (same buffer, not yet
+ * consumed) are not copied again: prefetch when the sweep arrives, prepare when its poses exist.  (Design, not reference.) */
 int s2m_scan_prepare_raw(s2m_engine *e, const float *points, int64_t stride_floats, int64_t n, int32_t time_off_a,
                          int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses,
                          const double state_end[S2M_STATE_DOUBLES], float leaf);

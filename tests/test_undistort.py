@@ -230,3 +230,31 @@ def test_prepared_frames_equal_frames_computed_in_place(oracle):
         assert fa[0] == fb[0] and (bits(fa[1]) == bits(fb[1])).all()
         assert (fa[2] == fb[2]).all() and fa[3:] == fb[3:]
     assert (bits(a[-1]) == bits(b[-1])).all()
+
+
+@pytest.mark.gpu
+def test_prefetch_then_prepare_is_the_same_scan(oracle):
+    """Records brought over by s2m_scan_prefetch_raw are used by a following s2m_scan_prepare_raw of the same buffer (no
+    second copy), and the prepared scan equals the one computed in place."""
+    from daliti_amd import Engine, synth
+    sc = synth.make_small()
+    n = len(sc["scan"])
+    rs = np.random.RandomState(9)
+    rec = np.zeros((n, 12), np.float32)
+    rec[:, :3] = sc["scan"]
+    rec[:, 4] = rs.permutation(n).astype(np.float32) / n
+    rec[:, 6] = 0.1
+    K = 12
+    poses = np.zeros((K, 22)); poses[:, 0] = np.linspace(0.0, 0.101, K); poses[:, 13:22] = np.eye(3).ravel()
+    poses[:, 7:10] = rs.normal(0, 0.4, (K, 3))
+    end = np.zeros(36); end[0:9] = np.eye(3).ravel(); end[12:21] = np.eye(3).ravel()
+    e = Engine()
+    e.map_build(sc["map"])
+    e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3)
+    plain = e.scan_get().copy()
+    for _ in range(3):
+        e.scan_prefetch_raw(rec)
+        e.scan_prepare_raw(rec, 4, 6, poses, end, 0.3)
+        assert e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3) == len(plain)
+        assert (bits(e.scan_get()) == bits(plain)).all()
+    e.close()

@@ -101,9 +101,9 @@ int s2m_bench_frames(s2m_engine *e, int32_t frames, const float *records, int64_
                      double cube_len, int32_t prefetch, double *x, double *frame_us, int32_t *merged, double *pose_us)
 {
     // prefetch: 0 = every frame on its own; 1 = the next sweep's records cross PCIe while this one is registered
-    // (s2m_scan_prefetch_raw); 2 = the next frame's whole front half (copy, undistortion, voxel grid) runs beside this
-    // frame's map update (s2m_scan_prepare_raw, called where the reference's loop has the next message's IMU poses: after
-    // the update, before map_incremental).  pose_us[f] (optional) = records in -> pose out of frame f.
+    // (s2m_scan_prefetch_raw); 2 = that, and the next frame's undistortion and voxel grid run beside this frame's map
+    // update (s2m_scan_prepare_raw, called where the reference's loop has the next message's IMU poses: after the update,
+    // before map_incremental).  pose_us[f] (optional) = records in -> pose out of frame f.
     if (!e || frames < 0 || !records || !poses || !state_end || !x_prop || !P0 || !x || !frame_us || !merged) return S2M_ERR_ARG;
     double P[S2M_DIM * S2M_DIM];
     s2m_iter_log log;
@@ -114,7 +114,7 @@ int s2m_bench_frames(s2m_engine *e, int32_t frames, const float *records, int64_
         int64_t n_out = 0, na = 0, nb = 0;
         int rc = s2m_scan_set_from_raw(e, records, stride_floats, n, time_off_a, time_off_b, poses, n_poses, state_end, leaf, 0, &n_out);
         if (rc) return rc;
-        if (prefetch == 1 && f + 1 < frames) {
+        if (prefetch >= 1 && f + 1 < frames) {
             rc = s2m_scan_prefetch_raw(e, records, stride_floats, n);
             if (rc) return rc;
         }
