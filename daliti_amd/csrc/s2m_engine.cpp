@@ -536,6 +536,8 @@ int s2m_map_share(s2m_engine *e, const s2m_engine *owner)
         e->stats = o->stats;
     }
     e->grid = owner->grid;
+    e->map.ids_dense = owner->map.ids_dense;  // (the borrower's own map buffers stay empty; the getters ask this flag)
+    e->map.next_id = owner->map.next_id;
     e->built_cell = owner->built_cell;
     e->map_ready = true;
     e->map_borrowed = true;
@@ -567,7 +569,7 @@ int commit_update(s2m_engine *e)
     };
     const bool drift_before = drifted(e->grid.m);
     if (!e->no_merge && !drift_before) {
-        he = merge_update(e->map, e->grid, e->stats, e->upd.alive, e->upd.alive_s, e->upd.stage, e->upd.stage_n, merged, e->stream);
+        he = merge_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, merged, e->stream);
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "merge_update", he);
     }
     e->last_update_merged = merged;
@@ -683,6 +685,20 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     return commit_update(e);
 }
 
+namespace {
+// rank[position] = caller index of every sorted position: the point ids themselves while no point has been removed since
+// the last build, else their ranks (a sort of the ids: the getters that answer in caller indices are not on any hot path)
+int caller_index_table(s2m_engine *e, const uint32_t **rank)
+{
+    *rank = e->grid.pidx;
+    if (e->map.ids_dense) return S2M_OK;
+    int64_t live = 0;
+    S2M_HIP(e, caller_ranks(e->upd, e->grid, nullptr, rank, &live, e->stream));
+    if (live != e->grid.m) return fail(e, S2M_ERR_STATE, "map ids out of step with the map size");
+    return S2M_OK;
+}
+}  // namespace
+
 int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity, int64_t *m)
 {
     if (!e || !m) return fail(e, S2M_ERR_ARG, "null argument");
@@ -698,7 +714,10 @@ int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity, int64_t *m)
         if (rc) return rc;
         e->stage_cap = floats;
     }
-    launch_map_to_xyz(e->grid.pts, e->grid.pidx, e->grid.m, e->d_stage, e->stream);  // caller order
+    const uint32_t *rank = nullptr;
+    int rc = caller_index_table(e, &rank);
+    if (rc) return rc;
+    launch_map_to_xyz(e->grid.pts, rank, e->grid.m, e->d_stage, e->stream);  // caller order
     S2M_HIP(e, hipMemcpyAsync(xyz, e->d_stage, (size_t)floats * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     S2M_HIP(e, hipStreamSynchronize(e->stream));
     return S2M_OK;
@@ -1194,7 +1213,10 @@ int s2m_get_neighbors(s2m_engine *e, int32_t *idx, float *d2)
             e->stage_cap = words;
         }
         int32_t *tmp = reinterpret_cast<int32_t *>(e->d_stage);
-        launch_positions_to_indices(e->d_nn_idx, e->grid.pidx, words, tmp, e->stream);
+        const uint32_t *rank = nullptr;
+        int rc = caller_index_table(e, &rank);
+        if (rc) return rc;
+        launch_positions_to_indices(e->d_nn_idx, rank, words, tmp, e->stream);
         S2M_HIP(e, hipMemcpyAsync(idx, tmp, (size_t)words * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
         S2M_HIP(e, hipStreamSynchronize(e->stream));
     }
@@ -1210,8 +1232,11 @@ int s2m_map_get_order(s2m_engine *e, uint32_t *order, int64_t capacity, int64_t 
     if (!order || e->grid.m == 0) return S2M_OK;
     if (capacity < e->grid.m) return fail(e, S2M_ERR_CAPACITY, "order buffer too small");
     S2M_HIP(e, hipSetDevice(e->device));
+    const uint32_t *rank = nullptr;
+    int rc = caller_index_table(e, &rank);
+    if (rc) return rc;
     S2M_HIP(e, hipStreamSynchronize(e->stream));
-    S2M_HIP(e, hipMemcpy(order, e->grid.pidx, (size_t)e->grid.m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    S2M_HIP(e, hipMemcpy(order, rank, (size_t)e->grid.m * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return S2M_OK;
 }
 

@@ -38,7 +38,10 @@ constexpr int kSentinelPoints = 32;  // pts[m .. m+32): padding targets of the s
 struct MapBuffers {
     // owned by the engine, (re)allocated by build_map
     float4 *pts = nullptr;
-    uint32_t *pidx = nullptr;                   // caller index of every sorted position
+    uint32_t *pidx = nullptr;                   // point id of every sorted position: the caller's index after a build, ascending in
+                                                // caller order ever after (removals leave gaps; new points take next_id, next_id + 1, ...)
+    int64_t next_id = 0;
+    bool ids_dense = true;                      // the ids ARE the caller indices (no point was removed since the last build)
     float4 *pts2 = nullptr;
     uint32_t *pidx2 = nullptr;                  // the other halves of the double buffers a merge update writes into
     uint4 *top = nullptr;
@@ -84,18 +87,17 @@ int64_t map_allocations();  // device (re)allocations by the map build / merge /
 void note_allocation();
 // bricks / occupied_cells of the last build or merge (a merge does not wait for them: they arrive behind it)
 hipError_t resolve_stats(MapBuffers &buf, MapStats &stats);
-// The map after an update without a new sort (s2m_map.hip, "merge update"): alive[caller index] and alive_s[sorted
-// position] for the m old points (m + 1 readable bytes each), n_new staged points in their order.  merged = false (and nothing changed) when the
-// update cannot be merged -- a new point outside the grid, no room in the scratch arrays, empty map -- and the caller
-// falls back to update_finish + build_map.
-hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive, const uint8_t *alive_s,
+// The map after an update without a new sort (s2m_map.hip, "merge update"): alive_s[sorted position] for the m old points
+// (m + 1 readable bytes), n_new staged points in their order.  merged = false (and nothing changed) when the update cannot be
+// merged -- a new point outside the grid, no room in the scratch arrays, empty map -- and the caller falls back to
+// update_finish + build_map.
+hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive_s,
                         const float4 *stage, int64_t n_new, bool &merged, hipStream_t st);
 
 // ---- s2m_mapupd.hip : incremental map maintenance (map_incremental / Add_Points / Delete_Point_Boxes) ----
 struct UpdateBuffers {
-    uint8_t *alive = nullptr;      // per old point by caller index, 0 = removed by this update (m + 1 bytes)
-    uint8_t *alive_s = nullptr;    // the same flags by sorted position (position in Grid::pts)
-    int64_t alive_cap = 0, alive_s_cap = 0;
+    uint8_t *alive_s = nullptr;    // per old point by sorted position (position in Grid::pts), 0 = removed by this update (m + 1 bytes)
+    int64_t alive_s_cap = 0;
     uint32_t *counters = nullptr;  // [1] voxels rewritten (tmp_counter), [2] points deleted by boxes
     float4 *stage = nullptr;       // points to append, in order
     int64_t stage_cap = 0, stage_n = 0;
@@ -105,9 +107,9 @@ struct UpdateBuffers {
     uint32_t *val = nullptr, *val2 = nullptr, *cnt = nullptr, *best_idx = nullptr, *best_pos = nullptr, *add_flag = nullptr, *pos = nullptr;
     float *dnew = nullptr, *best_d = nullptr;
     int64_t batch_cap = 0;
-    // compaction of the old points
-    uint32_t *flag32 = nullptr, *pos_old = nullptr;
-    int64_t old_cap = 0;
+    // the map ordered by point id (rebuild path; caller-order getters): unsorted / sorted (id, position) pairs
+    uint32_t *flag32 = nullptr, *pos_old = nullptr, *ord_key = nullptr, *ord_val = nullptr;
+    int64_t ord_cap = 0;
     float4 *list = nullptr;        // the new point list handed to build_map
     int64_t list_cap = 0;
     void *tmp = nullptr;
@@ -139,7 +141,9 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
                          float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox = nullptr, bool begin_update = false);
 hipError_t xyz_to_float4(UpdateBuffers &u, const float *xyz_dev, int64_t stride, int64_t n, float4 **out, hipStream_t st);
 // the map in CALLER order as packed xyz (ikdtree.flatten's counterpart): xyz[3 * pidx[j]] = pts[j]
-void launch_map_to_xyz(const float4 *pts, const uint32_t *pidx, int64_t m, float *xyz, hipStream_t st);
+void launch_map_to_xyz(const float4 *pts, const uint32_t *rank, int64_t m, float *xyz, hipStream_t st);
+// rank[position] = dense caller index of every live position (cold path: a sort of the ids), 0xffffffff for a removed one
+hipError_t caller_ranks(UpdateBuffers &u, const Grid &g, const uint8_t *alive_s, const uint32_t **rank, int64_t *live, hipStream_t st);
 // caller indices of a neighbour list: out[i] = nn[i] >= 0 ? pidx[nn[i]] : -1
 void launch_positions_to_indices(const int32_t *nn, const uint32_t *pidx, int64_t count, int32_t *out, hipStream_t st);
 

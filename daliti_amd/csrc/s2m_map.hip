@@ -451,6 +451,8 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t1, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m,
                                       0, (unsigned)bits, st));
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, buf.vals_alt, buf.pts, buf.pidx);
+    buf.next_id = m;        // the ids of a fresh build are the caller's indices
+    buf.ids_dense = true;
     S2M_TRY(build_tables(buf, buf.keys_alt, m, top_entries, stats, st));
     stats.top_entries = top_entries;
     g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
@@ -507,37 +509,32 @@ hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, Ma
 // rank of the dead among the caller indices: a bit mask of the dead per 64 indices and the number of dead before
 // every word (312 KB + 625 KB at 5 M points: L2-resident, so renumbering a caller index costs two cache hits
 // instead of a gather from a 20 MB array)
-__global__ __launch_bounds__(256) void dead_words_kernel(int64_t m, const uint8_t *__restrict__ alive, const uint8_t *__restrict__ alive_s,
-                                                         unsigned long long *__restrict__ word, unsigned long long *__restrict__ word_s,
-                                                         unsigned long long *__restrict__ cnt, uint32_t *__restrict__ outside_flag)
+__global__ __launch_bounds__(256) void dead_words_kernel(int64_t m, const uint8_t *__restrict__ alive_s,
+                                                         unsigned long long *__restrict__ word_s, uint32_t *__restrict__ cnt,
+                                                         uint32_t *__restrict__ outside_flag)
 {
-    // the removed points twice: by caller index (alive: renumbering) and by sorted position (alive_s: where a survivor
-    // lands); the two counts of a word travel as the halves of one 64-bit element, so ONE scan gives both prefixes
+    // the removed points by sorted position: where a survivor lands.  (Point ids are stable -- s2m_kernels.h, MapBuffers::pidx
+    // -- so nothing is renumbered: rounds 2-3 also ranked the removed CALLER INDICES here and every survivor gathered its
+    // new index from that rank.)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { cnt[(m + 63) >> 6] = 0ull; *outside_flag = 0u; }  // the scan's spare element; merge_newkey_kernel's flag
-    const unsigned long long w = __ballot(i < m && alive[i] == 0);
+    if (i == 0) { cnt[(m + 63) >> 6] = 0u; *outside_flag = 0u; }  // the scan's spare element; merge_newkey_kernel's flag
     const unsigned long long ws = __ballot(i < m && alive_s[i] == 0);
     if ((threadIdx.x & 63) == 0 && (i >> 6) <= ((m - 1) >> 6)) {
-        word[i >> 6] = w;
         word_s[i >> 6] = ws;
-        cnt[i >> 6] = (unsigned long long)__popcll(w) | ((unsigned long long)__popcll(ws) << 32);
+        cnt[i >> 6] = (uint32_t)__popcll(ws);
     }
 }
-struct DeadRank {  // per 64 indices: mask of the removed ones, number removed before the word (one 16-byte gather)
+struct DeadRank {  // per 64 positions: mask of the removed ones, number removed before the word (one 16-byte gather)
     unsigned long long word;
     uint32_t prefix, pad;
 };
 // entry `words` (one past the last word) is an empty mask with the total as its prefix: a position may equal m
-__global__ __launch_bounds__(256) void dead_pack_kernel(int64_t words, const unsigned long long *__restrict__ word,
-                                                        const unsigned long long *__restrict__ word_s,
-                                                        const unsigned long long *__restrict__ prefix, DeadRank *__restrict__ out,
-                                                        DeadRank *__restrict__ out_s)
+__global__ __launch_bounds__(256) void dead_pack_kernel(int64_t words, const unsigned long long *__restrict__ word_s,
+                                                        const uint32_t *__restrict__ prefix, DeadRank *__restrict__ out_s)
 {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w > words) return;
-    const unsigned long long p = prefix[w];
-    out[w] = DeadRank{w < words ? word[w] : 0ull, (uint32_t)p, 0u};
-    out_s[w] = DeadRank{w < words ? word_s[w] : 0ull, (uint32_t)(p >> 32), 0u};
+    out_s[w] = DeadRank{w < words ? word_s[w] : 0ull, prefix[w], 0u};
 }
 __device__ __forceinline__ uint32_t dead_before(uint32_t ci, const DeadRank *__restrict__ rank)
 {
@@ -591,7 +588,7 @@ __global__ __launch_bounds__(256) void merge_lb_kernel(int n, const uint64_t *__
 // entries inside the wave's 64 positions
 __global__ __launch_bounds__(256) void merge_old_kernel(int64_t m, const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
                                                         const uint64_t *__restrict__ okeys,
-                                                        const uint8_t *__restrict__ alive_s, const DeadRank *__restrict__ rank,
+                                                        const uint8_t *__restrict__ alive_s,
                                                         const DeadRank *__restrict__ rank_s, const uint32_t *__restrict__ lb, int n_new,
                                                         float4 *__restrict__ npts, uint32_t *__restrict__ npidx,
                                                         uint64_t *__restrict__ nkeys_out)
@@ -609,33 +606,30 @@ __global__ __launch_bounds__(256) void merge_old_kernel(int64_t m, const float4 
     while (k < n_new && lb[k] <= (uint32_t)j) ++k;
     const uint32_t pos = ((uint32_t)j - dead_before((uint32_t)j, rank_s)) + (uint32_t)k;
     const float4 p = pts[j];
-    const uint32_t ci = pidx[j];
     npts[pos] = make_map_point(p.x, p.y, map_point_z(p), pos);
-    npidx[pos] = ci - dead_before(ci, rank);
+    npidx[pos] = pidx[j];  // the point keeps its id
     nkeys_out[pos] = okeys[j];
 }
 
 // new point i (sorted order) -> (survivors before its lb) + i
 __global__ __launch_bounds__(256) void merge_new_kernel(int n, const uint64_t *__restrict__ nkeys, const uint32_t *__restrict__ nvals,
                                                         const uint32_t *__restrict__ lb, const DeadRank *__restrict__ rank_s,
-                                                        const float4 *__restrict__ stage, uint32_t m_old,
-                                                        const uint32_t *__restrict__ dead_total,
+                                                        const float4 *__restrict__ stage, uint32_t next_id,
                                                         float4 *__restrict__ npts, uint64_t *__restrict__ nkeys_out,
                                                         uint32_t *__restrict__ npidx)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t survivors = m_old - *dead_total;  // (the host learns the number while this kernel is in the queue)
     const uint32_t l = lb[i];
     const uint32_t pos = (l - dead_before(l, rank_s)) + (uint32_t)i;
     const uint32_t t = nvals[i];
     const float4 p = stage[t];
     npts[pos] = make_map_point(p.x, p.y, p.z, pos);
     nkeys_out[pos] = nkeys[i];
-    npidx[pos] = survivors + t;
+    npidx[pos] = next_id + t;  // staged order = caller order of the new points
 }
 
-hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive, const uint8_t *alive_s,
+hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive_s,
                         const float4 *stage, int64_t n_new, bool &merged, hipStream_t st)
 {
     merged = false;
@@ -644,16 +638,15 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return hipSuccess;
     const int n = (int)n_new;
     const int64_t words = (m + 63) / 64;
-    // dword: [masks by caller index | masks by position | packed records by caller index | by position], words + 1 each;
-    // work_c: [the two dead counts of every word as one 64-bit element | their exclusive prefix]; mv: [stage positions |
-    // upper bounds] of the new points
+    // dword: [masks of the removed positions | packed records], words + 1 each; work_c: [removed per word | exclusive prefix];
+    // mv: [stage positions | upper bounds] of the new points
     const int64_t w1 = words + 2;  // (even offsets keep the 16-byte records aligned)
-    S2M_TRY(ensure((void **)&buf.dword, &buf.dword_cap, 6 * w1 + 2, sizeof(unsigned long long), 6 * (words / 4 + 1024)));
-    unsigned long long *word = buf.dword, *word_s = buf.dword + w1 + (w1 & 1);
-    DeadRank *rank = reinterpret_cast<DeadRank *>(buf.dword + 2 * (w1 + (w1 & 1)));
-    DeadRank *rank_s = rank + w1;
-    unsigned long long *dcnt = reinterpret_cast<unsigned long long *>(buf.work_c), *dprefix = dcnt + (words + 1);
-    if ((int64_t)(2 * (words + 1) * sizeof(unsigned long long)) > (buf.scratch_cap + 1) * (int64_t)sizeof(uint32_t)) return hipSuccess;
+    S2M_TRY(ensure((void **)&buf.dword, &buf.dword_cap, 3 * w1 + 2, sizeof(unsigned long long), 3 * (words / 4 + 1024)));
+    unsigned long long *word_s = buf.dword;
+    DeadRank *rank_s = reinterpret_cast<DeadRank *>(buf.dword + (w1 + (w1 & 1)));
+    uint32_t *dcnt = buf.work_c, *dprefix = buf.work_c + (words + 1);
+    if (2 * (words + 1) > buf.scratch_cap + 1) return hipSuccess;
+    if (buf.next_id + n_new >= ((int64_t)1 << 32) - 2) return hipSuccess;  // ids exhausted: a rebuild makes them dense again
     unsigned kbits = 10;  // (brick << 9 | cell) of this grid
     {
         const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
@@ -663,7 +656,7 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     const int64_t m_bound = m + n_new;
     if (m_bound > buf.scratch_cap || m_bound >= ((int64_t)1 << 31)) return hipSuccess;
     size_t tmp = 0, tmp3 = 0;
-    S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, dcnt, dprefix, 0ull, (size_t)words + 1, rocprim::plus<unsigned long long>(), st));
+    S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
     if (n > 0)
         S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, buf.keys, buf.keys, buf.vals, buf.vals, (size_t)n_new, 0, kbits, st));
     S2M_TRY(ensure_sort_tmp(buf, std::max(tmp, tmp3)));
@@ -674,14 +667,12 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     S2M_TRY(ensure((void **)&buf.pts2, &buf.pts2_cap, m_bound + kSentinelPoints, sizeof(float4), headroom_for(m_bound)));
     S2M_TRY(ensure((void **)&buf.pidx2, &buf.pidx2_cap, m_bound + 1, sizeof(uint32_t), headroom_for(m_bound)));
 
-    // the removed points' ranks, by caller index and by position (element `words` of the counts is zero: the prefix there
-    // is the total, in both halves)
-    hipLaunchKernelGGL(dead_words_kernel, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, st, m, alive, alive_s, word, word_s, dcnt,
+    // the rank of the removed positions (element `words` of the counts is zero: the prefix there is the total)
+    hipLaunchKernelGGL(dead_words_kernel, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, st, m, alive_s, word_s, dcnt,
                        buf.counters + 8);
     size_t t = buf.sort_tmp_bytes;
-    S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, dcnt, dprefix, 0ull, (size_t)words + 1, rocprim::plus<unsigned long long>(), st));
-    hipLaunchKernelGGL(dead_pack_kernel, dim3((unsigned)((words + 256) / 256)), dim3(256), 0, st, words, word, word_s, dprefix, rank,
-                       rank_s);
+    S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL(dead_pack_kernel, dim3((unsigned)((words + 256) / 256)), dim3(256), 0, st, words, word_s, dprefix, rank_s);
     uint64_t *nk_sorted = buf.mk;
     uint32_t *nv_sorted = buf.mv, *lb = buf.mv + n_new;
     // keys of the new points in the CURRENT grid (keys / vals are free until the merge writes them); the kernel also says
@@ -691,7 +682,7 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
                            buf.counters + 8);
     // the one hand-back -- number of dead, "a new point lies outside the grid" -- is posted here and collected after the
     // merge kernels have been enqueued: they write into the spare arrays, which only become the map if the answer allows it
-    const uint32_t *dead_dev = reinterpret_cast<const uint32_t *>(dprefix + words);
+    const uint32_t *dead_dev = dprefix + words;
     {
         const uint32_t *src[2] = {dead_dev, buf.counters + 8};
         S2M_TRY(mail_post(buf.mail, src, 2, st));
@@ -702,10 +693,10 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
         hipLaunchKernelGGL(merge_lb_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, buf.keys_alt, m, lb);
     }
     hipLaunchKernelGGL(merge_old_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.pts, buf.pidx, buf.keys_alt,
-                       alive_s, rank, rank_s, lb, n, buf.pts2, buf.pidx2, buf.keys);
+                       alive_s, rank_s, lb, n, buf.pts2, buf.pidx2, buf.keys);
     if (n > 0)
         hipLaunchKernelGGL(merge_new_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, nv_sorted, lb, rank_s, stage,
-                           (uint32_t)m, dead_dev, buf.pts2, buf.keys, buf.pidx2);
+                           (uint32_t)buf.next_id, buf.pts2, buf.keys, buf.pidx2);
     uint32_t dead = 0, outside = 0;
     {
         uint32_t v[2] = {0, 0};
@@ -721,6 +712,8 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     const int64_t survivors = m - (int64_t)dead;
     const int64_t m_new = survivors + n_new;
     if (m_new == 0) return hipSuccess;
+    buf.next_id += n_new;
+    if (dead > 0) buf.ids_dense = false;
     S2M_TRY(put_sentinels(buf.pts2, m_new, st));
     // the merged arrays become the map
     std::swap(buf.pts, buf.pts2); std::swap(buf.pts_cap, buf.pts2_cap);

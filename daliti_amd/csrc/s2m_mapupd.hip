@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void add_resolve_kernel(Grid g, const float4 *
                                                           const uint32_t *__restrict__ best_idx,
                                                           const uint32_t *__restrict__ best_pos,
                                                           const float *__restrict__ best_d,
-                                                          uint8_t *__restrict__ alive, uint8_t *__restrict__ alive_s,
+                                                          uint8_t *__restrict__ alive_s,
                                                           uint32_t *__restrict__ add_flag, uint32_t *__restrict__ counters,
                                                           const unsigned long long *__restrict__ vtab)
 {
@@ -248,15 +248,15 @@ __global__ __launch_bounds__(256) void add_resolve_kernel(Grid g, const float4 *
     if (rewrite && c > (keep != 0xffffffffu ? 1u : 0u)) {
         const Voxel v = voxel_of(pw.x, pw.y, pw.z, ds);
         for_points_in_box(g, v.mn, v.mx, [&](const float4 &, uint32_t idx, uint32_t pos) {
-            if (idx != keep) { alive[idx] = 0; alive_s[pos] = 0; }  // by caller index and by sorted position
+            if (idx != keep) alive_s[pos] = 0;  // removed, by sorted position
         }, sub, kBoxLanes);
     }
 }
 
-// over the SORTED array (coordinates and, beside it, the caller indices): both alive arrays are written without a gather
-__global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx, int64_t m,
+// over the SORTED array
+__global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restrict__ pts, int64_t m,
                                                            const float *__restrict__ boxes, int nb,
-                                                           uint8_t *__restrict__ alive, uint8_t *__restrict__ alive_s,
+                                                           uint8_t *__restrict__ alive_s,
                                                            uint32_t *__restrict__ counters)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restr
             const float mn[3] = {bx[0], bx[1], bx[2]}, mx[3] = {bx[3], bx[4], bx[5]};
             hit = in_box(p, mn, mx);
         }
-        if (hit) { alive_s[j] = 0; alive[pidx[j]] = 0; }
+        if (hit) alive_s[j] = 0;
     }
     // one atomic per workgroup: a field-of-view trim deletes 1e5..1e6 points, per-point atomics on one
     // address would take milliseconds
@@ -277,25 +277,41 @@ __global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restr
     if (threadIdx.x == 0 && cnt) atomicAdd(&counters[2], (uint32_t)cnt);
 }
 
-__global__ __launch_bounds__(256) void flags_to_u32_kernel(const uint8_t *__restrict__ a, int64_t m,
-                                                           uint32_t *__restrict__ out)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) out[i] = a[i] ? 1u : 0u;
-}
-
-// survivors of the map in CALLER order: sorted position j holds caller index ci = pidx[j]; it goes to pos[ci]
-// (exclusive scan of the alive flags over the caller indices)
-__global__ __launch_bounds__(256) void scatter_survivors_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
-                                                                const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
-                                                                int64_t m, float4 *__restrict__ out)
+// survivors of the map in CALLER order = ascending point id: (id or ~0 for a removed point, position) pairs are sorted by
+// id, the first `survivors` positions are gathered
+__global__ __launch_bounds__(256) void id_key_kernel(const uint32_t *__restrict__ pidx, const uint8_t *__restrict__ alive_s, int64_t m,
+                                                     uint32_t *__restrict__ key, uint32_t *__restrict__ val)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    const uint32_t ci = pidx[j];
-    if (!flag[ci]) return;
-    const float4 q = pts[j];
-    out[pos[ci]] = make_float4(q.x, q.y, map_point_z(q), 0.0f);
+    key[j] = (!alive_s || alive_s[j]) ? pidx[j] : 0xffffffffu;
+    val[j] = (uint32_t)j;
+}
+// number of keys below ~0 in the sorted keys (one thread: a binary search)
+__global__ void live_count_kernel(const uint32_t *__restrict__ skey, int64_t m, uint32_t *__restrict__ out)
+{
+    int64_t lo = 0, hi = m;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (skey[mid] != 0xffffffffu) lo = mid + 1; else hi = mid;
+    }
+    *out = (uint32_t)lo;
+}
+__global__ __launch_bounds__(256) void gather_by_order_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ order,
+                                                              const uint32_t *__restrict__ count, float4 *__restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (int64_t)*count) return;
+    const float4 q = pts[order[r]];
+    out[r] = make_float4(q.x, q.y, map_point_z(q), 0.0f);
+}
+// rank[position] = r for the r-th smallest live id: the dense caller index of every live position
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const uint32_t *__restrict__ order, const uint32_t *__restrict__ skey, int64_t m,
+                                                           uint32_t *__restrict__ rank)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    rank[order[r]] = skey[r] != 0xffffffffu ? (uint32_t)r : 0xffffffffu;
 }
 
 // out[pos[i]] = src[i] for flagged i (pos = exclusive scan of the flags), shifted by base; with a winner table, every
@@ -387,13 +403,13 @@ __global__ __launch_bounds__(256) void xyz_to_float4_kernel(const float *__restr
 }
 
 // ikdtree.flatten's counterpart: the map in the caller's index order, packed xyz
-__global__ __launch_bounds__(256) void map_to_xyz_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
+__global__ __launch_bounds__(256) void map_to_xyz_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ rank,
                                                          int64_t m, float *__restrict__ xyz)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < m) {
+    if (j < m && rank[j] != 0xffffffffu) {
         const float4 p = pts[j];
-        const int64_t i = pidx[j];
+        const int64_t i = rank[j];
         xyz[3 * i] = p.x; xyz[3 * i + 1] = p.y; xyz[3 * i + 2] = map_point_z(p);
     }
 }
@@ -512,8 +528,8 @@ static hipError_t grow(T **p, int64_t *cap, int64_t need, bool keep = false, hip
 
 void free_update(UpdateBuffers &u)
 {
-    void *ptrs[] = {u.alive, u.alive_s, u.counters, u.stage, u.key, u.key2, u.val, u.val2, u.dnew, u.cnt, u.best_idx, u.best_pos, u.best_d,
-                    u.add_flag, u.pos, u.flag32, u.pos_old, u.list, u.tmp, u.boxes, u.cvt, u.vtab};
+    void *ptrs[] = {u.alive_s, u.counters, u.stage, u.key, u.key2, u.val, u.val2, u.dnew, u.cnt, u.best_idx, u.best_pos, u.best_d,
+                    u.add_flag, u.pos, u.flag32, u.pos_old, u.ord_key, u.ord_val, u.list, u.tmp, u.boxes, u.cvt, u.vtab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_mailbox(u.mail);
@@ -539,41 +555,27 @@ static hipError_t scan_u32(UpdateBuffers &u, const uint32_t *in, uint32_t *out, 
     return rocprim::exclusive_scan(u.tmp, b2, in, out, 0u, (size_t)n, rocprim::plus<uint32_t>(), st);
 }
 
-// number of set flags = pos[n-1] + flag[n-1]
-static hipError_t count_flags(UpdateBuffers &u, const uint32_t *flag, const uint32_t *pos, int64_t n, int64_t *out, hipStream_t st)
-{
-    *out = 0;
-    if (n <= 0) return hipSuccess;
-    const uint32_t *src[2] = {pos + (n - 1), flag + (n - 1)};
-    uint32_t v[2] = {0, 0};
-    S2M_TRY(mail_fetch(u.mail, src, 2, v, st));
-    *out = (int64_t)v[0] + v[1];
-    return hipSuccess;
-}
-
-// every old point alive (both orders), the update's counters zero: one launch (three memsets are six on this stack)
-__global__ __launch_bounds__(256) void update_reset_kernel(int64_t bytes, uint8_t *__restrict__ alive, uint8_t *__restrict__ alive_s,
+// every old point alive, the update's counters zero: one launch (memsets are two launches each on this stack)
+__global__ __launch_bounds__(256) void update_reset_kernel(int64_t bytes, uint8_t *__restrict__ alive_s,
                                                            uint32_t *__restrict__ counters)
 {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0u;
     if (i + 16 <= bytes) {
         const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-        *reinterpret_cast<uint4 *>(alive + i) = ones;
         *reinterpret_cast<uint4 *>(alive_s + i) = ones;
     } else {
-        for (int64_t k = i; k < bytes; ++k) { alive[k] = 1; alive_s[k] = 1; }
+        for (int64_t k = i; k < bytes; ++k) alive_s[k] = 1;
     }
 }
 
 hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st)
 {
-    S2M_TRY(grow(&u.alive, &u.alive_cap, g.m + 1));
     S2M_TRY(grow(&u.alive_s, &u.alive_s_cap, g.m + 1));
     if (!u.counters) S2M_TRY(hipMalloc((void **)&u.counters, 64));
     {
         const int64_t bytes = g.m + 1;
-        hipLaunchKernelGGL(update_reset_kernel, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, st, bytes, u.alive, u.alive_s,
+        hipLaunchKernelGGL(update_reset_kernel, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, st, bytes, u.alive_s,
                            u.counters);
     }
     u.stage_n = 0;
@@ -665,7 +667,7 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
         S2M_TRY(mail_fetch(u.mail, src, 1, &before, st));
     }
     hipLaunchKernelGGL(add_resolve_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, rkey, rval, u.dnew,
-                       u.cnt, u.best_idx, u.best_pos, u.best_d, u.alive, u.alive_s, u.add_flag, u.counters, vtab);
+                       u.cnt, u.best_idx, u.best_pos, u.best_d, u.alive_s, u.add_flag, u.counters, vtab);
     // winners, in batch order, go to the staging list
     S2M_TRY(scan_u32(u, u.add_flag, u.pos, n, st));
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage, u.key, vtab);
@@ -686,8 +688,7 @@ hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_hos
     S2M_TRY(hipMemcpyAsync(u.boxes, boxes_host, (size_t)nb * 6 * sizeof(float), hipMemcpyHostToDevice, st));
     // counters[2] is zero at update_begin and only this entry point adds to it: the count after the launch, minus
     // what earlier calls of the same update reported
-    hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.pts, g.pidx, g.m, u.boxes, nb, u.alive,
-                       u.alive_s, u.counters);
+    hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.pts, g.m, u.boxes, nb, u.alive_s, u.counters);
     const uint32_t *src[1] = {u.counters + 2};
     uint32_t after = 0;
     S2M_TRY(mail_fetch(u.mail, src, 1, &after, st));
@@ -696,28 +697,60 @@ hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_hos
     return hipGetLastError();
 }
 
-// survivors (index order) followed by the staged appends -> u.list; *m_out = new size
+// (id, position) pairs of the map sorted by id into u.ord_key / u.ord_val (removed points last); *live = their number
+static hipError_t order_by_id(UpdateBuffers &u, const Grid &g, const uint8_t *alive_s, int64_t *live, hipStream_t st)
+{
+    *live = 0;
+    if (g.m <= 0) return hipSuccess;
+    if (u.ord_cap < g.m) {
+        int64_t c;
+        c = u.ord_cap; S2M_TRY(grow(&u.flag32, &c, g.m));
+        c = u.ord_cap; S2M_TRY(grow(&u.pos_old, &c, g.m));
+        c = u.ord_cap; S2M_TRY(grow(&u.ord_key, &c, g.m));
+        c = u.ord_cap; S2M_TRY(grow(&u.ord_val, &c, g.m));
+        u.ord_cap = c;
+    }
+    hipLaunchKernelGGL(id_key_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.pidx, alive_s, g.m, u.flag32, u.pos_old);
+    size_t bytes = 0;
+    S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, u.flag32, u.ord_key, u.pos_old, u.ord_val, (size_t)g.m, 0, 32, st));
+    S2M_TRY(ensure_tmp(u, bytes));
+    size_t b2 = u.tmp_bytes;
+    S2M_TRY(rocprim::radix_sort_pairs(u.tmp, b2, u.flag32, u.ord_key, u.pos_old, u.ord_val, (size_t)g.m, 0, 32, st));
+    if (!u.counters) {
+        S2M_TRY(hipMalloc((void **)&u.counters, 64));
+        S2M_TRY(hipMemsetAsync(u.counters, 0, 64, st));
+    }
+    hipLaunchKernelGGL(live_count_kernel, dim3(1), dim3(1), 0, st, u.ord_key, g.m, u.counters + 14);
+    const uint32_t *src[1] = {u.counters + 14};
+    uint32_t v = 0;
+    S2M_TRY(mail_fetch(u.mail, src, 1, &v, st));
+    *live = v;
+    return hipSuccess;
+}
+
+// survivors (ascending id = caller order) followed by the staged appends -> u.list; *m_out = new size
 hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStream_t st)
 {
     int64_t survivors = 0;
-    if (g.m > 0) {
-        if (u.old_cap < g.m) {
-            int64_t c;
-            c = u.old_cap; S2M_TRY(grow(&u.flag32, &c, g.m));
-            c = u.old_cap; S2M_TRY(grow(&u.pos_old, &c, g.m));
-            u.old_cap = c;
-        }
-        hipLaunchKernelGGL(flags_to_u32_kernel, dim3(nblk(g.m)), dim3(256), 0, st, u.alive, g.m, u.flag32);
-        S2M_TRY(scan_u32(u, u.flag32, u.pos_old, g.m, st));
-        S2M_TRY(count_flags(u, u.flag32, u.pos_old, g.m, &survivors, st));
-    }
+    S2M_TRY(order_by_id(u, g, u.alive_s, &survivors, st));
     S2M_TRY(grow(&u.list, &u.list_cap, survivors + u.stage_n));
-    if (g.m > 0)
-        hipLaunchKernelGGL(scatter_survivors_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.pts, g.pidx, u.flag32, u.pos_old, g.m,
-                           u.list);
+    if (survivors > 0)
+        hipLaunchKernelGGL(gather_by_order_kernel, dim3(nblk(survivors)), dim3(256), 0, st, g.pts, u.ord_val, u.counters + 14, u.list);
     if (u.stage_n > 0)
         S2M_TRY(hipMemcpyAsync(u.list + survivors, u.stage, (size_t)u.stage_n * sizeof(float4), hipMemcpyDeviceToDevice, st));
     *m_out = survivors + u.stage_n;
+    return hipGetLastError();
+}
+
+// rank[position] = dense caller index (the rank of the point's id among the live points); alive_s == nullptr: every
+// position below g.m is live.  Cold path: the getters that answer in caller indices / caller order.
+hipError_t caller_ranks(UpdateBuffers &u, const Grid &g, const uint8_t *alive_s, const uint32_t **rank, int64_t *live, hipStream_t st)
+{
+    *rank = nullptr;
+    S2M_TRY(order_by_id(u, g, alive_s, live, st));
+    if (g.m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3(nblk(g.m)), dim3(256), 0, st, u.ord_val, u.ord_key, g.m, u.flag32);
+    *rank = u.flag32;
     return hipGetLastError();
 }
 
