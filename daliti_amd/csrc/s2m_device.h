@@ -43,7 +43,8 @@ struct Grid {
     const uint32_t *tab;
     const float4 *pts;
     const uint32_t *pidx;
-    int64_t m;
+    int64_t m;          // extent of pts (the sentinel block starts here)
+    int64_t live;       // points in the map: m after a build or a merge; in-place updates leave holes at the ends of bricks
     uint32_t sent_off;  // byte offset of the sentinel block pts[m..m+32) (valid while it fits 32 bits), else 0
 };
 

@@ -58,6 +58,8 @@ struct s2m_engine {
     Mailbox mail;                   // stream waits of the per-frame entry points (polled, not hipStreamSynchronize)
     bool in_batch = false;          // set while the handle is served by s2m_iterated_update_batch with several scans
     bool no_merge = false;          // S2M_NO_MERGE=1: every update rebuilds the grid from scratch (A/B and tests)
+    bool no_slab = false;           // S2M_NO_SLAB=1: no in-place update of the touched bricks, every update merges (A/B and tests)
+    int64_t n_inplace = 0;          // updates applied in place (counted among the merged ones too)
     bool last_update_merged = false;
     int64_t n_merged = 0, n_rebuilt = 0, n_regrid = 0;  // how this handle's map updates were produced (s2m_map_update_stats)
     std::mutex stats_mu;            // the lazily fetched counts of a merged update may be asked for by borrowers' threads
@@ -423,6 +425,7 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
         if (v >= 0 && v <= 2) { e->spec_mode = v; e->spec_env = true; }
     }
     e->no_merge = std::getenv("S2M_NO_MERGE") != nullptr;
+    e->no_slab = std::getenv("S2M_NO_SLAB") != nullptr;
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&e->ev[i]) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_block, S2M_BLOCK_DOUBLES * sizeof(double)) == hipSuccess;
@@ -546,6 +549,13 @@ int s2m_map_share(s2m_engine *e, const s2m_engine *owner)
 }
 
 namespace {
+// what the update kernels need to know about the map's layout (s2m_kernels.h, UpdateBuffers)
+void bind_update(s2m_engine *e)
+{
+    e->upd.bmark = e->map.bmark;
+    e->upd.layout_gen = e->map.layout_gen;
+}
+
 // the map after an update: merged into the sorted arrays when possible (s2m_map.hip, merge_update), else rebuilt
 // from upd.list (survivors in index order, then the staged points) -- the same caller order either way
 int commit_update(s2m_engine *e)
@@ -567,9 +577,14 @@ int commit_update(s2m_engine *e)
         const double mean = (double)m / (double)e->stats.occupied_cells;
         return mean < 5.5 || mean > 22.0;
     };
-    const bool drift_before = drifted(e->grid.m);
-    if (!e->no_merge && !drift_before) {
-        he = merge_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, merged, e->stream);
+    const bool drift_before = drifted(e->grid.live);
+    if (!e->no_merge && !e->no_slab && !drift_before) {  // in place when every touched brick fits where it stands
+        he = slab_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, e->upd.counters + 9, merged, e->stream);
+        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "slab_update", he);
+        if (merged) ++e->n_inplace;
+    }
+    if (!e->no_merge && !drift_before && !merged) {
+        he = merge_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, merged, e->stream, !e->no_slab);
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "merge_update", he);
     }
     e->last_update_merged = merged;
@@ -615,6 +630,7 @@ int s2m_map_add(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int 
     if (rc) return rc;
     float4 *np = nullptr;
     S2M_HIP(e, xyz_to_float4(e->upd, dev, stride, n, &np, e->stream));
+    bind_update(e);
     S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
     int64_t added = 0;
     S2M_HIP(e, update_add(e->upd, e->grid, np, n, downsample_on != 0, downsample_size, &added, e->stream));
@@ -628,6 +644,7 @@ int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
     if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
     S2M_HIP(e, hipSetDevice(e->device));
+    bind_update(e);
     S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
     int64_t del = 0;
     S2M_HIP(e, update_delete(e->upd, e->grid, boxes, (int)n, &del, e->stream));
@@ -675,6 +692,7 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
         if (rc) return rc;
     }
     VoxBox vox;
+    bind_update(e);
     S2M_HIP(e, incr_classify(e->upd, pose, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, (int)e->n,
                              e->d_nn_idx, e->grid, e->nn_valid && ekf_inited != 0, filter_size_map, &la, &na, &lb, &nb, e->stream,
                              &vox, true));   // (update_begin runs inside, while the counts travel to the host)
@@ -694,7 +712,7 @@ int caller_index_table(s2m_engine *e, const uint32_t **rank)
     if (e->map.ids_dense) return S2M_OK;
     int64_t live = 0;
     S2M_HIP(e, caller_ranks(e->upd, e->grid, nullptr, rank, &live, e->stream));
-    if (live != e->grid.m) return fail(e, S2M_ERR_STATE, "map ids out of step with the map size");
+    if (live != e->grid.live) return fail(e, S2M_ERR_STATE, "map ids out of step with the map size");
     return S2M_OK;
 }
 }  // namespace
@@ -703,12 +721,12 @@ int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity, int64_t *m)
 {
     if (!e || !m) return fail(e, S2M_ERR_ARG, "null argument");
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map");
-    *m = e->grid.m;
+    *m = e->grid.live;
     if (!xyz) return S2M_OK;
-    if (capacity < e->grid.m) return fail(e, S2M_ERR_CAPACITY, "point buffer too small");
-    if (e->grid.m == 0) return S2M_OK;
+    if (capacity < e->grid.live) return fail(e, S2M_ERR_CAPACITY, "point buffer too small");
+    if (e->grid.live == 0) return S2M_OK;
     S2M_HIP(e, hipSetDevice(e->device));
-    const int64_t floats = e->grid.m * 3;
+    const int64_t floats = e->grid.live * 3;
     if (floats > e->stage_cap) {
         int rc = grow(e, &e->d_stage, floats);
         if (rc) return rc;
@@ -726,7 +744,7 @@ int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity, int64_t *m)
 int s2m_map_size(const s2m_engine *e, int64_t *m)
 {
     if (!e || !m) return S2M_ERR_ARG;
-    *m = e->map_ready ? e->grid.m : 0;
+    *m = e->map_ready ? e->grid.live : 0;
     return S2M_OK;
 }
 
@@ -751,7 +769,7 @@ int s2m_map_info(const s2m_engine *ce, double info[8])
     info[4] = (double)e->stats.bricks;
     info[5] = (double)e->stats.top_entries;
     info[6] = (double)e->stats.occupied_cells;
-    info[7] = e->stats.occupied_cells ? (double)e->grid.m / (double)e->stats.occupied_cells : 0.0;
+    info[7] = e->stats.occupied_cells ? (double)e->grid.live / (double)e->stats.occupied_cells : 0.0;
     return S2M_OK;
 }
 
@@ -1245,6 +1263,13 @@ int s2m_map_grid(const s2m_engine *e, int32_t cells[3])
     if (!e || !cells) return S2M_ERR_ARG;
     if (!e->map_ready) return S2M_ERR_STATE;
     cells[0] = e->grid.ncx; cells[1] = e->grid.ncy; cells[2] = e->grid.ncz;
+    return S2M_OK;
+}
+
+int s2m_map_inplace_updates(const s2m_engine *e, int64_t *n)
+{
+    if (!e || !n) return S2M_ERR_ARG;
+    *n = e->n_inplace;
     return S2M_OK;
 }
 

@@ -56,6 +56,10 @@ struct MapBuffers {
     uint32_t *rank = nullptr;    // per top entry (+1): number of occupied bricks before it
     uint32_t *bstart = nullptr;  // per occupied brick: first position in pts
     int64_t rank_cap = 0, bstart_cap = 0;
+    uint32_t *bkey = nullptr;    // per occupied brick: its index in the top array (the high part of its points' keys)
+    uint8_t *bmark = nullptr;    // per occupied brick: bit 0 = a point of it was removed, bit 1 = a new point goes into it (this update)
+    int64_t bkey_cap = 0, bmark_cap = 0;
+    uint64_t layout_gen = 0;     // counts builds and merges: a new dense layout of pts (in-place updates keep the layout)
     uint64_t *mk = nullptr;      // merge update: sorted keys of the new points
     uint32_t *mv = nullptr;      // merge update: their stage positions, then their lower bounds among the old keys
     int64_t mk_cap = 0, mv_cap = 0;
@@ -92,12 +96,19 @@ hipError_t resolve_stats(MapBuffers &buf, MapStats &stats);
 // merged -- a new point outside the grid, no room in the scratch arrays, empty map -- and the caller falls back to
 // update_finish + build_map.
 hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive_s,
-                        const float4 *stage, int64_t n_new, bool &merged, hipStream_t st);
+                        const float4 *stage, int64_t n_new, bool &merged, hipStream_t st, bool with_slack = false);
+// The same update in place when every touched brick still fits where it stands (s2m_map.hip, slab_update): done = false and
+// nothing touched otherwise.  flags: three zeroed words of the update's counters.
+hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t n_new,
+                       uint32_t *flags, bool &done, hipStream_t st);
 
 // ---- s2m_mapupd.hip : incremental map maintenance (map_incremental / Add_Points / Delete_Point_Boxes) ----
 struct UpdateBuffers {
-    uint8_t *alive_s = nullptr;    // per old point by sorted position (position in Grid::pts), 0 = removed by this update (m + 1 bytes)
+    uint8_t *alive_s = nullptr;    // per sorted position (position in Grid::pts): 1 = holds a point; 0 = removed by this update, or a
+                                   // hole an in-place update left (m + 1 bytes)
     int64_t alive_s_cap = 0;
+    uint64_t alive_gen = ~0ull, layout_gen = 0;  // alive_s was made for layout alive_gen; the map's layout now (set by the engine)
+    uint8_t *bmark = nullptr;      // the map's per-brick marks (MapBuffers::bmark, set by the engine): bit 0 = a point of the brick was removed
     uint32_t *counters = nullptr;  // [1] voxels rewritten (tmp_counter), [2] points deleted by boxes
     float4 *stage = nullptr;       // points to append, in order
     int64_t stage_cap = 0, stage_n = 0;

@@ -161,7 +161,8 @@ struct TopOccupied {
 
 __global__ __launch_bounds__(256) void brick_assign_kernel(int64_t top_entries, uint4 *__restrict__ top,
                                                            const uint32_t *__restrict__ rank,
-                                                           uint32_t *__restrict__ bstart, uint32_t *__restrict__ occ)
+                                                           uint32_t *__restrict__ bstart, uint32_t *__restrict__ bkey,
+                                                           uint32_t *__restrict__ occ)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b < kOccShards) occ[b * 32] = 0u;  // the occupied-cell counters brick_table_kernel adds to
@@ -171,14 +172,52 @@ __global__ __launch_bounds__(256) void brick_assign_kernel(int64_t top_entries, 
     const uint32_t id = rank[b];
     reinterpret_cast<uint32_t *>(&top[b])[0] = id + 1u;
     bstart[id] = y - 1u;
+    bkey[id] = (uint32_t)b;  // the brick's place in the top array = the high part of its points' keys
 }
 
+
+// One wave: t[512] holds the first position of every non-empty cell of a brick (0xffffffff = empty), e the end of the
+// brick's points.  Writes the brick's 513 prefix words (an empty cell takes the start of the next non-empty one) and returns
+// this lane's number of non-empty cells; mask = the brick's occupied (z,y) rows (row = lane).
+__device__ __forceinline__ int table_from_firsts(const uint32_t *t, uint32_t e, uint32_t *__restrict__ out, int lane, unsigned long long &mask)
+{
+    int cells = 0;
+    uint32_t v[8];
+    uint32_t mn = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        v[k] = t[lane * 8 + k];
+        mn = min(mn, v[k]);
+        cells += v[k] != 0xffffffffu ? 1 : 0;
+    }
+    // row lane = (z,y) row of the brick: occupied when any of its eight cells is
+    mask = __ballot(mn != 0xffffffffu);
+    // suffix-min over the lanes behind this one, seeded with the brick end
+    uint32_t suf = mn;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_down(suf, off, 64);
+        if (lane + off < 64) suf = min(suf, o);
+    }
+    uint32_t nxt = __shfl_down(suf, 1, 64);
+    if (lane == 63) nxt = e;
+    nxt = min(nxt, e);
+#pragma unroll
+    for (int k = 7; k >= 0; --k) {
+        if (v[k] == 0xffffffffu) v[k] = nxt;
+        nxt = v[k];
+        out[lane * 8 + k] = v[k];
+    }
+    if (lane == 0) out[kBrickCells] = e;
+    return cells;
+}
 
 // bricks_dev: the number of occupied bricks when the host only knows an upper bound for it (merge update)
 __global__ __launch_bounds__(256) void brick_table_kernel(int64_t bricks, const uint32_t *__restrict__ bricks_dev, int64_t m,
                                                           const uint64_t *__restrict__ keys,
                                                           const uint32_t *__restrict__ bstart, uint4 *__restrict__ top,
-                                                          uint32_t *__restrict__ tab, uint32_t *__restrict__ occ)
+                                                          uint32_t *__restrict__ tab, uint32_t *__restrict__ occ,
+                                                          uint8_t *__restrict__ bmark)
 {
     __shared__ uint32_t lds[4][kBrickCells];
     if (bricks_dev) bricks = (int64_t)*bricks_dev;
@@ -197,38 +236,13 @@ __global__ __launch_bounds__(256) void brick_table_kernel(int64_t bricks, const 
             if (j == s || keys[j - 1] != k) t[(uint32_t)k & 511u] = j;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        uint32_t v[8];
-        uint32_t mn = 0xffffffffu;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            v[k] = t[lane * 8 + k];
-            mn = min(mn, v[k]);
-            cells += v[k] != 0xffffffffu ? 1 : 0;
-        }
-        // row lane = (z,y) row of the brick: occupied when any of its eight cells is
-        const unsigned long long mask = __ballot(mn != 0xffffffffu);
-        // suffix-min over the lanes behind this one, seeded with the brick end
-        uint32_t suf = mn;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_down(suf, off, 64);
-            if (lane + off < 64) suf = min(suf, o);
-        }
-        uint32_t nxt = __shfl_down(suf, 1, 64);
-        if (lane == 63) nxt = e;
-        nxt = min(nxt, e);
-        uint32_t *out = tab + id * kBrickStride;
-#pragma unroll
-        for (int k = 7; k >= 0; --k) {
-            if (v[k] == 0xffffffffu) v[k] = nxt;
-            nxt = v[k];
-            out[lane * 8 + k] = v[k];
-        }
+        unsigned long long mask;
+        cells = table_from_firsts(t, e, tab + id * kBrickStride, lane, mask);
         if (lane == 0) {
-            out[kBrickCells] = e;
             uint32_t *te = reinterpret_cast<uint32_t *>(&top[keys[s] >> 9]);
             te[2] = (uint32_t)mask;
             te[3] = (uint32_t)(mask >> 32);
+            bmark[id] = 0;  // no in-place update pending on a fresh layout (slab_update)
         }
     }
 #pragma unroll
@@ -265,7 +279,7 @@ static inline int64_t headroom_for(int64_t m) { return m / 4 + 65536; }
 void free_map(MapBuffers &b)
 {
     void *ptrs[] = {b.pts, b.pidx, b.pts2, b.pidx2, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.work_a, b.work_b,
-                    b.work_c, b.rank, b.bstart, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
+                    b.work_c, b.rank, b.bstart, b.bkey, b.bmark, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b.h_stats) { (void)hipHostFree(b.h_stats); (void)hipEventDestroy(b.stats_event); }
@@ -362,12 +376,15 @@ static hipError_t build_tables(MapBuffers &buf, const uint64_t *keys, int64_t m,
     }
     S2M_TRY(ensure((void **)&buf.tab, &buf.tab_cap, bricks * kBrickStride, sizeof(uint32_t), (bricks / 4 + 64) * kBrickStride));
     S2M_TRY(ensure((void **)&buf.bstart, &buf.bstart_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
+    S2M_TRY(ensure((void **)&buf.bkey, &buf.bkey_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
+    S2M_TRY(ensure((void **)&buf.bmark, &buf.bmark_cap, bricks, sizeof(uint8_t), bricks / 4 + 64));
     hipLaunchKernelGGL(brick_assign_kernel, dim3((unsigned)((top_entries + 255) / 256)), dim3(256), 0, st, top_entries,
-                       buf.top, buf.rank, buf.bstart, buf.counters + 64);
+                       buf.top, buf.rank, buf.bstart, buf.bkey, buf.counters + 64);
     if (bricks > 0)
         hipLaunchKernelGGL(brick_table_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks,
                            lazy ? buf.rank + top_entries : (const uint32_t *)nullptr, m, keys, buf.bstart, buf.top, buf.tab,
-                           buf.counters + 64);
+                           buf.counters + 64, buf.bmark);
+    ++buf.layout_gen;  // a fresh dense layout: every position below m holds a point
     if (!buf.h_stats) {
         S2M_TRY(hipHostMalloc((void **)&buf.h_stats, (1 + kOccShards) * sizeof(uint32_t), hipHostMallocMapped));
         S2M_TRY(hipHostGetDevicePointer((void **)&buf.h_stats_dev, buf.h_stats, 0));
@@ -397,6 +414,7 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     g.c = cell;
     g.inv_c = 1.0f / cell;
     g.m = m;
+    g.live = m;
     g.sent_off = (m + kSentinelPoints) < ((int64_t)1 << 28) ? (uint32_t)(m << 4) : 0u;
     // one cell of padding below the box; extents rounded up to whole bricks.  The origin is shifted
     // by an odd fraction of a cell per axis: man-made scenes have planes at round coordinates, and a
@@ -629,8 +647,113 @@ __global__ __launch_bounds__(256) void merge_new_kernel(int n, const uint64_t *_
     npidx[pos] = next_id + t;  // staged order = caller order of the new points
 }
 
+// ---- slack for the in-place updates -------------------------------------------------------------------------
+// A merge (or a rebuild inside an update) leaves the points densely packed; slab_update can only rewrite a brick where it
+// stands while the brick fits between its first position and the next brick's.  So a map that is being maintained gets
+// room behind every brick: an eighth of its points, 16 to 512 positions.  One more pass over the map on the frames that
+// merge anyway (the frames in between are the ones that stay in place): the points move to `position + slack of the bricks
+// before`, the holes are filled with sentinel points (never a neighbour: +inf distance), id ~0 and the brick's largest key
+// (the key array stays sorted), prefix words and brick starts are shifted.
+__global__ __launch_bounds__(256) void slack_size_kernel(int64_t bound, const uint32_t *__restrict__ bricks_dev, int64_t m,
+                                                         const uint32_t *__restrict__ bstart, uint32_t *__restrict__ slack)
+{
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id > bound) return;
+    const int64_t bricks = (int64_t)*bricks_dev;
+    uint32_t v = 0u;
+    if (id < bricks) {
+        const uint32_t cnt = (id + 1 < bricks ? bstart[id + 1] : (uint32_t)m) - bstart[id];
+        v = min(max(cnt >> 3, 16u), 512u);
+    }
+    slack[id] = v;
+}
+__global__ __launch_bounds__(256) void slack_move_kernel(int64_t m, const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
+                                                         const uint64_t *__restrict__ keys, const uint4 *__restrict__ top,
+                                                         const uint32_t *__restrict__ shift, float4 *__restrict__ npts,
+                                                         uint32_t *__restrict__ npidx, uint64_t *__restrict__ nkeys)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t k = keys[j];
+    const uint32_t dst = (uint32_t)j + shift[top[k >> 9].x - 1u];
+    const float4 p = pts[j];
+    npts[dst] = make_map_point(p.x, p.y, map_point_z(p), dst);
+    npidx[dst] = pidx[j];
+    nkeys[dst] = k;
+}
+// one wave per brick: the holes behind it, its prefix words and its start
+__global__ __launch_bounds__(256) void slack_brick_kernel(const uint32_t *__restrict__ bricks_dev, int64_t m, uint32_t *__restrict__ bstart,
+                                                          const uint32_t *__restrict__ bkey, const uint32_t *__restrict__ shift,
+                                                          uint32_t *__restrict__ tab, float4 *__restrict__ npts,
+                                                          uint32_t *__restrict__ npidx, uint64_t *__restrict__ nkeys)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t bricks = (int64_t)*bricks_dev;
+    const int64_t id = (int64_t)blockIdx.x * 4 + wave;
+    if (id >= bricks) return;
+    const uint32_t e0 = id + 1 < bricks ? bstart[id + 1] : (uint32_t)m;  // the brick's end in the dense layout (starts are shifted by a later launch)
+    const uint32_t sh = shift[id], room = shift[id + 1] - sh;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    uint32_t *t = tab + id * kBrickStride;
+    for (int c = lane; c <= kBrickCells; c += 64) t[c] += sh;
+    const uint64_t filler = ((uint64_t)bkey[id] << 9) | 511ull;
+    for (uint32_t h = e0 + sh + (uint32_t)lane; h < e0 + sh + room; h += 64u) {
+        npts[h] = make_map_point(3.0e38f, 3.0e38f, 3.0e38f, 0xffffffffu);
+        npidx[h] = 0xffffffffu;
+        nkeys[h] = filler;
+    }
+}
+// (a separate launch: a wave of slack_brick_kernel reads its successor's start)
+__global__ __launch_bounds__(256) void slack_start_kernel(const uint32_t *__restrict__ bricks_dev, const uint32_t *__restrict__ shift,
+                                                          uint32_t *__restrict__ bstart)
+{
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < (int64_t)*bricks_dev) bstart[id] += shift[id];
+}
+
+// dense layout of m points (buf.pts / pidx / keys_alt, tables built) -> layout with slack; g.m becomes the new extent
+static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bound, int64_t top_entries, hipStream_t st)
+{
+    const int64_t m = g.m;
+    if (m <= 0 || bricks_bound <= 0) return hipSuccess;
+    const int64_t room_bound = m / 8 + 16 * bricks_bound + 64;  // slack <= max(cnt / 8, 16) per brick
+    const int64_t ext_bound = m + room_bound;
+    if (ext_bound > buf.scratch_cap || ext_bound >= ((int64_t)1 << 31) || bricks_bound + 2 > buf.scratch_cap) return hipSuccess;  // stays dense
+    S2M_TRY(ensure((void **)&buf.pts2, &buf.pts2_cap, ext_bound + kSentinelPoints, sizeof(float4), headroom_for(ext_bound)));
+    S2M_TRY(ensure((void **)&buf.pidx2, &buf.pidx2_cap, ext_bound + 1, sizeof(uint32_t), headroom_for(ext_bound)));
+    const uint32_t *bricks_dev = buf.rank + top_entries;
+    uint32_t *slack = buf.work_a, *shift = buf.work_b;
+    size_t tmp = 0;
+    S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, slack, shift, 0u, (size_t)bricks_bound + 1, rocprim::plus<uint32_t>(), st));
+    S2M_TRY(ensure_sort_tmp(buf, tmp));
+    hipLaunchKernelGGL(slack_size_kernel, dim3((unsigned)((bricks_bound + 256) / 256)), dim3(256), 0, st, bricks_bound, bricks_dev, m,
+                       buf.bstart, slack);
+    size_t t = buf.sort_tmp_bytes;
+    S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, slack, shift, 0u, (size_t)bricks_bound + 1, rocprim::plus<uint32_t>(), st));
+    {   // the total room: the map's new extent
+        const uint32_t *src[1] = {shift + bricks_bound};
+        S2M_TRY(mail_post(buf.mail, src, 1, st));
+    }
+    hipLaunchKernelGGL(slack_move_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.pts, buf.pidx, buf.keys_alt,
+                       buf.top, shift, buf.pts2, buf.pidx2, buf.keys);
+    hipLaunchKernelGGL(slack_brick_kernel, dim3((unsigned)((bricks_bound + 3) / 4)), dim3(256), 0, st, bricks_dev, m, buf.bstart, buf.bkey,
+                       shift, buf.tab, buf.pts2, buf.pidx2, buf.keys);
+    hipLaunchKernelGGL(slack_start_kernel, dim3((unsigned)((bricks_bound + 255) / 256)), dim3(256), 0, st, bricks_dev, shift, buf.bstart);
+    uint32_t room = 0;
+    S2M_TRY(mail_collect(buf.mail, 1, &room, st));
+    const int64_t ext = m + (int64_t)room;
+    S2M_TRY(put_sentinels(buf.pts2, ext, st));
+    std::swap(buf.pts, buf.pts2); std::swap(buf.pts_cap, buf.pts2_cap);
+    std::swap(buf.pidx, buf.pidx2); std::swap(buf.pidx_cap, buf.pidx2_cap);
+    std::swap(buf.keys, buf.keys_alt);
+    g.m = ext;
+    g.sent_off = (ext + kSentinelPoints) < ((int64_t)1 << 28) ? (uint32_t)(ext << 4) : 0u;
+    g.pts = buf.pts; g.pidx = buf.pidx;
+    return hipGetLastError();
+}
+
 hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive_s,
-                        const float4 *stage, int64_t n_new, bool &merged, hipStream_t st)
+                        const float4 *stage, int64_t n_new, bool &merged, hipStream_t st, bool with_slack)
 {
     merged = false;
     const int64_t m = g.m;
@@ -722,14 +845,243 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
     S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(top_entries + 1) * sizeof(uint4), st));
     g.m = m_new;
+    g.live = m_new;
     g.sent_off = (m_new + kSentinelPoints) < ((int64_t)1 << 28) ? (uint32_t)(m_new << 4) : 0u;
     // every new point opens at most one brick: no read-back before the tables are built
     const int64_t brick_bound = std::min<int64_t>(stats.bricks + n_new, std::min<int64_t>(top_entries, m_new));
     S2M_TRY(build_tables(buf, buf.keys_alt, m_new, top_entries, stats, st, brick_bound));
     stats.top_entries = top_entries;
     g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
+    if (with_slack) S2M_TRY(spread_with_slack(buf, g, brick_bound, top_entries, st));
     merged = true;
     return hipSuccess;
+}
+
+// ---- in-place update: only the touched bricks are rewritten -------------------------------------------------
+// The merge update above moves every point of the map; what an ordinary frame changes is a few thousand voxels in a few
+// hundred bricks.  When every touched brick still fits the stretch of pts it owns -- [its first position, the next brick's
+// first position): a fresh layout leaves no slack, but every removal does -- and no new point opens a brick, each touched
+// brick is rewritten where it stands by one workgroup: survivors and new points staged in LDS, merged by cell (new points
+// behind the old ones of their cell: ascending id, the documented order), written back with their keys and ids, the
+// brick's 513 prefix words and row mask rebuilt from the merged cells; what is left of the stretch becomes a hole
+// (alive_s 0, id ~0, the brick's largest key so that the key array stays sorted for the next merge).  Positions outside the
+// touched bricks do not move, so the cost follows the scan, not the map.  Anything else -- a brick that would overflow, a
+// new brick, a point outside the grid, a brick too large to stage -- is decided on the device BEFORE anything is written
+// and falls back to the merge update (which lays the map out densely again).
+constexpr int kSlabMax = 2048;  // points of one brick the rewrite stages in LDS (47 KB: three workgroups per CU)
+enum : uint32_t { kSlabOutside = 1u, kSlabNewBrick = 2u, kSlabOverflow = 4u };
+
+__global__ __launch_bounds__(256) void slab_key_kernel(const float4 *__restrict__ stage, int n, Grid g, uint64_t *__restrict__ keys,
+                                                       uint32_t *__restrict__ vals, uint8_t *__restrict__ bmark,
+                                                       uint32_t *__restrict__ flags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t f = 0u;
+    if (i < n) {
+        const float4 p = stage[i];
+        const float fx = floorf((p.x - g.ox) * g.inv_c), fy = floorf((p.y - g.oy) * g.inv_c), fz = floorf((p.z - g.oz) * g.inv_c);
+        const bool out = !(fx >= 0.0f && fx <= (float)(g.ncx - 1) && fy >= 0.0f && fy <= (float)(g.ncy - 1) && fz >= 0.0f &&
+                           fz <= (float)(g.ncz - 1));
+        const int cx = cell_of(p.x, g.ox, g.inv_c, g.ncx), cy = cell_of(p.y, g.oy, g.inv_c, g.ncy),
+                  cz = cell_of(p.z, g.oz, g.inv_c, g.ncz);
+        const uint64_t brick = ((uint64_t)(cz >> 3) * g.nby + (cy >> 3)) * g.nbx + (cx >> 3);
+        const uint32_t local = (uint32_t)((((cz & 7) << 3) | (cy & 7)) << 3 | (cx & 7));
+        keys[i] = (brick << 9) | local;
+        vals[i] = (uint32_t)i;
+        if (out) {
+            f = kSlabOutside;
+        } else {
+            const uint32_t idp1 = g.top[brick].x;
+            if (idp1 == 0u) f = kSlabNewBrick;
+            else bmark[idp1 - 1u] |= 2u;  // (every writer of this byte in this launch stores the same value)
+        }
+    }
+    const unsigned long long any = __ballot(f != 0u);
+    if (any != 0ull) {
+        uint32_t w = f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) w |= __shfl_xor(w, off, 64);
+        if ((threadIdx.x & 63) == 0) atomicOr(flags, w);
+    }
+}
+
+// first index in the sorted keys whose brick part is >= b
+__device__ __forceinline__ int slab_lower(const uint64_t *__restrict__ nk, int n, uint64_t b)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((nk[mid] >> 9) < b) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// one wave per brick: does the touched brick fit where it stands?  flags[0] |= overflow, flags[1] += points removed
+__global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restrict__ bricks_dev, int64_t m,
+                                                        const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ tab,
+                                                        const uint32_t *__restrict__ bkey, const uint8_t *__restrict__ bmark,
+                                                        const uint8_t *__restrict__ alive_s, const uint64_t *__restrict__ nk, int n_new,
+                                                        uint32_t *__restrict__ flags)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t bricks = (int64_t)*bricks_dev;
+    const int64_t id = (int64_t)blockIdx.x * 4 + wave;
+    if (id >= bricks || bmark[id] == 0) return;
+    const uint32_t base = tab[id * kBrickStride], end = tab[id * kBrickStride + kBrickCells];
+    const uint32_t cap_end = id + 1 < bricks ? bstart[id + 1] : (uint32_t)m;
+    int alive = 0;
+    for (uint32_t j = base + (uint32_t)lane; j < end; j += 64u) alive += alive_s[j] ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) alive += __shfl_xor(alive, off, 64);
+    if (lane != 0) return;
+    const uint64_t b = bkey[id];
+    const int n_b = n_new > 0 ? slab_lower(nk, n_new, b + 1) - slab_lower(nk, n_new, b) : 0;
+    const uint32_t total = (uint32_t)alive + (uint32_t)n_b;
+    if (total > cap_end - base || total > (uint32_t)kSlabMax || end - base > (uint32_t)kSlabMax) atomicOr(flags, kSlabOverflow);
+    atomicAdd(flags + 1, (end - base) - (uint32_t)alive);
+}
+
+// one workgroup per touched brick (see the comment above); does nothing when the plan found a reason not to
+__global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__restrict__ bricks_dev, const uint32_t *__restrict__ flags,
+                                                           float4 *__restrict__ pts, uint32_t *__restrict__ pidx,
+                                                           uint64_t *__restrict__ keys, uint8_t *__restrict__ alive_s,
+                                                           uint32_t *__restrict__ tab, uint4 *__restrict__ top,
+                                                           const uint32_t *__restrict__ bkey, uint8_t *__restrict__ bmark,
+                                                           const uint64_t *__restrict__ nk, const uint32_t *__restrict__ nv, int n_new,
+                                                           const float4 *__restrict__ stage, uint32_t next_id)
+{
+    __shared__ float4 l_p[kSlabMax];
+    __shared__ uint32_t l_id[kSlabMax];
+    __shared__ uint16_t l_c[kSlabMax];
+    __shared__ uint32_t l_t[kBrickCells];
+    __shared__ int wsum[4];
+    if (*flags != 0u) return;
+    const int64_t id = blockIdx.x;
+    if (id >= (int64_t)*bricks_dev || bmark[id] == 0) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const uint32_t base = tab[id * kBrickStride], cnt = tab[id * kBrickStride + kBrickCells] - base;
+    const uint64_t bk = bkey[id];
+    // a. the survivors, in order, into LDS
+    int n_old = 0;
+    for (uint32_t c0 = 0; c0 < cnt; c0 += 256u) {
+        const uint32_t i = c0 + (uint32_t)tid;
+        const bool a = i < cnt && alive_s[base + i] != 0;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t pid = 0u, cell = 0u;
+        if (a) { p = pts[base + i]; pid = pidx[base + i]; cell = (uint32_t)keys[base + i] & 511u; }
+        const unsigned long long bal = __ballot(a);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = n_old;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        const int chunk = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (a) {
+            const int r = off + __popcll(bal & ((1ull << lane) - 1ull));
+            l_p[r] = p; l_id[r] = pid; l_c[r] = (uint16_t)cell;
+        }
+        n_old += chunk;
+        __syncthreads();
+    }
+    // b. the brick's new points behind them (sorted by cell; equal cells in staged = id order: the sort is stable)
+    int lo = 0, n_b = 0;
+    if (n_new > 0) { lo = slab_lower(nk, n_new, bk); n_b = slab_lower(nk, n_new, bk + 1) - lo; }
+    for (int k = tid; k < n_b; k += 256) {
+        const uint32_t t = nv[lo + k];
+        l_p[n_old + k] = stage[t];
+        l_id[n_old + k] = next_id + t;
+        l_c[n_old + k] = (uint16_t)((uint32_t)nk[lo + k] & 511u);
+    }
+    for (int c = tid; c < kBrickCells; c += 256) l_t[c] = 0xffffffffu;
+    __syncthreads();
+    // c. merged places: an old point goes behind the new points of EARLIER cells, a new one behind the old points of its
+    // own and earlier cells
+    const int total = n_old + n_b;
+    for (int e = tid; e < total; e += 256) {
+        const uint32_t c = l_c[e];
+        int dlo = 0, dhi = 0, dest;
+        if (e < n_old) {
+            dhi = n_b;  // first new k with cell >= c
+            while (dlo < dhi) { const int mid = (dlo + dhi) >> 1; if (l_c[n_old + mid] < c) dlo = mid + 1; else dhi = mid; }
+            dest = e + dlo;
+        } else {
+            dhi = n_old;  // first old r with cell > c
+            while (dlo < dhi) { const int mid = (dlo + dhi) >> 1; if (l_c[mid] <= c) dlo = mid + 1; else dhi = mid; }
+            dest = (e - n_old) + dlo;
+        }
+        const uint32_t pos = base + (uint32_t)dest;
+        const float4 p = l_p[e];
+        // (a survivor holds {x, y, position, z}, a staged point {x, y, z, -})
+        pts[pos] = e < n_old ? make_map_point(p.x, p.y, map_point_z(p), pos) : make_map_point(p.x, p.y, p.z, pos);
+        pidx[pos] = l_id[e];
+        keys[pos] = (bk << 9) | (uint64_t)c;
+        alive_s[pos] = 1;
+        atomicMin(&l_t[c], pos);
+    }
+    for (uint32_t h = (uint32_t)total + (uint32_t)tid; h < cnt; h += 256u) {  // what the brick no longer fills
+        alive_s[base + h] = 0;
+        pidx[base + h] = 0xffffffffu;
+        keys[base + h] = (bk << 9) | 511ull;
+    }
+    __syncthreads();
+    // d. prefix words and row mask
+    if (wave == 0) {
+        unsigned long long mask;
+        (void)table_from_firsts(l_t, base + (uint32_t)total, tab + id * kBrickStride, lane, mask);
+        if (lane == 0) {
+            uint32_t *te = reinterpret_cast<uint32_t *>(&top[bk]);
+            te[2] = (uint32_t)mask;
+            te[3] = (uint32_t)(mask >> 32);
+            bmark[id] = 0;
+        }
+    }
+}
+
+// flags: three zeroed words of the update's counters (outcome bits, points removed, spare).  done = the map was updated in
+// place; otherwise nothing was touched and the caller goes on to merge_update.
+hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t n_new,
+                       uint32_t *flags, bool &done, hipStream_t st)
+{
+    done = false;
+    const int64_t m = g.m;
+    if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || !buf.bmark || stats.bricks <= 0 || m > buf.scratch_cap) return hipSuccess;
+    if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return hipSuccess;
+    if (buf.next_id + n_new >= ((int64_t)1 << 32) - 2) return hipSuccess;
+    const int n = (int)n_new;
+    const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
+    const uint32_t *bricks_dev = buf.rank + top_entries;
+    uint64_t *nk_sorted = buf.mk;
+    uint32_t *nv_sorted = buf.mv;
+    if (n > 0) {
+        unsigned kbits = 10;
+        while (kbits < 64 && ((int64_t)1 << (kbits - 9)) < top_entries) ++kbits;
+        size_t tmp = 0;
+        S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp, buf.keys, buf.keys, buf.vals, buf.vals, (size_t)n_new, 0, kbits, st));
+        S2M_TRY(ensure_sort_tmp(buf, tmp));
+        S2M_TRY(ensure((void **)&buf.mk, &buf.mk_cap, n_new, sizeof(uint64_t), n_new / 2 + 4096));
+        S2M_TRY(ensure((void **)&buf.mv, &buf.mv_cap, 2 * n_new, sizeof(uint32_t), n_new + 8192));
+        nk_sorted = buf.mk;
+        nv_sorted = buf.mv;
+        hipLaunchKernelGGL(slab_key_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals, buf.bmark, flags);
+        size_t t = buf.sort_tmp_bytes;
+        S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, nk_sorted, buf.vals, nv_sorted, (size_t)n_new, 0, kbits, st));
+    }
+    const int64_t bricks = stats.bricks;  // (an upper bound while a merged update's counts are on their way)
+    hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, m, buf.bstart, buf.tab,
+                       buf.bkey, buf.bmark, alive_s, nk_sorted, n, flags);
+    {
+        const uint32_t *src[2] = {flags, flags + 1};
+        S2M_TRY(mail_post(buf.mail, src, 2, st));
+    }
+    hipLaunchKernelGGL(slab_rewrite_kernel, dim3((unsigned)bricks), dim3(256), 0, st, bricks_dev, flags, buf.pts, buf.pidx, buf.keys_alt,
+                       alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, nk_sorted, nv_sorted, n, stage, (uint32_t)buf.next_id);
+    uint32_t v[2] = {0, 0};
+    S2M_TRY(mail_collect(buf.mail, 2, v, st));
+    if (v[0] != 0u) return hipSuccess;  // the rewrite kernel saw the same word and left everything alone
+    g.live += n_new - (int64_t)v[1];
+    buf.next_id += n_new;
+    if (v[1] > 0u) buf.ids_dense = false;
+    done = true;
+    return hipGetLastError();
 }
 
 // AoS (caller stride) -> SoA scan arrays; feats_down keeps only x, y, z on this path

@@ -120,7 +120,7 @@ __device__ __forceinline__ void for_points_in_box(const Grid &g, const float (&m
                 for (uint32_t i = tb[l0] + sub; i < e; i += stride) {
                     const float4 q = g.pts[i];  // {x, y, position, z}
                     const float4 p = make_float4(q.x, q.y, map_point_z(q), 0.0f);
-                    if (in_box(p, mn, mx)) f(p, g.pidx[i], i);  // caller index (4-byte read beside the point), position
+                    if (in_box(p, mn, mx)) f(p, g.pidx[i], i, te.x - 1u);  // point id (4-byte read beside the point), position, brick
                 }
             }
         }
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void add_probe_kernel(Grid g, const float4 *__
     uint32_t c = 0, bi = 0xffffffffu, bp = 0u;
     float bd = INFINITY;
     if (live)
-        for_points_in_box(g, v.mn, v.mx, [&](const float4 &q, uint32_t idx, uint32_t pos) {
+        for_points_in_box(g, v.mn, v.mx, [&](const float4 &q, uint32_t idx, uint32_t pos, uint32_t) {
             ++c;
             const float d = dist2(q.x, q.y, q.z, v.mid);
             if (d < bd || (d == bd && idx < bi)) { bd = d; bi = idx; bp = pos; }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void add_resolve_kernel(Grid g, const float4 *
                                                           const float *__restrict__ best_d,
                                                           uint8_t *__restrict__ alive_s,
                                                           uint32_t *__restrict__ add_flag, uint32_t *__restrict__ counters,
-                                                          const unsigned long long *__restrict__ vtab)
+                                                          const unsigned long long *__restrict__ vtab, uint8_t *__restrict__ bmark)
 {
     // kBoxLanes lanes per sorted position: all of them take the (cheap) decision, the walk that marks the voxel's old
     // points is shared between them
@@ -247,16 +247,16 @@ __global__ __launch_bounds__(256) void add_resolve_kernel(Grid g, const float4 *
     if (rw != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)rw) - 1)) atomicAdd(&counters[1], (uint32_t)__popcll(rw));
     if (rewrite && c > (keep != 0xffffffffu ? 1u : 0u)) {
         const Voxel v = voxel_of(pw.x, pw.y, pw.z, ds);
-        for_points_in_box(g, v.mn, v.mx, [&](const float4 &, uint32_t idx, uint32_t pos) {
-            if (idx != keep) alive_s[pos] = 0;  // removed, by sorted position
+        for_points_in_box(g, v.mn, v.mx, [&](const float4 &, uint32_t idx, uint32_t pos, uint32_t brick) {
+            if (idx != keep) { alive_s[pos] = 0; bmark[brick] |= 1u; }  // removed (by sorted position); its brick is touched
         }, sub, kBoxLanes);
     }
 }
 
 // over the SORTED array
-__global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restrict__ pts, int64_t m,
+__global__ __launch_bounds__(256) void delete_boxes_kernel(Grid g, const float4 *__restrict__ pts, int64_t m,
                                                            const float *__restrict__ boxes, int nb,
-                                                           uint8_t *__restrict__ alive_s,
+                                                           uint8_t *__restrict__ alive_s, uint8_t *__restrict__ bmark,
                                                            uint32_t *__restrict__ counters)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,7 +269,14 @@ __global__ __launch_bounds__(256) void delete_boxes_kernel(const float4 *__restr
             const float mn[3] = {bx[0], bx[1], bx[2]}, mx[3] = {bx[3], bx[4], bx[5]};
             hit = in_box(p, mn, mx);
         }
-        if (hit) alive_s[j] = 0;
+        if (hit) {
+            alive_s[j] = 0;
+            // the brick that holds the point is touched (same cell arithmetic as the build)
+            const int cx = min(max((int)floorf((p.x - g.ox) * g.inv_c), 0), g.ncx - 1), cy = min(max((int)floorf((p.y - g.oy) * g.inv_c), 0), g.ncy - 1),
+                      cz = min(max((int)floorf((p.z - g.oz) * g.inv_c), 0), g.ncz - 1);
+            const uint32_t idp1 = g.top[((int64_t)(cz >> 3) * g.nby + (cy >> 3)) * g.nbx + (cx >> 3)].x;
+            if (idp1) bmark[idp1 - 1u] |= 1u;
+        }
     }
     // one atomic per workgroup: a field-of-view trim deletes 1e5..1e6 points, per-point atomics on one
     // address would take milliseconds
@@ -556,27 +563,40 @@ static hipError_t scan_u32(UpdateBuffers &u, const uint32_t *in, uint32_t *out, 
 }
 
 // every old point alive, the update's counters zero: one launch (memsets are two launches each on this stack)
-__global__ __launch_bounds__(256) void update_reset_kernel(int64_t bytes, uint8_t *__restrict__ alive_s,
+__global__ __launch_bounds__(256) void update_reset_kernel(int64_t bytes, uint8_t *__restrict__ alive_s, const uint32_t *__restrict__ pidx,
                                                            uint32_t *__restrict__ counters)
 {
+    // a position holds a point unless its id says "hole" (the slack a merge leaves behind every brick)
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
     if (blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0u;
-    if (i + 16 <= bytes) {
-        const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-        *reinterpret_cast<uint4 *>(alive_s + i) = ones;
+    if (i + 16 <= bytes - 1) {
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 id = *reinterpret_cast<const uint4 *>(pidx + i + 4 * q);
+            w[q] = (id.x != 0xffffffffu ? 1u : 0u) | (id.y != 0xffffffffu ? 0x100u : 0u) | (id.z != 0xffffffffu ? 0x10000u : 0u) |
+                   (id.w != 0xffffffffu ? 0x1000000u : 0u);
+        }
+        *reinterpret_cast<uint4 *>(alive_s + i) = make_uint4(w[0], w[1], w[2], w[3]);
     } else {
-        for (int64_t k = i; k < bytes; ++k) alive_s[k] = 1;
+        for (int64_t k = i; k < bytes; ++k) alive_s[k] = (k < bytes - 1 && pidx[k] != 0xffffffffu) ? 1 : 0;
     }
 }
 
 hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st)
 {
+    const uint8_t *before = u.alive_s;
     S2M_TRY(grow(&u.alive_s, &u.alive_s_cap, g.m + 1));
     if (!u.counters) S2M_TRY(hipMalloc((void **)&u.counters, 64));
     {
-        const int64_t bytes = g.m + 1;
-        hipLaunchKernelGGL(update_reset_kernel, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, st, bytes, u.alive_s,
-                           u.counters);
+        // alive_s says which positions hold a point.  It is all ones on a fresh layout (build / merge: layout_gen moved) and
+        // stays as the in-place updates left it otherwise (holes at the ends of rewritten bricks): then only the counters
+        // are zeroed
+        const bool fresh = u.alive_gen != u.layout_gen || before != u.alive_s || before == nullptr;
+        u.alive_gen = u.layout_gen;
+        const int64_t bytes = fresh ? g.m + 1 : 0;
+        hipLaunchKernelGGL(update_reset_kernel, dim3((unsigned)std::max<int64_t>((bytes + 4095) / 4096, 1)), dim3(256), 0, st, bytes, u.alive_s,
+                           g.pidx, u.counters);
     }
     u.stage_n = 0;
     u.deleted_reported = 0;
@@ -667,7 +687,7 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
         S2M_TRY(mail_fetch(u.mail, src, 1, &before, st));
     }
     hipLaunchKernelGGL(add_resolve_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, rkey, rval, u.dnew,
-                       u.cnt, u.best_idx, u.best_pos, u.best_d, u.alive_s, u.add_flag, u.counters, vtab);
+                       u.cnt, u.best_idx, u.best_pos, u.best_d, u.alive_s, u.add_flag, u.counters, vtab, u.bmark);
     // winners, in batch order, go to the staging list
     S2M_TRY(scan_u32(u, u.add_flag, u.pos, n, st));
     hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage, u.key, vtab);
@@ -688,7 +708,7 @@ hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_hos
     S2M_TRY(hipMemcpyAsync(u.boxes, boxes_host, (size_t)nb * 6 * sizeof(float), hipMemcpyHostToDevice, st));
     // counters[2] is zero at update_begin and only this entry point adds to it: the count after the launch, minus
     // what earlier calls of the same update reported
-    hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g.pts, g.m, u.boxes, nb, u.alive_s, u.counters);
+    hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g, g.pts, g.m, u.boxes, nb, u.alive_s, u.bmark, u.counters);
     const uint32_t *src[1] = {u.counters + 2};
     uint32_t after = 0;
     S2M_TRY(mail_fetch(u.mail, src, 1, &after, st));

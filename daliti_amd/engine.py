@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_scan_prefetch_raw", "s2m_scan_prepare_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
     "s2m_iterated_update", "s2m_iterated_update_batch", "s2m_iterated_update_multi", "s2m_iterated_update_sharded",
-    "s2m_complete_neighbors", "s2m_map_get_order", "s2m_map_grid", "s2m_map_update_stats", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_init_shm", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
+    "s2m_complete_neighbors", "s2m_map_get_order", "s2m_map_grid", "s2m_map_update_stats", "s2m_map_inplace_updates", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_init_shm", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
     "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats", "s2m_bet_stats",
 ]
 
@@ -206,8 +206,15 @@ class Engine:
         self._ck(self.lib.s2m_map_update_stats(self.h, st))
         return dict(merged=st[0], rebuilt=st[1], regridded=st[2], allocations=st[3])
 
+    def map_inplace_updates(self):
+        """Updates applied in place (only the touched bricks rewritten): s2m_map_inplace_updates."""
+        n = C.c_int64()
+        self._ck(self.lib.s2m_map_inplace_updates(self.h, C.byref(n)))
+        return n.value
+
     def map_order(self):
-        """order[j] = caller index of the point at sorted position j (the engine's tie order)."""
+        """order[j] = caller index of the point at sorted position j (the engine's tie order); 0xffffffff where an in-place
+        update left a hole."""
         m = C.c_int64()
         self._ck(self.lib.s2m_map_get_order(self.h, None, C.c_int64(0), C.byref(m)))
         out = np.zeros(max(m.value, 1), np.uint32)
@@ -223,6 +230,7 @@ class Engine:
     def map_rank(self):
         """rank[i] = sorted position of caller index i: what the oracle takes as the tie order of equal distances."""
         order = self.map_order()
+        order = order[order != 0xffffffff]          # holes do not take part in the order
         rank = np.empty(len(order), np.uint32)
         rank[order] = np.arange(len(order), dtype=np.uint32)
         return rank

@@ -163,11 +163,18 @@ int s2m_map_last_update(const s2m_engine *e, int32_t *merged);
  * rebuilt it, stats[2] = rebuilds that also chose a new cell size (density drift), stats[3] = device buffer
  * (re)allocations made by map builds and updates so far (process-wide). */
 int s2m_map_update_stats(const s2m_engine *e, int64_t stats[4]);
+/* How many of the merged updates (s2m_map_update_stats, stats[0]) were applied IN PLACE: only the bricks the update touched
+ * were rewritten where they stand -- possible when each of them still fits the stretch of the point array it owns and no new
+ * point opens a brick; cost proportional to the update, not to the map (ikd-Tree inserts per point in O(log M),
+ * ikd_Tree.cpp:477-573).  Every other update re-lays the whole map out (merge) or rebuilds the grid.  (Design, not reference.) */
+int s2m_map_inplace_updates(const s2m_engine *e, int64_t *n);
 /* The engine's internal point order (design, not reference): order[j] = the caller's index of the point at sorted
  * position j.  Positions are ordered by (brick of 8x8x8 cells, cell within the brick, caller index), the cell of a
  * coordinate v being floor((v - origin) * (1 / cell_size)) in float arithmetic with the origin and cell size of
- * s2m_map_info -- after a full build and after a merged update alike.  Candidates tied at exactly the same float
- * squared distance are ranked by this position (tests hand it to the oracle as the tie order). */
+ * s2m_map_info -- after a full build, a merged update and an in-place update alike.  *m = the extent of the position
+ * range; after in-place updates it may exceed s2m_map_size, and order[j] = 0xffffffff marks a position that holds no point
+ * (a hole at the end of a rewritten brick).  Candidates tied at exactly the same float squared distance are ranked by
+ * this position (tests hand it to the oracle as the tie order). */
 int s2m_map_get_order(s2m_engine *e, uint32_t *order, int64_t capacity_points, int64_t *m);
 /* cells[3] = cells per axis of the current grid (multiples of 8: a brick is 8x8x8 cells; bricks are numbered
  * x fastest, then y, then z, and so are the cells inside a brick); a coordinate's cell index is clamped to

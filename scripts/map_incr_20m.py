@@ -23,6 +23,6 @@ for name in ("C3", "C4"):
         e.map_incremental(r["x"], 0.5)
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
-    print("%s: map %d points, map_incremental median %.3f ms (min %.3f) over frames 2..11; merged %s" % (
-        name, e.map_size(), float(np.median(ts[2:])), min(ts[2:]), e.map_last_update_merged()))
+    print("%s: map %d points, map_incremental median %.3f ms (min %.3f) over frames 2..11; merged %s, %d of 12 updates in place" % (
+        name, e.map_size(), float(np.median(ts[2:])), min(ts[2:]), e.map_last_update_merged(), e.map_inplace_updates()))
     e.close()

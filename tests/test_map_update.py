@@ -439,3 +439,70 @@ def test_two_handles_updating_their_maps_from_two_threads(small_scene):
             assert (bits(a[0]) == bits(b[0])).all() and a[1:] == b[1:]
         assert ma.shape == mt.shape and (bits(ma) == bits(mt)).all()
         assert sum(r[6] for r in ra) >= 10      # the loops really went through the merge path
+
+
+@pytest.mark.gpu
+def test_inplace_updates_equal_merged_updates(oracle, small_scene, monkeypatch):
+    """The in-place update (only the touched bricks rewritten, s2m_map_inplace_updates) against the merge update
+    (S2M_NO_SLAB=1) and the oracle: a sequence of replacements inside existing voxels (the case it serves: same voxels, new
+    winners), removals by box, plain adds into existing bricks, then growth that does not fit (falls back to the merge) --
+    after every step the maps agree in ORDER, the neighbour lists of a scan agree in caller indices and distances bit for
+    bit, and the set equals the oracle's."""
+    from daliti_amd import Engine
+    rs = np.random.RandomState(31)
+    base = small_scene["map"][:14000]
+    steps = []
+    for k in range(5):      # jittered copies of map points: they fall into occupied voxels and replace or lose
+        pick = rs.choice(len(base), 1500, replace=False)
+        steps.append(("add", base[pick] + rs.normal(0, 0.03, (1500, 3)).astype(np.float32), True))
+    steps.append(("del", np.float32([[-3, -3, -1, 0.5, 1.5, 3.0]]), None))
+    steps.append(("add", base[rs.choice(len(base), 800, replace=False)] + rs.normal(0, 0.03, (800, 3)).astype(np.float32), True))
+    steps.append(("add", base[rs.choice(len(base), 300, replace=False)] + rs.normal(0, 0.01, (300, 3)).astype(np.float32), False))
+    # growth that cannot stay in place: 5 000 points into one cubic metre (more than a brick's stretch can take)
+    steps.append(("add", (base[100] + rs.uniform(-0.5, 0.5, (5000, 3))).astype(np.float32), False))
+    steps.append(("add", base[rs.choice(len(base), 1000, replace=False)] + rs.normal(0, 0.03, (1000, 3)).astype(np.float32), True))
+    x = small_scene["x_prop"]
+    om = oracle.Map(base)
+    res = {}
+    for mode in ("inplace", "merge"):
+        if mode == "merge":
+            monkeypatch.setenv("S2M_NO_SLAB", "1")
+        else:
+            monkeypatch.delenv("S2M_NO_SLAB", raising=False)
+        e = Engine(cell_size=0.4)
+        e.map_build(base)
+        maps, nns, sizes, inplace = [], [], [], []
+        for kind, arg, ds in steps:
+            if kind == "add":
+                e.map_add(arg, ds, 0.5)
+                if mode == "inplace":
+                    om.add(arg, True, 0.5) if ds else om.add(arg, False)
+            else:
+                e.map_delete_boxes(arg)
+                if mode == "inplace":
+                    for b in arg:
+                        om.delete_box(b)
+            assert e.map_last_update_merged()
+            inplace.append(e.map_inplace_updates())
+            sizes.append(e.map_size())
+            maps.append(e.map_points().copy())
+            if mode == "inplace":
+                assert sizes[-1] == om.size(), len(maps)
+                assert (bits(_rows(maps[-1])) == bits(_rows(om.points()))).all(), len(maps)
+            e.scan_set(small_scene["scan"])
+            e.residual_pass(x, True)
+            nns.append(tuple(a.copy() for a in e.get_neighbors()))
+        res[mode] = (maps, nns, sizes, inplace)
+        # the documented order still holds with holes in the position range
+        tree = ranked_tree(oracle, e, maps[-1])
+        oi, od, _ = tree.knn5(oracle.body_to_world(x, small_scene["scan"]))
+        near = od[:, 4] <= 5.0
+        assert (bits(nns[-1][1][near]) == bits(od[near])).all() and (nns[-1][0][near] == oi[near]).all()
+        e.close()
+    a, b = res["inplace"], res["merge"]
+    assert b[3][-1] == 0 and a[3][-1] >= 6, a[3]      # most steps stayed in place; the growth step did not
+    assert a[3][8] == a[3][7], a[3]
+    for k in range(len(steps)):
+        assert a[2][k] == b[2][k], k
+        assert a[0][k].shape == b[0][k].shape and (bits(a[0][k]) == bits(b[0][k])).all(), k
+        assert (a[1][k][0] == b[1][k][0]).all() and (bits(a[1][k][1]) == bits(b[1][k][1])).all(), k
