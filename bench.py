@@ -1044,8 +1044,10 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
     run_frames(1)
     med_prefetch = float(np.median(frame_us[:frames] * 1e-3))
     st0 = eng.map_update_stats()
+    ip0 = eng.map_inplace_updates()
     run_frames(2)
     st1 = eng.map_update_stats()
+    ip1 = eng.map_inplace_updates()
     per = frame_us[:frames] * 1e-3
     how = [bool(v) for v in merged[:frames]]
     med = float(np.median(per))
@@ -1061,7 +1063,7 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
             "p99_ms": float(np.percentile(per, 99)), "max_ms": float(per.max()),
             "max_over_median": float(per.max() / med), "worst_frame": worst,
             "frames_back_to_back": int(frames), "untimed_warmup_frames": 2,
-            "updates": {k: int(st1[k] - st0[k]) for k in st1},
+            "updates": dict({k: int(st1[k] - st0[k]) for k in st1}, in_place=int(ip1 - ip0)),
             "bets": dict(zip(("won", "lost"), eng.bet_stats())),
             "rebuilt_frames": [i for i, m in enumerate(how) if not m],
             "stages_ms": {"raw_to_scan": float(w[0]), "iterated_update": float(w[1]), "map_incremental": float(w[2]),
@@ -1069,8 +1071,9 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
             "scan_points_raw": int(n), "scan_points_after_voxel_grid": int(nd), "map_points": int(eng.map_size()),
             "note": "host-timed, host input (3 MB of records cross PCIe in raw_to_scan); pose_latency_ms = records in -> pose out of a frame on its own (no prefetch); the staged "
                     "frames (stages_ms, ms_per_frame) are Python calls with a device sync after every stage, the back-to-back "
-                    "frames one C++ loop (tools/bench_loop.cpp, s2m_bench_frames); not part of `value`; `updates` counts how the map updates of the back-to-back frames were "
-                    "produced (merged into the grid / rebuilt / re-gridded) and how often a device buffer grew"}
+                    "frames one C++ loop (tools/bench_loop.cpp, s2m_bench_frames); not part of `value`; `updates` counts how the map updates of the back-to-back frames (and the two warm-up ones) were "
+                    "produced (merged into the grid -- of those `in_place`: only the touched bricks rewritten, the others re-laid the whole map "
+                    "out and are the slow frames of the tail -- / rebuilt / re-gridded) and how often a device buffer grew"}
 
 
 def measured_copy_peak(torch, nbytes=1 << 30, reps=10):
