@@ -506,3 +506,45 @@ def test_inplace_updates_equal_merged_updates(oracle, small_scene, monkeypatch):
         assert a[2][k] == b[2][k], k
         assert a[0][k].shape == b[0][k].shape and (bits(a[0][k]) == bits(b[0][k])).all(), k
         assert (a[1][k][0] == b[1][k][0]).all() and (bits(a[1][k][1]) == bits(b[1][k][1])).all(), k
+
+
+@pytest.mark.gpu
+def test_inplace_long_moving_sequence_equals_merge(oracle, small_scene, monkeypatch):
+    """Forty frames of a sensor moving through the scene -- register, map_incremental, and every seventh frame a box of the
+    map behind the sensor deleted (what the field-of-view trim does) -- once with in-place updates (the default) and once
+    with every update merged (S2M_NO_SLAB=1): poses, iteration logs, counts and map sizes agree frame by frame, the final
+    maps agree in order, and both kinds of update took part in the default run (bricks that fill up, empty out and fill
+    again; new bricks; holes that a later merge has to read past)."""
+    from daliti_amd import Engine, synth
+    runs = {}
+    for mode in ("inplace", "merge"):
+        if mode == "merge":
+            monkeypatch.setenv("S2M_NO_SLAB", "1")
+        else:
+            monkeypatch.delenv("S2M_NO_SLAB", raising=False)
+        e = Engine(max_iter=5, feat_threshold=50, cell_size=0.5)
+        e.map_build(small_scene["map"])
+        rows = []
+        for k in range(40):
+            pos = synth.SENSOR_POS + np.array([0.04 * k, 0.02 * k, 0.0])
+            s = synth.make_scan(16, 256, small_scene["L"], seed=300 + k, sensor_pos=pos)
+            xt, xp, P = synth.filter_inputs(pos, dtheta=synth.DTHETA0 * 0.3, dpos=synth.DPOS0 * 0.3)
+            e.scan_set_downsampled(s, 0.5)
+            r = e.iterated_update(xp, xp, P)
+            na, nb = e.map_incremental(r["x"], 0.5)
+            nd = 0
+            if k % 7 == 6:
+                c = pos[:2] - np.array([3.0, 1.5])
+                nd = e.map_delete_boxes(np.float32([[c[0] - 1.0, c[1] - 1.0, -1.0, c[0] + 1.0, c[1] + 1.0, 4.0]]))
+            if k in (15, 30):   # a burst of points into one cubic metre: more than a brick's stretch takes -> the update merges
+                rs = np.random.RandomState(k)
+                e.map_add((small_scene["map"][50 * k] + rs.uniform(-0.5, 0.5, (4000, 3))).astype(np.float32), False)
+            rows.append((r["x"].copy(), r["iters"], tuple(r["effct"]), na, nb, nd, e.map_size(), e.map_last_update_merged()))
+        runs[mode] = (rows, e.map_points().copy(), e.map_inplace_updates(), e.map_update_stats())
+        e.close()
+    a, b = runs["inplace"], runs["merge"]
+    for k, (ra, rb) in enumerate(zip(a[0], b[0])):
+        assert (ra[0] == rb[0]).all() and ra[1:] == rb[1:], k
+    assert a[1].shape == b[1].shape and (bits(a[1]) == bits(b[1])).all()
+    assert b[2] == 0 and a[2] >= 10, (a[2], a[3])
+    assert a[3]["merged"] - a[2] >= 1, (a[2], a[3])      # at least one update of the default run had to re-lay the map out
