@@ -846,7 +846,7 @@ int s2m_scan_set_downsampled(s2m_engine *e, const float *xyz, int64_t stride, in
                                 &m, &too_fine, e->stream));
     if (too_fine) return fail(e, S2M_ERR_CAPACITY, "leaf size too small for the cloud extent (voxel index overflows int32)");
     if (n_out) *n_out = m;
-    return scan_reset(e, m);
+    return scan_reset(e, m, n == 0);  // (the voxel count came back through the mailbox: the caller's buffer has been read)
 }
 
 namespace {
@@ -1091,15 +1091,17 @@ int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, in
     }
     int64_t m = n;
     float *sx = e->d_scan, *sy = e->d_scan + e->n_cap, *sz = e->d_scan + 2 * e->n_cap;
+    bool synced = false;  // the host has already waited for something behind the copy of the caller's buffer
     if (leaf > 0.0f && n > 0) {
         bool too_fine = false;
         S2M_HIP(e, voxel_downsample(e->vox, e->und.out, 3, n, leaf, sx, sy, sz, &m, &too_fine, e->stream));
         if (too_fine) return fail(e, S2M_ERR_CAPACITY, "leaf size too small for the cloud extent (voxel index overflows int32)");
+        synced = true;  // (the voxel count came back through the mailbox: everything before it has finished)
     } else if (n > 0) {
         launch_deinterleave(e->und.out, 3, n, sx, sy, sz, e->stream);
     }
     if (n_out) *n_out = m;
-    return scan_reset(e, m);
+    return scan_reset(e, m, !synced);
 }
 
 int s2m_scan_get(s2m_engine *e, float *xyz, int64_t capacity, int64_t *n)
