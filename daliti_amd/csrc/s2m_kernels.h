@@ -57,8 +57,9 @@ struct MapBuffers {
     uint32_t *bstart = nullptr;  // per occupied brick: first position in pts
     int64_t rank_cap = 0, bstart_cap = 0;
     uint32_t *bkey = nullptr;    // per occupied brick: its index in the top array (the high part of its points' keys)
-    uint8_t *bmark = nullptr;    // per occupied brick: bit 0 = a point of it was removed, bit 1 = a new point goes into it (this update)
-    int64_t bkey_cap = 0, bmark_cap = 0;
+    uint8_t *bmark = nullptr;    // per occupied brick: bit 0 = a point of it was removed, bit 1 = a new point goes into it, bit 2 = opened (this update)
+    uint32_t *bend = nullptr;    // per occupied brick: end of the stretch of positions it owns (its points, then room)
+    int64_t bkey_cap = 0, bmark_cap = 0, bend_cap = 0;
     uint64_t layout_gen = 0;     // counts builds and merges: a new dense layout of pts (in-place updates keep the layout)
     uint64_t *mk = nullptr;      // merge update: sorted keys of the new points
     uint32_t *mv = nullptr;      // merge update: their stage positions, then their lower bounds among the old keys

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void brick_table_kernel(int64_t bricks, const 
                                                           const uint64_t *__restrict__ keys,
                                                           const uint32_t *__restrict__ bstart, uint4 *__restrict__ top,
                                                           uint32_t *__restrict__ tab, uint32_t *__restrict__ occ,
-                                                          uint8_t *__restrict__ bmark)
+                                                          uint8_t *__restrict__ bmark, uint32_t *__restrict__ bend)
 {
     __shared__ uint32_t lds[4][kBrickCells];
     if (bricks_dev) bricks = (int64_t)*bricks_dev;
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256) void brick_table_kernel(int64_t bricks, const 
             te[2] = (uint32_t)mask;
             te[3] = (uint32_t)(mask >> 32);
             bmark[id] = 0;  // no in-place update pending on a fresh layout (slab_update)
+            bend[id] = e;   // the brick's stretch ends where the next one starts (dense)
         }
     }
 #pragma unroll
@@ -279,7 +280,7 @@ static inline int64_t headroom_for(int64_t m) { return m / 4 + 65536; }
 void free_map(MapBuffers &b)
 {
     void *ptrs[] = {b.pts, b.pidx, b.pts2, b.pidx2, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.work_a, b.work_b,
-                    b.work_c, b.rank, b.bstart, b.bkey, b.bmark, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
+                    b.work_c, b.rank, b.bstart, b.bkey, b.bmark, b.bend, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b.h_stats) { (void)hipHostFree(b.h_stats); (void)hipEventDestroy(b.stats_event); }
@@ -378,12 +379,13 @@ static hipError_t build_tables(MapBuffers &buf, const uint64_t *keys, int64_t m,
     S2M_TRY(ensure((void **)&buf.bstart, &buf.bstart_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
     S2M_TRY(ensure((void **)&buf.bkey, &buf.bkey_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
     S2M_TRY(ensure((void **)&buf.bmark, &buf.bmark_cap, bricks, sizeof(uint8_t), bricks / 4 + 64));
+    S2M_TRY(ensure((void **)&buf.bend, &buf.bend_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
     hipLaunchKernelGGL(brick_assign_kernel, dim3((unsigned)((top_entries + 255) / 256)), dim3(256), 0, st, top_entries,
                        buf.top, buf.rank, buf.bstart, buf.bkey, buf.counters + 64);
     if (bricks > 0)
         hipLaunchKernelGGL(brick_table_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks,
                            lazy ? buf.rank + top_entries : (const uint32_t *)nullptr, m, keys, buf.bstart, buf.top, buf.tab,
-                           buf.counters + 64, buf.bmark);
+                           buf.counters + 64, buf.bmark, buf.bend);
     ++buf.layout_gen;  // a fresh dense layout: every position below m holds a point
     if (!buf.h_stats) {
         S2M_TRY(hipHostMalloc((void **)&buf.h_stats, (1 + kOccShards) * sizeof(uint32_t), hipHostMallocMapped));
@@ -683,6 +685,7 @@ __global__ __launch_bounds__(256) void slack_move_kernel(int64_t m, const float4
 }
 // one wave per brick: the holes behind it, its prefix words and its start
 __global__ __launch_bounds__(256) void slack_brick_kernel(const uint32_t *__restrict__ bricks_dev, int64_t m, uint32_t *__restrict__ bstart,
+                                                          uint32_t *__restrict__ bend,
                                                           const uint32_t *__restrict__ bkey, const uint32_t *__restrict__ shift,
                                                           uint32_t *__restrict__ tab, float4 *__restrict__ npts,
                                                           uint32_t *__restrict__ npidx, uint64_t *__restrict__ nkeys)
@@ -697,6 +700,7 @@ __global__ __launch_bounds__(256) void slack_brick_kernel(const uint32_t *__rest
     uint32_t *t = tab + id * kBrickStride;
     for (int c = lane; c <= kBrickCells; c += 64) t[c] += sh;
     const uint64_t filler = ((uint64_t)bkey[id] << 9) | 511ull;
+    if (lane == 0) bend[id] = e0 + sh + room;  // = the next brick's new start
     for (uint32_t h = e0 + sh + (uint32_t)lane; h < e0 + sh + room; h += 64u) {
         npts[h] = make_map_point(3.0e38f, 3.0e38f, 3.0e38f, 0xffffffffu);
         npidx[h] = 0xffffffffu;
@@ -736,8 +740,8 @@ static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bou
     }
     hipLaunchKernelGGL(slack_move_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.pts, buf.pidx, buf.keys_alt,
                        buf.top, shift, buf.pts2, buf.pidx2, buf.keys);
-    hipLaunchKernelGGL(slack_brick_kernel, dim3((unsigned)((bricks_bound + 3) / 4)), dim3(256), 0, st, bricks_dev, m, buf.bstart, buf.bkey,
-                       shift, buf.tab, buf.pts2, buf.pidx2, buf.keys);
+    hipLaunchKernelGGL(slack_brick_kernel, dim3((unsigned)((bricks_bound + 3) / 4)), dim3(256), 0, st, bricks_dev, m, buf.bstart, buf.bend,
+                       buf.bkey, shift, buf.tab, buf.pts2, buf.pidx2, buf.keys);
     hipLaunchKernelGGL(slack_start_kernel, dim3((unsigned)((bricks_bound + 255) / 256)), dim3(256), 0, st, bricks_dev, shift, buf.bstart);
     uint32_t room = 0;
     S2M_TRY(mail_collect(buf.mail, 1, &room, st));
@@ -892,8 +896,8 @@ __global__ __launch_bounds__(256) void slab_key_kernel(const float4 *__restrict_
             f = kSlabOutside;
         } else {
             const uint32_t idp1 = g.top[brick].x;
-            if (idp1 == 0u) f = kSlabNewBrick;
-            else bmark[idp1 - 1u] |= 2u;  // (every writer of this byte in this launch stores the same value)
+            if (idp1 != 0u) bmark[idp1 - 1u] |= 2u;  // (every writer of this byte in this launch stores the same value)
+            // (a point whose brick does not exist yet: slab_newbrick_kernel opens it)
         }
     }
     const unsigned long long any = __ballot(f != 0u);
@@ -916,9 +920,124 @@ __device__ __forceinline__ int slab_lower(const uint64_t *__restrict__ nk, int n
     return lo;
 }
 
+// Bricks that this update opens (new points in a brick of the grid that holds nothing yet: a sensor that moves sees new
+// ground every frame) get their stretch of positions from the END of the room of the brick before them in key order, so
+// that position order stays key order; several new bricks in front of the same old brick line up there in key order.
+// One workgroup: heads of the new-brick segments of the sorted new keys (in order) -> per head the first old position of
+// a later brick (binary search in the sorted keys) -> a backward walk assigns the stretches -> the room of the brick in
+// front must still hold its own points plus what this update adds to it (ignoring what it removes: conservative) ->
+// only then are the entries written: top, brick key / start / end, an empty prefix row, the mark "new" (4) + "touched" (2),
+// the brick count.  Any doubt -- more than 1 024 new bricks, no brick in front, not enough room, no spare table rows --
+// raises kSlabNewBrick instead and writes nothing: the merge re-lays the map out.
+constexpr int kNewBricksMax = 1024;
+__global__ __launch_bounds__(256) void slab_newbrick_kernel(const uint64_t *__restrict__ nk, int n_new, uint4 *__restrict__ top,
+                                                            const uint64_t *__restrict__ okeys, int64_t m,
+                                                            uint32_t *__restrict__ tab, uint32_t *__restrict__ bstart,
+                                                            uint32_t *__restrict__ bend, uint32_t *__restrict__ bkey,
+                                                            uint8_t *__restrict__ bmark, uint32_t *__restrict__ bricks_dev,
+                                                            int max_new, uint32_t *__restrict__ flags)
+{
+    __shared__ uint32_t h_b[kNewBricksMax], h_k0[kNewBricksMax], h_need[kNewBricksMax], h_p0[kNewBricksMax], h_ida[kNewBricksMax],
+        h_start[kNewBricksMax], h_end[kNewBricksMax];
+    __shared__ int wsum[4];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    // 1. the heads, in key order
+    int nh = 0;
+    for (int c0 = 0; c0 < n_new; c0 += 256) {
+        const int k = c0 + tid;
+        bool head = false;
+        uint32_t b = 0u;
+        if (k < n_new) {
+            b = (uint32_t)(nk[k] >> 9);
+            head = (k == 0 || (uint32_t)(nk[k - 1] >> 9) != b) && top[b].x == 0u;
+        }
+        const unsigned long long bal = __ballot(head);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = nh;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        const int chunk = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (head) {
+            const int i = off + __popcll(bal & ((1ull << lane) - 1ull));
+            if (i < kNewBricksMax) { h_b[i] = b; h_k0[i] = (uint32_t)k; }
+        }
+        nh += chunk;
+        __syncthreads();
+    }
+    if (nh == 0) return;  // (uniform)
+    if (nh > max_new || nh > kNewBricksMax) {
+        if (tid == 0) atomicOr(flags, kSlabNewBrick);
+        return;
+    }
+    // 2. per head: its points, what it asks for, the first old position of a later brick, the brick in front
+    for (int i = tid; i < nh; i += 256) {
+        const uint32_t b = h_b[i];
+        const int n_b = slab_lower(nk, n_new, (uint64_t)b + 1) - (int)h_k0[i];
+        h_need[i] = (uint32_t)n_b + max((uint32_t)n_b >> 2, 32u);
+        int64_t lo = 0, hi = m;  // first old position whose brick is later than b (b itself holds nothing)
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((okeys[mid] >> 9) <= (uint64_t)b) lo = mid + 1; else hi = mid;
+        }
+        h_p0[i] = (uint32_t)lo;
+        uint32_t ida = 0xffffffffu;
+        if (lo > 0) {
+            const uint32_t idp1 = top[okeys[lo - 1] >> 9].x;
+            if (idp1) ida = idp1 - 1u;
+        }
+        h_ida[i] = ida;
+        if (ida == 0xffffffffu) s_fail = 1;
+    }
+    __syncthreads();
+    // 3. stretches, from the back: the new bricks in front of the same old position line up in key order
+    if (tid == 0 && !s_fail) {
+        uint32_t cursor = 0u;
+        for (int i = nh - 1; i >= 0; --i) {
+            if (i == nh - 1 || h_p0[i] != h_p0[i + 1]) cursor = h_p0[i];
+            h_end[i] = cursor;
+            if (h_need[i] > cursor) { s_fail = 1; break; }
+            cursor -= h_need[i];
+            h_start[i] = cursor;
+            if (i == 0 || h_p0[i - 1] != h_p0[i]) {
+                // the lowest new brick of this group starts at `cursor`: the brick in front keeps [its start, cursor)
+                const uint32_t ida = h_ida[i];
+                const uint32_t a_base = tab[ida * kBrickStride], a_end = tab[ida * kBrickStride + kBrickCells];
+                const uint64_t ab = bkey[ida];
+                const int n_a = slab_lower(nk, n_new, ab + 1) - slab_lower(nk, n_new, ab);
+                // its room must be its own (bend says so: a stretch carved earlier in this launch cannot be carved twice)
+                if (bend[ida] != h_p0[i] || cursor < a_end + (uint32_t)n_a || cursor < a_base) { s_fail = 1; break; }
+            }
+        }
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) atomicOr(flags, kSlabNewBrick);
+        return;
+    }
+    // 4. the entries
+    const uint32_t first_id = *bricks_dev;
+    for (int i = tid; i < nh; i += 256) {
+        const uint32_t id = first_id + (uint32_t)i, b = h_b[i];
+        uint32_t *te = reinterpret_cast<uint32_t *>(&top[b]);
+        te[0] = id + 1u; te[1] = h_start[i] + 1u; te[2] = 0u; te[3] = 0u;
+        bkey[id] = b;
+        bstart[id] = h_start[i];
+        bend[id] = h_end[i];
+        tab[id * kBrickStride] = h_start[i];
+        tab[id * kBrickStride + kBrickCells] = h_start[i];
+        bmark[id] = 6u;
+        if (i == 0 || h_p0[i - 1] != h_p0[i]) bend[h_ida[i]] = h_start[i];
+    }
+    __syncthreads();
+    if (tid == 0) { *bricks_dev = first_id + (uint32_t)nh; flags[2] = (uint32_t)nh; }
+}
+
 // one wave per brick: does the touched brick fit where it stands?  flags[0] |= overflow, flags[1] += points removed
-__global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restrict__ bricks_dev, int64_t m,
-                                                        const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ tab,
+__global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restrict__ bricks_dev,
+                                                        const uint32_t *__restrict__ bend, const uint32_t *__restrict__ tab,
                                                         const uint32_t *__restrict__ bkey, const uint8_t *__restrict__ bmark,
                                                         const uint8_t *__restrict__ alive_s, const uint64_t *__restrict__ nk, int n_new,
                                                         uint32_t *__restrict__ flags)
@@ -928,7 +1047,7 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restri
     const int64_t id = (int64_t)blockIdx.x * 4 + wave;
     if (id >= bricks || bmark[id] == 0) return;
     const uint32_t base = tab[id * kBrickStride], end = tab[id * kBrickStride + kBrickCells];
-    const uint32_t cap_end = id + 1 < bricks ? bstart[id + 1] : (uint32_t)m;
+    const uint32_t cap_end = bend[id];
     int alive = 0;
     for (uint32_t j = base + (uint32_t)lane; j < end; j += 64u) alive += alive_s[j] ? 1 : 0;
 #pragma unroll
@@ -947,6 +1066,7 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
                                                            uint64_t *__restrict__ keys, uint8_t *__restrict__ alive_s,
                                                            uint32_t *__restrict__ tab, uint4 *__restrict__ top,
                                                            const uint32_t *__restrict__ bkey, uint8_t *__restrict__ bmark,
+                                                           const uint32_t *__restrict__ bend,
                                                            const uint64_t *__restrict__ nk, const uint32_t *__restrict__ nv, int n_new,
                                                            const float4 *__restrict__ stage, uint32_t next_id)
 {
@@ -1017,7 +1137,10 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
         alive_s[pos] = 1;
         atomicMin(&l_t[c], pos);
     }
-    for (uint32_t h = (uint32_t)total + (uint32_t)tid; h < cnt; h += 256u) {  // what the brick no longer fills
+    // what the brick no longer fills; a brick opened by this update takes over its whole stretch (it was its
+    // predecessor's room: the filler keys there are the predecessor's)
+    const uint32_t fill_end = (bmark[id] & 4u) ? bend[id] - base : cnt;
+    for (uint32_t h = (uint32_t)total + (uint32_t)tid; h < fill_end; h += 256u) {
         alive_s[base + h] = 0;
         pidx[base + h] = 0xffffffffu;
         keys[base + h] = (bk << 9) | 511ull;
@@ -1065,18 +1188,25 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
         size_t t = buf.sort_tmp_bytes;
         S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, nk_sorted, buf.vals, nv_sorted, (size_t)n_new, 0, kbits, st));
     }
-    const int64_t bricks = stats.bricks;  // (an upper bound while a merged update's counts are on their way)
-    hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, m, buf.bstart, buf.tab,
+    // spare rows for bricks this update opens (the tables were allocated with headroom)
+    const int64_t rows = std::min(std::min(buf.tab_cap / kBrickStride, buf.bstart_cap), std::min(std::min(buf.bkey_cap, buf.bmark_cap), buf.bend_cap));
+    const int max_new = (int)std::max<int64_t>(std::min<int64_t>(rows - stats.bricks, kNewBricksMax), 0);
+    if (n > 0)
+        hipLaunchKernelGGL(slab_newbrick_kernel, dim3(1), dim3(256), 0, st, nk_sorted, n, buf.top, buf.keys_alt, m, buf.tab, buf.bstart,
+                           buf.bend, buf.bkey, buf.bmark, buf.rank + top_entries, max_new, flags);
+    const int64_t bricks = stats.bricks + max_new;  // (an upper bound: a merged update's counts may be on their way, bricks may just have opened)
+    hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, buf.bend, buf.tab,
                        buf.bkey, buf.bmark, alive_s, nk_sorted, n, flags);
     {
-        const uint32_t *src[2] = {flags, flags + 1};
-        S2M_TRY(mail_post(buf.mail, src, 2, st));
+        const uint32_t *src[3] = {flags, flags + 1, flags + 2};
+        S2M_TRY(mail_post(buf.mail, src, 3, st));
     }
     hipLaunchKernelGGL(slab_rewrite_kernel, dim3((unsigned)bricks), dim3(256), 0, st, bricks_dev, flags, buf.pts, buf.pidx, buf.keys_alt,
-                       alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, nk_sorted, nv_sorted, n, stage, (uint32_t)buf.next_id);
-    uint32_t v[2] = {0, 0};
-    S2M_TRY(mail_collect(buf.mail, 2, v, st));
-    if (v[0] != 0u) return hipSuccess;  // the rewrite kernel saw the same word and left everything alone
+                       alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, nk_sorted, nv_sorted, n, stage, (uint32_t)buf.next_id);
+    uint32_t v[3] = {0, 0, 0};
+    S2M_TRY(mail_collect(buf.mail, 3, v, st));
+    if (v[0] != 0u) return hipSuccess;  // the rewrite kernel saw the same word and left the points alone
+    stats.bricks += v[2];
     g.live += n_new - (int64_t)v[1];
     buf.next_id += n_new;
     if (v[1] > 0u) buf.ids_dense = false;

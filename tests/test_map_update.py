@@ -548,3 +548,72 @@ def test_inplace_long_moving_sequence_equals_merge(oracle, small_scene, monkeypa
     assert a[1].shape == b[1].shape and (bits(a[1]) == bits(b[1])).all()
     assert b[2] == 0 and a[2] >= 10, (a[2], a[3])
     assert a[3]["merged"] - a[2] >= 1, (a[2], a[3])      # at least one update of the default run had to re-lay the map out
+
+
+@pytest.mark.gpu
+def test_inplace_update_opens_new_bricks(oracle, small_scene, monkeypatch):
+    """New points in bricks of the grid that hold nothing yet (here: blobs in the air inside the room; for a moving sensor:
+    new ground every frame) are taken in place too -- the new bricks get their stretch from the room of the brick in front of
+    them.  Blobs in several empty bricks at once, more points into the bricks just opened, a down-sampled add over them, a
+    box delete through them: maps (in order), sizes and neighbour lists equal the all-merge run and the oracle."""
+    from daliti_amd import Engine
+    rs = np.random.RandomState(41)
+    base = small_scene["map"]
+    lo, hi = base.min(axis=0), base.max(axis=0)
+    mid = 0.5 * (lo + hi)
+    def blob(c, n, s=0.3):
+        return (np.asarray(c) + rs.uniform(-s, s, (n, 3))).astype(np.float32)
+    centres = [mid + [0, 0, 0.0], mid + [1.9, -1.7, 1.2], mid + [-2.1, 1.6, -1.1], mid + [0.3, 2.2, 2.0]]
+    steps = [("add", base[rs.choice(len(base), 1500, replace=False)] + rs.normal(0, 0.03, (1500, 3)).astype(np.float32), True),
+             ("add", np.concatenate([blob(c, 120) for c in centres]), False),          # opens bricks
+             ("add", np.concatenate([blob(c, 60, 0.5) for c in centres[:2]]), False),   # grows them (and maybe their neighbours)
+             ("add", np.concatenate([blob(c, 200, 0.6) for c in centres]), True),       # voxel rule over the new bricks
+             ("del", np.float32([np.r_[mid - 0.4, mid + 0.4]]), None),
+             ("add", blob(mid + [0.0, 0.0, 3.0], 80), False),
+             ("add", base[rs.choice(len(base), 1000, replace=False)] + rs.normal(0, 0.03, (1000, 3)).astype(np.float32), True)]
+    # queries: the scene's scan plus points in the air next to the blobs (their neighbours live in the new bricks)
+    q = np.concatenate([small_scene["scan"], np.concatenate([blob(c, 200, 0.8) for c in centres])]).astype(np.float32)
+    om = oracle.Map(base)
+    res = {}
+    for mode in ("inplace", "merge"):
+        if mode == "merge":
+            monkeypatch.setenv("S2M_NO_SLAB", "1")
+        else:
+            monkeypatch.delenv("S2M_NO_SLAB", raising=False)
+        e = Engine(cell_size=0.4)
+        e.map_build(base)
+        maps, nns, sizes, inplace = [], [], [], []
+        for kind, arg, ds in steps:
+            if kind == "add":
+                e.map_add(arg, ds, 0.5)
+                if mode == "inplace":
+                    om.add(arg, True, 0.5) if ds else om.add(arg, False)
+            else:
+                e.map_delete_boxes(arg)
+                if mode == "inplace":
+                    for b in arg:
+                        om.delete_box(b)
+            assert e.map_last_update_merged()
+            inplace.append(e.map_inplace_updates())
+            sizes.append(e.map_size())
+            maps.append(e.map_points().copy())
+            if mode == "inplace":
+                assert sizes[-1] == om.size(), len(maps)
+                assert (bits(_rows(maps[-1])) == bits(_rows(om.points()))).all(), len(maps)
+            e.scan_set(q)
+            e.residual_pass(small_scene["x_true"], True)
+            nns.append(tuple(a.copy() for a in e.get_neighbors()))
+        res[mode] = (maps, nns, sizes, inplace)
+        tree = ranked_tree(oracle, e, maps[-1])
+        oi, od, _ = tree.knn5(oracle.body_to_world(small_scene["x_true"], q))
+        near = od[:, 4] <= 5.0
+        assert (bits(nns[-1][1][near]) == bits(od[near])).all() and (nns[-1][0][near] == oi[near]).all()
+        e.close()
+    a, b = res["inplace"], res["merge"]
+    assert b[3][-1] == 0
+    assert a[3][1] == a[3][0] + 1, a[3]          # the step that opens bricks stayed in place
+    assert a[3][-1] >= 3, a[3]
+    for k in range(len(steps)):
+        assert a[2][k] == b[2][k], k
+        assert a[0][k].shape == b[0][k].shape and (bits(a[0][k]) == bits(b[0][k])).all(), k
+        assert (a[1][k][0] == b[1][k][0]).all() and (bits(a[1][k][1]) == bits(b[1][k][1])).all(), k
