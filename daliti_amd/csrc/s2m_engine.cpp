@@ -556,7 +556,7 @@ void bind_update(s2m_engine *e)
     e->upd.layout_gen = e->map.layout_gen;
 }
 
-// the map after an update: merged into the sorted arrays when possible (s2m_map.hip, merge_update), else rebuilt
+// the map after an update: merged into the sorted arrays when possible (s2m_mapedit.hip: in place, else merge_update), else rebuilt
 // from upd.list (survivors in index order, then the staged points) -- the same caller order either way
 int commit_update(s2m_engine *e)
 {

@@ -92,13 +92,13 @@ int64_t map_allocations();  // device (re)allocations by the map build / merge /
 void note_allocation();
 // bricks / occupied_cells of the last build or merge (a merge does not wait for them: they arrive behind it)
 hipError_t resolve_stats(MapBuffers &buf, MapStats &stats);
-// The map after an update without a new sort (s2m_map.hip, "merge update"): alive_s[sorted position] for the m old points
+// The map after an update without a new sort (s2m_mapedit.hip, "merge update"): alive_s[sorted position] for the m old points
 // (m + 1 readable bytes), n_new staged points in their order.  merged = false (and nothing changed) when the update cannot be
 // merged -- a new point outside the grid, no room in the scratch arrays, empty map -- and the caller falls back to
 // update_finish + build_map.
 hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive_s,
                         const float4 *stage, int64_t n_new, bool &merged, hipStream_t st, bool with_slack = false);
-// The same update in place when every touched brick still fits where it stands (s2m_map.hip, slab_update): done = false and
+// The same update in place when every touched brick still fits where it stands (s2m_mapedit.hip, slab_update): done = false and
 // nothing touched otherwise.  flags: three zeroed words of the update's counters.
 hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t n_new,
                        uint32_t *flags, bool &done, hipStream_t st);

@@ -8,10 +8,10 @@
 // top-level array over the bounding box and a 513-entry prefix table per occupied brick locate
 // any run of cells along x with two 4-byte loads.
 //
-// This is the per-map part of the path, not the per-iteration hot loop: the full build (radix sort of all points),
-// the tables that both the build and an update derive from the sorted keys, and the merge update that turns the
-// verdicts of s2m_mapupd.hip into the new map without sorting it again.  The device-wide radix sort and scans come
-// from rocPRIM (ROCm's native primitives library), everything else is hand-written below.
+// This is the per-map part of the path, not the per-iteration hot loop: the full build (radix sort of all points) and
+// the tables that both the build and a merged update derive from the sorted keys; how the map changes after a scan is
+// s2m_mapedit.hip.  The device-wide radix sort and scans come from rocPRIM (ROCm's native primitives library),
+// everything else is hand-written below.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -21,16 +21,9 @@
 #include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/iterator/zip_iterator.hpp>
 
-#include "s2m_device.h"
-#include "s2m_kernels.h"
+#include "s2m_map_internal.h"
 
 namespace s2m {
-
-#define S2M_TRY(x)                      \
-    do {                                \
-        hipError_t e_ = (x);            \
-        if (e_ != hipSuccess) return e_; \
-    } while (0)
 
 // ---- bounding box of an AoS cloud ---------------------------------------------------------------------
 // Per-workgroup partial boxes, then one workgroup folds them: no atomics (same-line atomics cost ~11 ns
@@ -106,12 +99,6 @@ hipError_t cloud_bbox(const float *xyz, int64_t stride, int64_t n, float *scratc
     return hipGetLastError();
 }
 
-__device__ __forceinline__ int cell_of(float v, float o, float inv_c, int nc)
-{
-    const int c = (int)floorf((v - o) * inv_c);
-    return min(max(c, 0), nc - 1);
-}
-
 __global__ __launch_bounds__(256) void key_kernel(const float *__restrict__ xyz, int64_t stride, int64_t m, Grid g,
                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
@@ -176,42 +163,6 @@ __global__ __launch_bounds__(256) void brick_assign_kernel(int64_t top_entries, 
 }
 
 
-// One wave: t[512] holds the first position of every non-empty cell of a brick (0xffffffff = empty), e the end of the
-// brick's points.  Writes the brick's 513 prefix words (an empty cell takes the start of the next non-empty one) and returns
-// this lane's number of non-empty cells; mask = the brick's occupied (z,y) rows (row = lane).
-__device__ __forceinline__ int table_from_firsts(const uint32_t *t, uint32_t e, uint32_t *__restrict__ out, int lane, unsigned long long &mask)
-{
-    int cells = 0;
-    uint32_t v[8];
-    uint32_t mn = 0xffffffffu;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        v[k] = t[lane * 8 + k];
-        mn = min(mn, v[k]);
-        cells += v[k] != 0xffffffffu ? 1 : 0;
-    }
-    // row lane = (z,y) row of the brick: occupied when any of its eight cells is
-    mask = __ballot(mn != 0xffffffffu);
-    // suffix-min over the lanes behind this one, seeded with the brick end
-    uint32_t suf = mn;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_down(suf, off, 64);
-        if (lane + off < 64) suf = min(suf, o);
-    }
-    uint32_t nxt = __shfl_down(suf, 1, 64);
-    if (lane == 63) nxt = e;
-    nxt = min(nxt, e);
-#pragma unroll
-    for (int k = 7; k >= 0; --k) {
-        if (v[k] == 0xffffffffu) v[k] = nxt;
-        nxt = v[k];
-        out[lane * 8 + k] = v[k];
-    }
-    if (lane == 0) out[kBrickCells] = e;
-    return cells;
-}
-
 // bricks_dev: the number of occupied bricks when the host only knows an upper bound for it (merge update)
 __global__ __launch_bounds__(256) void brick_table_kernel(int64_t bricks, const uint32_t *__restrict__ bricks_dev, int64_t m,
                                                           const uint64_t *__restrict__ keys,
@@ -261,7 +212,7 @@ __global__ __launch_bounds__(256) void brick_table_kernel(int64_t bricks, const 
 // little with every scan does not reallocate -- two device-wide syncs and ~100 MB of hipMalloc at 5 M points --
 // on every update (round 2 compared the stored capacity against need + headroom: the headroom was never usable)
 static int64_t g_map_allocations = 0;  // diagnostic only (s2m_map_update_stats); racy increments are harmless
-static hipError_t ensure(void **p, int64_t *cap, int64_t need, size_t elem, int64_t headroom = 0)
+hipError_t map_ensure(void **p, int64_t *cap, int64_t need, size_t elem, int64_t headroom)
 {
     if (*cap >= need && *p) return hipSuccess;
     if (*p) S2M_TRY(hipFree(*p));
@@ -275,7 +226,7 @@ static hipError_t ensure(void **p, int64_t *cap, int64_t need, size_t elem, int6
 }
 int64_t map_allocations() { return g_map_allocations; }
 void note_allocation() { ++g_map_allocations; }
-static inline int64_t headroom_for(int64_t m) { return m / 4 + 65536; }
+int64_t map_headroom_for(int64_t m) { return m / 4 + 65536; }
 
 void free_map(MapBuffers &b)
 {
@@ -288,7 +239,7 @@ void free_map(MapBuffers &b)
     b = MapBuffers();
 }
 
-static hipError_t ensure_sort_tmp(MapBuffers &buf, size_t bytes)
+hipError_t map_ensure_sort_tmp(MapBuffers &buf, size_t bytes)
 {
     if (bytes <= buf.sort_tmp_bytes && buf.sort_tmp) return hipSuccess;
     if (buf.sort_tmp) S2M_TRY(hipFree(buf.sort_tmp));
@@ -304,7 +255,7 @@ static hipError_t ensure_sort_tmp(MapBuffers &buf, size_t bytes)
 static hipError_t ensure_scratch(MapBuffers &buf, int64_t m)
 {
     if (buf.scratch_cap >= m) return hipSuccess;
-    const int64_t cap = m + headroom_for(m);
+    const int64_t cap = m + map_headroom_for(m);
     void **ps[] = {(void **)&buf.keys, (void **)&buf.keys_alt, (void **)&buf.vals, (void **)&buf.vals_alt,
                    (void **)&buf.work_a, (void **)&buf.work_b, (void **)&buf.work_c};
     const size_t es[] = {8, 8, 4, 4, 4, 4, 4};
@@ -312,13 +263,13 @@ static hipError_t ensure_scratch(MapBuffers &buf, int64_t m)
     for (int k = 0; k < 7; ++k) {
         int64_t c = 0;
         if (*ps[k]) { S2M_TRY(hipFree(*ps[k])); *ps[k] = nullptr; }
-        S2M_TRY(ensure(ps[k], &c, cap + 1, es[k]));
+        S2M_TRY(map_ensure(ps[k], &c, cap + 1, es[k]));
     }
     buf.scratch_cap = cap;
     return hipSuccess;
 }
 
-static hipError_t put_sentinels(float4 *pts, int64_t m, hipStream_t st)
+hipError_t map_put_sentinels(float4 *pts, int64_t m, hipStream_t st)
 {
     // kSentinelPoints extra elements: the sentinel points the search kernels load for the padding slots of a batch
     // (far enough for the squared distance to overflow to +inf; index word 0xffffffff)
@@ -354,16 +305,16 @@ hipError_t resolve_stats(MapBuffers &buf, MapStats &stats)
 // top entries + brick tables of the m points whose sorted keys are `keys` (buf.top zeroed by the caller).
 // brick_bound >= 0: an upper bound of the number of occupied bricks known to the host -- nothing is read back
 // before the tables are built, and the counts arrive later (resolve_stats).
-static hipError_t build_tables(MapBuffers &buf, const uint64_t *keys, int64_t m, int64_t top_entries, MapStats &stats,
-                               hipStream_t st, int64_t brick_bound = -1)
+hipError_t map_build_tables(MapBuffers &buf, const uint64_t *keys, int64_t m, int64_t top_entries, MapStats &stats,
+                            hipStream_t st, int64_t brick_bound)
 {
     const int blocks = (int)std::min<int64_t>((m + 255) / 256, 4096);
     hipLaunchKernelGGL(brick_head_kernel, dim3(blocks), dim3(256), 0, st, m, keys, buf.top);
-    S2M_TRY(ensure((void **)&buf.rank, &buf.rank_cap, top_entries + 1, sizeof(uint32_t)));
+    S2M_TRY(map_ensure((void **)&buf.rank, &buf.rank_cap, top_entries + 1, sizeof(uint32_t)));
     auto occupied = rocprim::make_transform_iterator(static_cast<const uint4 *>(buf.top), TopOccupied());
     size_t tmp = 0;
     S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, occupied, buf.rank, 0u, (size_t)top_entries + 1, rocprim::plus<uint32_t>(), st));
-    S2M_TRY(ensure_sort_tmp(buf, tmp));
+    S2M_TRY(map_ensure_sort_tmp(buf, tmp));
     size_t t1 = buf.sort_tmp_bytes;
     // one element past the end (top has a zero spare entry): rank[top_entries] = number of occupied bricks
     S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t1, occupied, buf.rank, 0u, (size_t)top_entries + 1, rocprim::plus<uint32_t>(), st));
@@ -375,11 +326,11 @@ static hipError_t build_tables(MapBuffers &buf, const uint64_t *keys, int64_t m,
         S2M_TRY(mail_fetch(buf.mail, src, 1, &b32, st));
         bricks = b32;
     }
-    S2M_TRY(ensure((void **)&buf.tab, &buf.tab_cap, bricks * kBrickStride, sizeof(uint32_t), (bricks / 4 + 64) * kBrickStride));
-    S2M_TRY(ensure((void **)&buf.bstart, &buf.bstart_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
-    S2M_TRY(ensure((void **)&buf.bkey, &buf.bkey_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
-    S2M_TRY(ensure((void **)&buf.bmark, &buf.bmark_cap, bricks, sizeof(uint8_t), bricks / 4 + 64));
-    S2M_TRY(ensure((void **)&buf.bend, &buf.bend_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
+    S2M_TRY(map_ensure((void **)&buf.tab, &buf.tab_cap, bricks * kBrickStride, sizeof(uint32_t), (bricks / 4 + 64) * kBrickStride));
+    S2M_TRY(map_ensure((void **)&buf.bstart, &buf.bstart_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
+    S2M_TRY(map_ensure((void **)&buf.bkey, &buf.bkey_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
+    S2M_TRY(map_ensure((void **)&buf.bmark, &buf.bmark_cap, bricks, sizeof(uint8_t), bricks / 4 + 64));
+    S2M_TRY(map_ensure((void **)&buf.bend, &buf.bend_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
     hipLaunchKernelGGL(brick_assign_kernel, dim3((unsigned)((top_entries + 255) / 256)), dim3(256), 0, st, top_entries,
                        buf.top, buf.rank, buf.bstart, buf.bkey, buf.counters + 64);
     if (bricks > 0)
@@ -443,10 +394,10 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     const float max_cells = (float)std::max(std::max(nc[0], nc[1]), nc[2]);
     g.slop = std::max(1.0e-4f, 16.0f * max_cells * 1.1920929e-7f);
 
-    S2M_TRY(ensure((void **)&buf.pts, &buf.pts_cap, m + kSentinelPoints, sizeof(float4), headroom_for(m)));
-    S2M_TRY(put_sentinels(buf.pts, m, st));
-    S2M_TRY(ensure((void **)&buf.pidx, &buf.pidx_cap, m + 1, sizeof(uint32_t), headroom_for(m)));
-    S2M_TRY(ensure((void **)&buf.top, &buf.top_cap, top_entries + 1, sizeof(uint4)));
+    S2M_TRY(map_ensure((void **)&buf.pts, &buf.pts_cap, m + kSentinelPoints, sizeof(float4), map_headroom_for(m)));
+    S2M_TRY(map_put_sentinels(buf.pts, m, st));
+    S2M_TRY(map_ensure((void **)&buf.pidx, &buf.pidx_cap, m + 1, sizeof(uint32_t), map_headroom_for(m)));
+    S2M_TRY(map_ensure((void **)&buf.top, &buf.top_cap, top_entries + 1, sizeof(uint4)));
     S2M_TRY(ensure_scratch(buf, m));
     if (!buf.counters) S2M_TRY(hipMalloc((void **)&buf.counters, (64 + kOccShards * 32) * sizeof(uint32_t)));
     S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(top_entries + 1) * sizeof(uint4), st));
@@ -466,14 +417,14 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     size_t tmp = 0;
     S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m, 0,
                                       (unsigned)bits, st));
-    S2M_TRY(ensure_sort_tmp(buf, tmp));
+    S2M_TRY(map_ensure_sort_tmp(buf, tmp));
     size_t t1 = buf.sort_tmp_bytes;
     S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t1, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m,
                                       0, (unsigned)bits, st));
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, buf.vals_alt, buf.pts, buf.pidx);
     buf.next_id = m;        // the ids of a fresh build are the caller's indices
     buf.ids_dense = true;
-    S2M_TRY(build_tables(buf, buf.keys_alt, m, top_entries, stats, st));
+    S2M_TRY(map_build_tables(buf, buf.keys_alt, m, top_entries, stats, st));
     stats.top_entries = top_entries;
     g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
     return hipSuccess;
@@ -511,707 +462,6 @@ hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, Ma
         c = cn;
     }
     return build_once(xyz, stride, m, c, lo, hi, margin_for(c), buf, grid, stats, too_large, st);
-}
-
-// ---- merge update: the map after an incremental update WITHOUT a new sort ----------------------------------
-// Input: the current map (sorted points, their caller indices pidx, their sorted keys keys_alt), the update's
-// verdicts (alive[caller index] of every old point) and its staged new points (caller order of the new map:
-// survivors in index order, then the staged points -- the same list update_finish would hand to a full build).
-// The new points are sorted by their key in the CURRENT grid (tens of thousands, not millions), every one finds
-// its place among the old keys by binary search -- BEHIND the old points of its own cell (upper bound): the new
-// points carry the highest caller indices, so the merged array is ordered by (brick, cell, caller index) exactly
-// like a fresh build of the same list, and the search's tie order (sorted position) does not depend on which of
-// the two ways the map was produced -- and announces itself there (v[ub] += 1); one scan over
-// v[j] = alive(j) + announcements(j) then gives every surviving old point and every new point its position in
-// the merged order.  Old points move with one coalesced read and one scattered-but-monotone write; caller
-// indices are renumbered on the way (exclusive scan of alive).  ~0.3 GB of traffic at 5 M points instead of a
-// 5 M-key radix sort, a bounding-box pass and a gather.
-// rank of the dead among the caller indices: a bit mask of the dead per 64 indices and the number of dead before
-// every word (312 KB + 625 KB at 5 M points: L2-resident, so renumbering a caller index costs two cache hits
-// instead of a gather from a 20 MB array)
-__global__ __launch_bounds__(256) void dead_words_kernel(int64_t m, const uint8_t *__restrict__ alive_s,
-                                                         unsigned long long *__restrict__ word_s, uint32_t *__restrict__ cnt,
-                                                         uint32_t *__restrict__ outside_flag)
-{
-    // the removed points by sorted position: where a survivor lands.  (Point ids are stable -- s2m_kernels.h, MapBuffers::pidx
-    // -- so nothing is renumbered: rounds 2-3 also ranked the removed CALLER INDICES here and every survivor gathered its
-    // new index from that rank.)
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { cnt[(m + 63) >> 6] = 0u; *outside_flag = 0u; }  // the scan's spare element; merge_newkey_kernel's flag
-    const unsigned long long ws = __ballot(i < m && alive_s[i] == 0);
-    if ((threadIdx.x & 63) == 0 && (i >> 6) <= ((m - 1) >> 6)) {
-        word_s[i >> 6] = ws;
-        cnt[i >> 6] = (uint32_t)__popcll(ws);
-    }
-}
-struct DeadRank {  // per 64 positions: mask of the removed ones, number removed before the word (one 16-byte gather)
-    unsigned long long word;
-    uint32_t prefix, pad;
-};
-// entry `words` (one past the last word) is an empty mask with the total as its prefix: a position may equal m
-__global__ __launch_bounds__(256) void dead_pack_kernel(int64_t words, const unsigned long long *__restrict__ word_s,
-                                                        const uint32_t *__restrict__ prefix, DeadRank *__restrict__ out_s)
-{
-    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w > words) return;
-    out_s[w] = DeadRank{w < words ? word_s[w] : 0ull, prefix[w], 0u};
-}
-__device__ __forceinline__ uint32_t dead_before(uint32_t ci, const DeadRank *__restrict__ rank)
-{
-    const uint4 r = *reinterpret_cast<const uint4 *>(rank + (ci >> 6));
-    const unsigned long long w = ((unsigned long long)r.y << 32) | r.x;
-    return r.z + (uint32_t)__popcll(w & ((1ull << (ci & 63u)) - 1ull));
-}
-
-__global__ __launch_bounds__(256) void merge_newkey_kernel(const float4 *__restrict__ stage, int n, Grid g,
-                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                           uint32_t *__restrict__ outside)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool out = false;
-    if (i < n) {
-        const float4 p = stage[i];
-        // unclamped cell coordinates: a point outside the grid cannot be merged (cell_of would clamp it into a
-        // border cell whose box does not contain it, which the search's distance bounds rely on)
-        const float fx = floorf((p.x - g.ox) * g.inv_c), fy = floorf((p.y - g.oy) * g.inv_c), fz = floorf((p.z - g.oz) * g.inv_c);
-        out = !(fx >= 0.0f && fx <= (float)(g.ncx - 1) && fy >= 0.0f && fy <= (float)(g.ncy - 1) && fz >= 0.0f &&
-                fz <= (float)(g.ncz - 1));
-        const int cx = cell_of(p.x, g.ox, g.inv_c, g.ncx), cy = cell_of(p.y, g.oy, g.inv_c, g.ncy),
-                  cz = cell_of(p.z, g.oz, g.inv_c, g.ncz);
-        const uint64_t brick = ((uint64_t)(cz >> 3) * g.nby + (cy >> 3)) * g.nbx + (cx >> 3);
-        const uint32_t local = (uint32_t)((((cz & 7) << 3) | (cy & 7)) << 3 | (cx & 7));
-        keys[i] = (brick << 9) | local;
-        vals[i] = (uint32_t)i;
-    }
-    if (__syncthreads_or(out ? 1 : 0) && threadIdx.x == 0) atomicOr(outside, 1u);
-}
-
-// upper bound of every new key among the old keys (the first old point of a LATER cell): the new point goes in front
-// of that old point, behind the old points of its own cell.  The keys are sorted, so lb is ascending.
-__global__ __launch_bounds__(256) void merge_lb_kernel(int n, const uint64_t *__restrict__ nkeys, const uint64_t *__restrict__ okeys,
-                                                       int64_t m, uint32_t *__restrict__ lb)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = nkeys[i];
-    int64_t lo = 0, hi = m;  // first j with okeys[j] > k
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (okeys[mid] <= k) lo = mid + 1; else hi = mid;
-    }
-    lb[i] = (uint32_t)lo;
-}
-
-// surviving old point j -> (survivors before j) + (new points that go in front of j or of an earlier old point): no
-// map-sized scan and no per-position counter array -- the survivors before j come from the removed-by-position rank, the
-// new points from one scalar binary search per wave in the sorted lb[] (a few thousand entries, L2-resident) plus the few
-// entries inside the wave's 64 positions
-__global__ __launch_bounds__(256) void merge_old_kernel(int64_t m, const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
-                                                        const uint64_t *__restrict__ okeys,
-                                                        const uint8_t *__restrict__ alive_s,
-                                                        const DeadRank *__restrict__ rank_s, const uint32_t *__restrict__ lb, int n_new,
-                                                        float4 *__restrict__ npts, uint32_t *__restrict__ npidx,
-                                                        uint64_t *__restrict__ nkeys_out)
-{
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // wave-uniform: number of new points with lb < the wave's first position
-    const uint32_t j0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(j - (threadIdx.x & 63)));
-    int lo = 0, hi = n_new;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (lb[mid] < j0) lo = mid + 1; else hi = mid;
-    }
-    if (j >= m || !alive_s[j]) return;
-    int k = lo;
-    while (k < n_new && lb[k] <= (uint32_t)j) ++k;
-    const uint32_t pos = ((uint32_t)j - dead_before((uint32_t)j, rank_s)) + (uint32_t)k;
-    const float4 p = pts[j];
-    npts[pos] = make_map_point(p.x, p.y, map_point_z(p), pos);
-    npidx[pos] = pidx[j];  // the point keeps its id
-    nkeys_out[pos] = okeys[j];
-}
-
-// new point i (sorted order) -> (survivors before its lb) + i
-__global__ __launch_bounds__(256) void merge_new_kernel(int n, const uint64_t *__restrict__ nkeys, const uint32_t *__restrict__ nvals,
-                                                        const uint32_t *__restrict__ lb, const DeadRank *__restrict__ rank_s,
-                                                        const float4 *__restrict__ stage, uint32_t next_id,
-                                                        float4 *__restrict__ npts, uint64_t *__restrict__ nkeys_out,
-                                                        uint32_t *__restrict__ npidx)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t l = lb[i];
-    const uint32_t pos = (l - dead_before(l, rank_s)) + (uint32_t)i;
-    const uint32_t t = nvals[i];
-    const float4 p = stage[t];
-    npts[pos] = make_map_point(p.x, p.y, p.z, pos);
-    nkeys_out[pos] = nkeys[i];
-    npidx[pos] = next_id + t;  // staged order = caller order of the new points
-}
-
-// ---- slack for the in-place updates -------------------------------------------------------------------------
-// A merge (or a rebuild inside an update) leaves the points densely packed; slab_update can only rewrite a brick where it
-// stands while the brick fits between its first position and the next brick's.  So a map that is being maintained gets
-// room behind every brick: an eighth of its points, 16 to 512 positions.  One more pass over the map on the frames that
-// merge anyway (the frames in between are the ones that stay in place): the points move to `position + slack of the bricks
-// before`, the holes are filled with sentinel points (never a neighbour: +inf distance), id ~0 and the brick's largest key
-// (the key array stays sorted), prefix words and brick starts are shifted.
-__global__ __launch_bounds__(256) void slack_size_kernel(int64_t bound, const uint32_t *__restrict__ bricks_dev, int64_t m,
-                                                         const uint32_t *__restrict__ bstart, uint32_t *__restrict__ slack)
-{
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id > bound) return;
-    const int64_t bricks = (int64_t)*bricks_dev;
-    uint32_t v = 0u;
-    if (id < bricks) {
-        const uint32_t cnt = (id + 1 < bricks ? bstart[id + 1] : (uint32_t)m) - bstart[id];
-        v = min(max(cnt >> 3, 16u), 512u);
-    }
-    slack[id] = v;
-}
-__global__ __launch_bounds__(256) void slack_move_kernel(int64_t m, const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
-                                                         const uint64_t *__restrict__ keys, const uint4 *__restrict__ top,
-                                                         const uint32_t *__restrict__ shift, float4 *__restrict__ npts,
-                                                         uint32_t *__restrict__ npidx, uint64_t *__restrict__ nkeys)
-{
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const uint64_t k = keys[j];
-    const uint32_t dst = (uint32_t)j + shift[top[k >> 9].x - 1u];
-    const float4 p = pts[j];
-    npts[dst] = make_map_point(p.x, p.y, map_point_z(p), dst);
-    npidx[dst] = pidx[j];
-    nkeys[dst] = k;
-}
-// one wave per brick: the holes behind it, its prefix words and its start
-__global__ __launch_bounds__(256) void slack_brick_kernel(const uint32_t *__restrict__ bricks_dev, int64_t m, uint32_t *__restrict__ bstart,
-                                                          uint32_t *__restrict__ bend,
-                                                          const uint32_t *__restrict__ bkey, const uint32_t *__restrict__ shift,
-                                                          uint32_t *__restrict__ tab, float4 *__restrict__ npts,
-                                                          uint32_t *__restrict__ npidx, uint64_t *__restrict__ nkeys)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t bricks = (int64_t)*bricks_dev;
-    const int64_t id = (int64_t)blockIdx.x * 4 + wave;
-    if (id >= bricks) return;
-    const uint32_t e0 = id + 1 < bricks ? bstart[id + 1] : (uint32_t)m;  // the brick's end in the dense layout (starts are shifted by a later launch)
-    const uint32_t sh = shift[id], room = shift[id + 1] - sh;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    uint32_t *t = tab + id * kBrickStride;
-    for (int c = lane; c <= kBrickCells; c += 64) t[c] += sh;
-    const uint64_t filler = ((uint64_t)bkey[id] << 9) | 511ull;
-    if (lane == 0) bend[id] = e0 + sh + room;  // = the next brick's new start
-    for (uint32_t h = e0 + sh + (uint32_t)lane; h < e0 + sh + room; h += 64u) {
-        npts[h] = make_map_point(3.0e38f, 3.0e38f, 3.0e38f, 0xffffffffu);
-        npidx[h] = 0xffffffffu;
-        nkeys[h] = filler;
-    }
-}
-// (a separate launch: a wave of slack_brick_kernel reads its successor's start)
-__global__ __launch_bounds__(256) void slack_start_kernel(const uint32_t *__restrict__ bricks_dev, const uint32_t *__restrict__ shift,
-                                                          uint32_t *__restrict__ bstart)
-{
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id < (int64_t)*bricks_dev) bstart[id] += shift[id];
-}
-
-// dense layout of m points (buf.pts / pidx / keys_alt, tables built) -> layout with slack; g.m becomes the new extent
-static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bound, int64_t top_entries, hipStream_t st)
-{
-    const int64_t m = g.m;
-    if (m <= 0 || bricks_bound <= 0) return hipSuccess;
-    const int64_t room_bound = m / 8 + 16 * bricks_bound + 64;  // slack <= max(cnt / 8, 16) per brick
-    const int64_t ext_bound = m + room_bound;
-    if (ext_bound > buf.scratch_cap || ext_bound >= ((int64_t)1 << 31) || bricks_bound + 2 > buf.scratch_cap) return hipSuccess;  // stays dense
-    S2M_TRY(ensure((void **)&buf.pts2, &buf.pts2_cap, ext_bound + kSentinelPoints, sizeof(float4), headroom_for(ext_bound)));
-    S2M_TRY(ensure((void **)&buf.pidx2, &buf.pidx2_cap, ext_bound + 1, sizeof(uint32_t), headroom_for(ext_bound)));
-    const uint32_t *bricks_dev = buf.rank + top_entries;
-    uint32_t *slack = buf.work_a, *shift = buf.work_b;
-    size_t tmp = 0;
-    S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, slack, shift, 0u, (size_t)bricks_bound + 1, rocprim::plus<uint32_t>(), st));
-    S2M_TRY(ensure_sort_tmp(buf, tmp));
-    hipLaunchKernelGGL(slack_size_kernel, dim3((unsigned)((bricks_bound + 256) / 256)), dim3(256), 0, st, bricks_bound, bricks_dev, m,
-                       buf.bstart, slack);
-    size_t t = buf.sort_tmp_bytes;
-    S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, slack, shift, 0u, (size_t)bricks_bound + 1, rocprim::plus<uint32_t>(), st));
-    {   // the total room: the map's new extent
-        const uint32_t *src[1] = {shift + bricks_bound};
-        S2M_TRY(mail_post(buf.mail, src, 1, st));
-    }
-    hipLaunchKernelGGL(slack_move_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.pts, buf.pidx, buf.keys_alt,
-                       buf.top, shift, buf.pts2, buf.pidx2, buf.keys);
-    hipLaunchKernelGGL(slack_brick_kernel, dim3((unsigned)((bricks_bound + 3) / 4)), dim3(256), 0, st, bricks_dev, m, buf.bstart, buf.bend,
-                       buf.bkey, shift, buf.tab, buf.pts2, buf.pidx2, buf.keys);
-    hipLaunchKernelGGL(slack_start_kernel, dim3((unsigned)((bricks_bound + 255) / 256)), dim3(256), 0, st, bricks_dev, shift, buf.bstart);
-    uint32_t room = 0;
-    S2M_TRY(mail_collect(buf.mail, 1, &room, st));
-    const int64_t ext = m + (int64_t)room;
-    S2M_TRY(put_sentinels(buf.pts2, ext, st));
-    std::swap(buf.pts, buf.pts2); std::swap(buf.pts_cap, buf.pts2_cap);
-    std::swap(buf.pidx, buf.pidx2); std::swap(buf.pidx_cap, buf.pidx2_cap);
-    std::swap(buf.keys, buf.keys_alt);
-    g.m = ext;
-    g.sent_off = (ext + kSentinelPoints) < ((int64_t)1 << 28) ? (uint32_t)(ext << 4) : 0u;
-    g.pts = buf.pts; g.pidx = buf.pidx;
-    return hipGetLastError();
-}
-
-hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive_s,
-                        const float4 *stage, int64_t n_new, bool &merged, hipStream_t st, bool with_slack)
-{
-    merged = false;
-    const int64_t m = g.m;
-    if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || m > buf.scratch_cap) return hipSuccess;
-    if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return hipSuccess;
-    const int n = (int)n_new;
-    const int64_t words = (m + 63) / 64;
-    // dword: [masks of the removed positions | packed records], words + 1 each; work_c: [removed per word | exclusive prefix];
-    // mv: [stage positions | upper bounds] of the new points
-    const int64_t w1 = words + 2;  // (even offsets keep the 16-byte records aligned)
-    S2M_TRY(ensure((void **)&buf.dword, &buf.dword_cap, 3 * w1 + 2, sizeof(unsigned long long), 3 * (words / 4 + 1024)));
-    unsigned long long *word_s = buf.dword;
-    DeadRank *rank_s = reinterpret_cast<DeadRank *>(buf.dword + (w1 + (w1 & 1)));
-    uint32_t *dcnt = buf.work_c, *dprefix = buf.work_c + (words + 1);
-    if (2 * (words + 1) > buf.scratch_cap + 1) return hipSuccess;
-    if (buf.next_id + n_new >= ((int64_t)1 << 32) - 2) return hipSuccess;  // ids exhausted: a rebuild makes them dense again
-    unsigned kbits = 10;  // (brick << 9 | cell) of this grid
-    {
-        const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
-        while (kbits < 64 && ((int64_t)1 << (kbits - 9)) < top_entries) ++kbits;
-    }
-    // capacity for the merged map before anything is enqueued (the exact size arrives with the hand-back below)
-    const int64_t m_bound = m + n_new;
-    if (m_bound > buf.scratch_cap || m_bound >= ((int64_t)1 << 31)) return hipSuccess;
-    size_t tmp = 0, tmp3 = 0;
-    S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
-    if (n > 0)
-        S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, buf.keys, buf.keys, buf.vals, buf.vals, (size_t)n_new, 0, kbits, st));
-    S2M_TRY(ensure_sort_tmp(buf, std::max(tmp, tmp3)));
-    if (n > 0) {
-        S2M_TRY(ensure((void **)&buf.mk, &buf.mk_cap, n_new, sizeof(uint64_t), n_new / 2 + 4096));
-        S2M_TRY(ensure((void **)&buf.mv, &buf.mv_cap, 2 * n_new, sizeof(uint32_t), n_new + 8192));
-    }
-    S2M_TRY(ensure((void **)&buf.pts2, &buf.pts2_cap, m_bound + kSentinelPoints, sizeof(float4), headroom_for(m_bound)));
-    S2M_TRY(ensure((void **)&buf.pidx2, &buf.pidx2_cap, m_bound + 1, sizeof(uint32_t), headroom_for(m_bound)));
-
-    // the rank of the removed positions (element `words` of the counts is zero: the prefix there is the total)
-    hipLaunchKernelGGL(dead_words_kernel, dim3((unsigned)((m + 256) / 256)), dim3(256), 0, st, m, alive_s, word_s, dcnt,
-                       buf.counters + 8);
-    size_t t = buf.sort_tmp_bytes;
-    S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
-    hipLaunchKernelGGL(dead_pack_kernel, dim3((unsigned)((words + 256) / 256)), dim3(256), 0, st, words, word_s, dprefix, rank_s);
-    uint64_t *nk_sorted = buf.mk;
-    uint32_t *nv_sorted = buf.mv, *lb = buf.mv + n_new;
-    // keys of the new points in the CURRENT grid (keys / vals are free until the merge writes them); the kernel also says
-    // whether one of them lies outside the grid
-    if (n > 0)
-        hipLaunchKernelGGL(merge_newkey_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals,
-                           buf.counters + 8);
-    // the one hand-back -- number of dead, "a new point lies outside the grid" -- is posted here and collected after the
-    // merge kernels have been enqueued: they write into the spare arrays, which only become the map if the answer allows it
-    const uint32_t *dead_dev = dprefix + words;
-    {
-        const uint32_t *src[2] = {dead_dev, buf.counters + 8};
-        S2M_TRY(mail_post(buf.mail, src, 2, st));
-    }
-    if (n > 0) {
-        t = buf.sort_tmp_bytes;
-        S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, nk_sorted, buf.vals, nv_sorted, (size_t)n_new, 0, kbits, st));
-        hipLaunchKernelGGL(merge_lb_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, buf.keys_alt, m, lb);
-    }
-    hipLaunchKernelGGL(merge_old_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.pts, buf.pidx, buf.keys_alt,
-                       alive_s, rank_s, lb, n, buf.pts2, buf.pidx2, buf.keys);
-    if (n > 0)
-        hipLaunchKernelGGL(merge_new_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, nv_sorted, lb, rank_s, stage,
-                           (uint32_t)buf.next_id, buf.pts2, buf.keys, buf.pidx2);
-    uint32_t dead = 0, outside = 0;
-    {
-        uint32_t v[2] = {0, 0};
-        S2M_TRY(mail_collect(buf.mail, 2, v, st));
-        dead = v[0];
-        outside = v[1];
-    }
-    if (outside) return hipSuccess;     // full rebuild (with a fresh margin); what was written to the spare arrays is dropped
-    if (dead == 0 && n_new == 0) {      // nothing was removed and nothing is added: the map stands as it is
-        merged = true;
-        return hipSuccess;
-    }
-    const int64_t survivors = m - (int64_t)dead;
-    const int64_t m_new = survivors + n_new;
-    if (m_new == 0) return hipSuccess;
-    buf.next_id += n_new;
-    if (dead > 0) buf.ids_dense = false;
-    S2M_TRY(put_sentinels(buf.pts2, m_new, st));
-    // the merged arrays become the map
-    std::swap(buf.pts, buf.pts2); std::swap(buf.pts_cap, buf.pts2_cap);
-    std::swap(buf.pidx, buf.pidx2); std::swap(buf.pidx_cap, buf.pidx2_cap);
-    std::swap(buf.keys, buf.keys_alt);
-    const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
-    S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(top_entries + 1) * sizeof(uint4), st));
-    g.m = m_new;
-    g.live = m_new;
-    g.sent_off = (m_new + kSentinelPoints) < ((int64_t)1 << 28) ? (uint32_t)(m_new << 4) : 0u;
-    // every new point opens at most one brick: no read-back before the tables are built
-    const int64_t brick_bound = std::min<int64_t>(stats.bricks + n_new, std::min<int64_t>(top_entries, m_new));
-    S2M_TRY(build_tables(buf, buf.keys_alt, m_new, top_entries, stats, st, brick_bound));
-    stats.top_entries = top_entries;
-    g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
-    if (with_slack) S2M_TRY(spread_with_slack(buf, g, brick_bound, top_entries, st));
-    merged = true;
-    return hipSuccess;
-}
-
-// ---- in-place update: only the touched bricks are rewritten -------------------------------------------------
-// The merge update above moves every point of the map; what an ordinary frame changes is a few thousand voxels in a few
-// hundred bricks.  When every touched brick still fits the stretch of pts it owns -- [its first position, the next brick's
-// first position): a fresh layout leaves no slack, but every removal does -- and no new point opens a brick, each touched
-// brick is rewritten where it stands by one workgroup: survivors and new points staged in LDS, merged by cell (new points
-// behind the old ones of their cell: ascending id, the documented order), written back with their keys and ids, the
-// brick's 513 prefix words and row mask rebuilt from the merged cells; what is left of the stretch becomes a hole
-// (alive_s 0, id ~0, the brick's largest key so that the key array stays sorted for the next merge).  Positions outside the
-// touched bricks do not move, so the cost follows the scan, not the map.  Anything else -- a brick that would overflow, a
-// new brick, a point outside the grid, a brick too large to stage -- is decided on the device BEFORE anything is written
-// and falls back to the merge update (which lays the map out densely again).
-constexpr int kSlabMax = 2048;  // points of one brick the rewrite stages in LDS (47 KB: three workgroups per CU)
-enum : uint32_t { kSlabOutside = 1u, kSlabNewBrick = 2u, kSlabOverflow = 4u };
-
-__global__ __launch_bounds__(256) void slab_key_kernel(const float4 *__restrict__ stage, int n, Grid g, uint64_t *__restrict__ keys,
-                                                       uint32_t *__restrict__ vals, uint8_t *__restrict__ bmark,
-                                                       uint32_t *__restrict__ flags)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t f = 0u;
-    if (i < n) {
-        const float4 p = stage[i];
-        const float fx = floorf((p.x - g.ox) * g.inv_c), fy = floorf((p.y - g.oy) * g.inv_c), fz = floorf((p.z - g.oz) * g.inv_c);
-        const bool out = !(fx >= 0.0f && fx <= (float)(g.ncx - 1) && fy >= 0.0f && fy <= (float)(g.ncy - 1) && fz >= 0.0f &&
-                           fz <= (float)(g.ncz - 1));
-        const int cx = cell_of(p.x, g.ox, g.inv_c, g.ncx), cy = cell_of(p.y, g.oy, g.inv_c, g.ncy),
-                  cz = cell_of(p.z, g.oz, g.inv_c, g.ncz);
-        const uint64_t brick = ((uint64_t)(cz >> 3) * g.nby + (cy >> 3)) * g.nbx + (cx >> 3);
-        const uint32_t local = (uint32_t)((((cz & 7) << 3) | (cy & 7)) << 3 | (cx & 7));
-        keys[i] = (brick << 9) | local;
-        vals[i] = (uint32_t)i;
-        if (out) {
-            f = kSlabOutside;
-        } else {
-            const uint32_t idp1 = g.top[brick].x;
-            if (idp1 != 0u) bmark[idp1 - 1u] |= 2u;  // (every writer of this byte in this launch stores the same value)
-            // (a point whose brick does not exist yet: slab_newbrick_kernel opens it)
-        }
-    }
-    const unsigned long long any = __ballot(f != 0u);
-    if (any != 0ull) {
-        uint32_t w = f;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) w |= __shfl_xor(w, off, 64);
-        if ((threadIdx.x & 63) == 0) atomicOr(flags, w);
-    }
-}
-
-// first index in the sorted keys whose brick part is >= b
-__device__ __forceinline__ int slab_lower(const uint64_t *__restrict__ nk, int n, uint64_t b)
-{
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((nk[mid] >> 9) < b) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// Bricks that this update opens (new points in a brick of the grid that holds nothing yet: a sensor that moves sees new
-// ground every frame) get their stretch of positions from the END of the room of the brick before them in key order, so
-// that position order stays key order; several new bricks in front of the same old brick line up there in key order.
-// One workgroup: heads of the new-brick segments of the sorted new keys (in order) -> per head the first old position of
-// a later brick (binary search in the sorted keys) -> a backward walk assigns the stretches -> the room of the brick in
-// front must still hold its own points plus what this update adds to it (ignoring what it removes: conservative) ->
-// only then are the entries written: top, brick key / start / end, an empty prefix row, the mark "new" (4) + "touched" (2),
-// the brick count.  Any doubt -- more than 1 024 new bricks, no brick in front, not enough room, no spare table rows --
-// raises kSlabNewBrick instead and writes nothing: the merge re-lays the map out.
-constexpr int kNewBricksMax = 1024;
-__global__ __launch_bounds__(256) void slab_newbrick_kernel(const uint64_t *__restrict__ nk, int n_new, uint4 *__restrict__ top,
-                                                            const uint64_t *__restrict__ okeys, int64_t m,
-                                                            uint32_t *__restrict__ tab, uint32_t *__restrict__ bstart,
-                                                            uint32_t *__restrict__ bend, uint32_t *__restrict__ bkey,
-                                                            uint8_t *__restrict__ bmark, uint32_t *__restrict__ bricks_dev,
-                                                            int max_new, uint32_t *__restrict__ flags)
-{
-    __shared__ uint32_t h_b[kNewBricksMax], h_k0[kNewBricksMax], h_need[kNewBricksMax], h_p0[kNewBricksMax], h_ida[kNewBricksMax],
-        h_start[kNewBricksMax], h_end[kNewBricksMax];
-    __shared__ int wsum[4];
-    __shared__ int s_fail;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) s_fail = 0;
-    __syncthreads();
-    // 1. the heads, in key order
-    int nh = 0;
-    for (int c0 = 0; c0 < n_new; c0 += 256) {
-        const int k = c0 + tid;
-        bool head = false;
-        uint32_t b = 0u;
-        if (k < n_new) {
-            b = (uint32_t)(nk[k] >> 9);
-            head = (k == 0 || (uint32_t)(nk[k - 1] >> 9) != b) && top[b].x == 0u;
-        }
-        const unsigned long long bal = __ballot(head);
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int off = nh;
-        for (int w = 0; w < wave; ++w) off += wsum[w];
-        const int chunk = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (head) {
-            const int i = off + __popcll(bal & ((1ull << lane) - 1ull));
-            if (i < kNewBricksMax) { h_b[i] = b; h_k0[i] = (uint32_t)k; }
-        }
-        nh += chunk;
-        __syncthreads();
-    }
-    if (nh == 0) return;  // (uniform)
-    if (nh > max_new || nh > kNewBricksMax) {
-        if (tid == 0) atomicOr(flags, kSlabNewBrick);
-        return;
-    }
-    // 2. per head: its points, what it asks for, the first old position of a later brick, the brick in front
-    for (int i = tid; i < nh; i += 256) {
-        const uint32_t b = h_b[i];
-        const int n_b = slab_lower(nk, n_new, (uint64_t)b + 1) - (int)h_k0[i];
-        h_need[i] = (uint32_t)n_b + max((uint32_t)n_b >> 2, 32u);
-        int64_t lo = 0, hi = m;  // first old position whose brick is later than b (b itself holds nothing)
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if ((okeys[mid] >> 9) <= (uint64_t)b) lo = mid + 1; else hi = mid;
-        }
-        h_p0[i] = (uint32_t)lo;
-        uint32_t ida = 0xffffffffu;
-        if (lo > 0) {
-            const uint32_t idp1 = top[okeys[lo - 1] >> 9].x;
-            if (idp1) ida = idp1 - 1u;
-        }
-        h_ida[i] = ida;
-        if (ida == 0xffffffffu) s_fail = 1;
-    }
-    __syncthreads();
-    // 3. stretches, from the back: the new bricks in front of the same old position line up in key order
-    if (tid == 0 && !s_fail) {
-        uint32_t cursor = 0u;
-        for (int i = nh - 1; i >= 0; --i) {
-            if (i == nh - 1 || h_p0[i] != h_p0[i + 1]) cursor = h_p0[i];
-            h_end[i] = cursor;
-            if (h_need[i] > cursor) { s_fail = 1; break; }
-            cursor -= h_need[i];
-            h_start[i] = cursor;
-            if (i == 0 || h_p0[i - 1] != h_p0[i]) {
-                // the lowest new brick of this group starts at `cursor`: the brick in front keeps [its start, cursor)
-                const uint32_t ida = h_ida[i];
-                const uint32_t a_base = tab[ida * kBrickStride], a_end = tab[ida * kBrickStride + kBrickCells];
-                const uint64_t ab = bkey[ida];
-                const int n_a = slab_lower(nk, n_new, ab + 1) - slab_lower(nk, n_new, ab);
-                // its room must be its own (bend says so: a stretch carved earlier in this launch cannot be carved twice)
-                if (bend[ida] != h_p0[i] || cursor < a_end + (uint32_t)n_a || cursor < a_base) { s_fail = 1; break; }
-            }
-        }
-    }
-    __syncthreads();
-    if (s_fail) {
-        if (tid == 0) atomicOr(flags, kSlabNewBrick);
-        return;
-    }
-    // 4. the entries
-    const uint32_t first_id = *bricks_dev;
-    for (int i = tid; i < nh; i += 256) {
-        const uint32_t id = first_id + (uint32_t)i, b = h_b[i];
-        uint32_t *te = reinterpret_cast<uint32_t *>(&top[b]);
-        te[0] = id + 1u; te[1] = h_start[i] + 1u; te[2] = 0u; te[3] = 0u;
-        bkey[id] = b;
-        bstart[id] = h_start[i];
-        bend[id] = h_end[i];
-        tab[id * kBrickStride] = h_start[i];
-        tab[id * kBrickStride + kBrickCells] = h_start[i];
-        bmark[id] = 6u;
-        if (i == 0 || h_p0[i - 1] != h_p0[i]) bend[h_ida[i]] = h_start[i];
-    }
-    __syncthreads();
-    if (tid == 0) { *bricks_dev = first_id + (uint32_t)nh; flags[2] = (uint32_t)nh; }
-}
-
-// one wave per brick: does the touched brick fit where it stands?  flags[0] |= overflow, flags[1] += points removed
-__global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restrict__ bricks_dev,
-                                                        const uint32_t *__restrict__ bend, const uint32_t *__restrict__ tab,
-                                                        const uint32_t *__restrict__ bkey, const uint8_t *__restrict__ bmark,
-                                                        const uint8_t *__restrict__ alive_s, const uint64_t *__restrict__ nk, int n_new,
-                                                        uint32_t *__restrict__ flags)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t bricks = (int64_t)*bricks_dev;
-    const int64_t id = (int64_t)blockIdx.x * 4 + wave;
-    if (id >= bricks || bmark[id] == 0) return;
-    const uint32_t base = tab[id * kBrickStride], end = tab[id * kBrickStride + kBrickCells];
-    const uint32_t cap_end = bend[id];
-    int alive = 0;
-    for (uint32_t j = base + (uint32_t)lane; j < end; j += 64u) alive += alive_s[j] ? 1 : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) alive += __shfl_xor(alive, off, 64);
-    if (lane != 0) return;
-    const uint64_t b = bkey[id];
-    const int n_b = n_new > 0 ? slab_lower(nk, n_new, b + 1) - slab_lower(nk, n_new, b) : 0;
-    const uint32_t total = (uint32_t)alive + (uint32_t)n_b;
-    if (total > cap_end - base || total > (uint32_t)kSlabMax || end - base > (uint32_t)kSlabMax) atomicOr(flags, kSlabOverflow);
-    atomicAdd(flags + 1, (end - base) - (uint32_t)alive);
-}
-
-// one workgroup per touched brick (see the comment above); does nothing when the plan found a reason not to
-__global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__restrict__ bricks_dev, const uint32_t *__restrict__ flags,
-                                                           float4 *__restrict__ pts, uint32_t *__restrict__ pidx,
-                                                           uint64_t *__restrict__ keys, uint8_t *__restrict__ alive_s,
-                                                           uint32_t *__restrict__ tab, uint4 *__restrict__ top,
-                                                           const uint32_t *__restrict__ bkey, uint8_t *__restrict__ bmark,
-                                                           const uint32_t *__restrict__ bend,
-                                                           const uint64_t *__restrict__ nk, const uint32_t *__restrict__ nv, int n_new,
-                                                           const float4 *__restrict__ stage, uint32_t next_id)
-{
-    __shared__ float4 l_p[kSlabMax];
-    __shared__ uint32_t l_id[kSlabMax];
-    __shared__ uint16_t l_c[kSlabMax];
-    __shared__ uint32_t l_t[kBrickCells];
-    __shared__ int wsum[4];
-    if (*flags != 0u) return;
-    const int64_t id = blockIdx.x;
-    if (id >= (int64_t)*bricks_dev || bmark[id] == 0) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const uint32_t base = tab[id * kBrickStride], cnt = tab[id * kBrickStride + kBrickCells] - base;
-    const uint64_t bk = bkey[id];
-    // a. the survivors, in order, into LDS
-    int n_old = 0;
-    for (uint32_t c0 = 0; c0 < cnt; c0 += 256u) {
-        const uint32_t i = c0 + (uint32_t)tid;
-        const bool a = i < cnt && alive_s[base + i] != 0;
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint32_t pid = 0u, cell = 0u;
-        if (a) { p = pts[base + i]; pid = pidx[base + i]; cell = (uint32_t)keys[base + i] & 511u; }
-        const unsigned long long bal = __ballot(a);
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int off = n_old;
-        for (int w = 0; w < wave; ++w) off += wsum[w];
-        const int chunk = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (a) {
-            const int r = off + __popcll(bal & ((1ull << lane) - 1ull));
-            l_p[r] = p; l_id[r] = pid; l_c[r] = (uint16_t)cell;
-        }
-        n_old += chunk;
-        __syncthreads();
-    }
-    // b. the brick's new points behind them (sorted by cell; equal cells in staged = id order: the sort is stable)
-    int lo = 0, n_b = 0;
-    if (n_new > 0) { lo = slab_lower(nk, n_new, bk); n_b = slab_lower(nk, n_new, bk + 1) - lo; }
-    for (int k = tid; k < n_b; k += 256) {
-        const uint32_t t = nv[lo + k];
-        l_p[n_old + k] = stage[t];
-        l_id[n_old + k] = next_id + t;
-        l_c[n_old + k] = (uint16_t)((uint32_t)nk[lo + k] & 511u);
-    }
-    for (int c = tid; c < kBrickCells; c += 256) l_t[c] = 0xffffffffu;
-    __syncthreads();
-    // c. merged places: an old point goes behind the new points of EARLIER cells, a new one behind the old points of its
-    // own and earlier cells
-    const int total = n_old + n_b;
-    for (int e = tid; e < total; e += 256) {
-        const uint32_t c = l_c[e];
-        int dlo = 0, dhi = 0, dest;
-        if (e < n_old) {
-            dhi = n_b;  // first new k with cell >= c
-            while (dlo < dhi) { const int mid = (dlo + dhi) >> 1; if (l_c[n_old + mid] < c) dlo = mid + 1; else dhi = mid; }
-            dest = e + dlo;
-        } else {
-            dhi = n_old;  // first old r with cell > c
-            while (dlo < dhi) { const int mid = (dlo + dhi) >> 1; if (l_c[mid] <= c) dlo = mid + 1; else dhi = mid; }
-            dest = (e - n_old) + dlo;
-        }
-        const uint32_t pos = base + (uint32_t)dest;
-        const float4 p = l_p[e];
-        // (a survivor holds {x, y, position, z}, a staged point {x, y, z, -})
-        pts[pos] = e < n_old ? make_map_point(p.x, p.y, map_point_z(p), pos) : make_map_point(p.x, p.y, p.z, pos);
-        pidx[pos] = l_id[e];
-        keys[pos] = (bk << 9) | (uint64_t)c;
-        alive_s[pos] = 1;
-        atomicMin(&l_t[c], pos);
-    }
-    // what the brick no longer fills; a brick opened by this update takes over its whole stretch (it was its
-    // predecessor's room: the filler keys there are the predecessor's)
-    const uint32_t fill_end = (bmark[id] & 4u) ? bend[id] - base : cnt;
-    for (uint32_t h = (uint32_t)total + (uint32_t)tid; h < fill_end; h += 256u) {
-        alive_s[base + h] = 0;
-        pidx[base + h] = 0xffffffffu;
-        keys[base + h] = (bk << 9) | 511ull;
-    }
-    __syncthreads();
-    // d. prefix words and row mask
-    if (wave == 0) {
-        unsigned long long mask;
-        (void)table_from_firsts(l_t, base + (uint32_t)total, tab + id * kBrickStride, lane, mask);
-        if (lane == 0) {
-            uint32_t *te = reinterpret_cast<uint32_t *>(&top[bk]);
-            te[2] = (uint32_t)mask;
-            te[3] = (uint32_t)(mask >> 32);
-            bmark[id] = 0;
-        }
-    }
-}
-
-// flags: three zeroed words of the update's counters (outcome bits, points removed, spare).  done = the map was updated in
-// place; otherwise nothing was touched and the caller goes on to merge_update.
-hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t n_new,
-                       uint32_t *flags, bool &done, hipStream_t st)
-{
-    done = false;
-    const int64_t m = g.m;
-    if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || !buf.bmark || stats.bricks <= 0 || m > buf.scratch_cap) return hipSuccess;
-    if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return hipSuccess;
-    if (buf.next_id + n_new >= ((int64_t)1 << 32) - 2) return hipSuccess;
-    const int n = (int)n_new;
-    const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
-    const uint32_t *bricks_dev = buf.rank + top_entries;
-    uint64_t *nk_sorted = buf.mk;
-    uint32_t *nv_sorted = buf.mv;
-    if (n > 0) {
-        unsigned kbits = 10;
-        while (kbits < 64 && ((int64_t)1 << (kbits - 9)) < top_entries) ++kbits;
-        size_t tmp = 0;
-        S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp, buf.keys, buf.keys, buf.vals, buf.vals, (size_t)n_new, 0, kbits, st));
-        S2M_TRY(ensure_sort_tmp(buf, tmp));
-        S2M_TRY(ensure((void **)&buf.mk, &buf.mk_cap, n_new, sizeof(uint64_t), n_new / 2 + 4096));
-        S2M_TRY(ensure((void **)&buf.mv, &buf.mv_cap, 2 * n_new, sizeof(uint32_t), n_new + 8192));
-        nk_sorted = buf.mk;
-        nv_sorted = buf.mv;
-        hipLaunchKernelGGL(slab_key_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals, buf.bmark, flags);
-        size_t t = buf.sort_tmp_bytes;
-        S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, nk_sorted, buf.vals, nv_sorted, (size_t)n_new, 0, kbits, st));
-    }
-    // spare rows for bricks this update opens (the tables were allocated with headroom)
-    const int64_t rows = std::min(std::min(buf.tab_cap / kBrickStride, buf.bstart_cap), std::min(std::min(buf.bkey_cap, buf.bmark_cap), buf.bend_cap));
-    const int max_new = (int)std::max<int64_t>(std::min<int64_t>(rows - stats.bricks, kNewBricksMax), 0);
-    if (n > 0)
-        hipLaunchKernelGGL(slab_newbrick_kernel, dim3(1), dim3(256), 0, st, nk_sorted, n, buf.top, buf.keys_alt, m, buf.tab, buf.bstart,
-                           buf.bend, buf.bkey, buf.bmark, buf.rank + top_entries, max_new, flags);
-    const int64_t bricks = stats.bricks + max_new;  // (an upper bound: a merged update's counts may be on their way, bricks may just have opened)
-    hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, buf.bend, buf.tab,
-                       buf.bkey, buf.bmark, alive_s, nk_sorted, n, flags);
-    {
-        const uint32_t *src[3] = {flags, flags + 1, flags + 2};
-        S2M_TRY(mail_post(buf.mail, src, 3, st));
-    }
-    hipLaunchKernelGGL(slab_rewrite_kernel, dim3((unsigned)bricks), dim3(256), 0, st, bricks_dev, flags, buf.pts, buf.pidx, buf.keys_alt,
-                       alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, nk_sorted, nv_sorted, n, stage, (uint32_t)buf.next_id);
-    uint32_t v[3] = {0, 0, 0};
-    S2M_TRY(mail_collect(buf.mail, 3, v, st));
-    if (v[0] != 0u) return hipSuccess;  // the rewrite kernel saw the same word and left the points alone
-    stats.bricks += v[2];
-    g.live += n_new - (int64_t)v[1];
-    buf.next_id += n_new;
-    if (v[1] > 0u) buf.ids_dense = false;
-    done = true;
-    return hipGetLastError();
 }
 
 // AoS (caller stride) -> SoA scan arrays; feats_down keeps only x, y, z on this path

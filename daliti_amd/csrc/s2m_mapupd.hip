@@ -19,7 +19,7 @@
 //            sorted position
 //   stage    the winning new points in batch order
 // The new map is "survivors in index order, then the staged points": merged into the sorted arrays of the current
-// grid (s2m_map.hip, merge_update) or, when a new point lies outside the grid, compacted here (update_finish) and
+// grid (s2m_mapedit.hip: in place or merged) or, when a new point lies outside the grid, compacted here (update_finish) and
 // rebuilt.  Counts travel to the host through the pinned mailbox (mail_fetch), not through 4-byte copies.  Among several OLD
 // points tied for the smallest centre distance the lowest index wins (the reference takes the
 // first in its tree traversal, which has no GPU counterpart); such ties need two points at exactly
@@ -88,7 +88,7 @@ __device__ __forceinline__ uint64_t voxel_key(float x, float y, float z, float d
 
 // visit every old point inside box [mn, mx) through the brick grid.  The cell of a coordinate,
 // floor((v - o) * inv_c) clamped to the grid, is a monotone function of v (every float step in it is), and
-// the map points were binned with the same expression (cell_of, s2m_map.hip): a point with mn <= p < mx lies
+// the map points were binned with the same expression (cell_of, s2m_map_internal.h): a point with mn <= p < mx lies
 // in a cell between cell(mn) and cell(mx), so no slack cells are needed.  Per x-row the cells of one brick
 // are one contiguous run of the sorted array.
 // `sub` of `stride`: the lanes of a group share one box and take every stride-th point of each run -- a lane that

@@ -289,7 +289,7 @@ def test_isolated_far_points_complete_their_lists(oracle, small_scene):
 
 @pytest.mark.gpu
 def test_merge_update_equals_rebuild(oracle, small_scene, monkeypatch):
-    """An update merged into the sorted arrays of the current grid (s2m_map.hip, merge_update) and the same update
+    """An update merged into the sorted arrays of the current grid (s2m_mapedit.hip, merge_update) and the same update
     through a full rebuild give the same map in the same caller order, and the same exact neighbours afterwards."""
     from daliti_amd import Engine
     rs = np.random.RandomState(11)
