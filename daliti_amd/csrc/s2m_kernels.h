@@ -60,6 +60,9 @@ struct MapBuffers {
     uint8_t *bmark = nullptr;    // per occupied brick: bit 0 = a point of it was removed, bit 1 = a new point goes into it, bit 2 = opened (this update)
     uint32_t *bend = nullptr;    // per occupied brick: end of the stretch of positions it owns (its points, then room)
     int64_t bkey_cap = 0, bmark_cap = 0, bend_cap = 0;
+    uint32_t *grow = nullptr;    // per top entry: points the brick has gained (net) by in-place updates since the room was laid out
+    int64_t grow_cap = 0;
+    int64_t added_since_layout = 0;  // host bound of the sum of `grow`
     uint64_t layout_gen = 0;     // counts builds and merges: a new dense layout of pts (in-place updates keep the layout)
     uint64_t *mk = nullptr;      // merge update: sorted keys of the new points
     uint32_t *mv = nullptr;      // merge update: their stage positions, then their lower bounds among the old keys

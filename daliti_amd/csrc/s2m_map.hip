@@ -231,7 +231,7 @@ int64_t map_headroom_for(int64_t m) { return m / 4 + 65536; }
 void free_map(MapBuffers &b)
 {
     void *ptrs[] = {b.pts, b.pidx, b.pts2, b.pidx2, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.work_a, b.work_b,
-                    b.work_c, b.rank, b.bstart, b.bkey, b.bmark, b.bend, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
+                    b.work_c, b.rank, b.bstart, b.bkey, b.bmark, b.bend, b.grow, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b.h_stats) { (void)hipHostFree(b.h_stats); (void)hipEventDestroy(b.stats_event); }
@@ -401,6 +401,10 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     S2M_TRY(ensure_scratch(buf, m));
     if (!buf.counters) S2M_TRY(hipMalloc((void **)&buf.counters, (64 + kOccShards * 32) * sizeof(uint32_t)));
     S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(top_entries + 1) * sizeof(uint4), st));
+    // net growth of every brick of this grid since its room was last laid out (s2m_mapedit.hip): a new grid starts from zero
+    S2M_TRY(map_ensure((void **)&buf.grow, &buf.grow_cap, top_entries + 1, sizeof(uint32_t)));
+    S2M_TRY(hipMemsetAsync(buf.grow, 0, (size_t)(top_entries + 1) * sizeof(uint32_t), st));
+    buf.added_since_layout = 0;
     S2M_TRY(hipMemsetAsync(buf.counters, 0, 64 * sizeof(uint32_t), st));
     stats = MapStats();
     stats.top_entries = top_entries;

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void merge_new_kernel(int n, const uint64_t *_
 // before`, the holes are filled with sentinel points (never a neighbour: +inf distance), id ~0 and the brick's largest key
 // (the key array stays sorted), prefix words and brick starts are shifted.
 __global__ __launch_bounds__(256) void slack_size_kernel(int64_t bound, const uint32_t *__restrict__ bricks_dev, int64_t m,
-                                                         const uint32_t *__restrict__ bstart, uint32_t *__restrict__ slack)
+                                                         const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bkey,
+                                                         uint32_t *__restrict__ grow, uint32_t *__restrict__ slack)
 {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id > bound) return;
@@ -167,7 +168,11 @@ __global__ __launch_bounds__(256) void slack_size_kernel(int64_t bound, const ui
     uint32_t v = 0u;
     if (id < bricks) {
         const uint32_t cnt = (id + 1 < bricks ? bstart[id + 1] : (uint32_t)m) - bstart[id];
-        v = min(max(cnt >> 3, 16u), 512u);
+        // an eighth of the brick -- or four times what it has gained since the room was last laid out, if that is more: the
+        // bricks that grow (a frontier, a surface the sensor keeps refining) are the ones that would force the next merge
+        const uint32_t gained = grow[bkey[id]];
+        v = max(min(max(cnt >> 3, 16u), 512u), min(4u * gained, 4096u));
+        grow[bkey[id]] = gained >> 1;  // the history fades: half of it counts towards the next layout
     }
     slack[id] = v;
 }
@@ -222,7 +227,8 @@ static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bou
 {
     const int64_t m = g.m;
     if (m <= 0 || bricks_bound <= 0) return hipSuccess;
-    const int64_t room_bound = m / 8 + 16 * bricks_bound + 64;  // slack <= max(cnt / 8, 16) per brick
+    // slack <= max(cnt / 8, 16) + 4 x growth per brick; the host knows the sum of the growth as a bound
+    const int64_t room_bound = m / 8 + 16 * bricks_bound + 64 + 4 * buf.added_since_layout;
     const int64_t ext_bound = m + room_bound;
     if (ext_bound > buf.scratch_cap || ext_bound >= ((int64_t)1 << 31) || bricks_bound + 2 > buf.scratch_cap) return hipSuccess;  // stays dense
     S2M_TRY(map_ensure((void **)&buf.pts2, &buf.pts2_cap, ext_bound + kSentinelPoints, sizeof(float4), map_headroom_for(ext_bound)));
@@ -233,7 +239,8 @@ static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bou
     S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, slack, shift, 0u, (size_t)bricks_bound + 1, rocprim::plus<uint32_t>(), st));
     S2M_TRY(map_ensure_sort_tmp(buf, tmp));
     hipLaunchKernelGGL(slack_size_kernel, dim3((unsigned)((bricks_bound + 256) / 256)), dim3(256), 0, st, bricks_bound, bricks_dev, m,
-                       buf.bstart, slack);
+                       buf.bstart, buf.bkey, buf.grow, slack);
+    buf.added_since_layout = (buf.added_since_layout + 1) / 2;
     size_t t = buf.sort_tmp_bytes;
     S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, slack, shift, 0u, (size_t)bricks_bound + 1, rocprim::plus<uint32_t>(), st));
     {   // the total room: the map's new extent
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restri
                                                         const uint32_t *__restrict__ bend, const uint32_t *__restrict__ tab,
                                                         const uint32_t *__restrict__ bkey, const uint8_t *__restrict__ bmark,
                                                         const uint8_t *__restrict__ alive_s, const uint64_t *__restrict__ nk, int n_new,
-                                                        uint32_t *__restrict__ flags)
+                                                        uint32_t *__restrict__ grow, uint32_t *__restrict__ flags)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t bricks = (int64_t)*bricks_dev;
@@ -560,6 +567,8 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restri
     const uint32_t total = (uint32_t)alive + (uint32_t)n_b;
     if (total > cap_end - base || total > (uint32_t)kSlabMax || end - base > (uint32_t)kSlabMax) atomicOr(flags, kSlabOverflow);
     atomicAdd(flags + 1, (end - base) - (uint32_t)alive);
+    // what the brick gains by this update (whether it ends up in place or merged): the next layout sizes its room by it
+    if (total > end - base) grow[b] += total - (end - base);
 }
 
 // one workgroup per touched brick (see the comment above); does nothing when the plan found a reason not to
@@ -698,7 +707,8 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
                            buf.bend, buf.bkey, buf.bmark, buf.rank + top_entries, max_new, flags);
     const int64_t bricks = stats.bricks + max_new;  // (an upper bound: a merged update's counts may be on their way, bricks may just have opened)
     hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, buf.bend, buf.tab,
-                       buf.bkey, buf.bmark, alive_s, nk_sorted, n, flags);
+                       buf.bkey, buf.bmark, alive_s, nk_sorted, n, buf.grow, flags);
+    buf.added_since_layout += n_new;
     {
         const uint32_t *src[3] = {flags, flags + 1, flags + 2};
         S2M_TRY(mail_post(buf.mail, src, 3, st));
