@@ -108,20 +108,36 @@ __device__ __forceinline__ void match_rows_body(const MatchArgs &a, uint2 *__res
     const bool split = xok && bB != bA;
     const int ax1 = split ? (bA << 3) + 7 : x_hi;  // last cell of segment A
     const int bx0 = bB << 3;                         // first cell of segment B
-    // phase 1: brick ids of the nine rows (two per row where the row is split).  The row masks are not consulted:
-    // an empty row's prefix words are equal, i.e. an empty run.
+    // phase 1: brick ids of the nine rows (two per row where the row is split).  The rows cy-1..cy+1 x cz-1..cz+1 touch at
+    // most 2 x 2 bricks in (y, z): four top entries per x-brick are loaded and the nine rows select among them (nine loads
+    // per x-brick before: at saturation the kernel is bound by vector-memory instructions, scripts/ta_lines.hip).  The row
+    // masks are not consulted: an empty row's prefix words are equal, i.e. an empty run.
     uint32_t idA[9], idB[9];
     int rowbit[9];
+    {
+        const int yb0 = (q.cy - 1) >> 3, yb1 = (q.cy + 1) >> 3, zb0 = (q.cz - 1) >> 3, zb1 = (q.cz + 1) >> 3;
+        uint32_t tA[2][2] = {{0u, 0u}, {0u, 0u}}, tB[2][2] = {{0u, 0u}, {0u, 0u}};
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        const int yy = q.cy + (r % 3) - 1, zz = q.cz + (r / 3) - 1;
-        const bool ok = xok && yy >= 0 && yy < g.ncy && zz >= 0 && zz < g.ncz;
-        rowbit[r] = ((zz & 7) << 3) | (yy & 7);
-        const int64_t toprow = ((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx;
-        idA[r] = 0u;
-        idB[r] = 0u;
-        if (ok) idA[r] = g.top[toprow + bA].x;
-        if (ok && split) idB[r] = g.top[toprow + bB].x;
+        for (int zi = 0; zi < 2; ++zi)
+#pragma unroll
+            for (int yi = 0; yi < 2; ++yi) {
+                const int yb = yi ? yb1 : yb0, zb = zi ? zb1 : zb0;
+                const bool okb = xok && yb >= 0 && yb < g.nby && zb >= 0 && zb < g.nbz;
+                const int64_t toprow = ((int64_t)zb * g.nby + yb) * g.nbx;
+                if (okb) tA[zi][yi] = g.top[toprow + bA].x;
+                if (okb && split) tB[zi][yi] = g.top[toprow + bB].x;
+            }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const int yy = q.cy + (r % 3) - 1, zz = q.cz + (r / 3) - 1;
+            const bool ok = xok && yy >= 0 && yy < g.ncy && zz >= 0 && zz < g.ncz;
+            rowbit[r] = ((zz & 7) << 3) | (yy & 7);
+            const bool ysel = (yy >> 3) != yb0, zsel = (zz >> 3) != zb0;
+            const uint32_t a = zsel ? (ysel ? tA[1][1] : tA[1][0]) : (ysel ? tA[0][1] : tA[0][0]);
+            const uint32_t b = zsel ? (ysel ? tB[1][1] : tB[1][0]) : (ysel ? tB[0][1] : tB[0][0]);
+            idA[r] = ok ? a : 0u;
+            idB[r] = (ok && split) ? b : 0u;
+        }
     }
     // phase 2: the home row's prefix words (four consecutive words cover its three cells); the other rows' words are
     // fetched after the home row has produced a bound -- only for the rows and cells that survive it
