@@ -617,3 +617,15 @@ def test_inplace_update_opens_new_bricks(oracle, small_scene, monkeypatch):
         assert a[2][k] == b[2][k], k
         assert a[0][k].shape == b[0][k].shape and (bits(a[0][k]) == bits(b[0][k])).all(), k
         assert (a[1][k][0] == b[1][k][0]).all() and (bits(a[1][k][1]) == bits(b[1][k][1])).all(), k
+
+
+@pytest.mark.gpu
+def test_inplace_soak_random_updates():
+    """scripts/soak_inplace.py: 200 random updates (voxel-rule adds, plain adds, blobs in empty bricks, bursts, box deletes,
+    points outside the grid) through a handle that updates in place and, in a child process, one that merges every update:
+    size, points in caller order after every step and the neighbour lists of a fixed query set every tenth step identical."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_inplace.py"), "200", "5"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
