@@ -164,7 +164,7 @@ void launch_positions_to_indices(const int32_t *nn, const uint32_t *pidx, int64_
 
 // ---- s2m_voxel.hip : scan voxel down-sampling (pcl::VoxelGrid, laserMapping.cpp:775-776) ------------
 struct VoxelBuffers {
-    uint64_t *key = nullptr, *key2 = nullptr;
+    uint32_t *key = nullptr, *key2 = nullptr;  // voxel index (below 2^31: PCL's own limit)
     uint32_t *val = nullptr, *val2 = nullptr, *head = nullptr, *pos = nullptr;
     float *box = nullptr;  // cloud_bbox scratch
     void *tmp = nullptr;

@@ -37,18 +37,18 @@ struct VoxelDims {
 };
 
 __global__ __launch_bounds__(256) void vx_key_kernel(const float *__restrict__ xyz, int64_t stride, int64_t n,
-                                                     VoxelDims d, uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+                                                     VoxelDims d, uint32_t *__restrict__ key, uint32_t *__restrict__ val)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int i0 = (int)(floorf(xyz[i * stride] * d.inv_leaf) - (float)d.min_b[0]);
     const int i1 = (int)(floorf(xyz[i * stride + 1] * d.inv_leaf) - (float)d.min_b[1]);
     const int i2 = (int)(floorf(xyz[i * stride + 2] * d.inv_leaf) - (float)d.min_b[2]);
-    key[i] = (uint64_t)((int64_t)i0 + (int64_t)i1 * d.mul1 + (int64_t)i2 * d.mul2);
+    key[i] = (uint32_t)((int64_t)i0 + (int64_t)i1 * d.mul1 + (int64_t)i2 * d.mul2);  // < 2^31 (checked on the host)
     val[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void vx_head_kernel(const uint64_t *__restrict__ skey, int64_t n, uint32_t *__restrict__ head)
+__global__ __launch_bounds__(256) void vx_head_kernel(const uint32_t *__restrict__ skey, int64_t n, uint32_t *__restrict__ head)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s < n) head[s] = (s == 0 || skey[s - 1] != skey[s]) ? 1u : 0u;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void vx_head_kernel(const uint64_t *__restrict
 
 // one lane per voxel: float sum of its points in ascending input index, divided by the count
 __global__ __launch_bounds__(256) void vx_centroid_kernel(const float *__restrict__ xyz, int64_t stride, int64_t n,
-                                                          const uint64_t *__restrict__ skey,
+                                                          const uint32_t *__restrict__ skey,
                                                           const uint32_t *__restrict__ sval,
                                                           const uint32_t *__restrict__ head,
                                                           const uint32_t *__restrict__ pos, float *__restrict__ ox,
@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256) void vx_centroid_kernel(const float *__restric
     // four positions per trip: their keys, indices and points are requested together and added in order (a near-field
     // voxel holds dozens of points; one dependent key -> index -> point chain per point made this the longest kernel of
     // the front half)
-    const uint64_t k0 = skey[s];
+    const uint32_t k0 = skey[s];
     for (int64_t t = s; t < n; t += 4) {
-        uint64_t kk[4];
+        uint32_t kk[4];
         uint32_t ii[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -124,7 +124,7 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
     if (n <= 0) return hipSuccess;
     if (v.cap < n) {
         void **ps[] = {(void **)&v.key, (void **)&v.key2, (void **)&v.val, (void **)&v.val2, (void **)&v.head, (void **)&v.pos};
-        const size_t es[] = {8, 8, 4, 4, 4, 4};
+        const size_t es[] = {4, 4, 4, 4, 4, 4};
         for (int k = 0; k < 6; ++k) {
             if (*ps[k]) S2M_TRY(hipFree(*ps[k]));
             *ps[k] = nullptr;
