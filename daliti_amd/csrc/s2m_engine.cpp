@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -78,6 +79,8 @@ struct s2m_engine {
         std::mutex mu;
         std::condition_variable cv;
         bool quit = false, busy = false, ready = false;
+        std::atomic<int> busy_a{0};      // mirror of `busy` for the short spins in front of the condition-variable waits: a futex
+                                         // sleep / wake is tens of microseconds at best and has been seen to cost 10 ms once
         const float *src = nullptr;      // host records the job copies / the copy in d_buf belongs to
         int64_t floats = 0;
         hipError_t err = hipSuccess;
@@ -919,6 +922,11 @@ void prefetch_worker(s2m_engine *e)
     (void)hipSetDevice(e->device);
     std::unique_lock<std::mutex> lk(p.mu);
     for (;;) {
+        if (!(p.quit || p.busy)) {  // the next job usually follows within a frame: poll for it before going to sleep
+            lk.unlock();
+            for (int spin = 0; spin < 20000 && p.busy_a.load(std::memory_order_acquire) == 0; ++spin) __builtin_ia32_pause();
+            lk.lock();
+        }
         p.cv.wait(lk, [&] { return p.quit || p.busy; });
         if (p.quit) return;
         const float *src = p.src;
@@ -947,6 +955,7 @@ void prefetch_worker(s2m_engine *e)
         p.err = he;
         p.m = m;
         p.busy = false;
+        p.busy_a.store(0, std::memory_order_release);
         p.ready = he == hipSuccess && !prepare;
         p.prepared = ok && he == hipSuccess && prepare;
         p.cv.notify_all();
@@ -957,6 +966,7 @@ void prefetch_worker(s2m_engine *e)
 void pf_drain(s2m_engine *e)
 {
     if (!e->pf.worker.joinable()) return;
+    for (int spin = 0; spin < 40000 && e->pf.busy_a.load(std::memory_order_acquire) != 0; ++spin) __builtin_ia32_pause();
     std::unique_lock<std::mutex> lk(e->pf.mu);
     e->pf.cv.wait(lk, [&] { return !e->pf.busy; });
 }
@@ -995,6 +1005,7 @@ int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride, in
         e->pf.prepare = false;
         e->pf.copied = false;
         e->pf.busy = true;
+        e->pf.busy_a.store(1, std::memory_order_release);
     }
     e->pf.cv.notify_all();
     return S2M_OK;
@@ -1031,6 +1042,7 @@ int s2m_scan_prepare_raw(s2m_engine *e, const float *points, int64_t stride, int
         p.prepare = true;
         p.copied = have;
         p.busy = true;
+        p.busy_a.store(1, std::memory_order_release);
     }
     p.cv.notify_all();
     return S2M_OK;
