@@ -77,6 +77,44 @@ void body_to_world(const double x[S2M_STATE_DOUBLES], const float pb[3], float p
     for (int i = 0; i < 3; ++i) pw[i] = (float)g[i];
 }
 
+// one frame of the stream, parsed: what the loop body has in hand after `p_imu->Process` (:731-773)
+struct Frame {
+    double state[S2M_STATE_DOUBLES], P[S2M_DIM * S2M_DIM];
+    std::vector<s2m_imu_pose> poses;
+    std::vector<float> blob;  // the point records, realigned when the message body starts at an odd offset
+    s2m_pc2_view v;
+    const float *pts = nullptr;
+    int64_t stride = 0;
+    int32_t oa = 0, ob = 0;
+};
+// 0 = parsed, 65 = malformed (message on stderr)
+int parse_frame(Reader &rd, uint32_t f, Frame &fr)
+{
+    const uint32_t n_imu = rd.get<uint32_t>(), msg_len = rd.get<uint32_t>();
+    const uint8_t *ps = rd.take(sizeof(fr.state)), *pP = rd.take(sizeof(fr.P));
+    const uint8_t *pimu = rd.take((size_t)n_imu * sizeof(s2m_imu_pose));
+    const uint8_t *pmsg = rd.take(((size_t)msg_len + 7) & ~(size_t)7);
+    if (!rd.ok) { std::fprintf(stderr, "truncated frame %u\n", f); return 65; }
+    std::memcpy(fr.state, ps, sizeof(fr.state));
+    std::memcpy(fr.P, pP, sizeof(fr.P));
+    fr.poses.resize(n_imu);
+    std::memcpy(fr.poses.data(), pimu, (size_t)n_imu * sizeof(s2m_imu_pose));
+    // pcl::fromROSMsg(*(lidar_buffer.front()), *(meas.lidar)) (:545) without PCL
+    if (s2m_pc2_parse(pmsg, msg_len, &fr.v, nullptr) != S2M_WIRE_OK) { std::fprintf(stderr, "bad PointCloud2 in frame %u\n", f); return 65; }
+    int wrc = s2m_pc2_scan_args(&fr.v, &fr.pts, &fr.stride, &fr.oa, &fr.ob);
+    if (wrc == S2M_WIRE_UNALIGNED) {  // the blob starts wherever the header ends: realign it once
+        fr.blob.resize((fr.v.data_len + 3) / 4);
+        std::memcpy(fr.blob.data(), fr.v.data, fr.v.data_len);
+        fr.v.data = reinterpret_cast<const uint8_t *>(fr.blob.data());
+        wrc = s2m_pc2_scan_args(&fr.v, &fr.pts, &fr.stride, &fr.oa, &fr.ob);
+    }
+    if (wrc != S2M_WIRE_OK) {
+        std::fprintf(stderr, "frame %u: /laser_cloud_surf layout not usable (need float32 x,y,z,normal_x,normal_z)\n", f);
+        return 65;
+    }
+    return 0;
+}
+
 void append_msg(std::vector<uint8_t> &out, int kind, uint32_t seq, double stamp, const void *rec, uint32_t n)
 {
     const size_t sz = s2m_pc2_serialized_size(kind, n, "camera_init");
@@ -124,37 +162,31 @@ int main(int argc, char **argv)
     double first_lidar_time = 0.0;
     std::vector<float> xyz, world;
     std::vector<int32_t> ridx;
-    std::vector<s2m_imu_pose> poses;
-    std::vector<float> blob;
+    // One frame ahead: a replay has the next message (and the IMU poses propagated for it, an input of this stream) in hand
+    // while the current one is registered, so its records travel (s2m_scan_prefetch_raw) and its undistortion + voxel filter
+    // run (s2m_scan_prepare_raw, once this frame's update is done) beside this frame's map update; the next iteration's
+    // s2m_scan_set_from_raw picks the prepared scan up.  Same results as computing every frame in place.
+    Frame frames[2];
+    bool have_next = false;
+    if (n_frames > 0) {
+        const int prc = parse_frame(rd, 0, frames[0]);
+        if (prc) return prc;
+    }
     for (uint32_t f = 0; f < n_frames; ++f) {
-        const uint32_t n_imu = rd.get<uint32_t>(), msg_len = rd.get<uint32_t>();
-        double state[S2M_STATE_DOUBLES], P[S2M_DIM * S2M_DIM];
-        const uint8_t *ps = rd.take(sizeof(state)), *pP = rd.take(sizeof(P));
-        const uint8_t *pimu = rd.take((size_t)n_imu * sizeof(s2m_imu_pose));
-        const uint8_t *pmsg = rd.take(((size_t)msg_len + 7) & ~(size_t)7);
-        if (!rd.ok) { std::fprintf(stderr, "truncated frame %u\n", f); return 65; }
-        std::memcpy(state, ps, sizeof(state));
-        std::memcpy(P, pP, sizeof(P));
-        poses.resize(n_imu);
-        std::memcpy(poses.data(), pimu, (size_t)n_imu * sizeof(s2m_imu_pose));
-
-        // pcl::fromROSMsg(*(lidar_buffer.front()), *(meas.lidar)) (:545) without PCL
-        s2m_pc2_view v;
-        if (s2m_pc2_parse(pmsg, msg_len, &v, nullptr) != S2M_WIRE_OK) { std::fprintf(stderr, "bad PointCloud2 in frame %u\n", f); return 65; }
-        const float *pts = nullptr;
-        int64_t stride = 0;
-        int32_t oa = 0, ob = 0;
-        int wrc = s2m_pc2_scan_args(&v, &pts, &stride, &oa, &ob);
-        if (wrc == S2M_WIRE_UNALIGNED) {  // the blob starts wherever the header ends: realign it once
-            blob.resize((v.data_len + 3) / 4);
-            std::memcpy(blob.data(), v.data, v.data_len);
-            v.data = reinterpret_cast<const uint8_t *>(blob.data());
-            wrc = s2m_pc2_scan_args(&v, &pts, &stride, &oa, &ob);
+        Frame &cur = frames[f & 1], &nxt = frames[(f + 1) & 1];
+        have_next = false;
+        if (f + 1 < n_frames) {
+            const int prc = parse_frame(rd, f + 1, nxt);
+            if (prc) return prc;
+            have_next = true;
         }
-        if (wrc != S2M_WIRE_OK) {
-            std::fprintf(stderr, "frame %u: /laser_cloud_surf layout not usable (need float32 x,y,z,normal_x,normal_z)\n", f);
-            return 65;
-        }
+        double *state = cur.state, *P = cur.P;
+        std::vector<s2m_imu_pose> &poses = cur.poses;
+        const uint32_t n_imu = (uint32_t)poses.size();
+        const s2m_pc2_view &v = cur.v;
+        const float *pts = cur.pts;
+        const int64_t stride = cur.stride;
+        const int32_t oa = cur.oa, ob = cur.ob;
         const double lidar_beg_time = (double)v.stamp_sec + 1e-9 * (double)v.stamp_nsec;  // :546
         if (first_scan) { first_lidar_time = lidar_beg_time; first_scan = false; }          // :737-741
         // observation_end_time = lidar_beg_time + points.back().normal_z (:547): the stamp of everything published
@@ -165,6 +197,7 @@ int main(int argc, char **argv)
         int64_t n_down = 0;
         CK(s2m_scan_set_from_raw(eng, pts, stride, v.n_points, oa, ob, poses.data(), (int32_t)n_imu, state, (float)fs_surf,
                                  0, &n_down));
+        if (have_next) CK(s2m_scan_prefetch_raw(eng, nxt.pts, nxt.stride, nxt.v.n_points));
         // lasermap_fov_segment (:772): pos_lid = pos_end + rot_end * T_L_I (:753)
         double pos_lid[3];
         for (int i = 0; i < 3; ++i)
@@ -206,6 +239,9 @@ int main(int argc, char **argv)
         append_msg(effected_msgs, 0, f, obs_end, rec.data(), (uint32_t)m_eff);
         // map_incremental (:1165-1168)
         int64_t n_add = 0, n_nodown = 0, m_map = 0;
+        if (have_next)  // the next frame's front half beside this frame's map update
+            CK(s2m_scan_prepare_raw(eng, nxt.pts, nxt.stride, nxt.v.n_points, nxt.oa, nxt.ob, nxt.poses.data(), (int32_t)nxt.poses.size(),
+                                    nxt.state, (float)fs_surf));
         if (!log.ekf_stop) CK(s2m_map_incremental(eng, x, fs_map, 1, &n_add, &n_nodown));
         CK(s2m_map_size(eng, &m_map));
         fodom << lidar_beg_time - first_lidar_time;
