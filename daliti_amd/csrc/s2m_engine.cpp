@@ -92,6 +92,9 @@ struct s2m_engine {
         // the side stream; what it was asked for is kept so that s2m_scan_set_from_raw can recognise the same call
         bool prepare = false, prepared = false;
         bool copied = false;             // the records of this job are in d_buf already (a prefetch that was not consumed)
+        // the time order of the records in d_buf (und.val2) has been computed for these time fields (a prefetch with offsets)
+        bool want_order = false, ordered = false;
+        int32_t order_oa = 0, order_ob = 0;
         int64_t stride = 0, n = 0, m = 0;
         int32_t oa = 0, ob = 0;
         float leaf = 0.0f;
@@ -875,6 +878,7 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride, int64_t n,
     if (n == 0) return S2M_OK;
     S2M_HIP(e, hipSetDevice(e->device));
     pf_drain(e);  // the undistortion buffers are shared with the side thread
+    e->pf.ordered = false;  // (a time order the side thread left there is about to be overwritten)
     const float *dev = nullptr;
     // stage whole records (the time fields may sit anywhere in the record)
     if (on_device) {
@@ -937,9 +941,17 @@ void prefetch_worker(s2m_engine *e)
                                  : hipMemcpyAsync(p.d_buf, src, (size_t)floats * sizeof(float), hipMemcpyHostToDevice, p.stream);
         int64_t m = p.n;
         bool ok = he == hipSuccess;
+        bool ordered = p.copied && p.ordered;
+        if (ok && !prepare && p.want_order) {  // the time order needs the records only: it is ready when the poses arrive
+            he = undistort_order(e->und, p.d_buf, p.stride, p.n, p.order_oa, p.order_ob, p.stream);
+            ok = he == hipSuccess;
+            ordered = ok;
+        }
         if (ok && prepare) {
+            const bool have_order = ordered && p.order_oa == p.oa && p.order_ob == p.ob;
             he = undistort(e->und, p.d_buf, p.stride, p.n, p.oa, p.ob, p.poses.data(), (int)(p.poses.size() / 22), pose_of(p.state_end),
-                           true, nullptr, p.stream);
+                           true, nullptr, p.stream, have_order);
+            ordered = false;  // (the voxel grid and the next sort reuse the buffers)
             ok = he == hipSuccess;
             float *sx = e->d_scan_alt, *sy = e->d_scan_alt + e->scan_alt_cap, *sz = e->d_scan_alt + 2 * e->scan_alt_cap;
             if (ok && p.leaf > 0.0f) {
@@ -954,6 +966,7 @@ void prefetch_worker(s2m_engine *e)
         lk.lock();
         p.err = he;
         p.m = m;
+        p.ordered = ordered && he == hipSuccess;
         p.busy = false;
         p.busy_a.store(0, std::memory_order_release);
         p.ready = he == hipSuccess && !prepare;
@@ -993,9 +1006,10 @@ int pf_start(s2m_engine *e, const float *points, int64_t floats)
 }
 }  // namespace
 
-int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride, int64_t n)
+int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride, int64_t n, int32_t oa, int32_t ob)
 {
-    if (!e || n < 0 || stride < 3 || (n > 0 && !points)) return fail(e, S2M_ERR_ARG, "s2m_scan_prefetch_raw: bad argument");
+    if (!e || n < 0 || stride < 3 || (n > 0 && !points) || oa >= stride || ob >= stride)
+        return fail(e, S2M_ERR_ARG, "s2m_scan_prefetch_raw: bad argument");
     if (n == 0) return S2M_OK;
     S2M_HIP(e, hipSetDevice(e->device));
     int rc = pf_start(e, points, n * stride);
@@ -1004,6 +1018,10 @@ int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride, in
         std::lock_guard<std::mutex> lk(e->pf.mu);
         e->pf.prepare = false;
         e->pf.copied = false;
+        e->pf.want_order = oa >= 0;
+        e->pf.ordered = false;
+        e->pf.order_oa = oa; e->pf.order_ob = ob;
+        e->pf.stride = stride; e->pf.n = n;
         e->pf.busy = true;
         e->pf.busy_a.store(1, std::memory_order_release);
     }
@@ -1024,8 +1042,10 @@ int s2m_scan_prepare_raw(s2m_engine *e, const float *points, int64_t stride, int
     pf_drain(e);
     // the records may be on the device already: s2m_scan_prefetch_raw at the start of the frame, this call once the poses exist
     const bool have = e->pf.ready && e->pf.src == points && e->pf.floats == n * stride;
+    const bool have_order = have && e->pf.ordered;
     rc = pf_start(e, points, n * stride);
     if (rc) return rc;
+    e->pf.ordered = have_order;
     if (e->scan_alt_cap != e->n_cap) {
         if (e->d_scan_alt) S2M_HIP(e, hipFree(e->d_scan_alt));
         e->d_scan_alt = nullptr;
@@ -1073,7 +1093,7 @@ int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, in
     if (rc) return rc;
     if (n > 0) {
         const float *dev = points;
-        bool prefetched = false;
+        bool prefetched = false, order_ready = false;
         if (!on_device && e->pf.worker.joinable()) {  // has s2m_scan_prefetch_raw brought exactly these records over already?
             auto &p = e->pf;
             std::unique_lock<std::mutex> lk(p.mu);
@@ -1081,6 +1101,8 @@ int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, in
                 p.cv.wait(lk, [&] { return !p.busy; });
                 if (p.ready) {
                     p.ready = false;  // consumed
+                    order_ready = p.ordered && p.order_oa == oa && p.order_ob == ob;
+                    p.ordered = false;
                     lk.unlock();
                     S2M_HIP(e, hipStreamWaitEvent(e->stream, p.done, 0));
                     dev = p.d_buf;
@@ -1088,6 +1110,7 @@ int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, in
                 }
             }
         }
+        if (!prefetched) e->pf.ordered = false;  // (this call's own sort overwrites an order the side thread left for other records)
         if (!on_device && !prefetched) {
             const int64_t floats = n * stride;
             if (floats > e->stage_cap) {
@@ -1099,7 +1122,7 @@ int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, in
             dev = e->d_stage;
         }
         S2M_HIP(e, undistort(e->und, dev, stride, n, oa, ob, reinterpret_cast<const double *>(poses), np,
-                             pose_of(state_end), true, nullptr, e->stream));
+                             pose_of(state_end), true, nullptr, e->stream, order_ready));
     }
     int64_t m = n;
     float *sx = e->d_scan, *sy = e->d_scan + e->n_cap, *sz = e->d_scan + 2 * e->n_cap;

@@ -191,7 +191,8 @@ struct UndistBuffers {
 void free_undist(UndistBuffers &u);
 hipError_t undistort(UndistBuffers &u, const float *pts, int64_t stride, int64_t n, int off_a, int off_b,
                      const double *poses_host, int K, const Pose &end, bool sort_by_time, uint32_t *perm_dev,
-                     hipStream_t st);
+                     hipStream_t st, bool order_ready = false);
+hipError_t undistort_order(UndistBuffers &u, const float *pts, int64_t stride, int64_t n, int off_a, int off_b, hipStream_t st);
 
 // ---- s2m_match.hip : exact 5-NN ------------------------------------------------------------------
 // match_hard hands its list out dynamically: every resident wave takes the point of its own index first, then pulls

@@ -154,22 +154,50 @@ void free_undist(UndistBuffers &u)
     u = UndistBuffers();
 }
 
-// pts: device records; poses_host: K x 22 doubles; result: u.out (n x 3 floats, device), sorted by time when asked
-hipError_t undistort(UndistBuffers &u, const float *pts, int64_t stride, int64_t n, int off_a, int off_b,
-                     const double *poses_host, int K, const Pose &end, bool sort_by_time, uint32_t *perm_dev,
-                     hipStream_t st)
+static hipError_t undist_reserve(UndistBuffers &u, int64_t n)
+{
+    if (u.cap >= n) return hipSuccess;
+    void **ps[] = {(void **)&u.key, (void **)&u.key2, (void **)&u.val, (void **)&u.val2, (void **)&u.out};
+    const size_t es[] = {4, 4, 4, 4, 12};
+    for (int k = 0; k < 5; ++k) {
+        if (*ps[k]) S2M_TRY(hipFree(*ps[k]));
+        *ps[k] = nullptr;
+        S2M_TRY(hipMalloc(ps[k], (size_t)n * es[k]));
+    }
+    u.cap = n;
+    return hipSuccess;
+}
+
+// the time order of the records -- std::sort(pcl_out.points.begin(), pcl_out.points.end(), time_list) (:216), made stable
+// -- into u.val2 (sorted position -> input index).  It needs the records only, not the poses: the side thread computes
+// it as soon as a prefetched sweep has arrived (s2m_scan_prefetch_raw)
+hipError_t undistort_order(UndistBuffers &u, const float *pts, int64_t stride, int64_t n, int off_a, int off_b, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    if (u.cap < n) {
-        void **ps[] = {(void **)&u.key, (void **)&u.key2, (void **)&u.val, (void **)&u.val2, (void **)&u.out};
-        const size_t es[] = {4, 4, 4, 4, 12};
-        for (int k = 0; k < 5; ++k) {
-            if (*ps[k]) S2M_TRY(hipFree(*ps[k]));
-            *ps[k] = nullptr;
-            S2M_TRY(hipMalloc(ps[k], (size_t)n * es[k]));
-        }
-        u.cap = n;
+    S2M_TRY(undist_reserve(u, n));
+    const int nb = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(undist_key_kernel, dim3(nb), dim3(256), 0, st, pts, stride, n, off_a, off_b, u.key, u.val);
+    size_t bytes = 0;
+    S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 32, st));
+    if (bytes > u.tmp_bytes) {
+        if (u.tmp) S2M_TRY(hipFree(u.tmp));
+        u.tmp = nullptr;
+        S2M_TRY(hipMalloc(&u.tmp, bytes));
+        u.tmp_bytes = bytes;
     }
+    size_t b2 = u.tmp_bytes;
+    S2M_TRY(rocprim::radix_sort_pairs(u.tmp, b2, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 32, st));
+    return hipGetLastError();
+}
+
+// pts: device records; poses_host: K x 22 doubles; result: u.out (n x 3 floats, device), sorted by time when asked
+// (order_ready: u.val2 already holds the time order of exactly these records, undistort_order)
+hipError_t undistort(UndistBuffers &u, const float *pts, int64_t stride, int64_t n, int off_a, int off_b,
+                     const double *poses_host, int K, const Pose &end, bool sort_by_time, uint32_t *perm_dev,
+                     hipStream_t st, bool order_ready)
+{
+    if (n <= 0) return hipSuccess;
+    if (!(sort_by_time && order_ready)) S2M_TRY(undist_reserve(u, n));  // (a reserve would drop the order that is ready)
     if (u.pose_cap < K) {
         if (u.poses) S2M_TRY(hipFree(u.poses));
         u.poses = nullptr;
@@ -179,18 +207,8 @@ hipError_t undistort(UndistBuffers &u, const float *pts, int64_t stride, int64_t
     S2M_TRY(hipMemcpyAsync(u.poses, poses_host, (size_t)K * 22 * sizeof(double), hipMemcpyHostToDevice, st));
     const int nb = (int)((n + 255) / 256);
     const uint32_t *order = nullptr;
-    if (sort_by_time) {  // std::sort(pcl_out.points.begin(), pcl_out.points.end(), time_list) (:216), made stable
-        hipLaunchKernelGGL(undist_key_kernel, dim3(nb), dim3(256), 0, st, pts, stride, n, off_a, off_b, u.key, u.val);
-        size_t bytes = 0;
-        S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 32, st));
-        if (bytes > u.tmp_bytes) {
-            if (u.tmp) S2M_TRY(hipFree(u.tmp));
-            u.tmp = nullptr;
-            S2M_TRY(hipMalloc(&u.tmp, bytes));
-            u.tmp_bytes = bytes;
-        }
-        size_t b2 = u.tmp_bytes;
-        S2M_TRY(rocprim::radix_sort_pairs(u.tmp, b2, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 32, st));
+    if (sort_by_time) {
+        if (!order_ready) S2M_TRY(undistort_order(u, pts, stride, n, off_a, off_b, st));
         order = u.val2;
     }
     hipLaunchKernelGGL(undistort_kernel, dim3(nb), dim3(256), 0, st, pts, stride, n, off_a, off_b, order, u.poses, K,

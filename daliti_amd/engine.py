@@ -323,11 +323,12 @@ class Engine:
         self.n = m.value
         return m.value
 
-    def scan_prefetch_raw(self, records):
+    def scan_prefetch_raw(self, records, time_off_a=-1, time_off_b=-1):
         """Start the host-to-device copy of the NEXT sweep's records (a C-contiguous float32 array the caller keeps alive and
-        hands to scan_set_from_raw unchanged)."""
+        hands to scan_set_from_raw unchanged); with the time field offsets also their time order."""
         assert records.dtype == np.float32 and records.flags["C_CONTIGUOUS"]
-        self._ck(self.lib.s2m_scan_prefetch_raw(self.h, _p(records), C.c_int64(records.shape[1]), C.c_int64(records.shape[0])))
+        self._ck(self.lib.s2m_scan_prefetch_raw(self.h, _p(records), C.c_int64(records.shape[1]), C.c_int64(records.shape[0]),
+                                                C.c_int32(time_off_a), C.c_int32(time_off_b)))
 
     def scan_prepare_raw(self, records, time_off_a, time_off_b, poses, state_end, leaf=0.5):
         """The next frame's scan_set_from_raw on the handle's side stream (s2m_scan_prepare_raw); the same call of

@@ -223,8 +223,12 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride_floats, int
  * message while it works, laserMapping.cpp:726-731): starts the host-to-device copy of `points` (host memory, n records
  * of stride_floats floats) on a side stream, driven by a worker thread of the handle, and returns at once.  A following
  * s2m_scan_set_from_raw with the SAME pointer, stride and n uses that copy instead of copying itself (any other call
- * ignores it).  The caller keeps the buffer alive and unchanged until then.  (Design, not reference.) */
-int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride_floats, int64_t n);
+ * ignores it).  With time_off_a >= 0 (the time fields of s2m_undistort) the time order of the records
+ * (IMU_Processing.hpp:215-216: it needs no pose) is computed behind the copy and reused by the call that consumes the
+ * records; time_off_a < 0: the copy only.  The caller keeps the buffer alive and unchanged until then.  (Design, not
+ * reference.) */
+int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride_floats, int64_t n, int32_t time_off_a,
+                          int32_t time_off_b);
 /* The whole front half of the NEXT frame while the map update of the current one runs: s2m_scan_set_from_raw's work (copy,
  * undistortion, voxel grid) on the handle's side stream and worker thread, into spare scan arrays; returns at once.  A
  * following s2m_scan_set_from_raw with the SAME arguments (pointer, layout, poses and state_end by value, leaf; host

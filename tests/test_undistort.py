@@ -252,9 +252,21 @@ def test_prefetch_then_prepare_is_the_same_scan(oracle):
     e.map_build(sc["map"])
     e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3)
     plain = e.scan_get().copy()
-    for _ in range(3):
-        e.scan_prefetch_raw(rec)
-        e.scan_prepare_raw(rec, 4, 6, poses, end, 0.3)
+    for k in range(6):
+        # with the time fields (k even) the side thread also sorts the records by time behind the copy, and the call that
+        # consumes them -- prepare (k < 4) or scan_set_from_raw itself -- skips its own sort
+        if k % 2 == 0:
+            e.scan_prefetch_raw(rec, 4, 6)
+        else:
+            e.scan_prefetch_raw(rec)
+        if k < 4:
+            e.scan_prepare_raw(rec, 4, 6, poses, end, 0.3)
         assert e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3) == len(plain)
         assert (bits(e.scan_get()) == bits(plain)).all()
+    # an order that was computed and then overtaken by another call's sort must not be used
+    other = rec.copy(); other[:, 4] = other[::-1, 4]
+    e.scan_prefetch_raw(rec, 4, 6)
+    e.scan_set_from_raw(other, 4, 6, poses, end, 0.3)
+    assert e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3) == len(plain)
+    assert (bits(e.scan_get()) == bits(plain)).all()
     e.close()

@@ -115,7 +115,7 @@ int s2m_bench_frames(s2m_engine *e, int32_t frames, const float *records, int64_
         int rc = s2m_scan_set_from_raw(e, records, stride_floats, n, time_off_a, time_off_b, poses, n_poses, state_end, leaf, 0, &n_out);
         if (rc) return rc;
         if (prefetch >= 1 && f + 1 < frames) {
-            rc = s2m_scan_prefetch_raw(e, records, stride_floats, n);
+            rc = s2m_scan_prefetch_raw(e, records, stride_floats, n, time_off_a, time_off_b);
             if (rc) return rc;
         }
         std::memcpy(x, x_prop, S2M_STATE_DOUBLES * sizeof(double));

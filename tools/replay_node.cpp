@@ -197,7 +197,7 @@ int main(int argc, char **argv)
         int64_t n_down = 0;
         CK(s2m_scan_set_from_raw(eng, pts, stride, v.n_points, oa, ob, poses.data(), (int32_t)n_imu, state, (float)fs_surf,
                                  0, &n_down));
-        if (have_next) CK(s2m_scan_prefetch_raw(eng, nxt.pts, nxt.stride, nxt.v.n_points));
+        if (have_next) CK(s2m_scan_prefetch_raw(eng, nxt.pts, nxt.stride, nxt.v.n_points, nxt.oa, nxt.ob));
         // lasermap_fov_segment (:772): pos_lid = pos_end + rot_end * T_L_I (:753)
         double pos_lid[3];
         for (int i = 0; i < 3; ++i)
