@@ -1052,6 +1052,8 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
     how = [bool(v) for v in merged[:frames]]
     med = float(np.median(per))
     worst = int(np.argmax(per))
+    if os.environ.get("S2M_BENCH_FRAMES"):
+        sys.stderr.write("[bench] frame leg: all frames " + " ".join("%.3f" % v for v in per) + "\n")
     sys.stderr.write("[bench] frame leg: first frames %s ms; sorted tail %s ms\n" % (
         " ".join("%.3f" % v for v in per[:6]), " ".join("%.3f" % v for v in np.sort(per)[-6:])))
     sys.stderr.write("[bench] frame leg: %d frames back to back, median %.3f p99 %.3f max %.3f ms (frame %d, %s)\n" % (

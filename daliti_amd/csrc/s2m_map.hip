@@ -245,8 +245,10 @@ hipError_t map_ensure_sort_tmp(MapBuffers &buf, size_t bytes)
     if (buf.sort_tmp) S2M_TRY(hipFree(buf.sort_tmp));
     buf.sort_tmp = nullptr;
     buf.sort_tmp_bytes = 0;
-    S2M_TRY(hipMalloc(&buf.sort_tmp, std::max<size_t>(bytes, 256)));
-    buf.sort_tmp_bytes = std::max<size_t>(bytes, 256);
+    const size_t want = std::max<size_t>(2 * bytes, (size_t)1 << 20);  // with room to spare (s2m_mapupd.hip, ensure_tmp)
+    S2M_TRY(hipMalloc(&buf.sort_tmp, want));
+    ++g_map_allocations;
+    buf.sort_tmp_bytes = want;
     return hipSuccess;
 }
 

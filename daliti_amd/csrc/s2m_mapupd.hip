@@ -548,8 +548,12 @@ static hipError_t ensure_tmp(UpdateBuffers &u, size_t bytes)
     if (bytes <= u.tmp_bytes && u.tmp) return hipSuccess;
     if (u.tmp) S2M_TRY(hipFree(u.tmp));
     u.tmp = nullptr;
-    S2M_TRY(hipMalloc(&u.tmp, std::max<size_t>(bytes, 256)));
-    u.tmp_bytes = std::max<size_t>(bytes, 256);
+    // with room to spare: the scratch of a sort grows with the batch, and a hipFree + hipMalloc in the middle of a frame
+    // stalls the device for ~0.1 ms (seen as isolated slow frames while the map's growth per frame crept up)
+    const size_t want = std::max<size_t>(2 * bytes, (size_t)1 << 20);
+    S2M_TRY(hipMalloc(&u.tmp, want));
+    note_allocation();
+    u.tmp_bytes = want;
     return hipSuccess;
 }
 
