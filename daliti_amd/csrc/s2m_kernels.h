@@ -102,7 +102,7 @@ hipError_t resolve_stats(MapBuffers &buf, MapStats &stats);
 hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive_s,
                         const float4 *stage, int64_t n_new, bool &merged, hipStream_t st, bool with_slack = false);
 // The same update in place when every touched brick still fits where it stands (s2m_mapedit.hip, slab_update): done = false and
-// nothing touched otherwise.  flags: three zeroed words of the update's counters.
+// nothing touched otherwise.  flags: five zeroed words of the update's counters.
 hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t n_new,
                        uint32_t *flags, bool &done, hipStream_t st);
 

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void merge_new_kernel(int n, const uint64_t *_
 // (the key array stays sorted), prefix words and brick starts are shifted.
 __global__ __launch_bounds__(256) void slack_size_kernel(int64_t bound, const uint32_t *__restrict__ bricks_dev, int64_t m,
                                                          const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bkey,
-                                                         uint32_t *__restrict__ grow, uint32_t *__restrict__ slack)
+                                                         uint32_t *__restrict__ grow, int by_growth, uint32_t *__restrict__ slack)
 {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id > bound) return;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void slack_size_kernel(int64_t bound, const ui
         // an eighth of the brick -- or four times what it has gained since the room was last laid out, if that is more: the
         // bricks that grow (a frontier, a surface the sensor keeps refining) are the ones that would force the next merge
         const uint32_t gained = grow[bkey[id]];
-        v = max(min(max(cnt >> 3, 16u), 512u), min(4u * gained, 4096u));
+        v = max(min(max(cnt >> 3, 16u), 512u), by_growth ? min(4u * gained, 4096u) : 0u);
         grow[bkey[id]] = gained >> 1;  // the history fades: half of it counts towards the next layout
     }
     slack[id] = v;
@@ -228,7 +228,12 @@ static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bou
     const int64_t m = g.m;
     if (m <= 0 || bricks_bound <= 0) return hipSuccess;
     // slack <= max(cnt / 8, 16) + 4 x growth per brick; the host knows the sum of the growth as a bound
-    const int64_t room_bound = m / 8 + 16 * bricks_bound + 64 + 4 * buf.added_since_layout;
+    int64_t room_bound = m / 8 + 16 * bricks_bound + 64 + 4 * buf.added_since_layout;
+    int by_growth = 1;
+    if (m + room_bound > buf.scratch_cap) {  // no space for the growth-sized part: the plain eighth then
+        room_bound = m / 8 + 16 * bricks_bound + 64;
+        by_growth = 0;
+    }
     const int64_t ext_bound = m + room_bound;
     if (ext_bound > buf.scratch_cap || ext_bound >= ((int64_t)1 << 31) || bricks_bound + 2 > buf.scratch_cap) return hipSuccess;  // stays dense
     S2M_TRY(map_ensure((void **)&buf.pts2, &buf.pts2_cap, ext_bound + kSentinelPoints, sizeof(float4), map_headroom_for(ext_bound)));
@@ -239,7 +244,7 @@ static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bou
     S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, slack, shift, 0u, (size_t)bricks_bound + 1, rocprim::plus<uint32_t>(), st));
     S2M_TRY(map_ensure_sort_tmp(buf, tmp));
     hipLaunchKernelGGL(slack_size_kernel, dim3((unsigned)((bricks_bound + 256) / 256)), dim3(256), 0, st, bricks_bound, bricks_dev, m,
-                       buf.bstart, buf.bkey, buf.grow, slack);
+                       buf.bstart, buf.bkey, buf.grow, by_growth, slack);
     buf.added_since_layout = (buf.added_since_layout + 1) / 2;
     size_t t = buf.sort_tmp_bytes;
     S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, slack, shift, 0u, (size_t)bricks_bound + 1, rocprim::plus<uint32_t>(), st));
@@ -381,7 +386,8 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
 // touched bricks do not move, so the cost follows the scan, not the map.  Anything else -- a brick that would overflow, a
 // new brick, a point outside the grid, a brick too large to stage -- is decided on the device BEFORE anything is written
 // and falls back to the merge update (which lays the map out densely again).
-constexpr int kSlabMax = 2048;  // points of one brick the rewrite stages in LDS (47 KB: three workgroups per CU)
+constexpr int kSlabMax = 2048;  // points of one brick the rewrite stages in LDS (47 KB: three workgroups per CU) ...
+constexpr int kSlabBig = 6144;  // ... and in the second, rarely launched form for crowded bricks (134 KB of dynamic LDS: one per CU)
 enum : uint32_t { kSlabOutside = 1u, kSlabNewBrick = 2u, kSlabOverflow = 4u };
 
 __global__ __launch_bounds__(256) void slab_key_kernel(const float4 *__restrict__ stage, int n, Grid g, uint64_t *__restrict__ keys,
@@ -565,13 +571,21 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restri
     const uint64_t b = bkey[id];
     const int n_b = n_new > 0 ? slab_lower(nk, n_new, b + 1) - slab_lower(nk, n_new, b) : 0;
     const uint32_t total = (uint32_t)alive + (uint32_t)n_b;
-    if (total > cap_end - base || total > (uint32_t)kSlabMax || end - base > (uint32_t)kSlabMax) atomicOr(flags, kSlabOverflow);
+    // what the rewrite has to stage at most: the brick's positions so far plus its new points
+    const uint32_t stage = (end - base) + (uint32_t)n_b;
+    if (total > cap_end - base || stage > (uint32_t)kSlabBig) atomicOr(flags, kSlabOverflow);
+    else if (stage > (uint32_t)kSlabMax) atomicAdd(flags + 4, 1u);  // a crowded brick: the second launch takes it
     atomicAdd(flags + 1, (end - base) - (uint32_t)alive);
     // what the brick gains by this update (whether it ends up in place or merged): the next layout sizes its room by it
-    if (total > end - base) grow[b] += total - (end - base);
+    if (total > end - base) {
+        grow[b] += total - (end - base);
+        atomicAdd(flags + 3, total - (end - base));  // the host keeps the sum as the bound of the room it will need
+    }
 }
 
-// one workgroup per touched brick (see the comment above); does nothing when the plan found a reason not to
+// one workgroup per touched brick (see the comment above); does nothing when the plan found a reason not to.  CAP = 2 048:
+// the bricks whose staging fits that; CAP = 6 144: the crowded ones only (launched when the plan counted any)
+template <int CAP>
 __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__restrict__ bricks_dev, const uint32_t *__restrict__ flags,
                                                            float4 *__restrict__ pts, uint32_t *__restrict__ pidx,
                                                            uint64_t *__restrict__ keys, uint8_t *__restrict__ alive_s,
@@ -581,10 +595,11 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
                                                            const uint64_t *__restrict__ nk, const uint32_t *__restrict__ nv, int n_new,
                                                            const float4 *__restrict__ stage, uint32_t next_id)
 {
-    __shared__ float4 l_p[kSlabMax];
-    __shared__ uint32_t l_id[kSlabMax];
-    __shared__ uint16_t l_c[kSlabMax];
-    __shared__ uint32_t l_t[kBrickCells];
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab_lds[];
+    float4 *l_p = reinterpret_cast<float4 *>(slab_lds);
+    uint32_t *l_id = reinterpret_cast<uint32_t *>(l_p + CAP);
+    uint32_t *l_t = l_id + CAP;
+    uint16_t *l_c = reinterpret_cast<uint16_t *>(l_t + kBrickCells);
     __shared__ int wsum[4];
     if (*flags != 0u) return;
     const int64_t id = blockIdx.x;
@@ -592,6 +607,10 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const uint32_t base = tab[id * kBrickStride], cnt = tab[id * kBrickStride + kBrickCells] - base;
     const uint64_t bk = bkey[id];
+    {   // which of the two launches takes this brick (the same quantity the plan classified it by)
+        const uint32_t stage_n = cnt + (n_new > 0 ? (uint32_t)(slab_lower(nk, n_new, bk + 1) - slab_lower(nk, n_new, bk)) : 0u);
+        if (CAP == kSlabMax ? stage_n > (uint32_t)kSlabMax : stage_n <= (uint32_t)kSlabMax) return;
+    }
     // a. the survivors, in order, into LDS
     int n_old = 0;
     for (uint32_t c0 = 0; c0 < cnt; c0 += 256u) {
@@ -670,7 +689,8 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
     }
 }
 
-// flags: three zeroed words of the update's counters (outcome bits, points removed, spare).  done = the map was updated in
+// flags: five zeroed words of the update's counters (outcome bits, points removed, bricks opened, points gained by bricks,
+// crowded bricks among the touched ones).  done = the map was updated in
 // place; otherwise nothing was touched and the caller goes on to merge_update.
 hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t n_new,
                        uint32_t *flags, bool &done, hipStream_t st)
@@ -708,15 +728,28 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     const int64_t bricks = stats.bricks + max_new;  // (an upper bound: a merged update's counts may be on their way, bricks may just have opened)
     hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, buf.bend, buf.tab,
                        buf.bkey, buf.bmark, alive_s, nk_sorted, n, buf.grow, flags);
-    buf.added_since_layout += n_new;
     {
-        const uint32_t *src[3] = {flags, flags + 1, flags + 2};
-        S2M_TRY(mail_post(buf.mail, src, 3, st));
+        const uint32_t *src[5] = {flags, flags + 1, flags + 2, flags + 3, flags + 4};
+        S2M_TRY(mail_post(buf.mail, src, 5, st));
     }
-    hipLaunchKernelGGL(slab_rewrite_kernel, dim3((unsigned)bricks), dim3(256), 0, st, bricks_dev, flags, buf.pts, buf.pidx, buf.keys_alt,
-                       alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, nk_sorted, nv_sorted, n, stage, (uint32_t)buf.next_id);
-    uint32_t v[3] = {0, 0, 0};
-    S2M_TRY(mail_collect(buf.mail, 3, v, st));
+    constexpr size_t kLdsSmall = (size_t)kSlabMax * 22 + kBrickCells * 4, kLdsBig = (size_t)kSlabBig * 22 + kBrickCells * 4;
+    hipLaunchKernelGGL((slab_rewrite_kernel<kSlabMax>), dim3((unsigned)bricks), dim3(256), kLdsSmall, st, bricks_dev, flags, buf.pts, buf.pidx,
+                       buf.keys_alt, alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, nk_sorted, nv_sorted, n, stage,
+                       (uint32_t)buf.next_id);
+    uint32_t v[5] = {0, 0, 0, 0, 0};
+    S2M_TRY(mail_collect(buf.mail, 5, v, st));
+    if (v[0] == 0u && v[4] != 0u) {  // crowded bricks among the touched ones: the form with the large staging area
+        static bool attr_set = false;
+        if (!attr_set) {
+            S2M_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&slab_rewrite_kernel<kSlabBig>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kLdsBig));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((slab_rewrite_kernel<kSlabBig>), dim3((unsigned)bricks), dim3(256), kLdsBig, st, bricks_dev, flags, buf.pts, buf.pidx,
+                           buf.keys_alt, alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, nk_sorted, nv_sorted, n, stage,
+                           (uint32_t)buf.next_id);
+    }
+    buf.added_since_layout += v[3];  // (counted by the plan kernel whether the update stays in place or not)
     if (v[0] != 0u) return hipSuccess;  // the rewrite kernel saw the same word and left the points alone
     stats.bricks += v[2];
     g.live += n_new - (int64_t)v[1];
