@@ -31,8 +31,9 @@ extern "C" {
 
 /* 2: s2m_map_incremental gained `ekf_inited`, s2m_get_timing_stats writes 6 doubles, s2m_set_timing(n > 2) samples
  * (all round 2, which forgot to bump it); new in round 3: s2m_iterated_update_multi, s2m_complete_neighbors,
- * s2m_map_get_order, s2m_map_update_stats.  3 (round 4): s2m_config gained `device_loop`.  A caller built against an
- * s2m_bet_stats is new, block[159] carries the count of neighbour lists short of the gate.  A caller built against an
+ * s2m_map_get_order, s2m_map_update_stats.  3 (round 4): s2m_config gained `device_loop`; new: s2m_bet_stats,
+ * s2m_scan_prefetch_raw, s2m_scan_prepare_raw, s2m_map_inplace_updates; block[159] carries the count of neighbour lists
+ * short of the gate; s2m_map_get_order may report positions that hold no point (0xffffffff).  A caller built against an
  * older version must be recompiled. */
 #define S2M_ABI_VERSION 3
 #define S2M_K 5            /* NUM_MATCH_POINTS, laserMapping.cpp:77 */
