@@ -12,18 +12,19 @@
 // {argmin of centre distance over old and new points; new beats old on ties; the last of tied new
 // points wins} -- with one exception that keeps an untouched voxel untouched: a single old point
 // that is strictly closer than every new point.  That closed form is what runs here, in parallel:
-//   probe    eight lanes per new point: count / best old point inside its voxel via the brick grid
-//   sort     radix sort of the new points by voxel key (stable: batch order inside a voxel)
+//   probe    eight lanes per new point: count / best old point inside its voxel via the brick grid; the batch's winner
+//            per voxel by one 64-bit atomic minimum of (centre distance, ~batch index) in a direct-address table over the
+//            voxel box of the grid (map_incremental), or
+//   sort     radix sort of the new points by voxel key (stable: batch order inside a voxel) when no such box is known
 //   resolve  eight lanes per voxel: winner among the new points, verdict against the best old point, and the old
-//            points of a rewritten voxel (except the keeper) marked dead -- by caller index (Grid::pidx) and by
-//            sorted position
+//            points of a rewritten voxel (except the keeper) marked removed by sorted position, their bricks flagged
 //   stage    the winning new points in batch order
-// The new map is "survivors in index order, then the staged points": merged into the sorted arrays of the current
-// grid (s2m_mapedit.hip: in place or merged) or, when a new point lies outside the grid, compacted here (update_finish) and
-// rebuilt.  Counts travel to the host through the pinned mailbox (mail_fetch), not through 4-byte copies.  Among several OLD
-// points tied for the smallest centre distance the lowest index wins (the reference takes the
-// first in its tree traversal, which has no GPU counterpart); such ties need two points at exactly
-// the same float distance inside one voxel.
+// The new map is "survivors in point-id order, then the staged points": written into the current grid by
+// s2m_mapedit.hip (the touched bricks rewritten in place, or the whole map merged) or, when a new point lies outside the
+// grid, compacted here (update_finish) and rebuilt.  Counts travel to the host through the pinned mailbox (mail_post /
+// mail_collect), not through 4-byte copies.  Among several OLD points tied for the smallest centre distance the lowest
+// id wins (the reference takes the first in its tree traversal, which has no GPU counterpart); such ties need two points
+// at exactly the same float distance inside one voxel.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
