@@ -8,10 +8,11 @@
 //           per-iteration path: the plane fit gathers its five points from this array (the five neighbours of a
 //           query sit in the same or adjacent cells, i.e. in a few cache lines), so nothing in caller order is
 //           touched between two map updates.
-//   pidx  : M x uint32, the caller's index of every sorted position (the index into the array handed to
-//           s2m_map_build, renumbered by updates: survivors in index order, then the added points).  Read only
-//           when somebody asks for caller indices or caller order (s2m_get_neighbors, s2m_map_get_points) and by
-//           the map update; 4 B/point instead of the 16 B/point copy in caller order that round 2 kept.
+//   pidx  : M x uint32, the point id of every sorted position: the index into the array handed to s2m_map_build,
+//           next_id, next_id + 1, ... for points added later -- ascending in caller order (survivors, then the added
+//           points), never renumbered; ~0 = a position that holds no point.  Read only when somebody asks for caller
+//           indices or caller order (s2m_get_neighbors, s2m_map_get_points: the ids are ranked then) and by the map
+//           update; 4 B/point instead of the 16 B/point copy in caller order that round 2 kept.
 //   top   : dense nbx*nby*nbz array of 16-byte entries over the map bounding box:
 //           {brick id + 1 (0 = empty), position of the brick's first point + 1, 64-bit mask of the (y,z)
 //           rows of the brick that hold points}.  A brick is 8x8x8 cells; at c = 0.5 m this array is 7 K entries (0.1 MB) for

@@ -16,21 +16,18 @@
 namespace s2m {
 
 // ---- merge update: the map after an incremental update WITHOUT a new sort ----------------------------------
-// Input: the current map (sorted points, their caller indices pidx, their sorted keys keys_alt), the update's
-// verdicts (alive[caller index] of every old point) and its staged new points (caller order of the new map:
-// survivors in index order, then the staged points -- the same list update_finish would hand to a full build).
-// The new points are sorted by their key in the CURRENT grid (tens of thousands, not millions), every one finds
-// its place among the old keys by binary search -- BEHIND the old points of its own cell (upper bound): the new
-// points carry the highest caller indices, so the merged array is ordered by (brick, cell, caller index) exactly
-// like a fresh build of the same list, and the search's tie order (sorted position) does not depend on which of
-// the two ways the map was produced -- and announces itself there (v[ub] += 1); one scan over
-// v[j] = alive(j) + announcements(j) then gives every surviving old point and every new point its position in
-// the merged order.  Old points move with one coalesced read and one scattered-but-monotone write; caller
-// indices are renumbered on the way (exclusive scan of alive).  ~0.3 GB of traffic at 5 M points instead of a
-// 5 M-key radix sort, a bounding-box pass and a gather.
-// rank of the dead among the caller indices: a bit mask of the dead per 64 indices and the number of dead before
-// every word (312 KB + 625 KB at 5 M points: L2-resident, so renumbering a caller index costs two cache hits
-// instead of a gather from a 20 MB array)
+// Input: the current map (sorted points, their ids pidx, their sorted keys keys_alt; holes allowed), the update's
+// verdicts (alive_s[sorted position]: 0 = removed by this update, or a hole) and its staged new points (caller order of
+// the new map: survivors in id order, then the staged points -- the same list update_finish would hand to a full build).
+// The new points are sorted by their key in the CURRENT grid (thousands, not millions), every one finds its place among
+// the old keys by binary search -- BEHIND the old points of its own cell (upper bound): the new points carry the highest
+// ids, so the merged array is ordered by (brick, cell, id) exactly like a fresh build of the same list, and the search's
+// tie order (sorted position) does not depend on which way the map was produced.  A surviving old point j moves to
+// j - removed-before(j) + new-in-front-of(j): the first term from a rank over the removed positions (a bit mask per 64
+// positions + the number removed before every word: L2-resident), the second from one scalar binary search per wave in
+// the new points' sorted places plus the few entries inside the wave's 64 positions -- no map-sized scan.  Old points
+// move with one coalesced read and one scattered-but-monotone write and keep their ids.  ~0.3 GB of traffic at 5 M
+// points instead of a 5 M-key radix sort, a bounding-box pass and a gather.
 __global__ __launch_bounds__(256) void dead_words_kernel(int64_t m, const uint8_t *__restrict__ alive_s,
                                                          unsigned long long *__restrict__ word_s, uint32_t *__restrict__ cnt,
                                                          uint32_t *__restrict__ outside_flag)
