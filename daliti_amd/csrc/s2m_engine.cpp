@@ -79,6 +79,7 @@ struct s2m_engine {
         std::mutex mu;
         std::condition_variable cv;
         bool quit = false, busy = false, ready = false;
+        bool gpu_pending = false;        // the last job's work on `stream` has not been ordered in front of the main stream yet
         std::atomic<int> busy_a{0};      // mirror of `busy` for the short spins in front of the condition-variable waits: a futex
                                          // sleep / wake is tens of microseconds at best and has been seen to cost 10 ms once
         const float *src = nullptr;      // host records the job copies / the copy in d_buf belongs to
@@ -578,14 +579,16 @@ int commit_update(s2m_engine *e)
     // the ~11 points per occupied cell it was chosen for -- e.g. a map seeded from a handful of points and then
     // grown, or a dense seed thinned by the voxel rule: then it is chosen again from the density.  A merged update
     // does not wait for its own counts, so the drift it causes is seen when the next update begins.
-    auto drifted = [&](int64_t m) {
-        if (e->cfg.cell_size > 0.0f || e->stats.occupied_cells <= 0) return false;
-        const double mean = (double)m / (double)e->stats.occupied_cells;
+    // Judged from the counts of the last build or merge and THAT layout's point count (in-place updates change the number
+    // of points and of occupied cells alike, and only a layout counts the cells).
+    auto drifted = [&]() {
+        if (e->cfg.cell_size > 0.0f || e->stats.occupied_cells <= 0 || e->stats.layout_points <= 0) return false;
+        const double mean = (double)e->stats.layout_points / (double)e->stats.occupied_cells;
         return mean < 5.5 || mean > 22.0;
     };
-    const bool drift_before = drifted(e->grid.live);
+    const bool drift_before = drifted();
     if (!e->no_merge && !e->no_slab && !drift_before) {  // in place when every touched brick fits where it stands
-        he = slab_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, e->upd.counters + 9, merged, e->stream);
+        he = slab_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, e->upd.counters + kUpdSlabWord, merged, e->stream);
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "slab_update", he);
         if (merged) ++e->n_inplace;
     }
@@ -602,14 +605,18 @@ int commit_update(s2m_engine *e)
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "update_finish", he);
         if (m_new >= ((int64_t)1 << 31)) return fail(e, S2M_ERR_CAPACITY, "map too large (>= 2^31 points)");
         const float cell = e->cfg.cell_size > 0.0f ? e->cfg.cell_size : e->built_cell;
-        // with a margin of free bricks around the box, so that the next updates can be merged
+        // the cells stay where they are (same origin) unless the map was empty or has wandered beyond the representable range
+        const float origin[3] = {e->grid.ox, e->grid.oy, e->grid.oz};
+        const bool keep = e->grid.m > 0 && cell == e->grid.c;
         he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, cell, e->map, e->grid, e->stats, too_large,
-                       e->stream, true);
+                       e->stream, keep ? origin : nullptr);
+        if (he == hipSuccess && too_large && keep)   // beyond the range of the old origin: a new one
+            he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, cell, e->map, e->grid, e->stats, too_large, e->stream);
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
         if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
-        if (drifted(m_new)) {
+        if (drifted()) {
             he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, 0.0f, e->map, e->grid, e->stats, too_large,
-                           e->stream, true);
+                           e->stream);
             if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
             if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
             e->built_cell = e->grid.c;
@@ -781,6 +788,7 @@ int s2m_map_info(const s2m_engine *ce, double info[8])
 
 namespace {
 void pf_drain(s2m_engine *e);  // the side thread (s2m_scan_prefetch_raw / s2m_scan_prepare_raw) is idle
+void pf_invalidate(s2m_engine *e);
 
 int scan_reserve(s2m_engine *e, int64_t n)
 {
@@ -825,6 +833,7 @@ int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int
     if (!e || n < 0 || stride < 3 || (n > 0 && !xyz)) return fail(e, S2M_ERR_ARG, "s2m_scan_set: bad argument");
     if (n > (int64_t)1 << 28) return fail(e, S2M_ERR_CAPACITY, "scan too large");
     S2M_HIP(e, hipSetDevice(e->device));
+    pf_invalidate(e);  // whatever the side thread holds was meant for a sweep that is not coming by this road
     int rc = scan_reserve(e, n);
     if (rc) return rc;
     const float *dev = nullptr;
@@ -840,7 +849,7 @@ int s2m_scan_set_downsampled(s2m_engine *e, const float *xyz, int64_t stride, in
     if (!e || n < 0 || stride < 3 || (n > 0 && !xyz) || !(leaf > 0.0f)) return fail(e, S2M_ERR_ARG, "s2m_scan_set_downsampled: bad argument");
     if (n > (int64_t)1 << 28) return fail(e, S2M_ERR_CAPACITY, "scan too large");
     S2M_HIP(e, hipSetDevice(e->device));
-    pf_drain(e);  // the voxel-grid buffers are shared with the side thread
+    pf_invalidate(e);  // the voxel-grid buffers are shared with the side thread; what it holds is stale
     int rc = scan_reserve(e, n);  // the output cannot be larger than the input
     if (rc) return rc;
     const float *dev = nullptr;
@@ -971,17 +980,33 @@ void prefetch_worker(s2m_engine *e)
         p.busy_a.store(0, std::memory_order_release);
         p.ready = he == hipSuccess && !prepare;
         p.prepared = ok && he == hipSuccess && prepare;
+        p.gpu_pending = he == hipSuccess;
         p.cv.notify_all();
     }
 }
 
-// the side thread is idle (its buffers may be used / reallocated by the caller)
+// the side thread is idle AND whatever its last job enqueued on the side stream is ordered in front of everything the
+// caller enqueues on the main stream from here on: the undistortion / voxel-grid scratch (e->und, e->vox) is shared by the
+// two streams, so a caller that goes on to sort in it must not overtake a job's kernels that are still running
 void pf_drain(s2m_engine *e)
 {
     if (!e->pf.worker.joinable()) return;
     for (int spin = 0; spin < 40000 && e->pf.busy_a.load(std::memory_order_acquire) != 0; ++spin) __builtin_ia32_pause();
     std::unique_lock<std::mutex> lk(e->pf.mu);
     e->pf.cv.wait(lk, [&] { return !e->pf.busy; });
+    if (e->pf.gpu_pending && e->pf.done) {
+        (void)hipStreamWaitEvent(e->stream, e->pf.done, 0);
+        e->pf.gpu_pending = false;
+    }
+}
+// a scan arrives by another road than the one the side thread prepared for: what it holds is stale (a node that recycles
+// its host buffers may present NEW records at the address and size of a sweep that was prefetched and then dropped)
+void pf_invalidate(s2m_engine *e)
+{
+    pf_drain(e);
+    e->pf.ready = false;
+    e->pf.prepared = false;
+    e->pf.ordered = false;
 }
 
 int pf_start(s2m_engine *e, const float *points, int64_t floats)
@@ -1008,8 +1033,12 @@ int pf_start(s2m_engine *e, const float *points, int64_t floats)
 
 int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride, int64_t n, int32_t oa, int32_t ob)
 {
-    if (!e || n < 0 || stride < 3 || (n > 0 && !points) || oa >= stride || ob >= stride)
-        return fail(e, S2M_ERR_ARG, "s2m_scan_prefetch_raw: bad argument");
+    if (!e) return S2M_ERR_ARG;
+    if (!points) {  // cancel: the sweep that was announced is not coming (dropped, skipped): forget its copy
+        pf_invalidate(e);
+        return S2M_OK;
+    }
+    if (n < 0 || stride < 3 || oa >= stride || ob >= stride) return fail(e, S2M_ERR_ARG, "s2m_scan_prefetch_raw: bad argument");
     if (n == 0) return S2M_OK;
     S2M_HIP(e, hipSetDevice(e->device));
     int rc = pf_start(e, points, n * stride);
@@ -1110,7 +1139,10 @@ int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, in
                 }
             }
         }
-        if (!prefetched) e->pf.ordered = false;  // (this call's own sort overwrites an order the side thread left for other records)
+        if (!prefetched) {  // other records, or records on the device: a copy the side thread still holds is stale, and
+            e->pf.ordered = false;  // this call's own sort overwrites the order it may have left
+            e->pf.ready = false;
+        }
         if (!on_device && !prefetched) {
             const int64_t floats = n * stride;
             if (floats > e->stage_cap) {
@@ -1295,11 +1327,11 @@ int s2m_map_get_order(s2m_engine *e, uint32_t *order, int64_t capacity, int64_t 
     return S2M_OK;
 }
 
-int s2m_map_grid(const s2m_engine *e, int32_t cells[3])
+int s2m_map_grid(const s2m_engine *e, int32_t bricks[6])
 {
-    if (!e || !cells) return S2M_ERR_ARG;
+    if (!e || !bricks) return S2M_ERR_ARG;
     if (!e->map_ready) return S2M_ERR_STATE;
-    cells[0] = e->grid.ncx; cells[1] = e->grid.ncy; cells[2] = e->grid.ncz;
+    for (int k = 0; k < 3; ++k) { bricks[k] = e->grid.blo[k]; bricks[3 + k] = e->grid.bhi[k]; }
     return S2M_OK;
 }
 
@@ -1310,13 +1342,15 @@ int s2m_map_inplace_updates(const s2m_engine *e, int64_t *n)
     return S2M_OK;
 }
 
-int s2m_map_update_stats(const s2m_engine *e, int64_t stats[4])
+int s2m_map_update_stats(const s2m_engine *e, int64_t stats[6])
 {
     if (!e || !stats) return S2M_ERR_ARG;
     stats[0] = e->n_merged;
     stats[1] = e->n_rebuilt;
     stats[2] = e->n_regrid;
     stats[3] = map_allocations();
+    stats[4] = e->map.n_relaid;
+    stats[5] = e->map.n_big_slab;
     return S2M_OK;
 }
 
@@ -1344,8 +1378,12 @@ int s2m_complete_neighbors(s2m_engine *e, int64_t *n_completed)
     m.hard_rec = e->d_hrec; m.hard_off1 = n; m.hard_count = e->d_hard + 3 * e->n_cap;
     m.qheads = e->d_qheads;
     const double c = e->grid.c;
-    const double half_diag = 0.5 * c * std::sqrt((double)e->grid.ncx * e->grid.ncx + (double)e->grid.ncy * e->grid.ncy +
-                                                 (double)e->grid.ncz * e->grid.ncz);
+    double diag2 = 0.0;
+    for (int k = 0; k < 3; ++k) {  // (the box of the bricks in use, in cells)
+        const double cells = 8.0 * ((double)e->grid.bhi[k] - (double)e->grid.blo[k] + 1.0);
+        diag2 += cells * cells;
+    }
+    const double half_diag = 0.5 * c * std::sqrt(diag2);
     int64_t first = -1;
     for (int round = 0; round < 64; ++round) {
         // hard_count / qheads are zero here: every reduce launch and every round below leaves them so

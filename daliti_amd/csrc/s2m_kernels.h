@@ -16,7 +16,7 @@ struct Mailbox {
     uint32_t *dev = nullptr;  // the same memory as the device sees it
     uint32_t seq = 0;         // word 0 of the buffer carries the sequence number of the last fetch
 };
-constexpr int kMailSlots = 8;
+constexpr int kMailSlots = 16;
 void free_mailbox(Mailbox &mb);
 // out[i] = *src[i] for i < k (k <= kMailSlots); returns when the kernel -- and with it everything queued on the
 // stream before it -- has finished (the host polls the pinned sequence word instead of synchronising the stream)
@@ -44,23 +44,22 @@ struct MapBuffers {
     bool ids_dense = true;                      // the ids ARE the caller indices (no point was removed since the last build)
     float4 *pts2 = nullptr;
     uint32_t *pidx2 = nullptr;                  // the other halves of the double buffers a merge update writes into
-    uint4 *top = nullptr;
+    uint4 *top = nullptr, *top2 = nullptr;      // the toroidal top array and the spare a re-lay writes into
     uint32_t *tab = nullptr;
-    int64_t pts_cap = 0, pidx_cap = 0, pts2_cap = 0, pidx2_cap = 0, top_cap = 0, tab_cap = 0;
+    int64_t pts_cap = 0, pidx_cap = 0, pts2_cap = 0, pidx2_cap = 0, top_cap = 0, top2_cap = 0, tab_cap = 0;
     // per-point arrays of scratch_cap + 1 elements.  keys_alt holds the SORTED keys of the current map (it stays
     // valid between updates: the merge update reads it); keys is the unsorted input of a build or the output of a
     // merge; vals / vals_alt are the build sort's payload
     uint64_t *keys = nullptr, *keys_alt = nullptr;
     uint32_t *vals = nullptr, *vals_alt = nullptr;
     uint32_t *work_a = nullptr, *work_b = nullptr, *work_c = nullptr;
-    uint32_t *rank = nullptr;    // per top entry (+1): number of occupied bricks before it
     uint32_t *bstart = nullptr;  // per occupied brick: first position in pts
-    int64_t rank_cap = 0, bstart_cap = 0;
-    uint32_t *bkey = nullptr;    // per occupied brick: its index in the top array (the high part of its points' keys)
+    int64_t bstart_cap = 0;
+    uint64_t *bkey = nullptr;    // per occupied brick: its key (brick_key, s2m_device.h: the high part of its points' keys)
     uint8_t *bmark = nullptr;    // per occupied brick: bit 0 = a point of it was removed, bit 1 = a new point goes into it, bit 2 = opened (this update)
     uint32_t *bend = nullptr;    // per occupied brick: end of the stretch of positions it owns (its points, then room)
     int64_t bkey_cap = 0, bmark_cap = 0, bend_cap = 0;
-    uint32_t *grow = nullptr;    // per top entry: points the brick has gained (net) by in-place updates since the room was laid out
+    uint32_t *grow = nullptr;    // per top slot: points the brick has gained (net) by in-place updates since the room was laid out
     int64_t grow_cap = 0;
     int64_t added_since_layout = 0;  // host bound of the sum of `grow`
     uint64_t layout_gen = 0;     // counts builds and merges: a new dense layout of pts (in-place updates keep the layout)
@@ -78,18 +77,24 @@ struct MapBuffers {
     size_t sort_tmp_bytes = 0;
     int64_t scratch_cap = 0;
     float *bbox = nullptr;       // kBboxScratchFloats floats on device (cloud_bbox scratch)
-    uint32_t *counters = nullptr; // small device counters
+    uint32_t *counters = nullptr; // small device counters (64 words, then the occupied-cell shards)
+    int64_t n_relaid = 0;         // times the top array was re-laid for a box that had outgrown or left its window
+    int big_slab = 0;             // the crowded-brick form of the in-place rewrite: 0 = not asked yet, 1 = granted, -1 = refused by the device
+    int64_t n_big_slab = 0;       // bricks that went through it (diagnostic)
 };
+constexpr int kBricksWord = 32;   // MapBuffers::counters[kBricksWord]: the number of bricks (ids in use), kept on the device
+constexpr int kBoxWords = 34;     // ... [kBoxWords .. +6): a box of bricks on its way to the host (lo xyz, hi xyz)
 
 struct MapStats {
     int64_t bricks = 0, top_entries = 0, occupied_cells = 0;
+    int64_t layout_points = 0;  // points of the layout the cell count belongs to (the last build or merge)
 };
 
 // xyz_dev: device pointer, stride in floats.  cell <= 0 selects the cell size from the density.
 // Returns hipSuccess or the failing HIP error; *too_large set when the grid would not fit.
-// with_margin: leave free bricks around the bounding box (maps that will be updated incrementally).
+// keep_origin: the origin of the map this one replaces (a rebuild inside an update keeps the cells where they are).
 hipError_t build_map(const float *xyz_dev, int64_t stride, int64_t m, float cell, MapBuffers &buf, Grid &grid,
-                     MapStats &stats, bool &too_large, hipStream_t st, bool with_margin = false);
+                     MapStats &stats, bool &too_large, hipStream_t st, const float *keep_origin = nullptr);
 void free_map(MapBuffers &buf);
 int64_t map_allocations();  // device (re)allocations by the map build / merge / update code so far (all handles; diagnostic)
 void note_allocation();
@@ -97,8 +102,8 @@ void note_allocation();
 hipError_t resolve_stats(MapBuffers &buf, MapStats &stats);
 // The map after an update without a new sort (s2m_mapedit.hip, "merge update"): alive_s[sorted position] for the m old points
 // (m + 1 readable bytes), n_new staged points in their order.  merged = false (and nothing changed) when the update cannot be
-// merged -- a new point outside the grid, no room in the scratch arrays, empty map -- and the caller falls back to
-// update_finish + build_map.
+// merged -- a new point beyond the representable cell range, no room in the scratch arrays, empty map -- and the caller falls
+// back to update_finish + build_map.
 hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t *alive_s,
                         const float4 *stage, int64_t n_new, bool &merged, hipStream_t st, bool with_slack = false);
 // The same update in place when every touched brick still fits where it stands (s2m_mapedit.hip, slab_update): done = false and
@@ -113,7 +118,9 @@ struct UpdateBuffers {
     int64_t alive_s_cap = 0;
     uint64_t alive_gen = ~0ull, layout_gen = 0;  // alive_s was made for layout alive_gen; the map's layout now (set by the engine)
     uint8_t *bmark = nullptr;      // the map's per-brick marks (MapBuffers::bmark, set by the engine): bit 0 = a point of the brick was removed
-    uint32_t *counters = nullptr;  // [1] voxels rewritten (tmp_counter), [2] points deleted by boxes
+    uint32_t *counters = nullptr;  // kUpdWords words, zeroed by every update_begin: [1] voxels rewritten (tmp_counter), [2] points deleted
+                                   // by boxes, [14] live points (order_by_id), [kUpdSlabWord .. +11) the in-place update's words
+                                   // (s2m_mapedit.hip), [kUpdVoxWord .. +6) the box of the voxels of map_incremental's PointToAdd
     float4 *stage = nullptr;       // points to append, in order
     int64_t stage_cap = 0, stage_n = 0;
     uint32_t deleted_reported = 0;  // box deletes already reported to the caller within this update
@@ -137,8 +144,11 @@ struct UpdateBuffers {
     int64_t vtab_cap = 0;                // slots
     Mailbox mail;
 };
-// box of voxels (edge = the down-sampling size) that holds every point of a batch: lets the sort that groups the batch by voxel
-// use a linear index of `bits` bits instead of the 63-bit packed key; bits == 0: not available (use the packed key)
+constexpr int kUpdWords = 64, kUpdSlabWord = 16, kUpdVoxWord = 32;
+// box of voxels (edge = the down-sampling size) that holds every point of a batch: the batch's winner per voxel comes from a
+// direct-address table over it (or the sort that groups the batch by voxel uses a linear index of `bits` bits instead of the
+// 63-bit packed key); bits == 0: not available (use the packed key).  map_incremental measures it from the scan's own
+// PointToAdd list (incr_classify), so it follows the sensor and not the map.
 constexpr int kVoxTableBits = 25;  // a voxel box of up to 2^25 voxels gets a winner table (256 MB at most; 45 MB at C3)
 struct VoxBox {
     int lo[3] = {0, 0, 0}, d[3] = {0, 0, 0};

@@ -17,6 +17,7 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include <rocprim/iterator/zip_iterator.hpp>
@@ -99,23 +100,31 @@ hipError_t cloud_bbox(const float *xyz, int64_t stride, int64_t n, float *scratc
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void key_kernel(const float *__restrict__ xyz, int64_t stride, int64_t m, Grid g,
+// Sort key of the BUILD: the box-independent key (point_key, s2m_device.h) orders bricks lexicographically by their signed
+// (z, y, x); inside the build's bounding box the linear index ((bz - lo) * ny + (by - lo)) * nx + (bx - lo) orders them the
+// same way with far fewer bits for the radix sort (22 instead of 63 at 5 M points: three passes instead of eight).  The
+// gather kernel expands the sorted keys to the box-independent form, which is what the map keeps.
+struct BuildBox {
+    int lo[3], n[3];
+};
+__global__ __launch_bounds__(256) void key_kernel(const float *__restrict__ xyz, int64_t stride, int64_t m, Grid g, BuildBox bb,
                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    const int cx = cell_of(xyz[i * stride + 0], g.ox, g.inv_c, g.ncx);
-    const int cy = cell_of(xyz[i * stride + 1], g.oy, g.inv_c, g.ncy);
-    const int cz = cell_of(xyz[i * stride + 2], g.oz, g.inv_c, g.ncz);
-    const uint64_t brick = ((uint64_t)(cz >> 3) * g.nby + (cy >> 3)) * g.nbx + (cx >> 3);
+    const int cx = cell_coord(xyz[i * stride + 0], g.ox, g.inv_c);
+    const int cy = cell_coord(xyz[i * stride + 1], g.oy, g.inv_c);
+    const int cz = cell_coord(xyz[i * stride + 2], g.oz, g.inv_c);
+    const uint64_t brick = ((uint64_t)((cz >> 3) - bb.lo[2]) * (uint64_t)bb.n[1] + (uint64_t)((cy >> 3) - bb.lo[1])) * (uint64_t)bb.n[0] +
+                           (uint64_t)((cx >> 3) - bb.lo[0]);
     const uint32_t local = (uint32_t)((((cz & 7) << 3) | (cy & 7)) << 3 | (cx & 7));
     keys[i] = (brick << 9) | local;
     vals[i] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ xyz, int64_t stride, int64_t m,
-                                                     const uint32_t *__restrict__ vals, float4 *__restrict__ pts,
-                                                     uint32_t *__restrict__ pidx)
+                                                     const uint32_t *__restrict__ vals, BuildBox bb, float4 *__restrict__ pts,
+                                                     uint32_t *__restrict__ pidx, uint64_t *__restrict__ keys)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
@@ -123,55 +132,88 @@ __global__ __launch_bounds__(256) void gather_kernel(const float *__restrict__ x
     pts[j] = make_map_point(xyz[(int64_t)src * stride], xyz[(int64_t)src * stride + 1], xyz[(int64_t)src * stride + 2],
                             (uint32_t)j);
     pidx[j] = src;
+    const uint64_t k = keys[j], lin = k >> 9;
+    const int bx = (int)(lin % (uint64_t)bb.n[0]) + bb.lo[0], by = (int)((lin / (uint64_t)bb.n[0]) % (uint64_t)bb.n[1]) + bb.lo[1],
+              bz = (int)(lin / ((uint64_t)bb.n[0] * (uint64_t)bb.n[1])) + bb.lo[2];
+    keys[j] = (brick_key(bx, by, bz) << 9) | (k & 511ull);
 }
 
 // ---- top entries and per-brick prefix tables from the SORTED keys -------------------------------------------
-// Used by the full build and by the merge update alike.  (1) every first point of a brick leaves its position in
-// the second word of the brick's top entry; (2) an exclusive scan over the dense top array numbers the occupied
-// bricks in key order; (3) ids and brick starts are written; (4) one wave per occupied brick reads the brick's
-// keys once, coalesced, drops the first position of every cell into a 512-entry LDS table, turns it into the
-// exclusive prefix of the cell counts (an empty cell takes the start of the next non-empty one), and derives the
-// row mask and the occupied-cell count from it.  No per-point brick id, no global atomics per cell.
-__global__ __launch_bounds__(256) void brick_head_kernel(int64_t m, const uint64_t *__restrict__ keys, uint4 *__restrict__ top)
-{
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t k = keys[j];
-        if (j == 0 || (keys[j - 1] >> 9) != (k >> 9)) reinterpret_cast<uint32_t *>(&top[k >> 9])[1] = (uint32_t)(j + 1);
-    }
-}
+// Used by the full build and by the merge update alike.  (1) a run-length encoding of the keys' brick parts gives the
+// occupied bricks in key order -- their keys, their point counts, their number; (2) an exclusive scan of the counts gives
+// every brick's first position; (3) every brick takes its slot of the (zeroed) top array; (4) one wave per occupied brick
+// reads the brick's keys once, coalesced, drops the first position of every cell into a 512-entry LDS table, turns it into
+// the exclusive prefix of the cell counts (an empty cell takes the start of the next non-empty one), and derives the row
+// mask and the occupied-cell count from it.  No per-point brick id, no global atomics per cell.
+struct BrickOfKey {
+    __host__ __device__ uint64_t operator()(const uint64_t &k) const { return k >> 9; }
+};
 
 constexpr int kOccShards = 64;  // occupied-cell counters, 128 B apart (same-address atomics cost ~11 ns each)
 
-struct TopOccupied {
-    __host__ __device__ uint32_t operator()(const uint4 &t) const { return t.y != 0u ? 1u : 0u; }
-};
-
-__global__ __launch_bounds__(256) void brick_assign_kernel(int64_t top_entries, uint4 *__restrict__ top,
-                                                           const uint32_t *__restrict__ rank,
-                                                           uint32_t *__restrict__ bstart, uint32_t *__restrict__ bkey,
-                                                           uint32_t *__restrict__ occ)
+__global__ __launch_bounds__(256) void brick_assign_kernel(const uint32_t *__restrict__ bricks_dev, Grid g, uint4 *__restrict__ top,
+                                                           const uint64_t *__restrict__ bkey, uint32_t *__restrict__ occ)
 {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < kOccShards) occ[b * 32] = 0u;  // the occupied-cell counters brick_table_kernel adds to
-    if (b >= top_entries) return;
-    const uint32_t y = top[b].y;
-    if (y == 0u) return;
-    const uint32_t id = rank[b];
-    reinterpret_cast<uint32_t *>(&top[b])[0] = id + 1u;
-    bstart[id] = y - 1u;
-    bkey[id] = (uint32_t)b;  // the brick's place in the top array = the high part of its points' keys
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id < kOccShards) occ[id * 32] = 0u;  // the occupied-cell counters brick_table_kernel adds to
+    if (id >= (int64_t)*bricks_dev) return;
+    top[top_slot_of_key(g, bkey[id])] = make_uint4((uint32_t)id + 1u, 0u, 0u, 0u);
 }
 
+// box of the bricks in `bkey` (one workgroup: a few thousand to a few hundred thousand entries) and, when given, of the
+// brick parts of the n keys in `nk`; out6 = {lo xyz, hi xyz} as int32 (lo > hi: nothing)
+__global__ __launch_bounds__(1024) void brick_box_kernel(const uint32_t *__restrict__ bricks_dev, const uint64_t *__restrict__ bkey,
+                                                         const uint32_t *__restrict__ tab, const uint64_t *__restrict__ nk, int n,
+                                                         int32_t *__restrict__ out6)
+{
+    int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    auto take = [&](uint64_t bk) {
+        int b[3];
+        brick_coords(bk, b[0], b[1], b[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], b[k]); hi[k] = max(hi[k], b[k]); }
+    };
+    const int64_t bricks = bricks_dev ? (int64_t)*bricks_dev : 0;
+    for (int64_t id = threadIdx.x; id < bricks; id += blockDim.x)
+        if (!tab || tab[id * kBrickStride + kBrickCells] > tab[id * kBrickStride]) take(bkey[id]);  // (bricks that hold points)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) take(nk[i] >> 9);
+    __shared__ int slo[16][3], shi[16][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = min(lo[k], __shfl_xor(lo[k], off, 64));
+            hi[k] = max(hi[k], __shfl_xor(hi[k], off, 64));
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { slo[wave][k] = lo[k]; shi[wave][k] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int l = INT32_MAX, h = INT32_MIN;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { l = min(l, slo[w][threadIdx.x]); h = max(h, shi[w][threadIdx.x]); }
+        out6[threadIdx.x] = l;
+        out6[3 + threadIdx.x] = h;
+    }
+}
 
-// bricks_dev: the number of occupied bricks when the host only knows an upper bound for it (merge update)
-__global__ __launch_bounds__(256) void brick_table_kernel(int64_t bricks, const uint32_t *__restrict__ bricks_dev, int64_t m,
+void launch_brick_box(const uint32_t *bricks_dev, const uint64_t *bkey, const uint32_t *tab, const uint64_t *nk, int n, int32_t *out6,
+                      hipStream_t st)
+{
+    hipLaunchKernelGGL(brick_box_kernel, dim3(1), dim3(1024), 0, st, bricks_dev, bkey, tab, nk, n, out6);
+}
+
+// bricks_dev: the number of occupied bricks (the host may only know an upper bound for it)
+__global__ __launch_bounds__(256) void brick_table_kernel(const uint32_t *__restrict__ bricks_dev, int64_t m, Grid g,
                                                           const uint64_t *__restrict__ keys,
                                                           const uint32_t *__restrict__ bstart, uint4 *__restrict__ top,
                                                           uint32_t *__restrict__ tab, uint32_t *__restrict__ occ,
                                                           uint8_t *__restrict__ bmark, uint32_t *__restrict__ bend)
 {
     __shared__ uint32_t lds[4][kBrickCells];
-    if (bricks_dev) bricks = (int64_t)*bricks_dev;
+    const int64_t bricks = (int64_t)*bricks_dev;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t id = (int64_t)blockIdx.x * 4 + wave;
     int cells = 0;
@@ -190,7 +232,7 @@ __global__ __launch_bounds__(256) void brick_table_kernel(int64_t bricks, const 
         unsigned long long mask;
         cells = table_from_firsts(t, e, tab + id * kBrickStride, lane, mask);
         if (lane == 0) {
-            uint32_t *te = reinterpret_cast<uint32_t *>(&top[keys[s] >> 9]);
+            uint32_t *te = reinterpret_cast<uint32_t *>(&top[top_slot_of_key(g, keys[s] >> 9)]);
             te[2] = (uint32_t)mask;
             te[3] = (uint32_t)(mask >> 32);
             bmark[id] = 0;  // no in-place update pending on a fresh layout (slab_update)
@@ -231,7 +273,7 @@ int64_t map_headroom_for(int64_t m) { return m / 4 + 65536; }
 void free_map(MapBuffers &b)
 {
     void *ptrs[] = {b.pts, b.pidx, b.pts2, b.pidx2, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.work_a, b.work_b,
-                    b.work_c, b.rank, b.bstart, b.bkey, b.bmark, b.bend, b.grow, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
+                    b.work_c, b.top2, b.bstart, b.bkey, b.bmark, b.bend, b.grow, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b.h_stats) { (void)hipHostFree(b.h_stats); (void)hipEventDestroy(b.stats_event); }
@@ -304,121 +346,210 @@ hipError_t resolve_stats(MapBuffers &buf, MapStats &stats)
     return hipSuccess;
 }
 
-// top entries + brick tables of the m points whose sorted keys are `keys` (buf.top zeroed by the caller).
-// brick_bound >= 0: an upper bound of the number of occupied bricks known to the host -- nothing is read back
-// before the tables are built, and the counts arrive later (resolve_stats).
-hipError_t map_build_tables(MapBuffers &buf, const uint64_t *keys, int64_t m, int64_t top_entries, MapStats &stats,
-                            hipStream_t st, int64_t brick_bound)
+// ---- the window of the top array ---------------------------------------------------------------------------
+static int log2_ceil(int64_t v)
 {
-    const int blocks = (int)std::min<int64_t>((m + 255) / 256, 4096);
-    hipLaunchKernelGGL(brick_head_kernel, dim3(blocks), dim3(256), 0, st, m, keys, buf.top);
-    S2M_TRY(map_ensure((void **)&buf.rank, &buf.rank_cap, top_entries + 1, sizeof(uint32_t)));
-    auto occupied = rocprim::make_transform_iterator(static_cast<const uint4 *>(buf.top), TopOccupied());
+    int l = 0;
+    while (((int64_t)1 << l) < v) ++l;
+    return l;
+}
+// The box of bricks [lo, hi] becomes the grid's bounds.  The toroidal top array keeps its sizes when the box fits them
+// (nothing moves: a slot depends on the brick's coordinates and the sizes only); otherwise every axis gets the next power of
+// two above its extent plus half of it (at least 8 bricks more), so that the box can wander that far before the next
+// re-lay.  *resized says which.  An empty box (hi < lo) gets a one-entry array.  Sets the fields of g only.
+hipError_t map_window_for(Grid &g, const int lo[3], const int hi[3], bool &too_large, bool *resized)
+{
+    too_large = false;
+    if (resized) *resized = false;
+    int64_t ext[3];
+    for (int k = 0; k < 3; ++k) {
+        ext[k] = std::max<int64_t>((int64_t)hi[k] - lo[k] + 1, 0);
+        if (ext[k] > ((int64_t)1 << kBrickBits)) { too_large = true; return hipSuccess; }
+    }
+    const bool fits = g.top != nullptr && ext[0] <= (int64_t)g.tmx + 1 && ext[1] <= (int64_t)g.tmy + 1 && ext[2] <= (int64_t)g.tmz + 1;
+    if (!fits) {
+        int lg[3];
+        for (int k = 0; k < 3; ++k) lg[k] = ext[k] > 0 ? log2_ceil(ext[k] + std::max<int64_t>(ext[k] / 2, 8)) : 0;
+        // a box that is thin along some axes and long along others must not pay for slack it cannot afford
+        while (lg[0] + lg[1] + lg[2] > 28) {
+            int k = 0;
+            for (int j = 1; j < 3; ++j)
+                if (((int64_t)1 << lg[j]) - ext[j] > ((int64_t)1 << lg[k]) - ext[k]) k = j;
+            if (lg[k] == 0 || ((int64_t)1 << (lg[k] - 1)) < ext[k]) { too_large = true; return hipSuccess; }
+            --lg[k];
+        }
+        g.tmx = (1u << lg[0]) - 1u; g.tmy = (1u << lg[1]) - 1u; g.tmz = (1u << lg[2]) - 1u;
+        g.tsy = (uint32_t)lg[0]; g.tsz = (uint32_t)(lg[0] + lg[1]);
+        if (resized) *resized = true;
+    }
+    for (int k = 0; k < 3; ++k) { g.blo[k] = lo[k]; g.bhi[k] = hi[k]; }
+    return hipSuccess;
+}
+// the same for the map's own array, which the caller is about to fill from scratch: (re)allocated when the sizes change
+hipError_t map_set_window(MapBuffers &buf, Grid &g, const int lo[3], const int hi[3], bool &too_large, bool *resized, hipStream_t st)
+{
+    bool r = false;
+    if (g.top != buf.top || !buf.top) g.top = nullptr;  // no array yet (or not ours): sizes are chosen
+    S2M_TRY(map_window_for(g, lo, hi, too_large, &r));
+    if (resized) *resized = r;
+    if (too_large) return hipSuccess;
+    const int64_t slots = top_slots(g);
+    if (r || buf.top_cap < slots + 1 || buf.grow_cap < slots + 1) {
+        S2M_TRY(map_ensure((void **)&buf.top, &buf.top_cap, slots + 1, sizeof(uint4)));
+        S2M_TRY(map_ensure((void **)&buf.grow, &buf.grow_cap, slots + 1, sizeof(uint32_t)));
+        // (the growth history is kept per slot: it does not survive a change of the slots)
+        S2M_TRY(hipMemsetAsync(buf.grow, 0, (size_t)(slots + 1) * sizeof(uint32_t), st));
+    }
+    g.top = buf.top;
+    return hipSuccess;
+}
+
+// top entries + brick tables of the m points whose sorted (box-independent) keys are `keys`; buf.keys is free scratch.
+// brick_bound >= 0: an upper bound of the number of occupied bricks known to the host -- nothing is read back
+// before the tables are built, and the counts arrive later (resolve_stats).  find_bounds: the grid's bounds (and, if they
+// do not fit it, the top array's sizes) are taken from the bricks found -- one hand-back; otherwise g's bounds hold them.
+hipError_t map_build_tables(MapBuffers &buf, Grid &g, const uint64_t *keys, int64_t m, MapStats &stats, hipStream_t st,
+                            int64_t brick_bound, bool find_bounds, bool *too_large)
+{
+    if (too_large) *too_large = false;
+    uint32_t *bricks_dev = buf.counters + kBricksWord;
+    uint64_t *ukeys = buf.keys;        // the bricks in key order (scratch: as many as there are points at most)
+    uint32_t *ucount = buf.work_a;     // their point counts
+    auto brick_of = rocprim::make_transform_iterator(keys, BrickOfKey());
     size_t tmp = 0;
-    S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, occupied, buf.rank, 0u, (size_t)top_entries + 1, rocprim::plus<uint32_t>(), st));
+    S2M_TRY(rocprim::run_length_encode(nullptr, tmp, brick_of, (unsigned int)m, ukeys, ucount, bricks_dev, st));
     S2M_TRY(map_ensure_sort_tmp(buf, tmp));
     size_t t1 = buf.sort_tmp_bytes;
-    // one element past the end (top has a zero spare entry): rank[top_entries] = number of occupied bricks
-    S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t1, occupied, buf.rank, 0u, (size_t)top_entries + 1, rocprim::plus<uint32_t>(), st));
-    const bool lazy = brick_bound >= 0;
+    S2M_TRY(rocprim::run_length_encode(buf.sort_tmp, t1, brick_of, (unsigned int)m, ukeys, ucount, bricks_dev, st));
+    const bool lazy = brick_bound >= 0 && !find_bounds;
     int64_t bricks = brick_bound;
-    if (!lazy) {
+    if (find_bounds) {
+        int32_t *box = reinterpret_cast<int32_t *>(buf.counters + kBoxWords);
+        hipLaunchKernelGGL(brick_box_kernel, dim3(1), dim3(1024), 0, st, bricks_dev, ukeys, (const uint32_t *)nullptr,
+                           (const uint64_t *)nullptr, 0, box);
+        const uint32_t *src[7] = {bricks_dev, buf.counters + kBoxWords, buf.counters + kBoxWords + 1, buf.counters + kBoxWords + 2,
+                                  buf.counters + kBoxWords + 3, buf.counters + kBoxWords + 4, buf.counters + kBoxWords + 5};
+        uint32_t v[7];
+        S2M_TRY(mail_fetch(buf.mail, src, 7, v, st));
+        bricks = v[0];
+        int lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) { lo[k] = (int32_t)v[1 + k]; hi[k] = (int32_t)v[4 + k]; }
+        if (bricks == 0) { lo[0] = lo[1] = lo[2] = 0; hi[0] = hi[1] = hi[2] = -1; }
+        bool big = false;
+        S2M_TRY(map_set_window(buf, g, lo, hi, big, nullptr, st));
+        if (big) {
+            if (too_large) *too_large = true;
+            return hipSuccess;
+        }
+    } else if (!lazy) {
         uint32_t b32 = 0;
-        const uint32_t *src[1] = {buf.rank + top_entries};
+        const uint32_t *src[1] = {bricks_dev};
         S2M_TRY(mail_fetch(buf.mail, src, 1, &b32, st));
         bricks = b32;
     }
+    const int64_t slots = top_slots(g);
+    S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(slots + 1) * sizeof(uint4), st));
     S2M_TRY(map_ensure((void **)&buf.tab, &buf.tab_cap, bricks * kBrickStride, sizeof(uint32_t), (bricks / 4 + 64) * kBrickStride));
-    S2M_TRY(map_ensure((void **)&buf.bstart, &buf.bstart_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
-    S2M_TRY(map_ensure((void **)&buf.bkey, &buf.bkey_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
+    S2M_TRY(map_ensure((void **)&buf.bstart, &buf.bstart_cap, bricks + 1, sizeof(uint32_t), bricks / 4 + 64));
+    S2M_TRY(map_ensure((void **)&buf.bkey, &buf.bkey_cap, bricks, sizeof(uint64_t), bricks / 4 + 64));
     S2M_TRY(map_ensure((void **)&buf.bmark, &buf.bmark_cap, bricks, sizeof(uint8_t), bricks / 4 + 64));
     S2M_TRY(map_ensure((void **)&buf.bend, &buf.bend_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
-    hipLaunchKernelGGL(brick_assign_kernel, dim3((unsigned)((top_entries + 255) / 256)), dim3(256), 0, st, top_entries,
-                       buf.top, buf.rank, buf.bstart, buf.bkey, buf.counters + 64);
+    if (bricks > 0) {
+        // first position of every brick (entries beyond the actual number, in the lazy case, are never read)
+        size_t ts = 0;
+        S2M_TRY(rocprim::exclusive_scan(nullptr, ts, ucount, buf.bstart, 0u, (size_t)bricks, rocprim::plus<uint32_t>(), st));
+        S2M_TRY(map_ensure_sort_tmp(buf, ts));
+        size_t t2 = buf.sort_tmp_bytes;
+        S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t2, ucount, buf.bstart, 0u, (size_t)bricks, rocprim::plus<uint32_t>(), st));
+        S2M_TRY(hipMemcpyAsync(buf.bkey, ukeys, (size_t)bricks * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    }
+    hipLaunchKernelGGL(brick_assign_kernel, dim3((unsigned)((std::max<int64_t>(bricks, kOccShards) + 255) / 256)), dim3(256), 0, st,
+                       bricks_dev, g, buf.top, ukeys, buf.counters + 64);
     if (bricks > 0)
-        hipLaunchKernelGGL(brick_table_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks,
-                           lazy ? buf.rank + top_entries : (const uint32_t *)nullptr, m, keys, buf.bstart, buf.top, buf.tab,
-                           buf.counters + 64, buf.bmark, buf.bend);
+        hipLaunchKernelGGL(brick_table_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, m, g, keys,
+                           buf.bstart, buf.top, buf.tab, buf.counters + 64, buf.bmark, buf.bend);
     ++buf.layout_gen;  // a fresh dense layout: every position below m holds a point
     if (!buf.h_stats) {
         S2M_TRY(hipHostMalloc((void **)&buf.h_stats, (1 + kOccShards) * sizeof(uint32_t), hipHostMallocMapped));
         S2M_TRY(hipHostGetDevicePointer((void **)&buf.h_stats_dev, buf.h_stats, 0));
         S2M_TRY(hipEventCreateWithFlags(&buf.stats_event, hipEventDisableTiming));
     }
-    hipLaunchKernelGGL(stats_mail_kernel, dim3(1), dim3(128), 0, st, buf.rank + top_entries, buf.counters + 64, buf.h_stats_dev);
+    hipLaunchKernelGGL(stats_mail_kernel, dim3(1), dim3(128), 0, st, bricks_dev, buf.counters + 64, buf.h_stats_dev);
     S2M_TRY(hipEventRecord(buf.stats_event, st));
     buf.stats_pending = true;
+    stats.layout_points = m;
+    stats.top_entries = slots;
     if (!lazy) {
         S2M_TRY(resolve_stats(buf, stats));
         S2M_TRY(hipGetLastError());
     } else {
         stats.bricks = bricks;  // the bound, until the counts have arrived
     }
+    g.top = buf.top; g.tab = buf.tab;
     return hipSuccess;
 }
 
-// margin_cells: free cells kept around the bounding box on every side (rounded up to whole bricks by the
-// caller's arithmetic below); a map that is maintained incrementally gets one so that points just outside the
-// current box can be merged in without a new grid
+// The grid's origin is chosen by the FIRST build of a map (keep_origin == nullptr) and kept by every later one: a cell's
+// box-independent coordinates -- and with them the order of the points -- never change while the cell size stands.
 static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float cell, const float lo[3],
-                             const float hi[3], int margin_cells, MapBuffers &buf, Grid &g, MapStats &stats,
+                             const float hi[3], const float *keep_origin, MapBuffers &buf, Grid &g, MapStats &stats,
                              bool &too_large, hipStream_t st)
 {
     too_large = false;
+    const uint4 *old_top = g.top;
+    const uint32_t otm[3] = {g.tmx, g.tmy, g.tmz}, ots[2] = {g.tsy, g.tsz};
     g = Grid();
+    // (the window of a previous map on the same buffers is kept when the new box fits it: no reallocation on a rebuild)
+    g.top = old_top; g.tmx = otm[0]; g.tmy = otm[1]; g.tmz = otm[2]; g.tsy = ots[0]; g.tsz = ots[1];
     g.c = cell;
     g.inv_c = 1.0f / cell;
     g.m = m;
     g.live = m;
     g.sent_off = (m + kSentinelPoints) < ((int64_t)1 << 28) ? (uint32_t)(m << 4) : 0u;
-    // one cell of padding below the box; extents rounded up to whole bricks.  The origin is shifted
-    // by an odd fraction of a cell per axis: man-made scenes have planes at round coordinates, and a
-    // plane that coincides with a cell face splits its points over two cell layers and leaves every
-    // query on it with zero margin to the face (measured 2x slower searches).
+    // The origin sits one cell (and an odd fraction of a cell) below the first cloud's box: man-made scenes have planes at
+    // round coordinates, and a plane that coincides with a cell face splits its points over two cell layers and leaves
+    // every query on it with zero margin to the face (measured 2x slower searches).
     const float shift[3] = {0.37f, 0.41f, 0.29f};
-    int nc[3];
     float o[3];
-    for (int k = 0; k < 3; ++k) {
-        o[k] = std::floor(lo[k] / cell) * cell - cell - shift[k] * cell - (float)margin_cells * cell;
-        const double span = ((double)hi[k] - (double)o[k]) / (double)cell;
-        const int64_t cells = (int64_t)std::floor(span) + 2 + margin_cells;
-        const int64_t rounded = ((cells + kBrick - 1) / kBrick) * kBrick;
-        if (rounded > (int64_t)1 << 24) { too_large = true; return hipSuccess; }
-        nc[k] = (int)rounded;
-    }
+    for (int k = 0; k < 3; ++k) o[k] = keep_origin ? keep_origin[k] : std::floor(lo[k] / cell) * cell - cell - shift[k] * cell;
     g.ox = o[0]; g.oy = o[1]; g.oz = o[2];
-    g.ncx = nc[0]; g.ncy = nc[1]; g.ncz = nc[2];
-    g.nbx = nc[0] / kBrick; g.nby = nc[1] / kBrick; g.nbz = nc[2] / kBrick;
-    const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
-    if (top_entries > ((int64_t)1 << 31)) { too_large = true; return hipSuccess; }
-    // the bound of the search uses coordinates in cell units; their float rounding error is a few
-    // ulp of the largest cell coordinate
-    const float max_cells = (float)std::max(std::max(nc[0], nc[1]), nc[2]);
-    g.slop = std::max(1.0e-4f, 16.0f * max_cells * 1.1920929e-7f);
+    // the termination bound of the search works with in-cell positions rounded to float and with the float reciprocal
+    // of the cell size: both errors are relative (cell_pos, s2m_device.h), far below this margin wherever the map lies
+    g.slop = 1.0e-4f;
+    BuildBox bb;
+    int blo[3] = {0, 0, 0}, bhi[3] = {-1, -1, -1};
+    for (int k = 0; k < 3 && m > 0; ++k) {
+        const int c0 = cell_coord(lo[k], o[k], g.inv_c), c1 = cell_coord(hi[k], o[k], g.inv_c);  // (monotone: the extreme cells)
+        if (c0 <= -kCellLimit || c1 >= kCellLimit) { too_large = true; return hipSuccess; }
+        blo[k] = c0 >> 3; bhi[k] = c1 >> 3;
+    }
+    for (int k = 0; k < 3; ++k) { bb.lo[k] = blo[k]; bb.n[k] = std::max(bhi[k] - blo[k] + 1, 1); }
+    const double box_bricks = (double)bb.n[0] * (double)bb.n[1] * (double)bb.n[2];
+    if (box_bricks >= 9.0e15) { too_large = true; return hipSuccess; }  // (brick << 9 | cell) must fit 64 bits
 
     S2M_TRY(map_ensure((void **)&buf.pts, &buf.pts_cap, m + kSentinelPoints, sizeof(float4), map_headroom_for(m)));
     S2M_TRY(map_put_sentinels(buf.pts, m, st));
     S2M_TRY(map_ensure((void **)&buf.pidx, &buf.pidx_cap, m + 1, sizeof(uint32_t), map_headroom_for(m)));
-    S2M_TRY(map_ensure((void **)&buf.top, &buf.top_cap, top_entries + 1, sizeof(uint4)));
+    bool resized = false;
+    S2M_TRY(map_set_window(buf, g, blo, bhi, too_large, &resized, st));
+    if (too_large) return hipSuccess;
     S2M_TRY(ensure_scratch(buf, m));
     if (!buf.counters) S2M_TRY(hipMalloc((void **)&buf.counters, (64 + kOccShards * 32) * sizeof(uint32_t)));
-    S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(top_entries + 1) * sizeof(uint4), st));
     // net growth of every brick of this grid since its room was last laid out (s2m_mapedit.hip): a new grid starts from zero
-    S2M_TRY(map_ensure((void **)&buf.grow, &buf.grow_cap, top_entries + 1, sizeof(uint32_t)));
-    S2M_TRY(hipMemsetAsync(buf.grow, 0, (size_t)(top_entries + 1) * sizeof(uint32_t), st));
+    S2M_TRY(hipMemsetAsync(buf.grow, 0, (size_t)(top_slots(g) + 1) * sizeof(uint32_t), st));
     buf.added_since_layout = 0;
     S2M_TRY(hipMemsetAsync(buf.counters, 0, 64 * sizeof(uint32_t), st));
     stats = MapStats();
-    stats.top_entries = top_entries;
+    stats.top_entries = top_slots(g);
+    g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
     if (m == 0) {
-        g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
+        S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(top_slots(g) + 1) * sizeof(uint4), st));
         return hipStreamSynchronize(st);
     }
 
     const int blocks = (int)((m + 255) / 256);
-    hipLaunchKernelGGL(key_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, g, buf.keys, buf.vals);
-    int bits = 9;
-    while (((int64_t)1 << (bits - 9)) < top_entries) ++bits;
+    hipLaunchKernelGGL(key_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, g, bb, buf.keys, buf.vals);
+    int bits = 9 + log2_ceil((int64_t)box_bricks);
     bits = std::min(bits + 1, 64);
     size_t tmp = 0;
     S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m, 0,
@@ -427,37 +558,29 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     size_t t1 = buf.sort_tmp_bytes;
     S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t1, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m,
                                       0, (unsigned)bits, st));
-    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, buf.vals_alt, buf.pts, buf.pidx);
+    hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, buf.vals_alt, bb, buf.pts, buf.pidx, buf.keys_alt);
     buf.next_id = m;        // the ids of a fresh build are the caller's indices
     buf.ids_dense = true;
-    S2M_TRY(map_build_tables(buf, buf.keys_alt, m, top_entries, stats, st));
-    stats.top_entries = top_entries;
+    S2M_TRY(map_build_tables(buf, g, buf.keys_alt, m, stats, st, -1, false, nullptr));
     g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
     return hipSuccess;
 }
 
 hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, MapBuffers &buf, Grid &grid,
-                     MapStats &stats, bool &too_large, hipStream_t st, bool with_margin)
+                     MapStats &stats, bool &too_large, hipStream_t st, const float *keep_origin)
 {
     float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
     if (m > 0) {
         if (!buf.bbox) S2M_TRY(hipMalloc((void **)&buf.bbox, kBboxScratchFloats * sizeof(float)));
         S2M_TRY(cloud_bbox(xyz, stride, m, buf.bbox, buf.mail, lo, hi, st));
     }
-    // margin of an incrementally maintained map: an eighth of the longest extent, 2 to 64 bricks
-    auto margin_for = [&](float c) {
-        if (!with_margin) return 0;
-        const double ext = std::max(std::max((double)hi[0] - lo[0], (double)hi[1] - lo[1]), (double)hi[2] - lo[2]);
-        const int64_t cells = (int64_t)(ext / (8.0 * (double)c));
-        return (int)(std::min<int64_t>(std::max<int64_t>(cells / kBrick, 2), 64) * kBrick);
-    };
-    if (cell > 0.0f) return build_once(xyz, stride, m, cell, lo, hi, margin_for(cell), buf, grid, stats, too_large, st);
+    if (cell > 0.0f) return build_once(xyz, stride, m, cell, lo, hi, keep_origin, buf, grid, stats, too_large, st);
     // density-driven cell size: LiDAR maps are surfaces, so points per occupied cell ~ c^2; aim for
     // ~11 points per occupied cell (cell edge about twice the 5-NN radius): measured fastest on
     // MI355X for the first-shell + hard-list search, including the large-displacement first pass
     float c = 0.5f;
     for (int attempt = 0; attempt < 4; ++attempt) {
-        S2M_TRY(build_once(xyz, stride, m, c, lo, hi, margin_for(c), buf, grid, stats, too_large, st));
+        S2M_TRY(build_once(xyz, stride, m, c, lo, hi, nullptr, buf, grid, stats, too_large, st));
         if (too_large) { c *= 2.0f; continue; }
         if (m == 0 || stats.occupied_cells == 0) return hipSuccess;
         const double mean = (double)m / (double)stats.occupied_cells;
@@ -467,7 +590,7 @@ hipError_t build_map(const float *xyz, int64_t stride, int64_t m, float cell, Ma
         if (std::fabs(cn - c) < 0.05f * c) return hipSuccess;
         c = cn;
     }
-    return build_once(xyz, stride, m, c, lo, hi, margin_for(c), buf, grid, stats, too_large, st);
+    return build_once(xyz, stride, m, c, lo, hi, nullptr, buf, grid, stats, too_large, st);
 }
 
 // AoS (caller stride) -> SoA scan arrays; feats_down keeps only x, y, z on this path

@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void dead_words_kernel(int64_t m, const uint8_
     // -- so nothing is renumbered: rounds 2-3 also ranked the removed CALLER INDICES here and every survivor gathered its
     // new index from that rank.)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { cnt[(m + 63) >> 6] = 0u; *outside_flag = 0u; }  // the scan's spare element; merge_newkey_kernel's flag
+    if (i < 7) outside_flag[i] = 0u;  // merge_newkey_kernel's flag and excess words
+    if (i == 0) cnt[(m + 63) >> 6] = 0u;  // the scan's spare element
     const unsigned long long ws = __ballot(i < m && alive_s[i] == 0);
     if ((threadIdx.x & 63) == 0 && (i >> 6) <= ((m - 1) >> 6)) {
         word_s[i >> 6] = ws;
@@ -62,26 +63,37 @@ __device__ __forceinline__ uint32_t dead_before(uint32_t ci, const DeadRank *__r
     return r.z + (uint32_t)__popcll(w & ((1ull << (ci & 63u)) - 1ull));
 }
 
+// How far a batch of new points reaches beyond the bricks in use: ext6[0..3) = bricks below blo, ext6[3..6) = bricks above bhi
+// (maxima over the batch; zero-initialised by the caller).  Called by every lane of a wave; `valid` lanes contribute.
+__device__ __forceinline__ void report_excess(const Grid &g, int bx, int by, int bz, bool valid, uint32_t *__restrict__ ext6)
+{
+    const int b[3] = {bx, by, bz};
+    uint32_t e[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        e[k] = valid ? (uint32_t)max(g.blo[k] - b[k], 0) : 0u;
+        e[3 + k] = valid ? (uint32_t)max(b[k] - g.bhi[k], 0) : 0u;
+    }
+    wave_max6_to(e, ext6);
+}
+
+// outside[0] |= 1 when a point's cell is beyond the representable range (nothing can hold it: the caller rebuilds around a new
+// origin); outside[1..7) = how far the batch reaches beyond the bricks in use (report_excess)
 __global__ __launch_bounds__(256) void merge_newkey_kernel(const float4 *__restrict__ stage, int n, Grid g,
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                            uint32_t *__restrict__ outside)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool out = false;
+    int cx = 0, cy = 0, cz = 0;
     if (i < n) {
         const float4 p = stage[i];
-        // unclamped cell coordinates: a point outside the grid cannot be merged (cell_of would clamp it into a
-        // border cell whose box does not contain it, which the search's distance bounds rely on)
-        const float fx = floorf((p.x - g.ox) * g.inv_c), fy = floorf((p.y - g.oy) * g.inv_c), fz = floorf((p.z - g.oz) * g.inv_c);
-        out = !(fx >= 0.0f && fx <= (float)(g.ncx - 1) && fy >= 0.0f && fy <= (float)(g.ncy - 1) && fz >= 0.0f &&
-                fz <= (float)(g.ncz - 1));
-        const int cx = cell_of(p.x, g.ox, g.inv_c, g.ncx), cy = cell_of(p.y, g.oy, g.inv_c, g.ncy),
-                  cz = cell_of(p.z, g.oz, g.inv_c, g.ncz);
-        const uint64_t brick = ((uint64_t)(cz >> 3) * g.nby + (cy >> 3)) * g.nbx + (cx >> 3);
-        const uint32_t local = (uint32_t)((((cz & 7) << 3) | (cy & 7)) << 3 | (cx & 7));
-        keys[i] = (brick << 9) | local;
+        cx = cell_coord(p.x, g.ox, g.inv_c); cy = cell_coord(p.y, g.oy, g.inv_c); cz = cell_coord(p.z, g.oz, g.inv_c);
+        out = !cell_representable(cx, cy, cz);
+        keys[i] = out ? ~0ull : point_key(cx, cy, cz);
         vals[i] = (uint32_t)i;
     }
+    report_excess(g, cx >> 3, cy >> 3, cz >> 3, i < n && !out, outside + 1);
     if (__syncthreads_or(out ? 1 : 0) && threadIdx.x == 0) atomicOr(outside, 1u);
 }
 
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(256) void merge_new_kernel(int n, const uint64_t *_
 // before`, the holes are filled with sentinel points (never a neighbour: +inf distance), id ~0 and the brick's largest key
 // (the key array stays sorted), prefix words and brick starts are shifted.
 __global__ __launch_bounds__(256) void slack_size_kernel(int64_t bound, const uint32_t *__restrict__ bricks_dev, int64_t m,
-                                                         const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ bkey,
+                                                         const uint32_t *__restrict__ bstart, const uint64_t *__restrict__ bkey, Grid g,
                                                          uint32_t *__restrict__ grow, int by_growth, uint32_t *__restrict__ slack)
 {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,21 +179,22 @@ __global__ __launch_bounds__(256) void slack_size_kernel(int64_t bound, const ui
         const uint32_t cnt = (id + 1 < bricks ? bstart[id + 1] : (uint32_t)m) - bstart[id];
         // an eighth of the brick -- or four times what it has gained since the room was last laid out, if that is more: the
         // bricks that grow (a frontier, a surface the sensor keeps refining) are the ones that would force the next merge
-        const uint32_t gained = grow[bkey[id]];
+        const uint32_t slot = top_slot_of_key(g, bkey[id]);
+        const uint32_t gained = grow[slot];
         v = max(min(max(cnt >> 3, 16u), 512u), by_growth ? min(4u * gained, 4096u) : 0u);
-        grow[bkey[id]] = gained >> 1;  // the history fades: half of it counts towards the next layout
+        grow[slot] = gained >> 1;  // the history fades: half of it counts towards the next layout
     }
     slack[id] = v;
 }
 __global__ __launch_bounds__(256) void slack_move_kernel(int64_t m, const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
-                                                         const uint64_t *__restrict__ keys, const uint4 *__restrict__ top,
+                                                         const uint64_t *__restrict__ keys, Grid g,
                                                          const uint32_t *__restrict__ shift, float4 *__restrict__ npts,
                                                          uint32_t *__restrict__ npidx, uint64_t *__restrict__ nkeys)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     const uint64_t k = keys[j];
-    const uint32_t dst = (uint32_t)j + shift[top[k >> 9].x - 1u];
+    const uint32_t dst = (uint32_t)j + shift[g.top[top_slot_of_key(g, k >> 9)].x - 1u];
     const float4 p = pts[j];
     npts[dst] = make_map_point(p.x, p.y, map_point_z(p), dst);
     npidx[dst] = pidx[j];
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(256) void slack_move_kernel(int64_t m, const float4
 // one wave per brick: the holes behind it, its prefix words and its start
 __global__ __launch_bounds__(256) void slack_brick_kernel(const uint32_t *__restrict__ bricks_dev, int64_t m, uint32_t *__restrict__ bstart,
                                                           uint32_t *__restrict__ bend,
-                                                          const uint32_t *__restrict__ bkey, const uint32_t *__restrict__ shift,
+                                                          const uint64_t *__restrict__ bkey, const uint32_t *__restrict__ shift,
                                                           uint32_t *__restrict__ tab, float4 *__restrict__ npts,
                                                           uint32_t *__restrict__ npidx, uint64_t *__restrict__ nkeys)
 {
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(256) void slack_brick_kernel(const uint32_t *__rest
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     uint32_t *t = tab + id * kBrickStride;
     for (int c = lane; c <= kBrickCells; c += 64) t[c] += sh;
-    const uint64_t filler = ((uint64_t)bkey[id] << 9) | 511ull;
+    const uint64_t filler = (bkey[id] << 9) | 511ull;
     if (lane == 0) bend[id] = e0 + sh + room;  // = the next brick's new start
     for (uint32_t h = e0 + sh + (uint32_t)lane; h < e0 + sh + room; h += 64u) {
         npts[h] = make_map_point(3.0e38f, 3.0e38f, 3.0e38f, 0xffffffffu);
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(256) void slack_start_kernel(const uint32_t *__rest
 }
 
 // dense layout of m points (buf.pts / pidx / keys_alt, tables built) -> layout with slack; g.m becomes the new extent
-static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bound, int64_t top_entries, hipStream_t st)
+static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bound, hipStream_t st)
 {
     const int64_t m = g.m;
     if (m <= 0 || bricks_bound <= 0) return hipSuccess;
@@ -235,13 +248,13 @@ static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bou
     if (ext_bound > buf.scratch_cap || ext_bound >= ((int64_t)1 << 31) || bricks_bound + 2 > buf.scratch_cap) return hipSuccess;  // stays dense
     S2M_TRY(map_ensure((void **)&buf.pts2, &buf.pts2_cap, ext_bound + kSentinelPoints, sizeof(float4), map_headroom_for(ext_bound)));
     S2M_TRY(map_ensure((void **)&buf.pidx2, &buf.pidx2_cap, ext_bound + 1, sizeof(uint32_t), map_headroom_for(ext_bound)));
-    const uint32_t *bricks_dev = buf.rank + top_entries;
+    const uint32_t *bricks_dev = buf.counters + kBricksWord;
     uint32_t *slack = buf.work_a, *shift = buf.work_b;
     size_t tmp = 0;
     S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, slack, shift, 0u, (size_t)bricks_bound + 1, rocprim::plus<uint32_t>(), st));
     S2M_TRY(map_ensure_sort_tmp(buf, tmp));
     hipLaunchKernelGGL(slack_size_kernel, dim3((unsigned)((bricks_bound + 256) / 256)), dim3(256), 0, st, bricks_bound, bricks_dev, m,
-                       buf.bstart, buf.bkey, buf.grow, by_growth, slack);
+                       buf.bstart, buf.bkey, g, buf.grow, by_growth, slack);
     buf.added_since_layout = (buf.added_since_layout + 1) / 2;
     size_t t = buf.sort_tmp_bytes;
     S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, slack, shift, 0u, (size_t)bricks_bound + 1, rocprim::plus<uint32_t>(), st));
@@ -250,7 +263,7 @@ static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bou
         S2M_TRY(mail_post(buf.mail, src, 1, st));
     }
     hipLaunchKernelGGL(slack_move_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.pts, buf.pidx, buf.keys_alt,
-                       buf.top, shift, buf.pts2, buf.pidx2, buf.keys);
+                       g, shift, buf.pts2, buf.pidx2, buf.keys);
     hipLaunchKernelGGL(slack_brick_kernel, dim3((unsigned)((bricks_bound + 3) / 4)), dim3(256), 0, st, bricks_dev, m, buf.bstart, buf.bend,
                        buf.bkey, shift, buf.tab, buf.pts2, buf.pidx2, buf.keys);
     hipLaunchKernelGGL(slack_start_kernel, dim3((unsigned)((bricks_bound + 255) / 256)), dim3(256), 0, st, bricks_dev, shift, buf.bstart);
@@ -285,11 +298,7 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     uint32_t *dcnt = buf.work_c, *dprefix = buf.work_c + (words + 1);
     if (2 * (words + 1) > buf.scratch_cap + 1) return hipSuccess;
     if (buf.next_id + n_new >= ((int64_t)1 << 32) - 2) return hipSuccess;  // ids exhausted: a rebuild makes them dense again
-    unsigned kbits = 10;  // (brick << 9 | cell) of this grid
-    {
-        const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
-        while (kbits < 64 && ((int64_t)1 << (kbits - 9)) < top_entries) ++kbits;
-    }
+    const unsigned kbits = 9 + 3 * kBrickBits;  // the box-independent key (a batch of a few thousand keys: the merge sort path)
     // capacity for the merged map before anything is enqueued (the exact size arrives with the hand-back below)
     const int64_t m_bound = m + n_new;
     if (m_bound > buf.scratch_cap || m_bound >= ((int64_t)1 << 31)) return hipSuccess;
@@ -318,12 +327,14 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     if (n > 0)
         hipLaunchKernelGGL(merge_newkey_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals,
                            buf.counters + 8);
-    // the one hand-back -- number of dead, "a new point lies outside the grid" -- is posted here and collected after the
-    // merge kernels have been enqueued: they write into the spare arrays, which only become the map if the answer allows it
+    // the one hand-back -- number of dead, "a new point cannot be represented", how far the new points reach beyond the
+    // bricks in use -- is posted here and collected after the merge kernels have been enqueued: they write into the spare
+    // arrays, which only become the map if the answer allows it
     const uint32_t *dead_dev = dprefix + words;
     {
-        const uint32_t *src[2] = {dead_dev, buf.counters + 8};
-        S2M_TRY(mail_post(buf.mail, src, 2, st));
+        const uint32_t *src[8] = {dead_dev, buf.counters + 8, buf.counters + 9, buf.counters + 10, buf.counters + 11, buf.counters + 12,
+                                  buf.counters + 13, buf.counters + 14};
+        S2M_TRY(mail_post(buf.mail, src, 8, st));
     }
     if (n > 0) {
         t = buf.sort_tmp_bytes;
@@ -336,13 +347,15 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
         hipLaunchKernelGGL(merge_new_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, nv_sorted, lb, rank_s, stage,
                            (uint32_t)buf.next_id, buf.pts2, buf.keys, buf.pidx2);
     uint32_t dead = 0, outside = 0;
+    int lo[3], hi[3];
     {
-        uint32_t v[2] = {0, 0};
-        S2M_TRY(mail_collect(buf.mail, 2, v, st));
+        uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        S2M_TRY(mail_collect(buf.mail, 8, v, st));
         dead = v[0];
         outside = v[1];
+        for (int k = 0; k < 3; ++k) { lo[k] = g.blo[k] - (n > 0 ? (int)v[2 + k] : 0); hi[k] = g.bhi[k] + (n > 0 ? (int)v[5 + k] : 0); }
     }
-    if (outside) return hipSuccess;     // full rebuild (with a fresh margin); what was written to the spare arrays is dropped
+    if (outside) return hipSuccess;     // full rebuild around a new origin; what was written to the spare arrays is dropped
     if (dead == 0 && n_new == 0) {      // nothing was removed and nothing is added: the map stands as it is
         merged = true;
         return hipSuccess;
@@ -357,17 +370,22 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     std::swap(buf.pts, buf.pts2); std::swap(buf.pts_cap, buf.pts2_cap);
     std::swap(buf.pidx, buf.pidx2); std::swap(buf.pidx_cap, buf.pidx2_cap);
     std::swap(buf.keys, buf.keys_alt);
-    const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
-    S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(top_entries + 1) * sizeof(uint4), st));
     g.m = m_new;
     g.live = m_new;
     g.sent_off = (m_new + kSentinelPoints) < ((int64_t)1 << 28) ? (uint32_t)(m_new << 4) : 0u;
-    // every new point opens at most one brick: no read-back before the tables are built
-    const int64_t brick_bound = std::min<int64_t>(stats.bricks + n_new, std::min<int64_t>(top_entries, m_new));
-    S2M_TRY(map_build_tables(buf, buf.keys_alt, m_new, top_entries, stats, st, brick_bound));
-    stats.top_entries = top_entries;
+    // every new point opens at most one brick: no read-back before the tables are built -- unless the box of the bricks in
+    // use, grown by the new points, has left the window of the top array: then the exact box of the merged map is fetched
+    // (the bounds only ever grow between such events: bricks that the field-of-view trim emptied are dropped here) and the
+    // array resized if even that does not fit
+    const int64_t brick_bound = std::min<int64_t>(stats.bricks + n_new, m_new);
+    const bool fits = (int64_t)hi[0] - lo[0] <= (int64_t)g.tmx && (int64_t)hi[1] - lo[1] <= (int64_t)g.tmy && (int64_t)hi[2] - lo[2] <= (int64_t)g.tmz;
+    bool too_large = false;
+    if (fits) S2M_TRY(map_set_window(buf, g, lo, hi, too_large, nullptr, st));
+    else ++buf.n_relaid;
+    S2M_TRY(map_build_tables(buf, g, buf.keys_alt, m_new, stats, st, brick_bound, !fits, &too_large));
+    if (too_large) return hipErrorOutOfMemory;  // (a box of bricks beyond 2^28 top entries: not a map this engine can hold)
     g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
-    if (with_slack) S2M_TRY(spread_with_slack(buf, g, brick_bound, top_entries, st));
+    if (with_slack) S2M_TRY(spread_with_slack(buf, g, brick_bound, st));
     merged = true;
     return hipSuccess;
 }
@@ -385,7 +403,12 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
 // and falls back to the merge update (which lays the map out densely again).
 constexpr int kSlabMax = 2048;  // points of one brick the rewrite stages in LDS (47 KB: three workgroups per CU) ...
 constexpr int kSlabBig = 6144;  // ... and in the second, rarely launched form for crowded bricks (134 KB of dynamic LDS: one per CU)
-enum : uint32_t { kSlabOutside = 1u, kSlabNewBrick = 2u, kSlabOverflow = 4u };
+// kSlabOutside: a new point's cell cannot be represented (rebuild around a new origin); kSlabWindow: the box of the bricks in
+// use, grown by the new points, no longer fits the window of the top array (the host re-lays it and tries again)
+enum : uint32_t { kSlabOutside = 1u, kSlabNewBrick = 2u, kSlabOverflow = 4u, kSlabWindow = 8u };
+// words of the update's counters behind `flags`: [0] outcome bits, [1] points removed, [2] bricks opened, [3] points gained
+// by bricks, [4] crowded bricks among the touched ones, [5..11) how far the new points reach beyond the bricks in use
+constexpr int kSlabWords = 11;
 
 __global__ __launch_bounds__(256) void slab_key_kernel(const float4 *__restrict__ stage, int n, Grid g, uint64_t *__restrict__ keys,
                                                        uint32_t *__restrict__ vals, uint8_t *__restrict__ bmark,
@@ -393,25 +416,24 @@ __global__ __launch_bounds__(256) void slab_key_kernel(const float4 *__restrict_
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t f = 0u;
+    int cx = 0, cy = 0, cz = 0;
     if (i < n) {
         const float4 p = stage[i];
-        const float fx = floorf((p.x - g.ox) * g.inv_c), fy = floorf((p.y - g.oy) * g.inv_c), fz = floorf((p.z - g.oz) * g.inv_c);
-        const bool out = !(fx >= 0.0f && fx <= (float)(g.ncx - 1) && fy >= 0.0f && fy <= (float)(g.ncy - 1) && fz >= 0.0f &&
-                           fz <= (float)(g.ncz - 1));
-        const int cx = cell_of(p.x, g.ox, g.inv_c, g.ncx), cy = cell_of(p.y, g.oy, g.inv_c, g.ncy),
-                  cz = cell_of(p.z, g.oz, g.inv_c, g.ncz);
-        const uint64_t brick = ((uint64_t)(cz >> 3) * g.nby + (cy >> 3)) * g.nbx + (cx >> 3);
-        const uint32_t local = (uint32_t)((((cz & 7) << 3) | (cy & 7)) << 3 | (cx & 7));
-        keys[i] = (brick << 9) | local;
+        cx = cell_coord(p.x, g.ox, g.inv_c); cy = cell_coord(p.y, g.oy, g.inv_c); cz = cell_coord(p.z, g.oz, g.inv_c);
         vals[i] = (uint32_t)i;
-        if (out) {
+        if (!cell_representable(cx, cy, cz)) {
+            keys[i] = ~0ull;
             f = kSlabOutside;
         } else {
-            const uint32_t idp1 = g.top[brick].x;
-            if (idp1 != 0u) bmark[idp1 - 1u] |= 2u;  // (every writer of this byte in this launch stores the same value)
-            // (a point whose brick does not exist yet: slab_newbrick_kernel opens it)
+            keys[i] = point_key(cx, cy, cz);
+            if (brick_in_bounds(g, cx >> 3, cy >> 3, cz >> 3)) {
+                const uint32_t idp1 = g.top[top_slot(g, cx >> 3, cy >> 3, cz >> 3)].x;
+                if (idp1 != 0u) bmark[idp1 - 1u] |= 2u;  // (every writer of this byte in this launch stores the same value)
+            }
+            // (a point whose brick does not exist yet, inside the bounds or beyond them: slab_newbrick_kernel opens it)
         }
     }
+    report_excess(g, cx >> 3, cy >> 3, cz >> 3, i < n && f == 0u, flags + 5);
     const unsigned long long any = __ballot(f != 0u);
     if (any != 0ull) {
         uint32_t w = f;
@@ -431,40 +453,63 @@ __device__ __forceinline__ int slab_lower(const uint64_t *__restrict__ nk, int n
     }
     return lo;
 }
+// the entry of brick key b in the top array, if the brick lies inside the bounds in use (else "no brick": 0)
+__device__ __forceinline__ uint32_t slab_brick_id(const Grid &g, uint64_t b)
+{
+    int bx, by, bz;
+    brick_coords(b, bx, by, bz);
+    return brick_in_bounds(g, bx, by, bz) ? g.top[top_slot(g, bx, by, bz)].x : 0u;
+}
 
-// Bricks that this update opens (new points in a brick of the grid that holds nothing yet: a sensor that moves sees new
+// Bricks that this update opens (new points in a brick that holds nothing yet: a sensor that moves sees new
 // ground every frame) get their stretch of positions from the END of the room of the brick before them in key order, so
 // that position order stays key order; several new bricks in front of the same old brick line up there in key order.
-// One workgroup: heads of the new-brick segments of the sorted new keys (in order) -> per head the first old position of
-// a later brick (binary search in the sorted keys) -> a backward walk assigns the stretches -> the room of the brick in
-// front must still hold its own points plus what this update adds to it (ignoring what it removes: conservative) ->
-// only then are the entries written: top, brick key / start / end, an empty prefix row, the mark "new" (4) + "touched" (2),
-// the brick count.  Any doubt -- more than 1 024 new bricks, no brick in front, not enough room, no spare table rows --
-// raises kSlabNewBrick instead and writes nothing: the merge re-lays the map out.
+// One workgroup: the box of the bricks in use, grown by the new points, must fit the window of the top array (else
+// kSlabWindow: the host re-lays the array and calls again) -> heads of the new-brick segments of the sorted new keys (in
+// order) -> per head the first old position of a later brick (binary search in the sorted keys) -> a backward walk assigns
+// the stretches -> the room of the brick in front must still hold its own points plus what this update adds to it
+// (ignoring what it removes: conservative) -> only then are the entries written: top, brick key / start / end, an empty
+// prefix row, the mark "new" (4) + "touched" (2), the brick count.  Any doubt -- more than 1 024 new bricks, no brick in
+// front, not enough room, no spare table rows -- raises kSlabNewBrick instead and writes nothing: the merge re-lays the map
+// out.
 constexpr int kNewBricksMax = 1024;
-__global__ __launch_bounds__(256) void slab_newbrick_kernel(const uint64_t *__restrict__ nk, int n_new, uint4 *__restrict__ top,
+__global__ __launch_bounds__(256) void slab_newbrick_kernel(const uint64_t *__restrict__ nk, int n_new, Grid g, uint4 *__restrict__ top,
                                                             const uint64_t *__restrict__ okeys, int64_t m,
                                                             uint32_t *__restrict__ tab, uint32_t *__restrict__ bstart,
-                                                            uint32_t *__restrict__ bend, uint32_t *__restrict__ bkey,
+                                                            uint32_t *__restrict__ bend, uint64_t *__restrict__ bkey,
                                                             uint8_t *__restrict__ bmark, uint32_t *__restrict__ bricks_dev,
                                                             int max_new, uint32_t *__restrict__ flags)
 {
-    __shared__ uint32_t h_b[kNewBricksMax], h_k0[kNewBricksMax], h_need[kNewBricksMax], h_p0[kNewBricksMax], h_ida[kNewBricksMax],
+    __shared__ uint64_t h_b[kNewBricksMax];
+    __shared__ uint32_t h_k0[kNewBricksMax], h_need[kNewBricksMax], h_p0[kNewBricksMax], h_ida[kNewBricksMax],
         h_start[kNewBricksMax], h_end[kNewBricksMax];
     __shared__ int wsum[4];
     __shared__ int s_fail;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid == 0) s_fail = 0;
     __syncthreads();
+    if (flags[0] & kSlabOutside) return;  // (uniform; the key kernel has finished)
+    // 0. does the grown box still fit the window?  (uniform: every thread reads the same six words)
+    {
+        bool fits = true;
+        const uint32_t tm[3] = {g.tmx, g.tmy, g.tmz};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            fits = fits && ((int64_t)g.bhi[k] + flags[8 + k]) - ((int64_t)g.blo[k] - flags[5 + k]) <= (int64_t)tm[k];
+        if (!fits) {
+            if (tid == 0) atomicOr(flags, kSlabWindow);
+            return;
+        }
+    }
     // 1. the heads, in key order
     int nh = 0;
     for (int c0 = 0; c0 < n_new; c0 += 256) {
         const int k = c0 + tid;
         bool head = false;
-        uint32_t b = 0u;
+        uint64_t b = 0u;
         if (k < n_new) {
-            b = (uint32_t)(nk[k] >> 9);
-            head = (k == 0 || (uint32_t)(nk[k - 1] >> 9) != b) && top[b].x == 0u;
+            b = nk[k] >> 9;
+            head = (k == 0 || (nk[k - 1] >> 9) != b) && slab_brick_id(g, b) == 0u;
         }
         const unsigned long long bal = __ballot(head);
         if (lane == 0) wsum[wave] = __popcll(bal);
@@ -486,18 +531,18 @@ __global__ __launch_bounds__(256) void slab_newbrick_kernel(const uint64_t *__re
     }
     // 2. per head: its points, what it asks for, the first old position of a later brick, the brick in front
     for (int i = tid; i < nh; i += 256) {
-        const uint32_t b = h_b[i];
-        const int n_b = slab_lower(nk, n_new, (uint64_t)b + 1) - (int)h_k0[i];
+        const uint64_t b = h_b[i];
+        const int n_b = slab_lower(nk, n_new, b + 1) - (int)h_k0[i];
         h_need[i] = (uint32_t)n_b + max((uint32_t)n_b >> 2, 32u);
         int64_t lo = 0, hi = m;  // first old position whose brick is later than b (b itself holds nothing)
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
-            if ((okeys[mid] >> 9) <= (uint64_t)b) lo = mid + 1; else hi = mid;
+            if ((okeys[mid] >> 9) <= b) lo = mid + 1; else hi = mid;
         }
         h_p0[i] = (uint32_t)lo;
         uint32_t ida = 0xffffffffu;
         if (lo > 0) {
-            const uint32_t idp1 = top[okeys[lo - 1] >> 9].x;
+            const uint32_t idp1 = slab_brick_id(g, okeys[lo - 1] >> 9);
             if (idp1) ida = idp1 - 1u;
         }
         h_ida[i] = ida;
@@ -532,9 +577,9 @@ __global__ __launch_bounds__(256) void slab_newbrick_kernel(const uint64_t *__re
     // 4. the entries
     const uint32_t first_id = *bricks_dev;
     for (int i = tid; i < nh; i += 256) {
-        const uint32_t id = first_id + (uint32_t)i, b = h_b[i];
-        uint32_t *te = reinterpret_cast<uint32_t *>(&top[b]);
-        te[0] = id + 1u; te[1] = h_start[i] + 1u; te[2] = 0u; te[3] = 0u;
+        const uint32_t id = first_id + (uint32_t)i;
+        const uint64_t b = h_b[i];
+        top[top_slot_of_key(g, b)] = make_uint4(id + 1u, 0u, 0u, 0u);
         bkey[id] = b;
         bstart[id] = h_start[i];
         bend[id] = h_end[i];
@@ -548,16 +593,17 @@ __global__ __launch_bounds__(256) void slab_newbrick_kernel(const uint64_t *__re
 }
 
 // one wave per brick: does the touched brick fit where it stands?  flags[0] |= overflow, flags[1] += points removed
-__global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restrict__ bricks_dev,
+__global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restrict__ bricks_dev, Grid g,
                                                         const uint32_t *__restrict__ bend, const uint32_t *__restrict__ tab,
-                                                        const uint32_t *__restrict__ bkey, const uint8_t *__restrict__ bmark,
+                                                        const uint64_t *__restrict__ bkey, const uint8_t *__restrict__ bmark,
                                                         const uint8_t *__restrict__ alive_s, const uint64_t *__restrict__ nk, int n_new,
-                                                        uint32_t *__restrict__ grow, uint32_t *__restrict__ flags)
+                                                        uint32_t *__restrict__ grow, uint32_t *__restrict__ flags, int big_ok)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t bricks = (int64_t)*bricks_dev;
     const int64_t id = (int64_t)blockIdx.x * 4 + wave;
     if (id >= bricks || bmark[id] == 0) return;
+    if (flags[0] & (kSlabOutside | kSlabWindow)) return;  // the host deals with the window first and calls again: count nothing twice
     const uint32_t base = tab[id * kBrickStride], end = tab[id * kBrickStride + kBrickCells];
     const uint32_t cap_end = bend[id];
     int alive = 0;
@@ -570,12 +616,12 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restri
     const uint32_t total = (uint32_t)alive + (uint32_t)n_b;
     // what the rewrite has to stage at most: the brick's positions so far plus its new points
     const uint32_t stage = (end - base) + (uint32_t)n_b;
-    if (total > cap_end - base || stage > (uint32_t)kSlabBig) atomicOr(flags, kSlabOverflow);
+    if (total > cap_end - base || stage > (uint32_t)(big_ok ? kSlabBig : kSlabMax)) atomicOr(flags, kSlabOverflow);
     else if (stage > (uint32_t)kSlabMax) atomicAdd(flags + 4, 1u);  // a crowded brick: the second launch takes it
     atomicAdd(flags + 1, (end - base) - (uint32_t)alive);
     // what the brick gains by this update (whether it ends up in place or merged): the next layout sizes its room by it
     if (total > end - base) {
-        grow[b] += total - (end - base);
+        grow[top_slot_of_key(g, b)] += total - (end - base);
         atomicAdd(flags + 3, total - (end - base));  // the host keeps the sum as the bound of the room it will need
     }
 }
@@ -583,11 +629,11 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restri
 // one workgroup per touched brick (see the comment above); does nothing when the plan found a reason not to.  CAP = 2 048:
 // the bricks whose staging fits that; CAP = 6 144: the crowded ones only (launched when the plan counted any)
 template <int CAP>
-__global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__restrict__ bricks_dev, const uint32_t *__restrict__ flags,
+__global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__restrict__ bricks_dev, const uint32_t *__restrict__ flags, Grid g,
                                                            float4 *__restrict__ pts, uint32_t *__restrict__ pidx,
                                                            uint64_t *__restrict__ keys, uint8_t *__restrict__ alive_s,
                                                            uint32_t *__restrict__ tab, uint4 *__restrict__ top,
-                                                           const uint32_t *__restrict__ bkey, uint8_t *__restrict__ bmark,
+                                                           const uint64_t *__restrict__ bkey, uint8_t *__restrict__ bmark,
                                                            const uint32_t *__restrict__ bend,
                                                            const uint64_t *__restrict__ nk, const uint32_t *__restrict__ nv, int n_new,
                                                            const float4 *__restrict__ stage, uint32_t next_id)
@@ -678,7 +724,7 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
         unsigned long long mask;
         (void)table_from_firsts(l_t, base + (uint32_t)total, tab + id * kBrickStride, lane, mask);
         if (lane == 0) {
-            uint32_t *te = reinterpret_cast<uint32_t *>(&top[bk]);
+            uint32_t *te = reinterpret_cast<uint32_t *>(&top[top_slot_of_key(g, bk)]);
             te[2] = (uint32_t)mask;
             te[3] = (uint32_t)(mask >> 32);
             bmark[id] = 0;
@@ -686,9 +732,59 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
     }
 }
 
-// flags: five zeroed words of the update's counters (outcome bits, points removed, bricks opened, points gained by bricks,
-// crowded bricks among the touched ones).  done = the map was updated in
-// place; otherwise nothing was touched and the caller goes on to merge_update.
+// The top array for a box of bricks that has outgrown (or wandered out of) its window, WITHOUT touching a point: the exact box
+// of the bricks that hold points and of the update's new points comes back from the device (the bounds only ever grow
+// between such events, so this is also where the bricks the field-of-view trim emptied are let go), the array keeps its
+// sizes if that box fits them and is enlarged otherwise, and every brick inside the box moves its entry from its old slot to
+// its new one -- a few thousand 16-byte entries (ikd-Tree has no counterpart: its nodes hold absolute coordinates).
+__global__ __launch_bounds__(256) void top_relay_kernel(const uint32_t *__restrict__ bricks_dev, const uint64_t *__restrict__ bkey, Grid go,
+                                                        Grid gn, uint4 *__restrict__ ntop)
+{
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t)*bricks_dev) return;
+    int bx, by, bz;
+    brick_coords(bkey[id], bx, by, bz);
+    if (!brick_in_bounds(gn, bx, by, bz) || !brick_in_bounds(go, bx, by, bz)) return;
+    const uint4 e = go.top[top_slot(go, bx, by, bz)];
+    if (e.x == (uint32_t)id + 1u) ntop[top_slot(gn, bx, by, bz)] = e;
+}
+static hipError_t relay_top(MapBuffers &buf, Grid &g, MapStats &stats, const uint64_t *nk, int n, bool &too_large, hipStream_t st)
+{
+    too_large = false;
+    const uint32_t *bricks_dev = buf.counters + kBricksWord;
+    launch_brick_box(bricks_dev, buf.bkey, buf.tab, nk, n, reinterpret_cast<int32_t *>(buf.counters + kBoxWords), st);
+    const uint32_t *src[6] = {buf.counters + kBoxWords, buf.counters + kBoxWords + 1, buf.counters + kBoxWords + 2,
+                              buf.counters + kBoxWords + 3, buf.counters + kBoxWords + 4, buf.counters + kBoxWords + 5};
+    uint32_t v[6];
+    S2M_TRY(mail_fetch(buf.mail, src, 6, v, st));
+    int lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) { lo[k] = (int32_t)v[k]; hi[k] = (int32_t)v[3 + k]; }
+    if (lo[0] > hi[0]) { lo[0] = lo[1] = lo[2] = 0; hi[0] = hi[1] = hi[2] = -1; }
+    const Grid go = g;
+    Grid gn = g;
+    bool resized = false;
+    S2M_TRY(map_window_for(gn, lo, hi, too_large, &resized));  // (sizes are chosen anew only if the box does not fit the current ones)
+    if (too_large) return hipSuccess;
+    // the new array is written beside the old one (the kernel reads go.top = buf.top)
+    const int64_t slots = top_slots(gn);
+    S2M_TRY(map_ensure((void **)&buf.top2, &buf.top2_cap, slots + 1, sizeof(uint4)));
+    S2M_TRY(hipMemsetAsync(buf.top2, 0, (size_t)(slots + 1) * sizeof(uint4), st));
+    const int64_t bricks = stats.bricks + kNewBricksMax;  // (an upper bound, as in slab_update)
+    hipLaunchKernelGGL(top_relay_kernel, dim3((unsigned)((bricks + 255) / 256)), dim3(256), 0, st, bricks_dev, buf.bkey, go, gn, buf.top2);
+    std::swap(buf.top, buf.top2); std::swap(buf.top_cap, buf.top2_cap);
+    if (resized) {  // (the growth history is kept per slot: it does not survive a change of the slots)
+        S2M_TRY(map_ensure((void **)&buf.grow, &buf.grow_cap, slots + 1, sizeof(uint32_t)));
+        S2M_TRY(hipMemsetAsync(buf.grow, 0, (size_t)(slots + 1) * sizeof(uint32_t), st));
+    }
+    gn.top = buf.top;
+    g = gn;
+    stats.top_entries = slots;
+    ++buf.n_relaid;
+    return hipGetLastError();
+}
+
+// flags: kSlabWords zeroed words of the update's counters.  done = the map was updated in place; otherwise nothing was
+// touched and the caller goes on to merge_update.
 hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t n_new,
                        uint32_t *flags, bool &done, hipStream_t st)
 {
@@ -698,13 +794,11 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return hipSuccess;
     if (buf.next_id + n_new >= ((int64_t)1 << 32) - 2) return hipSuccess;
     const int n = (int)n_new;
-    const int64_t top_entries = (int64_t)g.nbx * g.nby * g.nbz;
-    const uint32_t *bricks_dev = buf.rank + top_entries;
+    uint32_t *bricks_dev = buf.counters + kBricksWord;
     uint64_t *nk_sorted = buf.mk;
     uint32_t *nv_sorted = buf.mv;
     if (n > 0) {
-        unsigned kbits = 10;
-        while (kbits < 64 && ((int64_t)1 << (kbits - 9)) < top_entries) ++kbits;
+        const unsigned kbits = 9 + 3 * kBrickBits;
         size_t tmp = 0;
         S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp, buf.keys, buf.keys, buf.vals, buf.vals, (size_t)n_new, 0, kbits, st));
         S2M_TRY(map_ensure_sort_tmp(buf, tmp));
@@ -716,38 +810,54 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
         size_t t = buf.sort_tmp_bytes;
         S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, nk_sorted, buf.vals, nv_sorted, (size_t)n_new, 0, kbits, st));
     }
+    // the crowded-brick form of the rewrite needs 134 KB of dynamic LDS: granted once per handle (= per device; the
+    // attribute belongs to the kernel object of the current device); a device that refuses leaves those bricks to the merge
+    constexpr size_t kLdsSmall = (size_t)kSlabMax * 22 + kBrickCells * 4, kLdsBig = (size_t)kSlabBig * 22 + kBrickCells * 4;
+    if (buf.big_slab == 0) {
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&slab_rewrite_kernel<kSlabBig>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBig);
+        if (ae != hipSuccess) (void)hipGetLastError();
+        buf.big_slab = ae == hipSuccess ? 1 : -1;
+    }
+    const int big_ok = buf.big_slab > 0 ? 1 : 0;
     // spare rows for bricks this update opens (the tables were allocated with headroom)
     const int64_t rows = std::min(std::min(buf.tab_cap / kBrickStride, buf.bstart_cap), std::min(std::min(buf.bkey_cap, buf.bmark_cap), buf.bend_cap));
     const int max_new = (int)std::max<int64_t>(std::min<int64_t>(rows - stats.bricks, kNewBricksMax), 0);
-    if (n > 0)
-        hipLaunchKernelGGL(slab_newbrick_kernel, dim3(1), dim3(256), 0, st, nk_sorted, n, buf.top, buf.keys_alt, m, buf.tab, buf.bstart,
-                           buf.bend, buf.bkey, buf.bmark, buf.rank + top_entries, max_new, flags);
     const int64_t bricks = stats.bricks + max_new;  // (an upper bound: a merged update's counts may be on their way, bricks may just have opened)
-    hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, buf.bend, buf.tab,
-                       buf.bkey, buf.bmark, alive_s, nk_sorted, n, buf.grow, flags);
-    {
-        const uint32_t *src[5] = {flags, flags + 1, flags + 2, flags + 3, flags + 4};
-        S2M_TRY(mail_post(buf.mail, src, 5, st));
-    }
-    constexpr size_t kLdsSmall = (size_t)kSlabMax * 22 + kBrickCells * 4, kLdsBig = (size_t)kSlabBig * 22 + kBrickCells * 4;
-    hipLaunchKernelGGL((slab_rewrite_kernel<kSlabMax>), dim3((unsigned)bricks), dim3(256), kLdsSmall, st, bricks_dev, flags, buf.pts, buf.pidx,
-                       buf.keys_alt, alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, nk_sorted, nv_sorted, n, stage,
-                       (uint32_t)buf.next_id);
-    uint32_t v[5] = {0, 0, 0, 0, 0};
-    S2M_TRY(mail_collect(buf.mail, 5, v, st));
-    if (v[0] == 0u && v[4] != 0u) {  // crowded bricks among the touched ones: the form with the large staging area
-        static bool attr_set = false;
-        if (!attr_set) {
-            S2M_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&slab_rewrite_kernel<kSlabBig>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)kLdsBig));
-            attr_set = true;
+    uint32_t v[kSlabWords];
+    for (int attempt = 0;; ++attempt) {
+        if (n > 0)
+            hipLaunchKernelGGL(slab_newbrick_kernel, dim3(1), dim3(256), 0, st, nk_sorted, n, g, buf.top, buf.keys_alt, m, buf.tab, buf.bstart,
+                               buf.bend, buf.bkey, buf.bmark, bricks_dev, max_new, flags);
+        hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, g, buf.bend, buf.tab,
+                           buf.bkey, buf.bmark, alive_s, nk_sorted, n, buf.grow, flags, big_ok);
+        {
+            const uint32_t *src[kSlabWords];
+            for (int k = 0; k < kSlabWords; ++k) src[k] = flags + k;
+            S2M_TRY(mail_post(buf.mail, src, kSlabWords, st));
         }
-        hipLaunchKernelGGL((slab_rewrite_kernel<kSlabBig>), dim3((unsigned)bricks), dim3(256), kLdsBig, st, bricks_dev, flags, buf.pts, buf.pidx,
+        hipLaunchKernelGGL((slab_rewrite_kernel<kSlabMax>), dim3((unsigned)bricks), dim3(256), kLdsSmall, st, bricks_dev, flags, g, buf.pts, buf.pidx,
                            buf.keys_alt, alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, nk_sorted, nv_sorted, n, stage,
                            (uint32_t)buf.next_id);
+        for (int k = 0; k < kSlabWords; ++k) v[k] = 0u;
+        S2M_TRY(mail_collect(buf.mail, kSlabWords, v, st));
+        if (v[0] != kSlabWindow || attempt > 0) break;
+        // the box of the bricks in use has left the window: re-lay the top array (nothing else was written) and go again
+        bool too_large = false;
+        S2M_TRY(relay_top(buf, g, stats, nk_sorted, n, too_large, st));
+        if (too_large) return hipSuccess;  // (the merge reports it)
+        S2M_TRY(hipMemsetAsync(flags, 0, kSlabWords * sizeof(uint32_t), st));
+    }
+    if (v[0] == 0u && v[4] != 0u) {  // crowded bricks among the touched ones: the form with the large staging area
+        hipLaunchKernelGGL((slab_rewrite_kernel<kSlabBig>), dim3((unsigned)bricks), dim3(256), kLdsBig, st, bricks_dev, flags, g, buf.pts, buf.pidx,
+                           buf.keys_alt, alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, nk_sorted, nv_sorted, n, stage,
+                           (uint32_t)buf.next_id);
+        buf.n_big_slab += v[4];  // (diagnostic: bricks that went through the large form)
     }
     buf.added_since_layout += v[3];  // (counted by the plan kernel whether the update stays in place or not)
     if (v[0] != 0u) return hipSuccess;  // the rewrite kernel saw the same word and left the points alone
+    // the bounds follow the bricks this update opened
+    for (int k = 0; k < 3; ++k) { g.blo[k] -= (int)v[5 + k]; g.bhi[k] += (int)v[8 + k]; }
     stats.bricks += v[2];
     g.live += n_new - (int64_t)v[1];
     buf.next_id += n_new;

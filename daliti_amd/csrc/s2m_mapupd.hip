@@ -32,16 +32,9 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
-#include "s2m_device.h"
-#include "s2m_kernels.h"
+#include "s2m_map_internal.h"
 
 namespace s2m {
-
-#define S2M_TRY(x)                       \
-    do {                                 \
-        hipError_t e_ = (x);             \
-        if (e_ != hipSuccess) return e_; \
-    } while (0)
 
 struct Voxel {
     float mn[3], mx[3], mid[3];
@@ -87,11 +80,10 @@ __device__ __forceinline__ uint64_t voxel_key(float x, float y, float z, float d
     return ((uint64_t)(kx & 0x1fffff) << 42) | ((uint64_t)(ky & 0x1fffff) << 21) | (uint64_t)(kz & 0x1fffff);
 }
 
-// visit every old point inside box [mn, mx) through the brick grid.  The cell of a coordinate,
-// floor((v - o) * inv_c) clamped to the grid, is a monotone function of v (every float step in it is), and
-// the map points were binned with the same expression (cell_of, s2m_map_internal.h): a point with mn <= p < mx lies
-// in a cell between cell(mn) and cell(mx), so no slack cells are needed.  Per x-row the cells of one brick
-// are one contiguous run of the sorted array.
+// visit every old point inside box [mn, mx) through the brick grid.  The cell of a coordinate (cell_coord,
+// s2m_device.h) is a monotone function of v (every step in it is), and the map points were binned with the same
+// expression: a point with mn <= p < mx lies in a cell between cell(mn) and cell(mx), so no slack cells are needed.
+// Per x-row the cells of one brick are one contiguous run of the sorted array.
 // `sub` of `stride`: the lanes of a group share one box and take every stride-th point of each run -- a lane that
 // walks a run alone waits a full memory latency per point (measured: 75 us for 11 k boxes of ~100 points).
 template <class F>
@@ -101,21 +93,20 @@ __device__ __forceinline__ void for_points_in_box(const Grid &g, const float (&m
     if (g.m == 0) return;
     int c0[3], c1[3];
     const float o[3] = {g.ox, g.oy, g.oz};
-    const int nc[3] = {g.ncx, g.ncy, g.ncz};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        c0[k] = min(max((int)floorf((mn[k] - o[k]) * g.inv_c), 0), nc[k] - 1);
-        c1[k] = min(max((int)floorf((mx[k] - o[k]) * g.inv_c), 0), nc[k] - 1);
+    for (int k = 0; k < 3; ++k) {  // clipped to the bricks in use (an empty range when the box lies outside them)
+        c0[k] = max(cell_coord(mn[k], o[k], g.inv_c), g.blo[k] * 8);
+        c1[k] = min(cell_coord(mx[k], o[k], g.inv_c), g.bhi[k] * 8 + 7);
     }
     for (int zz = c0[2]; zz <= c1[2]; ++zz)
         for (int yy = c0[1]; yy <= c1[1]; ++yy) {
             const int rowbit = ((zz & 7) << 3) | (yy & 7);
-            const int64_t toprow = ((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx;
+            const uint32_t toprow = top_row(g, yy >> 3, zz >> 3);
             for (int bx = c0[0] >> 3; bx <= (c1[0] >> 3); ++bx) {
-                const uint4 te = g.top[toprow + bx];
+                const uint4 te = g.top[toprow | ((uint32_t)bx & g.tmx)];
                 const uint32_t mword = (rowbit & 32) ? te.w : te.z;
                 if (te.x == 0 || ((mword >> (rowbit & 31)) & 1u) == 0) continue;
-                const int l0 = max(c0[0], bx << 3) & 7, l1 = min(c1[0], (bx << 3) + 7) & 7;
+                const int l0 = max(c0[0], bx * 8) & 7, l1 = min(c1[0], bx * 8 + 7) & 7;
                 const uint32_t *tb = g.tab + (int64_t)(te.x - 1) * kBrickStride + (rowbit << 3);
                 const uint32_t e = tb[l1 + 1];
                 for (uint32_t i = tb[l0] + sub; i < e; i += stride) {
@@ -272,10 +263,9 @@ __global__ __launch_bounds__(256) void delete_boxes_kernel(Grid g, const float4 
         }
         if (hit) {
             alive_s[j] = 0;
-            // the brick that holds the point is touched (same cell arithmetic as the build)
-            const int cx = min(max((int)floorf((p.x - g.ox) * g.inv_c), 0), g.ncx - 1), cy = min(max((int)floorf((p.y - g.oy) * g.inv_c), 0), g.ncy - 1),
-                      cz = min(max((int)floorf((p.z - g.oz) * g.inv_c), 0), g.ncz - 1);
-            const uint32_t idp1 = g.top[((int64_t)(cz >> 3) * g.nby + (cy >> 3)) * g.nbx + (cx >> 3)].x;
+            // the brick that holds the point is touched (same cell arithmetic as the build; a map point lies inside the bounds)
+            const int cx = cell_coord(p.x, g.ox, g.inv_c), cy = cell_coord(p.y, g.oy, g.inv_c), cz = cell_coord(p.z, g.oz, g.inv_c);
+            const uint32_t idp1 = brick_in_bounds(g, cx >> 3, cy >> 3, cz >> 3) ? g.top[top_slot(g, cx >> 3, cy >> 3, cz >> 3)].x : 0u;
             if (idp1) bmark[idp1 - 1u] |= 1u;
         }
     }
@@ -345,16 +335,16 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
                                                             const int32_t *__restrict__ nn_idx,
                                                             const float4 *__restrict__ pts, int have_nn, double fs,
                                                             float4 *__restrict__ pw_out,
-                                                            unsigned long long *__restrict__ cls_out, VoxBox vb,
-                                                            uint32_t *__restrict__ vox_outside)
+                                                            unsigned long long *__restrict__ cls_out, int ax, int ay, int az,
+                                                            uint32_t *__restrict__ vox_ext)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && vb.bits == 0) *vox_outside = 1u;
-    if (i >= n) return;
-    float wx, wy, wz;
+    float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+    int cls = 0;
+    if (i < n) {
     body_to_world(pose, sx[i], sy[i], sz[i], wx, wy, wz);  // pointBodyToWorld, :591
     pw_out[i] = make_float4(wx, wy, wz, 0.0f);
-    int cls = 1;
+    cls = 1;
     int cnt = 0;
     if (have_nn) {
 #pragma unroll
@@ -382,10 +372,21 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
     }
     // both list flags in one word (low half: PointToAdd, high half: PointNoNeedDownsample): one scan gives both positions
     cls_out[i] = cls == 1 ? 1ull : (cls == 2 ? (1ull << 32) : 0ull);
-    if (cls == 1 && vb.bits > 0) {  // PointToAdd goes through the voxel rule: does its voxel lie in the box the short key covers?
-        uint64_t lin;
-        if (!voxel_in_box(wx, wy, wz, (float)fs, vb, lin)) *vox_outside = 1u;
     }
+    // PointToAdd goes through the voxel rule: the box of its voxels, as distances from the anchor voxel (the sensor's), sizes
+    // the direct-address table of the batch's winners (VoxBox) -- a box that follows the SCAN, whatever the map has grown to
+    uint32_t e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    if (cls == 1) {
+        const float ds = (float)fs;
+        const int64_t k[3] = {(int64_t)floorf(wx / ds), (int64_t)floorf(wy / ds), (int64_t)floorf(wz / ds)};  // (voxel_in_box's floor)
+        const int64_t a[3] = {ax, ay, az};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            e[q] = (uint32_t)min(max(a[q] - k[q], (int64_t)0), (int64_t)0x7fffffff);
+            e[3 + q] = (uint32_t)min(max(k[q] - a[q], (int64_t)0), (int64_t)0x7fffffff);
+        }
+    }
+    wave_max6_to(e, vox_ext);
 }
 
 // list A (low halves) and list B (high halves) of the packed flags / positions
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(256) void update_reset_kernel(int64_t bytes, uint8_
 {
     // a position holds a point unless its id says "hole" (the slack a merge leaves behind every brick)
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < kUpdWords) counters[threadIdx.x] = 0u;
     if (i + 16 <= bytes - 1) {
         uint32_t w[4];
 #pragma unroll
@@ -592,7 +593,7 @@ hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st)
 {
     const uint8_t *before = u.alive_s;
     S2M_TRY(grow(&u.alive_s, &u.alive_s_cap, g.m + 1));
-    if (!u.counters) S2M_TRY(hipMalloc((void **)&u.counters, 64));
+    if (!u.counters) S2M_TRY(hipMalloc((void **)&u.counters, kUpdWords * sizeof(uint32_t)));
     {
         // alive_s says which positions hold a point.  It is all ones on a fresh layout (build / merge: layout_gen moved) and
         // stays as the in-place updates left it otherwise (holes at the ends of rewritten bricks): then only the counters
@@ -606,26 +607,6 @@ hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st)
     u.stage_n = 0;
     u.deleted_reported = 0;
     return hipSuccess;
-}
-
-// the voxels (edge ds) that can hold a point of the grid's box, two to spare on every side; bits = 0 when that is no use
-VoxBox vox_box_of(const Grid &g, float ds)
-{
-    VoxBox b{};
-    const float o[3] = {g.ox, g.oy, g.oz};
-    const int nc[3] = {g.ncx, g.ncy, g.ncz};
-    double prod = 1.0;
-    for (int k = 0; k < 3; ++k) {
-        const double lo = std::floor((double)o[k] / ds) - 2.0, hi = std::floor(((double)o[k] + (double)nc[k] * g.c) / ds) + 2.0;
-        if (!(hi - lo < 2.0e6) || !(std::fabs(lo) < 1.0e9)) return VoxBox{};
-        b.lo[k] = (int)lo;
-        b.d[k] = (int)(hi - lo + 1.0);
-        prod *= (double)b.d[k];
-    }
-    if (prod >= 1.0e12) return VoxBox{};
-    b.bits = 1;
-    while (((uint64_t)1 << b.bits) < (uint64_t)prod) ++b.bits;
-    return b;
 }
 
 hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t n, bool downsample, float ds,
@@ -662,13 +643,16 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
     if (vox && vox->bits > 0 && vox->bits <= kVoxTableBits) {
         const int64_t slots = (int64_t)vox->d[0] * vox->d[1] * vox->d[2];
         if (u.vtab_cap < slots) {
+            // (the box follows the scan and breathes from frame to frame: with room to spare, up to the largest box a
+            // table is used for)
+            const int64_t want = std::min<int64_t>(slots + slots / 2, (int64_t)1 << kVoxTableBits);
             if (u.vtab) S2M_TRY(hipFree(u.vtab));
             u.vtab = nullptr;
             u.vtab_cap = 0;
-            S2M_TRY(hipMalloc((void **)&u.vtab, (size_t)slots * sizeof(unsigned long long)));
+            S2M_TRY(hipMalloc((void **)&u.vtab, (size_t)want * sizeof(unsigned long long)));
             note_allocation();
-            S2M_TRY(hipMemsetAsync(u.vtab, 0xff, (size_t)slots * sizeof(unsigned long long), st));
-            u.vtab_cap = slots;
+            S2M_TRY(hipMemsetAsync(u.vtab, 0xff, (size_t)want * sizeof(unsigned long long), st));
+            u.vtab_cap = want;
         }
         vtab = u.vtab;
     }
@@ -742,8 +726,8 @@ static hipError_t order_by_id(UpdateBuffers &u, const Grid &g, const uint8_t *al
     size_t b2 = u.tmp_bytes;
     S2M_TRY(rocprim::radix_sort_pairs(u.tmp, b2, u.flag32, u.ord_key, u.pos_old, u.ord_val, (size_t)g.m, 0, 32, st));
     if (!u.counters) {
-        S2M_TRY(hipMalloc((void **)&u.counters, 64));
-        S2M_TRY(hipMemsetAsync(u.counters, 0, 64, st));
+        S2M_TRY(hipMalloc((void **)&u.counters, kUpdWords * sizeof(uint32_t)));
+        S2M_TRY(hipMemsetAsync(u.counters, 0, kUpdWords * sizeof(uint32_t), st));
     }
     hipLaunchKernelGGL(live_count_kernel, dim3(1), dim3(1), 0, st, u.ord_key, g.m, u.counters + 14);
     const uint32_t *src[1] = {u.counters + 14};
@@ -808,13 +792,15 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
     }
     float4 *pw = u.cvt, *la = u.cvt + n, *lb = u.cvt + 2 * (int64_t)n;
     unsigned long long *fl = reinterpret_cast<unsigned long long *>(u.key), *ps = reinterpret_cast<unsigned long long *>(u.key2);
-    const VoxBox vb = vox ? vox_box_of(g, (float)fs) : VoxBox{};
-    if (!u.counters) {  // (word 15 is this call's flag: zero here, and zeroed again by every update_begin behind the read-back)
-        S2M_TRY(hipMalloc((void **)&u.counters, 64));
-        S2M_TRY(hipMemsetAsync(u.counters, 0, 64, st));
+    // the anchor of the voxel box: the sensor's voxel (any voxel would do: the kernel reports distances from it)
+    int anchor[3];
+    for (int k = 0; k < 3; ++k) anchor[k] = (int)std::fmin(std::fmax(std::floor(pose.t[k] / fs), -1.0e9), 1.0e9);
+    if (!u.counters) {  // (the box words are zero here, and zeroed again by every update_begin behind the read-back)
+        S2M_TRY(hipMalloc((void **)&u.counters, kUpdWords * sizeof(uint32_t)));
+        S2M_TRY(hipMemsetAsync(u.counters, 0, kUpdWords * sizeof(uint32_t), st));
     }
     hipLaunchKernelGGL(incr_classify_kernel, dim3(nblk(n)), dim3(256), 0, st, pose, sx, sy, sz, n, nn_idx, g.pts,
-                       have_nn ? 1 : 0, fs, pw, fl, vb, u.counters + 15);
+                       have_nn ? 1 : 0, fs, pw, fl, anchor[0], anchor[1], anchor[2], u.counters + kUpdVoxWord);
     {
         size_t bytes = 0;
         S2M_TRY(rocprim::exclusive_scan(nullptr, bytes, fl, ps, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), st));
@@ -825,16 +811,34 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
     hipLaunchKernelGGL(scatter2_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fl, ps, (int64_t)n, la, lb);
     {   // both list lengths with one hand-back: last position + last flag, as four 32-bit words
         const uint32_t *p32 = reinterpret_cast<const uint32_t *>(ps + (n - 1)), *f32 = reinterpret_cast<const uint32_t *>(fl + (n - 1));
-        const uint32_t *src[5] = {p32, f32, p32 + 1, f32 + 1, u.counters + 15};
-        uint32_t h[5] = {0, 0, 0, 0, 1};
-        S2M_TRY(mail_post(u.mail, src, 5, st));
+        const uint32_t *v = u.counters + kUpdVoxWord;
+        const uint32_t *src[10] = {p32, f32, p32 + 1, f32 + 1, v, v + 1, v + 2, v + 3, v + 4, v + 5};
+        uint32_t h[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        S2M_TRY(mail_post(u.mail, src, 10, st));
         // the update this classification feeds begins while the counts travel (its reset kernel needs none of them and
-        // zeroes word 15 behind the read above, in stream order)
+        // zeroes the box words behind the read above, in stream order)
         if (begin_update) S2M_TRY(update_begin(u, g, st));
-        S2M_TRY(mail_collect(u.mail, 5, h, st));
+        else S2M_TRY(hipMemsetAsync(u.counters + kUpdVoxWord, 0, 6 * sizeof(uint32_t), st));
+        S2M_TRY(mail_collect(u.mail, 10, h, st));
         *n_add = (int64_t)h[0] + h[1];
         *n_no_down = (int64_t)h[2] + h[3];
-        if (vox && h[4] == 0u) *vox = vb;   // every PointToAdd lies in the box: the voxel sort can use the short key
+        if (vox && *n_add > 0) {  // the box of the PointToAdd voxels: every one of them lies inside by construction
+            VoxBox b{};
+            double prod = 1.0;
+            bool ok = true;
+            for (int k = 0; k < 3; ++k) {
+                const int64_t lo = (int64_t)anchor[k] - (int64_t)h[4 + k], d = (int64_t)h[4 + k] + (int64_t)h[7 + k] + 1;
+                ok = ok && d < 2000000 && lo > -1000000000ll && lo < 1000000000ll;
+                b.lo[k] = (int)lo;
+                b.d[k] = (int)d;
+                prod *= (double)d;
+            }
+            if (ok && prod < 1.0e12) {
+                b.bits = 1;
+                while (((uint64_t)1 << b.bits) < (uint64_t)prod) ++b.bits;
+                *vox = b;
+            }
+        }
     }
     *to_add = la;
     *no_down = lb;

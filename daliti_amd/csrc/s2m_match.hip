@@ -101,13 +101,14 @@ __device__ __forceinline__ void match_rows_body(const MatchArgs &a, uint2 *__res
     const int j = tid % G;
     if (qi >= a.n) return;  // group-uniform
     const Query q = make_query(g, a.pose, a.sx[qi], a.sy[qi], a.sz[qi]);
-    // x extent of the neighbourhood inside the grid; segment A lies in brick bA, segment B (if any) in bA + 1
-    const int x_lo = max(q.cx - 1, 0), x_hi = min(q.cx + 1, g.ncx - 1);
+    // x extent of the neighbourhood inside the bricks in use (signed cell coordinates: >> floors, & 7 is the cell inside
+    // its brick); segment A lies in brick bA, segment B (if any) in bA + 1
+    const int x_lo = max(q.cx - 1, g.blo[0] * 8), x_hi = min(q.cx + 1, g.bhi[0] * 8 + 7);
     const bool xok = x_lo <= x_hi;
     const int bA = x_lo >> 3, bB = x_hi >> 3;
     const bool split = xok && bB != bA;
-    const int ax1 = split ? (bA << 3) + 7 : x_hi;  // last cell of segment A
-    const int bx0 = bB << 3;                         // first cell of segment B
+    const int ax1 = split ? bA * 8 + 7 : x_hi;  // last cell of segment A
+    const int bx0 = bB * 8;                      // first cell of segment B
     // phase 1: brick ids of the nine rows (two per row where the row is split).  The rows cy-1..cy+1 x cz-1..cz+1 touch at
     // most 2 x 2 bricks in (y, z): four top entries per x-brick are loaded and the nine rows select among them (nine loads
     // per x-brick before: at saturation the kernel is bound by vector-memory instructions, scripts/ta_lines.hip).  The row
@@ -122,21 +123,21 @@ __device__ __forceinline__ void match_rows_body(const MatchArgs &a, uint2 *__res
 #pragma unroll
             for (int yi = 0; yi < 2; ++yi) {
                 const int yb = yi ? yb1 : yb0, zb = zi ? zb1 : zb0;
-                const bool okb = xok && yb >= 0 && yb < g.nby && zb >= 0 && zb < g.nbz;
-                const int64_t toprow = ((int64_t)zb * g.nby + yb) * g.nbx;
-                if (okb) tA[zi][yi] = g.top[toprow + bA].x;
-                if (okb && split) tB[zi][yi] = g.top[toprow + bB].x;
+                const bool okb = xok && yb >= g.blo[1] && yb <= g.bhi[1] && zb >= g.blo[2] && zb <= g.bhi[2];
+                const uint32_t toprow = top_row(g, yb, zb);
+                if (okb) tA[zi][yi] = g.top[toprow | ((uint32_t)bA & g.tmx)].x;
+                if (okb && split) tB[zi][yi] = g.top[toprow | ((uint32_t)bB & g.tmx)].x;
             }
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             const int yy = q.cy + (r % 3) - 1, zz = q.cz + (r / 3) - 1;
-            const bool ok = xok && yy >= 0 && yy < g.ncy && zz >= 0 && zz < g.ncz;
+            // (a row outside the bricks in use selects one of the zeros above)
             rowbit[r] = ((zz & 7) << 3) | (yy & 7);
             const bool ysel = (yy >> 3) != yb0, zsel = (zz >> 3) != zb0;
             const uint32_t a = zsel ? (ysel ? tA[1][1] : tA[1][0]) : (ysel ? tA[0][1] : tA[0][0]);
             const uint32_t b = zsel ? (ysel ? tB[1][1] : tB[1][0]) : (ysel ? tB[0][1] : tB[0][0]);
-            idA[r] = ok ? a : 0u;
-            idB[r] = (ok && split) ? b : 0u;
+            idA[r] = a;
+            idB[r] = b;
         }
     }
     // phase 2: the home row's prefix words (four consecutive words cover its three cells); the other rows' words are

@@ -93,7 +93,6 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
         const uint4 r0 = rp[0], r1 = rp[1];
         const int qi = (int)r0.w;
         const Query q = query_at(g, __uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
-        const float fxq = (float)q.cx + q.frx;  // query x in cell units
         bool have_tau = r1.y == (uint32_t)kK;
         float tau = have_tau ? __uint_as_float(r1.x) : 0.0f;  // squared
         u64 t[kK], best[kK];
@@ -192,26 +191,27 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
                 uint32_t nid[2] = {0u, 0u};
                 int nxa[2] = {0, 0}, ncl[2] = {0, 0}, nrow = 0;
                 const int yy = q.cy + ndy, zz = q.cz + ndz;
-                if (lane < 49 && yy >= 0 && yy < g.ncy && zz >= 0 && zz < g.ncz) {
+                if (lane < 49 && (yy >> 3) >= g.blo[1] && (yy >> 3) <= g.bhi[1] && (zz >> 3) >= g.blo[2] && (zz >> 3) <= g.bhi[2]) {
                     const float gy = ndy > 0 ? (float)ndy - q.fry : (ndy < 0 ? q.fry - (float)(ndy + 1) : 0.0f);
                     const float gz = ndz > 0 ? (float)ndz - q.frz : (ndz < 0 ? q.frz - (float)(ndz + 1) : 0.0f);
                     const float ay = fmaxf(gy - g.slop, 0.0f), az = fmaxf(gz - g.slop, 0.0f);
                     const float b2 = (ay * ay + az * az) * (g.c * g.c) * 0.99999f;
                     if (b2 <= r2) {
                         const float reach = sqrtf(fmaxf(r2 - b2, 0.0f)) * g.inv_c * 1.00001f + g.slop;
-                        const int xa = max((int)floorf(fxq - reach), 0), xb = min((int)floorf(fxq + reach), g.ncx - 1);
+                        // (relative to the home cell: exact however large the cell coordinates are)
+                        const int xa = max(q.cx + (int)floorf(q.frx - reach), g.blo[0] * 8), xb = min(q.cx + (int)floorf(q.frx + reach), g.bhi[0] * 8 + 7);
                         nrow = ((zz & 7) << 3) | (yy & 7);
-                        const int64_t toprow = ((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx;
+                        const uint32_t toprow = top_row(g, yy >> 3, zz >> 3);
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
                             const int bx = (xa >> 3) + k;
                             if (xa > xb || bx > (xb >> 3)) continue;
-                            const uint4 te = g.top[toprow + bx];
+                            const uint4 te = g.top[toprow | ((uint32_t)bx & g.tmx)];
                             const uint32_t mword = (nrow & 32) ? te.w : te.z;
                             if (te.x == 0 || ((mword >> (nrow & 31)) & 1u) == 0) continue;
                             nid[k] = te.x;
-                            nxa[k] = max(xa, bx << 3);
-                            ncl[k] = min(xb, (bx << 3) + 7) - nxa[k] + 1;
+                            nxa[k] = max(xa, bx * 8);
+                            ncl[k] = min(xb, bx * 8 + 7) - nxa[k] + 1;
                         }
                     }
                 }
@@ -219,10 +219,10 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
                 for (int k = 0; k < 2; ++k) append_cells(nid[k], nrow, nxa[k], ncl[k]);  // <= 2 x 49 x 7 cells
             } else {
             // FAR: the neighbourhood clipped to the grid (empty when the point lies further outside than the radius)
-            const int flx = max(hbx - NB, 0), fly = max(hby - NB, 0), flz = max(hbz - NB, 0);
-            const int fsx = FAR ? max(min(hbx + NB, g.nbx - 1) - flx + 1, 0) : 0;
-            const int fsy = FAR ? max(min(hby + NB, g.nby - 1) - fly + 1, 0) : 0;
-            const int fsz = FAR ? max(min(hbz + NB, g.nbz - 1) - flz + 1, 0) : 0;
+            const int flx = max(hbx - NB, g.blo[0]), fly = max(hby - NB, g.blo[1]), flz = max(hbz - NB, g.blo[2]);
+            const int fsx = FAR ? max(min(hbx + NB, g.bhi[0]) - flx + 1, 0) : 0;
+            const int fsy = FAR ? max(min(hby + NB, g.bhi[1]) - fly + 1, 0) : 0;
+            const int fsz = FAR ? max(min(hbz + NB, g.bhi[2]) - flz + 1, 0) : 0;
             const int nbr = FAR ? (int)min((long long)fsx * fsy * fsz, 0x7fffffc0ll) : nbricks;
             for (int bbase = 0; bbase < nbr; bbase += 64) {
                 // 1. top entries of up to 64 bricks, one per lane
@@ -240,8 +240,8 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
                         by = hby + ((b / bside) % bside) - NB;
                         bz = hbz + (b / (bside * bside)) - NB;
                     }
-                    if (bx >= 0 && bx < g.nbx && by >= 0 && by < g.nby && bz >= 0 && bz < g.nbz) {
-                        const uint4 te = g.top[((int64_t)bz * g.nby + by) * g.nbx + bx];
+                    if (brick_in_bounds(g, bx, by, bz)) {
+                        const uint4 te = g.top[top_slot(g, bx, by, bz)];
                         my_id = te.x;
                         my_mask = te.x ? ((uint64_t)te.w << 32 | te.z) : 0ull;
                     }
@@ -276,7 +276,7 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
                         if (p < total) {
                             const uint64_t om = ((uint64_t)mhi << 32) | mlo;
                             rowbit = kth_set_bit(om, p - oex);
-                            const int yy = (oby << 3) + (rowbit & 7), zz = (obz << 3) + (rowbit >> 3);
+                            const int yy = oby * 8 + (rowbit & 7), zz = obz * 8 + (rowbit >> 3);
                             // lower bound of the (y,z) distance from the query to this row, in cells
                             const int dy = yy - q.cy, dz = zz - q.cz;
                             const float gy = dy > 0 ? (float)dy - q.fry : (dy < 0 ? q.fry - (float)(dy + 1) : 0.0f);
@@ -286,8 +286,8 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
                             if (b2 <= r2) {
                                 // x cells the radius can reach in this row: |x - qx| <= sqrt(r2 - b2)
                                 const float reach = sqrtf(fmaxf(r2 - b2, 0.0f)) * g.inv_c * 1.00001f + g.slop;
-                                xa = max((int)floorf(fxq - reach), obx << 3);
-                                const int xb = min((int)floorf(fxq + reach), (obx << 3) + 7);
+                                xa = max(q.cx + (int)floorf(q.frx - reach), obx * 8);
+                                const int xb = min(q.cx + (int)floorf(q.frx + reach), obx * 8 + 7);
                                 ncell = max(xb - xa + 1, 0);
                             }
                         }
@@ -424,7 +424,7 @@ __device__ __forceinline__ void match_hard32_body(const MatchArgs &a, uint2 *__r
     // state of the half's current point
     uint32_t qi = 0, slot = 0, found = 0;
     Query q = {};
-    float fxq = 0.0f, tau = 0.0f, band = 0.0f;
+    float tau = 0.0f, band = 0.0f;
     bool have_tau = false;
     int hbx = 0, hby = 0, hbz = 0;
     u64 t[kK], best[kK];
@@ -436,7 +436,6 @@ __device__ __forceinline__ void match_hard32_body(const MatchArgs &a, uint2 *__r
             const uint4 r0 = rp[0], r1 = rp[1];
             qi = r0.w; found = r1.y; slot = r1.z;
             q = query_at(g, __uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
-            fxq = (float)q.cx + q.frx;
             have_tau = found == (uint32_t)kK;
             tau = have_tau ? __uint_as_float(r1.x) : 0.0f;
             band = (found == 0u ? S2M_HARD_BAND_EMPTY : S2M_HARD_BAND) * g.c;   // as in match_hard_body
@@ -512,26 +511,27 @@ __device__ __forceinline__ void match_hard32_body(const MatchArgs &a, uint2 *__r
                 uint32_t nid[2] = {0u, 0u};
                 int nxa[2] = {0, 0}, ncl[2] = {0, 0}, nrow = 0;
                 const int yy = q.cy + ndy, zz = q.cz + ndz;
-                if (rl < 49 && yy >= 0 && yy < g.ncy && zz >= 0 && zz < g.ncz) {
+                if (rl < 49 && (yy >> 3) >= g.blo[1] && (yy >> 3) <= g.bhi[1] && (zz >> 3) >= g.blo[2] && (zz >> 3) <= g.bhi[2]) {
                     const float gy = ndy > 0 ? (float)ndy - q.fry : (ndy < 0 ? q.fry - (float)(ndy + 1) : 0.0f);
                     const float gz = ndz > 0 ? (float)ndz - q.frz : (ndz < 0 ? q.frz - (float)(ndz + 1) : 0.0f);
                     const float ay = fmaxf(gy - g.slop, 0.0f), az = fmaxf(gz - g.slop, 0.0f);
                     const float b2 = (ay * ay + az * az) * (g.c * g.c) * 0.99999f;
                     if (b2 <= r2) {
                         const float reach = sqrtf(fmaxf(r2 - b2, 0.0f)) * g.inv_c * 1.00001f + g.slop;
-                        const int xa = max((int)floorf(fxq - reach), 0), xb = min((int)floorf(fxq + reach), g.ncx - 1);
+                        // (relative to the home cell: exact however large the cell coordinates are)
+                        const int xa = max(q.cx + (int)floorf(q.frx - reach), g.blo[0] * 8), xb = min(q.cx + (int)floorf(q.frx + reach), g.bhi[0] * 8 + 7);
                         nrow = ((zz & 7) << 3) | (yy & 7);
-                        const int64_t toprow = ((int64_t)(zz >> 3) * g.nby + (yy >> 3)) * g.nbx;
+                        const uint32_t toprow = top_row(g, yy >> 3, zz >> 3);
 #pragma unroll
                         for (int k = 0; k < 2; ++k) {
                             const int bx = (xa >> 3) + k;
                             if (xa > xb || bx > (xb >> 3)) continue;
-                            const uint4 te = g.top[toprow + bx];
+                            const uint4 te = g.top[toprow | ((uint32_t)bx & g.tmx)];
                             const uint32_t mword = (nrow & 32) ? te.w : te.z;
                             if (te.x == 0 || ((mword >> (nrow & 31)) & 1u) == 0) continue;
                             nid[k] = te.x;
-                            nxa[k] = max(xa, bx << 3);
-                            ncl[k] = min(xb, (bx << 3) + 7) - nxa[k] + 1;
+                            nxa[k] = max(xa, bx * 8);
+                            ncl[k] = min(xb, bx * 8 + 7) - nxa[k] + 1;
                         }
                     }
                 }
@@ -555,8 +555,8 @@ __device__ __forceinline__ void match_hard32_body(const MatchArgs &a, uint2 *__r
                         by = hby + ((b / bside) % bside) - NB;
                         bz = hbz + (b / (bside * bside)) - NB;
                     }
-                    if (bx >= 0 && bx < g.nbx && by >= 0 && by < g.nby && bz >= 0 && bz < g.nbz) {
-                        const uint4 te = g.top[((int64_t)bz * g.nby + by) * g.nbx + bx];
+                    if (brick_in_bounds(g, bx, by, bz)) {
+                        const uint4 te = g.top[top_slot(g, bx, by, bz)];
                         my_id = te.x;
                         my_mask = te.x ? ((uint64_t)te.w << 32 | te.z) : 0ull;
                     }
@@ -585,7 +585,7 @@ __device__ __forceinline__ void match_hard32_body(const MatchArgs &a, uint2 *__r
                         if (p < total) {
                             const uint64_t om = ((uint64_t)mhi << 32) | mlo;
                             rowbit = kth_set_bit(om, p - oex);
-                            const int yy = (oby << 3) + (rowbit & 7), zz = (obz << 3) + (rowbit >> 3);
+                            const int yy = oby * 8 + (rowbit & 7), zz = obz * 8 + (rowbit >> 3);
                             const int dy = yy - q.cy, dz = zz - q.cz;
                             const float gy = dy > 0 ? (float)dy - q.fry : (dy < 0 ? q.fry - (float)(dy + 1) : 0.0f);
                             const float gz = dz > 0 ? (float)dz - q.frz : (dz < 0 ? q.frz - (float)(dz + 1) : 0.0f);
@@ -593,8 +593,8 @@ __device__ __forceinline__ void match_hard32_body(const MatchArgs &a, uint2 *__r
                             const float b2 = (ay * ay + az * az) * (g.c * g.c) * 0.99999f;
                             if (b2 <= r2) {
                                 const float reach = sqrtf(fmaxf(r2 - b2, 0.0f)) * g.inv_c * 1.00001f + g.slop;
-                                xa = max((int)floorf(fxq - reach), obx << 3);
-                                const int xb = min((int)floorf(fxq + reach), (obx << 3) + 7);
+                                xa = max(q.cx + (int)floorf(q.frx - reach), obx * 8);
+                                const int xb = min(q.cx + (int)floorf(q.frx + reach), obx * 8 + 7);
                                 ncell = max(xb - xa + 1, 0);
                             }
                         }
@@ -705,7 +705,9 @@ __global__ __launch_bounds__(256) void collect_short_kernel(MatchArgs a)
         // map point has been seen (a query may lie far outside the grid).  A non-finite query can have no neighbours:
         // it is left as it is.
         const Grid &g = a.grid;
-        const float cx = g.ox + 0.5f * (float)g.ncx * g.c, cy = g.oy + 0.5f * (float)g.ncy * g.c, cz = g.oz + 0.5f * (float)g.ncz * g.c;
+        // (centre of the box of bricks in use)
+        const float cx = g.ox + 4.0f * (float)(g.blo[0] + g.bhi[0] + 1) * g.c, cy = g.oy + 4.0f * (float)(g.blo[1] + g.bhi[1] + 1) * g.c,
+                    cz = g.oz + 4.0f * (float)(g.blo[2] + g.bhi[2] + 1) * g.c;
         const float d2c = ((rec.wx - cx) * (rec.wx - cx) + (rec.wy - cy) * (rec.wy - cy)) + (rec.wz - cz) * (rec.wz - cz);
         want = d2c < 3.0e38f;  // false for NaN and +inf
         if (want) far_bits = __float_as_uint(d2c);  // >= 0: the bit pattern orders like the value

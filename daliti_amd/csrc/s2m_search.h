@@ -234,15 +234,17 @@ __device__ __forceinline__ Query query_at(const Grid &g, float wx, float wy, flo
 {
     Query q;
     q.wx = wx; q.wy = wy; q.wz = wz;
-    const float fx = (q.wx - g.ox) * g.inv_c, fy = (q.wy - g.oy) * g.inv_c, fz = (q.wz - g.oz) * g.inv_c;
-    const float flx = floorf(fx), fly = floorf(fy), flz = floorf(fz);
+    // cell and in-cell position in double from the float operands (cell_pos, s2m_device.h): the map was binned with this
+    // expression, and the fraction's only error is its rounding to float (6e-8 of a cell), wherever the origin is
+    const double fx = cell_pos(q.wx, g.ox, g.inv_c), fy = cell_pos(q.wy, g.oy, g.inv_c), fz = cell_pos(q.wz, g.oz, g.inv_c);
+    const double flx = floor(fx), fly = floor(fy), flz = floor(fz);
     // clamp far-away queries so the int conversion is defined; the bound stays valid because the
-    // clamped cells lie outside the grid and hold no points
-    const float lim = 1.0e9f;
-    q.cx = (int)fminf(fmaxf(flx, -lim), lim);
-    q.cy = (int)fminf(fmaxf(fly, -lim), lim);
-    q.cz = (int)fminf(fmaxf(flz, -lim), lim);
-    q.frx = fx - flx; q.fry = fy - fly; q.frz = fz - flz;
+    // clamped cells lie outside the bricks in use and hold no points
+    const double lim = 1.0e9;
+    q.cx = (int)fmin(fmax(flx, -lim), lim);
+    q.cy = (int)fmin(fmax(fly, -lim), lim);
+    q.cz = (int)fmin(fmax(flz, -lim), lim);
+    q.frx = (float)(fx - flx); q.fry = (float)(fy - fly); q.frz = (float)(fz - flz);
     float f = fminf(fminf(q.frx, 1.0f - q.frx), fminf(q.fry, 1.0f - q.fry));
     q.fmin = fminf(f, fminf(q.frz, 1.0f - q.frz));
     return q;

@@ -202,9 +202,9 @@ class Engine:
 
     def map_update_stats(self):
         """Running counts: updates merged / rebuilt / re-gridded, device buffer (re)allocations (process-wide)."""
-        st = (C.c_int64 * 4)()
+        st = (C.c_int64 * 6)()
         self._ck(self.lib.s2m_map_update_stats(self.h, st))
-        return dict(merged=st[0], rebuilt=st[1], regridded=st[2], allocations=st[3])
+        return dict(merged=st[0], rebuilt=st[1], regridded=st[2], allocations=st[3], relaid=st[4], big_bricks=st[5])
 
     def map_inplace_updates(self):
         """Updates applied in place (only the touched bricks rewritten): s2m_map_inplace_updates."""
@@ -222,10 +222,10 @@ class Engine:
         return out[:m.value]
 
     def map_grid(self):
-        """Cells per axis of the current grid."""
-        c = (C.c_int32 * 3)()
+        """(lo xyz, hi xyz) of the box of bricks the map may occupy (conservative; hi < lo: empty)."""
+        c = (C.c_int32 * 6)()
         self._ck(self.lib.s2m_map_grid(self.h, c))
-        return tuple(c)
+        return tuple(c[:3]), tuple(c[3:])
 
     def map_rank(self):
         """rank[i] = sorted position of caller index i: what the oracle takes as the tie order of equal distances."""

@@ -35,7 +35,7 @@ extern "C" {
  * s2m_scan_prefetch_raw, s2m_scan_prepare_raw, s2m_map_inplace_updates; block[159] carries the count of neighbour lists
  * short of the gate; s2m_map_get_order may report positions that hold no point (0xffffffff).  A caller built against an
  * older version must be recompiled. */
-#define S2M_ABI_VERSION 3
+#define S2M_ABI_VERSION 4
 #define S2M_K 5            /* NUM_MATCH_POINTS, laserMapping.cpp:77 */
 #define S2M_DIM 24         /* DIM_OF_STATES, common_lib.h:23 */
 #define S2M_STATE_DOUBLES 36
@@ -157,30 +157,37 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
 int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity_points, int64_t *m);
 /* How the last map_add / map_delete_boxes / fov_segment / map_incremental produced the new map (design, not
  * reference): *merged = 1 when the update was merged into the sorted arrays of the current grid, 0 when the grid
- * was rebuilt (a new point outside the grid and its margin, a density drift, an empty map). */
+ * was rebuilt (a density drift, an empty map; see s2m_map_update_stats). */
 int s2m_map_last_update(const s2m_engine *e, int32_t *merged);
 /* Running counts for latency diagnosis (design, not reference; the reference hides the same events behind ikd-Tree's
  * rebuild thread, ikd_Tree.cpp:192-203, 229-367): stats[0] = updates merged into the grid, stats[1] = updates that
- * rebuilt it, stats[2] = rebuilds that also chose a new cell size (density drift), stats[3] = device buffer
- * (re)allocations made by map builds and updates so far (process-wide). */
-int s2m_map_update_stats(const s2m_engine *e, int64_t stats[4]);
+ * rebuilt it (an empty map, ids or buffers exhausted, a point beyond the representable range of cells, a density drift --
+ * never growth as such), stats[2] = rebuilds that also chose a new cell size (density drift), stats[3] = device buffer
+ * (re)allocations made by map builds and updates so far (process-wide), stats[4] = times the top-level array was re-laid
+ * because the box of bricks in use had outgrown or left its window (a few thousand entries; no point moves), stats[5] =
+ * bricks rewritten in place through the large staging form (more than 2 048 points). */
+int s2m_map_update_stats(const s2m_engine *e, int64_t stats[6]);
 /* How many of the merged updates (s2m_map_update_stats, stats[0]) were applied IN PLACE: only the bricks the update touched
  * were rewritten where they stand -- possible when each of them still fits the stretch of the point array it owns and no new
  * point opens a brick; cost proportional to the update, not to the map (ikd-Tree inserts per point in O(log M),
  * ikd_Tree.cpp:477-573).  Every other update re-lays the whole map out (merge) or rebuilds the grid.  (Design, not reference.) */
 int s2m_map_inplace_updates(const s2m_engine *e, int64_t *n);
 /* The engine's internal point order (design, not reference): order[j] = the caller's index of the point at sorted
- * position j.  Positions are ordered by (brick of 8x8x8 cells, cell within the brick, caller index), the cell of a
- * coordinate v being floor((v - origin) * (1 / cell_size)) in float arithmetic with the origin and cell size of
- * s2m_map_info -- after a full build, a merged update and an in-place update alike.  *m = the extent of the position
+ * position j.  Positions are ordered by (brick of 8x8x8 cells, cell within the brick, caller index).  The cell of a
+ * coordinate v is floor(((double)v - (double)origin) * (double)(1.0f / cell_size)) -- float operands, double arithmetic --
+ * with the origin and cell size of s2m_map_info, a SIGNED integer per axis: the origin is fixed by the first build of a map
+ * and kept by every update, and the map grows around it in any direction.  A brick's coordinates are (cell >> 3) per axis
+ * (arithmetic shift), bricks are ordered by (z, y, x) lexicographically on these signed coordinates, the cells inside a brick
+ * by (cell & 7) in (z, y, x) likewise -- an order that does not depend on the box the map occupies, the same after a full
+ * build, a merged update and an in-place update.  *m = the extent of the position
  * range; after in-place updates it may exceed s2m_map_size, and order[j] = 0xffffffff marks a position that holds no point
  * (a hole at the end of a rewritten brick).  Candidates tied at exactly the same float squared distance are ranked by
  * this position (tests hand it to the oracle as the tie order). */
 int s2m_map_get_order(s2m_engine *e, uint32_t *order, int64_t capacity_points, int64_t *m);
-/* cells[3] = cells per axis of the current grid (multiples of 8: a brick is 8x8x8 cells; bricks are numbered
- * x fastest, then y, then z, and so are the cells inside a brick); a coordinate's cell index is clamped to
- * [0, cells - 1].  Together with s2m_map_info this determines the order of s2m_map_get_order. */
-int s2m_map_grid(const s2m_engine *e, int32_t cells[3]);
+/* bricks[6] = the box of bricks the map may occupy at the moment, in brick coordinates (lo xyz, hi xyz, inclusive; hi < lo:
+ * empty map).  Informative: it is conservative (it grows with the map and is tightened only when it outgrows the window of
+ * the top-level array), and the order of s2m_map_get_order does not depend on it. */
+int s2m_map_grid(const s2m_engine *e, int32_t bricks[6]);
 
 /* The down-sampled body-frame scan feats_down (laserMapping.cpp:775-778).  Resets the per-scan
  * state: point_selected_surf := true (:812), Nearest_Points cleared (:810).  Coordinates must be finite -- the
@@ -226,8 +233,10 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride_floats, int
  * s2m_scan_set_from_raw with the SAME pointer, stride and n uses that copy instead of copying itself (any other call
  * ignores it).  With time_off_a >= 0 (the time fields of s2m_undistort) the time order of the records
  * (IMU_Processing.hpp:215-216: it needs no pose) is computed behind the copy and reused by the call that consumes the
- * records; time_off_a < 0: the copy only.  The caller keeps the buffer alive and unchanged until then.  (Design, not
- * reference.) */
+ * records; time_off_a < 0: the copy only.  The caller keeps the buffer alive and unchanged until then.  A copy that is
+ * not consumed is dropped by the next s2m_scan_set* call of any kind (a node that recycles its host buffers could
+ * otherwise present new records under the address of a sweep that was announced and then skipped); points == NULL
+ * cancels explicitly.  (Design, not reference.) */
 int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride_floats, int64_t n, int32_t time_off_a,
                           int32_t time_off_b);
 /* The whole front half of the NEXT frame while the map update of the current one runs: s2m_scan_set_from_raw's work (copy,

@@ -161,23 +161,21 @@ def knn5_brute(map_xyz, q, rank=None):
     return idx, d2, cnt
 
 
-def grid_rank(map_xyz, cell, origin, cells):
+def grid_rank(map_xyz, cell, origin):
     """The GPU engine's documented point order, computed independently of it (include/daliti_s2m.h,
     s2m_map_get_order): points sorted by (brick of 8x8x8 cells, cell within the brick, caller index), the cell of a
-    coordinate v being floor((v - origin) * (1 / cell)) in float arithmetic, clamped to the grid; bricks and the
-    cells inside a brick are numbered x fastest, then y, then z.  Returns rank[i] = sorted position of point i."""
+    coordinate v being floor(((double)v - (double)origin) * (double)(1.0f / cell)) -- float operands, double arithmetic --
+    as a signed integer; a brick is (cell >> 3) per axis, bricks are ordered by (z, y, x) on the signed coordinates and so
+    are the cells inside a brick: no bounding box enters.  Returns rank[i] = sorted position of point i."""
     p = np.ascontiguousarray(map_xyz, np.float32).reshape(-1, 3)
-    inv_c = np.float32(1.0) / np.float32(cell)
-    key = np.zeros(len(p), np.uint64)
+    inv_c = np.float64(np.float32(1.0) / np.float32(cell))
     c = []
     for k in range(3):
-        v = np.floor((p[:, k] - np.float32(origin[k])) * inv_c)
-        c.append(np.clip(v, 0, cells[k] - 1).astype(np.int64))
-    nbx, nby = cells[0] // 8, cells[1] // 8
-    brick = ((c[2] >> 3) * nby + (c[1] >> 3)) * nbx + (c[0] >> 3)
+        v = np.floor((p[:, k].astype(np.float64) - np.float64(np.float32(origin[k]))) * inv_c)
+        c.append(v.astype(np.int64))
+    # a sort on the signed triple (bz, by, bx, local): lexsort takes the LAST key as the primary one
     local = (((c[2] & 7) << 3) | (c[1] & 7)) << 3 | (c[0] & 7)
-    key = (brick << 9) | local
-    order = np.argsort(key, kind="stable")
+    order = np.lexsort((np.arange(len(p)), local, c[0] >> 3, c[1] >> 3, c[2] >> 3))
     rank = np.empty(len(p), np.uint32)
     rank[order] = np.arange(len(p), dtype=np.uint32)
     return rank

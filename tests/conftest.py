@@ -36,7 +36,7 @@ def ranked_tree(oracle, eng, map_xyz):
     caller index).  The order is computed here from the grid parameters alone (oracle.grid_rank) and must equal what
     the engine reports -- that pins the documented order, not only consistency between the two sides."""
     info = eng.map_info()
-    rank = oracle.grid_rank(map_xyz, info["cell"], info["origin"], eng.map_grid())
+    rank = oracle.grid_rank(map_xyz, info["cell"], info["origin"])
     assert np.array_equal(rank, eng.map_rank()), "the engine's point order differs from the documented one"
     return oracle.KdTree(map_xyz).set_rank(rank)
 

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_defaults(lib):
     from daliti_amd.engine import Config
-    assert lib.s2m_abi_version() == 3
+    assert lib.s2m_abi_version() == 4
     cfg = Config()
     assert lib.s2m_config_default(C.byref(cfg)) == 0
     # reference constants (laserMapping.cpp:76-77, 853, 863, 870, 889, 1040; feat.yaml)

@@ -299,7 +299,7 @@ def test_merge_update_equals_rebuild(oracle, small_scene, monkeypatch):
              ("del", np.float32([[-10, -10, -1, -1.0, 10, 20]]), None),
              ("add", small_scene["map"][16000:18000] + rs.normal(0, 0.2, (2000, 3)).astype(np.float32), True),
              ("del", np.float32([[2.5, -10, -1, 10, 10, 0.05], [0, 0, 0, 1, 1, 1]]), None),
-             # far outside the grid (margin included): this one cannot be merged on either engine
+             # far outside the bricks in use: the map grows there like anywhere else (the top array is re-laid, nothing rebuilt)
              ("add", np.float32([[500.0, 400.0, 30.0], [500.2, 400.1, 30.0]]), False),
              ("add", small_scene["map"][18000:19000], True)]
     x = small_scene["x_prop"]
@@ -333,8 +333,8 @@ def test_merge_update_equals_rebuild(oracle, small_scene, monkeypatch):
         results[mode] = (merged, maps, nns)
         e.close()
     mg, rb = results["merge"], results["rebuild"]
-    # every update merges except the one with points far outside the grid
-    assert mg[0] == [True, True, True, True, True, False, True], mg[0]
+    # every update merges, the one with points far outside the box of the others included
+    assert all(mg[0]), mg[0]
     assert not any(rb[0])
     for k in range(len(steps)):
         assert mg[1][k].shape == rb[1][k].shape and (bits(mg[1][k]) == bits(rb[1][k])).all(), k   # same ORDER too
@@ -349,8 +349,8 @@ def test_merge_update_equals_rebuild(oracle, small_scene, monkeypatch):
 
 @pytest.mark.gpu
 def test_merge_update_random_sequence(oracle, monkeypatch):
-    """Twenty random updates (downsampled adds, plain adds, box deletes, points beyond the grid) on a small map:
-    merged and rebuilt maps agree in order after every step, and with the oracle as sets."""
+    """Twenty random updates (downsampled adds, plain adds, box deletes, points far beyond the bricks in use) on a small
+    map: merged and rebuilt maps agree in order after every step, and with the oracle as sets."""
     from daliti_amd import Engine
     rs = np.random.RandomState(23)
     base = rs.uniform(-6, 6, (6000, 3)).astype(np.float32)
@@ -397,7 +397,9 @@ def test_merge_update_random_sequence(oracle, monkeypatch):
                 assert (bits(_rows(seq[-1])) == bits(_rows(om.points()))).all(), len(seq)
         maps[mode] = seq
         if mode == "merge":
-            assert 8 <= merged < 20          # both paths were exercised
+            # every update is merged (or applied in place): points far beyond the box of the others -- up to 240 m off a 12 m
+            # map -- grow the map like any others, and the top array was re-laid for them at least once
+            assert merged == len(steps) and e.map_update_stats()["relaid"] >= 1, (merged, e.map_update_stats())
         e.close()
     for k, (a, b) in enumerate(zip(maps["merge"], maps["rebuild"])):
         assert a.shape == b.shape and (bits(a) == bits(b)).all(), k

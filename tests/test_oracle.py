@@ -55,8 +55,8 @@ def test_ranked_tie_order(oracle):
     base_i, base_d, _ = oracle.KdTree(m).knn5(q)
     differs = 0
     for rank in (rs.permutation(len(m)).astype(np.uint32),
-                 oracle.grid_rank(m, 0.5, (-2.0, -2.0, -1.0), (16, 16, 8)),
-                 oracle.grid_rank(m, 0.11, (-1.7, -1.9, -0.3), (40, 40, 16))):
+                 oracle.grid_rank(m, 0.5, (-2.0, -2.0, -1.0)),
+                 oracle.grid_rank(m, 0.11, (0.4, 0.3, 1.1))):   # (an origin inside the cloud: negative cells)
         assert sorted(rank.tolist()) == list(range(len(m)))            # a permutation
         ti, td, _ = oracle.KdTree(m).set_rank(rank).knn5(q)
         bi, bd, _ = oracle.knn5_brute(m, q, rank)
@@ -73,8 +73,12 @@ def test_ranked_tie_order(oracle):
     # grid_rank: stable in the caller index inside a cell, cells ordered x fastest inside a brick, bricks x fastest
     pts = np.float32([[0.1, 0.1, 0.1], [0.6, 0.1, 0.1], [0.1, 0.6, 0.1], [0.1, 0.1, 0.6], [4.1, 0.1, 0.1],
                       [0.2, 0.2, 0.2], [0.1, 4.1, 0.1]])
-    r = oracle.grid_rank(pts, 0.5, (0.0, 0.0, 0.0), (16, 16, 8))
+    r = oracle.grid_rank(pts, 0.5, (0.0, 0.0, 0.0))
     assert list(np.argsort(r)) == [0, 5, 1, 2, 3, 4, 6]
+    # signed cells: a point below the origin sorts in front (floor, not truncation), whatever the box of the others
+    pts2 = np.r_[pts, np.float32([[-0.1, 0.1, 0.1], [0.1, -4.2, 0.1], [0.1, 0.1, -0.1]])]
+    r2 = oracle.grid_rank(pts2, 0.5, (0.0, 0.0, 0.0))
+    assert list(np.argsort(r2)) == [9, 8, 7, 0, 5, 1, 2, 3, 4, 6]
 
 
 def test_plane_fit_matches_lstsq(oracle):
