@@ -168,17 +168,9 @@ def build_reference_density_map(eng, cloud, leaf=0.5, chunk=1 << 20):
 
 
 def bench_helper():
-    """tools/bench_loop.cpp as a shared object next to the product library (S2M_LIB may point elsewhere); normally built by
-    __graft_entry__.build(), rebuilt here when it is missing or older than its source: plain g++ against the C ABI."""
-    from daliti_amd.engine import library_path
-    lib_dir = os.path.join(ROOT, "daliti_amd", "_lib")
-    path = os.path.join(lib_dir, "libs2m_benchloop.so")
-    src = os.path.join(ROOT, "tools", "bench_loop.cpp")
-    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), src,
-                               "-L", lib_dir, "-ldaliti_s2m", "-Wl,-rpath," + lib_dir, "-o", path])
-    C.CDLL(library_path(), mode=C.RTLD_GLOBAL)
-    return C.CDLL(path)
+    """tools/bench_loop.cpp as a shared object next to the product library (daliti_amd/world.py builds and loads it)."""
+    from daliti_amd.world import helper_library
+    return helper_library()
 
 
 class CLoop:

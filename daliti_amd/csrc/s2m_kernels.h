@@ -58,7 +58,14 @@ struct MapBuffers {
     uint64_t *bkey = nullptr;    // per occupied brick: its key (brick_key, s2m_device.h: the high part of its points' keys)
     uint8_t *bmark = nullptr;    // per occupied brick: bit 0 = a point of it was removed, bit 1 = a new point goes into it, bit 2 = opened (this update)
     uint32_t *bend = nullptr;    // per occupied brick: end of the stretch of positions it owns (its points, then room)
-    int64_t bkey_cap = 0, bmark_cap = 0, bend_cap = 0;
+    uint32_t *bmove = nullptr;   // per touched brick of an in-place update: first position of its new stretch in the tail, ~0 = it stays
+    void *bplan = nullptr;       // per brick: what the in-place update's plan found for it (s2m_mapedit.hip, BrickPlan: 32 bytes)
+    uint32_t *blist = nullptr;   // the ids of the bricks an in-place update touches, compact
+    int64_t bkey_cap = 0, bmark_cap = 0, bend_cap = 0, bmove_cap = 0, bplan_cap = 0, blist_cap = 0;
+    int64_t main_ext = 0;        // positions [0, main_ext) are ordered by key (the layout of the last build or merge); [main_ext, Grid::m)
+                                 // is the TAIL: stretches handed to bricks that in-place updates opened or moved, in the order they asked
+    int64_t tail_used = 0;       // positions of the tail handed out so far (host copy of the device cursor, counters[kTailWord] - main_ext)
+    int64_t n_moved = 0;         // bricks that in-place updates have put into the tail (diagnostic)
     uint32_t *grow = nullptr;    // per top slot: points the brick has gained (net) by in-place updates since the room was laid out
     int64_t grow_cap = 0;
     int64_t added_since_layout = 0;  // host bound of the sum of `grow`
@@ -84,6 +91,7 @@ struct MapBuffers {
 };
 constexpr int kBricksWord = 32;   // MapBuffers::counters[kBricksWord]: the number of bricks (ids in use), kept on the device
 constexpr int kBoxWords = 34;     // ... [kBoxWords .. +6): a box of bricks on its way to the host (lo xyz, hi xyz)
+constexpr int kTailWord = 40;     // ... [kTailWord]: the next free position of the tail
 
 struct MapStats {
     int64_t bricks = 0, top_entries = 0, occupied_cells = 0;
@@ -97,7 +105,7 @@ hipError_t build_map(const float *xyz_dev, int64_t stride, int64_t m, float cell
                      MapStats &stats, bool &too_large, hipStream_t st, const float *keep_origin = nullptr);
 void free_map(MapBuffers &buf);
 int64_t map_allocations();  // device (re)allocations by the map build / merge / update code so far (all handles; diagnostic)
-void note_allocation();
+void note_allocation(const char *what = "", size_t bytes = 0);
 // bricks / occupied_cells of the last build or merge (a merge does not wait for them: they arrive behind it)
 hipError_t resolve_stats(MapBuffers &buf, MapStats &stats);
 // The map after an update without a new sort (s2m_mapedit.hip, "merge update"): alive_s[sorted position] for the m old points

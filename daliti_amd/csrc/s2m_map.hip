@@ -14,6 +14,8 @@
 // everything else is hand-written below.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -199,6 +201,9 @@ __global__ __launch_bounds__(1024) void brick_box_kernel(const uint32_t *__restr
     }
 }
 
+__global__ void set_word_kernel(uint32_t *dst, uint32_t value) { *dst = value; }
+void launch_set_word(uint32_t *dst, uint32_t value, hipStream_t st) { hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, st, dst, value); }
+
 void launch_brick_box(const uint32_t *bricks_dev, const uint64_t *bkey, const uint32_t *tab, const uint64_t *nk, int n, int32_t *out6,
                       hipStream_t st)
 {
@@ -254,6 +259,13 @@ __global__ __launch_bounds__(256) void brick_table_kernel(const uint32_t *__rest
 // little with every scan does not reallocate -- two device-wide syncs and ~100 MB of hipMalloc at 5 M points --
 // on every update (round 2 compared the stored capacity against need + headroom: the headroom was never usable)
 static int64_t g_map_allocations = 0;  // diagnostic only (s2m_map_update_stats); racy increments are harmless
+// S2M_TRACE_ALLOC=1: every (re)allocation of the map / update code is reported on stderr (a device allocation stalls the
+// stream for ~0.1-1 ms: in a frame loop each one is a slow frame, and this is how they are found)
+static void trace_alloc(const char *what, size_t bytes)
+{
+    static const bool on = std::getenv("S2M_TRACE_ALLOC") != nullptr;
+    if (on) std::fprintf(stderr, "[s2m alloc] %s: %.1f MB (allocation %lld)\n", what, (double)bytes / 1048576.0, (long long)g_map_allocations);
+}
 hipError_t map_ensure(void **p, int64_t *cap, int64_t need, size_t elem, int64_t headroom)
 {
     if (*cap >= need && *p) return hipSuccess;
@@ -264,16 +276,18 @@ hipError_t map_ensure(void **p, int64_t *cap, int64_t need, size_t elem, int64_t
     S2M_TRY(hipMalloc(p, (size_t)c * elem));
     *cap = c;
     ++g_map_allocations;
+    trace_alloc("map_ensure", (size_t)c * elem);
     return hipSuccess;
 }
 int64_t map_allocations() { return g_map_allocations; }
-void note_allocation() { ++g_map_allocations; }
-int64_t map_headroom_for(int64_t m) { return m / 4 + 65536; }
+void note_allocation(const char *what, size_t bytes) { ++g_map_allocations; trace_alloc(what, bytes); }
+// (with room for the slack and the tail a maintained map is laid out with: s2m_mapedit.hip)
+int64_t map_headroom_for(int64_t m) { return m + ((int64_t)1 << 20); }
 
 void free_map(MapBuffers &b)
 {
     void *ptrs[] = {b.pts, b.pidx, b.pts2, b.pidx2, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.work_a, b.work_b,
-                    b.work_c, b.top2, b.bstart, b.bkey, b.bmark, b.bend, b.grow, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
+                    b.work_c, b.top2, b.bstart, b.bkey, b.bmark, b.bend, b.bmove, b.bplan, b.blist, b.grow, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b.h_stats) { (void)hipHostFree(b.h_stats); (void)hipEventDestroy(b.stats_event); }
@@ -290,6 +304,7 @@ hipError_t map_ensure_sort_tmp(MapBuffers &buf, size_t bytes)
     const size_t want = std::max<size_t>(2 * bytes, (size_t)1 << 20);  // with room to spare (s2m_mapupd.hip, ensure_tmp)
     S2M_TRY(hipMalloc(&buf.sort_tmp, want));
     ++g_map_allocations;
+    trace_alloc("map sort_tmp", want);
     buf.sort_tmp_bytes = want;
     return hipSuccess;
 }
@@ -394,8 +409,9 @@ hipError_t map_set_window(MapBuffers &buf, Grid &g, const int lo[3], const int h
     if (resized) *resized = r;
     if (too_large) return hipSuccess;
     const int64_t slots = top_slots(g);
-    if (r || buf.top_cap < slots + 1 || buf.grow_cap < slots + 1) {
+    if (r || buf.top_cap < slots + 1 || buf.top2_cap < slots + 1 || buf.grow_cap < slots + 1) {
         S2M_TRY(map_ensure((void **)&buf.top, &buf.top_cap, slots + 1, sizeof(uint4)));
+        S2M_TRY(map_ensure((void **)&buf.top2, &buf.top2_cap, slots + 1, sizeof(uint4)));  // (the spare a re-lay writes: no allocation in a frame)
         S2M_TRY(map_ensure((void **)&buf.grow, &buf.grow_cap, slots + 1, sizeof(uint32_t)));
         // (the growth history is kept per slot: it does not survive a change of the slots)
         S2M_TRY(hipMemsetAsync(buf.grow, 0, (size_t)(slots + 1) * sizeof(uint32_t), st));
@@ -449,11 +465,14 @@ hipError_t map_build_tables(MapBuffers &buf, Grid &g, const uint64_t *keys, int6
     }
     const int64_t slots = top_slots(g);
     S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(slots + 1) * sizeof(uint4), st));
-    S2M_TRY(map_ensure((void **)&buf.tab, &buf.tab_cap, bricks * kBrickStride, sizeof(uint32_t), (bricks / 4 + 64) * kBrickStride));
-    S2M_TRY(map_ensure((void **)&buf.bstart, &buf.bstart_cap, bricks + 1, sizeof(uint32_t), bricks / 4 + 64));
-    S2M_TRY(map_ensure((void **)&buf.bkey, &buf.bkey_cap, bricks, sizeof(uint64_t), bricks / 4 + 64));
-    S2M_TRY(map_ensure((void **)&buf.bmark, &buf.bmark_cap, bricks, sizeof(uint8_t), bricks / 4 + 64));
-    S2M_TRY(map_ensure((void **)&buf.bend, &buf.bend_cap, bricks, sizeof(uint32_t), bricks / 4 + 64));
+    // (rows to spare for the bricks that in-place updates open until the next merge: a moving sensor opens dozens per frame)
+    const int64_t spare = bricks / 2 + 16384;
+    S2M_TRY(map_ensure((void **)&buf.tab, &buf.tab_cap, bricks * kBrickStride, sizeof(uint32_t), spare * kBrickStride));
+    S2M_TRY(map_ensure((void **)&buf.bstart, &buf.bstart_cap, bricks + 1, sizeof(uint32_t), spare));
+    S2M_TRY(map_ensure((void **)&buf.bkey, &buf.bkey_cap, bricks, sizeof(uint64_t), spare));
+    S2M_TRY(map_ensure((void **)&buf.bmark, &buf.bmark_cap, bricks, sizeof(uint8_t), spare));
+    S2M_TRY(map_ensure((void **)&buf.bend, &buf.bend_cap, bricks, sizeof(uint32_t), spare));
+    S2M_TRY(map_ensure((void **)&buf.bmove, &buf.bmove_cap, bricks, sizeof(uint32_t), spare));
     if (bricks > 0) {
         // first position of every brick (entries beyond the actual number, in the lazy case, are never read)
         size_t ts = 0;
@@ -468,7 +487,10 @@ hipError_t map_build_tables(MapBuffers &buf, Grid &g, const uint64_t *keys, int6
     if (bricks > 0)
         hipLaunchKernelGGL(brick_table_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, m, g, keys,
                            buf.bstart, buf.top, buf.tab, buf.counters + 64, buf.bmark, buf.bend);
-    ++buf.layout_gen;  // a fresh dense layout: every position below m holds a point
+    ++buf.layout_gen;  // a fresh dense layout: every position below m holds a point, and there is no tail
+    buf.main_ext = m;
+    buf.tail_used = 0;
+    launch_set_word(buf.counters + kTailWord, (uint32_t)m, st);
     if (!buf.h_stats) {
         S2M_TRY(hipHostMalloc((void **)&buf.h_stats, (1 + kOccShards) * sizeof(uint32_t), hipHostMallocMapped));
         S2M_TRY(hipHostGetDevicePointer((void **)&buf.h_stats_dev, buf.h_stats, 0));

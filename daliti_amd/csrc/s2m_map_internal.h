@@ -65,6 +65,7 @@ __device__ __forceinline__ void wave_max6_to(uint32_t (&e)[6], uint32_t *__restr
 }
 
 // host helpers of s2m_map.hip
+void launch_set_word(uint32_t *dst, uint32_t value, hipStream_t st);  // *dst = value, in stream order
 hipError_t map_ensure(void **p, int64_t *cap, int64_t need, size_t elem, int64_t headroom = 0);
 hipError_t map_ensure_sort_tmp(MapBuffers &buf, size_t bytes);
 int64_t map_headroom_for(int64_t m);

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void dead_words_kernel(int64_t m, const uint8_
     // -- so nothing is renumbered: rounds 2-3 also ranked the removed CALLER INDICES here and every survivor gathered its
     // new index from that rank.)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 7) outside_flag[i] = 0u;  // merge_newkey_kernel's flag and excess words
+    if (i < 8) outside_flag[i] = 0u;  // merge_newkey_kernel's flag and excess words, tail_key_kernel's count
     if (i == 0) cnt[(m + 63) >> 6] = 0u;  // the scan's spare element
     const unsigned long long ws = __ballot(i < m && alive_s[i] == 0);
     if ((threadIdx.x & 63) == 0 && (i >> 6) <= ((m - 1) >> 6)) {
@@ -79,11 +79,12 @@ __device__ __forceinline__ void report_excess(const Grid &g, int bx, int by, int
 
 // outside[0] |= 1 when a point's cell is beyond the representable range (nothing can hold it: the caller rebuilds around a new
 // origin); outside[1..7) = how far the batch reaches beyond the bricks in use (report_excess)
-__global__ __launch_bounds__(256) void merge_newkey_kernel(const float4 *__restrict__ stage, int n, Grid g,
+__global__ __launch_bounds__(256) void merge_newkey_kernel(const float4 *__restrict__ stage, int n, Grid g, int n_tail,
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
                                                            uint32_t *__restrict__ outside)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    keys += n_tail; vals += n_tail;  // (the staged points follow the tail's in the list that is sorted)
     bool out = false;
     int cx = 0, cy = 0, cz = 0;
     if (i < n) {
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void merge_newkey_kernel(const float4 *__restr
         cx = cell_coord(p.x, g.ox, g.inv_c); cy = cell_coord(p.y, g.oy, g.inv_c); cz = cell_coord(p.z, g.oz, g.inv_c);
         out = !cell_representable(cx, cy, cz);
         keys[i] = out ? ~0ull : point_key(cx, cy, cz);
-        vals[i] = (uint32_t)i;
+        vals[i] = (uint32_t)(n_tail + i);
     }
     report_excess(g, cx >> 3, cy >> 3, cz >> 3, i < n && !out, outside + 1);
     if (__syncthreads_or(out ? 1 : 0) && threadIdx.x == 0) atomicOr(outside, 1u);
@@ -142,22 +143,49 @@ __global__ __launch_bounds__(256) void merge_old_kernel(int64_t m, const float4 
     nkeys_out[pos] = okeys[j];
 }
 
-// new point i (sorted order) -> (survivors before its lb) + i
+// new point i (sorted order) -> (survivors before its lb) + i.  The "new" points of a merge are the live points of the TAIL
+// (bricks that in-place updates moved or opened behind the key-ordered part of the array: they keep their ids) followed by
+// the staged points of the update (ids next_id, next_id + 1, ...); value t < n_tail names tail position main_ext + t, the
+// others staged point t - n_tail.  Dead tail positions carry the key ~0: sorted last, skipped here.
 __global__ __launch_bounds__(256) void merge_new_kernel(int n, const uint64_t *__restrict__ nkeys, const uint32_t *__restrict__ nvals,
                                                         const uint32_t *__restrict__ lb, const DeadRank *__restrict__ rank_s,
-                                                        const float4 *__restrict__ stage, uint32_t next_id,
+                                                        const float4 *__restrict__ stage, uint32_t next_id, int n_tail, int64_t main_ext,
+                                                        const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx,
                                                         float4 *__restrict__ npts, uint64_t *__restrict__ nkeys_out,
                                                         uint32_t *__restrict__ npidx)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint64_t key = nkeys[i];
+    if (key == ~0ull) return;
     const uint32_t l = lb[i];
     const uint32_t pos = (l - dead_before(l, rank_s)) + (uint32_t)i;
     const uint32_t t = nvals[i];
-    const float4 p = stage[t];
-    npts[pos] = make_map_point(p.x, p.y, p.z, pos);
-    nkeys_out[pos] = nkeys[i];
-    npidx[pos] = next_id + t;  // staged order = caller order of the new points
+    if ((int)t < n_tail) {
+        const float4 p = pts[main_ext + t];
+        npts[pos] = make_map_point(p.x, p.y, map_point_z(p), pos);
+        npidx[pos] = pidx[main_ext + t];
+    } else {
+        const float4 p = stage[t - (uint32_t)n_tail];
+        npts[pos] = make_map_point(p.x, p.y, p.z, pos);
+        npidx[pos] = next_id + (t - (uint32_t)n_tail);  // staged order = caller order of the new points
+    }
+    nkeys_out[pos] = key;
+}
+// keys of the tail's positions for that sort: the point's own key, ~0 for a position that holds no point (counted in *dead)
+__global__ __launch_bounds__(256) void tail_key_kernel(int n_tail, int64_t main_ext, const uint64_t *__restrict__ okeys,
+                                                       const uint8_t *__restrict__ alive_s, uint64_t *__restrict__ keys,
+                                                       uint32_t *__restrict__ vals, uint32_t *__restrict__ dead)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool d = false;
+    if (i < n_tail) {
+        d = alive_s[main_ext + i] == 0;
+        keys[i] = d ? ~0ull : okeys[main_ext + i];
+        vals[i] = (uint32_t)i;
+    }
+    const int c = __syncthreads_count(d ? 1 : 0);
+    if (threadIdx.x == 0 && c) atomicAdd(dead, (uint32_t)c);
 }
 
 // ---- slack for the in-place updates -------------------------------------------------------------------------
@@ -232,10 +260,28 @@ __global__ __launch_bounds__(256) void slack_start_kernel(const uint32_t *__rest
     if (id < (int64_t)*bricks_dev) bstart[id] += shift[id];
 }
 
-// dense layout of m points (buf.pts / pidx / keys_alt, tables built) -> layout with slack; g.m becomes the new extent
+// every position of the tail holds nothing: far coordinates (never a neighbour), id ~0, key ~0
+__global__ __launch_bounds__(256) void tail_fill_kernel(int64_t from, int64_t to, float4 *__restrict__ pts, uint32_t *__restrict__ pidx,
+                                                        uint64_t *__restrict__ keys)
+{
+    const int64_t j = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= to) return;
+    pts[j] = make_map_point(3.0e38f, 3.0e38f, 3.0e38f, 0xffffffffu);
+    pidx[j] = 0xffffffffu;
+    keys[j] = ~0ull;
+}
+
+// How many positions the tail of a layout of m points gets: room for the bricks that in-place updates open or move until the
+// next merge.  Generous (HBM is not what this engine is short of): half the map, at least half a million positions.
+static int64_t tail_size_for(int64_t m) { return std::max<int64_t>(m / 2, (int64_t)1 << 19); }
+
+// dense layout of m points (buf.pts / pidx / keys_alt, tables built) -> layout with slack behind every brick and the tail
+// behind the last one; g.m becomes the new extent, buf.main_ext the extent of the key-ordered part
 static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bound, hipStream_t st)
 {
     const int64_t m = g.m;
+    buf.main_ext = m;
+    buf.tail_used = 0;
     if (m <= 0 || bricks_bound <= 0) return hipSuccess;
     // slack <= max(cnt / 8, 16) + 4 x growth per brick; the host knows the sum of the growth as a bound
     int64_t room_bound = m / 8 + 16 * bricks_bound + 64 + 4 * buf.added_since_layout;
@@ -246,8 +292,9 @@ static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bou
     }
     const int64_t ext_bound = m + room_bound;
     if (ext_bound > buf.scratch_cap || ext_bound >= ((int64_t)1 << 31) || bricks_bound + 2 > buf.scratch_cap) return hipSuccess;  // stays dense
-    S2M_TRY(map_ensure((void **)&buf.pts2, &buf.pts2_cap, ext_bound + kSentinelPoints, sizeof(float4), map_headroom_for(ext_bound)));
-    S2M_TRY(map_ensure((void **)&buf.pidx2, &buf.pidx2_cap, ext_bound + 1, sizeof(uint32_t), map_headroom_for(ext_bound)));
+    const int64_t tail = std::max<int64_t>(std::min<int64_t>(std::min<int64_t>(tail_size_for(m), buf.scratch_cap - ext_bound), ((int64_t)1 << 31) - 64 - ext_bound), 0);
+    S2M_TRY(map_ensure((void **)&buf.pts2, &buf.pts2_cap, ext_bound + tail + kSentinelPoints, sizeof(float4), map_headroom_for(ext_bound)));
+    S2M_TRY(map_ensure((void **)&buf.pidx2, &buf.pidx2_cap, ext_bound + tail + 1, sizeof(uint32_t), map_headroom_for(ext_bound)));
     const uint32_t *bricks_dev = buf.counters + kBricksWord;
     uint32_t *slack = buf.work_a, *shift = buf.work_b;
     size_t tmp = 0;
@@ -269,11 +316,16 @@ static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bou
     hipLaunchKernelGGL(slack_start_kernel, dim3((unsigned)((bricks_bound + 255) / 256)), dim3(256), 0, st, bricks_dev, shift, buf.bstart);
     uint32_t room = 0;
     S2M_TRY(mail_collect(buf.mail, 1, &room, st));
-    const int64_t ext = m + (int64_t)room;
+    const int64_t main_ext = m + (int64_t)room, ext = main_ext + tail;
+    if (tail > 0)
+        hipLaunchKernelGGL(tail_fill_kernel, dim3((unsigned)((tail + 255) / 256)), dim3(256), 0, st, main_ext, ext, buf.pts2, buf.pidx2, buf.keys);
     S2M_TRY(map_put_sentinels(buf.pts2, ext, st));
+    // the tail's cursor lives on the device (the in-place update's plan kernel hands positions out)
+    launch_set_word(buf.counters + kTailWord, (uint32_t)main_ext, st);
     std::swap(buf.pts, buf.pts2); std::swap(buf.pts_cap, buf.pts2_cap);
     std::swap(buf.pidx, buf.pidx2); std::swap(buf.pidx_cap, buf.pidx2_cap);
     std::swap(buf.keys, buf.keys_alt);
+    buf.main_ext = main_ext;
     g.m = ext;
     g.sent_off = (ext + kSentinelPoints) < ((int64_t)1 << 28) ? (uint32_t)(ext << 4) : 0u;
     g.pts = buf.pts; g.pidx = buf.pidx;
@@ -284,10 +336,12 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
                         const float4 *stage, int64_t n_new, bool &merged, hipStream_t st, bool with_slack)
 {
     merged = false;
-    const int64_t m = g.m;
-    if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || m > buf.scratch_cap) return hipSuccess;
-    if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return hipSuccess;
-    const int n = (int)n_new;
+    // [0, m): the key-ordered part of the array; [m, m + n_tail): the part of the tail that in-place updates have handed out
+    const int64_t m = buf.main_ext > 0 && buf.main_ext <= g.m ? buf.main_ext : g.m;
+    const int64_t n_tail = std::min<int64_t>(buf.tail_used, g.m - m);
+    if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || g.m > buf.scratch_cap) return hipSuccess;
+    if (n_new >= ((int64_t)1 << 30) || n_new + n_tail > buf.scratch_cap || n_new + n_tail >= ((int64_t)1 << 31)) return hipSuccess;
+    const int n = (int)(n_new + n_tail), nt = (int)n_tail;  // the points the merge sorts: the tail's, then the staged ones
     const int64_t words = (m + 63) / 64;
     // dword: [masks of the removed positions | packed records], words + 1 each; work_c: [removed per word | exclusive prefix];
     // mv: [stage positions | upper bounds] of the new points
@@ -298,18 +352,18 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     uint32_t *dcnt = buf.work_c, *dprefix = buf.work_c + (words + 1);
     if (2 * (words + 1) > buf.scratch_cap + 1) return hipSuccess;
     if (buf.next_id + n_new >= ((int64_t)1 << 32) - 2) return hipSuccess;  // ids exhausted: a rebuild makes them dense again
-    const unsigned kbits = 9 + 3 * kBrickBits;  // the box-independent key (a batch of a few thousand keys: the merge sort path)
+    const unsigned kbits = 64;  // the box-independent key, ~0 for the tail's empty positions (a batch of thousands: the merge sort path)
     // capacity for the merged map before anything is enqueued (the exact size arrives with the hand-back below)
-    const int64_t m_bound = m + n_new;
+    const int64_t m_bound = m + n;
     if (m_bound > buf.scratch_cap || m_bound >= ((int64_t)1 << 31)) return hipSuccess;
     size_t tmp = 0, tmp3 = 0;
     S2M_TRY(rocprim::exclusive_scan(nullptr, tmp, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
     if (n > 0)
-        S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, buf.keys, buf.keys, buf.vals, buf.vals, (size_t)n_new, 0, kbits, st));
+        S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp3, buf.keys, buf.keys, buf.vals, buf.vals, (size_t)n, 0, kbits, st));
     S2M_TRY(map_ensure_sort_tmp(buf, std::max(tmp, tmp3)));
     if (n > 0) {
-        S2M_TRY(map_ensure((void **)&buf.mk, &buf.mk_cap, n_new, sizeof(uint64_t), n_new / 2 + 4096));
-        S2M_TRY(map_ensure((void **)&buf.mv, &buf.mv_cap, 2 * n_new, sizeof(uint32_t), n_new + 8192));
+        S2M_TRY(map_ensure((void **)&buf.mk, &buf.mk_cap, n, sizeof(uint64_t), n / 2 + 4096));
+        S2M_TRY(map_ensure((void **)&buf.mv, &buf.mv_cap, 2 * (int64_t)n, sizeof(uint32_t), n + 8192));
     }
     S2M_TRY(map_ensure((void **)&buf.pts2, &buf.pts2_cap, m_bound + kSentinelPoints, sizeof(float4), map_headroom_for(m_bound)));
     S2M_TRY(map_ensure((void **)&buf.pidx2, &buf.pidx2_cap, m_bound + 1, sizeof(uint32_t), map_headroom_for(m_bound)));
@@ -321,50 +375,54 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, t, dcnt, dprefix, 0u, (size_t)words + 1, rocprim::plus<uint32_t>(), st));
     hipLaunchKernelGGL(dead_pack_kernel, dim3((unsigned)((words + 256) / 256)), dim3(256), 0, st, words, word_s, dprefix, rank_s);
     uint64_t *nk_sorted = buf.mk;
-    uint32_t *nv_sorted = buf.mv, *lb = buf.mv + n_new;
-    // keys of the new points in the CURRENT grid (keys / vals are free until the merge writes them); the kernel also says
-    // whether one of them lies outside the grid
-    if (n > 0)
-        hipLaunchKernelGGL(merge_newkey_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals,
-                           buf.counters + 8);
+    uint32_t *nv_sorted = buf.mv, *lb = buf.mv + n;
+    // keys of the points to merge in (keys / vals are free until the merge writes them): the tail's own, the staged points' from
+    // their cells; the second kernel also says whether one of them cannot be represented and how far they reach beyond the bounds
+    if (nt > 0)
+        hipLaunchKernelGGL(tail_key_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, nt, m, buf.keys_alt, alive_s, buf.keys, buf.vals,
+                           buf.counters + 15);
+    if (n_new > 0)
+        hipLaunchKernelGGL(merge_newkey_kernel, dim3((unsigned)((n_new + 255) / 256)), dim3(256), 0, st, stage, (int)n_new, g, nt, buf.keys,
+                           buf.vals, buf.counters + 8);
     // the one hand-back -- number of dead, "a new point cannot be represented", how far the new points reach beyond the
-    // bricks in use -- is posted here and collected after the merge kernels have been enqueued: they write into the spare
-    // arrays, which only become the map if the answer allows it
+    // bricks in use, the tail's empty positions -- is posted here and collected after the merge kernels have been enqueued:
+    // they write into the spare arrays, which only become the map if the answer allows it
     const uint32_t *dead_dev = dprefix + words;
     {
-        const uint32_t *src[8] = {dead_dev, buf.counters + 8, buf.counters + 9, buf.counters + 10, buf.counters + 11, buf.counters + 12,
-                                  buf.counters + 13, buf.counters + 14};
-        S2M_TRY(mail_post(buf.mail, src, 8, st));
+        const uint32_t *src[9] = {dead_dev, buf.counters + 8, buf.counters + 9, buf.counters + 10, buf.counters + 11, buf.counters + 12,
+                                  buf.counters + 13, buf.counters + 14, buf.counters + 15};
+        S2M_TRY(mail_post(buf.mail, src, 9, st));
     }
     if (n > 0) {
         t = buf.sort_tmp_bytes;
-        S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, nk_sorted, buf.vals, nv_sorted, (size_t)n_new, 0, kbits, st));
+        S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, nk_sorted, buf.vals, nv_sorted, (size_t)n, 0, kbits, st));
         hipLaunchKernelGGL(merge_lb_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, buf.keys_alt, m, lb);
     }
     hipLaunchKernelGGL(merge_old_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, m, buf.pts, buf.pidx, buf.keys_alt,
                        alive_s, rank_s, lb, n, buf.pts2, buf.pidx2, buf.keys);
     if (n > 0)
         hipLaunchKernelGGL(merge_new_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nk_sorted, nv_sorted, lb, rank_s, stage,
-                           (uint32_t)buf.next_id, buf.pts2, buf.keys, buf.pidx2);
-    uint32_t dead = 0, outside = 0;
+                           (uint32_t)buf.next_id, nt, m, buf.pts, buf.pidx, buf.pts2, buf.keys, buf.pidx2);
+    uint32_t dead = 0, outside = 0, tail_dead = 0;
     int lo[3], hi[3];
     {
-        uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        S2M_TRY(mail_collect(buf.mail, 8, v, st));
+        uint32_t v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        S2M_TRY(mail_collect(buf.mail, 9, v, st));
         dead = v[0];
         outside = v[1];
-        for (int k = 0; k < 3; ++k) { lo[k] = g.blo[k] - (n > 0 ? (int)v[2 + k] : 0); hi[k] = g.bhi[k] + (n > 0 ? (int)v[5 + k] : 0); }
+        tail_dead = v[8];
+        for (int k = 0; k < 3; ++k) { lo[k] = g.blo[k] - (n_new > 0 ? (int)v[2 + k] : 0); hi[k] = g.bhi[k] + (n_new > 0 ? (int)v[5 + k] : 0); }
     }
     if (outside) return hipSuccess;     // full rebuild around a new origin; what was written to the spare arrays is dropped
-    if (dead == 0 && n_new == 0) {      // nothing was removed and nothing is added: the map stands as it is
+    if (dead == 0 && n_new == 0 && nt == 0) {  // nothing was removed, nothing is added, nothing to bring home: the map stands as it is
         merged = true;
         return hipSuccess;
     }
     const int64_t survivors = m - (int64_t)dead;
-    const int64_t m_new = survivors + n_new;
+    const int64_t m_new = survivors + ((int64_t)n - (int64_t)tail_dead);
     if (m_new == 0) return hipSuccess;
     buf.next_id += n_new;
-    if (dead > 0) buf.ids_dense = false;
+    if (dead > 0 || tail_dead > 0) buf.ids_dense = false;
     S2M_TRY(map_put_sentinels(buf.pts2, m_new, st));
     // the merged arrays become the map
     std::swap(buf.pts, buf.pts2); std::swap(buf.pts_cap, buf.pts2_cap);
@@ -372,6 +430,8 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     std::swap(buf.keys, buf.keys_alt);
     g.m = m_new;
     g.live = m_new;
+    buf.main_ext = m_new;
+    buf.tail_used = 0;
     g.sent_off = (m_new + kSentinelPoints) < ((int64_t)1 << 28) ? (uint32_t)(m_new << 4) : 0u;
     // every new point opens at most one brick: no read-back before the tables are built -- unless the box of the bricks in
     // use, grown by the new points, has left the window of the top array: then the exact box of the merged map is fetched
@@ -407,8 +467,9 @@ constexpr int kSlabBig = 6144;  // ... and in the second, rarely launched form f
 // use, grown by the new points, no longer fits the window of the top array (the host re-lays it and tries again)
 enum : uint32_t { kSlabOutside = 1u, kSlabNewBrick = 2u, kSlabOverflow = 4u, kSlabWindow = 8u };
 // words of the update's counters behind `flags`: [0] outcome bits, [1] points removed, [2] bricks opened, [3] points gained
-// by bricks, [4] crowded bricks among the touched ones, [5..11) how far the new points reach beyond the bricks in use
-constexpr int kSlabWords = 11;
+// by bricks, [4] crowded bricks among the touched ones, [5..11) how far the new points reach beyond the bricks in use,
+// [11] bricks moved to the tail (the opened ones included), [12] bricks touched
+constexpr int kSlabWords = 13;
 
 __global__ __launch_bounds__(256) void slab_key_kernel(const float4 *__restrict__ stage, int n, Grid g, uint64_t *__restrict__ keys,
                                                        uint32_t *__restrict__ vals, uint8_t *__restrict__ bmark,
@@ -461,149 +522,93 @@ __device__ __forceinline__ uint32_t slab_brick_id(const Grid &g, uint64_t b)
     return brick_in_bounds(g, bx, by, bz) ? g.top[top_slot(g, bx, by, bz)].x : 0u;
 }
 
-// Bricks that this update opens (new points in a brick that holds nothing yet: a sensor that moves sees new
-// ground every frame) get their stretch of positions from the END of the room of the brick before them in key order, so
-// that position order stays key order; several new bricks in front of the same old brick line up there in key order.
-// One workgroup: the box of the bricks in use, grown by the new points, must fit the window of the top array (else
-// kSlabWindow: the host re-lays the array and calls again) -> heads of the new-brick segments of the sorted new keys (in
-// order) -> per head the first old position of a later brick (binary search in the sorted keys) -> a backward walk assigns
-// the stretches -> the room of the brick in front must still hold its own points plus what this update adds to it
-// (ignoring what it removes: conservative) -> only then are the entries written: top, brick key / start / end, an empty
-// prefix row, the mark "new" (4) + "touched" (2), the brick count.  Any doubt -- more than 1 024 new bricks, no brick in
-// front, not enough room, no spare table rows -- raises kSlabNewBrick instead and writes nothing: the merge re-lays the map
-// out.
-constexpr int kNewBricksMax = 1024;
-__global__ __launch_bounds__(256) void slab_newbrick_kernel(const uint64_t *__restrict__ nk, int n_new, Grid g, uint4 *__restrict__ top,
-                                                            const uint64_t *__restrict__ okeys, int64_t m,
-                                                            uint32_t *__restrict__ tab, uint32_t *__restrict__ bstart,
-                                                            uint32_t *__restrict__ bend, uint64_t *__restrict__ bkey,
-                                                            uint8_t *__restrict__ bmark, uint32_t *__restrict__ bricks_dev,
-                                                            int max_new, uint32_t *__restrict__ flags)
+// What a brick that cannot stay where it stands -- one that this update opens (a sensor that moves sees new ground every
+// frame), or one whose points no longer fit the stretch it owns -- asks of the TAIL, the part of the array behind the
+// key-ordered one: its points and room to grow (a brick at the frontier fills up over the next frames as the sensor comes
+// closer).  Handing such bricks a fresh stretch instead of re-laying the map out keeps every frame's cost proportional to
+// the scan; the price is that a brick's position no longer says where its key stands among the others -- between two merges
+// the order of s2m_map_get_order is (brick, cell, id) only INSIDE every brick (include/daliti_s2m.h).
+__device__ __forceinline__ uint32_t reloc_need(uint32_t total, bool opened)
 {
-    __shared__ uint64_t h_b[kNewBricksMax];
-    __shared__ uint32_t h_k0[kNewBricksMax], h_need[kNewBricksMax], h_p0[kNewBricksMax], h_ida[kNewBricksMax],
-        h_start[kNewBricksMax], h_end[kNewBricksMax];
-    __shared__ int wsum[4];
-    __shared__ int s_fail;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) s_fail = 0;
-    __syncthreads();
+    return total + (opened ? max(total, 96u) : max(total >> 1, 64u));
+}
+
+// Bricks that this update opens, in three parallel steps over the sorted new keys: (1) the first point of every brick that
+// does not exist yet raises a flag -- after the check that the box of the bricks in use, grown by the new points, still
+// fits the window of the top array (else kSlabWindow: nothing is written, the host re-lays the array and calls again);
+// (2) an exclusive scan numbers the flags in key order; (3) every flagged point opens its brick: top entry, key, an empty
+// table row, the marks "new" (4) + "touched" (2) -- the plan gives it its stretch.  More bricks than there are table rows
+// to spare: kSlabNewBrick (the merge re-lays the map and its tables out).
+__global__ __launch_bounds__(256) void slab_head_kernel(const uint64_t *__restrict__ nk, int n_new, Grid g, uint32_t *__restrict__ head,
+                                                        uint32_t *__restrict__ bricks_dev, uint32_t *__restrict__ flags)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (flags[0] & kSlabOutside) return;  // (uniform; the key kernel has finished)
-    // 0. does the grown box still fit the window?  (uniform: every thread reads the same six words)
     {
         bool fits = true;
         const uint32_t tm[3] = {g.tmx, g.tmy, g.tmz};
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            fits = fits && ((int64_t)g.bhi[k] + flags[8 + k]) - ((int64_t)g.blo[k] - flags[5 + k]) <= (int64_t)tm[k];
-        if (!fits) {
-            if (tid == 0) atomicOr(flags, kSlabWindow);
+        for (int q = 0; q < 3; ++q)
+            fits = fits && ((int64_t)g.bhi[q] + flags[8 + q]) - ((int64_t)g.blo[q] - flags[5 + q]) <= (int64_t)tm[q];
+        if (!fits) {  // (uniform: every thread reads the same six words)
+            if (k == 0) atomicOr(flags, kSlabWindow);
             return;
         }
     }
-    // 1. the heads, in key order
-    int nh = 0;
-    for (int c0 = 0; c0 < n_new; c0 += 256) {
-        const int k = c0 + tid;
-        bool head = false;
-        uint64_t b = 0u;
-        if (k < n_new) {
-            b = nk[k] >> 9;
-            head = (k == 0 || (nk[k - 1] >> 9) != b) && slab_brick_id(g, b) == 0u;
-        }
-        const unsigned long long bal = __ballot(head);
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int off = nh;
-        for (int w = 0; w < wave; ++w) off += wsum[w];
-        const int chunk = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (head) {
-            const int i = off + __popcll(bal & ((1ull << lane) - 1ull));
-            if (i < kNewBricksMax) { h_b[i] = b; h_k0[i] = (uint32_t)k; }
-        }
-        nh += chunk;
-        __syncthreads();
+    if (k == 0) bricks_dev[1] = bricks_dev[0];  // the bricks before this update: where the new ids start
+    if (k >= n_new) return;
+    const uint64_t b = nk[k] >> 9;
+    head[k] = ((k == 0 || (nk[k - 1] >> 9) != b) && slab_brick_id(g, b) == 0u) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void slab_open_kernel(const uint64_t *__restrict__ nk, int n_new, Grid g, const uint32_t *__restrict__ head,
+                                                        const uint32_t *__restrict__ rank, uint4 *__restrict__ top, uint32_t *__restrict__ tab,
+                                                        uint32_t *__restrict__ bend, uint64_t *__restrict__ bkey, uint8_t *__restrict__ bmark,
+                                                        uint32_t *__restrict__ bricks_dev, int max_new, uint32_t *__restrict__ flags)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_new || (flags[0] & (kSlabOutside | kSlabWindow))) return;
+    const uint32_t first_id = bricks_dev[1];
+    if (k == n_new - 1) {  // the last point knows how many bricks open
+        const uint32_t nh = rank[k] + head[k];
+        if (nh > (uint32_t)max_new) atomicOr(flags, kSlabNewBrick);
+        else { bricks_dev[0] = first_id + nh; flags[2] = nh; }
     }
-    if (nh == 0) return;  // (uniform)
-    if (nh > max_new || nh > kNewBricksMax) {
-        if (tid == 0) atomicOr(flags, kSlabNewBrick);
-        return;
-    }
-    // 2. per head: its points, what it asks for, the first old position of a later brick, the brick in front
-    for (int i = tid; i < nh; i += 256) {
-        const uint64_t b = h_b[i];
-        const int n_b = slab_lower(nk, n_new, b + 1) - (int)h_k0[i];
-        h_need[i] = (uint32_t)n_b + max((uint32_t)n_b >> 2, 32u);
-        int64_t lo = 0, hi = m;  // first old position whose brick is later than b (b itself holds nothing)
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if ((okeys[mid] >> 9) <= b) lo = mid + 1; else hi = mid;
-        }
-        h_p0[i] = (uint32_t)lo;
-        uint32_t ida = 0xffffffffu;
-        if (lo > 0) {
-            const uint32_t idp1 = slab_brick_id(g, okeys[lo - 1] >> 9);
-            if (idp1) ida = idp1 - 1u;
-        }
-        h_ida[i] = ida;
-        if (ida == 0xffffffffu) s_fail = 1;
-    }
-    __syncthreads();
-    // 3. stretches, from the back: the new bricks in front of the same old position line up in key order
-    if (tid == 0 && !s_fail) {
-        uint32_t cursor = 0u;
-        for (int i = nh - 1; i >= 0; --i) {
-            if (i == nh - 1 || h_p0[i] != h_p0[i + 1]) cursor = h_p0[i];
-            h_end[i] = cursor;
-            if (h_need[i] > cursor) { s_fail = 1; break; }
-            cursor -= h_need[i];
-            h_start[i] = cursor;
-            if (i == 0 || h_p0[i - 1] != h_p0[i]) {
-                // the lowest new brick of this group starts at `cursor`: the brick in front keeps [its start, cursor)
-                const uint32_t ida = h_ida[i];
-                const uint32_t a_base = tab[ida * kBrickStride], a_end = tab[ida * kBrickStride + kBrickCells];
-                const uint64_t ab = bkey[ida];
-                const int n_a = slab_lower(nk, n_new, ab + 1) - slab_lower(nk, n_new, ab);
-                // its room must be its own (bend says so: a stretch carved earlier in this launch cannot be carved twice)
-                if (bend[ida] != h_p0[i] || cursor < a_end + (uint32_t)n_a || cursor < a_base) { s_fail = 1; break; }
-            }
-        }
-    }
-    __syncthreads();
-    if (s_fail) {
-        if (tid == 0) atomicOr(flags, kSlabNewBrick);
-        return;
-    }
-    // 4. the entries
-    const uint32_t first_id = *bricks_dev;
-    for (int i = tid; i < nh; i += 256) {
-        const uint32_t id = first_id + (uint32_t)i;
-        const uint64_t b = h_b[i];
-        top[top_slot_of_key(g, b)] = make_uint4(id + 1u, 0u, 0u, 0u);
-        bkey[id] = b;
-        bstart[id] = h_start[i];
-        bend[id] = h_end[i];
-        tab[id * kBrickStride] = h_start[i];
-        tab[id * kBrickStride + kBrickCells] = h_start[i];
-        bmark[id] = 6u;
-        if (i == 0 || h_p0[i - 1] != h_p0[i]) bend[h_ida[i]] = h_start[i];
-    }
-    __syncthreads();
-    if (tid == 0) { *bricks_dev = first_id + (uint32_t)nh; flags[2] = (uint32_t)nh; }
+    if (!head[k] || rank[k] >= (uint32_t)max_new) return;
+    const uint32_t id = first_id + rank[k];
+    const uint64_t b = nk[k] >> 9;
+    top[top_slot_of_key(g, b)] = make_uint4(id + 1u, 0u, 0u, 0u);
+    bkey[id] = b;
+    bend[id] = 0u;
+    tab[id * kBrickStride] = 0u;
+    tab[id * kBrickStride + kBrickCells] = 0u;
+    bmark[id] = 6u;
 }
 
-// one wave per brick: does the touched brick fit where it stands?  flags[0] |= overflow, flags[1] += points removed
+// What the plan found for a touched brick
+struct BrickPlan {
+    uint32_t lo, n_b;    // its new points: nk[lo .. lo + n_b)
+    uint32_t need;       // positions it asks of the tail (0: it stays where it stands)
+    uint32_t info;       // bits 0..23 points removed from it, bit 24 crowded (the large staging form), bit 25 cannot be staged at all
+    uint32_t gained, pad[3];
+};
+
+static_assert(sizeof(BrickPlan) == 32, "BrickPlan is two 16-byte words");
+
+// one wave per brick: does the touched brick fit where it stands -- and if not, how much of the tail it needs.  No shared
+// counters here (a few thousand touched bricks adding to the same words cost more than the rest of the kernel: same-line
+// atomics serialise at ~11 ns each): every brick leaves its record, slab_alloc_kernel adds them up.
 __global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restrict__ bricks_dev, Grid g,
                                                         const uint32_t *__restrict__ bend, const uint32_t *__restrict__ tab,
                                                         const uint64_t *__restrict__ bkey, const uint8_t *__restrict__ bmark,
                                                         const uint8_t *__restrict__ alive_s, const uint64_t *__restrict__ nk, int n_new,
-                                                        uint32_t *__restrict__ grow, uint32_t *__restrict__ flags, int big_ok)
+                                                        uint32_t *__restrict__ grow, BrickPlan *__restrict__ plan,
+                                                        const uint32_t *__restrict__ flags, int big_ok)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t bricks = (int64_t)*bricks_dev;
     const int64_t id = (int64_t)blockIdx.x * 4 + wave;
     if (id >= bricks || bmark[id] == 0) return;
-    if (flags[0] & (kSlabOutside | kSlabWindow)) return;  // the host deals with the window first and calls again: count nothing twice
+    if (flags[0] & (kSlabOutside | kSlabWindow | kSlabNewBrick)) return;  // the host deals with those first: count nothing twice
     const uint32_t base = tab[id * kBrickStride], end = tab[id * kBrickStride + kBrickCells];
     const uint32_t cap_end = bend[id];
     int alive = 0;
@@ -612,30 +617,102 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restri
     for (int off = 32; off > 0; off >>= 1) alive += __shfl_xor(alive, off, 64);
     if (lane != 0) return;
     const uint64_t b = bkey[id];
-    const int n_b = n_new > 0 ? slab_lower(nk, n_new, b + 1) - slab_lower(nk, n_new, b) : 0;
+    const int lo = n_new > 0 ? slab_lower(nk, n_new, b) : 0;
+    const int n_b = n_new > 0 ? slab_lower(nk, n_new, b + 1) - lo : 0;
     const uint32_t total = (uint32_t)alive + (uint32_t)n_b;
     // what the rewrite has to stage at most: the brick's positions so far plus its new points
     const uint32_t stage = (end - base) + (uint32_t)n_b;
-    if (total > cap_end - base || stage > (uint32_t)(big_ok ? kSlabBig : kSlabMax)) atomicOr(flags, kSlabOverflow);
-    else if (stage > (uint32_t)kSlabMax) atomicAdd(flags + 4, 1u);  // a crowded brick: the second launch takes it
-    atomicAdd(flags + 1, (end - base) - (uint32_t)alive);
+    BrickPlan p = {(uint32_t)lo, (uint32_t)n_b, 0u, min((end - base) - (uint32_t)alive, 0xffffffu), 0u, {0u, 0u, 0u}};
+    if (stage > (uint32_t)(big_ok ? kSlabBig : kSlabMax)) p.info |= 1u << 25;
+    else if (stage > (uint32_t)kSlabMax) p.info |= 1u << 24;
+    if (total > cap_end - base) p.need = reloc_need(total, (bmark[id] & 4u) != 0u);  // it does not fit where it stands
     // what the brick gains by this update (whether it ends up in place or merged): the next layout sizes its room by it
     if (total > end - base) {
-        grow[top_slot_of_key(g, b)] += total - (end - base);
-        atomicAdd(flags + 3, total - (end - base));  // the host keeps the sum as the bound of the room it will need
+        p.gained = total - (end - base);
+        grow[top_slot_of_key(g, b)] += p.gained;
+    }
+    plan[id] = p;
+}
+
+// One workgroup walks the brick ids in order: the touched bricks' requests become stretches of the tail (a prefix sum: the
+// same positions whatever order the waves of the plan finished in), their ids a compact list for the rewrite, their counts
+// the update's totals.  flags[0] |= overflow when a brick cannot be staged or the tail is exhausted (nothing is handed out then).
+constexpr int kAllocThreads = 1024;
+__global__ __launch_bounds__(kAllocThreads) void slab_alloc_kernel(const uint32_t *__restrict__ bricks_dev, const uint8_t *__restrict__ bmark,
+                                                                   const BrickPlan *__restrict__ plan, uint32_t *__restrict__ bmove,
+                                                                   uint32_t *__restrict__ blist, uint32_t *__restrict__ tail_cursor,
+                                                                   uint32_t tail_end, uint32_t *__restrict__ flags)
+{
+    __shared__ uint32_t w_need[16], w_touch[16];
+    __shared__ uint32_t s_removed, s_gained, s_crowded, s_moved, s_bad;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (flags[0] & (kSlabOutside | kSlabWindow | kSlabNewBrick)) return;
+    if (tid == 0) { s_removed = 0u; s_gained = 0u; s_crowded = 0u; s_moved = 0u; s_bad = 0u; }
+    __syncthreads();
+    const int64_t bricks = (int64_t)*bricks_dev;
+    const uint32_t cursor0 = *tail_cursor;
+    uint64_t run_need = 0;   // (uniform) tail positions handed out to the ids before this chunk
+    uint32_t run_touch = 0;
+    for (int64_t c0 = 0; c0 < bricks; c0 += kAllocThreads) {
+        const int64_t id = c0 + tid;
+        uint32_t need = 0u, touch = 0u;
+        if (id < bricks && bmark[id] != 0) {
+            const BrickPlan p = plan[id];
+            touch = 1u;
+            need = p.need;
+            if (p.info & 0xffffffu) atomicAdd(&s_removed, p.info & 0xffffffu);
+            if (p.gained) atomicAdd(&s_gained, p.gained);
+            if (p.info & (1u << 24)) atomicAdd(&s_crowded, 1u);
+            if (p.info & (1u << 25)) s_bad = 1u;
+            if (need) atomicAdd(&s_moved, 1u);
+        }
+        // exclusive prefix of (need, touch) over the workgroup
+        uint32_t in = need, it = touch;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t a = __shfl_up(in, off, 64), b = __shfl_up(it, off, 64);
+            if (lane >= off) { in += a; it += b; }
+        }
+        if (lane == 63) { w_need[wave] = in; w_touch[wave] = it; }
+        __syncthreads();
+        uint32_t on = 0u, ot = 0u, tn = 0u, tt = 0u;
+        for (int w = 0; w < kAllocThreads / 64; ++w) {
+            if (w < wave) { on += w_need[w]; ot += w_touch[w]; }
+            tn += w_need[w]; tt += w_touch[w];
+        }
+        if (touch) {
+            const uint64_t at = (uint64_t)cursor0 + run_need + on + (in - need);
+            bmove[id] = need ? (at + need <= (uint64_t)tail_end ? (uint32_t)at : 0xfffffffeu) : 0xffffffffu;
+            blist[run_touch + ot + (it - touch)] = (uint32_t)id;
+        }
+        run_need += tn;
+        run_touch += tt;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool over = (uint64_t)cursor0 + run_need > (uint64_t)tail_end;
+        if (s_bad || over) atomicOr(flags, kSlabOverflow);
+        else *tail_cursor = cursor0 + (uint32_t)run_need;
+        flags[1] = s_removed;
+        flags[3] = s_gained;
+        flags[4] = s_crowded;
+        flags[11] = s_moved;
+        flags[12] = run_touch;
     }
 }
 
-// one workgroup per touched brick (see the comment above); does nothing when the plan found a reason not to.  CAP = 2 048:
-// the bricks whose staging fits that; CAP = 6 144: the crowded ones only (launched when the plan counted any)
+// one workgroup per touched brick (the list of slab_alloc_kernel, dealt round-robin to a fixed grid: a launch of one workgroup
+// per brick id spent its time starting workgroups that had nothing to do); does nothing when the plan found a reason not to.
+// CAP = 2 048: the bricks whose staging fits that; CAP = 6 144: the crowded ones only (launched when the plan counted any)
 template <int CAP>
-__global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__restrict__ bricks_dev, const uint32_t *__restrict__ flags, Grid g,
+__global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__restrict__ flags, Grid g, const uint32_t *__restrict__ blist,
+                                                           const BrickPlan *__restrict__ plan,
                                                            float4 *__restrict__ pts, uint32_t *__restrict__ pidx,
                                                            uint64_t *__restrict__ keys, uint8_t *__restrict__ alive_s,
                                                            uint32_t *__restrict__ tab, uint4 *__restrict__ top,
                                                            const uint64_t *__restrict__ bkey, uint8_t *__restrict__ bmark,
-                                                           const uint32_t *__restrict__ bend,
-                                                           const uint64_t *__restrict__ nk, const uint32_t *__restrict__ nv, int n_new,
+                                                           uint32_t *__restrict__ bend, const uint32_t *__restrict__ bmove,
+                                                           const uint64_t *__restrict__ nk, const uint32_t *__restrict__ nv,
                                                            const float4 *__restrict__ stage, uint32_t next_id)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char slab_lds[];
@@ -644,16 +721,16 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
     uint32_t *l_t = l_id + CAP;
     uint16_t *l_c = reinterpret_cast<uint16_t *>(l_t + kBrickCells);
     __shared__ int wsum[4];
-    if (*flags != 0u) return;
-    const int64_t id = blockIdx.x;
-    if (id >= (int64_t)*bricks_dev || bmark[id] == 0) return;
+    if (flags[0] != 0u) return;
+    const uint32_t n_touched = flags[12];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (uint32_t li = blockIdx.x; li < n_touched; li += gridDim.x) {
+    const int64_t id = blist[li];
+    const BrickPlan bp = plan[id];
+    if (CAP == kSlabMax ? (bp.info & (1u << 24)) != 0u : (bp.info & (1u << 24)) == 0u) continue;  // (the other launch's brick)
     const uint32_t base = tab[id * kBrickStride], cnt = tab[id * kBrickStride + kBrickCells] - base;
     const uint64_t bk = bkey[id];
-    {   // which of the two launches takes this brick (the same quantity the plan classified it by)
-        const uint32_t stage_n = cnt + (n_new > 0 ? (uint32_t)(slab_lower(nk, n_new, bk + 1) - slab_lower(nk, n_new, bk)) : 0u);
-        if (CAP == kSlabMax ? stage_n > (uint32_t)kSlabMax : stage_n <= (uint32_t)kSlabMax) return;
-    }
+    __syncthreads();  // (the previous brick's LDS is no longer read)
     // a. the survivors, in order, into LDS
     int n_old = 0;
     for (uint32_t c0 = 0; c0 < cnt; c0 += 256u) {
@@ -676,8 +753,7 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
         __syncthreads();
     }
     // b. the brick's new points behind them (sorted by cell; equal cells in staged = id order: the sort is stable)
-    int lo = 0, n_b = 0;
-    if (n_new > 0) { lo = slab_lower(nk, n_new, bk); n_b = slab_lower(nk, n_new, bk + 1) - lo; }
+    const int lo = (int)bp.lo, n_b = (int)bp.n_b;
     for (int k = tid; k < n_b; k += 256) {
         const uint32_t t = nv[lo + k];
         l_p[n_old + k] = stage[t];
@@ -687,8 +763,11 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
     for (int c = tid; c < kBrickCells; c += 256) l_t[c] = 0xffffffffu;
     __syncthreads();
     // c. merged places: an old point goes behind the new points of EARLIER cells, a new one behind the old points of its
-    // own and earlier cells
+    // own and earlier cells.  A brick that moves is written to its new stretch (everything it held is in LDS by now).
     const int total = n_old + n_b;
+    const uint32_t moved_to = bmove[id];
+    const bool moves = moved_to != 0xffffffffu;
+    const uint32_t dst = moves ? moved_to : base;
     for (int e = tid; e < total; e += 256) {
         const uint32_t c = l_c[e];
         int dlo = 0, dhi = 0, dest;
@@ -701,7 +780,7 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
             while (dlo < dhi) { const int mid = (dlo + dhi) >> 1; if (l_c[mid] <= c) dlo = mid + 1; else dhi = mid; }
             dest = (e - n_old) + dlo;
         }
-        const uint32_t pos = base + (uint32_t)dest;
+        const uint32_t pos = dst + (uint32_t)dest;
         const float4 p = l_p[e];
         // (a survivor holds {x, y, position, z}, a staged point {x, y, z, -})
         pts[pos] = e < n_old ? make_map_point(p.x, p.y, map_point_z(p), pos) : make_map_point(p.x, p.y, p.z, pos);
@@ -710,25 +789,41 @@ __global__ __launch_bounds__(256) void slab_rewrite_kernel(const uint32_t *__res
         alive_s[pos] = 1;
         atomicMin(&l_t[c], pos);
     }
-    // what the brick no longer fills; a brick opened by this update takes over its whole stretch (it was its
-    // predecessor's room: the filler keys there are the predecessor's)
-    const uint32_t fill_end = (bmark[id] & 4u) ? bend[id] - base : cnt;
-    for (uint32_t h = (uint32_t)total + (uint32_t)tid; h < fill_end; h += 256u) {
-        alive_s[base + h] = 0;
-        pidx[base + h] = 0xffffffffu;
-        keys[base + h] = (bk << 9) | 511ull;
+    if (moves) {
+        // the new stretch beyond the points, and the whole old one, hold nothing (the old stretch keeps the brick's largest key:
+        // the key-ordered part of the array stays sorted for the next merge)
+        const uint32_t need = bp.need;
+        for (uint32_t h = (uint32_t)total + (uint32_t)tid; h < need; h += 256u) {
+            alive_s[dst + h] = 0;
+            pidx[dst + h] = 0xffffffffu;
+            keys[dst + h] = (bk << 9) | 511ull;
+        }
+        for (uint32_t h = (uint32_t)tid; h < cnt; h += 256u) {
+            alive_s[base + h] = 0;
+            pidx[base + h] = 0xffffffffu;
+            keys[base + h] = (bk << 9) | 511ull;
+        }
+        if (tid == 0) bend[id] = dst + need;
+    } else {
+        // what the brick no longer fills
+        for (uint32_t h = (uint32_t)total + (uint32_t)tid; h < cnt; h += 256u) {
+            alive_s[base + h] = 0;
+            pidx[base + h] = 0xffffffffu;
+            keys[base + h] = (bk << 9) | 511ull;
+        }
     }
     __syncthreads();
     // d. prefix words and row mask
     if (wave == 0) {
         unsigned long long mask;
-        (void)table_from_firsts(l_t, base + (uint32_t)total, tab + id * kBrickStride, lane, mask);
+        (void)table_from_firsts(l_t, dst + (uint32_t)total, tab + id * kBrickStride, lane, mask);
         if (lane == 0) {
             uint32_t *te = reinterpret_cast<uint32_t *>(&top[top_slot_of_key(g, bk)]);
             te[2] = (uint32_t)mask;
             te[3] = (uint32_t)(mask >> 32);
             bmark[id] = 0;
         }
+    }
     }
 }
 
@@ -748,7 +843,7 @@ __global__ __launch_bounds__(256) void top_relay_kernel(const uint32_t *__restri
     const uint4 e = go.top[top_slot(go, bx, by, bz)];
     if (e.x == (uint32_t)id + 1u) ntop[top_slot(gn, bx, by, bz)] = e;
 }
-static hipError_t relay_top(MapBuffers &buf, Grid &g, MapStats &stats, const uint64_t *nk, int n, bool &too_large, hipStream_t st)
+static hipError_t relay_top(MapBuffers &buf, Grid &g, MapStats &stats, int64_t bricks, const uint64_t *nk, int n, bool &too_large, hipStream_t st)
 {
     too_large = false;
     const uint32_t *bricks_dev = buf.counters + kBricksWord;
@@ -769,7 +864,6 @@ static hipError_t relay_top(MapBuffers &buf, Grid &g, MapStats &stats, const uin
     const int64_t slots = top_slots(gn);
     S2M_TRY(map_ensure((void **)&buf.top2, &buf.top2_cap, slots + 1, sizeof(uint4)));
     S2M_TRY(hipMemsetAsync(buf.top2, 0, (size_t)(slots + 1) * sizeof(uint4), st));
-    const int64_t bricks = stats.bricks + kNewBricksMax;  // (an upper bound, as in slab_update)
     hipLaunchKernelGGL(top_relay_kernel, dim3((unsigned)((bricks + 255) / 256)), dim3(256), 0, st, bricks_dev, buf.bkey, go, gn, buf.top2);
     std::swap(buf.top, buf.top2); std::swap(buf.top_cap, buf.top2_cap);
     if (resized) {  // (the growth history is kept per slot: it does not survive a change of the slots)
@@ -790,7 +884,7 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
 {
     done = false;
     const int64_t m = g.m;
-    if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || !buf.bmark || stats.bricks <= 0 || m > buf.scratch_cap) return hipSuccess;
+    if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || !buf.bmark || !buf.bmove || stats.bricks <= 0 || m > buf.scratch_cap) return hipSuccess;
     if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return hipSuccess;
     if (buf.next_id + n_new >= ((int64_t)1 << 32) - 2) return hipSuccess;
     const int n = (int)n_new;
@@ -821,36 +915,56 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     }
     const int big_ok = buf.big_slab > 0 ? 1 : 0;
     // spare rows for bricks this update opens (the tables were allocated with headroom)
-    const int64_t rows = std::min(std::min(buf.tab_cap / kBrickStride, buf.bstart_cap), std::min(std::min(buf.bkey_cap, buf.bmark_cap), buf.bend_cap));
-    const int max_new = (int)std::max<int64_t>(std::min<int64_t>(rows - stats.bricks, kNewBricksMax), 0);
-    const int64_t bricks = stats.bricks + max_new;  // (an upper bound: a merged update's counts may be on their way, bricks may just have opened)
-    uint32_t v[kSlabWords];
+    const int64_t rows = std::min(std::min(buf.tab_cap / kBrickStride, buf.bmove_cap), std::min(std::min(buf.bkey_cap, buf.bmark_cap), buf.bend_cap));
+    const int max_new = (int)std::max<int64_t>(std::min<int64_t>(rows - stats.bricks, (int64_t)1 << 20), 0);
+    const int64_t bricks = stats.bricks + std::min<int64_t>(max_new, n_new);  // (an upper bound: every new point opens at most one brick)
+    S2M_TRY(map_ensure((void **)&buf.bplan, &buf.bplan_cap, rows, 32, 0));
+    S2M_TRY(map_ensure((void **)&buf.blist, &buf.blist_cap, rows, sizeof(uint32_t), 0));
+    BrickPlan *plan = reinterpret_cast<BrickPlan *>(buf.bplan);
+    uint32_t *tail_cursor = buf.counters + kTailWord;
+    uint32_t *head = buf.work_a, *rank = buf.work_b;
+    if (n > 0) {
+        size_t ts = 0;
+        S2M_TRY(rocprim::exclusive_scan(nullptr, ts, head, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+        S2M_TRY(map_ensure_sort_tmp(buf, ts));
+    }
+    const unsigned rewrite_grid = (unsigned)std::max<int64_t>(std::min<int64_t>(bricks, 1024), 1);
+    uint32_t v[kSlabWords + 1];
     for (int attempt = 0;; ++attempt) {
-        if (n > 0)
-            hipLaunchKernelGGL(slab_newbrick_kernel, dim3(1), dim3(256), 0, st, nk_sorted, n, g, buf.top, buf.keys_alt, m, buf.tab, buf.bstart,
-                               buf.bend, buf.bkey, buf.bmark, bricks_dev, max_new, flags);
-        hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, g, buf.bend, buf.tab,
-                           buf.bkey, buf.bmark, alive_s, nk_sorted, n, buf.grow, flags, big_ok);
-        {
-            const uint32_t *src[kSlabWords];
-            for (int k = 0; k < kSlabWords; ++k) src[k] = flags + k;
-            S2M_TRY(mail_post(buf.mail, src, kSlabWords, st));
+        if (n > 0) {
+            hipLaunchKernelGGL(slab_head_kernel, dim3((n + 255) / 256), dim3(256), 0, st, nk_sorted, n, g, head, bricks_dev, flags);
+            size_t ts = buf.sort_tmp_bytes;
+            S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, ts, head, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+            hipLaunchKernelGGL(slab_open_kernel, dim3((n + 255) / 256), dim3(256), 0, st, nk_sorted, n, g, head, rank, buf.top, buf.tab, buf.bend,
+                               buf.bkey, buf.bmark, bricks_dev, max_new, flags);
         }
-        hipLaunchKernelGGL((slab_rewrite_kernel<kSlabMax>), dim3((unsigned)bricks), dim3(256), kLdsSmall, st, bricks_dev, flags, g, buf.pts, buf.pidx,
-                           buf.keys_alt, alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, nk_sorted, nv_sorted, n, stage,
+        hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, g, buf.bend, buf.tab,
+                           buf.bkey, buf.bmark, alive_s, nk_sorted, n, buf.grow, plan, flags, big_ok);
+        hipLaunchKernelGGL(slab_alloc_kernel, dim3(1), dim3(kAllocThreads), 0, st, bricks_dev, buf.bmark, plan, buf.bmove, buf.blist, tail_cursor,
+                           (uint32_t)m, flags);
+        {
+            const uint32_t *src[kSlabWords + 1];
+            for (int k = 0; k < kSlabWords; ++k) src[k] = flags + k;
+            src[kSlabWords] = tail_cursor;
+            S2M_TRY(mail_post(buf.mail, src, kSlabWords + 1, st));
+        }
+        hipLaunchKernelGGL((slab_rewrite_kernel<kSlabMax>), dim3(rewrite_grid), dim3(256), kLdsSmall, st, flags, g, buf.blist, plan, buf.pts, buf.pidx,
+                           buf.keys_alt, alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, buf.bmove, nk_sorted, nv_sorted, stage,
                            (uint32_t)buf.next_id);
-        for (int k = 0; k < kSlabWords; ++k) v[k] = 0u;
-        S2M_TRY(mail_collect(buf.mail, kSlabWords, v, st));
+        for (int k = 0; k <= kSlabWords; ++k) v[k] = 0u;
+        S2M_TRY(mail_collect(buf.mail, kSlabWords + 1, v, st));
         if (v[0] != kSlabWindow || attempt > 0) break;
         // the box of the bricks in use has left the window: re-lay the top array (nothing else was written) and go again
         bool too_large = false;
-        S2M_TRY(relay_top(buf, g, stats, nk_sorted, n, too_large, st));
+        S2M_TRY(relay_top(buf, g, stats, bricks, nk_sorted, n, too_large, st));
         if (too_large) return hipSuccess;  // (the merge reports it)
         S2M_TRY(hipMemsetAsync(flags, 0, kSlabWords * sizeof(uint32_t), st));
     }
+    // what the tail has handed out so far -- also by an attempt that was given up: the merge brings home whatever lies below
+    if (buf.main_ext > 0 && (int64_t)v[kSlabWords] >= buf.main_ext) buf.tail_used = std::min<int64_t>((int64_t)v[kSlabWords], m) - buf.main_ext;
     if (v[0] == 0u && v[4] != 0u) {  // crowded bricks among the touched ones: the form with the large staging area
-        hipLaunchKernelGGL((slab_rewrite_kernel<kSlabBig>), dim3((unsigned)bricks), dim3(256), kLdsBig, st, bricks_dev, flags, g, buf.pts, buf.pidx,
-                           buf.keys_alt, alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, nk_sorted, nv_sorted, n, stage,
+        hipLaunchKernelGGL((slab_rewrite_kernel<kSlabBig>), dim3(std::min(rewrite_grid, 256u)), dim3(256), kLdsBig, st, flags, g, buf.blist, plan, buf.pts,
+                           buf.pidx, buf.keys_alt, alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, buf.bmove, nk_sorted, nv_sorted, stage,
                            (uint32_t)buf.next_id);
         buf.n_big_slab += v[4];  // (diagnostic: bricks that went through the large form)
     }
@@ -859,6 +973,7 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     // the bounds follow the bricks this update opened
     for (int k = 0; k < 3; ++k) { g.blo[k] -= (int)v[5 + k]; g.bhi[k] += (int)v[8 + k]; }
     stats.bricks += v[2];
+    buf.n_moved += v[11];
     g.live += n_new - (int64_t)v[1];
     buf.next_id += n_new;
     if (v[1] > 0u) buf.ids_dense = false;

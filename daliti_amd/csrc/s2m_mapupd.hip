@@ -522,7 +522,7 @@ static hipError_t grow(T **p, int64_t *cap, int64_t need, bool keep = false, hip
     const int64_t c = std::max<int64_t>(need + need / 4, 1024);
     T *q = nullptr;
     S2M_TRY(hipMalloc((void **)&q, (size_t)c * sizeof(T)));
-    note_allocation();
+    note_allocation("update grow", (size_t)c * sizeof(T));
     if (*p) {
         if (keep && *cap > 0) {
             S2M_TRY(hipMemcpyAsync(q, *p, (size_t)*cap * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -554,7 +554,7 @@ static hipError_t ensure_tmp(UpdateBuffers &u, size_t bytes)
     // stalls the device for ~0.1 ms (seen as isolated slow frames while the map's growth per frame crept up)
     const size_t want = std::max<size_t>(2 * bytes, (size_t)1 << 20);
     S2M_TRY(hipMalloc(&u.tmp, want));
-    note_allocation();
+    note_allocation("update tmp", want);
     u.tmp_bytes = want;
     return hipSuccess;
 }
@@ -650,7 +650,7 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
             u.vtab = nullptr;
             u.vtab_cap = 0;
             S2M_TRY(hipMalloc((void **)&u.vtab, (size_t)want * sizeof(unsigned long long)));
-            note_allocation();
+            note_allocation("voxel table", (size_t)want * sizeof(unsigned long long));
             S2M_TRY(hipMemsetAsync(u.vtab, 0xff, (size_t)want * sizeof(unsigned long long), st));
             u.vtab_cap = want;
         }

@@ -179,7 +179,10 @@ int s2m_map_inplace_updates(const s2m_engine *e, int64_t *n);
  * and kept by every update, and the map grows around it in any direction.  A brick's coordinates are (cell >> 3) per axis
  * (arithmetic shift), bricks are ordered by (z, y, x) lexicographically on these signed coordinates, the cells inside a brick
  * by (cell & 7) in (z, y, x) likewise -- an order that does not depend on the box the map occupies, the same after a full
- * build, a merged update and an in-place update.  *m = the extent of the position
+ * build and after a merged update.  An in-place update keeps this order INSIDE every brick; a brick that the update opens,
+ * or that outgrows the stretch of positions it owns, is handed a stretch behind the key-ordered part of the array (the
+ * price of an update whose cost follows the scan and not the map), so between two merges a brick is one contiguous run of
+ * positions whose place among the other bricks' runs is history, not key order.  *m = the extent of the position
  * range; after in-place updates it may exceed s2m_map_size, and order[j] = 0xffffffff marks a position that holds no point
  * (a hole at the end of a rewritten brick).  Candidates tied at exactly the same float squared distance are ranked by
  * this position (tests hand it to the oracle as the tie order). */

@@ -161,7 +161,7 @@ def knn5_brute(map_xyz, q, rank=None):
     return idx, d2, cnt
 
 
-def grid_rank(map_xyz, cell, origin):
+def grid_rank(map_xyz, cell, origin, bricks_only=False):
     """The GPU engine's documented point order, computed independently of it (include/daliti_s2m.h,
     s2m_map_get_order): points sorted by (brick of 8x8x8 cells, cell within the brick, caller index), the cell of a
     coordinate v being floor(((double)v - (double)origin) * (double)(1.0f / cell)) -- float operands, double arithmetic --
@@ -175,6 +175,8 @@ def grid_rank(map_xyz, cell, origin):
         c.append(v.astype(np.int64))
     # a sort on the signed triple (bz, by, bx, local): lexsort takes the LAST key as the primary one
     local = (((c[2] & 7) << 3) | (c[1] & 7)) << 3 | (c[0] & 7)
+    if bricks_only:  # one integer per point that names its brick
+        return ((c[2] >> 3) + (1 << 20)) << 42 | ((c[1] >> 3) + (1 << 20)) << 21 | ((c[0] >> 3) + (1 << 20))
     order = np.lexsort((np.arange(len(p)), local, c[0] >> 3, c[1] >> 3, c[2] >> 3))
     rank = np.empty(len(p), np.uint32)
     rank[order] = np.arange(len(p), dtype=np.uint32)

@@ -36,8 +36,17 @@ def ranked_tree(oracle, eng, map_xyz):
     caller index).  The order is computed here from the grid parameters alone (oracle.grid_rank) and must equal what
     the engine reports -- that pins the documented order, not only consistency between the two sides."""
     info = eng.map_info()
-    rank = oracle.grid_rank(map_xyz, info["cell"], info["origin"])
-    assert np.array_equal(rank, eng.map_rank()), "the engine's point order differs from the documented one"
+    doc = oracle.grid_rank(map_xyz, info["cell"], info["origin"])
+    rank = eng.map_rank()
+    if not np.array_equal(doc, rank):
+        # In-place updates hand a brick that opens, or outgrows its place, a stretch BEHIND the key-ordered part of the array
+        # (include/daliti_s2m.h, s2m_map_get_order): until the next merge the documented order holds inside every brick, and
+        # every brick is one contiguous run of positions.
+        assert eng.map_inplace_updates() > 0, "the engine's point order differs from the documented one"
+        brick = oracle.grid_rank(map_xyz, info["cell"], info["origin"], bricks_only=True)
+        along = brick[np.argsort(rank)]
+        assert 1 + int((along[1:] != along[:-1]).sum()) == len(np.unique(brick)), "a brick's points are not contiguous"
+        assert np.array_equal(np.lexsort((doc, brick)), np.lexsort((rank, brick))), "the order inside a brick differs from the documented one"
     return oracle.KdTree(map_xyz).set_rank(rank)
 
 

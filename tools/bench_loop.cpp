@@ -9,8 +9,11 @@
 #include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "daliti_s2m.h"
+#include "world.h"
 
 extern "C" {
 
@@ -135,6 +138,117 @@ int s2m_bench_frames(s2m_engine *e, int32_t frames, const float *records, int64_
         frame_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         rc = s2m_map_last_update(e, &merged[f]);
         if (rc) return rc;
+    }
+    return S2M_OK;
+}
+
+
+// ---- the moving-trajectory workload (tools/world.h) ----------------------------------------------------------------------
+// `count` consecutive sweeps starting at frame f0, generated on `threads` host threads: sweep k's records at
+// rec + k * rec_stride_floats (room for beams * az records of 12 floats), its record count in n_out[k], its IMU poses at
+// poses + k * n_poses, its predicted / true end-of-sweep states at x_prop / x_true + 36 k.
+int s2m_world_sweeps(const s2m_world *w, int32_t f0, int32_t count, int32_t beams, int32_t az, float *rec, int64_t rec_stride_floats,
+                     int64_t *n_out, s2m_imu_pose *poses, int32_t n_poses, double *x_prop, double *x_true, int32_t threads)
+{
+    if (!w || count < 0 || beams < 1 || az < 1 || !rec || !n_out || !poses || n_poses < 1 || !x_prop || !x_true) return S2M_ERR_ARG;
+    if (rec_stride_floats < (int64_t)beams * az * 12) return S2M_ERR_ARG;
+    const int nt = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; ++t)
+        pool.emplace_back([=] {
+            for (int k = t; k < count; k += nt)
+                n_out[k] = s2m_world_sweep_impl(*w, f0 + k, beams, az, rec + (int64_t)k * rec_stride_floats, poses + (int64_t)k * n_poses, n_poses,
+                                                x_prop + (int64_t)k * S2M_STATE_DOUBLES, x_true + (int64_t)k * S2M_STATE_DOUBLES);
+        });
+    for (auto &th : pool) th.join();
+    return S2M_OK;
+}
+int s2m_world_seed(const s2m_world *w, double span, int64_t m, float *xyz)
+{
+    if (!w || m < 0 || !xyz || !(span > 0.0)) return S2M_ERR_ARG;
+    s2m_world_seed_impl(*w, span, m, xyz);
+    return S2M_OK;
+}
+
+// What the reference's node does per scan (laserMapping.cpp:731-1175) along a trajectory: every frame its own sweep, poses
+// and predicted state -- raw records on the host -> s2m_scan_set_from_raw (undistort + voxel grid) -> s2m_iterated_update
+// from the frame's predicted state -> s2m_map_incremental at the updated state -> s2m_fov_segment at the LiDAR position.
+// Frames 0 .. warm - 1 are part of the drive but not timed.  frame_us[f], how[f] (0 = map rebuilt, 1 = map re-laid by a
+// merge, 2 = updated in place), deleted[f] (points the field-of-view trim removed), n_scan[f] (points after the voxel
+// grid), allocs[f] (device buffers the map code (re)allocated during the frame), x_out (36 per frame: the updated state)
+// for f = 0 .. warm + frames - 1.  prefetch as in s2m_bench_frames.
+int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const float *rec, int64_t rec_stride_floats, const int64_t *n,
+                            int32_t time_off_a, int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses, const double *x_prop,
+                            const double *P0, float leaf, double filter_size_map, double cube_len, int32_t prefetch, double *x_out,
+                            double *frame_us, int32_t *how, int64_t *deleted, int64_t *n_scan, s2m_iter_log *logs, int32_t *allocs)
+{
+    if (!e || frames < 0 || warm < 0 || !rec || !n || !poses || !x_prop || !P0 || !x_out || !frame_us || !how) return S2M_ERR_ARG;
+    double P[S2M_DIM * S2M_DIM];
+    s2m_iter_log log;
+    const int total = warm + frames;
+    int64_t inplace_before = 0;
+    int rc = s2m_map_inplace_updates(e, &inplace_before);
+    if (rc) return rc;
+    int64_t st_prev[6] = {0, 0, 0, 0, 0, 0};
+    (void)s2m_map_update_stats(e, st_prev);
+    for (int f = 0; f < total; ++f) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const float *r = rec + (int64_t)f * rec_stride_floats;
+        const s2m_imu_pose *ps = poses + (int64_t)f * n_poses;
+        const double *xp = x_prop + (int64_t)f * S2M_STATE_DOUBLES;
+        double *x = x_out + (int64_t)f * S2M_STATE_DOUBLES;
+        int64_t n_out = 0, na = 0, nb = 0, nd = 0;
+        rc = s2m_scan_set_from_raw(e, r, 12, n[f], time_off_a, time_off_b, ps, n_poses, xp, leaf, 0, &n_out);
+        if (rc) return rc;
+        if (prefetch >= 1 && f + 1 < total) {
+            rc = s2m_scan_prefetch_raw(e, r + rec_stride_floats, 12, n[f + 1], time_off_a, time_off_b);
+            if (rc) return rc;
+        }
+        std::memcpy(x, xp, S2M_STATE_DOUBLES * sizeof(double));
+        std::memcpy(P, P0, sizeof(P));
+        P[0] += (double)(f & 1) * 1e-15;
+        rc = s2m_iterated_update(e, x, xp, P, &log);
+        if (rc) return rc;
+        if (logs) logs[f] = log;
+        if (prefetch == 2 && f + 1 < total) {
+            rc = s2m_scan_prepare_raw(e, r + rec_stride_floats, 12, n[f + 1], time_off_a, time_off_b, ps + n_poses, n_poses,
+                                      xp + S2M_STATE_DOUBLES, leaf);
+            if (rc) return rc;
+        }
+        rc = s2m_map_incremental(e, x, filter_size_map, 1, &na, &nb);
+        if (rc) return rc;
+        int32_t merged = 0;
+        rc = s2m_map_last_update(e, &merged);
+        if (rc) return rc;
+        int64_t inplace_now = 0;
+        rc = s2m_map_inplace_updates(e, &inplace_now);
+        if (rc) return rc;
+        int32_t h = !merged ? 0 : (inplace_now > inplace_before ? 2 : 1);
+        inplace_before = inplace_now;
+        // pos_lid = pos_end + rot_end * T_L_I (laserMapping.cpp:753)
+        double lid[3];
+        for (int k = 0; k < 3; ++k) lid[k] = x[9 + k] + (x[3 * k] * x[21] + x[3 * k + 1] * x[22] + x[3 * k + 2] * x[23]);
+        rc = s2m_fov_segment(e, lid, cube_len, nullptr, nullptr, &nd);
+        if (rc) return rc;
+        if (nd > 0) {  // the trim changed the map too: how that update was produced counts for the frame
+            rc = s2m_map_last_update(e, &merged);
+            if (rc) return rc;
+            rc = s2m_map_inplace_updates(e, &inplace_now);
+            if (rc) return rc;
+            const int32_t h2 = !merged ? 0 : (inplace_now > inplace_before ? 2 : 1);
+            inplace_before = inplace_now;
+            if (h2 < h) h = h2;
+        }
+        frame_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        how[f] = h;
+        if (deleted) deleted[f] = nd;
+        if (n_scan) n_scan[f] = n_out;
+        if (allocs) {  // device buffers (re)allocated by the map code during this frame (each one stalls the stream)
+            int64_t st_now[6] = {0, 0, 0, 0, 0, 0};
+            (void)s2m_map_update_stats(e, st_now);
+            allocs[f] = (int32_t)(st_now[3] - st_prev[3]);
+            st_prev[3] = st_now[3];
+        }
     }
     return S2M_OK;
 }

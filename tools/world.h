@@ -195,8 +195,8 @@ inline int64_t s2m_world_sweep_impl(const s2m_world &w, int f, int beams, int az
     for (int k = 0; k < 3; ++k) {
         x_true[9 + k] = p0[k] + v[k] * T;
         x_prop[9 + k] = x_true[9 + k] + ep[k];
-        x_true[21 + k] = v[k];
-        x_prop[21 + k] = v[k];
+        x_true[24 + k] = v[k];  // (state layout: rot 0..8, pos 9..11, R_L_I 12..20, T_L_I 21..23, vel 24..26, ...)
+        x_prop[24 + k] = v[k];
     }
     // IMU poses of the propagated (erroneous) trajectory: the same error all along the sweep.  The reference's loop holds
     // the pose's offset time, mean acceleration and angular velocity, velocity, position, attitude (common_lib.h, Pose6D);
