@@ -134,6 +134,10 @@ struct s2m_engine {
     HardRec *d_hrec = nullptr;    // the far points' records: 2 x n_cap (without / with a radius)
     bool nn_valid = false;
     bool nn_complete = false;     // s2m_complete_neighbors has run on the current lists
+    bool nn_nearest = false;      // ... or at least every list's nearest neighbour is proven (what s2m_map_incremental needs)
+    int blind_rounds = 1;         // completion rounds that s2m_map_incremental enqueues without asking whether anything is open
+    float first_round_gain = 16.0f; // ... and the factor on the gate (squared radius) of their first round: radius x 4 (measured on
+                                    // the moving-trajectory leg, x2 / x4 with 1 / 2 blind rounds: median frame 0.51 / 0.50 ms, p99 0.82 / 0.63)
     // far points (scan points the first-shell kernel could not resolve) of the last FIRST rematch pass of a scan and of
     // the last LATER one; -1 = unknown.  A pass whose predecessor in the same position had none runs without the
     // far-point kernel on that bet (spec_mode: 0 never, 1 by history, 2 always -- the last two for tests)
@@ -169,6 +173,8 @@ struct s2m_engine {
 };
 
 namespace {
+
+int complete_lists(s2m_engine *e, int k, int blind, int64_t *n_completed);  // (defined with s2m_complete_neighbors)
 
 int fail(s2m_engine *e, int code, const char *what, hipError_t he = hipSuccess)
 {
@@ -283,6 +289,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
         launch_match(m, group, e->stream);  // hard_count is zero: reset by every reduce launch
         e->nn_valid = true;
         e->nn_complete = false;
+        e->nn_nearest = false;
         e->rematch_pose = pose;
     }
     if (timed) S2M_HIP(e, hipEventRecord(e->ev[1], e->stream));
@@ -433,6 +440,8 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
     }
     e->no_merge = std::getenv("S2M_NO_MERGE") != nullptr;
     e->no_slab = std::getenv("S2M_NO_SLAB") != nullptr;
+    if (const char *g = std::getenv("S2M_FIRST_GAIN")) e->first_round_gain = std::max(1.5f, std::min(256.0f, (float)std::atof(g)));
+    if (const char *g = std::getenv("S2M_BLIND_ROUNDS")) e->blind_rounds = std::max(0, std::min(8, std::atoi(g)));  // (A/B runs)
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&e->ev[i]) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_block, S2M_BLOCK_DOUBLES * sizeof(double)) == hipSuccess;
@@ -561,6 +570,7 @@ void bind_update(s2m_engine *e)
 {
     e->upd.bmark = e->map.bmark;
     e->upd.layout_gen = e->map.layout_gen;
+    e->upd.reserve_hint = std::max(e->upd.reserve_hint, e->n_cap);
 }
 
 // the map after an update: merged into the sorted arrays when possible (s2m_mapedit.hip: in place, else merge_update), else rebuilt
@@ -700,9 +710,10 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     int64_t na = 0, nb = 0;
     // Nearest_Points[i] of the reference is never short (unbounded search): finish the lists that ended at the gate -- when
     // the last rematch pass reported any (block[159]; a scan inside the mapped area has none: no launch, no round trip)
-    if (e->nn_valid && ekf_inited != 0 && e->short_lists != 0) {
-        int rc = s2m_complete_neighbors(e, nullptr);
+    if (e->nn_valid && ekf_inited != 0 && e->short_lists != 0 && !e->nn_complete && !e->nn_nearest && e->n > 0 && e->grid.m > 0) {
+        int rc = complete_lists(e, 1, e->blind_rounds, nullptr);
         if (rc) return rc;
+        e->nn_nearest = true;
     }
     VoxBox vox;
     bind_update(e);
@@ -1362,25 +1373,27 @@ int s2m_map_update_stats(const s2m_engine *e, int64_t stats[6])
 // lists: the points whose 5th distance is not inside the radius searched so far are collected and handed to the
 // far-point kernel again with the radius doubled per round, until every one has its exact five (or the radius exceeds
 // the grid).  Cold path: nothing to do for a scan inside the mapped area.
-int s2m_complete_neighbors(s2m_engine *e, int64_t *n_completed)
+namespace {
+// k = 5: every list complete (s2m_complete_neighbors).  k = 1: only the NEAREST neighbour of every scan point proven -- all
+// that map_incremental reads of a list beyond the gate (laserMapping.cpp:603 tests points_near[0]; the other entries of a
+// list that ends at the gate lie more than sqrt(5) m from the point and cannot pass the test of :612-616, see
+// incr_classify_kernel) -- a radius that a frontier point reaches one or two doublings earlier than the radius that holds
+// five.  blind: that many rounds are enqueued without asking the device whether anything is still open (a round over an
+// empty list costs a few microseconds, a question ~15): the sensor at the edge of the mapped area always has open lists.
+int complete_lists(s2m_engine *e, int k, int blind, int64_t *n_completed)
 {
-    if (n_completed) *n_completed = 0;
-    if (!e) return S2M_ERR_ARG;
-    if (!e->map_ready || !e->nn_valid) return fail(e, S2M_ERR_STATE, "no rematch pass yet");
-    S2M_HIP(e, hipSetDevice(e->device));
     const int n = (int)e->n;
-    if (n == 0 || e->grid.m == 0 || e->nn_complete) return S2M_OK;
-    if (e->short_lists == 0) { e->nn_complete = true; return S2M_OK; }  // the last rematch pass counted them: none
     MatchArgs m;
     m.grid = e->grid; m.pose = e->rematch_pose; m.gates = gates_of(e->cfg);
     m.sx = e->d_scan; m.sy = e->d_scan + e->n_cap; m.sz = e->d_scan + 2 * e->n_cap; m.n = n;
     m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
     m.hard_rec = e->d_hrec; m.hard_off1 = n; m.hard_count = e->d_hard + 3 * e->n_cap;
     m.qheads = e->d_qheads;
+    m.short_k = k;
     const double c = e->grid.c;
     double diag2 = 0.0;
-    for (int k = 0; k < 3; ++k) {  // (the box of the bricks in use, in cells)
-        const double cells = 8.0 * ((double)e->grid.bhi[k] - (double)e->grid.blo[k] + 1.0);
+    for (int q = 0; q < 3; ++q) {  // (the box of the bricks in use, in cells)
+        const double cells = 8.0 * ((double)e->grid.bhi[q] - (double)e->grid.blo[q] + 1.0);
         diag2 += cells * cells;
     }
     const double half_diag = 0.5 * c * std::sqrt(diag2);
@@ -1388,29 +1401,47 @@ int s2m_complete_neighbors(s2m_engine *e, int64_t *n_completed)
     for (int round = 0; round < 64; ++round) {
         // hard_count / qheads are zero here: every reduce launch and every round below leaves them so
         launch_collect_short(m, e->stream);
-        const uint32_t *src[2] = {m.hard_count, m.hard_count + 2};
-        uint32_t v[2] = {0, 0};
-        S2M_HIP(e, mail_fetch(e->mail, src, 2, v, e->stream));
-        const uint32_t cnt = v[0];
-        if (first < 0) first = cnt;
-        bool last = cnt == 0;
-        if (!last) {
+        const bool ask = round >= blind;
+        bool last = false;
+        double reach = 0.0;
+        if (ask) {
+            const uint32_t *src[2] = {m.hard_count, m.hard_count + 2};
+            uint32_t v[2] = {0, 0};
+            S2M_HIP(e, mail_fetch(e->mail, src, 2, v, e->stream));
+            if (first < 0) first = v[0];
+            last = v[0] == 0;
             // the farthest of the open queries from the grid centre, plus half the grid's diagonal: a radius beyond
             // that has seen every map point (a list still short then belongs to a map of fewer than five points)
             float far2;
             std::memcpy(&far2, &v[1], sizeof(far2));
-            const double reach = std::sqrt((double)far2) + half_diag + c;
-            m.gates.knn_d2_gate *= 4.0f;  // radius x 2
-            launch_match_hard_only(m, e->stream);
-            last = (double)m.gates.knn_d2_gate > reach * reach || !(m.gates.knn_d2_gate < 1.0e37f);
+            reach = std::sqrt((double)far2) + half_diag + c;
         }
-        S2M_HIP(e, hipMemsetAsync(m.hard_count, 0, 4 * sizeof(uint32_t), e->stream));
-        S2M_HIP(e, hipMemsetAsync(e->d_qheads, 0, kQueueWords * sizeof(uint32_t), e->stream));
+        if (!last) {
+            m.gates.knn_d2_gate *= (round == 0 && k == 1) ? e->first_round_gain : 4.0f;  // radius x 2
+            launch_match_hard_only(m, e->stream);
+            if (ask) last = (double)m.gates.knn_d2_gate > reach * reach || !(m.gates.knn_d2_gate < 1.0e37f);
+        }
+        launch_far_reset(m.hard_count, e->d_qheads, e->stream);
         if (last) break;
     }
     S2M_HIP(e, hipGetLastError());
-    e->nn_complete = true;
     if (n_completed) *n_completed = first < 0 ? 0 : first;
+    return S2M_OK;
+}
+}  // namespace
+
+int s2m_complete_neighbors(s2m_engine *e, int64_t *n_completed)
+{
+    if (n_completed) *n_completed = 0;
+    if (!e) return S2M_ERR_ARG;
+    if (!e->map_ready || !e->nn_valid) return fail(e, S2M_ERR_STATE, "no rematch pass yet");
+    S2M_HIP(e, hipSetDevice(e->device));
+    if (e->n == 0 || e->grid.m == 0 || e->nn_complete) return S2M_OK;
+    if (e->short_lists == 0) { e->nn_complete = true; return S2M_OK; }  // the last rematch pass counted them: none
+    int rc = complete_lists(e, kK, 0, n_completed);
+    if (rc) return rc;
+    e->nn_complete = true;
+    e->nn_nearest = true;
     return S2M_OK;
 }
 
@@ -1614,6 +1645,7 @@ int loop_finish(s2m_engine *e, double *x, double *P, s2m_iter_log *log)
     e->last_rematch = iters > 0 && rec.rematch[iters - 1] != 0;
     e->nn_valid = true;
     e->nn_complete = false;
+    e->nn_nearest = false;
     e->pass_done = true;
     e->short_lists = -1;
     e->sched_hist.assign((size_t)e->cfg.max_iter, 0);
@@ -2221,7 +2253,7 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
             ++G.waiting;
             e->last_rematch = s.c.rematch != 0;
             e->last_pose = d.pose;
-            if (s.c.rematch) { e->nn_valid = true; e->nn_complete = false; e->rematch_pose = d.pose; }
+            if (s.c.rematch) { e->nn_valid = true; e->nn_complete = false; e->nn_nearest = false; e->rematch_pose = d.pose; }
             e->pass_done = true;
             e->timed_this_pass = false;
         }

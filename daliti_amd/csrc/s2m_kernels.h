@@ -148,6 +148,8 @@ struct UpdateBuffers {
     int64_t boxes_cap = 0;
     float4 *cvt = nullptr;         // conversion / classification scratch
     int64_t cvt_cap = 0;
+    int vox_reach[6] = {0, 0, 0, 0, 0, 0};  // voxels below / above the sensor's that the last scans' PointToAdd lists reached (incr_classify)
+    int64_t reserve_hint = 0;            // points of the largest scan the handle has seen: staging arrays are sized for it at once
     unsigned long long *vtab = nullptr;  // direct-address table over a batch's voxel box (winner per voxel), all ~0 between batches
     int64_t vtab_cap = 0;                // slots
     Mailbox mail;
@@ -169,6 +171,7 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
 hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_host, int nb, int64_t *n_deleted,
                          hipStream_t st);
 hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStream_t st);
+// (the neighbour lists need only be exact up to the gate and in their first entry: s2m_mapupd.hip, incr_classify_kernel)
 hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, const float *sy, const float *sz, int n,
                          const int32_t *nn_idx, const Grid &g, bool have_nn, double fs, float4 **to_add, int64_t *n_add,
                          float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox = nullptr, bool begin_update = false);
@@ -245,6 +248,7 @@ struct MatchArgs {
     uint32_t *qheads = nullptr;  // kQueueShards dequeue heads of match_hard's work queue, kQueueStride words apart
     LoopLaunch loop;             // device-resident loop (s2m_loop.h): state == nullptr for a host-stepped pass
     int32_t far_waves = 0;       // > 0: waves of the far-point launch (few far points expected); 0: as many as stay resident
+    int32_t short_k = kK;        // launch_collect_short: a list is open while its short_k-th entry is not proven (5: the whole list; 1: the nearest)
 };
 // first shell (s2m_match.hip), then -- unless `group` carries bit 0x40000 -- the far-point kernel (s2m_match_far.hip)
 void launch_match(const MatchArgs &a, int group, hipStream_t st);
@@ -257,6 +261,8 @@ void launch_far_points(const MatchArgs &a, bool wide, hipStream_t st);
 // this round)
 void launch_collect_short(const MatchArgs &a, hipStream_t st);
 void launch_match_hard_only(const MatchArgs &a, hipStream_t st);
+// the far-point list's counters and queue heads back to zero (one launch; two memsets are four)
+void launch_far_reset(uint32_t *hard_count, uint32_t *qheads, hipStream_t st);
 
 // ---- s2m_reduce.hip : [plane fit +] residual + Jacobian + normal block ----------------------------
 constexpr int kRedBlock = 512;   // 8 waves per workgroup: 128 partial rows at 65k points for the in-kernel final sum

@@ -410,9 +410,11 @@ hipError_t map_set_window(MapBuffers &buf, Grid &g, const int lo[3], const int h
     if (too_large) return hipSuccess;
     const int64_t slots = top_slots(g);
     if (r || buf.top_cap < slots + 1 || buf.top2_cap < slots + 1 || buf.grow_cap < slots + 1) {
-        S2M_TRY(map_ensure((void **)&buf.top, &buf.top_cap, slots + 1, sizeof(uint4)));
-        S2M_TRY(map_ensure((void **)&buf.top2, &buf.top2_cap, slots + 1, sizeof(uint4)));  // (the spare a re-lay writes: no allocation in a frame)
-        S2M_TRY(map_ensure((void **)&buf.grow, &buf.grow_cap, slots + 1, sizeof(uint32_t)));
+        // (with room for the window to double twice -- a map that is driven through grows along the drive until the
+        // field-of-view trim bounds it -- and the spare a re-lay writes: no allocation in a frame)
+        S2M_TRY(map_ensure((void **)&buf.top, &buf.top_cap, slots + 1, sizeof(uint4), 3 * slots));
+        S2M_TRY(map_ensure((void **)&buf.top2, &buf.top2_cap, slots + 1, sizeof(uint4), 3 * slots));
+        S2M_TRY(map_ensure((void **)&buf.grow, &buf.grow_cap, slots + 1, sizeof(uint32_t), 3 * slots));
         // (the growth history is kept per slot: it does not survive a change of the slots)
         S2M_TRY(hipMemsetAsync(buf.grow, 0, (size_t)(slots + 1) * sizeof(uint32_t), st));
     }

@@ -644,29 +644,30 @@ __global__ __launch_bounds__(kAllocThreads) void slab_alloc_kernel(const uint32_
                                                                    uint32_t tail_end, uint32_t *__restrict__ flags)
 {
     __shared__ uint32_t w_need[16], w_touch[16];
-    __shared__ uint32_t s_removed, s_gained, s_crowded, s_moved, s_bad;
+    __shared__ uint32_t s_sum[5];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (flags[0] & (kSlabOutside | kSlabWindow | kSlabNewBrick)) return;
-    if (tid == 0) { s_removed = 0u; s_gained = 0u; s_crowded = 0u; s_moved = 0u; s_bad = 0u; }
-    __syncthreads();
+    if (tid < 5) s_sum[tid] = 0u;
     const int64_t bricks = (int64_t)*bricks_dev;
     const uint32_t cursor0 = *tail_cursor;
     uint64_t run_need = 0;   // (uniform) tail positions handed out to the ids before this chunk
     uint32_t run_touch = 0;
+    uint32_t my[5] = {0u, 0u, 0u, 0u, 0u};  // this thread's share of: points removed, points gained, crowded, moved, cannot be staged
     for (int64_t c0 = 0; c0 < bricks; c0 += kAllocThreads) {
         const int64_t id = c0 + tid;
         uint32_t need = 0u, touch = 0u;
         if (id < bricks && bmark[id] != 0) {
-            const BrickPlan p = plan[id];
+            const uint4 p = reinterpret_cast<const uint4 *>(plan + id)[0];  // {lo, n_b, need, info}
             touch = 1u;
-            need = p.need;
-            if (p.info & 0xffffffu) atomicAdd(&s_removed, p.info & 0xffffffu);
-            if (p.gained) atomicAdd(&s_gained, p.gained);
-            if (p.info & (1u << 24)) atomicAdd(&s_crowded, 1u);
-            if (p.info & (1u << 25)) s_bad = 1u;
-            if (need) atomicAdd(&s_moved, 1u);
+            need = p.z;
+            my[0] += p.w & 0xffffffu;
+            my[1] += plan[id].gained;
+            my[2] += (p.w >> 24) & 1u;
+            my[3] += need ? 1u : 0u;
+            my[4] += (p.w >> 25) & 1u;
         }
-        // exclusive prefix of (need, touch) over the workgroup
+        // exclusive prefix of (need, touch) over the workgroup; a chunk without a touched brick (most of them) is skipped
+        if (!__syncthreads_or((int)touch)) continue;
         uint32_t in = need, it = touch;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -689,14 +690,22 @@ __global__ __launch_bounds__(kAllocThreads) void slab_alloc_kernel(const uint32_
         run_touch += tt;
         __syncthreads();
     }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        uint32_t v = my[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && v) atomicAdd(&s_sum[q], v);
+    }
+    __syncthreads();
     if (tid == 0) {
         const bool over = (uint64_t)cursor0 + run_need > (uint64_t)tail_end;
-        if (s_bad || over) atomicOr(flags, kSlabOverflow);
+        if (s_sum[4] || over) atomicOr(flags, kSlabOverflow);
         else *tail_cursor = cursor0 + (uint32_t)run_need;
-        flags[1] = s_removed;
-        flags[3] = s_gained;
-        flags[4] = s_crowded;
-        flags[11] = s_moved;
+        flags[1] = s_sum[0];
+        flags[3] = s_sum[1];
+        flags[4] = s_sum[2];
+        flags[11] = s_sum[3];
         flags[12] = run_touch;
     }
 }
@@ -862,12 +871,12 @@ static hipError_t relay_top(MapBuffers &buf, Grid &g, MapStats &stats, int64_t b
     if (too_large) return hipSuccess;
     // the new array is written beside the old one (the kernel reads go.top = buf.top)
     const int64_t slots = top_slots(gn);
-    S2M_TRY(map_ensure((void **)&buf.top2, &buf.top2_cap, slots + 1, sizeof(uint4)));
+    S2M_TRY(map_ensure((void **)&buf.top2, &buf.top2_cap, slots + 1, sizeof(uint4), 3 * slots));
     S2M_TRY(hipMemsetAsync(buf.top2, 0, (size_t)(slots + 1) * sizeof(uint4), st));
     hipLaunchKernelGGL(top_relay_kernel, dim3((unsigned)((bricks + 255) / 256)), dim3(256), 0, st, bricks_dev, buf.bkey, go, gn, buf.top2);
     std::swap(buf.top, buf.top2); std::swap(buf.top_cap, buf.top2_cap);
     if (resized) {  // (the growth history is kept per slot: it does not survive a change of the slots)
-        S2M_TRY(map_ensure((void **)&buf.grow, &buf.grow_cap, slots + 1, sizeof(uint32_t)));
+        S2M_TRY(map_ensure((void **)&buf.grow, &buf.grow_cap, slots + 1, sizeof(uint32_t), 3 * slots));
         S2M_TRY(hipMemsetAsync(buf.grow, 0, (size_t)(slots + 1) * sizeof(uint32_t), st));
     }
     gn.top = buf.top;

@@ -329,14 +329,17 @@ __global__ __launch_bounds__(256) void scatter_kernel(const float4 *__restrict__
 }
 
 // map_incremental() (laserMapping.cpp:582-630): class 1 = PointToAdd, 2 = PointNoNeedDownsample, 0 = skip
+struct VoxReach {
+    int r[6];
+};
 __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const float *__restrict__ sx,
                                                             const float *__restrict__ sy,
                                                             const float *__restrict__ sz, int n,
                                                             const int32_t *__restrict__ nn_idx,
-                                                            const float4 *__restrict__ pts, int have_nn, double fs,
+                                                            const float4 *__restrict__ pts, int have_nn, int map_has5, double fs,
                                                             float4 *__restrict__ pw_out,
                                                             unsigned long long *__restrict__ cls_out, int ax, int ay, int az,
-                                                            uint32_t *__restrict__ vox_ext)
+                                                            VoxReach reach, uint32_t *__restrict__ vox_ext)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float wx = 0.0f, wy = 0.0f, wz = 0.0f;
@@ -360,10 +363,16 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
             cls = 2;
         } else {
             bool need_add = true;
-            if (cnt >= kK) {                                                    // :610
+            // :610-616 run over the five neighbours of the reference's UNBOUNDED search whenever the map holds five points.
+            // The lists here are exact up to the gate (and in their first entry); what is missing or unproven beyond it lies
+            // more than sqrt(5) m from the point, i.e. more than 1.8 m from the voxel centre, and cannot be closer to it
+            // than the point itself (at most 0.44 m): only the entries present can say "no need to add".
+            if (map_has5) {
 #pragma unroll
                 for (int r = 0; r < kK; ++r) {
-                    const float4 q = pts[nn_idx[(int64_t)i * kK + r]];
+                    const int32_t j = nn_idx[(int64_t)i * kK + r];
+                    if (j < 0) continue;
+                    const float4 q = pts[j];
                     if (need_add && dist2(q.x, q.y, map_point_z(q), mid) < dist) need_add = false;  // :612-616
                 }
             }
@@ -373,8 +382,9 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
     // both list flags in one word (low half: PointToAdd, high half: PointNoNeedDownsample): one scan gives both positions
     cls_out[i] = cls == 1 ? 1ull : (cls == 2 ? (1ull << 32) : 0ull);
     }
-    // PointToAdd goes through the voxel rule: the box of its voxels, as distances from the anchor voxel (the sensor's), sizes
-    // the direct-address table of the batch's winners (VoxBox) -- a box that follows the SCAN, whatever the map has grown to
+    // PointToAdd goes through the voxel rule: the box of its voxels sizes the direct-address table of the batch's winners
+    // (VoxBox) -- a box that follows the SCAN, whatever the map has grown to.  Reported as the excess over the reach of the
+    // last scans around the anchor voxel (the sensor's): in a steady stream no wave has anything to report
     uint32_t e[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     if (cls == 1) {
         const float ds = (float)fs;
@@ -382,8 +392,8 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
         const int64_t a[3] = {ax, ay, az};
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            e[q] = (uint32_t)min(max(a[q] - k[q], (int64_t)0), (int64_t)0x7fffffff);
-            e[3 + q] = (uint32_t)min(max(k[q] - a[q], (int64_t)0), (int64_t)0x7fffffff);
+            e[q] = (uint32_t)min(max(a[q] - k[q] - (int64_t)reach.r[q], (int64_t)0), (int64_t)0x7fffffff);
+            e[3 + q] = (uint32_t)min(max(k[q] - a[q] - (int64_t)reach.r[3 + q], (int64_t)0), (int64_t)0x7fffffff);
         }
     }
     wave_max6_to(e, vox_ext);
@@ -594,6 +604,7 @@ hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st)
     const uint8_t *before = u.alive_s;
     S2M_TRY(grow(&u.alive_s, &u.alive_s_cap, g.m + 1));
     if (!u.counters) S2M_TRY(hipMalloc((void **)&u.counters, kUpdWords * sizeof(uint32_t)));
+    if (!u.boxes) S2M_TRY(grow(&u.boxes, &u.boxes_cap, 4096 * 6));  // (the ABI's maximum: the first field-of-view trim allocates nothing)
     {
         // alive_s says which positions hold a point.  It is all ones on a fresh layout (build / merge: layout_gen moved) and
         // stays as the in-place updates left it otherwise (holes at the ends of rewritten bricks): then only the counters
@@ -614,7 +625,7 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
 {
     if (n_added) *n_added = 0;
     if (n <= 0) return hipSuccess;
-    S2M_TRY(grow(&u.stage, &u.stage_cap, u.stage_n + n, true, st));
+    S2M_TRY(grow(&u.stage, &u.stage_cap, std::max(u.stage_n + n, u.reserve_hint), true, st));
     if (!downsample) {  // Add_Points(points, false): every point is inserted (ikd_Tree.cpp:549-570)
         S2M_TRY(hipMemcpyAsync(u.stage + u.stage_n, np, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, st));
         u.stage_n += n;
@@ -622,18 +633,19 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
         return hipSuccess;
     }
     if (u.batch_cap < n) {
+        const int64_t want = std::max<int64_t>(n, u.reserve_hint);
         int64_t c;
-        c = u.batch_cap; S2M_TRY(grow(&u.key, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.key2, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.val, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.val2, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.dnew, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.cnt, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.best_idx, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.best_pos, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.best_d, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.add_flag, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.pos, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.key, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.key2, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.val, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.val2, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.dnew, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.cnt, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_idx, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_pos, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_d, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.add_flag, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.pos, &c, want));
         u.batch_cap = c;
     }
     const int in = (int)n;
@@ -693,7 +705,7 @@ hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_hos
 {
     if (n_deleted) *n_deleted = 0;
     if (nb <= 0 || g.m == 0) return hipSuccess;
-    S2M_TRY(grow(&u.boxes, &u.boxes_cap, (int64_t)nb * 6));
+    S2M_TRY(grow(&u.boxes, &u.boxes_cap, std::max<int64_t>((int64_t)nb * 6, 4096 * 6)));  // (the ABI's maximum: no growth in a frame)
     S2M_TRY(hipMemcpyAsync(u.boxes, boxes_host, (size_t)nb * 6 * sizeof(float), hipMemcpyHostToDevice, st));
     // counters[2] is zero at update_begin and only this entry point adds to it: the count after the launch, minus
     // what earlier calls of the same update reported
@@ -774,20 +786,21 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
     *no_down = nullptr;
     if (n <= 0) return begin_update ? update_begin(u, g, st) : hipSuccess;
     // scratch: cvt holds [pw (n) | list A (n) | list B (n)], flags in add_flag / cnt, positions in pos / best_idx
-    S2M_TRY(grow(&u.cvt, &u.cvt_cap, (int64_t)3 * n));
+    S2M_TRY(grow(&u.cvt, &u.cvt_cap, (int64_t)3 * std::max<int64_t>(n, u.reserve_hint)));
     if (u.batch_cap < n) {
+        const int64_t want = std::max<int64_t>(n, u.reserve_hint);
         int64_t c;
-        c = u.batch_cap; S2M_TRY(grow(&u.key, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.key2, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.val, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.val2, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.dnew, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.cnt, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.best_idx, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.best_pos, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.best_d, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.add_flag, &c, n));
-        c = u.batch_cap; S2M_TRY(grow(&u.pos, &c, n));
+        c = u.batch_cap; S2M_TRY(grow(&u.key, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.key2, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.val, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.val2, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.dnew, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.cnt, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_idx, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_pos, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.best_d, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.add_flag, &c, want));
+        c = u.batch_cap; S2M_TRY(grow(&u.pos, &c, want));
         u.batch_cap = c;
     }
     float4 *pw = u.cvt, *la = u.cvt + n, *lb = u.cvt + 2 * (int64_t)n;
@@ -795,12 +808,14 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
     // the anchor of the voxel box: the sensor's voxel (any voxel would do: the kernel reports distances from it)
     int anchor[3];
     for (int k = 0; k < 3; ++k) anchor[k] = (int)std::fmin(std::fmax(std::floor(pose.t[k] / fs), -1.0e9), 1.0e9);
+    VoxReach reach;
+    for (int k = 0; k < 6; ++k) reach.r[k] = u.vox_reach[k];
     if (!u.counters) {  // (the box words are zero here, and zeroed again by every update_begin behind the read-back)
         S2M_TRY(hipMalloc((void **)&u.counters, kUpdWords * sizeof(uint32_t)));
         S2M_TRY(hipMemsetAsync(u.counters, 0, kUpdWords * sizeof(uint32_t), st));
     }
     hipLaunchKernelGGL(incr_classify_kernel, dim3(nblk(n)), dim3(256), 0, st, pose, sx, sy, sz, n, nn_idx, g.pts,
-                       have_nn ? 1 : 0, fs, pw, fl, anchor[0], anchor[1], anchor[2], u.counters + kUpdVoxWord);
+                       have_nn ? 1 : 0, g.live >= kK ? 1 : 0, fs, pw, fl, anchor[0], anchor[1], anchor[2], reach, u.counters + kUpdVoxWord);
     {
         size_t bytes = 0;
         S2M_TRY(rocprim::exclusive_scan(nullptr, bytes, fl, ps, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), st));
@@ -827,7 +842,12 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
             double prod = 1.0;
             bool ok = true;
             for (int k = 0; k < 3; ++k) {
-                const int64_t lo = (int64_t)anchor[k] - (int64_t)h[4 + k], d = (int64_t)h[4 + k] + (int64_t)h[7 + k] + 1;
+                const int64_t below = (int64_t)reach.r[k] + (int64_t)h[4 + k], above = (int64_t)reach.r[3 + k] + (int64_t)h[7 + k];
+                const int64_t lo = (int64_t)anchor[k] - below, d = below + above + 1;
+                // the reach the next scan is measured against: what this one needed and a little more where it grew, a
+                // little less (never below 16 voxels) where it did not
+                u.vox_reach[k] = (int)std::min<int64_t>(h[4 + k] ? below + 8 : std::max<int64_t>(below - 2, 16), 1 << 20);
+                u.vox_reach[3 + k] = (int)std::min<int64_t>(h[7 + k] ? above + 8 : std::max<int64_t>(above - 2, 16), 1 << 20);
                 ok = ok && d < 2000000 && lo > -1000000000ll && lo < 1000000000ll;
                 b.lo[k] = (int)lo;
                 b.d[k] = (int)d;

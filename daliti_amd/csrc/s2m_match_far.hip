@@ -698,7 +698,8 @@ __global__ __launch_bounds__(256) void collect_short_kernel(MatchArgs a)
     bool want = false;
     uint32_t far_bits = 0u;
     HardRec rec = {0.f, 0.f, 0.f, 0u, 0.f, 0u, 0u, 0u};
-    if (i < a.n && !(a.nn_idx[(int64_t)i * kK + (kK - 1)] >= 0 && a.nn_d2[(int64_t)i * kK + (kK - 1)] <= a.gates.knn_d2_gate)) {
+    const int last = a.short_k - 1;  // the entry that must be proven: the 5th for a complete list, the first for the nearest neighbour only
+    if (i < a.n && !(a.nn_idx[(int64_t)i * kK + last] >= 0 && a.nn_d2[(int64_t)i * kK + last] <= a.gates.knn_d2_gate)) {
         body_to_world(a.pose, a.sx[i], a.sy[i], a.sz[i], rec.wx, rec.wy, rec.wz);
         rec.qi = (uint32_t)i;
         // squared distance to the centre of the grid: the host derives from its maximum the radius at which every
@@ -723,6 +724,17 @@ void launch_collect_short(const MatchArgs &a, hipStream_t st)
 {
     if (a.n <= 0) return;
     hipLaunchKernelGGL(collect_short_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
+}
+
+__global__ __launch_bounds__(256) void far_reset_kernel(uint32_t *__restrict__ hard_count, uint32_t *__restrict__ qheads)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 4) hard_count[i] = 0u;
+    if (i < kQueueWords) qheads[i] = 0u;
+}
+void launch_far_reset(uint32_t *hard_count, uint32_t *qheads, hipStream_t st)
+{
+    hipLaunchKernelGGL(far_reset_kernel, dim3((kQueueWords + 255) / 256), dim3(256), 0, st, hard_count, qheads);
 }
 
 void launch_match_hard_only(const MatchArgs &a, hipStream_t st)

@@ -20,7 +20,13 @@ extra = 12
 sw = w.sweeps(0, frames + warm + extra, beams, az, threads=16)
 print("gen %.1fs: seed %d pts, sweeps n min/mean/max %d/%d/%d" % (time.time() - t0, len(seed), sw["n"].min(), sw["n"].mean(), sw["n"].max()), flush=True)
 e = Engine(max_iter=5)
-e.map_build(seed)
+if os.environ.get("SEED") == "r1":   # the reference's map density: the seed cloud through Add_Points(downsample 0.5 m), as config R1
+    e.map_build(seed[:1])
+    for lo in range(0, len(seed), 1 << 20):
+        e.map_add(seed[lo:lo + (1 << 20)], True, 0.5)
+    print("seed at the reference's density:", e.map_size(), "points", e.map_info())
+else:
+    e.map_build(seed)
 _, _, P0 = synth.filter_inputs()
 st0 = e.map_update_stats()
 r = run_frames(e, sw, P0, frames, warm, cube_len=float(os.environ.get("CUBE", "901")))

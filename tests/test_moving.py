@@ -1,0 +1,111 @@
+"""A drive through a world that is longer than any fixed grid (tools/world.h): raw sweeps from a moving sensor -> undistort +
+voxel grid -> iterated update -> map_incremental -> field-of-view trim, sixty frames, the engine against the oracle's
+sequential restatement of the same loop (laserMapping.cpp:731-1175).  The map leaves the box of its seed by twenty times
+its size, the trim deletes what falls behind, and nothing is ever rebuilt: the map grows brick by brick like ikd-Tree grows
+node by node (ikd_Tree.cpp:477-573).
+
+CPU: the world generator itself (determinism, geometry, the undistortion contract)."""
+import numpy as np
+import pytest
+
+from conftest import bits, ranked_tree
+
+
+def _world(step=9.0):
+    from daliti_amd.world import World
+    return World(24.0, 700.0, step, pitch=8.0, lane=2.5, max_range=40.0, wobble=0.5, wobble_period=60.0)
+
+
+def _rows(a):
+    a = np.ascontiguousarray(a, np.float32).reshape(-1, 3)
+    return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+
+
+def test_world_sweeps_are_deterministic_and_undistort_onto_the_world(oracle):
+    w = _world()
+    a = w.sweeps(3, 2, 16, 256, threads=1)
+    b = w.sweeps(4, 1, 16, 256, threads=2)
+    n = int(b["n"][0])
+    assert a["n"][1] == n and (bits(a["rec"][1][:n]) == bits(b["rec"][0][:n])).all()
+    assert (a["x_prop"][1] == b["x_prop"][0]).all() and (a["poses"][1] == b["poses"][0]).all()
+    # returns beyond the range are dropped, the rest carry their firing time
+    rec = b["rec"][0][:n]
+    assert 0.5 * 16 * 256 < n <= 16 * 256 and np.linalg.norm(rec[:, :3], axis=1).max() <= 40.0 + 0.1
+    assert (np.diff(rec[:, 4]) >= 0).all() and rec[0, 6] == np.float32(0.1)
+    # the sweep is distorted by the motion (9 m per frame: up to 9 m); the reference's backward propagation, fed with the
+    # poses that come with it, puts the points back onto the world's surfaces as seen from the TRUE end-of-sweep pose
+    und, _ = oracle.undistort(rec, 4, 6, b["poses"][0], b["x_prop"][0], True)
+    pw = und.astype(np.float64) + b["x_true"][0][9:12]
+
+    def off_planes(p):
+        return np.minimum.reduce([np.abs(p[:, 2]), np.abs(p[:, 2] - 10.0), np.abs(p[:, 1] - 12.0), np.abs(p[:, 1] + 12.0)])
+    hit_plane = off_planes(pw) < 0.05
+    raw = off_planes(rec[:, :3].astype(np.float64) + b["x_true"][0][9:12]) < 0.05
+    assert hit_plane.mean() > 0.7 and hit_plane.sum() >= raw.sum()
+    # the prediction error is the size asked for
+    e = b["x_prop"][0][9:12] - b["x_true"][0][9:12]
+    assert abs(np.linalg.norm(e) - 0.02) < 1e-12
+    seed = w.seed_map(5000)
+    assert seed[:, 0].min() > -12.1 and seed[:, 0].max() < 12.1 and np.abs(seed[:, 1]).max() < 12.1
+
+
+@pytest.mark.gpu
+def test_sixty_frames_of_a_drive_match_the_oracle(oracle):
+    from daliti_amd import Engine, synth
+    frames, beams, az, fs = 60, 16, 256, 0.5
+    w = _world()
+    seed = w.seed_map(30000)
+    sw = w.sweeps(0, frames, beams, az, threads=8)
+    _, _, P0 = synth.filter_inputs()
+    cfg = oracle.default_cfg(max_iter=5, feat_threshold=50)
+    e = Engine(max_iter=5, feat_threshold=50, cell_size=0.5)
+    e.map_build(seed)
+    om = oracle.Map(seed)
+    fov = oracle.FovSegmenter(1000.0)
+    trimmed = 0
+    seed_box = (seed.min(axis=0), seed.max(axis=0))
+    for f in range(frames):
+        n = int(sw["n"][f])
+        rec, poses, xp = sw["rec"][f][:n], sw["poses"][f], sw["x_prop"][f]
+        # -- the engine
+        nd = e.scan_set_from_raw(rec, 4, 6, poses, xp, fs)
+        got = e.iterated_update(xp, xp, P0)
+        na, nb = e.map_incremental(got["x"], fs)
+        assert e.map_last_update_merged(), f
+        deleted = e.fov_segment(got["x"][9:12], 1000.0)[2]
+        # -- the oracle, stage by stage
+        und, _ = oracle.undistort(rec, 4, 6, poses, xp, True)
+        down = oracle.voxel_downsample(und, fs)
+        assert nd == len(down), f
+        tree = oracle.KdTree(om.points())
+        ref = oracle.iterated_update(cfg, tree, down, xp, xp, P0)
+        assert got["iters"] == ref["iters"] and (got["effct"] == ref["effct"]).all(), (f, got["effct"], ref["effct"])
+        assert np.abs(got["x"] - ref["x"]).max() < 1e-9, (f, np.abs(got["x"] - ref["x"]).max())
+        nn = ref["nn_idx"]
+        to_add, no_down = oracle.map_incremental_lists(down, ref["x"], tree.xyz[np.maximum(nn, 0)], (nn >= 0).sum(1).astype(np.int32), fs)
+        assert (na, nb) == (len(to_add), len(no_down)), (f, na, nb, len(to_add), len(no_down))
+        om.add(to_add, True, fs)
+        om.add(no_down, False)
+        want_deleted = 0
+        for box in fov.step(ref["x"][9:12]):
+            want_deleted += om.delete_box(box)
+        assert deleted == want_deleted, (f, deleted, want_deleted)
+        trimmed += int(want_deleted > 0)
+        assert e.map_size() == om.size(), f
+    st = e.map_update_stats()
+    # the drive left the seed's box far behind, the trim removed map points, nothing was rebuilt -- and most updates touched
+    # only the bricks they changed
+    lo, hi = e.map_grid()
+    assert sw["x_true"][frames - 1][9] > 20 * (seed_box[1][0] - seed_box[0][0]) and trimmed >= 1
+    assert st["rebuilt"] == 0 and st["regridded"] == 0 and e.map_inplace_updates() >= frames // 2, (st, e.map_inplace_updates())
+    assert hi[0] - lo[0] > 50 and st["relaid"] >= 1, (lo, hi, st)     # 4 m bricks: the box of bricks grew 20 x and the window followed
+    pts = e.map_points()
+    assert (bits(_rows(pts)) == bits(_rows(om.points()))).all()
+    # exact neighbours in the engine's order on the final map, for a scan at the last pose
+    x = got["x"]
+    e.residual_pass(x, True)
+    idx, d2 = e.get_neighbors()
+    oi, od, _ = ranked_tree(oracle, e, pts).knn5(oracle.body_to_world(x, e.scan_get()))
+    near = od[:, 4] <= 5.0
+    assert near.sum() > 100 and (bits(d2[near]) == bits(od[near])).all() and (idx[near] == oi[near]).all()
+    e.close()
