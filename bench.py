@@ -116,6 +116,8 @@ def parse(argv=None):
     ap.add_argument("--py-loop", action="store_true",
                     help="drive the timed steps from Python (one ctypes call per step) instead of tools/bench_loop.cpp")
     ap.add_argument("--frames", type=int, default=64, help="frames of the frame_pipeline side leg")
+    ap.add_argument("--moving-frames", type=int, default=520, help="frames of the frame_pipeline_moving side leg (0: skip it)")
+    ap.add_argument("--moving-step", type=float, default=1.0, help="metres the sensor advances per frame in that leg")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="skip the two child rocprofv3 --pmc passes that measure roofline.traffic in this run")
     ap.add_argument("--device-loop", action="store_true",
@@ -834,6 +836,13 @@ def main():
             out["frame_pipeline"] = frame_pipeline(torch, eng, scans[0][0], x_prop0, P0, frames=a.frames)
         except Exception as ex:  # noqa: BLE001 - a side leg never takes the headline down
             out["frame_pipeline"] = {"error": str(ex)[:300]}
+    if rank == 0 and single and side and a.config == "C3" and not a.extrinsic and not a.sequential and a.moving_frames > 0:
+        # the same frame on a MOVING trajectory: new ground every frame, a map that leaves the box of its seed, the
+        # field-of-view trim deleting what falls behind
+        try:
+            out["frame_pipeline_moving"] = frame_pipeline_moving(torch, Engine, synth, a)
+        except Exception as ex:  # noqa: BLE001 - a side leg never takes the headline down
+            out["frame_pipeline_moving"] = {"error": str(ex)[:300]}
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
@@ -1068,6 +1077,66 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
                     "frames one C++ loop (tools/bench_loop.cpp, s2m_bench_frames); not part of `value`; `updates` counts how the map updates of the back-to-back frames (and the two warm-up ones) were "
                     "produced (merged into the grid -- of those `in_place`: only the touched bricks rewritten, the others re-laid the whole map "
                     "out and are the slow frames of the tail -- / rebuilt / re-gridded) and how often a device buffer grew"}
+
+
+def frame_pipeline_moving(torch, Engine, synth, a):
+    """The frame of `frame_pipeline` along a drive (daliti_amd/world.py, tools/world.h): a hall as wide as C3's box and six
+    times as long, seeded with C3's 5 M points over its first square section; a 64-beam sensor sweeps 65 536 rays per
+    frame while it advances `--moving-step` metres (returns beyond 150 m dropped), every frame's predicted pose = truth [+]
+    an IMU-sized error (2 cm, 0.1 deg); cube_len 1000 m (feat.yaml) so that lasermap_fov_segment moves the local-map cube
+    every 150 m and deletes the slab behind it.  One C++ loop (tools/bench_loop.cpp, s2m_bench_frames_moving), front half of
+    frame k + 1 beside frame k's map update as in `frame_pipeline`.  Host-timed per frame."""
+    from daliti_amd.world import World, run_frames
+    frames, step, warm = a.moving_frames, a.moving_step, 4
+    L = synth.CONFIGS["C3"]["L"]
+    t0 = time.perf_counter()
+    w = World(L, 6.0 * L, step)
+    seed = w.seed_map(synth.CONFIGS["C3"]["M"])
+    sw = w.sweeps(0, frames + warm, 64, 1024, threads=min(32, os.cpu_count() or 8))
+    t_gen = time.perf_counter() - t0
+    eng = Engine(max_iter=a.max_iter, device=torch.cuda.current_device())
+    eng.map_build(seed)
+    info0 = eng.map_info()
+    _, _, P0 = synth.filter_inputs()
+    st0 = eng.map_update_stats()
+    ip0 = eng.map_inplace_updates()
+    r = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2)
+    torch.cuda.synchronize()
+    st1 = eng.map_update_stats()
+    ip1 = eng.map_inplace_updates()
+    ms, how = r["ms"][warm:], r["how"][warm:]
+    med = float(np.median(ms))
+    err = np.linalg.norm(r["x"][warm:, 9:12] - sw["x_true"][warm:warm + frames, 9:12], axis=1)
+    trims = [(int(i), int(d)) for i, d in enumerate(r["deleted"]) if d > 0]
+    lo, hi = eng.map_grid()
+    info1 = eng.map_info()
+    worst = int(np.argmax(ms))
+    sys.stderr.write("[bench] moving frame leg: %d frames at %.1f m/frame, median %.3f p99 %.3f max %.3f ms; in place %d merged %d rebuilt %d; "
+                     "trims %s; gen %.1fs\n" % (frames, step, med, float(np.percentile(ms, 99)), float(ms.max()), int((how == 2).sum()),
+                                                 int((how == 1).sum()), int((how == 0).sum()), trims, t_gen))
+    out = {"frames": int(frames), "untimed_warmup_frames": warm, "metres_per_frame": float(step), "metres_driven": float(step * (frames + warm)),
+           "median_ms": med, "p99_ms": float(np.percentile(ms, 99)), "max_ms": float(ms.max()), "max_over_median": float(ms.max() / med),
+           "worst_frame": worst + warm, "frames_per_s": float(1e3 / med),
+           "updates": {"in_place": int((how == 2).sum()), "merged": int((how == 1).sum()), "rebuilt": int((how == 0).sum()),
+                       "regridded": int(st1["regridded"] - st0["regridded"]), "top_array_relaid": int(st1["relaid"] - st0["relaid"]),
+                       "bricks_through_large_form": int(st1["big_bricks"] - st0["big_bricks"]),
+                       "device_allocations_in_timed_frames": int(r["allocs"][warm:].sum()), "map_updates_in_place_total": int(ip1 - ip0)},
+           "fov_trims": [{"frame": f, "points_deleted": d} for f, d in trims],
+           "bets": dict(zip(("won", "lost"), eng.bet_stats())),
+           "scan_points_raw_mean": float(sw["n"][:frames + warm].mean()), "scan_points_after_voxel_grid_mean": float(r["n_scan"].mean()),
+           "iterations_mean": float(r["iters"][warm:].mean()),
+           "map_points_seed": int(len(seed)), "map_points_end": int(eng.map_size()),
+           "seed_box_bricks": int(info0["bricks"]), "bricks_end": int(info1["bricks"]), "brick_box_end": [list(lo), list(hi)],
+           "cell_m": float(info1["cell"]), "cube_len_m": 1000.0, "sensor_range_m": 150.0,
+           "predicted_pose_error": "2 cm, 0.1 deg per frame (truth [+] error, not chained)",
+           "pose_error_vs_truth_m": {"median": float(np.median(err)), "max": float(err.max())},
+           "world": "hall %.0f m wide, %.0f m long, 10 m high, pillars on a 24 m lattice; seed = %d points over its first %.0f m" % (
+               L, 6.0 * L, len(seed), L),
+           "note": "host-timed per frame, raw records cross PCIe; front half of frame k + 1 beside frame k's map update (s2m_scan_prepare_raw); "
+                   "not part of `value`.  how a frame's map update was produced: in_place = only the bricks it touched were rewritten (bricks that "
+                   "open or outgrow their stretch move to the tail of the point array), merged = the whole map re-laid out, rebuilt = re-sorted"}
+    eng.close()
+    return out
 
 
 def measured_copy_peak(torch, nbytes=1 << 30, reps=10):

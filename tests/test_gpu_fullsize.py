@@ -30,6 +30,15 @@ def eng3(c3):
     e.close()
 
 
+@pytest.fixture(scope="module")
+def oracle_c3(c3, oracle):
+    """The oracle's k-d tree over the 5 M-point map and its iterated update of the C3 scan (computed once per module)."""
+    tree = oracle.KdTree(c3["map"])
+    r = oracle.iterated_update(oracle.default_cfg(max_iter=5, nthreads=16), tree, c3["scan"], c3["x_prop"], c3["x_prop"], c3["P"])
+    r["tree"] = tree
+    return r
+
+
 def test_fullsize_first_pass_matches_oracle(eng3, c3, oracle):
     x = c3["x_prop"]
     out = eng3.residual_pass(x, True)
@@ -84,16 +93,14 @@ def test_fullsize_shard_additivity(eng3, c3):
     assert abs(tot - ref["total_res"]) <= 1e-12 * ref["total_res"]
 
 
-def test_fullsize_registration_recovers_true_pose(eng3, c3, oracle):
+def test_fullsize_registration_recovers_true_pose(eng3, c3, oracle, oracle_c3):
     r = eng3.iterated_update(c3["x_prop"], c3["x_prop"], c3["P"])
     assert r["iters"] == 5 and r["rematch_passes"] == 2
     # from (5 cm, ~1 deg) to the noise floor of a 1 cm-noise scene with the propagated state as prior
     assert np.abs(r["x"][9:12] - c3["x_true"][9:12]).max() < 0.02
     assert np.abs(oracle.so3_log(r["x"][:9].reshape(3, 3))).max() < 2e-3
     # pose delta against the CPU path on identical inputs: the north-star bar is 1e-4 m / 1e-4 rad
-    tree = oracle.KdTree(c3["map"])
-    ro = oracle.iterated_update(oracle.default_cfg(max_iter=5, nthreads=16), tree, c3["scan"], c3["x_prop"],
-                                c3["x_prop"], c3["P"])
+    ro = oracle_c3
     assert (ro["effct"] == r["effct"]).all()
     assert np.abs(ro["x"][9:12] - r["x"][9:12]).max() < 1e-9
     dR = ro["x"][:9].reshape(3, 3).T @ r["x"][:9].reshape(3, 3)
@@ -332,22 +339,27 @@ def test_c5_batch_call_equals_one_by_one(c3, eng3, oracle):
         e.close()
 
 
-def test_c3_scan_in_eight_shards_is_bit_identical(c3, eng3):
-    """north star's split at full size on one GPU: the 65 536-point C3 scan in 8 shard_range pieces (8 192 points
+def test_c3_scan_in_eight_shards_is_bit_identical(c3, eng3, oracle_c3):
+    """The device-resident loop (device_loop = 1) against the host-stepped default and the oracle at full C3 size; then north
+    star's split at full size on one GPU: the 65 536-point C3 scan in 8 shard_range pieces (8 192 points
     each) on 8 handles sharing the map, blocks summed by the host (s2m_iterated_update_multi).  The sums are trees
     over the point index on the device and over the handle index on the host, so the result equals the single
     handle's bit for bit -- the same would hold for 8 GPUs, whatever their number (2, 4, 8)."""
     from daliti_amd import Engine
     from daliti_amd.sharding import shard_range
     eng3.scan_set(c3["scan"])
-    eng3.set_feat_queue(())
-    dev = eng3.iterated_update(c3["x_prop"], c3["x_prop"], c3["P"])     # state on the device (the default)
-    eng3.set_config(device_loop=0)                                       # host-stepped, like the multi-handle form
+    try:
+        eng3.set_config(device_loop=1)                                   # the whole loop on the device (opt-in, s2m_loop.h)
+        eng3.set_feat_queue(())
+        dev = eng3.iterated_update(c3["x_prop"], c3["x_prop"], c3["P"])
+    finally:
+        eng3.set_config(device_loop=0)                                   # the default: host-stepped, like the multi-handle form
     eng3.set_feat_queue(())
     ref = eng3.iterated_update(c3["x_prop"], c3["x_prop"], c3["P"])
-    eng3.set_config(device_loop=1)
     assert dev["iters"] == ref["iters"] and (dev["effct"] == ref["effct"]).all()
     assert np.abs(dev["x"] - ref["x"]).max() < 1e-11 and np.abs(dev["P"] - ref["P"]).max() < 1e-13
+    assert dev["iters"] == oracle_c3["iters"] and (dev["effct"] == oracle_c3["effct"]).all()
+    assert np.abs(dev["x"][9:12] - oracle_c3["x"][9:12]).max() < 1e-9
     for n in (2, 8):
         engs = []
         for r in range(n):
@@ -362,6 +374,43 @@ def test_c3_scan_in_eight_shards_is_bit_identical(c3, eng3):
         assert (bits(x) == bits(ref["x"])).all() and (bits(P) == bits(ref["P"])).all(), n
         for e in engs:
             e.close()
+
+
+def test_fullsize_map_incremental_matches_oracle(c3, oracle, oracle_c3):
+    """map_incremental() (laserMapping.cpp:582-630) at full C3 size: after the registration of the 65 536-point scan against
+    the 5 M-point map the engine's two lists have the sizes of the oracle's -- computed from the oracle's own unbounded
+    neighbour lists -- and the resulting map is the oracle's map as a set (Add_Points with the voxel rule over 5 M points)."""
+    from daliti_amd import Engine
+    e = Engine(max_iter=5)
+    e.map_build(c3["map"])
+    e.scan_set(c3["scan"])
+    r = e.iterated_update(c3["x_prop"], c3["x_prop"], c3["P"])
+    ro = oracle_c3
+    assert np.abs(ro["x"] - r["x"]).max() < 1e-9
+    na, nb = e.map_incremental(r["x"], 0.5)
+    nn = ro["nn_idx"]
+    to_add, no_down = oracle.map_incremental_lists(c3["scan"], ro["x"], ro["tree"].xyz[np.maximum(nn, 0)], (nn >= 0).sum(1).astype(np.int32), 0.5)
+    assert (na, nb) == (len(to_add), len(no_down)) and na > 1000, (na, nb, len(to_add), len(no_down))
+    # The voxel rule looks at the old points of a new point's own voxel only (ikd_Tree.cpp:491-520; 0.5 m voxels: the float
+    # arithmetic of Box_of_Point is exact), so the oracle's sequential Add_Points runs on the old points of the touched
+    # voxels -- its map restatement is a per-point loop, 5 M points through it would take minutes -- and the rest of the
+    # map must come through untouched.
+    def voxel_key(p):
+        k = np.floor(p.astype(np.float32) / np.float32(0.5)).astype(np.int64) + (1 << 20)
+        return (k[:, 0] << 42) | (k[:, 1] << 21) | k[:, 2]
+    touched = np.isin(voxel_key(c3["map"]), np.unique(voxel_key(to_add)))
+    assert 1000 < touched.sum() < len(c3["map"]) // 4
+    om = oracle.Map(c3["map"][touched])
+    om.add(to_add, True, 0.5)
+    om.add(no_down, False)
+    want = np.concatenate([c3["map"][~touched], om.points()])
+    assert e.map_size() == len(want)
+
+    def rows(a):
+        a = np.ascontiguousarray(a, np.float32).reshape(-1, 3)
+        return a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+    assert (bits(rows(e.map_points())) == bits(rows(want))).all()
+    e.close()
 
 
 def test_fullsize_merge_update_equals_rebuild(c3, monkeypatch):

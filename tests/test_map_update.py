@@ -633,3 +633,116 @@ def test_inplace_soak_random_updates():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_inplace.py"), "200", "5"], capture_output=True, text=True,
                        timeout=600, cwd=root)
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def _crowded_steps(base, seed):
+    """A brick in the air above the scene that holds ~3 000 points (0.5 m cells: a 4 m cube), then updates THROUGH it while
+    its staging lies between 2 048 and 6 144 points -- the large form of the in-place rewrite (s2m_mapedit.hip, kSlabBig)."""
+    rs = np.random.RandomState(seed)
+    lo = np.float32([0.3, 0.3, 4.3])    # inside one brick for any origin within a cell of the scene's corner: see the test
+
+    def blob(n, s=1.6):
+        return (lo + rs.uniform(0.0, s, (n, 3))).astype(np.float32)
+    return [("add", blob(3000), False),                       # dense build, no tail yet: re-laid by a merge (room + tail)
+            ("add", blob(300), False),                        # the brick is rewritten with 3 300 points staged
+            ("del", np.float32([np.r_[lo + 0.2, lo + 0.9]]), None),
+            ("add", blob(1200), False),                       # 4 000+ points staged (in place or moved to the tail, as its room allows)
+            ("add", blob(400), True),                         # the voxel rule through it: it thins the brick to a point per voxel
+            ("add", base[rs.choice(len(base), 500, replace=False)] + rs.normal(0, 0.03, (500, 3)).astype(np.float32), True)]
+
+
+def _run_crowded(Engine, base, steps, q, x, om=None):
+    e = Engine(cell_size=0.5)
+    e.map_build(base)
+    maps, nns, sizes, inplace = [], [], [], []
+    for kind, arg, ds in steps:
+        if kind == "add":
+            e.map_add(arg, ds, 0.5)
+            if om is not None:
+                om.add(arg, True, 0.5) if ds else om.add(arg, False)
+        else:
+            e.map_delete_boxes(arg)
+            if om is not None:
+                for b in arg:
+                    om.delete_box(b)
+        assert e.map_last_update_merged()
+        inplace.append(e.map_inplace_updates())
+        sizes.append(e.map_size())
+        maps.append(e.map_points().copy())
+        if om is not None:
+            assert sizes[-1] == om.size(), len(maps)
+            assert (bits(_rows(maps[-1])) == bits(_rows(om.points()))).all(), len(maps)
+        e.scan_set(q)
+        e.residual_pass(x, True)
+        nns.append(tuple(a.copy() for a in e.get_neighbors()))
+    return e, maps, nns, sizes, inplace
+
+
+@pytest.mark.gpu
+def test_crowded_brick_is_rewritten_in_place_through_the_large_form(oracle, small_scene, monkeypatch):
+    from daliti_amd import Engine
+    base = small_scene["map"][:14000]
+    steps = _crowded_steps(base, 5)
+    # queries inside and around the crowded brick, and the scene's scan
+    rs = np.random.RandomState(6)
+    q = np.concatenate([small_scene["scan"], (np.float32([0.3, 0.3, 4.3]) + rs.uniform(-0.5, 2.1, (600, 3))).astype(np.float32)])
+    x = small_scene["x_true"]
+    res = {}
+    for mode in ("inplace", "merge"):
+        if mode == "merge":
+            monkeypatch.setenv("S2M_NO_SLAB", "1")
+        else:
+            monkeypatch.delenv("S2M_NO_SLAB", raising=False)
+        e, maps, nns, sizes, inplace = _run_crowded(Engine, base, steps, q, x, oracle.Map(base) if mode == "inplace" else None)
+        st = e.map_update_stats()
+        if mode == "inplace":
+            # every update after the first stayed in place, and the crowded brick went through the large form every time it
+            # was touched (steps 1..4); the blob really sits in ONE brick
+            assert inplace == [0, 1, 2, 3, 4, 5], inplace
+            assert st["big_bricks"] >= 4 and st["rebuilt"] == 0, st
+            info = e.map_info()
+            brick = oracle.grid_rank(maps[0][len(base):], info["cell"], info["origin"], bricks_only=True)
+            assert len(np.unique(brick)) == 1
+            tree = ranked_tree(oracle, e, maps[-1])
+            oi, od, _ = tree.knn5(oracle.body_to_world(x, q))
+            near = od[:, 4] <= 5.0
+            assert (bits(nns[-1][1][near]) == bits(od[near])).all() and (nns[-1][0][near] == oi[near]).all()
+        else:
+            assert inplace[-1] == 0 and st["big_bricks"] == 0
+        res[mode] = (maps, nns, sizes)
+        e.close()
+    a, b = res["inplace"], res["merge"]
+    for k in range(len(steps)):
+        assert a[2][k] == b[2][k], k
+        assert a[0][k].shape == b[0][k].shape and (bits(a[0][k]) == bits(b[0][k])).all(), k
+        assert (a[1][k][0] == b[1][k][0]).all() and (bits(a[1][k][1]) == bits(b[1][k][1])).all(), k
+
+
+@pytest.mark.gpu
+def test_two_threads_drive_two_handles_through_the_large_form(small_scene):
+    """The large form needs 134 KB of dynamic LDS, granted per handle (a process-wide flag raced here and would have left a
+    second device without it): two handles on two host threads both rewrite crowded bricks at once, each result equal to the
+    same sequence run alone."""
+    import threading
+    from daliti_amd import Engine
+    base = small_scene["map"][:14000]
+    q = small_scene["scan"]
+    x = small_scene["x_true"]
+
+    def run(seed, out):
+        e, maps, nns, sizes, inplace = _run_crowded(Engine, base, _crowded_steps(base, seed), q, x)
+        out.append((maps, nns, sizes, inplace, e.map_update_stats()["big_bricks"]))
+        e.close()
+    alone = [[], []]
+    for k in (0, 1):
+        run(11 + k, alone[k])
+    together = [[], []]
+    ts = [threading.Thread(target=run, args=(11 + k, together[k])) for k in (0, 1)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    for k in (0, 1):
+        a, b = alone[k][0], together[k][0]
+        assert b[3] == a[3] == [0, 1, 2, 3, 4, 5] and b[4] >= 4 and a[4] >= 4
+        for s in range(len(a[0])):
+            assert a[2][s] == b[2][s] and (bits(a[0][s]) == bits(b[0][s])).all(), (k, s)
+            assert (a[1][s][0] == b[1][s][0]).all() and (bits(a[1][s][1]) == bits(b[1][s][1])).all(), (k, s)
