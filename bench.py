@@ -1087,7 +1087,7 @@ def frame_pipeline_moving(torch, Engine, synth, a):
     every 150 m and deletes the slab behind it.  One C++ loop (tools/bench_loop.cpp, s2m_bench_frames_moving), front half of
     frame k + 1 beside frame k's map update as in `frame_pipeline`.  Host-timed per frame."""
     from daliti_amd.world import World, run_frames
-    frames, step, warm = a.moving_frames, a.moving_step, 4
+    frames, step, warm = a.moving_frames, a.moving_step, 8
     L = synth.CONFIGS["C3"]["L"]
     t0 = time.perf_counter()
     w = World(L, 6.0 * L, step)
@@ -1132,10 +1132,37 @@ def frame_pipeline_moving(torch, Engine, synth, a):
            "pose_error_vs_truth_m": {"median": float(np.median(err)), "max": float(err.max())},
            "world": "hall %.0f m wide, %.0f m long, 10 m high, pillars on a 24 m lattice; seed = %d points over its first %.0f m" % (
                L, 6.0 * L, len(seed), L),
+           "with_map_publishing": None,
            "note": "host-timed per frame, raw records cross PCIe; front half of frame k + 1 beside frame k's map update (s2m_scan_prepare_raw); "
                    "not part of `value`.  how a frame's map update was produced: in_place = only the bricks it touched were rewritten (bricks that "
                    "open or outgrow their stretch move to the tail of the point array), merged = the whole map re-laid out, rebuilt = re-sorted"}
     eng.close()
+    # the same drive with /Laser_map kept up to date every frame (laserMapping.cpp:1170-1175, 1229-1235): a host mirror fed
+    # by the change log (s2m_map_get_changes) against what the reference does, a flatten of the whole map per frame
+    try:
+        eng = Engine(max_iter=a.max_iter, device=torch.cuda.current_device())
+        eng.map_build(seed)
+        t0 = time.perf_counter()
+        flat = eng.map_points()
+        t_flat5 = (time.perf_counter() - t0) * 1e3
+        rp = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2, publish=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        flat_end = eng.map_points()
+        t_flat_end = (time.perf_counter() - t0) * 1e3
+        msp = rp["ms"][warm:]
+        out["with_map_publishing"] = {
+            "median_ms": float(np.median(msp)), "p99_ms": float(np.percentile(msp, 99)), "max_ms": float(msp.max()),
+            "map_delta_ms": {"median": float(np.median(rp["publish_ms"][warm:])), "p99": float(np.percentile(rp["publish_ms"][warm:], 99))},
+            "map_flatten_ms": {"at_%d_points" % len(flat): float(t_flat5), "at_%d_points" % len(flat_end): float(t_flat_end)},
+            "mirror_points_end": rp["mirror_points"], "map_points_end": rp["map_points"], "whole_map_fetches": rp["mirror_resyncs"],
+            "note": "map_delta_ms = s2m_map_get_changes + applying it to the host mirror (include/daliti_s2m_mirror.hpp), inside the frame; "
+                    "map_flatten_ms = one s2m_map_get_points (rank the ids, gather, D2H of the whole map), what publishing every frame "
+                    "cost before and what the reference's ikdtree.flatten does on the CPU"}
+        assert rp["mirror_points"] == rp["map_points"] == len(flat_end)
+        eng.close()
+    except Exception as ex:  # noqa: BLE001
+        out["with_map_publishing"] = {"error": str(ex)[:300]}
     return out
 
 

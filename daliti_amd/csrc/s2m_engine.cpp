@@ -61,6 +61,8 @@ struct s2m_engine {
     bool no_merge = false;          // S2M_NO_MERGE=1: every update rebuilds the grid from scratch (A/B and tests)
     bool no_slab = false;           // S2M_NO_SLAB=1: no in-place update of the touched bricks, every update merges (A/B and tests)
     int64_t n_inplace = 0;          // updates applied in place (counted among the merged ones too)
+    ChangeLog log;                  // what the updates added / removed since the last s2m_map_get_changes
+    uint64_t log_seq = 0;
     bool last_update_merged = false;
     int64_t n_merged = 0, n_rebuilt = 0, n_regrid = 0;  // how this handle's map updates were produced (s2m_map_update_stats)
     std::mutex stats_mu;            // the lazily fetched counts of a merged update may be asked for by borrowers' threads
@@ -168,6 +170,7 @@ struct s2m_engine {
     Comm comm;  // attached RCCL communicator (multi-GPU form), handle == nullptr when single GPU
     ShmExchange shm;               // or: host shared-memory exchange between the processes of one node (s2m_comm_init_shm)
     std::vector<double> shm_blocks;  // the ranks' blocks of one exchange, padded to a power of two for the tree sum
+    std::vector<float> h_changes;    // s2m_map_get_changes: the added points on their way to the caller's arrays
     int32_t queue[S2M_FEAT_QUEUE + 1] = {0};
     int32_t queue_len = 0;
 };
@@ -477,6 +480,7 @@ int s2m_destroy(s2m_engine *e)
     if (e->d_scan_alt) (void)hipFree(e->d_scan_alt);
     free_map(e->map);
     free_update(e->upd);
+    free_changelog(e->log);
     free_mailbox(e->mail);
     free_voxel(e->vox);
     free_undist(e->und);
@@ -537,6 +541,7 @@ int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride, int64_t m, in
     e->map_ready = true;
     e->nn_valid = false;
     e->built_cell = e->grid.c;
+    e->log.token = 0;  // (a follower of the old map starts over)
     return S2M_OK;
 }
 
@@ -597,6 +602,9 @@ int commit_update(s2m_engine *e)
         return mean < 5.5 || mean > 22.0;
     };
     const bool drift_before = drifted();
+    const int64_t id0 = e->map.next_id;  // the first id this update hands out
+    if (e->log.on && e->log.token != 0 && e->grid.m > 0)   // somebody follows the map: the ids about to disappear, before anything moves
+        launch_log_removed(e->log, e->map.counters + kBricksWord, e->stats.bricks, e->map.bmark, e->grid.tab, e->upd.alive_s, e->grid.pidx, e->stream);
     if (!e->no_merge && !e->no_slab && !drift_before) {  // in place when every touched brick fits where it stands
         he = slab_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, e->upd.counters + kUpdSlabWord, merged, e->stream);
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "slab_update", he);
@@ -608,6 +616,10 @@ int commit_update(s2m_engine *e)
     }
     e->last_update_merged = merged;
     if (merged) ++e->n_merged; else ++e->n_rebuilt;
+    if (e->log.on && e->log.token != 0) {
+        if (merged) launch_log_added(e->log, e->upd.stage, e->upd.stage_n, (uint32_t)id0, e->stream);
+        else e->log.token = 0;  // a rebuild numbers the points anew: whoever follows the map starts over
+    }
     if (!merged) {
         int64_t m_new = 0;
         bool too_large = false;
@@ -1319,6 +1331,79 @@ int s2m_get_neighbors(s2m_engine *e, int32_t *idx, float *d2)
         S2M_HIP(e, hipStreamSynchronize(e->stream));
     }
     if (d2) S2M_HIP(e, hipMemcpy(d2, e->d_nn_d2, n * S2M_K * sizeof(float), hipMemcpyDeviceToHost));
+    return S2M_OK;
+}
+
+int s2m_map_get_ids(s2m_engine *e, uint32_t *ids, int64_t capacity, int64_t *m)
+{
+    if (!e || !m) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map");
+    *m = e->grid.live;
+    if (!ids || e->grid.live == 0) return S2M_OK;
+    if (capacity < e->grid.live) return fail(e, S2M_ERR_CAPACITY, "id buffer too small");
+    S2M_HIP(e, hipSetDevice(e->device));
+    if (e->grid.live > e->stage_cap) {
+        int rc = grow(e, &e->d_stage, e->grid.live);
+        if (rc) return rc;
+        e->stage_cap = e->grid.live;
+    }
+    const uint32_t *rank = nullptr;
+    int rc = caller_index_table(e, &rank);
+    if (rc) return rc;
+    launch_ids_by_rank(e->grid.pidx, rank, e->grid.m, reinterpret_cast<uint32_t *>(e->d_stage), e->stream);
+    S2M_HIP(e, hipMemcpyAsync(ids, e->d_stage, (size_t)e->grid.live * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    return S2M_OK;
+}
+
+int s2m_map_get_changes(s2m_engine *e, uint64_t *token, float *added_xyz, uint32_t *added_ids, int64_t cap_added, int64_t *n_added,
+                        uint32_t *removed_ids, int64_t cap_removed, int64_t *n_removed, int32_t *resync)
+{
+    if (!e || !token || !n_added || !n_removed || !resync) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map");
+    if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
+    S2M_HIP(e, hipSetDevice(e->device));
+    *n_added = 0; *n_removed = 0; *resync = 0;
+    auto fresh = [&]() {
+        e->log.on = true;
+        e->log.token = (++e->log_seq << 8) | 1u;
+        *token = e->log.token;
+    };
+    if (!e->log.on || e->log.token == 0 || *token != e->log.token) {
+        // the caller does not hold the state the log starts from (first call, a rebuild in between, another follower's token)
+        // (room for a field-of-view trim of a few million points: 20 bytes per entry; beyond that the follower fetches the map)
+        S2M_HIP(e, changelog_ensure(e->log, std::max<int64_t>((int64_t)1 << 22, 4 * e->n_cap), e->stream));
+        launch_log_reset(e->log, e->stream);
+        fresh();
+        *resync = 1;
+        return S2M_OK;
+    }
+    const uint32_t *src[3] = {e->log.counts, e->log.counts + 1, e->log.counts + 2};
+    uint32_t v[3] = {0, 0, 0};
+    S2M_HIP(e, mail_fetch(e->mail, src, 3, v, e->stream));
+    if (v[2] != 0u) {  // more changes than the log holds: start over
+        launch_log_reset(e->log, e->stream);
+        fresh();
+        *resync = 1;
+        return S2M_OK;
+    }
+    *n_added = v[0];
+    *n_removed = v[1];
+    if ((v[0] > 0 && (!added_xyz || !added_ids || cap_added < (int64_t)v[0])) || (v[1] > 0 && (!removed_ids || cap_removed < (int64_t)v[1])))
+        return fail(e, S2M_ERR_CAPACITY, "s2m_map_get_changes: buffers too small (the changes are kept)");
+    if (v[0] > 0) {
+        e->h_changes.resize((size_t)v[0] * 4);
+        S2M_HIP(e, hipMemcpyAsync(e->h_changes.data(), e->log.added, (size_t)v[0] * sizeof(float4), hipMemcpyDeviceToHost, e->stream));
+    }
+    if (v[1] > 0) S2M_HIP(e, hipMemcpyAsync(removed_ids, e->log.removed, (size_t)v[1] * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    launch_log_reset(e->log, e->stream);
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    for (uint32_t i = 0; i < v[0]; ++i) {
+        const float *p = e->h_changes.data() + (size_t)i * 4;
+        added_xyz[3 * (size_t)i] = p[0]; added_xyz[3 * (size_t)i + 1] = p[1]; added_xyz[3 * (size_t)i + 2] = p[2];
+        std::memcpy(&added_ids[i], &p[3], sizeof(uint32_t));
+    }
+    fresh();
     return S2M_OK;
 }
 

@@ -180,6 +180,25 @@ hipError_t xyz_to_float4(UpdateBuffers &u, const float *xyz_dev, int64_t stride,
 void launch_map_to_xyz(const float4 *pts, const uint32_t *rank, int64_t m, float *xyz, hipStream_t st);
 // rank[position] = dense caller index of every live position (cold path: a sort of the ids), 0xffffffff for a removed one
 hipError_t caller_ranks(UpdateBuffers &u, const Grid &g, const uint8_t *alive_s, const uint32_t **rank, int64_t *live, hipStream_t st);
+// ---- the change log (s2m_map_get_changes): what the updates since the last report added and removed, by point id ----------
+struct ChangeLog {
+    float4 *added = nullptr;      // {x, y, z, bitcast(id)} of every point added
+    uint32_t *removed = nullptr;  // ids of the points removed
+    uint32_t *counts = nullptr;   // device: [0] added, [1] removed, [2] overflow
+    int64_t cap = 0;
+    bool on = false;              // somebody follows the map (the first s2m_map_get_changes switches it on)
+    uint64_t token = 0;           // the map state of the last report; 0: none yet
+};
+void free_changelog(ChangeLog &c);
+hipError_t changelog_ensure(ChangeLog &c, int64_t cap, hipStream_t st);
+// ids of the points this update removes (alive_s == 0 where a point was), found through the bricks the update marked as
+// touched by a removal: cost proportional to the change.  Runs before the map is rewritten.
+void launch_log_removed(ChangeLog &c, const uint32_t *bricks_dev, int64_t bricks_bound, const uint8_t *bmark, const uint32_t *tab,
+                        const uint8_t *alive_s, const uint32_t *pidx, hipStream_t st);
+void launch_log_added(ChangeLog &c, const float4 *stage, int64_t n, uint32_t first_id, hipStream_t st);
+void launch_log_reset(ChangeLog &c, hipStream_t st);
+// ids in caller order: ids[rank[j]] = pidx[j]
+void launch_ids_by_rank(const uint32_t *pidx, const uint32_t *rank, int64_t m, uint32_t *ids, hipStream_t st);
 // caller indices of a neighbour list: out[i] = nn[i] >= 0 ? pidx[nn[i]] : -1
 void launch_positions_to_indices(const int32_t *nn, const uint32_t *pidx, int64_t count, int32_t *out, hipStream_t st);
 

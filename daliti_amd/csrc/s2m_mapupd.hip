@@ -883,4 +883,98 @@ void launch_positions_to_indices(const int32_t *nn, const uint32_t *pidx, int64_
     if (count > 0) hipLaunchKernelGGL(positions_to_indices_kernel, dim3(nblk(count)), dim3(256), 0, st, nn, pidx, count, out);
 }
 
+
+// ---- the change log ---------------------------------------------------------------------------------------------------
+// The reference flattens and publishes the whole map every frame (laserMapping.cpp:1170-1175, 1229-1235); a node that follows
+// this engine's map keeps a mirror keyed by point id and asks for what changed (s2m_map_get_changes).  Removed ids come from
+// the bricks the update's verdict kernels marked (bit 0 of bmark: a point of the brick was removed): one wave per brick id,
+// the marked ones walk their stretch -- the plan kernel of the in-place update does the same walk.
+__global__ __launch_bounds__(256) void log_removed_kernel(const uint32_t *__restrict__ bricks_dev, const uint8_t *__restrict__ bmark,
+                                                          const uint32_t *__restrict__ tab, const uint8_t *__restrict__ alive_s,
+                                                          const uint32_t *__restrict__ pidx, uint32_t *__restrict__ removed,
+                                                          uint32_t *__restrict__ counts, uint32_t cap)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t id = (int64_t)blockIdx.x * 4 + wave;
+    if (id >= (int64_t)*bricks_dev || (bmark[id] & 1u) == 0) return;
+    const uint32_t base = tab[id * kBrickStride], end = tab[id * kBrickStride + kBrickCells];
+    for (uint32_t j0 = base; j0 < end; j0 += 64u) {
+        const uint32_t j = j0 + (uint32_t)lane;
+        uint32_t pid = 0xffffffffu;
+        const bool gone = j < end && alive_s[j] == 0 && (pid = pidx[j]) != 0xffffffffu;
+        const unsigned long long bal = __ballot(gone);
+        if (bal == 0ull) continue;
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(counts + 1, (uint32_t)__popcll(bal));
+        at = __shfl(at, 0, 64);
+        const uint32_t mine = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (gone) {
+            if (mine < cap) removed[mine] = pid;
+            else counts[2] = 1u;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void log_added_kernel(const float4 *__restrict__ stage, int64_t n, uint32_t first_id, float4 *__restrict__ added,
+                                                        uint32_t *__restrict__ counts, uint32_t cap)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t at = counts[0];  // (the count moves on in a separate launch: every thread reads the same value)
+    if (i >= n) return;
+    if ((uint64_t)at + (uint64_t)i < cap) {
+        float4 p = stage[i];
+        p.w = __uint_as_float(first_id + (uint32_t)i);
+        added[at + i] = p;
+    } else {
+        counts[2] = 1u;
+    }
+}
+__global__ void log_count_kernel(uint32_t *counts, uint32_t add_n, int reset)
+{
+    if (reset) { counts[0] = 0u; counts[1] = 0u; counts[2] = 0u; }
+    else counts[0] += add_n;
+}
+__global__ __launch_bounds__(256) void ids_by_rank_kernel(const uint32_t *__restrict__ pidx, const uint32_t *__restrict__ rank, int64_t m,
+                                                          uint32_t *__restrict__ ids)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m && rank[j] != 0xffffffffu) ids[rank[j]] = pidx[j];
+}
+
+void free_changelog(ChangeLog &c)
+{
+    if (c.added) (void)hipFree(c.added);
+    if (c.removed) (void)hipFree(c.removed);
+    if (c.counts) (void)hipFree(c.counts);
+    c = ChangeLog();
+}
+hipError_t changelog_ensure(ChangeLog &c, int64_t cap, hipStream_t st)
+{
+    if (c.cap >= cap && c.added) return hipSuccess;
+    free_changelog(c);
+    S2M_TRY(hipMalloc((void **)&c.added, (size_t)cap * sizeof(float4)));
+    S2M_TRY(hipMalloc((void **)&c.removed, (size_t)cap * sizeof(uint32_t)));
+    S2M_TRY(hipMalloc((void **)&c.counts, 4 * sizeof(uint32_t)));
+    S2M_TRY(hipMemsetAsync(c.counts, 0, 4 * sizeof(uint32_t), st));
+    c.cap = cap;
+    return hipSuccess;
+}
+void launch_log_removed(ChangeLog &c, const uint32_t *bricks_dev, int64_t bricks_bound, const uint8_t *bmark, const uint32_t *tab,
+                        const uint8_t *alive_s, const uint32_t *pidx, hipStream_t st)
+{
+    if (bricks_bound > 0)
+        hipLaunchKernelGGL(log_removed_kernel, dim3((unsigned)((bricks_bound + 3) / 4)), dim3(256), 0, st, bricks_dev, bmark, tab, alive_s, pidx,
+                           c.removed, c.counts, (uint32_t)c.cap);
+}
+void launch_log_added(ChangeLog &c, const float4 *stage, int64_t n, uint32_t first_id, hipStream_t st)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(log_added_kernel, dim3(nblk(n)), dim3(256), 0, st, stage, n, first_id, c.added, c.counts, (uint32_t)c.cap);
+    hipLaunchKernelGGL(log_count_kernel, dim3(1), dim3(1), 0, st, c.counts, (uint32_t)n, 0);
+}
+void launch_log_reset(ChangeLog &c, hipStream_t st) { hipLaunchKernelGGL(log_count_kernel, dim3(1), dim3(1), 0, st, c.counts, 0u, 1); }
+void launch_ids_by_rank(const uint32_t *pidx, const uint32_t *rank, int64_t m, uint32_t *ids, hipStream_t st)
+{
+    if (m > 0) hipLaunchKernelGGL(ids_by_rank_kernel, dim3(nblk(m)), dim3(256), 0, st, pidx, rank, m, ids);
+}
+
 }  // namespace s2m

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_scan_prefetch_raw", "s2m_scan_prepare_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
     "s2m_get_point_state", "s2m_get_neighbors", "s2m_eskf_update", "s2m_cov_update",
     "s2m_iterated_update", "s2m_iterated_update_batch", "s2m_iterated_update_multi", "s2m_iterated_update_sharded",
-    "s2m_complete_neighbors", "s2m_map_get_order", "s2m_map_grid", "s2m_map_update_stats", "s2m_map_inplace_updates", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_init_shm", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
+    "s2m_complete_neighbors", "s2m_map_get_order", "s2m_map_get_ids", "s2m_map_get_changes", "s2m_map_grid", "s2m_map_update_stats", "s2m_map_inplace_updates", "s2m_comm_unique_id", "s2m_comm_init", "s2m_comm_init_shm", "s2m_comm_destroy", "s2m_feat_queue_get", "s2m_feat_queue_set", "s2m_h_share_model",
     "s2m_set_timing", "s2m_get_timing", "s2m_get_timing_stats", "s2m_bet_stats",
 ]
 
@@ -211,6 +211,25 @@ class Engine:
         n = C.c_int64()
         self._ck(self.lib.s2m_map_inplace_updates(self.h, C.byref(n)))
         return n.value
+
+    def map_ids(self):
+        """Point ids in the order of map_points() (ascending)."""
+        m = C.c_int64()
+        self._ck(self.lib.s2m_map_get_ids(self.h, None, C.c_int64(0), C.byref(m)))
+        out = np.zeros(max(m.value, 1), np.uint32)
+        self._ck(self.lib.s2m_map_get_ids(self.h, _p(out), C.c_int64(len(out)), C.byref(m)))
+        return out[:m.value]
+
+    def map_changes(self, token, capacity=1 << 20):
+        """s2m_map_get_changes: (token, resync, added_xyz, added_ids, removed_ids) since the call that returned `token`."""
+        tok = C.c_uint64(int(token))
+        xyz = np.zeros((capacity, 3), np.float32)
+        ids = np.zeros(capacity, np.uint32)
+        rem = np.zeros(capacity, np.uint32)
+        na, nr, rs = C.c_int64(), C.c_int64(), C.c_int32()
+        self._ck(self.lib.s2m_map_get_changes(self.h, C.byref(tok), _p(xyz), _p(ids), C.c_int64(capacity), C.byref(na), _p(rem),
+                                              C.c_int64(capacity), C.byref(nr), C.byref(rs)))
+        return tok.value, bool(rs.value), xyz[:na.value], ids[:na.value], rem[:nr.value]
 
     def map_order(self):
         """order[j] = caller index of the point at sorted position j (the engine's tie order); 0xffffffff where an in-place

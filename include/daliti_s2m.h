@@ -155,6 +155,20 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
  * packed xyz, in the caller's index order (the order the indices of s2m_get_neighbors refer to: the array given to
  * s2m_map_build; after updates the survivors in index order followed by the added points). */
 int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity_points, int64_t *m);
+/* The map's point ids in the order of s2m_map_get_points (ascending): the index into the array handed to s2m_map_build for
+ * the points of a build, consecutive numbers for the points added since; an id never changes while the map is only updated
+ * (a rebuild -- s2m_map_update_stats, stats[1] -- numbers the points anew). */
+int s2m_map_get_ids(s2m_engine *e, uint32_t *ids, int64_t capacity_points, int64_t *m);
+/* Map publishing proportional to the change (design; the reference flattens and publishes the whole map every frame,
+ * laserMapping.cpp:1170-1175, 1229-1235 -- O(M) per frame): what the updates since the previous call added (packed xyz and
+ * ids) and removed (ids).  A follower keeps a mirror keyed by point id: the first call (*token = 0) and every call whose
+ * token is not the one the previous call returned -- a rebuild in between, more changes than the log holds -- answer
+ * *resync = 1 with no changes: fetch s2m_map_get_points + s2m_map_get_ids and go on from the token returned.  Otherwise the
+ * arrays receive *n_added / *n_removed entries (S2M_ERR_CAPACITY if they are too small: the counts are set, the changes
+ * kept).  One follower per handle.  Cost: the removed ids are collected from the bricks an update touches, the added points
+ * are the update's staging list -- nothing map-sized runs, nothing map-sized crosses PCIe. */
+int s2m_map_get_changes(s2m_engine *e, uint64_t *token, float *added_xyz, uint32_t *added_ids, int64_t capacity_added,
+                        int64_t *n_added, uint32_t *removed_ids, int64_t capacity_removed, int64_t *n_removed, int32_t *resync);
 /* How the last map_add / map_delete_boxes / fov_segment / map_incremental produced the new map (design, not
  * reference): *merged = 1 when the update was merged into the sorted arrays of the current grid, 0 when the grid
  * was rebuilt (a density drift, an empty map; see s2m_map_update_stats). */

@@ -22,7 +22,9 @@ HELPERS = r'''
 // MI355X scan-to-map engine (include/daliti_s2m.h of daliti_amd): replaces the ikd-Tree search, esti_plane, the
 // residual / Jacobian loops and the iterated Kalman update below with HIP kernels behind a C ABI.
 #include "daliti_s2m.h"
+#include "daliti_s2m_mirror.hpp"
 static s2m_engine *s2m_eng = nullptr;
+static s2m_map_mirror s2m_mirror;   // featsFromMap, followed through the engine's change log
 static void s2m_check(int rc, const char *what)
 {
     if (rc == S2M_OK) return;
@@ -168,18 +170,17 @@ UPDATE = r'''#ifdef DALITI_S2M
 
 FLATTEN = r'''#ifdef DALITI_S2M
                 if (pubLaserCloudMap.getNumSubscribers() > 0)
-                {   // the O(map) flatten only when somebody listens to /Laser_map
-                    int64_t s2m_m = 0;
-                    s2m_check(s2m_map_get_points(s2m_eng, nullptr, 0, &s2m_m), "s2m_map_get_points");
-                    std::vector<float> s2m_xyz(3 * (s2m_m > 0 ? s2m_m : 1));
-                    s2m_check(s2m_map_get_points(s2m_eng, s2m_xyz.data(), s2m_m, &s2m_m), "s2m_map_get_points");
+                {   // only when somebody listens to /Laser_map; the host mirror takes this frame's changes from the
+                    // engine (daliti_s2m_mirror.hpp: a few thousand points cross PCIe, not the map)
+                    s2m_check(s2m_mirror.update(s2m_eng), "s2m_map_get_changes");
+                    const int64_t s2m_m = (int64_t)s2m_mirror.ids.size();
                     featsFromMap->clear();
                     featsFromMap->points.resize(s2m_m);
                     for (int64_t i = 0; i < s2m_m; i++)
                     {
-                        featsFromMap->points[i].x = s2m_xyz[3 * i];
-                        featsFromMap->points[i].y = s2m_xyz[3 * i + 1];
-                        featsFromMap->points[i].z = s2m_xyz[3 * i + 2];
+                        featsFromMap->points[i].x = s2m_mirror.xyz[3 * i];
+                        featsFromMap->points[i].y = s2m_mirror.xyz[3 * i + 1];
+                        featsFromMap->points[i].z = s2m_mirror.xyz[3 * i + 2];
                     }
                 }
 #else

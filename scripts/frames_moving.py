@@ -55,3 +55,5 @@ for k in range(frames + warm, frames + warm + extra):
     e.fov_segment(rr["x"][9:12], 901.0); torch.cuda.synchronize(); t.append(time.perf_counter())
     rows.append(np.diff(t) * 1e3)
 print("staged (raw_to_scan, update, map_incremental, fov) median ms:", np.round(np.median(np.array(rows[2:]), axis=0), 3), "iters", rr["iters"], "rematch", rr.get("rematch"))
+if os.environ.get("DUMP"):
+    print("all frames ms:", " ".join("%.3f" % v for v in r["ms"]))

@@ -64,6 +64,11 @@ def test_sixty_frames_of_a_drive_match_the_oracle(oracle):
     fov = oracle.FovSegmenter(1000.0)
     trimmed = 0
     seed_box = (seed.min(axis=0), seed.max(axis=0))
+    # a follower of the map (s2m_map_get_changes): a mirror keyed by point id, brought up to date after every frame
+    token, resync, _, _, _ = e.map_changes(0)
+    assert resync
+    mirror_ids, mirror_xyz = e.map_ids(), e.map_points().copy()
+    assert (mirror_ids == np.arange(len(seed))).all() and (bits(mirror_xyz) == bits(seed)).all()
     for f in range(frames):
         n = int(sw["n"][f])
         rec, poses, xp = sw["rec"][f][:n], sw["poses"][f], sw["x_prop"][f]
@@ -92,6 +97,14 @@ def test_sixty_frames_of_a_drive_match_the_oracle(oracle):
         assert deleted == want_deleted, (f, deleted, want_deleted)
         trimmed += int(want_deleted > 0)
         assert e.map_size() == om.size(), f
+        token, resync, add_xyz, add_ids, rem_ids = e.map_changes(token)
+        assert not resync and len(np.unique(rem_ids)) == len(rem_ids), f
+        gone = np.isin(mirror_ids, rem_ids)
+        assert gone.sum() == len(rem_ids) - np.isin(rem_ids, add_ids).sum(), f    # (a point may come and go within one frame: add, then trim)
+        keep_new = ~np.isin(add_ids, rem_ids)
+        mirror_ids = np.concatenate([mirror_ids[~gone], add_ids[keep_new]])
+        mirror_xyz = np.concatenate([mirror_xyz[~gone], add_xyz[keep_new]])
+        assert len(mirror_ids) == e.map_size() and (np.diff(mirror_ids.astype(np.int64)) > 0).all(), f
     st = e.map_update_stats()
     # the drive left the seed's box far behind, the trim removed map points, nothing was rebuilt -- and most updates touched
     # only the bricks they changed
@@ -101,6 +114,8 @@ def test_sixty_frames_of_a_drive_match_the_oracle(oracle):
     assert hi[0] - lo[0] > 50 and st["relaid"] >= 1, (lo, hi, st)     # 4 m bricks: the box of bricks grew 20 x and the window followed
     pts = e.map_points()
     assert (bits(_rows(pts)) == bits(_rows(om.points()))).all()
+    # the mirror that only ever saw the changes IS the map: same ids, same points, same (ascending id) order
+    assert (mirror_ids == e.map_ids()).all() and (bits(mirror_xyz) == bits(pts)).all()
     # exact neighbours in the engine's order on the final map, for a scan at the last pose
     x = got["x"]
     e.residual_pass(x, True)

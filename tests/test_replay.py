@@ -198,8 +198,12 @@ def test_replay_node_matches_the_oracle(tmp_path, oracle):
         assert m["point_step"] == 32 and m["frame_id"] == "camera_init" and [f[0] for f in m["fields"]] == ["x", "y", "z", "intensity"]
         assert m["records"].shape[0] == len(w)
         assert (np.abs(m["records"][:, :3] - w) <= np.spacing(np.abs(w))).all()
-    # /Laser_map after the last frame: the same point set as the oracle's map
-    mm = rf.parse_length_prefixed_messages((out / "laser_map.pc2s").read_bytes())[0]
+    # /Laser_map after every registered frame (a host mirror fed by s2m_map_get_changes, one whole-map fetch at the start);
+    # after the last frame: the same point set as the oracle's map
+    maps = rf.parse_length_prefixed_messages((out / "laser_map.pc2s").read_bytes())
+    assert len(maps) == len(frames) - 1 and "1 whole-map fetches" in r.stderr, r.stderr[-300:]
+    assert [m["records"].shape[0] for m in maps] == [o[4] for o in odom]
+    mm = maps[-1]
     assert mm["point_step"] == 48 and mm["records"].shape[0] == om.size()
 
     def rows_sorted(a):

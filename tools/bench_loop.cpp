@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "daliti_s2m.h"
+#include "daliti_s2m_mirror.hpp"
 #include "world.h"
 
 extern "C" {
@@ -180,7 +181,8 @@ int s2m_world_seed(const s2m_world *w, double span, int64_t m, float *xyz)
 int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const float *rec, int64_t rec_stride_floats, const int64_t *n,
                             int32_t time_off_a, int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses, const double *x_prop,
                             const double *P0, float leaf, double filter_size_map, double cube_len, int32_t prefetch, double *x_out,
-                            double *frame_us, int32_t *how, int64_t *deleted, int64_t *n_scan, s2m_iter_log *logs, int32_t *allocs)
+                            double *frame_us, int32_t *how, int64_t *deleted, int64_t *n_scan, s2m_iter_log *logs, int32_t *allocs,
+                            int32_t publish, double *publish_us, int64_t *mirror_stats)
 {
     if (!e || frames < 0 || warm < 0 || !rec || !n || !poses || !x_prop || !P0 || !x_out || !frame_us || !how) return S2M_ERR_ARG;
     double P[S2M_DIM * S2M_DIM];
@@ -191,6 +193,13 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
     if (rc) return rc;
     int64_t st_prev[6] = {0, 0, 0, 0, 0, 0};
     (void)s2m_map_update_stats(e, st_prev);
+    // publish != 0: the node also keeps /Laser_map up to date every frame (laserMapping.cpp:1170-1175, 1229-1235) -- a host
+    // mirror fed by s2m_map_get_changes (daliti_s2m_mirror.hpp); publish_us[f] = that call's share of the frame
+    s2m_map_mirror mirror;
+    if (publish) {
+        rc = mirror.update(e);  // the one whole-map fetch, before the drive
+        if (rc) return rc;
+    }
     for (int f = 0; f < total; ++f) {
         const auto t0 = std::chrono::steady_clock::now();
         const float *r = rec + (int64_t)f * rec_stride_floats;
@@ -239,6 +248,12 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
             inplace_before = inplace_now;
             if (h2 < h) h = h2;
         }
+        if (publish) {
+            const auto tp = std::chrono::steady_clock::now();
+            rc = mirror.update(e);
+            if (rc) return rc;
+            if (publish_us) publish_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp).count();
+        }
         frame_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         how[f] = h;
         if (deleted) deleted[f] = nd;
@@ -249,6 +264,13 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
             allocs[f] = (int32_t)(st_now[3] - st_prev[3]);
             st_prev[3] = st_now[3];
         }
+    }
+    if (publish && mirror_stats) {
+        int64_t m = 0;
+        (void)s2m_map_size(e, &m);
+        mirror_stats[0] = (int64_t)mirror.ids.size();
+        mirror_stats[1] = m;
+        mirror_stats[2] = mirror.resyncs;
     }
     return S2M_OK;
 }

@@ -10,7 +10,8 @@
 // and writes what the node writes:
 //   * Log/mat_out.txt rows, one per ESKF iteration (:936-937), with the same iostream formatting,
 //   * /cloud_effected (laserCloudOri in the world frame, :1213-1227) as serialised PointCloud2 (PointXYZI),
-//   * the flattened map of the last frame (/Laser_map, :1170-1175, 1229-1235) as PointCloud2 (PointXYZINormal),
+//   * the map after every frame (/Laser_map, :1170-1175, 1229-1235) as PointCloud2 (PointXYZINormal): a host mirror kept
+//     up to date from the engine's change log (include/daliti_s2m_mirror.hpp), not a flatten of the device map per frame,
 //   * odometry.txt: time, position, rotation, iterations, last effct_feat_num, map size (full precision).
 // The TIS / zeta fusion (:1105-1129), the TIS fallback (:1054-1063) and every publisher stay in the node.
 //
@@ -32,6 +33,7 @@
 #include <vector>
 
 #include "daliti_s2m.h"
+#include "daliti_s2m_mirror.hpp"
 #include "daliti_s2m_wire.h"
 
 #define CK(call)                                                                                     \
@@ -159,6 +161,8 @@ int main(int argc, char **argv)
     fodom << std::setprecision(17);
 
     bool first_scan = true, have_map = false;
+    s2m_map_mirror mirror;
+    std::vector<uint8_t> map_msgs;
     double first_lidar_time = 0.0;
     std::vector<float> xyz, world;
     std::vector<int32_t> ridx;
@@ -244,6 +248,14 @@ int main(int argc, char **argv)
                                     nxt.state, (float)fs_surf));
         if (!log.ekf_stop) CK(s2m_map_incremental(eng, x, fs_map, 1, &n_add, &n_nodown));
         CK(s2m_map_size(eng, &m_map));
+        {   // ikdtree.flatten -> featsFromMap -> /Laser_map (:1170-1175, 1229-1235), every frame: the mirror takes this frame's
+            // changes (a few thousand points) and is published as it stands
+            CK(mirror.update(eng));
+            const size_t m = mirror.ids.size();
+            std::vector<float> rec(m * S2M_PXYZIN_FLOATS, 0.0f);
+            for (size_t i = 0; i < m; ++i) std::memcpy(&rec[i * S2M_PXYZIN_FLOATS], &mirror.xyz[3 * i], 3 * sizeof(float));
+            append_msg(map_msgs, 1, f, obs_end, rec.data(), (uint32_t)m);
+        }
         fodom << lidar_beg_time - first_lidar_time;
         for (int i = 0; i < 3; ++i) fodom << " " << x[9 + i];
         for (int i = 0; i < 9; ++i) fodom << " " << x[i];
@@ -254,16 +266,11 @@ int main(int argc, char **argv)
         std::ofstream fe(dir + "/cloud_effected.pc2s", std::ios::binary);
         fe.write(reinterpret_cast<const char *>(effected_msgs.data()), (std::streamsize)effected_msgs.size());
     }
-    if (have_map) {  // ikdtree.flatten -> featsFromMap -> /Laser_map (:1170-1175, 1229-1235), last frame only here
-        int64_t m = 0;
-        CK(s2m_map_get_points(eng, nullptr, 0, &m));
-        std::vector<float> mp((size_t)std::max<int64_t>(m, 1) * 3), rec((size_t)m * S2M_PXYZIN_FLOATS, 0.0f);
-        CK(s2m_map_get_points(eng, mp.data(), m, &m));
-        for (int64_t i = 0; i < m; ++i) std::memcpy(&rec[(size_t)i * S2M_PXYZIN_FLOATS], &mp[3 * (size_t)i], 3 * sizeof(float));
-        std::vector<uint8_t> out;
-        append_msg(out, 1, n_frames, 0.0, rec.data(), (uint32_t)m);
+    if (have_map) {
         std::ofstream fm(dir + "/laser_map.pc2s", std::ios::binary);
-        fm.write(reinterpret_cast<const char *>(out.data()), (std::streamsize)out.size());
+        fm.write(reinterpret_cast<const char *>(map_msgs.data()), (std::streamsize)map_msgs.size());
+        std::fprintf(stderr, "replay_node: /Laser_map followed through the change log: %lld whole-map fetches in %u frames\n",
+                     (long long)mirror.resyncs, n_frames);
     }
     s2m_destroy(eng);
     return 0;
