@@ -79,7 +79,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "R1"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "C5b", "R1"])
     ap.add_argument("--mode", default="auto", choices=["auto", "sharded", "replicas"],
                     help="auto: replicas for C5, sharded otherwise")
     ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
@@ -249,7 +249,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfgd = synth.CONFIGS[a.config]
-    mode = a.mode if a.mode != "auto" else ("replicas" if a.config == "C5" else "sharded")
+    mode = a.mode if a.mode != "auto" else ("replicas" if a.config in ("C5", "C5b") else "sharded")
     host_multi = a.collective == "host" and mode == "sharded"
     n_dev = torch.cuda.device_count()
     n_shards = (a.shards or max(a.gpus, 1)) if host_multi else 1
@@ -282,7 +282,7 @@ def main():
         for i in range(n_shards):
             sc, n_scan_total = sharded_scan(scaling, i)
             scans.append((sc, synth.SENSOR_POS))
-    elif mode == "replicas" and (a.config == "C5" or world > 1):
+    elif mode == "replicas" and (a.config in ("C5", "C5b") or world > 1):
         nrep = a.replicas or cfgd.get("replicas", world)
         for k in range(rank, nrep, world):   # seeds 2..9, sensor offsets (k - 3.5) * 2 m in x
             sc, pos = synth.replica_scan(a.config, k)
@@ -752,8 +752,17 @@ def main():
                 out["config"]["collective_probe_ms_per_step"] = dict(exchange_probe, **{"rccl" if a.backend == "nccl" else "torch_callback": "timed out"})
                 out["rccl_probe"] = "timed out"
                 C.CDLL(None).fflush(None)
-                sys.stdout.write(json.dumps(out) + "\n")
+                line = None
+                for _ in range(5):   # (the main thread may be adding to `out` while this one serialises it)
+                    try:
+                        line = json.dumps(out)
+                        break
+                    except RuntimeError:
+                        time.sleep(0.01)
+                sys.stdout.write((line or json.dumps({"error": "watchdog: the record could not be serialised"})) + "\n")
                 sys.stdout.flush()
+            # exit status 0 on purpose: the headline was measured before the probe and its line says "rccl_probe": "timed out";
+            # a non-zero status would make the launcher throw the whole record away
             os._exit(0)
         dog = threading.Timer(float(os.environ.get("S2M_PROBE_TIMEOUT_S", "120")), expire)
         dog.daemon = True
@@ -820,6 +829,10 @@ def main():
         sat = c5_batch(torch, Engine, synth, eng, a, k=24, steps=20, warmup=3)
         out["c5_batch"]["at_24_in_flight"] = {q: sat[q] for q in ("scans_in_flight", "scans_per_sec", "value", "unit",
                                                                   "algorithmic_GBps", "frac", "pose_error_vs_truth_m_max")}
+        try:  # the node's operating point: the same scan with an IMU-sized prediction error instead of BASELINE's 1 deg / 5 cm
+            out["realistic_prior"] = realistic_prior(torch, eng, synth, scans[0][0], P0)
+        except Exception as ex:  # noqa: BLE001
+            out["realistic_prior"] = {"error": str(ex)[:300]}
         try:  # the headline's bet on an empty far-point list against input that changes every step
             out["varying_scan"] = varying_scan(torch, Engine, synth, eng, a)
         except Exception as ex:  # noqa: BLE001 - a side leg never takes the headline down
@@ -877,27 +890,47 @@ def other_configs(torch, Engine, synth, a, c3_map, steps=50, warmup=5):
             x_true, x_prop, P0 = synth.filter_inputs()
             cl = CLoop([e], [x_prop], [P0], 0)
             cl.run(warmup)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            it, rm = cl.run(steps)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            res[name] = {"ms_per_step": 1e3 * dt / steps, "value": n * it / dt, "unit": "evals/s",
-                         "eskf_iters_per_sec": it / dt, "scan_points": int(n), "map_points": int(m_pts), "steps": steps,
+            runs = []
+            for _ in range(3):   # the median of three runs (single-shot side legs were noisy: VERDICT r4 weak #11)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                it, rm = cl.run(steps)
+                torch.cuda.synchronize()
+                runs.append((time.perf_counter() - t0, it, rm))
+            runs.sort(key=lambda r: r[0])
+            dt, it, rm = runs[1]
+            res[name] = {"ms_per_step": 1e3 * dt / steps, "ms_per_step_min_max": [1e3 * runs[0][0] / steps, 1e3 * runs[-1][0] / steps],
+                         "value": n * it / dt, "unit": "evals/s",
+                         "eskf_iters_per_sec": it / dt, "scan_points": int(n), "map_points": int(m_pts), "steps": steps, "repeats": 3,
                          "iters_per_step": it / steps, "rematch_passes_per_step": rm / steps,
                          "pose_error_vs_truth_m": float(np.abs(cl.x[0][9:12] - x_true[9:12]).max())}
+            if name == "C4":
+                # the batched entry point where HBM is the roof: 8 and 24 scans of 65 536 points in flight against this
+                # 20 M-point map (320 MB of points: C3 / C5 sit inside the 256 MB Infinity Cache, this does not)
+                try:
+                    b8 = c5_batch(torch, Engine, synth, e, a, k=8, steps=20, warmup=3, config="C5b")
+                    b24 = c5_batch(torch, Engine, synth, e, a, k=24, steps=10, warmup=2, config="C5b")
+                    keys = ("scans_in_flight", "scans_per_sec", "scans_per_sec_min_max", "value", "unit", "algorithmic_GBps", "frac",
+                            "pose_error_vs_truth_m_max", "repeats")
+                    res["C5b_batch_on_C4_map"] = {"k8": {q: b8[q] for q in keys}, "k24": {q: b24[q] for q in keys},
+                                                  "note": "counter traffic of this leg: profiles/*_C5b_pmc.json (separate rocprofv3 --pmc passes of "
+                                                          "`bench.py --config C5b --replicas 24`)"}
+                except Exception as ex:  # noqa: BLE001
+                    res["C5b_batch_on_C4_map"] = {"error": str(ex)[:200]}
             e.close()
         except Exception as ex:  # noqa: BLE001 - a side leg never takes the headline down
             res[name] = {"error": str(ex)[:200]}
     return res
 
 
-def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5, fence=None):
+def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5, fence=None, config="C5", repeats=3):
     """BASELINE configs[4] on ONE GPU: k independent 65,536-point scans (seeds 2.., sensor offsets (i - 3.5) * 2 m)
-    in flight through s2m_iterated_update_batch from one host thread, searching the map `owner` already holds."""
+    in flight through s2m_iterated_update_batch from one host thread, searching the map `owner` already holds
+    (config "C5b": the scans of the 440 m box against C4's 20 M-point map).  The timed `steps` are run `repeats` times
+    and the MEDIAN run reported (side legs were single-shot and noisy: VERDICT r4 weak #11)."""
     engs, keep, filt = [], [], []
     for i in range(k):
-        sc, pos = synth.replica_scan("C5", i)
+        sc, pos = synth.replica_scan(config, i)
         e = Engine(max_iter=a.max_iter, cell_size=a.cell, device=owner.cfg.device, feat_threshold=100,
                    device_loop=1 if a.device_loop else 0)
         e.map_share(owner)
@@ -910,11 +943,15 @@ def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5, fence=None
     cl = CLoop(engs, [f[1] for f in filt], [f[2] for f in filt], 1)
     cl.run(warmup)
     fence = fence or torch.cuda.synchronize   # N > 1: barrier + synchronise, so that every rank's batches run side by side
-    fence()
-    t0 = time.perf_counter()
-    it, rm = cl.run(steps)
-    fence()
-    dt = time.perf_counter() - t0
+    runs = []
+    for _ in range(max(repeats, 1)):
+        fence()
+        t0 = time.perf_counter()
+        it, rm = cl.run(steps)
+        fence()
+        runs.append((time.perf_counter() - t0, it, rm))
+    runs.sort(key=lambda r: r[0])
+    dt, it, rm = runs[len(runs) // 2]
     n = 65536
     reuse = it - rm
     algo_bytes = float(n) * (rm * BYTES_REMATCH + reuse * BYTES_REUSE)
@@ -925,10 +962,38 @@ def c5_batch(torch, Engine, synth, owner, a, k=8, steps=40, warmup=5, fence=None
             "scans_per_sec": k * steps / dt, "value": n * it / dt, "unit": "evals/s",
             "ms_per_batch": 1e3 * dt / steps, "eskf_iters_per_sec": it / dt,
             "algorithmic_GBps": algo_bytes / dt / 1e9, "frac": algo_bytes / dt / 1e9 / HBM_PEAK_GBS,
-            "pose_error_vs_truth_m_max": max(errs),
+            "pose_error_vs_truth_m_max": max(errs), "repeats": len(runs), "scans_per_sec_min_max": [k * steps / runs[-1][0], k * steps / runs[0][0]],
             "note": "BASELINE configs[4] shape on one device: %d scans (seeds 2..%d) vs the resident 5M-pt map, one host "
                     "thread, s2m_iterated_update_batch driven by tools/bench_loop.cpp; algorithmic bytes = 88 B per "
                     "eval of a rematch pass + 28 B per eval of a reuse pass" % (k, 1 + k)}
+
+
+def realistic_prior(torch, eng, synth, scan, P0, steps=60, warmup=10):
+    """BASELINE's filter inputs (1 deg / 5 cm off) stay the headline; a node at 10 Hz with a healthy IMU
+    predicts within ~2 cm / 0.1 deg (laserMapping.cpp:750, 820): the first pass has next to no far points and the loop
+    converges early.  Same scan, same map, same loop; median of three runs."""
+    x_true, _, _ = synth.filter_inputs()
+    out = {}
+    for label, dth, dp in (("imu_sized_2cm_0.1deg", np.deg2rad(0.1) * np.array([0.6, -0.5, 0.62]), 0.02 * np.array([0.66, -0.53, 0.53])),
+                           ("baseline_1deg_5cm", synth.DTHETA0, synth.DPOS0)):
+        _, x_prop, _ = synth.filter_inputs(dtheta=dth, dpos=dp)
+        cl = CLoop([eng], [x_prop], [P0], 0)
+        cl.run(warmup)
+        runs = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            it, rm = cl.run(steps)
+            torch.cuda.synchronize()
+            runs.append((time.perf_counter() - t0, it, rm))
+        runs.sort(key=lambda r: r[0])
+        dt, it, rm = runs[1]
+        out[label] = {"ms_per_step": 1e3 * dt / steps, "iters_per_step": it / steps, "rematch_passes_per_step": rm / steps,
+                      "pose_error_vs_truth_m": float(np.abs(cl.x[0][9:12] - x_true[9:12]).max()),
+                      "bets": dict(zip(("won", "lost"), eng.bet_stats()))}
+    out["note"] = ("one handle, the C3 scan against the resident map, s2m_iterated_update per step from tools/bench_loop.cpp; the "
+                   "IMU-sized prior is what frame_pipeline_moving feeds every frame")
+    return out
 
 
 def varying_scan(torch, Engine, synth, owner, a, k=8, steps=80, warmup=16):
@@ -1240,9 +1305,20 @@ def live_pmc_traffic(a):
             cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable,
                    os.path.abspath(__file__), "--config", a.config, "--steps", "12", "--warmup", "3", "--no-cpu", "--no-side",
                    "--max-iter", str(a.max_iter)]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
-            if r.returncode != 0:
-                return None, "rocprofv3 --pmc %s child failed (rc %d)" % (counter, r.returncode)
+            # (its own session, so that a timeout can end the profiler AND the bench it started: a grandchild left
+            # running would share the GPU with the side legs that follow)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+            try:
+                proc.communicate(timeout=180)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, 9)
+                except OSError:
+                    pass
+                proc.wait()
+                raise
+            if proc.returncode != 0:
+                return None, "rocprofv3 --pmc %s child failed (rc %d)" % (counter, proc.returncode)
             acc = {}
             for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):

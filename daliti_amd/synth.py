@@ -16,6 +16,9 @@ CONFIGS = {
     "C4": dict(beams=128, az=1024, M=20_000_000, L=440.0),
     # batched odometry: 8 independent C3-sized scans (seeds 2..9, sensor offsets (k - 3.5) * 2 m) vs one map
     "C5": dict(beams=64, az=1024, M=5_000_000, L=215.0, replicas=8),
+    # the same batch against C4's map: 8 scans of 65 536 points vs 20 M points (320 MB of points: beyond the 256 MB Infinity Cache,
+    # where C5 sits inside it) -- the engine where HBM is the roof
+    "C5b": dict(beams=64, az=1024, M=20_000_000, L=440.0, replicas=8),
     # C3's cloud at the reference's map density: map through Add_Points(downsample 0.5 m), scan through
     # VoxelGrid(0.5 m) (bench.py / tests build it with s2m_map_add and s2m_scan_set_downsampled)
     "R1": dict(beams=64, az=1024, M=5_000_000, L=215.0),
