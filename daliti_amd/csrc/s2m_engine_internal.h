@@ -1,0 +1,212 @@
+#pragma once
+// s2m_engine_internal.h -- what the translation units of the host engine share: the handle and a few helpers.
+//
+// The engine is split by what the reference's node does with it:
+//   s2m_engine.cpp       handle lifetime, configuration, exchange attachment (s2m_comm_*)
+//   s2m_engine_map.cpp   the map: build, share, incremental maintenance, field-of-view trim, getters, change log
+//   s2m_engine_scan.cpp  the scan's front half: set / down-sample / undistort, the prefetch and prepare worker
+//   s2m_engine_loop.cpp  residual passes and the iterated update in its four forms (single, batch, multi, sharded)
+//
+// The engine owns what laserMapping.cpp keeps in globals for this path (ikdtree :164,
+// Nearest_Points :578, point_selected_surf :812, effct_feat_numQueue :193, K / H_T_H :696,983) and
+// drives the HIP kernels; there is no CPU fallback for any compute entry point.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/daliti_s2m.h"
+#include "s2m_comm.h"
+#include "s2m_eskf.h"
+#include "s2m_fov.h"
+#include "s2m_iterctl.h"
+#include "s2m_kernels.h"
+
+namespace s2m {
+void launch_deinterleave(const float *src, int64_t stride, int64_t n, float *sx, float *sy, float *sz,
+                         hipStream_t st);
+void launch_scan_reset(int64_t n, uint8_t *sel, uint8_t *eff, uint8_t *flags, hipStream_t st);
+}
+
+using namespace s2m;
+
+struct s2m_engine {
+    s2m_config cfg{};
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool timing = false;
+    int timing_stride = 1, timing_phase = 0;   // time every stride-th pass (sampling keeps the probe cheap)
+    bool timed_this_pass = false;
+    double last_ms[3] = {0, 0, 0};
+    double tstats[6] = {0, 0, 0, 0, 0, 0};     // {match ms, n, reduce<FIT> ms, n, reduce (reuse pass) ms, n}
+    bool last_rematch = false;
+    int match_group = 0;  // launch_match flags (s2m_kernels.h): wide addresses, point batches per trip
+    std::string err;
+
+    MapBuffers map;
+    UpdateBuffers upd;
+    VoxelBuffers vox;
+    UndistBuffers und;
+    // lasermap_fov_segment state (laserMapping.cpp:311-312)
+    float local_map[6] = {0, 0, 0, 0, 0, 0};
+    bool local_map_init = false;
+    float built_cell = 0.0f;  // cell size of the current grid (kept across incremental rebuilds)
+    Mailbox mail;                   // stream waits of the per-frame entry points (polled, not hipStreamSynchronize)
+    bool in_batch = false;          // set while the handle is served by s2m_iterated_update_batch with several scans
+    bool no_merge = false;          // S2M_NO_MERGE=1: every update rebuilds the grid from scratch (A/B and tests)
+    bool no_slab = false;           // S2M_NO_SLAB=1: no in-place update of the touched bricks, every update merges (A/B and tests)
+    int64_t n_inplace = 0;          // updates applied in place (counted among the merged ones too)
+    ChangeLog log;                  // what the updates added / removed since the last s2m_map_get_changes
+    uint64_t log_seq = 0;
+    bool last_update_merged = false;
+    int64_t n_merged = 0, n_rebuilt = 0, n_regrid = 0;  // how this handle's map updates were produced (s2m_map_update_stats)
+    std::mutex stats_mu;            // the lazily fetched counts of a merged update may be asked for by borrowers' threads
+    Grid grid{};
+    MapStats stats;
+    bool map_ready = false;
+    bool map_borrowed = false;  // grid points into another handle's buffers (s2m_map_share)
+
+    // staging for host inputs
+    float *d_stage = nullptr;
+    int64_t stage_cap = 0;  // floats
+    // s2m_scan_prefetch_raw: the NEXT sweep's records cross PCIe on a side stream, driven by a worker thread (a copy out of
+    // pageable memory blocks the thread that issues it), while the caller's thread registers the current sweep
+    struct Prefetch {
+        std::thread worker;
+        std::mutex mu;
+        std::condition_variable cv;
+        bool quit = false, busy = false, ready = false;
+        bool gpu_pending = false;        // the last job's work on `stream` has not been ordered in front of the main stream yet
+        std::atomic<int> busy_a{0};      // mirror of `busy` for the short spins in front of the condition-variable waits: a futex
+                                         // sleep / wake is tens of microseconds at best and has been seen to cost 10 ms once
+        const float *src = nullptr;      // host records the job copies / the copy in d_buf belongs to
+        int64_t floats = 0;
+        hipError_t err = hipSuccess;
+        float *d_buf = nullptr;
+        int64_t cap = 0;                 // floats
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        // s2m_scan_prepare_raw: the job also undistorts and down-samples into the spare scan arrays (d_scan_alt) on
+        // the side stream; what it was asked for is kept so that s2m_scan_set_from_raw can recognise the same call
+        bool prepare = false, prepared = false;
+        bool copied = false;             // the records of this job are in d_buf already (a prefetch that was not consumed)
+        // the time order of the records in d_buf (und.val2) has been computed for these time fields (a prefetch with offsets)
+        bool want_order = false, ordered = false;
+        int32_t order_oa = 0, order_ob = 0;
+        int64_t stride = 0, n = 0, m = 0;
+        int32_t oa = 0, ob = 0;
+        float leaf = 0.0f;
+        std::vector<double> poses;       // 22 doubles per pose
+        double state_end[S2M_STATE_DOUBLES] = {0};
+    } pf;
+    float *d_scan_alt = nullptr;  // sx | sy | sz of the scan being prepared, laid out like d_scan (same n_cap)
+    int64_t scan_alt_cap = 0;     // the n_cap it was allocated for
+
+    // scan + per-point state
+    int64_t n = 0, n_cap = 0;
+    bool scan_ready = false, pass_done = false;
+    float *d_scan = nullptr;  // sx | sy | sz, each n_cap floats
+    float4 *d_plane = nullptr;
+    uint8_t *d_flags = nullptr, *d_sel = nullptr, *d_eff = nullptr;
+    float *d_pd2 = nullptr;
+    int32_t *d_nn_idx = nullptr;
+    float *d_nn_d2 = nullptr;
+    double *d_partials = nullptr;
+    double *d_block = nullptr;
+    double *h_block = nullptr;  // pinned host: 160 doubles + completion flag, written by the reduce kernel
+    double *h_block_dev = nullptr;          // the same memory as seen from the device
+    unsigned long long seq = 0;             // pass sequence number published through the flag
+    uint32_t *d_ticket = nullptr;
+    bool host_poll = true;                  // the reduce kernel publishes the block to pinned host memory (else: D2H copy + sync)
+    // rows on request
+    uint32_t *d_block_off = nullptr;
+    double *d_hx = nullptr, *d_h = nullptr;
+    int32_t *d_rowidx = nullptr;
+    int64_t rows_cap = 0;
+
+    Pose last_pose{};
+    Pose rematch_pose{};          // pose of the last rematch pass: the world-frame queries Nearest_Points belong to
+    uint32_t *d_hard = nullptr;   // the far-point lists' counters sit behind 3 x n_cap words (the words themselves are free)
+    uint32_t *d_qheads = nullptr; // match_hard's dequeue heads (kQueueWords)
+    HardRec *d_hrec = nullptr;    // the far points' records: 2 x n_cap (without / with a radius)
+    bool nn_valid = false;
+    bool nn_complete = false;     // s2m_complete_neighbors has run on the current lists
+    bool nn_nearest = false;      // ... or at least every list's nearest neighbour is proven (what s2m_map_incremental needs)
+    int blind_rounds = 1;         // completion rounds that s2m_map_incremental enqueues without asking whether anything is open
+    float first_round_gain = 16.0f; // ... and the factor on the gate (squared radius) of their first round: radius x 4 (measured on
+                                    // the moving-trajectory leg, x2 / x4 with 1 / 2 blind rounds: median frame 0.51 / 0.50 ms, p99 0.82 / 0.63)
+    // far points (scan points the first-shell kernel could not resolve) of the last FIRST rematch pass of a scan and of
+    // the last LATER one; -1 = unknown.  A pass whose predecessor in the same position had none runs without the
+    // far-point kernel on that bet (spec_mode: 0 never, 1 by history, 2 always -- the last two for tests)
+    int64_t far_first = -1, far_later = -1;
+    int64_t bets_won = 0, bets_lost = 0;   // passes that ran without the far-point kernel and were right / had to be redone
+    // neighbour lists of the last rematch pass that did not fill inside the gate (block[159]); -1 = not known for this
+    // handle (forms that only see the sum over shards, the device-resident loop): s2m_map_incremental then asks the device
+    int64_t short_lists = -1;
+    int spec_mode = 1;
+    bool spec_env = false;  // S2M_SPEC set: the environment overrides the config (A/B runs)
+
+    // far-point lists, counters and queue heads shared by the scans of a batched launch; owned by the first handle of
+    // a launch group of s2m_iterated_update_batch
+    HardRec *d_brec = nullptr;
+    int64_t brec_cap = 0;          // records per list
+    uint32_t *d_bcnt = nullptr;    // two sets of {16 counter words, kQueueWords queue heads}, used alternately
+    unsigned long long bwave = 0;  // launches so far (selects the set)
+
+    // device-resident loop (s2m_loop.h): state on the device, init record and result record in pinned host memory
+    LoopState *d_loop = nullptr;
+    LoopInit *h_init = nullptr, *h_init_dev = nullptr;
+    LoopRecord *h_rec = nullptr, *h_rec_dev = nullptr;
+    unsigned long long loop_seq = 0;   // one per enqueued chunk: the value the record's flag takes
+    int32_t loop_gen = 0;              // generation of the enqueued plan (a re-plan after a wrong prediction takes a new one)
+    std::vector<int8_t> sched_hist;    // which iterations of the last scan searched: the plan for the next one
+
+    EskfWork work;
+    Comm comm;  // attached RCCL communicator (multi-GPU form), handle == nullptr when single GPU
+    ShmExchange shm;               // or: host shared-memory exchange between the processes of one node (s2m_comm_init_shm)
+    std::vector<double> shm_blocks;  // the ranks' blocks of one exchange, padded to a power of two for the tree sum
+    std::vector<float> h_changes;    // s2m_map_get_changes: the added points on their way to the caller's arrays
+    int32_t queue[S2M_FEAT_QUEUE + 1] = {0};
+    int32_t queue_len = 0;
+};
+
+// ---- helpers shared by the engine's translation units (defined in s2m_engine.cpp) -----------------------------------
+namespace s2m_eng {
+int fail(s2m_engine *e, int code, const char *what, hipError_t he = hipSuccess);
+s2m::Gates gates_of(const s2m_config &c);
+s2m::Pose pose_of(const double s[S2M_STATE_DOUBLES]);
+int check_config(const s2m_config *c);
+// stage a host or device AoS cloud; returns a device pointer usable until the next stage call
+int stage_cloud(s2m_engine *e, const float *xyz, int64_t stride, int64_t count, int on_device, const float **dev);
+// rank[position] = caller index of every sorted position (s2m_engine_map.cpp)
+int caller_index_table(s2m_engine *e, const uint32_t **rank);
+}  // namespace s2m_eng
+
+#define S2M_HIP(e, call)                                                          \
+    do {                                                                          \
+        hipError_t he_ = (call);                                                  \
+        if (he_ != hipSuccess) return s2m_eng::fail((e), S2M_ERR_HIP, #call, he_); \
+    } while (0)
+
+namespace s2m_eng {
+template <class T>
+int grow(s2m_engine *e, T **p, int64_t count)
+{
+    if (*p) S2M_HIP(e, hipFree(*p));
+    *p = nullptr;
+    S2M_HIP(e, hipMalloc((void **)p, (size_t)std::max<int64_t>(count, 1) * sizeof(T)));
+    return S2M_OK;
+}
+}  // namespace s2m_eng

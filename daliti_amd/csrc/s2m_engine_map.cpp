@@ -1,0 +1,500 @@
+// s2m_engine_map.cpp -- the map behind the handle: build (ikdtree.Build, laserMapping.cpp:784-790), sharing between handles,
+// incremental maintenance (map_incremental :582-630, Add_Points / Delete_Point_Boxes ikd_Tree.cpp:477-573, 631-658), the
+// field-of-view trim (:313-369), the getters (flatten :1170-1175) and the change log a follower of the map reads.
+#include "s2m_engine_internal.h"
+
+using namespace s2m;
+using namespace s2m_eng;
+
+namespace {
+int complete_lists(s2m_engine *e, int k, int blind, int64_t *n_completed);  // (defined with s2m_complete_neighbors)
+}
+
+extern "C" {
+
+int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride, int64_t m, int on_device)
+{
+    if (!e || m < 0 || stride < 3 || (m > 0 && !xyz)) return fail(e, S2M_ERR_ARG, "s2m_map_build: bad argument");
+    if (m >= ((int64_t)1 << 31)) return fail(e, S2M_ERR_CAPACITY, "map too large (>= 2^31 points)");
+    S2M_HIP(e, hipSetDevice(e->device));
+    const float *dev = nullptr;
+    int rc = stage_cloud(e, xyz, stride, m, on_device, &dev);
+    if (rc) return rc;
+    e->map_ready = false;
+    e->map_borrowed = false;
+    bool too_large = false;
+    hipError_t he = build_map(dev, stride, m, e->cfg.cell_size, e->map, e->grid, e->stats, too_large, e->stream);
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
+    if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
+    e->map_ready = true;
+    e->nn_valid = false;
+    e->built_cell = e->grid.c;
+    e->log.token = 0;  // (a follower of the old map starts over)
+    return S2M_OK;
+}
+
+int s2m_map_share(s2m_engine *e, const s2m_engine *owner)
+{
+    if (!e || !owner || e == owner) return fail(e, S2M_ERR_ARG, "s2m_map_share: bad argument");
+    if (!owner->map_ready) return fail(e, S2M_ERR_STATE, "s2m_map_share: the owner has no map");
+    if (owner->device != e->device) return fail(e, S2M_ERR_ARG, "s2m_map_share: handles on different devices");
+    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    S2M_HIP(e, hipStreamSynchronize(owner->stream));  // the owner's build has finished
+    {   // the counts of the owner's last merged update arrive lazily; several borrowers may ask at once
+        s2m_engine *o = const_cast<s2m_engine *>(owner);
+        std::lock_guard<std::mutex> lk(o->stats_mu);
+        (void)resolve_stats(o->map, o->stats);
+        e->stats = o->stats;
+    }
+    e->grid = owner->grid;
+    e->map.ids_dense = owner->map.ids_dense;  // (the borrower's own map buffers stay empty; the getters ask this flag)
+    e->map.next_id = owner->map.next_id;
+    e->built_cell = owner->built_cell;
+    e->map_ready = true;
+    e->map_borrowed = true;
+    e->nn_valid = false;
+    return S2M_OK;
+}
+
+namespace {
+// what the update kernels need to know about the map's layout (s2m_kernels.h, UpdateBuffers)
+void bind_update(s2m_engine *e)
+{
+    e->upd.bmark = e->map.bmark;
+    e->upd.layout_gen = e->map.layout_gen;
+    e->upd.reserve_hint = std::max(e->upd.reserve_hint, e->n_cap);
+}
+
+// the map after an update: merged into the sorted arrays when possible (s2m_mapedit.hip: in place, else merge_update), else rebuilt
+// from upd.list (survivors in index order, then the staged points) -- the same caller order either way
+int commit_update(s2m_engine *e)
+{
+    bool merged = false;
+    e->map_ready = false;
+    hipError_t he;
+    {
+        std::lock_guard<std::mutex> lk(e->stats_mu);
+        he = resolve_stats(e->map, e->stats);  // counts of the previous build / merge
+    }
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "resolve_stats", he);
+    // The cell size is kept across updates (a stable grid) unless the density has drifted by more than 2x from
+    // the ~11 points per occupied cell it was chosen for -- e.g. a map seeded from a handful of points and then
+    // grown, or a dense seed thinned by the voxel rule: then it is chosen again from the density.  A merged update
+    // does not wait for its own counts, so the drift it causes is seen when the next update begins.
+    // Judged from the counts of the last build or merge and THAT layout's point count (in-place updates change the number
+    // of points and of occupied cells alike, and only a layout counts the cells).
+    auto drifted = [&]() {
+        if (e->cfg.cell_size > 0.0f || e->stats.occupied_cells <= 0 || e->stats.layout_points <= 0) return false;
+        const double mean = (double)e->stats.layout_points / (double)e->stats.occupied_cells;
+        return mean < 5.5 || mean > 22.0;
+    };
+    const bool drift_before = drifted();
+    const int64_t id0 = e->map.next_id;  // the first id this update hands out
+    if (e->log.on && e->log.token != 0 && e->grid.m > 0)   // somebody follows the map: the ids about to disappear, before anything moves
+        launch_log_removed(e->log, e->map.counters + kBricksWord, e->stats.bricks, e->map.bmark, e->grid.tab, e->upd.alive_s, e->grid.pidx, e->stream);
+    if (!e->no_merge && !e->no_slab && !drift_before) {  // in place when every touched brick fits where it stands
+        he = slab_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, e->upd.counters + kUpdSlabWord, merged, e->stream);
+        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "slab_update", he);
+        if (merged) ++e->n_inplace;
+    }
+    if (!e->no_merge && !drift_before && !merged) {
+        he = merge_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, merged, e->stream, !e->no_slab);
+        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "merge_update", he);
+    }
+    e->last_update_merged = merged;
+    if (merged) ++e->n_merged; else ++e->n_rebuilt;
+    if (e->log.on && e->log.token != 0) {
+        if (merged) launch_log_added(e->log, e->upd.stage, e->upd.stage_n, (uint32_t)id0, e->stream);
+        else e->log.token = 0;  // a rebuild numbers the points anew: whoever follows the map starts over
+    }
+    if (!merged) {
+        int64_t m_new = 0;
+        bool too_large = false;
+        he = update_finish(e->upd, e->grid, &m_new, e->stream);
+        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "update_finish", he);
+        if (m_new >= ((int64_t)1 << 31)) return fail(e, S2M_ERR_CAPACITY, "map too large (>= 2^31 points)");
+        const float cell = e->cfg.cell_size > 0.0f ? e->cfg.cell_size : e->built_cell;
+        // the cells stay where they are (same origin) unless the map was empty or has wandered beyond the representable range
+        const float origin[3] = {e->grid.ox, e->grid.oy, e->grid.oz};
+        const bool keep = e->grid.m > 0 && cell == e->grid.c;
+        he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, cell, e->map, e->grid, e->stats, too_large,
+                       e->stream, keep ? origin : nullptr);
+        if (he == hipSuccess && too_large && keep)   // beyond the range of the old origin: a new one
+            he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, cell, e->map, e->grid, e->stats, too_large, e->stream);
+        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
+        if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
+        if (drifted()) {
+            he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, 0.0f, e->map, e->grid, e->stats, too_large,
+                           e->stream);
+            if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
+            if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
+            e->built_cell = e->grid.c;
+            ++e->n_regrid;
+        }
+    }
+    e->map_ready = true;
+    e->nn_valid = false;  // neighbour indices referred to the old point list
+    if (e->built_cell <= 0.0f) e->built_cell = e->grid.c;
+    return S2M_OK;
+}
+}  // namespace
+
+int s2m_map_add(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int downsample_on, float downsample_size,
+                int on_device, int64_t *n_added)
+{
+    if (!e || n < 0 || stride < 3 || (n > 0 && !xyz)) return fail(e, S2M_ERR_ARG, "s2m_map_add: bad argument");
+    if (downsample_on && !(downsample_size > 0.0f)) return fail(e, S2M_ERR_ARG, "s2m_map_add: downsample size must be > 0");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
+    if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
+    S2M_HIP(e, hipSetDevice(e->device));
+    const float *dev = nullptr;
+    int rc = stage_cloud(e, xyz, stride, n, on_device, &dev);
+    if (rc) return rc;
+    float4 *np = nullptr;
+    S2M_HIP(e, xyz_to_float4(e->upd, dev, stride, n, &np, e->stream));
+    bind_update(e);
+    S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
+    int64_t added = 0;
+    S2M_HIP(e, update_add(e->upd, e->grid, np, n, downsample_on != 0, downsample_size, &added, e->stream));
+    if (n_added) *n_added = added;
+    return commit_update(e);
+}
+
+int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *n_deleted)
+{
+    if (!e || n < 0 || (n > 0 && !boxes) || n > 4096) return fail(e, S2M_ERR_ARG, "s2m_map_delete_boxes: bad argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
+    if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
+    S2M_HIP(e, hipSetDevice(e->device));
+    bind_update(e);
+    S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
+    int64_t del = 0;
+    S2M_HIP(e, update_delete(e->upd, e->grid, boxes, (int)n, &del, e->stream));
+    if (n_deleted) *n_deleted = del;
+    if (del == 0) return S2M_OK;  // nothing changed: keep the grid and the neighbour indices
+    return commit_update(e);
+}
+
+int s2m_fov_reset(s2m_engine *e)
+{
+    if (!e) return S2M_ERR_ARG;
+    e->local_map_init = false;
+    return S2M_OK;
+}
+
+int s2m_fov_segment(s2m_engine *e, const double pos_lid[3], double cube_len, float local_map[6], int32_t *n_boxes,
+                    int64_t *n_deleted)
+{
+    if (!e || !pos_lid || !(cube_len > 0.0)) return fail(e, S2M_ERR_ARG, "s2m_fov_segment: bad argument");
+    if (n_boxes) *n_boxes = 0;
+    if (n_deleted) *n_deleted = 0;
+    float boxes[3][6];
+    const int nb = fov_step(e->local_map, e->local_map_init, pos_lid, cube_len, boxes);  // :313-366 (s2m_fov.h)
+    if (local_map) std::memcpy(local_map, e->local_map, sizeof(e->local_map));
+    if (n_boxes) *n_boxes = nb;
+    if (nb > 0 && e->map_ready) return s2m_map_delete_boxes(e, &boxes[0][0], nb, n_deleted);  // :367-368
+    return S2M_OK;
+}
+
+int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], double filter_size_map,
+                        int32_t ekf_inited, int64_t *n_to_add, int64_t *n_no_downsample)
+{
+    if (!e || !state || !(filter_size_map > 0.0)) return fail(e, S2M_ERR_ARG, "s2m_map_incremental: bad argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
+    if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
+    if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
+    S2M_HIP(e, hipSetDevice(e->device));
+    const Pose pose = pose_of(state);
+    float4 *la = nullptr, *lb = nullptr;
+    int64_t na = 0, nb = 0;
+    // Nearest_Points[i] of the reference is never short (unbounded search): finish the lists that ended at the gate -- when
+    // the last rematch pass reported any (block[159]; a scan inside the mapped area has none: no launch, no round trip)
+    if (e->nn_valid && ekf_inited != 0 && e->short_lists != 0 && !e->nn_complete && !e->nn_nearest && e->n > 0 && e->grid.m > 0) {
+        int rc = complete_lists(e, 1, e->blind_rounds, nullptr);
+        if (rc) return rc;
+        e->nn_nearest = true;
+    }
+    VoxBox vox;
+    bind_update(e);
+    S2M_HIP(e, incr_classify(e->upd, pose, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, (int)e->n,
+                             e->d_nn_idx, e->grid, e->nn_valid && ekf_inited != 0, filter_size_map, &la, &na, &lb, &nb, e->stream,
+                             &vox, true));   // (update_begin runs inside, while the counts travel to the host)
+    if (n_to_add) *n_to_add = na;
+    if (n_no_downsample) *n_no_downsample = nb;
+    S2M_HIP(e, update_add(e->upd, e->grid, la, na, true, (float)filter_size_map, nullptr, e->stream, &vox));   // :627
+    S2M_HIP(e, update_add(e->upd, e->grid, lb, nb, false, 0.0f, nullptr, e->stream));                    // :628
+    return commit_update(e);
+}
+
+}  // extern "C"
+namespace s2m_eng {
+// rank[position] = caller index of every sorted position: the point ids themselves while no point has been removed since
+// the last build, else their ranks (a sort of the ids: the getters that answer in caller indices are not on any hot path)
+int caller_index_table(s2m_engine *e, const uint32_t **rank)
+{
+    *rank = e->grid.pidx;
+    if (e->map.ids_dense) return S2M_OK;
+    int64_t live = 0;
+    S2M_HIP(e, caller_ranks(e->upd, e->grid, nullptr, rank, &live, e->stream));
+    if (live != e->grid.live) return fail(e, S2M_ERR_STATE, "map ids out of step with the map size");
+    return S2M_OK;
+}
+}  // namespace s2m_eng
+extern "C" {
+
+int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity, int64_t *m)
+{
+    if (!e || !m) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map");
+    *m = e->grid.live;
+    if (!xyz) return S2M_OK;
+    if (capacity < e->grid.live) return fail(e, S2M_ERR_CAPACITY, "point buffer too small");
+    if (e->grid.live == 0) return S2M_OK;
+    S2M_HIP(e, hipSetDevice(e->device));
+    const int64_t floats = e->grid.live * 3;
+    if (floats > e->stage_cap) {
+        int rc = grow(e, &e->d_stage, floats);
+        if (rc) return rc;
+        e->stage_cap = floats;
+    }
+    const uint32_t *rank = nullptr;
+    int rc = caller_index_table(e, &rank);
+    if (rc) return rc;
+    launch_map_to_xyz(e->grid.pts, rank, e->grid.m, e->d_stage, e->stream);  // caller order
+    S2M_HIP(e, hipMemcpyAsync(xyz, e->d_stage, (size_t)floats * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    return S2M_OK;
+}
+
+int s2m_map_size(const s2m_engine *e, int64_t *m)
+{
+    if (!e || !m) return S2M_ERR_ARG;
+    *m = e->map_ready ? e->grid.live : 0;
+    return S2M_OK;
+}
+
+int s2m_map_last_update(const s2m_engine *e, int32_t *merged)
+{
+    if (!e || !merged) return S2M_ERR_ARG;
+    *merged = e->last_update_merged ? 1 : 0;
+    return S2M_OK;
+}
+
+int s2m_map_info(const s2m_engine *ce, double info[8])
+{
+    if (!ce || !info) return S2M_ERR_ARG;
+    if (!ce->map_ready) return S2M_ERR_STATE;
+    s2m_engine *e = const_cast<s2m_engine *>(ce);  // the counts of a merged update are fetched on demand
+    if (!e->map_borrowed) {
+        std::lock_guard<std::mutex> lk(e->stats_mu);
+        if (resolve_stats(e->map, e->stats) != hipSuccess) return S2M_ERR_HIP;
+    }
+    info[0] = e->grid.c;
+    info[1] = e->grid.ox; info[2] = e->grid.oy; info[3] = e->grid.oz;
+    info[4] = (double)e->stats.bricks;
+    info[5] = (double)e->stats.top_entries;
+    info[6] = (double)e->stats.occupied_cells;
+    info[7] = e->stats.occupied_cells ? (double)e->grid.live / (double)e->stats.occupied_cells : 0.0;
+    return S2M_OK;
+}
+
+
+int s2m_map_get_ids(s2m_engine *e, uint32_t *ids, int64_t capacity, int64_t *m)
+{
+    if (!e || !m) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map");
+    *m = e->grid.live;
+    if (!ids || e->grid.live == 0) return S2M_OK;
+    if (capacity < e->grid.live) return fail(e, S2M_ERR_CAPACITY, "id buffer too small");
+    S2M_HIP(e, hipSetDevice(e->device));
+    if (e->grid.live > e->stage_cap) {
+        int rc = grow(e, &e->d_stage, e->grid.live);
+        if (rc) return rc;
+        e->stage_cap = e->grid.live;
+    }
+    const uint32_t *rank = nullptr;
+    int rc = caller_index_table(e, &rank);
+    if (rc) return rc;
+    launch_ids_by_rank(e->grid.pidx, rank, e->grid.m, reinterpret_cast<uint32_t *>(e->d_stage), e->stream);
+    S2M_HIP(e, hipMemcpyAsync(ids, e->d_stage, (size_t)e->grid.live * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    return S2M_OK;
+}
+
+int s2m_map_get_changes(s2m_engine *e, uint64_t *token, float *added_xyz, uint32_t *added_ids, int64_t cap_added, int64_t *n_added,
+                        uint32_t *removed_ids, int64_t cap_removed, int64_t *n_removed, int32_t *resync)
+{
+    if (!e || !token || !n_added || !n_removed || !resync) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map");
+    if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
+    S2M_HIP(e, hipSetDevice(e->device));
+    *n_added = 0; *n_removed = 0; *resync = 0;
+    auto fresh = [&]() {
+        e->log.on = true;
+        e->log.token = (++e->log_seq << 8) | 1u;
+        *token = e->log.token;
+    };
+    if (!e->log.on || e->log.token == 0 || *token != e->log.token) {
+        // the caller does not hold the state the log starts from (first call, a rebuild in between, another follower's token)
+        // (room for a field-of-view trim of a few million points: 20 bytes per entry; beyond that the follower fetches the map)
+        S2M_HIP(e, changelog_ensure(e->log, std::max<int64_t>((int64_t)1 << 22, 4 * e->n_cap), e->stream));
+        launch_log_reset(e->log, e->stream);
+        fresh();
+        *resync = 1;
+        return S2M_OK;
+    }
+    const uint32_t *src[3] = {e->log.counts, e->log.counts + 1, e->log.counts + 2};
+    uint32_t v[3] = {0, 0, 0};
+    S2M_HIP(e, mail_fetch(e->mail, src, 3, v, e->stream));
+    if (v[2] != 0u) {  // more changes than the log holds: start over
+        launch_log_reset(e->log, e->stream);
+        fresh();
+        *resync = 1;
+        return S2M_OK;
+    }
+    *n_added = v[0];
+    *n_removed = v[1];
+    if ((v[0] > 0 && (!added_xyz || !added_ids || cap_added < (int64_t)v[0])) || (v[1] > 0 && (!removed_ids || cap_removed < (int64_t)v[1])))
+        return fail(e, S2M_ERR_CAPACITY, "s2m_map_get_changes: buffers too small (the changes are kept)");
+    if (v[0] > 0) {
+        e->h_changes.resize((size_t)v[0] * 4);
+        S2M_HIP(e, hipMemcpyAsync(e->h_changes.data(), e->log.added, (size_t)v[0] * sizeof(float4), hipMemcpyDeviceToHost, e->stream));
+    }
+    if (v[1] > 0) S2M_HIP(e, hipMemcpyAsync(removed_ids, e->log.removed, (size_t)v[1] * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    launch_log_reset(e->log, e->stream);
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    for (uint32_t i = 0; i < v[0]; ++i) {
+        const float *p = e->h_changes.data() + (size_t)i * 4;
+        added_xyz[3 * (size_t)i] = p[0]; added_xyz[3 * (size_t)i + 1] = p[1]; added_xyz[3 * (size_t)i + 2] = p[2];
+        std::memcpy(&added_ids[i], &p[3], sizeof(uint32_t));
+    }
+    fresh();
+    return S2M_OK;
+}
+
+int s2m_map_get_order(s2m_engine *e, uint32_t *order, int64_t capacity, int64_t *m)
+{
+    if (!e || !m) return fail(e, S2M_ERR_ARG, "null argument");
+    if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map");
+    *m = e->grid.m;
+    if (!order || e->grid.m == 0) return S2M_OK;
+    if (capacity < e->grid.m) return fail(e, S2M_ERR_CAPACITY, "order buffer too small");
+    S2M_HIP(e, hipSetDevice(e->device));
+    const uint32_t *rank = nullptr;
+    int rc = caller_index_table(e, &rank);
+    if (rc) return rc;
+    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    S2M_HIP(e, hipMemcpy(order, rank, (size_t)e->grid.m * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return S2M_OK;
+}
+
+int s2m_map_grid(const s2m_engine *e, int32_t bricks[6])
+{
+    if (!e || !bricks) return S2M_ERR_ARG;
+    if (!e->map_ready) return S2M_ERR_STATE;
+    for (int k = 0; k < 3; ++k) { bricks[k] = e->grid.blo[k]; bricks[3 + k] = e->grid.bhi[k]; }
+    return S2M_OK;
+}
+
+int s2m_map_inplace_updates(const s2m_engine *e, int64_t *n)
+{
+    if (!e || !n) return S2M_ERR_ARG;
+    *n = e->n_inplace;
+    return S2M_OK;
+}
+
+int s2m_map_update_stats(const s2m_engine *e, int64_t stats[6])
+{
+    if (!e || !stats) return S2M_ERR_ARG;
+    stats[0] = e->n_merged;
+    stats[1] = e->n_rebuilt;
+    stats[2] = e->n_regrid;
+    stats[3] = map_allocations();
+    stats[4] = e->map.n_relaid;
+    stats[5] = e->map.n_big_slab;
+    return S2M_OK;
+}
+
+// Nearest_Points beyond the gate.  ikdtree.Nearest_Search is unbounded (max_dist = INFINITY, ikd_Tree.cpp:425): every
+// scan point gets its five nearest map points however far they are, and map_incremental reads points_near[0] of
+// exactly those far points when the sensor enters new territory (laserMapping.cpp:593-607).  The per-iteration search
+// stops at the d2 <= 5 gate (:853) -- nothing beyond it can enter the update -- so a point whose neighbourhood is
+// emptier than that ends the pass with a list that is short, or not proven beyond the gate.  This call completes those
+// lists: the points whose 5th distance is not inside the radius searched so far are collected and handed to the
+// far-point kernel again with the radius doubled per round, until every one has its exact five (or the radius exceeds
+// the grid).  Cold path: nothing to do for a scan inside the mapped area.
+namespace {
+// k = 5: every list complete (s2m_complete_neighbors).  k = 1: only the NEAREST neighbour of every scan point proven -- all
+// that map_incremental reads of a list beyond the gate (laserMapping.cpp:603 tests points_near[0]; the other entries of a
+// list that ends at the gate lie more than sqrt(5) m from the point and cannot pass the test of :612-616, see
+// incr_classify_kernel) -- a radius that a frontier point reaches one or two doublings earlier than the radius that holds
+// five.  blind: that many rounds are enqueued without asking the device whether anything is still open (a round over an
+// empty list costs a few microseconds, a question ~15): the sensor at the edge of the mapped area always has open lists.
+int complete_lists(s2m_engine *e, int k, int blind, int64_t *n_completed)
+{
+    const int n = (int)e->n;
+    MatchArgs m;
+    m.grid = e->grid; m.pose = e->rematch_pose; m.gates = gates_of(e->cfg);
+    m.sx = e->d_scan; m.sy = e->d_scan + e->n_cap; m.sz = e->d_scan + 2 * e->n_cap; m.n = n;
+    m.nn_idx = e->d_nn_idx; m.nn_d2 = e->d_nn_d2;
+    m.hard_rec = e->d_hrec; m.hard_off1 = n; m.hard_count = e->d_hard + 3 * e->n_cap;
+    m.qheads = e->d_qheads;
+    m.short_k = k;
+    const double c = e->grid.c;
+    double diag2 = 0.0;
+    for (int q = 0; q < 3; ++q) {  // (the box of the bricks in use, in cells)
+        const double cells = 8.0 * ((double)e->grid.bhi[q] - (double)e->grid.blo[q] + 1.0);
+        diag2 += cells * cells;
+    }
+    const double half_diag = 0.5 * c * std::sqrt(diag2);
+    int64_t first = -1;
+    for (int round = 0; round < 64; ++round) {
+        // hard_count / qheads are zero here: every reduce launch and every round below leaves them so
+        launch_collect_short(m, e->stream);
+        const bool ask = round >= blind;
+        bool last = false;
+        double reach = 0.0;
+        if (ask) {
+            const uint32_t *src[2] = {m.hard_count, m.hard_count + 2};
+            uint32_t v[2] = {0, 0};
+            S2M_HIP(e, mail_fetch(e->mail, src, 2, v, e->stream));
+            if (first < 0) first = v[0];
+            last = v[0] == 0;
+            // the farthest of the open queries from the grid centre, plus half the grid's diagonal: a radius beyond
+            // that has seen every map point (a list still short then belongs to a map of fewer than five points)
+            float far2;
+            std::memcpy(&far2, &v[1], sizeof(far2));
+            reach = std::sqrt((double)far2) + half_diag + c;
+        }
+        if (!last) {
+            m.gates.knn_d2_gate *= (round == 0 && k == 1) ? e->first_round_gain : 4.0f;  // radius x 2
+            launch_match_hard_only(m, e->stream);
+            if (ask) last = (double)m.gates.knn_d2_gate > reach * reach || !(m.gates.knn_d2_gate < 1.0e37f);
+        }
+        launch_far_reset(m.hard_count, e->d_qheads, e->stream);
+        if (last) break;
+    }
+    S2M_HIP(e, hipGetLastError());
+    if (n_completed) *n_completed = first < 0 ? 0 : first;
+    return S2M_OK;
+}
+}  // namespace
+
+int s2m_complete_neighbors(s2m_engine *e, int64_t *n_completed)
+{
+    if (n_completed) *n_completed = 0;
+    if (!e) return S2M_ERR_ARG;
+    if (!e->map_ready || !e->nn_valid) return fail(e, S2M_ERR_STATE, "no rematch pass yet");
+    S2M_HIP(e, hipSetDevice(e->device));
+    if (e->n == 0 || e->grid.m == 0 || e->nn_complete) return S2M_OK;
+    if (e->short_lists == 0) { e->nn_complete = true; return S2M_OK; }  // the last rematch pass counted them: none
+    int rc = complete_lists(e, kK, 0, n_completed);
+    if (rc) return rc;
+    e->nn_complete = true;
+    e->nn_nearest = true;
+    return S2M_OK;
+}
+
+
+}  // extern "C"

@@ -335,7 +335,7 @@ def test_bench_defaults_follow_baseline_configs():
     assert n == 131072 and [shard_range(n, r, 8) for r in (0, 7)] == [(0, 16384), (114688, 131072)]
     assert shard_range(65536, 3, 8) == (24576, 32768)
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert 'a.scaling if a.scaling != "auto" else "strong"' in src and '"replicas" if a.config == "C5"' in src
+    assert 'a.scaling if a.scaling != "auto" else "strong"' in src and '"replicas" if a.config in ("C5", "C5b")' in src
     c5 = synth.CONFIGS["C5"]
     assert c5["replicas"] == 8 and (c5["M"], c5["beams"] * c5["az"]) == (5_000_000, 65536)
     assert [synth.replica_offset(k) for k in (0, 7)] == [-7.0, 7.0]
