@@ -1131,7 +1131,7 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
             "p99_ms": float(np.percentile(per, 99)), "max_ms": float(per.max()),
             "max_over_median": float(per.max() / med), "worst_frame": worst,
             "frames_back_to_back": int(frames), "untimed_warmup_frames": 2,
-            "updates": dict({k: int(st1[k] - st0[k]) for k in st1}, in_place=int(ip1 - ip0)),
+            "updates": dict({k: int(st1[k] - st0[k]) for k in st1 if not isinstance(st1[k], dict)}, in_place=int(ip1 - ip0)),
             "bets": dict(zip(("won", "lost"), eng.bet_stats())),
             "rebuilt_frames": [i for i, m in enumerate(how) if not m],
             "stages_ms": {"raw_to_scan": float(w[0]), "iterated_update": float(w[1]), "map_incremental": float(w[2]),

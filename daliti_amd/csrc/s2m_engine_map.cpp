@@ -404,7 +404,7 @@ int s2m_map_inplace_updates(const s2m_engine *e, int64_t *n)
     return S2M_OK;
 }
 
-int s2m_map_update_stats(const s2m_engine *e, int64_t stats[6])
+int s2m_map_update_stats(const s2m_engine *e, int64_t stats[10])
 {
     if (!e || !stats) return S2M_ERR_ARG;
     stats[0] = e->n_merged;
@@ -413,6 +413,7 @@ int s2m_map_update_stats(const s2m_engine *e, int64_t stats[6])
     stats[3] = map_allocations();
     stats[4] = e->map.n_relaid;
     stats[5] = e->map.n_big_slab;
+    for (int k = 0; k < 4; ++k) stats[6 + k] = e->map.slab_fail[k];
     return S2M_OK;
 }
 
@@ -468,6 +469,7 @@ int complete_lists(s2m_engine *e, int k, int blind, int64_t *n_completed)
             reach = std::sqrt((double)far2) + half_diag + c;
         }
         if (!last) {
+            m.band0 = 2.0f * std::sqrt(m.gates.knn_d2_gate);  // nothing closer than the radius searched so far: start at twice that
             m.gates.knn_d2_gate *= (round == 0 && k == 1) ? e->first_round_gain : 4.0f;  // radius x 2
             launch_match_hard_only(m, e->stream);
             if (ask) last = (double)m.gates.knn_d2_gate > reach * reach || !(m.gates.knn_d2_gate < 1.0e37f);

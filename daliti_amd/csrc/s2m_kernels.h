@@ -66,6 +66,8 @@ struct MapBuffers {
                                  // is the TAIL: stretches handed to bricks that in-place updates opened or moved, in the order they asked
     int64_t tail_used = 0;       // positions of the tail handed out so far (host copy of the device cursor, counters[kTailWord] - main_ext)
     int64_t n_moved = 0;         // bricks that in-place updates have put into the tail (diagnostic)
+    int64_t slab_fail[4] = {0, 0, 0, 0};  // in-place updates given up because of: a point beyond the representable cells, no spare
+                                 // table rows, a brick too large to stage, the tail exhausted (diagnostic)
     uint32_t *grow = nullptr;    // per top slot: points the brick has gained (net) by in-place updates since the room was laid out
     int64_t grow_cap = 0;
     int64_t added_since_layout = 0;  // host bound of the sum of `grow`
@@ -267,7 +269,8 @@ struct MatchArgs {
     uint32_t *qheads = nullptr;  // kQueueShards dequeue heads of match_hard's work queue, kQueueStride words apart
     LoopLaunch loop;             // device-resident loop (s2m_loop.h): state == nullptr for a host-stepped pass
     int32_t far_waves = 0;       // > 0: waves of the far-point launch (few far points expected); 0: as many as stay resident
-    int32_t short_k = kK;        // launch_collect_short: a list is open while its short_k-th entry is not proven (5: the whole list; 1: the nearest)
+    float band0 = 0.0f;          // launch_match_hard_only: first band of the search in metres (0: the kernel's own)
+    int32_t short_k = kK;        // launch_collect_short / launch_match_hard_only: a list is open while its short_k-th entry is not proven (5: the whole list; 1: the nearest)
 };
 // first shell (s2m_match.hip), then -- unless `group` carries bit 0x40000 -- the far-point kernel (s2m_match_far.hip)
 void launch_match(const MatchArgs &a, int group, hipStream_t st);

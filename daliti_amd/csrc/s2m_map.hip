@@ -4,9 +4,9 @@
 // (eskf_lio/src/laserMapping.cpp:784-790; KD_TREE::Build / BuildTree,
 // eskf_lio/include/ikd-Tree/ikd_Tree.cpp:408-423, 678-733).  Instead of a pointer tree of 176-byte
 // nodes the points are radix-sorted by (brick, cell-in-brick; stable, i.e. then by caller index) into one float4
-// array whose third word is the sorted position itself, with the caller indices beside it (pidx); a dense
-// top-level array over the bounding box and a 513-entry prefix table per occupied brick locate
-// any run of cells along x with two 4-byte loads.
+// array whose third word is the sorted position itself, with the caller indices beside it (pidx); a toroidally addressed
+// top-level array over the bricks' signed integer coordinates and a 513-entry prefix table per occupied brick locate
+// any run of cells along x with two 4-byte loads -- and none of it depends on the box the cloud happens to occupy.
 //
 // This is the per-map part of the path, not the per-iteration hot loop: the full build (radix sort of all points) and
 // the tables that both the build and a merged update derive from the sorted keys; how the map changes after a scan is
@@ -323,6 +323,33 @@ static hipError_t ensure_scratch(MapBuffers &buf, int64_t m)
         int64_t c = 0;
         if (*ps[k]) { S2M_TRY(hipFree(*ps[k])); *ps[k] = nullptr; }
         S2M_TRY(map_ensure(ps[k], &c, cap + 1, es[k]));
+    }
+    buf.scratch_cap = cap;
+    return hipSuccess;
+}
+
+// The same arrays for a map that has outgrown them in the middle of an update: everything is re-allocated (room for twice the
+// need: a map that is driven through keeps growing), the sorted keys of the current map -- the one array an update reads --
+// carried over.  A slow frame (allocations stall the stream) instead of a rebuild; the reference's tree allocates per node.
+hipError_t map_grow_scratch(MapBuffers &buf, int64_t need, int64_t keys_in_use, hipStream_t st)
+{
+    if (buf.scratch_cap >= need) return hipSuccess;
+    const int64_t cap = 2 * need + ((int64_t)1 << 20);
+    uint64_t *old_sorted = buf.keys_alt;
+    buf.keys_alt = nullptr;
+    void **ps[] = {(void **)&buf.keys, (void **)&buf.keys_alt, (void **)&buf.vals, (void **)&buf.vals_alt,
+                   (void **)&buf.work_a, (void **)&buf.work_b, (void **)&buf.work_c};
+    const size_t es[] = {8, 8, 4, 4, 4, 4, 4};
+    S2M_TRY(hipStreamSynchronize(st));  // (kernels in flight may still read the arrays about to be freed)
+    for (int k = 0; k < 7; ++k) {
+        int64_t c = 0;
+        if (*ps[k]) { S2M_TRY(hipFree(*ps[k])); *ps[k] = nullptr; }
+        S2M_TRY(map_ensure(ps[k], &c, cap + 1, es[k]));
+    }
+    if (old_sorted) {
+        if (keys_in_use > 0) S2M_TRY(hipMemcpyAsync(buf.keys_alt, old_sorted, (size_t)keys_in_use * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+        S2M_TRY(hipStreamSynchronize(st));
+        S2M_TRY(hipFree(old_sorted));
     }
     buf.scratch_cap = cap;
     return hipSuccess;

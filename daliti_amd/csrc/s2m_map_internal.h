@@ -68,6 +68,8 @@ __device__ __forceinline__ void wave_max6_to(uint32_t (&e)[6], uint32_t *__restr
 void launch_set_word(uint32_t *dst, uint32_t value, hipStream_t st);  // *dst = value, in stream order
 hipError_t map_ensure(void **p, int64_t *cap, int64_t need, size_t elem, int64_t headroom = 0);
 hipError_t map_ensure_sort_tmp(MapBuffers &buf, size_t bytes);
+// the per-point scratch arrays grown to hold `need` points, the first keys_in_use sorted keys (keys_alt) carried over
+hipError_t map_grow_scratch(MapBuffers &buf, int64_t need, int64_t keys_in_use, hipStream_t st);
 int64_t map_headroom_for(int64_t m);
 hipError_t map_put_sentinels(float4 *pts, int64_t m, hipStream_t st);
 // top entries + brick tables of the m points whose sorted keys are `keys` (s2m_map.hip)

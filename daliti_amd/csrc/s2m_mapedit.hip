@@ -272,8 +272,10 @@ __global__ __launch_bounds__(256) void tail_fill_kernel(int64_t from, int64_t to
 }
 
 // How many positions the tail of a layout of m points gets: room for the bricks that in-place updates open or move until the
-// next merge.  Generous (HBM is not what this engine is short of): half the map, at least half a million positions.
-static int64_t tail_size_for(int64_t m) { return std::max<int64_t>(m / 2, (int64_t)1 << 19); }
+// next merge.  Generous (HBM is not what this engine is short of -- 29 bytes per position): as many as the map has points, at
+// least two million.  Measured on the drive of DESIGN section 6: ~13 K positions per frame at 0.5 m cells (4 m bricks), ~6 K at
+// the reference's map density (1.25 m cells, 10 m bricks that are moved whole): 150+ frames per merge at the smallest size.
+static int64_t tail_size_for(int64_t m) { return std::max<int64_t>(m, (int64_t)1 << 21); }
 
 // dense layout of m points (buf.pts / pidx / keys_alt, tables built) -> layout with slack behind every brick and the tail
 // behind the last one; g.m becomes the new extent, buf.main_ext the extent of the key-ordered part
@@ -286,6 +288,8 @@ static hipError_t spread_with_slack(MapBuffers &buf, Grid &g, int64_t bricks_bou
     // slack <= max(cnt / 8, 16) + 4 x growth per brick; the host knows the sum of the growth as a bound
     int64_t room_bound = m / 8 + 16 * bricks_bound + 64 + 4 * buf.added_since_layout;
     int by_growth = 1;
+    // room for the slack and a full-sized tail (a map that started small -- one scan -- and has grown since)
+    S2M_TRY(map_grow_scratch(buf, m + room_bound + tail_size_for(m) + 64, m, st));
     if (m + room_bound > buf.scratch_cap) {  // no space for the growth-sized part: the plain eighth then
         room_bound = m / 8 + 16 * bricks_bound + 64;
         by_growth = 0;
@@ -340,7 +344,8 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
     const int64_t m = buf.main_ext > 0 && buf.main_ext <= g.m ? buf.main_ext : g.m;
     const int64_t n_tail = std::min<int64_t>(buf.tail_used, g.m - m);
     if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || g.m > buf.scratch_cap) return hipSuccess;
-    if (n_new >= ((int64_t)1 << 30) || n_new + n_tail > buf.scratch_cap || n_new + n_tail >= ((int64_t)1 << 31)) return hipSuccess;
+    if (n_new >= ((int64_t)1 << 30) || n_new + n_tail >= ((int64_t)1 << 31)) return hipSuccess;
+    S2M_TRY(map_grow_scratch(buf, m + n_new + n_tail + 64, g.m, st));  // (the merged map, before its room is laid out)
     const int n = (int)(n_new + n_tail), nt = (int)n_tail;  // the points the merge sorts: the tail's, then the staged ones
     const int64_t words = (m + 63) / 64;
     // dword: [masks of the removed positions | packed records], words + 1 each; work_c: [removed per word | exclusive prefix];
@@ -465,7 +470,7 @@ constexpr int kSlabMax = 2048;  // points of one brick the rewrite stages in LDS
 constexpr int kSlabBig = 6144;  // ... and in the second, rarely launched form for crowded bricks (134 KB of dynamic LDS: one per CU)
 // kSlabOutside: a new point's cell cannot be represented (rebuild around a new origin); kSlabWindow: the box of the bricks in
 // use, grown by the new points, no longer fits the window of the top array (the host re-lays it and tries again)
-enum : uint32_t { kSlabOutside = 1u, kSlabNewBrick = 2u, kSlabOverflow = 4u, kSlabWindow = 8u };
+enum : uint32_t { kSlabOutside = 1u, kSlabNewBrick = 2u, kSlabOverflow = 4u, kSlabWindow = 8u, kSlabTooBig = 16u };
 // words of the update's counters behind `flags`: [0] outcome bits, [1] points removed, [2] bricks opened, [3] points gained
 // by bricks, [4] crowded bricks among the touched ones, [5..11) how far the new points reach beyond the bricks in use,
 // [11] bricks moved to the tail (the opened ones included), [12] bricks touched
@@ -650,45 +655,46 @@ __global__ __launch_bounds__(kAllocThreads) void slab_alloc_kernel(const uint32_
     if (tid < 5) s_sum[tid] = 0u;
     const int64_t bricks = (int64_t)*bricks_dev;
     const uint32_t cursor0 = *tail_cursor;
-    uint64_t run_need = 0;   // (uniform) tail positions handed out to the ids before this chunk
-    uint32_t run_touch = 0;
+    // every thread owns a contiguous run of ids (so that the prefix over the threads is the prefix over the ids): two walks
+    // over its run -- add up, then hand out -- and ONE prefix sum over the workgroup in between
+    const int64_t per = (bricks + kAllocThreads - 1) / kAllocThreads;
+    const int64_t id0 = (int64_t)tid * per, id1 = min(id0 + per, bricks);
+    uint32_t need = 0u, touch = 0u;
     uint32_t my[5] = {0u, 0u, 0u, 0u, 0u};  // this thread's share of: points removed, points gained, crowded, moved, cannot be staged
-    for (int64_t c0 = 0; c0 < bricks; c0 += kAllocThreads) {
-        const int64_t id = c0 + tid;
-        uint32_t need = 0u, touch = 0u;
-        if (id < bricks && bmark[id] != 0) {
-            const uint4 p = reinterpret_cast<const uint4 *>(plan + id)[0];  // {lo, n_b, need, info}
-            touch = 1u;
-            need = p.z;
-            my[0] += p.w & 0xffffffu;
-            my[1] += plan[id].gained;
-            my[2] += (p.w >> 24) & 1u;
-            my[3] += need ? 1u : 0u;
-            my[4] += (p.w >> 25) & 1u;
-        }
-        // exclusive prefix of (need, touch) over the workgroup; a chunk without a touched brick (most of them) is skipped
-        if (!__syncthreads_or((int)touch)) continue;
-        uint32_t in = need, it = touch;
+    for (int64_t id = id0; id < id1; ++id) {
+        if (bmark[id] == 0) continue;
+        const uint4 p = reinterpret_cast<const uint4 *>(plan + id)[0];  // {lo, n_b, need, info}
+        ++touch;
+        need += p.z;
+        my[0] += p.w & 0xffffffu;
+        my[1] += plan[id].gained;
+        my[2] += (p.w >> 24) & 1u;
+        my[3] += p.z ? 1u : 0u;
+        my[4] += (p.w >> 25) & 1u;
+    }
+    uint32_t in = need, it = touch;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t a = __shfl_up(in, off, 64), b = __shfl_up(it, off, 64);
-            if (lane >= off) { in += a; it += b; }
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t a = __shfl_up(in, off, 64), b = __shfl_up(it, off, 64);
+        if (lane >= off) { in += a; it += b; }
+    }
+    if (lane == 63) { w_need[wave] = in; w_touch[wave] = it; }
+    __syncthreads();
+    uint32_t on = 0u, ot = 0u, tn = 0u, tt = 0u;
+    for (int w = 0; w < kAllocThreads / 64; ++w) {
+        if (w < wave) { on += w_need[w]; ot += w_touch[w]; }
+        tn += w_need[w]; tt += w_touch[w];
+    }
+    if (touch) {
+        uint64_t at = (uint64_t)cursor0 + on + (in - need);
+        uint32_t li = ot + (it - touch);
+        for (int64_t id = id0; id < id1; ++id) {
+            if (bmark[id] == 0) continue;
+            const uint32_t nd = plan[id].need;
+            bmove[id] = nd ? (at + nd <= (uint64_t)tail_end ? (uint32_t)at : 0xfffffffeu) : 0xffffffffu;
+            at += nd;
+            blist[li++] = (uint32_t)id;
         }
-        if (lane == 63) { w_need[wave] = in; w_touch[wave] = it; }
-        __syncthreads();
-        uint32_t on = 0u, ot = 0u, tn = 0u, tt = 0u;
-        for (int w = 0; w < kAllocThreads / 64; ++w) {
-            if (w < wave) { on += w_need[w]; ot += w_touch[w]; }
-            tn += w_need[w]; tt += w_touch[w];
-        }
-        if (touch) {
-            const uint64_t at = (uint64_t)cursor0 + run_need + on + (in - need);
-            bmove[id] = need ? (at + need <= (uint64_t)tail_end ? (uint32_t)at : 0xfffffffeu) : 0xffffffffu;
-            blist[run_touch + ot + (it - touch)] = (uint32_t)id;
-        }
-        run_need += tn;
-        run_touch += tt;
-        __syncthreads();
     }
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
@@ -699,14 +705,14 @@ __global__ __launch_bounds__(kAllocThreads) void slab_alloc_kernel(const uint32_
     }
     __syncthreads();
     if (tid == 0) {
-        const bool over = (uint64_t)cursor0 + run_need > (uint64_t)tail_end;
-        if (s_sum[4] || over) atomicOr(flags, kSlabOverflow);
-        else *tail_cursor = cursor0 + (uint32_t)run_need;
+        const bool over = (uint64_t)cursor0 + tn > (uint64_t)tail_end;
+        if (s_sum[4] || over) atomicOr(flags, kSlabOverflow | (s_sum[4] ? kSlabTooBig : 0u));
+        else *tail_cursor = cursor0 + tn;
         flags[1] = s_sum[0];
         flags[3] = s_sum[1];
         flags[4] = s_sum[2];
         flags[11] = s_sum[3];
-        flags[12] = run_touch;
+        flags[12] = tt;
     }
 }
 
@@ -978,7 +984,13 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
         buf.n_big_slab += v[4];  // (diagnostic: bricks that went through the large form)
     }
     buf.added_since_layout += v[3];  // (counted by the plan kernel whether the update stays in place or not)
-    if (v[0] != 0u) return hipSuccess;  // the rewrite kernel saw the same word and left the points alone
+    if (v[0] != 0u) {  // the rewrite kernel saw the same word and left the points alone
+        if (v[0] & kSlabOutside) ++buf.slab_fail[0];
+        else if (v[0] & kSlabNewBrick) ++buf.slab_fail[1];
+        else if (v[0] & kSlabTooBig) ++buf.slab_fail[2];
+        else if (v[0] & kSlabOverflow) ++buf.slab_fail[3];
+        return hipSuccess;
+    }
     // the bounds follow the bricks this update opened
     for (int k = 0; k < 3; ++k) { g.blo[k] -= (int)v[5 + k]; g.bhi[k] += (int)v[8 + k]; }
     stats.bricks += v[2];

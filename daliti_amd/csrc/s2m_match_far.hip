@@ -108,6 +108,8 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
         // general path) 41.3 / 74.2 / 24.0 / 29.9.  Re-checked at the end of round 3 (search kernels per rematch pass): 2.2 cells
         // C3 32.6 / C4 59.7, 2.5 cells 32.5 / 53.9, against 31.7 / 53.0 with 2.8.
         if (r1.y == 0u) band = S2M_HARD_BAND_EMPTY * g.c;
+        // the completion of lists beyond the gate knows that an earlier search found nothing closer than its radius
+        if (FAR && a.band0 > 0.0f) band = a.band0;
         band = fminf(band, sqrtf(a.gates.knn_d2_gate * 1.0001f));  // no first band beyond the gate either (coarse grids)
         const int hbx = q.cx >> 3, hby = q.cy >> 3, hbz = q.cz >> 3;
         int nc = 0;  // cells waiting in the wave's list (wave-uniform)
@@ -300,8 +302,10 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
             }
             flush_cells();
             merge_lists<G>(t, best);
-            const bool found5 = !is_empty(best[kK - 1]);
-            const float d5 = __uint_as_float((uint32_t)(best[kK - 1] >> 32));
+            // (the completion may ask for the NEAREST neighbour only: the list is settled once its short_k-th entry is)
+            const u64 kth = (FAR && a.short_k == 1) ? best[0] : best[kK - 1];
+            const bool found5 = !is_empty(kth);
+            const float d5 = __uint_as_float((uint32_t)(kth >> 32));
             if (have_tau) break;  // every point within tau was visited: exact
             // band mode: rows with bound <= band^2 were scanned over their whole reach of this band only,
             // so restart the private lists when the radius changes (rows are rescanned with the new reach)

@@ -202,9 +202,10 @@ class Engine:
 
     def map_update_stats(self):
         """Running counts: updates merged / rebuilt / re-gridded, device buffer (re)allocations (process-wide)."""
-        st = (C.c_int64 * 6)()
+        st = (C.c_int64 * 10)()
         self._ck(self.lib.s2m_map_update_stats(self.h, st))
-        return dict(merged=st[0], rebuilt=st[1], regridded=st[2], allocations=st[3], relaid=st[4], big_bricks=st[5])
+        return dict(merged=st[0], rebuilt=st[1], regridded=st[2], allocations=st[3], relaid=st[4], big_bricks=st[5],
+                    not_in_place=dict(unrepresentable=st[6], no_table_rows=st[7], brick_too_large=st[8], tail_exhausted=st[9]))
 
     def map_inplace_updates(self):
         """Updates applied in place (only the touched bricks rewritten): s2m_map_inplace_updates."""

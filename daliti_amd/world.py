@@ -94,6 +94,7 @@ def run_frames(eng, sw, P0, frames, warm, leaf=0.5, filter_size_map=0.5, cube_le
     allocs = np.zeros(total, np.int32)
     publish_us = np.zeros(total)
     mirror_stats = np.zeros(3, np.int64)
+    stage_us = np.zeros((total, 6))
     P0 = np.ascontiguousarray(P0, np.float64)
     rc = fn(eng.h, C.c_int32(frames), C.c_int32(warm), C.c_void_p(rec.ctypes.data), C.c_int64(rec.shape[1] * 12),
             C.c_void_p(sw["n"].ctypes.data), C.c_int32(4), C.c_int32(6), C.c_void_p(sw["poses"].ctypes.data), C.c_int32(N_POSES),
@@ -101,9 +102,10 @@ def run_frames(eng, sw, P0, frames, warm, leaf=0.5, filter_size_map=0.5, cube_le
             C.c_double(cube_len), C.c_int32(prefetch), C.c_void_p(x.ctypes.data), C.c_void_p(us.ctypes.data),
             C.c_void_p(how.ctypes.data), C.c_void_p(deleted.ctypes.data), C.c_void_p(n_scan.ctypes.data), logs,
             C.c_void_p(allocs.ctypes.data), C.c_int32(int(bool(publish))), C.c_void_p(publish_us.ctypes.data),
-            C.c_void_p(mirror_stats.ctypes.data))
+            C.c_void_p(mirror_stats.ctypes.data), C.c_void_p(stage_us.ctypes.data))
     if rc != 0:
         raise RuntimeError("s2m_bench_frames_moving failed: %d (%s)" % (rc, eng.lib.s2m_last_error(eng.h).decode()))
     return dict(ms=us * 1e-3, how=how, deleted=deleted, n_scan=n_scan, x=x, allocs=allocs, publish_ms=publish_us * 1e-3,
-                mirror_points=int(mirror_stats[0]), map_points=int(mirror_stats[1]), mirror_resyncs=int(mirror_stats[2]), iters=np.array([l.iters for l in logs]),
+                mirror_points=int(mirror_stats[0]), map_points=int(mirror_stats[1]), mirror_resyncs=int(mirror_stats[2]),
+                stage_ms=np.diff(np.concatenate([np.zeros((total, 1)), stage_us], axis=1), axis=1) * 1e-3, iters=np.array([l.iters for l in logs]),
                 effct=[np.array(l.effct[:l.iters]) for l in logs])

@@ -179,8 +179,10 @@ int s2m_map_last_update(const s2m_engine *e, int32_t *merged);
  * never growth as such), stats[2] = rebuilds that also chose a new cell size (density drift), stats[3] = device buffer
  * (re)allocations made by map builds and updates so far (process-wide), stats[4] = times the top-level array was re-laid
  * because the box of bricks in use had outgrown or left its window (a few thousand entries; no point moves), stats[5] =
- * bricks rewritten in place through the large staging form (more than 2 048 points). */
-int s2m_map_update_stats(const s2m_engine *e, int64_t stats[6]);
+ * bricks rewritten in place through the large staging form (more than 2 048 points), stats[6..9] = updates that could not
+ * stay in place (and were merged) because of: a point beyond the representable cell range, no spare table rows for the
+ * bricks to open, a brick too large to stage (more than 6 144 points), the tail of the point array exhausted. */
+int s2m_map_update_stats(const s2m_engine *e, int64_t stats[10]);
 /* How many of the merged updates (s2m_map_update_stats, stats[0]) were applied IN PLACE: only the bricks the update touched
  * were rewritten where they stand -- possible when each of them still fits the stretch of the point array it owns and no new
  * point opens a brick; cost proportional to the update, not to the map (ikd-Tree inserts per point in O(log M),

@@ -35,18 +35,26 @@ ms = r["ms"][warm:]
 how = r["how"][warm:]
 err = np.linalg.norm(r["x"][:, 9:12] - sw["x_true"][:frames + warm, 9:12], axis=1)
 print("frames %d step %.1f m: median %.3f p99 %.3f max %.3f ms, max/median %.2f" % (frames, step, np.median(ms), np.percentile(ms, 99), ms.max(), ms.max() / np.median(ms)))
-print("how: in place %d, merged %d, rebuilt %d; stats delta %s" % ((how == 2).sum(), (how == 1).sum(), (how == 0).sum(), {k: st1[k] - st0[k] for k in st1}))
+print("how: in place %d, merged %d, rebuilt %d; stats delta %s" % ((how == 2).sum(), (how == 1).sum(), (how == 0).sum(), {k: (st1[k] - st0[k]) if not isinstance(st1[k], dict) else st1[k] for k in st1}))
 print("deleted by trim:", [(int(i), int(d)) for i, d in enumerate(r["deleted"]) if d > 0])
 print("scan pts after voxel grid: mean %d; iters mean %.2f; pose err vs truth: median %.4f max %.4f m; map size %d; bets %s" % (
     r["n_scan"].mean(), r["iters"].mean(), np.median(err), err.max(), e.map_size(), e.bet_stats()))
 slow = np.argsort(ms)[-8:][::-1]
 print("slowest frames:", [(int(i + warm), round(float(ms[i]), 3), int(how[i]), int(r["deleted"][i + warm])) for i in slow])
 print("every 25th frame ms:", " ".join("%.3f" % v for v in ms[::25]))
+print("host wall per call, median ms (set_from_raw, prefetch, iterated_update, prepare, map_incremental, fov):", np.round(np.median(r["stage_ms"][warm:], axis=0), 3))
+it = r["iters"][warm:]
+for k in sorted(set(it.tolist())):
+    sel = it == k
+    print("  frames with %d iterations: %d, median %.3f ms (update %.3f, map_incremental %.3f)" % (k, sel.sum(), np.median(ms[sel]),
+          np.median(r["stage_ms"][warm:][sel, 2]), np.median(r["stage_ms"][warm:][sel, 4])))
 print("frames with allocations:", [(int(i), int(a)) for i, a in enumerate(r["allocs"]) if a > 0])
 print("map grid", e.map_grid(), e.map_info())
 # a few more frames with a device sync after every stage
 import torch
 rows = []
+if os.environ.get("NOSTAGE"):
+    sys.exit(0)
 for k in range(frames + warm, frames + warm + extra):
     n = int(sw["n"][k]); t = [time.perf_counter()]
     e.scan_set_from_raw(sw["rec"][k][:n], 4, 6, sw["poses"][k], sw["x_prop"][k], 0.5); torch.cuda.synchronize(); t.append(time.perf_counter())

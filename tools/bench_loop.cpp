@@ -182,7 +182,7 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
                             int32_t time_off_a, int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses, const double *x_prop,
                             const double *P0, float leaf, double filter_size_map, double cube_len, int32_t prefetch, double *x_out,
                             double *frame_us, int32_t *how, int64_t *deleted, int64_t *n_scan, s2m_iter_log *logs, int32_t *allocs,
-                            int32_t publish, double *publish_us, int64_t *mirror_stats)
+                            int32_t publish, double *publish_us, int64_t *mirror_stats, double *stage_us)
 {
     if (!e || frames < 0 || warm < 0 || !rec || !n || !poses || !x_prop || !P0 || !x_out || !frame_us || !how) return S2M_ERR_ARG;
     double P[S2M_DIM * S2M_DIM];
@@ -191,7 +191,7 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
     int64_t inplace_before = 0;
     int rc = s2m_map_inplace_updates(e, &inplace_before);
     if (rc) return rc;
-    int64_t st_prev[6] = {0, 0, 0, 0, 0, 0};
+    int64_t st_prev[10] = {0};
     (void)s2m_map_update_stats(e, st_prev);
     // publish != 0: the node also keeps /Laser_map up to date every frame (laserMapping.cpp:1170-1175, 1229-1235) -- a host
     // mirror fed by s2m_map_get_changes (daliti_s2m_mirror.hpp); publish_us[f] = that call's share of the frame
@@ -207,8 +207,12 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         const double *xp = x_prop + (int64_t)f * S2M_STATE_DOUBLES;
         double *x = x_out + (int64_t)f * S2M_STATE_DOUBLES;
         int64_t n_out = 0, na = 0, nb = 0, nd = 0;
+        auto lap = [&](int k) {  // host wall time of the frame's calls, in order (stage_us: 6 per frame, optional)
+            if (stage_us) stage_us[(int64_t)f * 6 + k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        };
         rc = s2m_scan_set_from_raw(e, r, 12, n[f], time_off_a, time_off_b, ps, n_poses, xp, leaf, 0, &n_out);
         if (rc) return rc;
+        lap(0);
         if (prefetch >= 1 && f + 1 < total) {
             rc = s2m_scan_prefetch_raw(e, r + rec_stride_floats, 12, n[f + 1], time_off_a, time_off_b);
             if (rc) return rc;
@@ -216,16 +220,20 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         std::memcpy(x, xp, S2M_STATE_DOUBLES * sizeof(double));
         std::memcpy(P, P0, sizeof(P));
         P[0] += (double)(f & 1) * 1e-15;
+        lap(1);
         rc = s2m_iterated_update(e, x, xp, P, &log);
         if (rc) return rc;
+        lap(2);
         if (logs) logs[f] = log;
         if (prefetch == 2 && f + 1 < total) {
             rc = s2m_scan_prepare_raw(e, r + rec_stride_floats, 12, n[f + 1], time_off_a, time_off_b, ps + n_poses, n_poses,
                                       xp + S2M_STATE_DOUBLES, leaf);
             if (rc) return rc;
         }
+        lap(3);
         rc = s2m_map_incremental(e, x, filter_size_map, 1, &na, &nb);
         if (rc) return rc;
+        lap(4);
         int32_t merged = 0;
         rc = s2m_map_last_update(e, &merged);
         if (rc) return rc;
@@ -248,6 +256,7 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
             inplace_before = inplace_now;
             if (h2 < h) h = h2;
         }
+        lap(5);
         if (publish) {
             const auto tp = std::chrono::steady_clock::now();
             rc = mirror.update(e);
@@ -259,7 +268,7 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         if (deleted) deleted[f] = nd;
         if (n_scan) n_scan[f] = n_out;
         if (allocs) {  // device buffers (re)allocated by the map code during this frame (each one stalls the stream)
-            int64_t st_now[6] = {0, 0, 0, 0, 0, 0};
+            int64_t st_now[10] = {0};
             (void)s2m_map_update_stats(e, st_now);
             allocs[f] = (int32_t)(st_now[3] - st_prev[3]);
             st_prev[3] = st_now[3];
