@@ -210,16 +210,31 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     int64_t na = 0, nb = 0;
     // Nearest_Points[i] of the reference is never short (unbounded search): finish the lists that ended at the gate -- when
     // the last rematch pass reported any (block[159]; a scan inside the mapped area has none: no launch, no round trip)
-    if (e->nn_valid && ekf_inited != 0 && e->short_lists != 0 && !e->nn_complete && !e->nn_nearest && e->n > 0 && e->grid.m > 0) {
-        int rc = complete_lists(e, 1, e->blind_rounds, nullptr);
+    // ONE launch of the far-point kernel with the radius of the whole map (its rounds grow their band -- and the bricks they
+    // look at -- until the nearest neighbour is proven), nobody asked whether anything was open before or is open after: the
+    // count of lists it had to leave open comes back with the classification's own hand-back, and only then (a scan point
+    // further from every map point than the map is wide) the classic loop of rounds and questions runs and the scan is
+    // classified again.
+    const bool complete = e->nn_valid && ekf_inited != 0 && e->short_lists != 0 && !e->nn_complete && !e->nn_nearest && e->n > 0 && e->grid.m > 0;
+    const uint32_t *open_word = nullptr;
+    if (complete) {
+        int rc = complete_lists(e, 1, -1, nullptr);
         if (rc) return rc;
-        e->nn_nearest = true;
+        open_word = e->d_hard + 3 * e->n_cap + 3;
     }
     VoxBox vox;
     bind_update(e);
+    uint32_t left_open = 0;
     S2M_HIP(e, incr_classify(e->upd, pose, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, (int)e->n,
                              e->d_nn_idx, e->grid, e->nn_valid && ekf_inited != 0, filter_size_map, &la, &na, &lb, &nb, e->stream,
-                             &vox, true));   // (update_begin runs inside, while the counts travel to the host)
+                             &vox, true, open_word, &left_open));   // (update_begin runs inside, while the counts travel to the host)
+    if (complete && left_open != 0) {
+        int rc = complete_lists(e, 1, 0, nullptr);
+        if (rc) return rc;
+        S2M_HIP(e, incr_classify(e->upd, pose, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, (int)e->n,
+                                 e->d_nn_idx, e->grid, true, filter_size_map, &la, &na, &lb, &nb, e->stream, &vox, true));
+    }
+    if (complete) e->nn_nearest = true;
     if (n_to_add) *n_to_add = na;
     if (n_no_downsample) *n_no_downsample = nb;
     S2M_HIP(e, update_add(e->upd, e->grid, la, na, true, (float)filter_size_map, nullptr, e->stream, &vox));   // :627
@@ -450,6 +465,19 @@ int complete_lists(s2m_engine *e, int k, int blind, int64_t *n_completed)
     }
     const double half_diag = 0.5 * c * std::sqrt(diag2);
     int64_t first = -1;
+    if (blind < 0) {
+        // the whole map's radius in one launch: the box of the bricks in use seen from anywhere within a sensor's reach of it
+        const double r = 4.0 * half_diag + 1000.0;
+        m.open_count = m.hard_count + 3;   // (zeroed by the collecting kernel, read by the caller's next hand-back)
+        launch_collect_short(m, e->stream);
+        m.band0 = 2.0f * std::sqrt(m.gates.knn_d2_gate);
+        m.gates.knn_d2_gate = (float)std::min(r * r, 1.0e37);
+        launch_match_hard_only(m, e->stream);
+        launch_far_reset(m.hard_count, e->d_qheads, e->stream, /*keep_open=*/true);
+        S2M_HIP(e, hipGetLastError());
+        return S2M_OK;
+    }
+    launch_far_reset(m.hard_count, e->d_qheads, e->stream);  // (also the word a blind launch may have left)
     for (int round = 0; round < 64; ++round) {
         // hard_count / qheads are zero here: every reduce launch and every round below leaves them so
         launch_collect_short(m, e->stream);

@@ -174,9 +174,11 @@ hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_hos
                          hipStream_t st);
 hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStream_t st);
 // (the neighbour lists need only be exact up to the gate and in their first entry: s2m_mapupd.hip, incr_classify_kernel)
+// extra / extra_out: one more device word brought back with the counts (the completion's "lists left open")
 hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, const float *sy, const float *sz, int n,
                          const int32_t *nn_idx, const Grid &g, bool have_nn, double fs, float4 **to_add, int64_t *n_add,
-                         float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox = nullptr, bool begin_update = false);
+                         float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox = nullptr, bool begin_update = false,
+                         const uint32_t *extra = nullptr, uint32_t *extra_out = nullptr);
 hipError_t xyz_to_float4(UpdateBuffers &u, const float *xyz_dev, int64_t stride, int64_t n, float4 **out, hipStream_t st);
 // the map in CALLER order as packed xyz (ikdtree.flatten's counterpart): xyz[3 * pidx[j]] = pts[j]
 void launch_map_to_xyz(const float4 *pts, const uint32_t *rank, int64_t m, float *xyz, hipStream_t st);
@@ -269,6 +271,7 @@ struct MatchArgs {
     uint32_t *qheads = nullptr;  // kQueueShards dequeue heads of match_hard's work queue, kQueueStride words apart
     LoopLaunch loop;             // device-resident loop (s2m_loop.h): state == nullptr for a host-stepped pass
     int32_t far_waves = 0;       // > 0: waves of the far-point launch (few far points expected); 0: as many as stay resident
+    uint32_t *open_count = nullptr;  // launch_match_hard_only: += 1 for every list that is still unsettled at the launch's radius
     float band0 = 0.0f;          // launch_match_hard_only: first band of the search in metres (0: the kernel's own)
     int32_t short_k = kK;        // launch_collect_short / launch_match_hard_only: a list is open while its short_k-th entry is not proven (5: the whole list; 1: the nearest)
 };
@@ -284,7 +287,7 @@ void launch_far_points(const MatchArgs &a, bool wide, hipStream_t st);
 void launch_collect_short(const MatchArgs &a, hipStream_t st);
 void launch_match_hard_only(const MatchArgs &a, hipStream_t st);
 // the far-point list's counters and queue heads back to zero (one launch; two memsets are four)
-void launch_far_reset(uint32_t *hard_count, uint32_t *qheads, hipStream_t st);
+void launch_far_reset(uint32_t *hard_count, uint32_t *qheads, hipStream_t st, bool keep_open = false);  // keep_open: word 3 (lists left open) stays
 
 // ---- s2m_reduce.hip : [plane fit +] residual + Jacobian + normal block ----------------------------
 constexpr int kRedBlock = 512;   // 8 waves per workgroup: 128 partial rows at 65k points for the in-kernel final sum

@@ -777,8 +777,10 @@ hipError_t caller_ranks(UpdateBuffers &u, const Grid &g, const uint8_t *alive_s,
 
 hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, const float *sy, const float *sz, int n,
                          const int32_t *nn_idx, const Grid &g, bool have_nn, double fs, float4 **to_add, int64_t *n_add,
-                         float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox, bool begin_update)
+                         float4 **no_down, int64_t *n_no_down, hipStream_t st, VoxBox *vox, bool begin_update, const uint32_t *extra,
+                         uint32_t *extra_out)
 {
+    if (extra_out) *extra_out = 0u;
     if (vox) *vox = VoxBox{};
     *n_add = 0;
     *n_no_down = 0;
@@ -827,14 +829,15 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
     {   // both list lengths with one hand-back: last position + last flag, as four 32-bit words
         const uint32_t *p32 = reinterpret_cast<const uint32_t *>(ps + (n - 1)), *f32 = reinterpret_cast<const uint32_t *>(fl + (n - 1));
         const uint32_t *v = u.counters + kUpdVoxWord;
-        const uint32_t *src[10] = {p32, f32, p32 + 1, f32 + 1, v, v + 1, v + 2, v + 3, v + 4, v + 5};
-        uint32_t h[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        S2M_TRY(mail_post(u.mail, src, 10, st));
+        const uint32_t *src[11] = {p32, f32, p32 + 1, f32 + 1, v, v + 1, v + 2, v + 3, v + 4, v + 5, extra ? extra : p32};
+        uint32_t h[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        S2M_TRY(mail_post(u.mail, src, 11, st));
         // the update this classification feeds begins while the counts travel (its reset kernel needs none of them and
         // zeroes the box words behind the read above, in stream order)
         if (begin_update) S2M_TRY(update_begin(u, g, st));
         else S2M_TRY(hipMemsetAsync(u.counters + kUpdVoxWord, 0, 6 * sizeof(uint32_t), st));
-        S2M_TRY(mail_collect(u.mail, 10, h, st));
+        S2M_TRY(mail_collect(u.mail, 11, h, st));
+        if (extra && extra_out) *extra_out = h[10];
         *n_add = (int64_t)h[0] + h[1];
         *n_no_down = (int64_t)h[2] + h[3];
         if (vox && *n_add > 0) {  // the box of the PointToAdd voxels: every one of them lies inside by construction

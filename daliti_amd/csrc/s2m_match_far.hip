@@ -220,11 +220,14 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
 #pragma unroll
                 for (int k = 0; k < 2; ++k) append_cells(nid[k], nrow, nxa[k], ncl[k]);  // <= 2 x 49 x 7 cells
             } else {
-            // FAR: the neighbourhood clipped to the grid (empty when the point lies further outside than the radius)
-            const int flx = max(hbx - NB, g.blo[0]), fly = max(hby - NB, g.blo[1]), flz = max(hbz - NB, g.blo[2]);
-            const int fsx = FAR ? max(min(hbx + NB, g.bhi[0]) - flx + 1, 0) : 0;
-            const int fsy = FAR ? max(min(hby + NB, g.bhi[1]) - fly + 1, 0) : 0;
-            const int fsz = FAR ? max(min(hbz + NB, g.bhi[2]) - flz + 1, 0) : 0;
+            // FAR: the neighbourhood clipped to the grid (empty when the point lies further outside than the radius) -- and to
+            // the rings THIS round's radius needs: the launch's own radius may be that of the whole map (one launch finishes
+            // every list, s2m_engine_map.cpp), a round must not pay for more bricks than its band reaches
+            const int NBr = FAR ? min(NB, max(1, (int)fminf(ceilf(sqrtf(r2) * g.inv_c * 0.125f + 1e-3f), 1048576.0f))) : NB;
+            const int flx = max(hbx - NBr, g.blo[0]), fly = max(hby - NBr, g.blo[1]), flz = max(hbz - NBr, g.blo[2]);
+            const int fsx = FAR ? max(min(hbx + NBr, g.bhi[0]) - flx + 1, 0) : 0;
+            const int fsy = FAR ? max(min(hby + NBr, g.bhi[1]) - fly + 1, 0) : 0;
+            const int fsz = FAR ? max(min(hbz + NBr, g.bhi[2]) - flz + 1, 0) : 0;
             const int nbr = FAR ? (int)min((long long)fsx * fsy * fsz, 0x7fffffc0ll) : nbricks;
             for (int bbase = 0; bbase < nbr; bbase += 64) {
                 // 1. top entries of up to 64 bricks, one per lane
@@ -310,7 +313,10 @@ __device__ __forceinline__ void match_hard_body(const MatchArgs &a, uint2 *__res
             // band mode: rows with bound <= band^2 were scanned over their whole reach of this band only,
             // so restart the private lists when the radius changes (rows are rescanned with the new reach)
             if (found5 && d5 <= band * band) break;          // five found inside the fully scanned band
-            if (band * band > a.gates.knn_d2_gate) break;    // beyond the gate: result is "not five within it"
+            if (band * band > a.gates.knn_d2_gate) {         // beyond the gate: result is "not five within it"
+                if (FAR && a.open_count && lane == 0) atomicAdd(a.open_count, 1u);  // (the completion counts the lists it leaves open)
+                break;
+            }
             // Nothing beyond the gate matters (a 5th neighbour past it is rejected, :853): neither the exact round nor a
             // grown band goes further than just past the gate radius.  (At C4, where the predicted pose displaces far
             // returns by metres, the band used to double from 3.4 to 6.8 cells -- 3.4 m against a 2.24 m gate -- for every
@@ -699,6 +705,7 @@ __device__ __forceinline__ uint32_t wave_max_u32_slow(uint32_t v)
 __global__ __launch_bounds__(256) void collect_short_kernel(MatchArgs a)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && a.open_count) *a.open_count = 0u;  // (the far-point launch behind this one counts the lists it leaves open)
     bool want = false;
     uint32_t far_bits = 0u;
     HardRec rec = {0.f, 0.f, 0.f, 0u, 0.f, 0u, 0u, 0u};
@@ -730,15 +737,15 @@ void launch_collect_short(const MatchArgs &a, hipStream_t st)
     hipLaunchKernelGGL(collect_short_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
 }
 
-__global__ __launch_bounds__(256) void far_reset_kernel(uint32_t *__restrict__ hard_count, uint32_t *__restrict__ qheads)
+__global__ __launch_bounds__(256) void far_reset_kernel(uint32_t *__restrict__ hard_count, uint32_t *__restrict__ qheads, int words)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 4) hard_count[i] = 0u;
+    if (i < words) hard_count[i] = 0u;
     if (i < kQueueWords) qheads[i] = 0u;
 }
-void launch_far_reset(uint32_t *hard_count, uint32_t *qheads, hipStream_t st)
+void launch_far_reset(uint32_t *hard_count, uint32_t *qheads, hipStream_t st, bool keep_open)
 {
-    hipLaunchKernelGGL(far_reset_kernel, dim3((kQueueWords + 255) / 256), dim3(256), 0, st, hard_count, qheads);
+    hipLaunchKernelGGL(far_reset_kernel, dim3((kQueueWords + 255) / 256), dim3(256), 0, st, hard_count, qheads, keep_open ? 3 : 4);
 }
 
 void launch_match_hard_only(const MatchArgs &a, hipStream_t st)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How much of the neighbour search of a later rematch pass is already known from the pass before it?
-GPU box: python3 scripts/nn_stability.py [C3|R1|C1|C2]
+GPU box: python3 scripts/nn_stability.py [C3|R1|C1|C2] [imu]
 Prints, for the two rematch poses of the iterated update of the config (x_prop and the converged pose): the share of
 points whose 5-NN SET is unchanged, whose ORDERED list is unchanged, and how tight the bound "farthest old neighbour
 seen from the new query" is against the true 5th distance (the warm-start lever, NOTEBOOK.md round 4)."""
@@ -13,7 +13,11 @@ name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 cfgd = synth.CONFIGS[name]
 map_xyz = synth.make_map(cfgd["M"], cfgd["L"], seed=1)
 scan = synth.make_scan(cfgd["beams"], cfgd["az"], cfgd["L"], seed=2)
-_xt, x_prop, P0 = synth.filter_inputs(synth.SENSOR_POS)
+# third argument "imu": an IMU-sized prediction error (2 cm, 0.1 deg) instead of BASELINE's 5 cm / 1 deg
+if len(sys.argv) > 2 and sys.argv[2] == "imu":
+    _xt, x_prop, P0 = synth.filter_inputs(synth.SENSOR_POS, dtheta=np.deg2rad(0.1) * np.array([0.6, -0.5, 0.62]), dpos=0.02 * np.array([0.66, -0.53, 0.53]))
+else:
+    _xt, x_prop, P0 = synth.filter_inputs(synth.SENSOR_POS)
 e = Engine(max_iter=5, feat_threshold=100)
 if name == "R1":
     import bench
