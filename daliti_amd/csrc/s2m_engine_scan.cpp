@@ -16,7 +16,9 @@ int scan_reserve(s2m_engine *e, int64_t n)
 {
     if (n <= e->n_cap && e->n_cap > 0) return S2M_OK;
     pf_drain(e);  // (a prepared scan was laid out for the old capacity: it is recognised as stale when it is picked up)
-    const int64_t cap = ((std::max<int64_t>(n, 1) + 255) / 256) * 256;  // an empty first scan still gets buffers
+    // (an eighth more than asked: a stream's sweeps differ by a few hundred points, and a larger one must not re-allocate
+    // fourteen arrays in the middle of a frame; an empty first scan still gets buffers)
+    const int64_t cap = ((std::max<int64_t>(n + n / 8, 1) + 255) / 256) * 256;
     int rc = 0;
     rc = rc ? rc : grow(e, &e->d_scan, 3 * cap);
     rc = rc ? rc : grow(e, &e->d_plane, cap);
@@ -117,9 +119,9 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride, int64_t n,
     } else {
         const int64_t floats = n * stride;
         if (floats > e->stage_cap) {
-            rc = grow(e, &e->d_stage, floats);
+            rc = grow(e, &e->d_stage, floats + floats / 8);  // (room for the next, slightly larger sweep)
             if (rc) return rc;
-            e->stage_cap = floats;
+            e->stage_cap = floats + floats / 8;
         }
         S2M_HIP(e, hipMemcpyAsync(e->d_stage, points, (size_t)floats * sizeof(float), hipMemcpyHostToDevice, e->stream));
         dev = e->d_stage;
@@ -243,8 +245,11 @@ int pf_start(s2m_engine *e, const float *points, int64_t floats)
         S2M_HIP(e, hipStreamSynchronize(p.stream));
         if (p.d_buf) S2M_HIP(e, hipFree(p.d_buf));
         p.d_buf = nullptr;
-        S2M_HIP(e, hipMalloc((void **)&p.d_buf, (size_t)floats * sizeof(float)));
-        p.cap = floats;
+        // (an eighth more than asked: sweeps differ by a few hundred returns, and a reallocation -- a device-wide stall of
+        // ~0.3 ms -- every time a slightly larger one arrives showed up as the worst frame of a drive)
+        const int64_t want = floats + floats / 8;
+        S2M_HIP(e, hipMalloc((void **)&p.d_buf, (size_t)want * sizeof(float)));
+        p.cap = want;
     }
     if (!p.worker.joinable()) p.worker = std::thread(prefetch_worker, e);
     p.src = points;
@@ -368,9 +373,9 @@ int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, in
         if (!on_device && !prefetched) {
             const int64_t floats = n * stride;
             if (floats > e->stage_cap) {
-                rc = grow(e, &e->d_stage, floats);
+                rc = grow(e, &e->d_stage, floats + floats / 8);  // (room for the next, slightly larger sweep)
                 if (rc) return rc;
-                e->stage_cap = floats;
+                e->stage_cap = floats + floats / 8;
             }
             S2M_HIP(e, hipMemcpyAsync(e->d_stage, points, (size_t)floats * sizeof(float), hipMemcpyHostToDevice, e->stream));
             dev = e->d_stage;

@@ -43,6 +43,8 @@ slow = np.argsort(ms)[-8:][::-1]
 print("slowest frames:", [(int(i + warm), round(float(ms[i]), 3), int(how[i]), int(r["deleted"][i + warm])) for i in slow])
 print("every 25th frame ms:", " ".join("%.3f" % v for v in ms[::25]))
 print("host wall per call, median ms (set_from_raw, prefetch, iterated_update, prepare, map_incremental, fov):", np.round(np.median(r["stage_ms"][warm:], axis=0), 3))
+for f in range(6, 14):
+    print("  frame %d: %.3f ms, stages %s, iters %d, scan %d, how %d" % (f, r["ms"][f], np.round(r["stage_ms"][f], 3), r["iters"][f], r["n_scan"][f], r["how"][f]))
 it = r["iters"][warm:]
 for k in sorted(set(it.tolist())):
     sel = it == k
