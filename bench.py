@@ -1197,11 +1197,32 @@ def frame_pipeline_moving(torch, Engine, synth, a):
            "pose_error_vs_truth_m": {"median": float(np.median(err)), "max": float(err.max())},
            "world": "hall %.0f m wide, %.0f m long, 10 m high, pillars on a 24 m lattice; seed = %d points over its first %.0f m" % (
                L, 6.0 * L, len(seed), L),
-           "with_map_publishing": None,
+           "at_reference_map_density": None, "with_map_publishing": None,
            "note": "host-timed per frame, raw records cross PCIe; front half of frame k + 1 beside frame k's map update (s2m_scan_prepare_raw); "
                    "not part of `value`.  how a frame's map update was produced: in_place = only the bricks it touched were rewritten (bricks that "
                    "open or outgrow their stretch move to the tail of the point array), merged = the whole map re-laid out, rebuilt = re-sorted"}
     eng.close()
+    # the same drive seeded at the REFERENCE's map density: the seed cloud through Add_Points(downsample 0.5 m), as config R1
+    # (the node's map only ever holds voxel-filtered points; the 5 M-point seed above is the benchmark's density)
+    try:
+        eng = Engine(max_iter=a.max_iter, device=torch.cuda.current_device())
+        m_ref = build_reference_density_map(eng, seed)
+        info_r = eng.map_info()
+        st0 = eng.map_update_stats()
+        rr = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2)
+        torch.cuda.synchronize()
+        st1 = eng.map_update_stats()
+        msr, howr = rr["ms"][warm:], rr["how"][warm:]
+        out["at_reference_map_density"] = {
+            "map_points_seed": int(m_ref), "cell_m": float(info_r["cell"]), "median_ms": float(np.median(msr)),
+            "p99_ms": float(np.percentile(msr, 99)), "max_ms": float(msr.max()), "max_over_median": float(msr.max() / np.median(msr)),
+            "updates": {"in_place": int((howr == 2).sum()), "merged": int((howr == 1).sum()), "rebuilt": int((howr == 0).sum()),
+                        "regridded": int(st1["regridded"] - st0["regridded"]), "not_in_place_because": st1["not_in_place"]},
+            "map_points_end": int(eng.map_size()),
+            "note": "same sweeps, same loop; the seed is C3's cloud of the hall's first section through s2m_map_add(downsample 0.5 m)"}
+        eng.close()
+    except Exception as ex:  # noqa: BLE001
+        out["at_reference_map_density"] = {"error": str(ex)[:300]}
     # the same drive with /Laser_map kept up to date every frame (laserMapping.cpp:1170-1175, 1229-1235): a host mirror fed
     # by the change log (s2m_map_get_changes) against what the reference does, a flatten of the whole map per frame
     try:

@@ -72,3 +72,15 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "s2m_oracle" not in src.replace("oracle/s2m_oracle.c", ""), f
+
+
+def test_mirror_header_compiles_against_the_abi(tmp_path):
+    """include/daliti_s2m_mirror.hpp (the node's copy of the map, fed by s2m_map_get_changes) is header-only C++ over the C ABI:
+    it compiles on its own with plain g++ and uses nothing the header does not declare."""
+    import subprocess
+    src = tmp_path / "mirror_tu.cpp"
+    src.write_text('#include "daliti_s2m_mirror.hpp"\nint use(s2m_engine *e) { static s2m_map_mirror m; return m.update(e); }\n')
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+    hpp = open(os.path.join(ROOT, "include", "daliti_s2m_mirror.hpp")).read()
+    used = set(re.findall(r"\b(s2m_[a-z0-9_]+)\s*\(", hpp))
+    assert {"s2m_map_get_changes", "s2m_map_get_points", "s2m_map_get_ids"} <= used and used <= set(_declared())
