@@ -352,8 +352,11 @@ int s2m_map_get_changes(s2m_engine *e, uint64_t *token, float *added_xyz, uint32
     };
     if (!e->log.on || e->log.token == 0 || *token != e->log.token) {
         // the caller does not hold the state the log starts from (first call, a rebuild in between, another follower's token)
-        // (room for a field-of-view trim of a few million points: 20 bytes per entry; beyond that the follower fetches the map)
-        S2M_HIP(e, changelog_ensure(e->log, std::max<int64_t>((int64_t)1 << 22, 4 * e->n_cap), e->stream));
+        // (room for a field-of-view trim of a few million points: 20 bytes per entry; beyond that the follower fetches the map.
+        // S2M_LOG_CAP: test hook, a capacity small enough to overflow)
+        int64_t cap = std::max<int64_t>((int64_t)1 << 22, 4 * e->n_cap);
+        if (const char *g = std::getenv("S2M_LOG_CAP")) cap = std::max<int64_t>(16, std::atoll(g));
+        S2M_HIP(e, changelog_ensure(e->log, cap, e->stream));
         launch_log_reset(e->log, e->stream);
         fresh();
         *resync = 1;

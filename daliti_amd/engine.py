@@ -346,6 +346,9 @@ class Engine:
     def scan_prefetch_raw(self, records, time_off_a=-1, time_off_b=-1):
         """Start the host-to-device copy of the NEXT sweep's records (a C-contiguous float32 array the caller keeps alive and
         hands to scan_set_from_raw unchanged); with the time field offsets also their time order."""
+        if records is None:     # cancel: the sweep that was announced is not coming
+            self._ck(self.lib.s2m_scan_prefetch_raw(self.h, None, C.c_int64(3), C.c_int64(0), C.c_int32(-1), C.c_int32(-1)))
+            return
         assert records.dtype == np.float32 and records.flags["C_CONTIGUOUS"]
         self._ck(self.lib.s2m_scan_prefetch_raw(self.h, _p(records), C.c_int64(records.shape[1]), C.c_int64(records.shape[0]),
                                                 C.c_int32(time_off_a), C.c_int32(time_off_b)))

@@ -746,3 +746,75 @@ def test_two_threads_drive_two_handles_through_the_large_form(small_scene):
         for s in range(len(a[0])):
             assert a[2][s] == b[2][s] and (bits(a[0][s]) == bits(b[0][s])).all(), (k, s)
             assert (a[1][s][0] == b[1][s][0]).all() and (bits(a[1][s][1]) == bits(b[1][s][1])).all(), (k, s)
+
+
+@pytest.mark.gpu
+def test_scan_far_from_any_map_point_is_classified_like_the_reference(oracle, small_scene):
+    """map_incremental proves the nearest neighbour of the points beyond the gate in ONE far-point launch whose radius is that
+    of the whole map and a sensor's reach around it; a scan further away than that leaves lists open, the count comes back with
+    the classification, the classic loop of rounds finishes them and the scan is classified again: same lists as the oracle's
+    unbounded search either way."""
+    from daliti_amd import Engine
+    e = Engine(max_iter=3, feat_threshold=1, cell_size=0.5)
+    base = small_scene["map"]
+    e.map_build(base)
+    x = small_scene["x_true"].copy()
+    # half of the scan where it is, half moved 6 km along x (further than 4 x the map's half diagonal + 1 km)
+    scan = small_scene["scan"].copy()
+    scan[::2, 0] += np.float32(6000.0)
+    e.scan_set(scan)
+    e.residual_pass(x, True)
+    na, nb = e.map_incremental(x, 0.5)
+    tree = oracle.KdTree(base)
+    oi, od, oc = tree.knn5(oracle.body_to_world(x, scan))
+    to_add, no_down = oracle.map_incremental_lists(scan, x, tree.xyz[np.maximum(oi, 0)], oc.astype(np.int32), 0.5)
+    assert (na, nb) == (len(to_add), len(no_down)) and nb > 100, (na, nb, len(to_add), len(no_down))
+    om = oracle.Map(base)
+    om.add(to_add, True, 0.5)
+    om.add(no_down, False)
+    assert e.map_size() == om.size() and (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
+    st = e.map_update_stats()
+    assert st["rebuilt"] == 0, st     # 6 km at 0.5 m cells: 12 000 cells from the origin, far inside the representable range
+    e.close()
+
+
+@pytest.mark.gpu
+def test_change_log_overflow_and_rebuild_ask_the_follower_to_start_over(small_scene, monkeypatch):
+    """s2m_map_get_changes: more changes than the log holds, or a rebuild (ids numbered anew), answer *resync = 1; the follower
+    fetches the map once and is in step again."""
+    from daliti_amd import Engine
+    rs = np.random.RandomState(8)
+    base = small_scene["map"][:8000]
+
+    def follow(e, token, ids, xyz):
+        token, resync, ax, ai, rem = e.map_changes(token)
+        if resync:
+            return token, True, e.map_ids(), e.map_points().copy()
+        keep = ~np.isin(ids, rem)
+        new = ~np.isin(ai, rem)
+        return token, False, np.concatenate([ids[keep], ai[new]]), np.concatenate([xyz[keep], ax[new]])
+    monkeypatch.setenv("S2M_LOG_CAP", "64")
+    e = Engine(cell_size=0.5)
+    e.map_build(base)
+    token, resync, ids, xyz = follow(e, 0, None, None)
+    assert resync
+    e.map_add(base[:20] + np.float32(0.07), False)                      # 20 changes: inside the log
+    token, resync, ids, xyz = follow(e, token, ids, xyz)
+    assert not resync and len(ids) == 8020
+    e.map_add((base[:500] + rs.normal(0, 0.3, (500, 3))).astype(np.float32), False)   # 500 changes: more than 64
+    token, resync, ids, xyz = follow(e, token, ids, xyz)
+    assert resync and len(ids) == 8520
+    e.map_delete_boxes(np.float32([[-1, -1, -1, 1, 1, 0.5]]))            # inside the log again?  (a handful of points)
+    n_after = e.map_size()
+    token, resync, ids, xyz = follow(e, token, ids, xyz)
+    assert len(ids) == n_after and (ids == e.map_ids()).all() and (bits(xyz) == bits(e.map_points())).all()
+    e.close()
+    monkeypatch.delenv("S2M_LOG_CAP")
+    monkeypatch.setenv("S2M_NO_MERGE", "1")                               # every update rebuilds: the ids are numbered anew
+    e = Engine(cell_size=0.5)
+    e.map_build(base)
+    token, resync, ids, xyz = follow(e, 0, None, None)
+    e.map_add(base[:20] + np.float32(0.07), False)
+    token, resync, ids, xyz = follow(e, token, ids, xyz)
+    assert resync and (ids == np.arange(8020)).all() and (bits(xyz) == bits(e.map_points())).all()
+    e.close()

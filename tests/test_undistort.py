@@ -170,10 +170,24 @@ def test_prefetched_records_give_the_same_scan(oracle):
         assert (bits(e.scan_get()) == bits(plain)).all()
     e.scan_prefetch_raw(rec)
     e.scan_prefetch_raw(rec)                                   # a second request while (or after) the first one runs
-    e.scan_set_from_raw(other, 4, 6, poses, end, 0.3)          # another buffer: the prefetch is ignored ...
+    e.scan_set_from_raw(other, 4, 6, poses, end, 0.3)          # another buffer: the prefetch is ignored -- and dropped ...
     assert (bits(e.scan_get()) == bits(plain_other)).all()
-    e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3)            # ... and still there for the buffer it was made from
+    e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3)            # ... this call copies for itself
     assert (bits(e.scan_get()) == bits(plain)).all()
+    # a node that recycles its host buffers: a sweep is announced and then dropped, something else is registered, and NEW
+    # records arrive at the same address with the same size -- the copy made for the dropped sweep must not be used
+    recycled = rec.copy()
+    e.scan_prefetch_raw(recycled, 4, 6)
+    e.scan_set(sc["scan"])                                     # (any other road a scan arrives by drops the copy)
+    recycled[:, :3] = other[:, :3]
+    e.scan_set_from_raw(recycled, 4, 6, poses, end, 0.3)
+    assert (bits(e.scan_get()) == bits(plain_other)).all()
+    recycled[:, :3] = rec[:, :3]
+    e.scan_prefetch_raw(recycled, 4, 6)
+    e.scan_prefetch_raw(None)                                  # explicit cancel
+    recycled[:, :3] = other[:, :3]
+    e.scan_set_from_raw(recycled, 4, 6, poses, end, 0.3)
+    assert (bits(e.scan_get()) == bits(plain_other)).all()
     e.scan_prefetch_raw(other)                                 # never consumed: close() must not hang
     e.close()
 
