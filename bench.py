@@ -822,6 +822,29 @@ def main():
         cpu_scan = eng.scan_get() if a.config == "R1" else scans[0][0]
         out["cpu_baseline"] = cpu_baseline(a, cpu_map, cpu_scan, x_prop0, P0, res)
         out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
+    side_dog = None
+    if rank == 0 and single and side:
+        # The headline, its roofline and the CPU baseline are measured.  The side legs that follow must never cost the record:
+        # each is wrapped in try / except, and a leg that HANGS (a stall that no exception reports) is cut off here -- the line
+        # is printed with what has been collected and the process leaves with status 0.
+        import threading
+
+        def side_expired():
+            out["side_legs"] = "timed out after %s s: the legs not present in this line did not finish" % os.environ.get("S2M_SIDE_TIMEOUT_S", "600")
+            C.CDLL(None).fflush(None)
+            line = None
+            for _ in range(5):
+                try:
+                    line = json.dumps(out)
+                    break
+                except RuntimeError:
+                    time.sleep(0.01)
+            sys.stdout.write((line or json.dumps({"error": "watchdog: the record could not be serialised"})) + "\n")
+            sys.stdout.flush()
+            os._exit(0)
+        side_dog = threading.Timer(float(os.environ.get("S2M_SIDE_TIMEOUT_S", "600")), side_expired)
+        side_dog.daemon = True
+        side_dog.start()
     if rank == 0 and single and side and a.config == "C3" and not a.extrinsic:
         # BASELINE configs[4] on this one device, against the map that is already resident
         out["c5_batch"] = c5_batch(torch, Engine, synth, eng, a)
@@ -856,6 +879,8 @@ def main():
             out["frame_pipeline_moving"] = frame_pipeline_moving(torch, Engine, synth, a)
         except Exception as ex:  # noqa: BLE001 - a side leg never takes the headline down
             out["frame_pipeline_moving"] = {"error": str(ex)[:300]}
+    if side_dog is not None:
+        side_dog.cancel()
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:

@@ -52,6 +52,8 @@ for k in sorted(set(it.tolist())):
           np.median(r["stage_ms"][warm:][sel, 2]), np.median(r["stage_ms"][warm:][sel, 4])))
 print("frames with allocations:", [(int(i), int(a)) for i, a in enumerate(r["allocs"]) if a > 0])
 print("map grid", e.map_grid(), e.map_info())
+if os.environ.get("DUMP"):
+    print("all frames ms:", " ".join("%.3f" % v for v in r["ms"]))
 # a few more frames with a device sync after every stage
 import torch
 rows = []
@@ -65,5 +67,3 @@ for k in range(frames + warm, frames + warm + extra):
     e.fov_segment(rr["x"][9:12], 901.0); torch.cuda.synchronize(); t.append(time.perf_counter())
     rows.append(np.diff(t) * 1e3)
 print("staged (raw_to_scan, update, map_incremental, fov) median ms:", np.round(np.median(np.array(rows[2:]), axis=0), 3), "iters", rr["iters"], "rematch", rr.get("rematch"))
-if os.environ.get("DUMP"):
-    print("all frames ms:", " ".join("%.3f" % v for v in r["ms"]))

@@ -8,6 +8,8 @@
 // daliti_amd/_lib/libs2m_benchloop.so and loaded by bench.py with ctypes.
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -207,7 +209,12 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         const double *xp = x_prop + (int64_t)f * S2M_STATE_DOUBLES;
         double *x = x_out + (int64_t)f * S2M_STATE_DOUBLES;
         int64_t n_out = 0, na = 0, nb = 0, nd = 0;
+        static const bool progress = std::getenv("S2M_PROGRESS") != nullptr;  // (hunting a stall: which frame, which call)
+        auto say = [&](const char *what) { if (progress) { std::fprintf(stderr, "[frame %d] %s\n", f, what); std::fflush(stderr); } };
+        say("begin");
         auto lap = [&](int k) {  // host wall time of the frame's calls, in order (stage_us: 6 per frame, optional)
+            static const char *names[6] = {"set_from_raw", "prefetch", "iterated_update", "prepare", "map_incremental", "fov"};
+            say(names[k]);
             if (stage_us) stage_us[(int64_t)f * 6 + k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         };
         rc = s2m_scan_set_from_raw(e, r, 12, n[f], time_off_a, time_off_b, ps, n_poses, xp, leaf, 0, &n_out);
