@@ -272,10 +272,10 @@ __global__ __launch_bounds__(256) void tail_fill_kernel(int64_t from, int64_t to
 }
 
 // How many positions the tail of a layout of m points gets: room for the bricks that in-place updates open or move until the
-// next merge.  Generous (HBM is not what this engine is short of -- 29 bytes per position): as many as the map has points, at
-// least two million.  Measured on the drive of DESIGN section 6: ~13 K positions per frame at 0.5 m cells (4 m bricks), ~6 K at
-// the reference's map density (1.25 m cells, 10 m bricks that are moved whole): 150+ frames per merge at the smallest size.
-static int64_t tail_size_for(int64_t m) { return std::max<int64_t>(m, (int64_t)1 << 21); }
+// next merge.  Generous (HBM is not what this engine is short of -- 29 bytes per position): twice the map's points, at
+// least four million.  Measured on the drive of DESIGN section 6: ~13 K positions per frame at 0.5 m cells (4 m bricks), ~6 K at
+// the reference's map density (1.25 m cells, 10 m bricks that are moved whole): 600+ frames per merge at the smallest size.
+static int64_t tail_size_for(int64_t m) { return std::max<int64_t>(2 * m, (int64_t)1 << 22); }
 
 // dense layout of m points (buf.pts / pidx / keys_alt, tables built) -> layout with slack behind every brick and the tail
 // behind the last one; g.m becomes the new extent, buf.main_ext the extent of the key-ordered part
