@@ -1197,7 +1197,7 @@ def frame_pipeline_moving(torch, Engine, synth, a):
     ms, how = r["ms"][warm:], r["how"][warm:]
     med = float(np.median(ms))
     err = np.linalg.norm(r["x"][warm:, 9:12] - sw["x_true"][warm:warm + frames, 9:12], axis=1)
-    trims = [(int(i), int(d)) for i, d in enumerate(r["deleted"]) if d > 0]
+    trims = [(int(i) - warm, int(d)) for i, d in enumerate(r["deleted"]) if d > 0 and i >= warm]  # numbered like the timed frames
     lo, hi = eng.map_grid()
     info1 = eng.map_info()
     worst = int(np.argmax(ms))
@@ -1253,23 +1253,31 @@ def frame_pipeline_moving(torch, Engine, synth, a):
     try:
         eng = Engine(max_iter=a.max_iter, device=torch.cuda.current_device())
         eng.map_build(seed)
-        t0 = time.perf_counter()
-        flat = eng.map_points()
-        t_flat5 = (time.perf_counter() - t0) * 1e3
+        def flatten_ms():
+            best, pts = None, None
+            for _ in range(3):  # the first call of a size grows the pinned staging buffer
+                t0 = time.perf_counter()
+                pts = eng.map_points()
+                dt = (time.perf_counter() - t0) * 1e3
+                best = dt if best is None else min(best, dt)
+            return pts, best
+        flat, t_flat5 = flatten_ms()
         rp = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2, publish=True)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        flat_end = eng.map_points()
-        t_flat_end = (time.perf_counter() - t0) * 1e3
+        flat_end, t_flat_end = flatten_ms()
         msp = rp["ms"][warm:]
+        worst_p = int(np.argmax(msp))
+        trims_p = [int(f) - warm for f in np.nonzero(rp["deleted"])[0]]
         out["with_map_publishing"] = {
             "median_ms": float(np.median(msp)), "p99_ms": float(np.percentile(msp, 99)), "max_ms": float(msp.max()),
+            "worst_frame": worst_p, "worst_frame_is_a_fov_trim": bool(worst_p in trims_p),
             "map_delta_ms": {"median": float(np.median(rp["publish_ms"][warm:])), "p99": float(np.percentile(rp["publish_ms"][warm:], 99))},
             "map_flatten_ms": {"at_%d_points" % len(flat): float(t_flat5), "at_%d_points" % len(flat_end): float(t_flat_end)},
             "mirror_points_end": rp["mirror_points"], "map_points_end": rp["map_points"], "whole_map_fetches": rp["mirror_resyncs"],
             "note": "map_delta_ms = s2m_map_get_changes + applying it to the host mirror (include/daliti_s2m_mirror.hpp), inside the frame; "
-                    "map_flatten_ms = one s2m_map_get_points (rank the ids, gather, D2H of the whole map), what publishing every frame "
-                    "cost before and what the reference's ikdtree.flatten does on the CPU"}
+                    "map_flatten_ms = one s2m_map_get_points (rank the ids, gather, D2H of the whole map; best of 3), what publishing "
+                    "every frame cost before and what the reference's ikdtree.flatten does on the CPU.  the delta is proportional to the "
+                    "change: the frame of a field-of-view trim hands millions of removed ids to the mirror and is the max_ms here"}
         assert rp["mirror_points"] == rp["map_points"] == len(flat_end)
         eng.close()
     except Exception as ex:  # noqa: BLE001

@@ -166,6 +166,8 @@ int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *
     if (!e || n < 0 || (n > 0 && !boxes) || n > 4096) return fail(e, S2M_ERR_ARG, "s2m_map_delete_boxes: bad argument");
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
     if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
+    if (n_deleted) *n_deleted = 0;
+    if (!delete_touches_map(e->grid, boxes, (int)n)) return S2M_OK;  // (the slab ahead of the sensor after a cube move)
     S2M_HIP(e, hipSetDevice(e->device));
     bind_update(e);
     S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));

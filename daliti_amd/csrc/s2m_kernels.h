@@ -170,6 +170,8 @@ void free_update(UpdateBuffers &u);
 hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st);
 hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t n, bool downsample, float ds,
                       int64_t *n_added, hipStream_t st, const VoxBox *vox = nullptr);
+// false when no box of the call reaches the bricks in use (host arithmetic: such a call launches nothing and waits for nothing)
+bool delete_touches_map(const Grid &g, const float *boxes_host, int nb);
 hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_host, int nb, int64_t *n_deleted,
                          hipStream_t st);
 hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStream_t st);

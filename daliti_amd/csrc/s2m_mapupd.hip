@@ -275,6 +275,56 @@ __global__ __launch_bounds__(256) void delete_boxes_kernel(Grid g, const float4 
     if (threadIdx.x == 0 && cnt) atomicAdd(&counters[2], (uint32_t)cnt);
 }
 
+// the same deletion by BRICK, for a few large boxes (the slabs of a field-of-view move: laserMapping.cpp:346-368): one
+// wave per brick of the box's brick range (clipped to the bricks in use).  A brick whose cells all lie strictly between the
+// box's end cells is inside it whole (cell_coord is monotone: cell(p) > cell(mn) means p > mn, cell(p) < cell(mx) means
+// p < mx) and only its `alive` bytes are touched; the shell of bricks on the box's faces tests its points.  The kernel over
+// every position above read 15 M positions and chained three memory latencies per deleted point (183 us for 2.6 M points).
+struct DeleteBox {
+    float mn[3], mx[3];
+    int c0[3], c1[3];   // the cells of the box's corners
+    int b0[3], nbk[3];  // its brick range, clipped to the bricks in use
+};
+__global__ __launch_bounds__(256) void delete_box_bricks_kernel(Grid g, DeleteBox d, uint8_t *__restrict__ alive_s,
+                                                                uint8_t *__restrict__ bmark, uint32_t *__restrict__ counters)
+{
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0u;
+    __syncthreads();
+    const int64_t w = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t total = (int64_t)d.nbk[0] * d.nbk[1] * d.nbk[2];
+    uint32_t cnt = 0;
+    if (w < total) {
+        const int bx = d.b0[0] + (int)(w % d.nbk[0]), by = d.b0[1] + (int)((w / d.nbk[0]) % d.nbk[1]);
+        const int bz = d.b0[2] + (int)(w / ((int64_t)d.nbk[0] * d.nbk[1]));
+        const uint4 te = g.top[top_slot(g, bx, by, bz)];
+        if (te.x != 0u) {
+            const uint32_t *tb = g.tab + (int64_t)(te.x - 1u) * kBrickStride;
+            const uint32_t i0 = tb[0], i1 = tb[512];
+            const bool whole = bx * 8 > d.c0[0] && bx * 8 + 7 < d.c1[0] && by * 8 > d.c0[1] && by * 8 + 7 < d.c1[1] &&
+                               bz * 8 > d.c0[2] && bz * 8 + 7 < d.c1[2];
+            for (uint32_t i = i0 + lane; i < i1; i += 64u) {
+                if (!alive_s[i]) continue;
+                bool hit = whole;
+                if (!whole) {
+                    const float4 q = g.pts[i];
+                    hit = in_box(make_float4(q.x, q.y, map_point_z(q), 0.0f), d.mn, d.mx);
+                }
+                if (hit) { alive_s[i] = 0; ++cnt; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+            if (lane == 0u && cnt) {
+                bmark[te.x - 1u] |= 1u;
+                atomicAdd(&s_cnt, cnt);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(&counters[2], s_cnt);
+}
+
 // survivors of the map in CALLER order = ascending point id: (id or ~0 for a removed point, position) pairs are sorted by
 // id, the first `survivors` positions are gathered
 __global__ __launch_bounds__(256) void id_key_kernel(const uint32_t *__restrict__ pidx, const uint8_t *__restrict__ alive_s, int64_t m,
@@ -700,16 +750,57 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
     return hipGetLastError();
 }
 
+constexpr int kBrickBoxes = 8;  // up to this many boxes per call go brick by brick
+// the brick range of one box, clipped to the bricks in use; false when the box misses them
+static bool delete_box_range(const Grid &g, const float *box, DeleteBox &d)
+{
+    const float o[3] = {g.ox, g.oy, g.oz};
+    for (int k = 0; k < 3; ++k) {
+        d.mn[k] = box[k];
+        d.mx[k] = box[3 + k];
+        if (!(box[k] < box[3 + k])) return false;  // (an empty or NaN interval holds no point: min <= p < max)
+        d.c0[k] = cell_coord(box[k], o[k], g.inv_c);
+        d.c1[k] = cell_coord(box[3 + k], o[k], g.inv_c);
+        const int lo = std::max(d.c0[k], g.blo[k] * 8), hi = std::min(d.c1[k], g.bhi[k] * 8 + 7);
+        if (lo > hi) return false;
+        d.b0[k] = lo >> 3;
+        d.nbk[k] = (hi >> 3) - d.b0[k] + 1;
+    }
+    return true;
+}
+bool delete_touches_map(const Grid &g, const float *boxes_host, int nb)
+{
+    if (g.m == 0) return false;
+    if (nb > kBrickBoxes) return true;
+    DeleteBox d;
+    for (int b = 0; b < nb; ++b)
+        if (delete_box_range(g, boxes_host + 6 * b, d)) return true;
+    return false;
+}
+
 hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_host, int nb, int64_t *n_deleted,
                          hipStream_t st)
 {
     if (n_deleted) *n_deleted = 0;
     if (nb <= 0 || g.m == 0) return hipSuccess;
-    S2M_TRY(grow(&u.boxes, &u.boxes_cap, std::max<int64_t>((int64_t)nb * 6, 4096 * 6)));  // (the ABI's maximum: no growth in a frame)
-    S2M_TRY(hipMemcpyAsync(u.boxes, boxes_host, (size_t)nb * 6 * sizeof(float), hipMemcpyHostToDevice, st));
     // counters[2] is zero at update_begin and only this entry point adds to it: the count after the launch, minus
     // what earlier calls of the same update reported
-    hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g, g.pts, g.m, u.boxes, nb, u.alive_s, u.bmark, u.counters);
+    if (nb <= kBrickBoxes) {
+        // a few boxes: one launch per box over its bricks, one after the other (overlapping boxes count a point once)
+        int launched = 0;
+        for (int b = 0; b < nb; ++b) {
+            DeleteBox d;
+            if (!delete_box_range(g, boxes_host + 6 * b, d)) continue;  // outside the bricks in use: nothing to look at
+            const int64_t total = (int64_t)d.nbk[0] * d.nbk[1] * d.nbk[2];
+            hipLaunchKernelGGL(delete_box_bricks_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, g, d, u.alive_s, u.bmark, u.counters);
+            ++launched;
+        }
+        if (!launched) return hipSuccess;
+    } else {
+        S2M_TRY(grow(&u.boxes, &u.boxes_cap, std::max<int64_t>((int64_t)nb * 6, 4096 * 6)));  // (the ABI's maximum: no growth in a frame)
+        S2M_TRY(hipMemcpyAsync(u.boxes, boxes_host, (size_t)nb * 6 * sizeof(float), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(delete_boxes_kernel, dim3(nblk(g.m)), dim3(256), 0, st, g, g.pts, g.m, u.boxes, nb, u.alive_s, u.bmark, u.counters);
+    }
     const uint32_t *src[1] = {u.counters + 2};
     uint32_t after = 0;
     S2M_TRY(mail_fetch(u.mail, src, 1, &after, st));

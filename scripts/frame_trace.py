@@ -51,3 +51,24 @@ if len(sys.argv) > 4 and sys.argv[4] == "seq":
             k = ("rocprim::" + k.split("::")[-1].split("<")[0]) if "rocprim" in k else k[:44]
             print("  q%-3s +%7.1f us  %6.1f us  gap %5.1f  %s" % (q[-3:], (s - t0) / 1e3, (e - s) / 1e3, max(0, s - last_end) / 1e3, k))
             last_end = max(last_end, e)
+
+# a field-of-view trim as a sequence (4th argument "trim"): from the longest delete_boxes_kernel to the next classify
+if len(sys.argv) > 4 and sys.argv[4] == "trim":
+    full = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            full.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
+    full.sort()
+    dels = [i for i, r in enumerate(full) if "delete_boxes_kernel" in r[2]]
+    print("\n%d delete_boxes_kernel launches" % len(dels))
+    for a in sorted(dels, key=lambda i: full[i][0] - full[i][1])[:2]:
+        b = next(i for i in range(a, len(full)) if "incr_classify_kernel" in full[i][2])
+        t0 = full[a][0]; last_end = t0
+        print("trim, delete to the next classify: %.1f us" % ((full[b][0] - t0) / 1e3))
+        for s, e, n, q in full[max(a - 3, 0):b]:
+            k = n.split("(")[0].replace("void ", "")
+            k = ("rocprim::" + k.split("::")[-1].split("<")[0]) if "rocprim" in k else k[:44]
+            if "q3" == "q" + q[-1:] and False:
+                continue
+            print("  q%-3s +%7.1f us  %6.1f us  gap %5.1f  %s" % (q[-3:], (s - t0) / 1e3, (e - s) / 1e3, max(0, s - last_end) / 1e3, k))
+            last_end = max(last_end, e)

@@ -67,3 +67,7 @@ for k in range(frames + warm, frames + warm + extra):
     e.fov_segment(rr["x"][9:12], 901.0); torch.cuda.synchronize(); t.append(time.perf_counter())
     rows.append(np.diff(t) * 1e3)
 print("staged (raw_to_scan, update, map_incremental, fov) median ms:", np.round(np.median(np.array(rows[2:]), axis=0), 3), "iters", rr["iters"], "rematch", rr.get("rematch"))
+for f in np.nonzero(r["deleted"])[0]:
+    for g in (f - 1, f, f + 1, f + 2):
+        if 0 <= g < len(r["ms"]):
+            print("frame", int(g), "deleted", int(r["deleted"][g]), "ms %.3f" % r["ms"][g], "stages", np.round(r["stage_ms"][g], 3))

@@ -818,3 +818,44 @@ def test_change_log_overflow_and_rebuild_ask_the_follower_to_start_over(small_sc
     token, resync, ids, xyz = follow(e, token, ids, xyz)
     assert resync and (ids == np.arange(8020)).all() and (bits(xyz) == bits(e.map_points())).all()
     e.close()
+
+
+@pytest.mark.gpu
+def test_delete_boxes_by_brick_and_by_position(oracle, small_scene):
+    """s2m_map_delete_boxes takes two roads: up to eight boxes go brick by brick (whole bricks inside a box lose their
+    points without a coordinate being read, the shell on the faces is tested point by point), more boxes go through the
+    kernel over every position.  Overlapping slabs like a diagonal cube move's (laserMapping.cpp:346-363) count a point
+    once; a box that misses the bricks in use, an empty interval and a box with a face ON a point's coordinate (min <= p <
+    max, ikd_Tree.cpp:794) behave like the oracle's; and the two roads leave the same map."""
+    from daliti_amd import Engine
+    rs = np.random.RandomState(17)
+    base = (rs.uniform(0, 1, (120000, 3)) * [40.0, 40.0, 12.0] - [20.0, 20.0, 2.0]).astype(np.float32)   # 13 x 13 x 4 bricks of 3.2 m
+    lo, hi = base.min(0), base.max(0)
+    mid = (lo + hi) / 2
+    p_on = base[123]
+    slabs = np.float32([[lo[0] - 5, lo[1] - 5, lo[2] - 5, mid[0], hi[1] + 5, hi[2] + 5],           # the low-x half
+                        [lo[0] - 5, lo[1] - 5, lo[2] - 5, hi[0] + 5, lo[1] + 3.0, hi[2] + 5],      # a y slab crossing it
+                        [p_on[0], p_on[1], p_on[2], hi[0] + 5, hi[1] + 5, p_on[2] + 0.75]])        # a corner ON a point
+    many = np.concatenate([slabs] + [np.float32([[c[0] - 0.4, c[1] - 0.4, c[2] - 0.4, c[0] + 0.4, c[1] + 0.4, c[2] + 0.4]])
+                                     for c in base[rs.choice(len(base), 9, replace=False)]])
+    results = []
+    for boxes in (slabs, many):
+        e = Engine(cell_size=0.4)
+        e.map_build(base)
+        om = oracle.Map(base)
+        assert e.map_delete_boxes(np.float32([[hi[0] + 50, lo[1], lo[2], hi[0] + 60, hi[1], hi[2]]])) == 0      # beyond the bricks in use
+        assert e.map_delete_boxes(np.float32([[mid[0], mid[1], mid[2], mid[0], mid[1] + 1, mid[2] + 1]])) == 0  # empty interval
+        nd = e.map_delete_boxes(boxes)
+        no = sum(om.delete_box(b) for b in boxes)
+        assert nd == no > 20000
+        assert e.map_size() == om.size()
+        assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
+        assert e.map_delete_boxes(boxes[:3]) == 0                        # (what a cube that moves back and forth asks every frame)
+        # the map still takes an update and answers like the oracle's afterwards
+        new = base[:4000] + rs.normal(0, 0.05, (4000, 3)).astype(np.float32)
+        e.map_add(new, True, 0.5)
+        om.add(new, True, 0.5)
+        assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
+        results.append(_rows(e.map_points()))
+        e.close()
+    assert len(results[0]) >= len(results[1])
