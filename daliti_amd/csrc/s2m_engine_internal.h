@@ -66,6 +66,7 @@ struct s2m_engine {
     Mailbox mail;                   // stream waits of the per-frame entry points (polled, not hipStreamSynchronize)
     bool in_batch = false;          // set while the handle is served by s2m_iterated_update_batch with several scans
     bool no_merge = false;          // S2M_NO_MERGE=1: every update rebuilds the grid from scratch (A/B and tests)
+    bool exact_stage = false;       // S2M_EXACT_STAGE=1: map_incremental asks for the staged count after every batch (A/B and tests)
     bool no_slab = false;           // S2M_NO_SLAB=1: no in-place update of the touched bricks, every update merges (A/B and tests)
     int64_t n_inplace = 0;          // updates applied in place (counted among the merged ones too)
     ChangeLog log;                  // what the updates added / removed since the last s2m_map_get_changes

@@ -94,10 +94,16 @@ int commit_update(s2m_engine *e)
     if (e->log.on && e->log.token != 0 && e->grid.m > 0)   // somebody follows the map: the ids about to disappear, before anything moves
         launch_log_removed(e->log, e->map.counters + kBricksWord, e->stats.bricks, e->map.bmark, e->grid.tab, e->upd.alive_s, e->grid.pidx, e->stream);
     if (!e->no_merge && !e->no_slab && !drift_before) {  // in place when every touched brick fits where it stands
-        he = slab_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, e->upd.counters + kUpdSlabWord, merged, e->stream);
+        bool counted = false;
+        he = slab_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, e->upd.counters + kUpdSlabWord, merged, e->stream,
+                         update_stage_word(e->upd), &counted);
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "slab_update", he);
+        if (counted) e->upd.stage_deferred = false;  // (stage_n is the count now)
         if (merged) ++e->n_inplace;
     }
+    // (a count that stayed on the device and did not come back with the in-place update's hand-back)
+    he = update_stage_count(e->upd, e->stream);
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "update_stage_count", he);
     if (!e->no_merge && !drift_before && !merged) {
         he = merge_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, merged, e->stream, !e->no_slab);
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "merge_update", he);
@@ -239,8 +245,18 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     if (complete) e->nn_nearest = true;
     if (n_to_add) *n_to_add = na;
     if (n_no_downsample) *n_no_downsample = nb;
-    S2M_HIP(e, update_add(e->upd, e->grid, la, na, true, (float)filter_size_map, nullptr, e->stream, &vox));   // :627
-    S2M_HIP(e, update_add(e->upd, e->grid, lb, nb, false, 0.0f, nullptr, e->stream));                    // :628
+    {
+        static const bool hosttime = std::getenv("S2M_HOSTTIME") != nullptr;  // (diagnostic: sizes of the batches)
+        if (hosttime) {
+            static int64_t calls = 0, sa = 0, sb = 0, ma = 0, mb = 0;
+            sa += na; sb += nb; ma = std::max(ma, na); mb = std::max(mb, nb);
+            if (++calls % 200 == 0) std::fprintf(stderr, "[batches] %ld scans: to add mean %ld max %ld, no downsample mean %ld max %ld\n", (long)calls, (long)(sa / calls), (long)ma, (long)(sb / calls), (long)mb);
+        }
+    }
+    // (nobody asks for the number of points each call adds: the count stays on the device until the commit's own hand-back)
+    const bool defer = !e->exact_stage;
+    S2M_HIP(e, update_add(e->upd, e->grid, la, na, true, (float)filter_size_map, nullptr, e->stream, &vox, defer));   // :627
+    S2M_HIP(e, update_add(e->upd, e->grid, lb, nb, false, 0.0f, nullptr, e->stream, nullptr, defer));           // :628
     return commit_update(e);
 }
 

@@ -68,6 +68,8 @@ struct MapBuffers {
     int64_t n_moved = 0;         // bricks that in-place updates have put into the tail (diagnostic)
     int64_t slab_fail[4] = {0, 0, 0, 0};  // in-place updates given up because of: a point beyond the representable cells, no spare
                                  // table rows, a brick too large to stage, the tail exhausted (diagnostic)
+    uint2 *run = nullptr;        // per top slot: where the brick's new points stand among the update's sorted ones (slab_head_kernel)
+    int64_t run_cap = 0;
     uint32_t *grow = nullptr;    // per top slot: points the brick has gained (net) by in-place updates since the room was laid out
     int64_t grow_cap = 0;
     int64_t added_since_layout = 0;  // host bound of the sum of `grow`
@@ -118,8 +120,11 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
                         const float4 *stage, int64_t n_new, bool &merged, hipStream_t st, bool with_slack = false);
 // The same update in place when every touched brick still fits where it stands (s2m_mapedit.hip, slab_update): done = false and
 // nothing touched otherwise.  flags: five zeroed words of the update's counters.
-hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t n_new,
-                       uint32_t *flags, bool &done, hipStream_t st);
+// n_dev (optional): the device's word with the number of staged points when the host only knows the bound n_new (update_add
+// with defer): the points from *n_dev on are ignored, n_new comes back as that number and counted = true once the update's
+// hand-back has been read (also when the update could not be done in place).
+hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t &n_new,
+                       uint32_t *flags, bool &done, hipStream_t st, const uint32_t *n_dev = nullptr, bool *counted = nullptr);
 
 // ---- s2m_mapupd.hip : incremental map maintenance (map_incremental / Add_Points / Delete_Point_Boxes) ----
 struct UpdateBuffers {
@@ -129,10 +134,14 @@ struct UpdateBuffers {
     uint64_t alive_gen = ~0ull, layout_gen = 0;  // alive_s was made for layout alive_gen; the map's layout now (set by the engine)
     uint8_t *bmark = nullptr;      // the map's per-brick marks (MapBuffers::bmark, set by the engine): bit 0 = a point of the brick was removed
     uint32_t *counters = nullptr;  // kUpdWords words, zeroed by every update_begin: [1] voxels rewritten (tmp_counter), [2] points deleted
-                                   // by boxes, [14] live points (order_by_id), [kUpdSlabWord .. +11) the in-place update's words
+                                   // by boxes, [kUpdStageWord .. +2) staged points (deferred count), [14] live points (order_by_id), [kUpdSlabWord .. +11) the in-place update's words
                                    // (s2m_mapedit.hip), [kUpdVoxWord .. +6) the box of the voxels of map_incremental's PointToAdd
     float4 *stage = nullptr;       // points to append, in order
     int64_t stage_cap = 0, stage_n = 0;
+    // update_add(defer): the count stays on the device (counters[kUpdStageWord + (stage_ops & 1)]) and stage_n is an upper
+    // bound of it until the update's commit reads it back with the hand-back it waits for anyway (update_stage_count)
+    bool stage_deferred = false;
+    int stage_ops = 0;
     uint32_t deleted_reported = 0;  // box deletes already reported to the caller within this update
     // per-batch scratch
     uint64_t *key = nullptr, *key2 = nullptr;
@@ -156,7 +165,7 @@ struct UpdateBuffers {
     int64_t vtab_cap = 0;                // slots
     Mailbox mail;
 };
-constexpr int kUpdWords = 64, kUpdSlabWord = 16, kUpdVoxWord = 32;
+constexpr int kUpdWords = 64, kUpdStageWord = 8, kUpdSlabWord = 16, kUpdVoxWord = 32;
 // box of voxels (edge = the down-sampling size) that holds every point of a batch: the batch's winner per voxel comes from a
 // direct-address table over it (or the sort that groups the batch by voxel uses a linear index of `bits` bits instead of the
 // 63-bit packed key); bits == 0: not available (use the packed key).  map_incremental measures it from the scan's own
@@ -169,7 +178,10 @@ struct VoxBox {
 void free_update(UpdateBuffers &u);
 hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st);
 hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t n, bool downsample, float ds,
-                      int64_t *n_added, hipStream_t st, const VoxBox *vox = nullptr);
+                      int64_t *n_added, hipStream_t st, const VoxBox *vox = nullptr, bool defer = false);
+// the staged count of a deferred update: its device word (nullptr when the host's stage_n is exact) / read back now
+const uint32_t *update_stage_word(const UpdateBuffers &u);
+hipError_t update_stage_count(UpdateBuffers &u, hipStream_t st);
 // false when no box of the call reaches the bricks in use (host arithmetic: such a call launches nothing and waits for nothing)
 bool delete_touches_map(const Grid &g, const float *boxes_host, int nb);
 hipError_t update_delete(UpdateBuffers &u, const Grid &g, const float *boxes_host, int nb, int64_t *n_deleted,

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(1024) void brick_box_kernel(const uint32_t *__restr
     const int64_t bricks = bricks_dev ? (int64_t)*bricks_dev : 0;
     for (int64_t id = threadIdx.x; id < bricks; id += blockDim.x)
         if (!tab || tab[id * kBrickStride + kBrickCells] > tab[id * kBrickStride]) take(bkey[id]);  // (bricks that hold points)
-    for (int i = threadIdx.x; i < n; i += blockDim.x) take(nk[i] >> 9);
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        if (nk[i] != ~0ull) take(nk[i] >> 9);  // (~0: a place behind the device's count of the staged points, slab_key_kernel)
     __shared__ int slo[16][3], shi[16][3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -287,7 +288,7 @@ int64_t map_headroom_for(int64_t m) { return m + ((int64_t)1 << 20); }
 void free_map(MapBuffers &b)
 {
     void *ptrs[] = {b.pts, b.pidx, b.pts2, b.pidx2, b.top, b.tab, b.keys, b.keys_alt, b.vals, b.vals_alt, b.work_a, b.work_b,
-                    b.work_c, b.top2, b.bstart, b.bkey, b.bmark, b.bend, b.bmove, b.bplan, b.blist, b.grow, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
+                    b.work_c, b.top2, b.bstart, b.bkey, b.bmark, b.bend, b.bmove, b.bplan, b.blist, b.grow, b.run, b.mk, b.mv, b.dword, b.sort_tmp, b.bbox, b.counters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (b.h_stats) { (void)hipHostFree(b.h_stats); (void)hipEventDestroy(b.stats_event); }

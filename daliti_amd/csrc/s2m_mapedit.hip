@@ -478,12 +478,16 @@ constexpr int kSlabWords = 13;
 
 __global__ __launch_bounds__(256) void slab_key_kernel(const float4 *__restrict__ stage, int n, Grid g, uint64_t *__restrict__ keys,
                                                        uint32_t *__restrict__ vals, uint8_t *__restrict__ bmark,
-                                                       uint32_t *__restrict__ flags)
+                                                       uint32_t *__restrict__ flags, const uint32_t *__restrict__ n_dev)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t f = 0u;
     int cx = 0, cy = 0, cz = 0;
-    if (i < n) {
+    // n is the host's bound when the count stayed on the device: the places behind the count sort to the end as ~0 and no
+    // later step takes them for points (a real key never has all of its 63 sorted bits set: kCellLimit)
+    const int n_act = n_dev ? min((int)*n_dev, n) : n;
+    if (i >= n_act && i < n) { keys[i] = ~0ull; vals[i] = (uint32_t)i; }
+    if (i < n_act) {
         const float4 p = stage[i];
         cx = cell_coord(p.x, g.ox, g.inv_c); cy = cell_coord(p.y, g.oy, g.inv_c); cz = cell_coord(p.z, g.oz, g.inv_c);
         vals[i] = (uint32_t)i;
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(256) void slab_key_kernel(const float4 *__restrict_
             // (a point whose brick does not exist yet, inside the bounds or beyond them: slab_newbrick_kernel opens it)
         }
     }
-    report_excess(g, cx >> 3, cy >> 3, cz >> 3, i < n && f == 0u, flags + 5);
+    report_excess(g, cx >> 3, cy >> 3, cz >> 3, i < n_act && f == 0u, flags + 5);
     const unsigned long long any = __ballot(f != 0u);
     if (any != 0ull) {
         uint32_t w = f;
@@ -545,7 +549,7 @@ __device__ __forceinline__ uint32_t reloc_need(uint32_t total, bool opened)
 // table row, the marks "new" (4) + "touched" (2) -- the plan gives it its stretch.  More bricks than there are table rows
 // to spare: kSlabNewBrick (the merge re-lays the map and its tables out).
 __global__ __launch_bounds__(256) void slab_head_kernel(const uint64_t *__restrict__ nk, int n_new, Grid g, uint32_t *__restrict__ head,
-                                                        uint32_t *__restrict__ bricks_dev, uint32_t *__restrict__ flags)
+                                                        uint32_t *__restrict__ bricks_dev, uint32_t *__restrict__ flags, uint2 *__restrict__ run)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (flags[0] & kSlabOutside) return;  // (uniform; the key kernel has finished)
@@ -562,8 +566,17 @@ __global__ __launch_bounds__(256) void slab_head_kernel(const uint64_t *__restri
     }
     if (k == 0) bricks_dev[1] = bricks_dev[0];  // the bricks before this update: where the new ids start
     if (k >= n_new) return;
+    if (nk[k] == ~0ull) { head[k] = 0u; return; }  // (behind the device's count of the staged points: not a point)
     const uint64_t b = nk[k] >> 9;
-    head[k] = ((k == 0 || (nk[k - 1] >> 9) != b) && slab_brick_id(g, b) == 0u) ? 1u : 0u;
+    const bool first = k == 0 || (nk[k - 1] >> 9) != b, last = k == n_new - 1 || (nk[k + 1] >> 9) != b;
+    head[k] = (first && slab_brick_id(g, b) == 0u) ? 1u : 0u;
+    // where the brick's new points stand among the sorted ones, left at the brick's slot of the top array: the plan reads
+    // two words instead of searching the keys twice (26 dependent loads per touched brick were the plan's critical path)
+    if (first || last) {
+        uint2 *r = run + top_slot_of_key(g, b);
+        if (first) r->x = (uint32_t)k;
+        if (last) r->y = (uint32_t)k + 1u;
+    }
 }
 __global__ __launch_bounds__(256) void slab_open_kernel(const uint64_t *__restrict__ nk, int n_new, Grid g, const uint32_t *__restrict__ head,
                                                         const uint32_t *__restrict__ rank, uint4 *__restrict__ top, uint32_t *__restrict__ tab,
@@ -607,7 +620,7 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restri
                                                         const uint64_t *__restrict__ bkey, const uint8_t *__restrict__ bmark,
                                                         const uint8_t *__restrict__ alive_s, const uint64_t *__restrict__ nk, int n_new,
                                                         uint32_t *__restrict__ grow, BrickPlan *__restrict__ plan,
-                                                        const uint32_t *__restrict__ flags, int big_ok)
+                                                        const uint32_t *__restrict__ flags, int big_ok, const uint2 *__restrict__ run)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t bricks = (int64_t)*bricks_dev;
@@ -622,8 +635,12 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restri
     for (int off = 32; off > 0; off >>= 1) alive += __shfl_xor(alive, off, 64);
     if (lane != 0) return;
     const uint64_t b = bkey[id];
-    const int lo = n_new > 0 ? slab_lower(nk, n_new, b) : 0;
-    const int n_b = n_new > 0 ? slab_lower(nk, n_new, b + 1) - lo : 0;
+    int lo = 0, n_b = 0;
+    if (n_new > 0 && (bmark[id] & 2u)) {  // (the mark of a brick that new points fall into: slab_key_kernel, slab_open_kernel)
+        const uint2 r = run[top_slot_of_key(g, b)];
+        lo = (int)r.x;
+        n_b = (int)(r.y - r.x);
+    }
     const uint32_t total = (uint32_t)alive + (uint32_t)n_b;
     // what the rewrite has to stage at most: the brick's positions so far plus its new points
     const uint32_t stage = (end - base) + (uint32_t)n_b;
@@ -639,62 +656,97 @@ __global__ __launch_bounds__(256) void slab_plan_kernel(const uint32_t *__restri
     plan[id] = p;
 }
 
-// One workgroup walks the brick ids in order: the touched bricks' requests become stretches of the tail (a prefix sum: the
-// same positions whatever order the waves of the plan finished in), their ids a compact list for the rewrite, their counts
-// the update's totals.  flags[0] |= overflow when a brick cannot be staged or the tail is exhausted (nothing is handed out then).
+// One workgroup turns the touched bricks' requests into stretches of the tail (a prefix sum in id order: the same positions
+// whatever order the waves of the plan finished in), their ids into a compact list for the rewrite, their counts into the
+// update's totals.  Two steps: (a) every thread reads the marks of a run of ids (sixteen at a time) and the ids of the
+// touched ones go, in order, to the list; (b) the threads share the LIST -- the touched bricks of a drive are the frontier's,
+// opened together and so consecutive ids: walked by the owners of their id runs they were a chain of 32 memory latencies in
+// the last few threads (20 us of the frame).  flags[0] |= overflow when a brick cannot be staged or the tail is exhausted
+// (nothing is handed out then).
 constexpr int kAllocThreads = 1024;
+__device__ __forceinline__ uint32_t alloc_block_scan(uint32_t v, uint32_t *w_part, uint32_t &total)  // exclusive, over the workgroup
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    uint32_t in = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t a = __shfl_up(in, off, 64);
+        if (lane >= off) in += a;
+    }
+    __syncthreads();  // (w_part of the previous use has been read)
+    if (lane == 63) w_part[wave] = in;
+    __syncthreads();
+    uint32_t before = 0u;
+    total = 0u;
+    for (int w = 0; w < kAllocThreads / 64; ++w) {
+        if (w < wave) before += w_part[w];
+        total += w_part[w];
+    }
+    return before + in - v;
+}
 __global__ __launch_bounds__(kAllocThreads) void slab_alloc_kernel(const uint32_t *__restrict__ bricks_dev, const uint8_t *__restrict__ bmark,
                                                                    const BrickPlan *__restrict__ plan, uint32_t *__restrict__ bmove,
                                                                    uint32_t *__restrict__ blist, uint32_t *__restrict__ tail_cursor,
-                                                                   uint32_t tail_end, uint32_t *__restrict__ flags)
+                                                                   uint32_t tail_end, uint32_t *__restrict__ flags, int64_t mark_cap)
 {
-    __shared__ uint32_t w_need[16], w_touch[16];
+    __shared__ uint32_t w_part[kAllocThreads / 64];
     __shared__ uint32_t s_sum[5];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     if (flags[0] & (kSlabOutside | kSlabWindow | kSlabNewBrick)) return;
     if (tid < 5) s_sum[tid] = 0u;
     const int64_t bricks = (int64_t)*bricks_dev;
     const uint32_t cursor0 = *tail_cursor;
-    // every thread owns a contiguous run of ids (so that the prefix over the threads is the prefix over the ids): two walks
-    // over its run -- add up, then hand out -- and ONE prefix sum over the workgroup in between
-    const int64_t per = (bricks + kAllocThreads - 1) / kAllocThreads;
+    // a. the list
+    const int64_t per = (((bricks + kAllocThreads - 1) / kAllocThreads) + 15) & ~(int64_t)15;
     const int64_t id0 = (int64_t)tid * per, id1 = min(id0 + per, bricks);
-    uint32_t need = 0u, touch = 0u;
-    uint32_t my[5] = {0u, 0u, 0u, 0u, 0u};  // this thread's share of: points removed, points gained, crowded, moved, cannot be staged
-    for (int64_t id = id0; id < id1; ++id) {
-        if (bmark[id] == 0) continue;
-        const uint4 p = reinterpret_cast<const uint4 *>(plan + id)[0];  // {lo, n_b, need, info}
-        ++touch;
-        need += p.z;
-        my[0] += p.w & 0xffffffu;
-        my[1] += plan[id].gained;
-        my[2] += (p.w >> 24) & 1u;
-        my[3] += p.z ? 1u : 0u;
-        my[4] += (p.w >> 25) & 1u;
-    }
-    uint32_t in = need, it = touch;
+    auto marks16 = [&](int64_t base) {  // 16 marks from `base` on, as bits; ids from id1 on read as untouched
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (base + 16 <= mark_cap) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(bmark + base);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t a = __shfl_up(in, off, 64), b = __shfl_up(it, off, 64);
-        if (lane >= off) { in += a; it += b; }
-    }
-    if (lane == 63) { w_need[wave] = in; w_touch[wave] = it; }
-    __syncthreads();
-    uint32_t on = 0u, ot = 0u, tn = 0u, tt = 0u;
-    for (int w = 0; w < kAllocThreads / 64; ++w) {
-        if (w < wave) { on += w_need[w]; ot += w_touch[w]; }
-        tn += w_need[w]; tt += w_touch[w];
-    }
-    if (touch) {
-        uint64_t at = (uint64_t)cursor0 + on + (in - need);
-        uint32_t li = ot + (it - touch);
-        for (int64_t id = id0; id < id1; ++id) {
-            if (bmark[id] == 0) continue;
-            const uint32_t nd = plan[id].need;
-            bmove[id] = nd ? (at + nd <= (uint64_t)tail_end ? (uint32_t)at : 0xfffffffeu) : 0xffffffffu;
-            at += nd;
-            blist[li++] = (uint32_t)id;
+            for (int j = 0; j < 16; ++j)
+                if (base + j < mark_cap) w[j >> 2] |= (uint32_t)bmark[base + j] << ((j & 3) * 8);
         }
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (((w[j >> 2] >> ((j & 3) * 8)) & 0xffu) != 0u && base + j < id1) bits |= 1u << j;
+        return bits;
+    };
+    uint32_t touch = 0u;
+    for (int64_t base = id0; base < id1; base += 16) touch += (uint32_t)__popc(marks16(base));
+    uint32_t tt = 0u;
+    uint32_t li = alloc_block_scan(touch, w_part, tt);
+    if (touch)
+        for (int64_t base = id0; base < id1; base += 16)
+            for (uint32_t bits = marks16(base); bits != 0u; bits &= bits - 1u) blist[li++] = (uint32_t)(base + (__ffs((int)bits) - 1));
+    __threadfence();
+    __syncthreads();
+    // b. the touched bricks, one per thread and round, in list (= id) order
+    uint32_t my[5] = {0u, 0u, 0u, 0u, 0u};  // this thread's share of: points removed, points gained, crowded, moved, cannot be staged
+    uint64_t carry = (uint64_t)cursor0;
+    for (uint32_t base = 0u; base < tt; base += (uint32_t)kAllocThreads) {
+        const uint32_t i = base + (uint32_t)tid;
+        uint32_t nd = 0u, id = 0u;
+        if (i < tt) {
+            id = blist[i];
+            const uint4 p = reinterpret_cast<const uint4 *>(plan + id)[0];  // {lo, n_b, need, info}
+            nd = p.z;
+            my[0] += p.w & 0xffffffu;
+            my[1] += plan[id].gained;
+            my[2] += (p.w >> 24) & 1u;
+            my[3] += p.z ? 1u : 0u;
+            my[4] += (p.w >> 25) & 1u;
+        }
+        uint32_t round = 0u;
+        const uint32_t before = alloc_block_scan(nd, w_part, round);
+        if (i < tt) {
+            const uint64_t at = carry + before;
+            bmove[id] = nd ? (at + nd <= (uint64_t)tail_end ? (uint32_t)at : 0xfffffffeu) : 0xffffffffu;
+        }
+        carry += round;
     }
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
@@ -705,9 +757,9 @@ __global__ __launch_bounds__(kAllocThreads) void slab_alloc_kernel(const uint32_
     }
     __syncthreads();
     if (tid == 0) {
-        const bool over = (uint64_t)cursor0 + tn > (uint64_t)tail_end;
+        const bool over = carry > (uint64_t)tail_end;
         if (s_sum[4] || over) atomicOr(flags, kSlabOverflow | (s_sum[4] ? kSlabTooBig : 0u));
-        else *tail_cursor = cursor0 + tn;
+        else *tail_cursor = (uint32_t)carry;
         flags[1] = s_sum[0];
         flags[3] = s_sum[1];
         flags[4] = s_sum[2];
@@ -894,10 +946,12 @@ static hipError_t relay_top(MapBuffers &buf, Grid &g, MapStats &stats, int64_t b
 
 // flags: kSlabWords zeroed words of the update's counters.  done = the map was updated in place; otherwise nothing was
 // touched and the caller goes on to merge_update.
-hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t n_new,
-                       uint32_t *flags, bool &done, hipStream_t st)
+hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t &n_new_io,
+                       uint32_t *flags, bool &done, hipStream_t st, const uint32_t *n_dev, bool *counted)
 {
     done = false;
+    if (counted) *counted = false;
+    const int64_t n_new = n_new_io;  // (a bound when n_dev is given)
     const int64_t m = g.m;
     if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || !buf.bmark || !buf.bmove || stats.bricks <= 0 || m > buf.scratch_cap) return hipSuccess;
     if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return hipSuccess;
@@ -915,7 +969,7 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
         S2M_TRY(map_ensure((void **)&buf.mv, &buf.mv_cap, 2 * n_new, sizeof(uint32_t), n_new + 8192));
         nk_sorted = buf.mk;
         nv_sorted = buf.mv;
-        hipLaunchKernelGGL(slab_key_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals, buf.bmark, flags);
+        hipLaunchKernelGGL(slab_key_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals, buf.bmark, flags, n_dev);
         size_t t = buf.sort_tmp_bytes;
         S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, nk_sorted, buf.vals, nv_sorted, (size_t)n_new, 0, kbits, st));
     }
@@ -939,40 +993,48 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     uint32_t *tail_cursor = buf.counters + kTailWord;
     uint32_t *head = buf.work_a, *rank = buf.work_b;
     if (n > 0) {
+        const int64_t slots = top_slots(g);
+        S2M_TRY(map_ensure((void **)&buf.run, &buf.run_cap, slots + 1, sizeof(uint2), 3 * slots));
         size_t ts = 0;
         S2M_TRY(rocprim::exclusive_scan(nullptr, ts, head, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
         S2M_TRY(map_ensure_sort_tmp(buf, ts));
     }
     const unsigned rewrite_grid = (unsigned)std::max<int64_t>(std::min<int64_t>(bricks, 1024), 1);
-    uint32_t v[kSlabWords + 1];
+    uint32_t v[kSlabWords + 2];
     for (int attempt = 0;; ++attempt) {
         if (n > 0) {
-            hipLaunchKernelGGL(slab_head_kernel, dim3((n + 255) / 256), dim3(256), 0, st, nk_sorted, n, g, head, bricks_dev, flags);
+            hipLaunchKernelGGL(slab_head_kernel, dim3((n + 255) / 256), dim3(256), 0, st, nk_sorted, n, g, head, bricks_dev, flags, buf.run);
             size_t ts = buf.sort_tmp_bytes;
             S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, ts, head, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
             hipLaunchKernelGGL(slab_open_kernel, dim3((n + 255) / 256), dim3(256), 0, st, nk_sorted, n, g, head, rank, buf.top, buf.tab, buf.bend,
                                buf.bkey, buf.bmark, bricks_dev, max_new, flags);
         }
         hipLaunchKernelGGL(slab_plan_kernel, dim3((unsigned)((bricks + 3) / 4)), dim3(256), 0, st, bricks_dev, g, buf.bend, buf.tab,
-                           buf.bkey, buf.bmark, alive_s, nk_sorted, n, buf.grow, plan, flags, big_ok);
+                           buf.bkey, buf.bmark, alive_s, nk_sorted, n, buf.grow, plan, flags, big_ok, buf.run);
         hipLaunchKernelGGL(slab_alloc_kernel, dim3(1), dim3(kAllocThreads), 0, st, bricks_dev, buf.bmark, plan, buf.bmove, buf.blist, tail_cursor,
-                           (uint32_t)m, flags);
+                           (uint32_t)m, flags, buf.bmark_cap);
         {
-            const uint32_t *src[kSlabWords + 1];
+            const uint32_t *src[kSlabWords + 2];
             for (int k = 0; k < kSlabWords; ++k) src[k] = flags + k;
             src[kSlabWords] = tail_cursor;
-            S2M_TRY(mail_post(buf.mail, src, kSlabWords + 1, st));
+            src[kSlabWords + 1] = n_dev ? n_dev : tail_cursor;  // (the staged count rides along)
+            S2M_TRY(mail_post(buf.mail, src, kSlabWords + 2, st));
         }
         hipLaunchKernelGGL((slab_rewrite_kernel<kSlabMax>), dim3(rewrite_grid), dim3(256), kLdsSmall, st, flags, g, buf.blist, plan, buf.pts, buf.pidx,
                            buf.keys_alt, alive_s, buf.tab, buf.top, buf.bkey, buf.bmark, buf.bend, buf.bmove, nk_sorted, nv_sorted, stage,
                            (uint32_t)buf.next_id);
-        for (int k = 0; k <= kSlabWords; ++k) v[k] = 0u;
-        S2M_TRY(mail_collect(buf.mail, kSlabWords + 1, v, st));
+        for (int k = 0; k <= kSlabWords + 1; ++k) v[k] = 0u;
+        S2M_TRY(mail_collect(buf.mail, kSlabWords + 2, v, st));
+        if (n_dev) {
+            n_new_io = std::min<int64_t>((int64_t)v[kSlabWords + 1], n_new);
+            if (counted) *counted = true;
+        }
         if (v[0] != kSlabWindow || attempt > 0) break;
         // the box of the bricks in use has left the window: re-lay the top array (nothing else was written) and go again
         bool too_large = false;
         S2M_TRY(relay_top(buf, g, stats, bricks, nk_sorted, n, too_large, st));
         if (too_large) return hipSuccess;  // (the merge reports it)
+        if (n > 0) S2M_TRY(map_ensure((void **)&buf.run, &buf.run_cap, top_slots(g) + 1, sizeof(uint2), 3 * top_slots(g)));
         S2M_TRY(hipMemsetAsync(flags, 0, kSlabWords * sizeof(uint32_t), st));
     }
     // what the tail has handed out so far -- also by an attempt that was given up: the merge brings home whatever lies below
@@ -995,8 +1057,8 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     for (int k = 0; k < 3; ++k) { g.blo[k] -= (int)v[5 + k]; g.bhi[k] += (int)v[8 + k]; }
     stats.bricks += v[2];
     buf.n_moved += v[11];
-    g.live += n_new - (int64_t)v[1];
-    buf.next_id += n_new;
+    g.live += n_new_io - (int64_t)v[1];
+    buf.next_id += n_new_io;
     if (v[1] > 0u) buf.ids_dense = false;
     done = true;
     return hipGetLastError();

@@ -26,6 +26,9 @@
 // id wins (the reference takes the first in its tree traversal, which has no GPU counterpart); such ties need two points
 // at exactly the same float distance inside one voxel.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 
@@ -364,18 +367,32 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const uint32_t *__res
 
 // out[pos[i]] = src[i] for flagged i (pos = exclusive scan of the flags), shifted by base; with a winner table, every
 // point also puts its voxel's slot back to "empty" (all points of a voxel write the same value)
+// base_in / count_out (deferred count): the base is read from the device and the count behind this batch left in ANOTHER
+// word (every thread of the launch reads the first)
 __global__ __launch_bounds__(256) void scatter_kernel(const float4 *__restrict__ src, const uint32_t *__restrict__ flag,
                                                       const uint32_t *__restrict__ pos, int64_t m, int64_t base,
                                                       float4 *__restrict__ out, const uint64_t *__restrict__ vkey,
-                                                      unsigned long long *__restrict__ vtab)
+                                                      unsigned long long *__restrict__ vtab,
+                                                      const uint32_t *__restrict__ base_in, uint32_t *__restrict__ count_out)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (base_in) base = (int64_t)*base_in;
     if (i < m && vtab) vtab[vkey[i]] = ~0ull;
     if (i < m && flag[i]) {
         float4 p = src[i];
         p.w = 0.0f;
         out[base + pos[i]] = p;
     }
+    if (count_out && i == m - 1) *count_out = (uint32_t)base + pos[i] + flag[i];
+}
+// Add_Points(points, false) behind a count that lives on the device
+__global__ __launch_bounds__(256) void append_kernel(const float4 *__restrict__ src, int64_t n, float4 *__restrict__ out,
+                                                     const uint32_t *__restrict__ base_in, uint32_t *__restrict__ count_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t base = (int64_t)*base_in;
+    if (i < n) out[base + i] = src[i];
+    if (i == n - 1) *count_out = (uint32_t)(base + n);
 }
 
 // map_incremental() (laserMapping.cpp:582-630): class 1 = PointToAdd, 2 = PointNoNeedDownsample, 0 = skip
@@ -542,9 +559,17 @@ hipError_t mail_collect(Mailbox &mb, int k, uint32_t *out, hipStream_t st)
     volatile uint32_t *flag = mb.h;
     const uint32_t seq = mb.seq;
     bool seen = false;
+    static const bool hosttime = std::getenv("S2M_HOSTTIME") != nullptr;  // (diagnostic: how long the host waits for the device)
+    const auto t0 = hosttime ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     for (long spin = 0; spin < 20000000L; ++spin) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
         __builtin_ia32_pause();
+    }
+    if (hosttime) {
+        static double total_us = 0.0;
+        static long calls = 0;
+        total_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (++calls % 2000 == 0) std::fprintf(stderr, "[hosttime] %ld hand-backs, %.1f us waited on average\n", calls, total_us / calls);
     }
     if (!seen) {  // slow or failed: let the runtime tell us
         S2M_TRY(hipStreamSynchronize(st));
@@ -666,21 +691,54 @@ hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st)
                            g.pidx, u.counters);
     }
     u.stage_n = 0;
+    u.stage_deferred = false;
+    u.stage_ops = 0;
     u.deleted_reported = 0;
     return hipSuccess;
 }
 
+const uint32_t *update_stage_word(const UpdateBuffers &u)
+{
+    return u.stage_deferred ? u.counters + kUpdStageWord + (u.stage_ops & 1) : nullptr;
+}
+hipError_t update_stage_count(UpdateBuffers &u, hipStream_t st)
+{
+    if (!u.stage_deferred) return hipSuccess;
+    const uint32_t *src[1] = {update_stage_word(u)};
+    uint32_t v = 0;
+    S2M_TRY(mail_fetch(u.mail, src, 1, &v, st));
+    u.stage_n = (int64_t)v;
+    u.stage_deferred = false;
+    return hipSuccess;
+}
+
 hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t n, bool downsample, float ds,
-                      int64_t *n_added, hipStream_t st, const VoxBox *vox)
+                      int64_t *n_added, hipStream_t st, const VoxBox *vox, bool defer)
 {
     if (n_added) *n_added = 0;
     if (n <= 0) return hipSuccess;
+    // defer: nobody asks how many points this batch adds before the update is committed -- the count stays on the device and
+    // the host goes on launching with a bound (one round trip less per scan, and the launches behind it no longer wait for
+    // the host: s2m_map_incremental)
+    defer = defer && !n_added;
+    if (!defer && u.stage_deferred) S2M_TRY(update_stage_count(u, st));
+    if (defer && !u.stage_deferred) {  // the count so far moves to the device
+        if (u.stage_n != 0) defer = false;  // (an exact batch came first: stay exact)
+        else u.stage_deferred = true;
+    }
     S2M_TRY(grow(&u.stage, &u.stage_cap, std::max(u.stage_n + n, u.reserve_hint), true, st));
+    const uint32_t *w_in = defer ? u.counters + kUpdStageWord + (u.stage_ops & 1) : nullptr;
+    uint32_t *w_out = defer ? u.counters + kUpdStageWord + ((u.stage_ops + 1) & 1) : nullptr;
     if (!downsample) {  // Add_Points(points, false): every point is inserted (ikd_Tree.cpp:549-570)
-        S2M_TRY(hipMemcpyAsync(u.stage + u.stage_n, np, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, st));
+        if (defer) {
+            hipLaunchKernelGGL(append_kernel, dim3(nblk(n)), dim3(256), 0, st, np, n, u.stage, w_in, w_out);
+            ++u.stage_ops;
+        } else {
+            S2M_TRY(hipMemcpyAsync(u.stage + u.stage_n, np, (size_t)n * sizeof(float4), hipMemcpyDeviceToDevice, st));
+        }
         u.stage_n += n;
         if (n_added) *n_added = n;
-        return hipSuccess;
+        return hipGetLastError();
     }
     if (u.batch_cap < n) {
         const int64_t want = std::max<int64_t>(n, u.reserve_hint);
@@ -741,7 +799,12 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
                        u.cnt, u.best_idx, u.best_pos, u.best_d, u.alive_s, u.add_flag, u.counters, vtab, u.bmark);
     // winners, in batch order, go to the staging list
     S2M_TRY(scan_u32(u, u.add_flag, u.pos, n, st));
-    hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage, u.key, vtab);
+    hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage, u.key, vtab, w_in, w_out);
+    if (defer) {
+        ++u.stage_ops;
+        u.stage_n += n;  // (a bound: every point of the batch may have won its voxel)
+        return hipGetLastError();
+    }
     const uint32_t *src[3] = {u.pos + (n - 1), u.add_flag + (n - 1), u.counters + 1};
     uint32_t v[3] = {0, 0, 0};
     S2M_TRY(mail_fetch(u.mail, src, 3, v, st));
