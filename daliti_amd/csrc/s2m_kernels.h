@@ -166,6 +166,9 @@ struct UpdateBuffers {
     Mailbox mail;
 };
 constexpr int kUpdWords = 64, kUpdStageWord = 8, kUpdSlabWord = 16, kUpdVoxWord = 32;
+// [kUpdListWord .. +2) lengths of map_incremental's two lists (+2, +3 stay zero), [kUpdBatchWord] winners of update_add's batch
+// (+1 stays zero): written by the one-workgroup compactions
+constexpr int kUpdListWord = 40, kUpdBatchWord = 44;
 // box of voxels (edge = the down-sampling size) that holds every point of a batch: the batch's winner per voxel comes from a
 // direct-address table over it (or the sort that groups the batch by voxel uses a linear index of `bits` bits instead of the
 // 63-bit packed key); bits == 0: not available (use the packed key).  map_incremental measures it from the scan's own

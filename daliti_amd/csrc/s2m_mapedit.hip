@@ -6,8 +6,10 @@
 // Both leave the map in the order a fresh build of the same point list would produce: (brick, cell, point id).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
+#include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -470,7 +472,8 @@ constexpr int kSlabMax = 2048;  // points of one brick the rewrite stages in LDS
 constexpr int kSlabBig = 6144;  // ... and in the second, rarely launched form for crowded bricks (134 KB of dynamic LDS: one per CU)
 // kSlabOutside: a new point's cell cannot be represented (rebuild around a new origin); kSlabWindow: the box of the bricks in
 // use, grown by the new points, no longer fits the window of the top array (the host re-lays it and tries again)
-enum : uint32_t { kSlabOutside = 1u, kSlabNewBrick = 2u, kSlabOverflow = 4u, kSlabWindow = 8u, kSlabTooBig = 16u };
+enum : uint32_t { kSlabOutside = 1u, kSlabNewBrick = 2u, kSlabOverflow = 4u, kSlabWindow = 8u, kSlabTooBig = 16u,
+                  kSlabRefuse = 32u };  // (refuse: the one-workgroup preparation cannot number the batch's bricks: the separate kernels run)
 // words of the update's counters behind `flags`: [0] outcome bits, [1] points removed, [2] bricks opened, [3] points gained
 // by bricks, [4] crowded bricks among the touched ones, [5..11) how far the new points reach beyond the bricks in use,
 // [11] bricks moved to the tail (the opened ones included), [12] bricks touched
@@ -600,6 +603,188 @@ __global__ __launch_bounds__(256) void slab_open_kernel(const uint64_t *__restri
     tab[id * kBrickStride] = 0u;
     tab[id * kBrickStride + kBrickCells] = 0u;
     bmark[id] = 6u;
+}
+
+// The preparation of an in-place update in ONE workgroup, for the batch of a scan (up to kPrepMax staged points; larger batches
+// take the kernels above): keys, their sort, the runs of the touched bricks, the bricks that open.  Eleven launches -- the key
+// kernel, rocprim's sort of 63-bit keys (six kernels for 6 k pairs, 42 us), head flags, their scan (two), the opening --
+// were half of what the host enqueues for a map update and the frame is bound by that, not by the device.  The keys are
+// sorted as 32-bit numbers: brick index inside the BATCH's own box of bricks (z, y, x like the brick key) << 9 | cell -- the
+// same order as the 63-bit keys, found by a block-wide radix sort (rocprim::block_radix_sort, 8 bits per pass, stable: equal
+// keys keep the staged order).  The 64-bit keys are written out for the steps that follow.
+constexpr int kPrepThreads = 1024, kPrepItems = 8, kPrepMax = kPrepThreads * kPrepItems;
+__global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4 *__restrict__ stage, int n, const uint32_t *__restrict__ n_dev,
+                                                                    Grid g, uint64_t *__restrict__ nk, uint32_t *__restrict__ nv,
+                                                                    uint8_t *__restrict__ bmark, uint32_t *__restrict__ flags,
+                                                                    uint2 *__restrict__ run, uint32_t *__restrict__ bricks_dev,
+                                                                    uint4 *__restrict__ top, uint32_t *__restrict__ tab,
+                                                                    uint32_t *__restrict__ bend, uint64_t *__restrict__ bkey, int max_new)
+{
+    using Sort = rocprim::block_radix_sort<uint32_t, kPrepThreads, kPrepItems, uint32_t>;
+    __shared__ typename Sort::storage_type sort_mem;
+    __shared__ int s_lo[kPrepThreads / 64][3], s_hi[kPrepThreads / 64][3];
+    __shared__ uint32_t s_bad[kPrepThreads / 64], s_part[kPrepThreads / 64];
+    __shared__ int s_box[6];
+    __shared__ uint32_t s_f;
+    __shared__ uint32_t s_first[kPrepThreads], s_last[kPrepThreads];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n_act = n_dev ? min((int)*n_dev, n) : n;  // (n: the host's bound when the count stayed on the device)
+    const uint32_t first_id = bricks_dev[0];
+    // 1. the cells of the points (blocked: thread t holds staged points t * 8 ..), the batch's box of bricks
+    int bx[kPrepItems], by[kPrepItems], bz[kPrepItems];
+    uint32_t cell[kPrepItems];
+    int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    uint32_t bad = 0u;
+#pragma unroll
+    for (int j = 0; j < kPrepItems; ++j) {
+        const int i = tid * kPrepItems + j;
+        cell[j] = 0xffffffffu;  // (not a point)
+        bx[j] = by[j] = bz[j] = 0;
+        if (i < n_act) {
+            const float4 p = stage[i];
+            const int cx = cell_coord(p.x, g.ox, g.inv_c), cy = cell_coord(p.y, g.oy, g.inv_c), cz = cell_coord(p.z, g.oz, g.inv_c);
+            if (!cell_representable(cx, cy, cz)) bad = kSlabOutside;
+            else {
+                bx[j] = cx >> 3; by[j] = cy >> 3; bz[j] = cz >> 3;
+                cell[j] = (uint32_t)((((cz & 7) << 3) | (cy & 7)) << 3 | (cx & 7));
+                lo[0] = min(lo[0], bx[j]); lo[1] = min(lo[1], by[j]); lo[2] = min(lo[2], bz[j]);
+                hi[0] = max(hi[0], bx[j]); hi[1] = max(hi[1], by[j]); hi[2] = max(hi[2], bz[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = min(lo[k], __shfl_xor(lo[k], off, 64));
+            hi[k] = max(hi[k], __shfl_xor(hi[k], off, 64));
+        }
+        bad |= __shfl_xor(bad, off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s_lo[wave][k] = lo[k]; s_hi[wave][k] = hi[k]; }
+        s_bad[wave] = bad;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t f = 0u;
+        int l[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, h[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+        for (int w = 0; w < kPrepThreads / 64; ++w) {
+            f |= s_bad[w];
+            for (int k = 0; k < 3; ++k) { l[k] = min(l[k], s_lo[w][k]); h[k] = max(h[k], s_hi[w][k]); }
+        }
+        for (int k = 0; k < 3; ++k) { s_box[k] = l[k]; s_box[3 + k] = h[k]; }
+        s_f = f;
+    }
+    __syncthreads();
+    if (s_f != 0u) {  // a cell that cannot be represented: the caller rebuilds around a new origin
+        if (tid == 0) atomicOr(flags, s_f);
+        return;
+    }
+    const bool any = s_box[0] <= s_box[3];
+    int b0[3] = {0, 0, 0}, nb[3] = {1, 1, 1};
+    // 2. how far the batch reaches beyond the bricks in use, and whether the grown box still fits the window of the top array
+    // (a batch that does not fit leaves its sorted keys -- the host re-lays the top array around them -- and nothing else)
+    bool fits = true;
+    {
+        const uint32_t tm[3] = {g.tmx, g.tmy, g.tmz};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t below = any ? (uint32_t)max(g.blo[k] - s_box[k], 0) : 0u, above = any ? (uint32_t)max(s_box[3 + k] - g.bhi[k], 0) : 0u;
+            if (tid == 0) { flags[5 + k] = below; flags[8 + k] = above; }
+            fits = fits && ((int64_t)g.bhi[k] + above) - ((int64_t)g.blo[k] - below) <= (int64_t)tm[k];
+            if (any) { b0[k] = s_box[k]; nb[k] = s_box[3 + k] - s_box[k] + 1; }
+        }
+    }
+    const uint64_t vol = (uint64_t)nb[0] * (uint64_t)nb[1] * (uint64_t)nb[2];
+    if (vol >= (1ull << 22)) {  // (brick index + 9 cell bits + the "not a point" value in 32 bits)
+        if (tid == 0) atomicOr(flags, kSlabRefuse);
+        return;
+    }
+    if (tid == 0 && fits) bricks_dev[1] = first_id;  // the bricks before this update: where the new ids start
+    // 3. the sort
+    const uint32_t none = (uint32_t)vol << 9;  // sorts behind every point
+    uint32_t key[kPrepItems], val[kPrepItems];
+#pragma unroll
+    for (int j = 0; j < kPrepItems; ++j) {
+        val[j] = (uint32_t)(tid * kPrepItems + j);
+        key[j] = cell[j] == 0xffffffffu
+                     ? none
+                     : ((uint32_t)(((bz[j] - b0[2]) * nb[1] + (by[j] - b0[1])) * nb[0] + (bx[j] - b0[0])) << 9) | cell[j];
+    }
+    const unsigned bits = 32u - (unsigned)__clz((int)(none | 1u));
+    Sort().sort(key, val, sort_mem, 0u, bits);
+    // 4. the sorted keys, the runs of the bricks, the bricks that do not exist yet
+    s_first[tid] = key[0] >> 9;
+    s_last[tid] = key[kPrepItems - 1] >> 9;
+    __syncthreads();
+    uint32_t heads = 0u, head_mask = 0u;
+#pragma unroll
+    for (int j = 0; j < kPrepItems; ++j) {
+        const int sp = tid * kPrepItems + j;
+        const uint32_t bl = key[j] >> 9;
+        const bool pt = bl < (uint32_t)vol;
+        const int rx = (int)(bl % (uint32_t)nb[0]) + b0[0], ry = (int)((bl / (uint32_t)nb[0]) % (uint32_t)nb[1]) + b0[1];
+        const int rz = (int)(bl / ((uint32_t)nb[0] * (uint32_t)nb[1])) + b0[2];
+        const uint64_t b64 = brick_key(rx, ry, rz);
+        if (sp < n) {
+            nk[sp] = pt ? (b64 << 9) | (uint64_t)(key[j] & 511u) : ~0ull;
+            nv[sp] = val[j];
+        }
+        if (!pt || !fits) continue;
+        const uint32_t prev = j > 0 ? key[j - 1] >> 9 : (tid > 0 ? s_last[tid - 1] : 0xffffffffu);
+        const uint32_t next = j + 1 < kPrepItems ? key[j + 1] >> 9 : (tid + 1 < kPrepThreads ? s_first[tid + 1] : 0xffffffffu);
+        const bool first = prev != bl, last = next != bl;
+        if (first || last) {
+            const uint32_t slot = top_slot(g, rx, ry, rz);
+            if (first) run[slot].x = (uint32_t)sp;
+            if (last) run[slot].y = (uint32_t)sp + 1u;
+            if (first) {
+                const uint32_t idp1 = brick_in_bounds(g, rx, ry, rz) ? g.top[slot].x : 0u;
+                if (idp1 != 0u) bmark[idp1 - 1u] |= 2u;  // a brick that new points fall into
+                else { ++heads; head_mask |= 1u << j; }
+            }
+        }
+    }
+    if (!fits) {  // (uniform)
+        if (tid == 0) atomicOr(flags, kSlabWindow);
+        return;
+    }
+    // the bricks that open, numbered in key order
+    uint32_t in = heads;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t a = __shfl_up(in, off, 64);
+        if (lane >= off) in += a;
+    }
+    if (lane == 63) s_part[wave] = in;
+    __syncthreads();
+    uint32_t before = 0u, nh = 0u;
+    for (int w = 0; w < kPrepThreads / 64; ++w) {
+        if (w < wave) before += s_part[w];
+        nh += s_part[w];
+    }
+    if (nh > (uint32_t)max_new) {  // more bricks than there are table rows to spare: the merge re-lays the map and its tables out
+        if (tid == 0) atomicOr(flags, kSlabNewBrick);
+        return;
+    }
+    if (tid == 0) { bricks_dev[0] = first_id + nh; flags[2] = nh; }
+    uint32_t id = first_id + before + in - heads;
+#pragma unroll
+    for (int j = 0; j < kPrepItems; ++j) {
+        if (!((head_mask >> j) & 1u)) continue;
+        const uint32_t bl = key[j] >> 9;
+        const int rx = (int)(bl % (uint32_t)nb[0]) + b0[0], ry = (int)((bl / (uint32_t)nb[0]) % (uint32_t)nb[1]) + b0[1];
+        const int rz = (int)(bl / ((uint32_t)nb[0] * (uint32_t)nb[1])) + b0[2];
+        top[top_slot(g, rx, ry, rz)] = make_uint4(id + 1u, 0u, 0u, 0u);
+        bkey[id] = brick_key(rx, ry, rz);
+        bend[id] = 0u;
+        tab[(int64_t)id * kBrickStride] = 0u;
+        tab[(int64_t)id * kBrickStride + kBrickCells] = 0u;
+        bmark[id] = 6u;  // "new" (4) + "touched" (2)
+        ++id;
+    }
 }
 
 // What the plan found for a touched brick
@@ -960,18 +1145,25 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     uint32_t *bricks_dev = buf.counters + kBricksWord;
     uint64_t *nk_sorted = buf.mk;
     uint32_t *nv_sorted = buf.mv;
-    if (n > 0) {
+    // a scan's batch is prepared by one workgroup (slab_prepare_kernel); larger ones -- and S2M_NO_FUSED_PREP=1, for A/B and
+    // tests -- by the separate kernels
+    static const bool no_fused = std::getenv("S2M_NO_FUSED_PREP") != nullptr;
+    bool fused = n > 0 && n <= kPrepMax && !no_fused;
+    auto sort_keys = [&]() -> hipError_t {  // the separate kernels' keys, sorted
         const unsigned kbits = 9 + 3 * kBrickBits;
         size_t tmp = 0;
         S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp, buf.keys, buf.keys, buf.vals, buf.vals, (size_t)n_new, 0, kbits, st));
         S2M_TRY(map_ensure_sort_tmp(buf, tmp));
-        S2M_TRY(map_ensure((void **)&buf.mk, &buf.mk_cap, n_new, sizeof(uint64_t), n_new / 2 + 4096));
-        S2M_TRY(map_ensure((void **)&buf.mv, &buf.mv_cap, 2 * n_new, sizeof(uint32_t), n_new + 8192));
-        nk_sorted = buf.mk;
-        nv_sorted = buf.mv;
         hipLaunchKernelGGL(slab_key_kernel, dim3((n + 255) / 256), dim3(256), 0, st, stage, n, g, buf.keys, buf.vals, buf.bmark, flags, n_dev);
         size_t t = buf.sort_tmp_bytes;
-        S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, nk_sorted, buf.vals, nv_sorted, (size_t)n_new, 0, kbits, st));
+        return rocprim::radix_sort_pairs(buf.sort_tmp, t, buf.keys, buf.mk, buf.vals, buf.mv, (size_t)n_new, 0, kbits, st);
+    };
+    if (n > 0) {
+        S2M_TRY(map_ensure((void **)&buf.mk, &buf.mk_cap, n_new, sizeof(uint64_t), std::max<int64_t>(n_new / 2 + 4096, kPrepMax)));
+        S2M_TRY(map_ensure((void **)&buf.mv, &buf.mv_cap, 2 * n_new, sizeof(uint32_t), std::max<int64_t>(n_new + 8192, 2 * kPrepMax)));
+        nk_sorted = buf.mk;
+        nv_sorted = buf.mv;
+        if (!fused) S2M_TRY(sort_keys());
     }
     // the crowded-brick form of the rewrite needs 134 KB of dynamic LDS: granted once per handle (= per device; the
     // attribute belongs to the kernel object of the current device); a device that refuses leaves those bricks to the merge
@@ -1002,7 +1194,10 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     const unsigned rewrite_grid = (unsigned)std::max<int64_t>(std::min<int64_t>(bricks, 1024), 1);
     uint32_t v[kSlabWords + 2];
     for (int attempt = 0;; ++attempt) {
-        if (n > 0) {
+        if (n > 0 && fused) {
+            hipLaunchKernelGGL(slab_prepare_kernel, dim3(1), dim3(kPrepThreads), 0, st, stage, n, n_dev, g, nk_sorted, nv_sorted, buf.bmark, flags,
+                               buf.run, bricks_dev, buf.top, buf.tab, buf.bend, buf.bkey, max_new);
+        } else if (n > 0) {
             hipLaunchKernelGGL(slab_head_kernel, dim3((n + 255) / 256), dim3(256), 0, st, nk_sorted, n, g, head, bricks_dev, flags, buf.run);
             size_t ts = buf.sort_tmp_bytes;
             S2M_TRY(rocprim::exclusive_scan(buf.sort_tmp, ts, head, rank, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
@@ -1028,6 +1223,13 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
         if (n_dev) {
             n_new_io = std::min<int64_t>((int64_t)v[kSlabWords + 1], n_new);
             if (counted) *counted = true;
+        }
+        if (fused && (v[0] & kSlabRefuse)) {  // (a batch strewn over more than 4 M bricks: nothing was written, the separate kernels do it)
+            fused = false;
+            --attempt;
+            S2M_TRY(hipMemsetAsync(flags, 0, kSlabWords * sizeof(uint32_t), st));
+            S2M_TRY(sort_keys());
+            continue;
         }
         if (v[0] != kSlabWindow || attempt > 0) break;
         // the box of the bricks in use has left the window: re-lay the top array (nothing else was written) and go again

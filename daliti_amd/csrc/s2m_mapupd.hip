@@ -406,8 +406,10 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
                                                             const float4 *__restrict__ pts, int have_nn, int map_has5, double fs,
                                                             float4 *__restrict__ pw_out,
                                                             unsigned long long *__restrict__ cls_out, int ax, int ay, int az,
-                                                            VoxReach reach, uint32_t *__restrict__ vox_ext)
+                                                            VoxReach reach, uint32_t *__restrict__ vox_ext,
+                                                            unsigned long long *__restrict__ blk_cnt)
 {
+    __shared__ unsigned long long s_cnt[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float wx = 0.0f, wy = 0.0f, wz = 0.0f;
     int cls = 0;
@@ -464,21 +466,102 @@ __global__ __launch_bounds__(256) void incr_classify_kernel(Pose pose, const flo
         }
     }
     wave_max6_to(e, vox_ext);
+    // the workgroup's two counts, packed like the flags: scatter2_blocks_kernel adds up the workgroups in front of its own
+    unsigned long long c = cls == 1 ? 1ull : (cls == 2 ? (1ull << 32) : 0ull);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-// list A (low halves) and list B (high halves) of the packed flags / positions
-__global__ __launch_bounds__(256) void scatter2_kernel(const float4 *__restrict__ src, const unsigned long long *__restrict__ flag,
-                                                       const unsigned long long *__restrict__ pos, int64_t n,
-                                                       float4 *__restrict__ out_a, float4 *__restrict__ out_b)
+// Lists A and B without a device-wide scan: the classification left every workgroup's counts (blk_cnt), a workgroup here
+// adds up the ones in front of it, scans its own 256 flags and writes its points -- one launch where the scan (two kernels
+// of rocprim) and the scatter below were three.  counts2 = the lengths of the two lists.
+__global__ __launch_bounds__(256) void scatter2_blocks_kernel(const float4 *__restrict__ src, const unsigned long long *__restrict__ flag,
+                                                              const unsigned long long *__restrict__ blk_cnt, int n,
+                                                              float4 *__restrict__ out_a, float4 *__restrict__ out_b,
+                                                              uint32_t *__restrict__ counts2)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long f = flag[i];
-    if (f == 0ull) return;
-    float4 p = src[i];
-    p.w = 0.0f;
-    const unsigned long long q = pos[i];
-    if (f & 1ull) out_a[(uint32_t)q] = p; else out_b[(uint32_t)(q >> 32)] = p;
+    __shared__ unsigned long long s_part[4], s_wave[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    unsigned long long before = 0ull;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) before += blk_cnt[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    const int i = blockIdx.x * 256 + tid;
+    const unsigned long long f = i < n ? flag[i] : 0ull;
+    unsigned long long in = f;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long a = __shfl_up(in, off, 64);
+        if (lane >= off) in += a;
+    }
+    if (lane == 0) s_part[wave] = before;
+    if (lane == 63) s_wave[wave] = in;
+    __syncthreads();
+    unsigned long long at = s_part[0] + s_part[1] + s_part[2] + s_part[3] + in - f;
+    for (int w = 0; w < wave; ++w) at += s_wave[w];
+    if (f != 0ull) {
+        float4 p = src[i];
+        p.w = 0.0f;
+        if (f & 1ull) out_a[(uint32_t)at] = p; else out_b[(uint32_t)(at >> 32)] = p;
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) {
+        const unsigned long long total = at + f;
+        counts2[0] = (uint32_t)total;
+        counts2[1] = (uint32_t)(total >> 32);
+    }
+}
+
+// The winners of update_add's batch behind the staged points by ONE workgroup, for the batch of a scan (up to kCompactMax
+// points): the flags come in with coalesced reads and wait in LDS as bytes, every thread counts a contiguous run of them,
+// one prefix sum over the workgroup, every thread writes its run's winners out.  The device-wide scan (two kernels of
+// rocprim) and the scatter behind it were three launches for a few thousand points, and the host's launches are what bounds
+// a frame.  (scatter_kernel's arguments; batch_count = the winners.)
+constexpr int kCompactThreads = 1024, kCompactMax = 16384;
+__global__ __launch_bounds__(kCompactThreads) void compact1_kernel(const float4 *__restrict__ src, const uint32_t *__restrict__ flag, int n,
+                                                                   int64_t base, float4 *__restrict__ out, const uint64_t *__restrict__ vkey,
+                                                                   unsigned long long *__restrict__ vtab, const uint32_t *__restrict__ base_in,
+                                                                   uint32_t *__restrict__ count_out, uint32_t *__restrict__ batch_count)
+{
+    __shared__ uint8_t l_f[kCompactMax];
+    __shared__ uint32_t w_part[kCompactThreads / 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (base_in) base = (int64_t)*base_in;
+    for (int i = tid; i < n; i += kCompactThreads) {
+        l_f[i] = (uint8_t)(flag[i] != 0u);
+        if (vtab) vtab[vkey[i]] = ~0ull;  // the voxel's slot of the winner table back to "empty"
+    }
+    __syncthreads();
+    const int per = (n + kCompactThreads - 1) / kCompactThreads;
+    const int i0 = min(tid * per, n), i1 = min(i0 + per, n);
+    uint32_t c = 0u;
+    for (int i = i0; i < i1; ++i) c += l_f[i];
+    uint32_t in = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t a = __shfl_up(in, off, 64);
+        if (lane >= off) in += a;
+    }
+    if (lane == 63) w_part[wave] = in;
+    __syncthreads();
+    uint32_t at = in - c, total = 0u;
+    for (int w = 0; w < kCompactThreads / 64; ++w) {
+        if (w < wave) at += w_part[w];
+        total += w_part[w];
+    }
+    if (c != 0u)
+        for (int i = i0; i < i1; ++i) {
+            if (!l_f[i]) continue;
+            float4 p = src[i];
+            p.w = 0.0f;
+            out[base + at++] = p;
+        }
+    if (tid == 0) {
+        if (count_out) *count_out = (uint32_t)base + total;
+        *batch_count = total;
+    }
 }
 
 __global__ __launch_bounds__(256) void xyz_to_float4_kernel(const float *__restrict__ xyz, int64_t stride, int64_t n,
@@ -798,14 +881,21 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
     hipLaunchKernelGGL(add_resolve_kernel, dim3(nblk(n * kBoxLanes)), dim3(256), 0, st, g, np, in, ds, rkey, rval, u.dnew,
                        u.cnt, u.best_idx, u.best_pos, u.best_d, u.alive_s, u.add_flag, u.counters, vtab, u.bmark);
     // winners, in batch order, go to the staging list
-    S2M_TRY(scan_u32(u, u.add_flag, u.pos, n, st));
-    hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage, u.key, vtab, w_in, w_out);
+    const bool one_group = n <= kCompactMax;
+    if (one_group) {
+        hipLaunchKernelGGL(compact1_kernel, dim3(1), dim3(kCompactThreads), 0, st, np, u.add_flag, in, u.stage_n, u.stage, u.key, vtab, w_in, w_out,
+                           u.counters + kUpdBatchWord);
+    } else {
+        S2M_TRY(scan_u32(u, u.add_flag, u.pos, n, st));
+        hipLaunchKernelGGL(scatter_kernel, dim3(nblk(n)), dim3(256), 0, st, np, u.add_flag, u.pos, n, u.stage_n, u.stage, u.key, vtab, w_in, w_out);
+    }
     if (defer) {
         ++u.stage_ops;
         u.stage_n += n;  // (a bound: every point of the batch may have won its voxel)
         return hipGetLastError();
     }
-    const uint32_t *src[3] = {u.pos + (n - 1), u.add_flag + (n - 1), u.counters + 1};
+    const uint32_t *src[3] = {one_group ? u.counters + kUpdBatchWord : u.pos + (n - 1), one_group ? u.counters + kUpdBatchWord + 1 : u.add_flag + (n - 1),
+                              u.counters + 1};   // (word kUpdBatchWord + 1 is never written: zero)
     uint32_t v[3] = {0, 0, 0};
     S2M_TRY(mail_fetch(u.mail, src, 3, v, st));
     u.stage_n += (int64_t)v[0] + v[1];
@@ -971,17 +1061,11 @@ hipError_t incr_classify(UpdateBuffers &u, const Pose &pose, const float *sx, co
         S2M_TRY(hipMemsetAsync(u.counters, 0, kUpdWords * sizeof(uint32_t), st));
     }
     hipLaunchKernelGGL(incr_classify_kernel, dim3(nblk(n)), dim3(256), 0, st, pose, sx, sy, sz, n, nn_idx, g.pts,
-                       have_nn ? 1 : 0, g.live >= kK ? 1 : 0, fs, pw, fl, anchor[0], anchor[1], anchor[2], reach, u.counters + kUpdVoxWord);
-    {
-        size_t bytes = 0;
-        S2M_TRY(rocprim::exclusive_scan(nullptr, bytes, fl, ps, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), st));
-        S2M_TRY(ensure_tmp(u, bytes));
-        size_t b2 = u.tmp_bytes;
-        S2M_TRY(rocprim::exclusive_scan(u.tmp, b2, fl, ps, 0ull, (size_t)n, rocprim::plus<unsigned long long>(), st));
-    }
-    hipLaunchKernelGGL(scatter2_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fl, ps, (int64_t)n, la, lb);
-    {   // both list lengths with one hand-back: last position + last flag, as four 32-bit words
-        const uint32_t *p32 = reinterpret_cast<const uint32_t *>(ps + (n - 1)), *f32 = reinterpret_cast<const uint32_t *>(fl + (n - 1));
+                       have_nn ? 1 : 0, g.live >= kK ? 1 : 0, fs, pw, fl, anchor[0], anchor[1], anchor[2], reach, u.counters + kUpdVoxWord, ps);
+    hipLaunchKernelGGL(scatter2_blocks_kernel, dim3(nblk(n)), dim3(256), 0, st, pw, fl, ps, n, la, lb, u.counters + kUpdListWord);
+    {   // both list lengths with one hand-back (and two words that stay zero)
+        const uint32_t *c2 = u.counters + kUpdListWord;
+        const uint32_t *p32 = c2, *f32 = c2 + 2;
         const uint32_t *v = u.counters + kUpdVoxWord;
         const uint32_t *src[11] = {p32, f32, p32 + 1, f32 + 1, v, v + 1, v + 2, v + 3, v + 4, v + 5, extra ? extra : p32};
         uint32_t h[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

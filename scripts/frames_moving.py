@@ -17,7 +17,11 @@ w = World(L, 6.0 * L, step)
 t0 = time.time()
 seed = w.seed_map(M)
 extra = 12
+import sys, time
+_t0 = time.time()
+sys.stderr.write('[frames_moving] generating sweeps\n'); sys.stderr.flush()
 sw = w.sweeps(0, frames + warm + extra, beams, az, threads=16)
+sys.stderr.write('[frames_moving] sweeps in %.1f s\n' % (time.time() - _t0)); sys.stderr.flush()
 print("gen %.1fs: seed %d pts, sweeps n min/mean/max %d/%d/%d" % (time.time() - t0, len(seed), sw["n"].min(), sw["n"].mean(), sw["n"].max()), flush=True)
 e = Engine(max_iter=5)
 if os.environ.get("SEED") == "r1":   # the reference's map density: the seed cloud through Add_Points(downsample 0.5 m), as config R1
@@ -29,6 +33,7 @@ else:
     e.map_build(seed)
 _, _, P0 = synth.filter_inputs()
 st0 = e.map_update_stats()
+sys.stderr.write('[frames_moving] map ready at %.1f s, driving\n' % (time.time() - _t0)); sys.stderr.flush()
 r = run_frames(e, sw, P0, frames, warm, cube_len=float(os.environ.get("CUBE", "901")))
 st1 = e.map_update_stats()
 ms = r["ms"][warm:]
