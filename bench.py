@@ -830,7 +830,7 @@ def main():
         import threading
 
         def side_expired():
-            out["side_legs"] = "timed out after %s s: the legs not present in this line did not finish" % os.environ.get("S2M_SIDE_TIMEOUT_S", "600")
+            out["side_legs"] = "timed out after %s s: the legs not present in this line did not finish" % os.environ.get("S2M_SIDE_TIMEOUT_S", "300")
             C.CDLL(None).fflush(None)
             line = None
             for _ in range(5):
@@ -842,7 +842,7 @@ def main():
             sys.stdout.write((line or json.dumps({"error": "watchdog: the record could not be serialised"})) + "\n")
             sys.stdout.flush()
             os._exit(0)
-        side_dog = threading.Timer(float(os.environ.get("S2M_SIDE_TIMEOUT_S", "600")), side_expired)
+        side_dog = threading.Timer(float(os.environ.get("S2M_SIDE_TIMEOUT_S", "300")), side_expired)
         side_dog.daemon = True
         side_dog.start()
     if rank == 0 and single and side and a.config == "C3" and not a.extrinsic:

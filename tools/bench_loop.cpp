@@ -6,7 +6,10 @@
 // the K timed steps from here instead of from Python keeps the interpreter's ~10 us per call out of a
 // 150 us step.  Plain g++, links only libdaliti_s2m.so; built by __graft_entry__.build() as
 // daliti_amd/_lib/libs2m_benchloop.so and loaded by bench.py with ctypes.
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -173,6 +176,52 @@ int s2m_world_seed(const s2m_world *w, double span, int64_t m, float *xyz)
     return S2M_OK;
 }
 
+// A stall reporter for the frame loops: the loop leaves its frame and call numbers in two atomics, a side thread looks once a
+// second and says on stderr where the loop stands when nothing has moved for ten seconds (a frame takes well under a
+// millisecond; a stall seen once on a shared box left no trace of where it was).  Costs the loop two relaxed stores per call.
+namespace {
+struct StallReporter {
+    std::atomic<int64_t> beat{0};
+    std::atomic<int32_t> frame{-1}, call{-1};
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false;
+    std::thread th;
+    const char *const *names;
+    explicit StallReporter(const char *const *call_names) : names(call_names)
+    {
+        th = std::thread([this] {
+            int64_t seen = -1;
+            int idle = 0;
+            std::unique_lock<std::mutex> lk(mu);
+            while (!cv.wait_for(lk, std::chrono::seconds(1), [this] { return stop; })) {
+                const int64_t b = beat.load(std::memory_order_relaxed);
+                idle = b == seen ? idle + 1 : 0;
+                seen = b;
+                if (idle == 10 || (idle > 10 && idle % 60 == 0)) {
+                    const int c = call.load(std::memory_order_relaxed);
+                    std::fprintf(stderr, "[bench_loop] no progress for %d s: frame %d, inside %s\n", idle, frame.load(std::memory_order_relaxed),
+                                 c >= 0 ? names[c] : "(start)");
+                    std::fflush(stderr);
+                }
+            }
+        });
+    }
+    void at(int32_t f, int32_t c)
+    {
+        frame.store(f, std::memory_order_relaxed);
+        call.store(c, std::memory_order_relaxed);
+        beat.fetch_add(1, std::memory_order_relaxed);
+    }
+    ~StallReporter()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        th.join();
+    }
+};
+}  // namespace
+
 // What the reference's node does per scan (laserMapping.cpp:731-1175) along a trajectory: every frame its own sweep, poses
 // and predicted state -- raw records on the host -> s2m_scan_set_from_raw (undistort + voxel grid) -> s2m_iterated_update
 // from the frame's predicted state -> s2m_map_incremental at the updated state -> s2m_fov_segment at the LiDAR position.
@@ -202,6 +251,9 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         rc = mirror.update(e);  // the one whole-map fetch, before the drive
         if (rc) return rc;
     }
+    static const char *const call_names[7] = {"s2m_scan_set_from_raw", "s2m_scan_prefetch_raw", "s2m_iterated_update", "s2m_scan_prepare_raw",
+                                              "s2m_map_incremental", "s2m_fov_segment", "the map mirror"};
+    StallReporter stall(call_names);
     for (int f = 0; f < total; ++f) {
         const auto t0 = std::chrono::steady_clock::now();
         const float *r = rec + (int64_t)f * rec_stride_floats;
@@ -217,10 +269,12 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
             say(names[k]);
             if (stage_us) stage_us[(int64_t)f * 6 + k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         };
+        stall.at(f, 0);
         rc = s2m_scan_set_from_raw(e, r, 12, n[f], time_off_a, time_off_b, ps, n_poses, xp, leaf, 0, &n_out);
         if (rc) return rc;
         lap(0);
         if (prefetch >= 1 && f + 1 < total) {
+            stall.at(f, 1);
             rc = s2m_scan_prefetch_raw(e, r + rec_stride_floats, 12, n[f + 1], time_off_a, time_off_b);
             if (rc) return rc;
         }
@@ -228,16 +282,19 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         std::memcpy(P, P0, sizeof(P));
         P[0] += (double)(f & 1) * 1e-15;
         lap(1);
+        stall.at(f, 2);
         rc = s2m_iterated_update(e, x, xp, P, &log);
         if (rc) return rc;
         lap(2);
         if (logs) logs[f] = log;
         if (prefetch == 2 && f + 1 < total) {
+            stall.at(f, 3);
             rc = s2m_scan_prepare_raw(e, r + rec_stride_floats, 12, n[f + 1], time_off_a, time_off_b, ps + n_poses, n_poses,
                                       xp + S2M_STATE_DOUBLES, leaf);
             if (rc) return rc;
         }
         lap(3);
+        stall.at(f, 4);
         rc = s2m_map_incremental(e, x, filter_size_map, 1, &na, &nb);
         if (rc) return rc;
         lap(4);
@@ -252,6 +309,7 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         // pos_lid = pos_end + rot_end * T_L_I (laserMapping.cpp:753)
         double lid[3];
         for (int k = 0; k < 3; ++k) lid[k] = x[9 + k] + (x[3 * k] * x[21] + x[3 * k + 1] * x[22] + x[3 * k + 2] * x[23]);
+        stall.at(f, 5);
         rc = s2m_fov_segment(e, lid, cube_len, nullptr, nullptr, &nd);
         if (rc) return rc;
         if (nd > 0) {  // the trim changed the map too: how that update was produced counts for the frame
@@ -266,6 +324,7 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         lap(5);
         if (publish) {
             const auto tp = std::chrono::steady_clock::now();
+            stall.at(f, 6);
             rc = mirror.update(e);
             if (rc) return rc;
             if (publish_us) publish_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp).count();
