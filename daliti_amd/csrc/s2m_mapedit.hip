@@ -1145,10 +1145,9 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     uint32_t *bricks_dev = buf.counters + kBricksWord;
     uint64_t *nk_sorted = buf.mk;
     uint32_t *nv_sorted = buf.mv;
-    // a scan's batch is prepared by one workgroup (slab_prepare_kernel); larger ones -- and S2M_NO_FUSED_PREP=1, for A/B and
+    // a scan's batch is prepared by one workgroup (slab_prepare_kernel); larger ones -- and a handle made under S2M_NO_FUSED_PREP=1, for A/B and
     // tests -- by the separate kernels
-    static const bool no_fused = std::getenv("S2M_NO_FUSED_PREP") != nullptr;
-    bool fused = n > 0 && n <= kPrepMax && !no_fused;
+    bool fused = n > 0 && n <= kPrepMax && !buf.no_fused_prep;
     auto sort_keys = [&]() -> hipError_t {  // the separate kernels' keys, sorted
         const unsigned kbits = 9 + 3 * kBrickBits;
         size_t tmp = 0;

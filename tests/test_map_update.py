@@ -859,3 +859,47 @@ def test_delete_boxes_by_brick_and_by_position(oracle, small_scene):
         results.append(_rows(e.map_points()))
         e.close()
     assert len(results[0]) >= len(results[1])
+
+
+@pytest.mark.gpu
+def test_update_roads_agree(oracle, small_scene, monkeypatch):
+    """The in-place update prepares a scan-sized batch in one workgroup (slab_prepare_kernel) with the staged count left on
+    the device, and larger batches -- or a handle made under S2M_NO_FUSED_PREP / S2M_EXACT_STAGE -- with the separate
+    kernels and a count asked for after every batch.  Same updates down both roads, batches either side of the limits
+    (8 192 staged points for the preparation, 16 384 for the one-workgroup compaction of the winners): the same map in the
+    same LAYOUT (sorted positions, ids), equal to the oracle's."""
+    from daliti_amd import Engine
+    rs = np.random.RandomState(5)
+    base = (rs.uniform(0, 1, (150000, 3)) * [60.0, 60.0, 8.0] - [30.0, 30.0, 1.0]).astype(np.float32)
+
+    def batches():
+        r = np.random.RandomState(6)
+        for k, (n, ds) in enumerate([(3000, True), (7000, False), (9000, True), (20000, True), (9000, False), (500, True), (18000, False)]):
+            c = r.uniform(-25, 25, 2)
+            p = np.column_stack([r.normal(c[0], 6.0 + 3 * k, n), r.normal(c[1], 6.0, n), r.uniform(-1, 9, n)]).astype(np.float32)
+            yield p, ds
+
+    layouts = []
+    om = oracle.Map(base)
+    for road in (0, 1):
+        if road == 1:
+            monkeypatch.setenv("S2M_NO_FUSED_PREP", "1")
+            monkeypatch.setenv("S2M_EXACT_STAGE", "1")
+        e = Engine(cell_size=0.5)
+        e.map_build(base)
+        for p, ds in batches():
+            got = e.map_add(p, ds, 0.5)
+            assert e.map_last_update_merged()
+            if road == 0:
+                om.add(p, ds, 0.5) if ds else om.add(p, False)
+                assert e.map_size() == om.size()
+            assert got >= 0
+        nd = e.map_delete_boxes(np.float32([[-40, -40, -5, -10, 40, 20]]))
+        if road == 0:
+            assert nd == om.delete_box(np.float32([-40, -40, -5, -10, 40, 20]))
+            assert (bits(_rows(e.map_points())) == bits(_rows(om.points()))).all()
+        assert e.map_inplace_updates() >= 3
+        layouts.append((e.map_points().copy(), e.map_ids().copy(), e.map_rank().copy(), np.int64([e.map_inplace_updates()])))
+        e.close()
+    for a, b in zip(layouts[0], layouts[1]):
+        assert a.shape == b.shape and (bits(a) == bits(b)).all() if a.dtype == np.float32 else (a == b).all()
