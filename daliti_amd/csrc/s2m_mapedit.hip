@@ -613,6 +613,14 @@ __global__ __launch_bounds__(256) void slab_open_kernel(const uint64_t *__restri
 // same order as the 63-bit keys, found by a block-wide radix sort (rocprim::block_radix_sort, 8 bits per pass, stable: equal
 // keys keep the staged order).  The 64-bit keys are written out for the steps that follow.
 constexpr int kPrepThreads = 1024, kPrepItems = 8, kPrepMax = kPrepThreads * kPrepItems;
+// q = a / d for a workgroup-uniform divisor (a < 2^24, d < 2^22: exact in float up to one unit, corrected)
+__device__ __forceinline__ uint32_t prep_div(uint32_t a, uint32_t d, float inv_d)
+{
+    uint32_t q = (uint32_t)((float)a * inv_d);
+    if (q * d > a) --q;
+    else if ((q + 1u) * d <= a) ++q;
+    return q;
+}
 __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4 *__restrict__ stage, int n, const uint32_t *__restrict__ n_dev,
                                                                     Grid g, uint64_t *__restrict__ nk, uint32_t *__restrict__ nv,
                                                                     uint8_t *__restrict__ bmark, uint32_t *__restrict__ flags,
@@ -621,23 +629,30 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
                                                                     uint32_t *__restrict__ bend, uint64_t *__restrict__ bkey, int max_new)
 {
     using Sort = rocprim::block_radix_sort<uint32_t, kPrepThreads, kPrepItems, uint32_t>;
-    __shared__ typename Sort::storage_type sort_mem;
+    // one piece of LDS, three uses one after the other: the keys on their way from the order they are computed in (striped:
+    // coalesced reads of the staged points) to the order they are sorted from (blocked: the staged order, which the stable
+    // sort keeps among equal keys), the sort's own storage, the sorted keys for the look at the neighbours
+    __shared__ union {
+        typename Sort::storage_type sort;
+        uint32_t keys[kPrepMax];
+    } mem;
+    __shared__ uint8_t s_head[kPrepMax];
     __shared__ int s_lo[kPrepThreads / 64][3], s_hi[kPrepThreads / 64][3];
     __shared__ uint32_t s_bad[kPrepThreads / 64], s_part[kPrepThreads / 64];
     __shared__ int s_box[6];
     __shared__ uint32_t s_f;
-    __shared__ uint32_t s_first[kPrepThreads], s_last[kPrepThreads];
+    __shared__ uint32_t s_rank[kPrepThreads];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n_act = n_dev ? min((int)*n_dev, n) : n;  // (n: the host's bound when the count stayed on the device)
     const uint32_t first_id = bricks_dev[0];
-    // 1. the cells of the points (blocked: thread t holds staged points t * 8 ..), the batch's box of bricks
+    // 1. the cells of the points (striped: thread t holds staged points t, t + 1024, ..), the batch's box of bricks
     int bx[kPrepItems], by[kPrepItems], bz[kPrepItems];
     uint32_t cell[kPrepItems];
     int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
     uint32_t bad = 0u;
 #pragma unroll
     for (int j = 0; j < kPrepItems; ++j) {
-        const int i = tid * kPrepItems + j;
+        const int i = j * kPrepThreads + tid;
         cell[j] = 0xffffffffu;  // (not a point)
         bx[j] = by[j] = bz[j] = 0;
         if (i < n_act) {
@@ -703,56 +718,68 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
         return;
     }
     if (tid == 0 && fits) bricks_dev[1] = first_id;  // the bricks before this update: where the new ids start
-    // 3. the sort
+    // 3. the sort, from the staged order
     const uint32_t none = (uint32_t)vol << 9;  // sorts behind every point
+#pragma unroll
+    for (int j = 0; j < kPrepItems; ++j)
+        mem.keys[j * kPrepThreads + tid] =
+            cell[j] == 0xffffffffu ? none : ((uint32_t)(((bz[j] - b0[2]) * nb[1] + (by[j] - b0[1])) * nb[0] + (bx[j] - b0[0])) << 9) | cell[j];
+    __syncthreads();
     uint32_t key[kPrepItems], val[kPrepItems];
 #pragma unroll
     for (int j = 0; j < kPrepItems; ++j) {
         val[j] = (uint32_t)(tid * kPrepItems + j);
-        key[j] = cell[j] == 0xffffffffu
-                     ? none
-                     : ((uint32_t)(((bz[j] - b0[2]) * nb[1] + (by[j] - b0[1])) * nb[0] + (bx[j] - b0[0])) << 9) | cell[j];
+        key[j] = mem.keys[tid * kPrepItems + j];
     }
-    const unsigned bits = 32u - (unsigned)__clz((int)(none | 1u));
-    Sort().sort(key, val, sort_mem, 0u, bits);
-    // 4. the sorted keys, the runs of the bricks, the bricks that do not exist yet
-    s_first[tid] = key[0] >> 9;
-    s_last[tid] = key[kPrepItems - 1] >> 9;
     __syncthreads();
-    uint32_t heads = 0u, head_mask = 0u;
+    const unsigned bits = 32u - (unsigned)__clz((int)(none | 1u));
+    Sort().sort_to_striped(key, val, mem.sort, 0u, bits);  // thread t: sorted positions t, t + 1024, ..
+    __syncthreads();
+    // 4. the sorted keys, the runs of the bricks, the bricks that do not exist yet
+#pragma unroll
+    for (int j = 0; j < kPrepItems; ++j) mem.keys[j * kPrepThreads + tid] = key[j];
+    __syncthreads();
+    const uint32_t nbx = (uint32_t)nb[0], nbxy = (uint32_t)nb[0] * (uint32_t)nb[1];
+    const float inv_x = 1.0f / (float)nbx, inv_xy = 1.0f / (float)nbxy;
+    uint32_t head_mask = 0u;
 #pragma unroll
     for (int j = 0; j < kPrepItems; ++j) {
-        const int sp = tid * kPrepItems + j;
+        const int sp = j * kPrepThreads + tid;
         const uint32_t bl = key[j] >> 9;
         const bool pt = bl < (uint32_t)vol;
-        const int rx = (int)(bl % (uint32_t)nb[0]) + b0[0], ry = (int)((bl / (uint32_t)nb[0]) % (uint32_t)nb[1]) + b0[1];
-        const int rz = (int)(bl / ((uint32_t)nb[0] * (uint32_t)nb[1])) + b0[2];
-        const uint64_t b64 = brick_key(rx, ry, rz);
+        const uint32_t qz = prep_div(bl, nbxy, inv_xy), rem = bl - qz * nbxy, qy = prep_div(rem, nbx, inv_x);
+        const int rx = (int)(rem - qy * nbx) + b0[0], ry = (int)qy + b0[1], rz = (int)qz + b0[2];
         if (sp < n) {
-            nk[sp] = pt ? (b64 << 9) | (uint64_t)(key[j] & 511u) : ~0ull;
+            nk[sp] = pt ? (brick_key(rx, ry, rz) << 9) | (uint64_t)(key[j] & 511u) : ~0ull;
             nv[sp] = val[j];
         }
-        if (!pt || !fits) continue;
-        const uint32_t prev = j > 0 ? key[j - 1] >> 9 : (tid > 0 ? s_last[tid - 1] : 0xffffffffu);
-        const uint32_t next = j + 1 < kPrepItems ? key[j + 1] >> 9 : (tid + 1 < kPrepThreads ? s_first[tid + 1] : 0xffffffffu);
-        const bool first = prev != bl, last = next != bl;
-        if (first || last) {
-            const uint32_t slot = top_slot(g, rx, ry, rz);
-            if (first) run[slot].x = (uint32_t)sp;
-            if (last) run[slot].y = (uint32_t)sp + 1u;
-            if (first) {
-                const uint32_t idp1 = brick_in_bounds(g, rx, ry, rz) ? g.top[slot].x : 0u;
-                if (idp1 != 0u) bmark[idp1 - 1u] |= 2u;  // a brick that new points fall into
-                else { ++heads; head_mask |= 1u << j; }
+        bool head = false;
+        if (pt && fits) {
+            const bool first = sp == 0 || (mem.keys[sp - 1] >> 9) != bl, last = sp + 1 == kPrepMax || (mem.keys[sp + 1] >> 9) != bl;
+            if (first || last) {
+                const uint32_t slot = top_slot(g, rx, ry, rz);
+                if (first) run[slot].x = (uint32_t)sp;
+                if (last) run[slot].y = (uint32_t)sp + 1u;
+                if (first) {
+                    const uint32_t idp1 = brick_in_bounds(g, rx, ry, rz) ? g.top[slot].x : 0u;
+                    if (idp1 != 0u) bmark[idp1 - 1u] |= 2u;  // a brick that new points fall into
+                    else head = true;
+                }
             }
         }
+        s_head[sp] = head ? 1 : 0;
+        if (head) head_mask |= 1u << j;
     }
     if (!fits) {  // (uniform)
         if (tid == 0) atomicOr(flags, kSlabWindow);
         return;
     }
-    // the bricks that open, numbered in key order
-    uint32_t in = heads;
+    __syncthreads();
+    // the bricks that open, numbered in key order: the heads in front of every run of eight sorted positions, then inside it
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int j = 0; j < kPrepItems; ++j) mine += s_head[tid * kPrepItems + j];
+    uint32_t in = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t a = __shfl_up(in, off, 64);
@@ -765,27 +792,31 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
         if (w < wave) before += s_part[w];
         nh += s_part[w];
     }
+    s_rank[tid] = before + in - mine;  // heads in front of sorted position tid * 8
+    __syncthreads();
     if (nh > (uint32_t)max_new) {  // more bricks than there are table rows to spare: the merge re-lays the map and its tables out
         if (tid == 0) atomicOr(flags, kSlabNewBrick);
         return;
     }
     if (tid == 0) { bricks_dev[0] = first_id + nh; flags[2] = nh; }
-    uint32_t id = first_id + before + in - heads;
 #pragma unroll
     for (int j = 0; j < kPrepItems; ++j) {
         if (!((head_mask >> j) & 1u)) continue;
+        const int sp = j * kPrepThreads + tid;
+        uint32_t id = first_id + s_rank[sp >> 3];
+        for (int q = sp & ~7; q < sp; ++q) id += s_head[q];
         const uint32_t bl = key[j] >> 9;
-        const int rx = (int)(bl % (uint32_t)nb[0]) + b0[0], ry = (int)((bl / (uint32_t)nb[0]) % (uint32_t)nb[1]) + b0[1];
-        const int rz = (int)(bl / ((uint32_t)nb[0] * (uint32_t)nb[1])) + b0[2];
+        const uint32_t qz = prep_div(bl, nbxy, inv_xy), rem = bl - qz * nbxy, qy = prep_div(rem, nbx, inv_x);
+        const int rx = (int)(rem - qy * nbx) + b0[0], ry = (int)qy + b0[1], rz = (int)qz + b0[2];
         top[top_slot(g, rx, ry, rz)] = make_uint4(id + 1u, 0u, 0u, 0u);
         bkey[id] = brick_key(rx, ry, rz);
         bend[id] = 0u;
         tab[(int64_t)id * kBrickStride] = 0u;
         tab[(int64_t)id * kBrickStride + kBrickCells] = 0u;
         bmark[id] = 6u;  // "new" (4) + "touched" (2)
-        ++id;
     }
 }
+
 
 // What the plan found for a touched brick
 struct BrickPlan {
