@@ -68,6 +68,7 @@ struct MapBuffers {
     int64_t n_moved = 0;         // bricks that in-place updates have put into the tail (diagnostic)
     int64_t slab_fail[4] = {0, 0, 0, 0};  // in-place updates given up because of: a point beyond the representable cells, no spare
                                  // table rows, a brick too large to stage, the tail exhausted (diagnostic)
+    int prep_lds = 0;            // slab_prepare_kernel's dynamic LDS: 0 not asked yet, 1 granted, -1 refused (the separate kernels run)
     bool no_fused_prep = false;  // (set by the engine from S2M_NO_FUSED_PREP: the in-place update's separate kernels instead of slab_prepare_kernel)
     uint2 *run = nullptr;        // per top slot: where the brick's new points stand among the update's sorted ones (slab_head_kernel)
     int64_t run_cap = 0;

@@ -9,7 +9,6 @@
 #include <cstdlib>
 #include <cstring>
 
-#include <rocprim/block/block_radix_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
@@ -473,7 +472,7 @@ constexpr int kSlabBig = 6144;  // ... and in the second, rarely launched form f
 // kSlabOutside: a new point's cell cannot be represented (rebuild around a new origin); kSlabWindow: the box of the bricks in
 // use, grown by the new points, no longer fits the window of the top array (the host re-lays it and tries again)
 enum : uint32_t { kSlabOutside = 1u, kSlabNewBrick = 2u, kSlabOverflow = 4u, kSlabWindow = 8u, kSlabTooBig = 16u,
-                  kSlabRefuse = 32u };  // (refuse: the one-workgroup preparation cannot number the batch's bricks: the separate kernels run)
+                  kSlabRefuse = 32u };  // (refuse: the one-workgroup preparation cannot number the batch's bricks, or one of them is crowded: the separate kernels run)
 // words of the update's counters behind `flags`: [0] outcome bits, [1] points removed, [2] bricks opened, [3] points gained
 // by bricks, [4] crowded bricks among the touched ones, [5..11) how far the new points reach beyond the bricks in use,
 // [11] bricks moved to the tail (the opened ones included), [12] bricks touched
@@ -606,13 +605,18 @@ __global__ __launch_bounds__(256) void slab_open_kernel(const uint64_t *__restri
 }
 
 // The preparation of an in-place update in ONE workgroup, for the batch of a scan (up to kPrepMax staged points; larger batches
-// take the kernels above): keys, their sort, the runs of the touched bricks, the bricks that open.  Eleven launches -- the key
+// take the kernels above): keys, their order, the runs of the touched bricks, the bricks that open.  Eleven launches -- the key
 // kernel, rocprim's sort of 63-bit keys (six kernels for 6 k pairs, 42 us), head flags, their scan (two), the opening --
-// were half of what the host enqueues for a map update and the frame is bound by that, not by the device.  The keys are
-// sorted as 32-bit numbers: brick index inside the BATCH's own box of bricks (z, y, x like the brick key) << 9 | cell -- the
-// same order as the 63-bit keys, found by a block-wide radix sort (rocprim::block_radix_sort, 8 bits per pass, stable: equal
-// keys keep the staged order).  The 64-bit keys are written out for the steps that follow.
+// were half of what the host enqueues for a map update and the frame is bound by that, not by the device.
+// The order is found without a general sort: a scan's batch falls into a few hundred bricks of the batch's own box of bricks
+// (numbered z, y, x like the brick key: at most kPrepBricks of them), a dozen points each -- a histogram over the box in LDS
+// (packed 16-bit counters, LDS atomics), its prefix sum, every point dropped into its brick's stretch in arrival order, and
+// then every point counts the points of its brick in front of it by (cell, staged index): its place.  The same order as the
+// 63-bit keys' (a block-wide radix sort of 32-bit keys, three passes of rocprim::block_radix_sort, took 21 us of the
+// kernel's 39).  A brick with more than kPrepCrowd new points, or a box of more bricks, is left to the separate kernels.
 constexpr int kPrepThreads = 1024, kPrepItems = 8, kPrepMax = kPrepThreads * kPrepItems;
+constexpr int kPrepBricks = 32768, kPrepCrowd = 128;
+constexpr size_t kPrepLds = ((size_t)kPrepMax + (size_t)kPrepBricks / 2 + 1) * sizeof(uint32_t);
 // q = a / d for a workgroup-uniform divisor (a < 2^24, d < 2^22: exact in float up to one unit, corrected)
 __device__ __forceinline__ uint32_t prep_div(uint32_t a, uint32_t d, float inv_d)
 {
@@ -628,23 +632,18 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
                                                                     uint4 *__restrict__ top, uint32_t *__restrict__ tab,
                                                                     uint32_t *__restrict__ bend, uint64_t *__restrict__ bkey, int max_new)
 {
-    using Sort = rocprim::block_radix_sort<uint32_t, kPrepThreads, kPrepItems, uint32_t>;
-    // one piece of LDS, three uses one after the other: the keys on their way from the order they are computed in (striped:
-    // coalesced reads of the staged points) to the order they are sorted from (blocked: the staged order, which the stable
-    // sort keeps among equal keys), the sort's own storage, the sorted keys for the look at the neighbours
-    __shared__ union {
-        typename Sort::storage_type sort;
-        uint32_t keys[kPrepMax];
-    } mem;
-    __shared__ uint8_t s_head[kPrepMax];
+    extern __shared__ __attribute__((aligned(16))) unsigned char prep_lds[];
+    uint32_t *seg = reinterpret_cast<uint32_t *>(prep_lds);  // (cell << 13 | staged index) of the points, brick by brick
+    uint32_t *hist = seg + kPrepMax;                         // per brick of the box, two to a word: count, then offset
     __shared__ int s_lo[kPrepThreads / 64][3], s_hi[kPrepThreads / 64][3];
-    __shared__ uint32_t s_bad[kPrepThreads / 64], s_part[kPrepThreads / 64];
+    __shared__ uint32_t s_bad[kPrepThreads / 64], s_part[kPrepThreads / 64], s_max[kPrepThreads / 64];
     __shared__ int s_box[6];
     __shared__ uint32_t s_f;
-    __shared__ uint32_t s_rank[kPrepThreads];
+    __shared__ uint32_t s_headbits[kPrepBricks / 32], s_headrank[kPrepBricks / 32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n_act = n_dev ? min((int)*n_dev, n) : n;  // (n: the host's bound when the count stayed on the device)
     const uint32_t first_id = bricks_dev[0];
+    auto half = [&](uint32_t e) { return (hist[e >> 1] >> ((e & 1u) * 16u)) & 0xffffu; };
     // 1. the cells of the points (striped: thread t holds staged points t, t + 1024, ..), the batch's box of bricks
     int bx[kPrepItems], by[kPrepItems], bz[kPrepItems];
     uint32_t cell[kPrepItems];
@@ -700,7 +699,7 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
     const bool any = s_box[0] <= s_box[3];
     int b0[3] = {0, 0, 0}, nb[3] = {1, 1, 1};
     // 2. how far the batch reaches beyond the bricks in use, and whether the grown box still fits the window of the top array
-    // (a batch that does not fit leaves its sorted keys -- the host re-lays the top array around them -- and nothing else)
+    // (a batch that does not fit leaves its keys -- the host re-lays the top array around them -- and nothing else)
     bool fits = true;
     {
         const uint32_t tm[3] = {g.tmx, g.tmy, g.tmz};
@@ -712,101 +711,136 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
             if (any) { b0[k] = s_box[k]; nb[k] = s_box[3 + k] - s_box[k] + 1; }
         }
     }
-    const uint64_t vol = (uint64_t)nb[0] * (uint64_t)nb[1] * (uint64_t)nb[2];
-    if (vol >= (1ull << 22)) {  // (brick index + 9 cell bits + the "not a point" value in 32 bits)
+    const uint64_t vol64 = (uint64_t)nb[0] * (uint64_t)nb[1] * (uint64_t)nb[2];
+    if (vol64 >= (uint64_t)kPrepBricks) {  // a batch strewn over more bricks than the histogram holds
         if (tid == 0) atomicOr(flags, kSlabRefuse);
         return;
     }
-    if (tid == 0 && fits) bricks_dev[1] = first_id;  // the bricks before this update: where the new ids start
-    // 3. the sort, from the staged order
-    const uint32_t none = (uint32_t)vol << 9;  // sorts behind every point
-#pragma unroll
-    for (int j = 0; j < kPrepItems; ++j)
-        mem.keys[j * kPrepThreads + tid] =
-            cell[j] == 0xffffffffu ? none : ((uint32_t)(((bz[j] - b0[2]) * nb[1] + (by[j] - b0[1])) * nb[0] + (bx[j] - b0[0])) << 9) | cell[j];
+    const uint32_t vol = (uint32_t)vol64, words = (vol + 2u) / 2u;  // entries 0 .. vol (the last one: the end of the points)
+    // 3. the histogram over the box, its prefix sum
+    for (uint32_t w = tid; w < words; w += kPrepThreads) hist[w] = 0u;
+    for (uint32_t w = tid; w < kPrepBricks / 32; w += kPrepThreads) s_headbits[w] = 0u;
     __syncthreads();
-    uint32_t key[kPrepItems], val[kPrepItems];
+    uint32_t bidx[kPrepItems], arrival[kPrepItems];
 #pragma unroll
     for (int j = 0; j < kPrepItems; ++j) {
-        val[j] = (uint32_t)(tid * kPrepItems + j);
-        key[j] = mem.keys[tid * kPrepItems + j];
-    }
-    __syncthreads();
-    const unsigned bits = 32u - (unsigned)__clz((int)(none | 1u));
-    Sort().sort_to_striped(key, val, mem.sort, 0u, bits);  // thread t: sorted positions t, t + 1024, ..
-    __syncthreads();
-    // 4. the sorted keys, the runs of the bricks, the bricks that do not exist yet
-#pragma unroll
-    for (int j = 0; j < kPrepItems; ++j) mem.keys[j * kPrepThreads + tid] = key[j];
-    __syncthreads();
-    const uint32_t nbx = (uint32_t)nb[0], nbxy = (uint32_t)nb[0] * (uint32_t)nb[1];
-    const float inv_x = 1.0f / (float)nbx, inv_xy = 1.0f / (float)nbxy;
-    uint32_t head_mask = 0u;
-#pragma unroll
-    for (int j = 0; j < kPrepItems; ++j) {
-        const int sp = j * kPrepThreads + tid;
-        const uint32_t bl = key[j] >> 9;
-        const bool pt = bl < (uint32_t)vol;
-        const uint32_t qz = prep_div(bl, nbxy, inv_xy), rem = bl - qz * nbxy, qy = prep_div(rem, nbx, inv_x);
-        const int rx = (int)(rem - qy * nbx) + b0[0], ry = (int)qy + b0[1], rz = (int)qz + b0[2];
-        if (sp < n) {
-            nk[sp] = pt ? (brick_key(rx, ry, rz) << 9) | (uint64_t)(key[j] & 511u) : ~0ull;
-            nv[sp] = val[j];
+        bidx[j] = 0xffffffffu;
+        arrival[j] = 0u;
+        if (cell[j] != 0xffffffffu) {
+            const uint32_t b = (uint32_t)(((bz[j] - b0[2]) * nb[1] + (by[j] - b0[1])) * nb[0] + (bx[j] - b0[0]));
+            const uint32_t sh = (b & 1u) * 16u;
+            arrival[j] = (atomicAdd(&hist[b >> 1], 1u << sh) >> sh) & 0xffffu;
+            bidx[j] = b;
         }
-        bool head = false;
-        if (pt && fits) {
-            const bool first = sp == 0 || (mem.keys[sp - 1] >> 9) != bl, last = sp + 1 == kPrepMax || (mem.keys[sp + 1] >> 9) != bl;
-            if (first || last) {
-                const uint32_t slot = top_slot(g, rx, ry, rz);
-                if (first) run[slot].x = (uint32_t)sp;
-                if (last) run[slot].y = (uint32_t)sp + 1u;
-                if (first) {
-                    const uint32_t idp1 = brick_in_bounds(g, rx, ry, rz) ? g.top[slot].x : 0u;
-                    if (idp1 != 0u) bmark[idp1 - 1u] |= 2u;  // a brick that new points fall into
-                    else head = true;
-                }
-            }
-        }
-        s_head[sp] = head ? 1 : 0;
-        if (head) head_mask |= 1u << j;
-    }
-    if (!fits) {  // (uniform)
-        if (tid == 0) atomicOr(flags, kSlabWindow);
-        return;
     }
     __syncthreads();
-    // the bricks that open, numbered in key order: the heads in front of every run of eight sorted positions, then inside it
-    uint32_t mine = 0u;
-#pragma unroll
-    for (int j = 0; j < kPrepItems; ++j) mine += s_head[tid * kPrepItems + j];
-    uint32_t in = mine;
+    const uint32_t per = (words + kPrepThreads - 1) / kPrepThreads;
+    const uint32_t w0 = min((uint32_t)tid * per, words), w1 = min(w0 + per, words);
+    uint32_t sum = 0u, most = 0u;
+    for (uint32_t w = w0; w < w1; ++w) {
+        const uint32_t v = hist[w];
+        sum += (v & 0xffffu) + (v >> 16);
+        most = max(most, max(v & 0xffffu, v >> 16));
+    }
+    uint32_t in = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t a = __shfl_up(in, off, 64);
         if (lane >= off) in += a;
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) most = max(most, __shfl_xor(most, off, 64));
     if (lane == 63) s_part[wave] = in;
+    if (lane == 0) s_max[wave] = most;
     __syncthreads();
-    uint32_t before = 0u, nh = 0u;
+    uint32_t at = in - sum;
+    most = 0u;
     for (int w = 0; w < kPrepThreads / 64; ++w) {
-        if (w < wave) before += s_part[w];
-        nh += s_part[w];
+        if (w < wave) at += s_part[w];
+        most = max(most, s_max[w]);
     }
-    s_rank[tid] = before + in - mine;  // heads in front of sorted position tid * 8
+    if (most > (uint32_t)kPrepCrowd) {  // (uniform) a crowded brick: ranking by counting would be quadratic in it
+        if (tid == 0) atomicOr(flags, kSlabRefuse);
+        return;
+    }
+    for (uint32_t w = w0; w < w1; ++w) {
+        const uint32_t v = hist[w], c0 = v & 0xffffu, c1 = v >> 16;
+        hist[w] = at | ((at + c0) << 16);
+        at += c0 + c1;
+    }
     __syncthreads();
+    if (tid == 0 && fits) bricks_dev[1] = first_id;  // the bricks before this update: where the new ids start
+    // 4. every point into its brick's stretch, then to its place there: (cell, staged index) ascending
+#pragma unroll
+    for (int j = 0; j < kPrepItems; ++j)
+        if (bidx[j] != 0xffffffffu) seg[half(bidx[j]) + arrival[j]] = (cell[j] << 13) | (uint32_t)(j * kPrepThreads + tid);
+    __syncthreads();
+    const uint32_t total = half(vol);
+#pragma unroll
+    for (int j = 0; j < kPrepItems; ++j) {
+        if (bidx[j] == 0xffffffffu) continue;
+        const uint32_t off = half(bidx[j]), end = half(bidx[j] + 1u), mine = (cell[j] << 13) | (uint32_t)(j * kPrepThreads + tid);
+        uint32_t sp = off + arrival[j];
+        if (fits) {
+            sp = off;
+            for (uint32_t q = off; q < end; ++q) sp += seg[q] < mine ? 1u : 0u;
+        }
+        nk[sp] = (brick_key(bx[j], by[j], bz[j]) << 9) | (uint64_t)cell[j];
+        nv[sp] = (uint32_t)(j * kPrepThreads + tid);
+    }
+    for (uint32_t sp = total + (uint32_t)tid; sp < (uint32_t)n; sp += kPrepThreads) {  // behind the device's count: not points
+        nk[sp] = ~0ull;
+        nv[sp] = sp;
+    }
+    if (!fits) {  // (uniform)
+        if (tid == 0) atomicOr(flags, kSlabWindow);
+        return;
+    }
+    // 5. the bricks of the box that got points: their runs, their marks -- and the ones that do not exist yet
+    const uint32_t nbx = (uint32_t)nb[0], nbxy = (uint32_t)nb[0] * (uint32_t)nb[1];
+    const float inv_x = 1.0f / (float)nbx, inv_xy = 1.0f / (float)nbxy;
+    for (uint32_t e = tid; e < vol; e += kPrepThreads) {
+        const uint32_t off = half(e), end = half(e + 1u);
+        if (end == off) continue;
+        const uint32_t qz = prep_div(e, nbxy, inv_xy), rem = e - qz * nbxy, qy = prep_div(rem, nbx, inv_x);
+        const int rx = (int)(rem - qy * nbx) + b0[0], ry = (int)qy + b0[1], rz = (int)qz + b0[2];
+        const uint32_t slot = top_slot(g, rx, ry, rz);
+        run[slot] = make_uint2(off, end);
+        const uint32_t idp1 = brick_in_bounds(g, rx, ry, rz) ? g.top[slot].x : 0u;
+        if (idp1 != 0u) bmark[idp1 - 1u] |= 2u;  // a brick that new points fall into
+        else atomicOr(&s_headbits[e >> 5], 1u << (e & 31u));
+    }
+    __syncthreads();
+    // the bricks that open, numbered in key order (= the order of the box's entries)
+    {
+        const uint32_t v = tid < kPrepBricks / 32 ? s_headbits[tid] : 0u;  // (kPrepBricks / 32 = the workgroup's size)
+        const uint32_t c = (uint32_t)__popc(v);
+        uint32_t inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t a = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += a;
+        }
+        __syncthreads();  // (s_part of the prefix sum above has been read)
+        if (lane == 63) s_part[wave] = inc;
+        __syncthreads();
+        uint32_t before = inc - c;
+        for (int w = 0; w < wave; ++w) before += s_part[w];
+        s_headrank[tid] = before;
+    }
+    __syncthreads();
+    uint32_t nh = 0u;
+    for (int w = 0; w < kPrepThreads / 64; ++w) nh += s_part[w];
     if (nh > (uint32_t)max_new) {  // more bricks than there are table rows to spare: the merge re-lays the map and its tables out
         if (tid == 0) atomicOr(flags, kSlabNewBrick);
         return;
     }
     if (tid == 0) { bricks_dev[0] = first_id + nh; flags[2] = nh; }
-#pragma unroll
-    for (int j = 0; j < kPrepItems; ++j) {
-        if (!((head_mask >> j) & 1u)) continue;
-        const int sp = j * kPrepThreads + tid;
-        uint32_t id = first_id + s_rank[sp >> 3];
-        for (int q = sp & ~7; q < sp; ++q) id += s_head[q];
-        const uint32_t bl = key[j] >> 9;
-        const uint32_t qz = prep_div(bl, nbxy, inv_xy), rem = bl - qz * nbxy, qy = prep_div(rem, nbx, inv_x);
+    for (uint32_t e = tid; e < vol; e += kPrepThreads) {
+        const uint32_t bits = s_headbits[e >> 5];
+        if (!((bits >> (e & 31u)) & 1u)) continue;
+        const uint32_t id = first_id + s_headrank[e >> 5] + (uint32_t)__popc(bits & ((1u << (e & 31u)) - 1u));
+        const uint32_t qz = prep_div(e, nbxy, inv_xy), rem = e - qz * nbxy, qy = prep_div(rem, nbx, inv_x);
         const int rx = (int)(rem - qy * nbx) + b0[0], ry = (int)qy + b0[1], rz = (int)qz + b0[2];
         top[top_slot(g, rx, ry, rz)] = make_uint4(id + 1u, 0u, 0u, 0u);
         bkey[id] = brick_key(rx, ry, rz);
@@ -816,7 +850,6 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
         bmark[id] = 6u;  // "new" (4) + "touched" (2)
     }
 }
-
 
 // What the plan found for a touched brick
 struct BrickPlan {
@@ -1178,7 +1211,13 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     uint32_t *nv_sorted = buf.mv;
     // a scan's batch is prepared by one workgroup (slab_prepare_kernel); larger ones -- and a handle made under S2M_NO_FUSED_PREP=1, for A/B and
     // tests -- by the separate kernels
-    bool fused = n > 0 && n <= kPrepMax && !buf.no_fused_prep;
+    if (buf.prep_lds == 0) {  // (its histogram wants 96 KB of dynamic LDS: granted once per handle like the crowded-brick rewrite's)
+        const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&slab_prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)kPrepLds);
+        if (ae != hipSuccess) (void)hipGetLastError();
+        buf.prep_lds = ae == hipSuccess ? 1 : -1;
+    }
+    bool fused = n > 0 && n <= kPrepMax && !buf.no_fused_prep && buf.prep_lds > 0;
     auto sort_keys = [&]() -> hipError_t {  // the separate kernels' keys, sorted
         const unsigned kbits = 9 + 3 * kBrickBits;
         size_t tmp = 0;
@@ -1225,7 +1264,7 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     uint32_t v[kSlabWords + 2];
     for (int attempt = 0;; ++attempt) {
         if (n > 0 && fused) {
-            hipLaunchKernelGGL(slab_prepare_kernel, dim3(1), dim3(kPrepThreads), 0, st, stage, n, n_dev, g, nk_sorted, nv_sorted, buf.bmark, flags,
+            hipLaunchKernelGGL(slab_prepare_kernel, dim3(1), dim3(kPrepThreads), kPrepLds, st, stage, n, n_dev, g, nk_sorted, nv_sorted, buf.bmark, flags,
                                buf.run, bricks_dev, buf.top, buf.tab, buf.bend, buf.bkey, max_new);
         } else if (n > 0) {
             hipLaunchKernelGGL(slab_head_kernel, dim3((n + 255) / 256), dim3(256), 0, st, nk_sorted, n, g, head, bricks_dev, flags, buf.run);
@@ -1254,7 +1293,7 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
             n_new_io = std::min<int64_t>((int64_t)v[kSlabWords + 1], n_new);
             if (counted) *counted = true;
         }
-        if (fused && (v[0] & kSlabRefuse)) {  // (a batch strewn over more than 4 M bricks: nothing was written, the separate kernels do it)
+        if (fused && (v[0] & kSlabRefuse)) {  // (a batch strewn over too many bricks, or a crowded brick: nothing that counts was written, the separate kernels do it)
             fused = false;
             --attempt;
             S2M_TRY(hipMemsetAsync(flags, 0, kSlabWords * sizeof(uint32_t), st));
