@@ -95,8 +95,14 @@ int commit_update(s2m_engine *e)
         launch_log_removed(e->log, e->map.counters + kBricksWord, e->stats.bricks, e->map.bmark, e->grid.tab, e->upd.alive_s, e->grid.pidx, e->stream);
     if (!e->no_merge && !e->no_slab && !drift_before) {  // in place when every touched brick fits where it stands
         bool counted = false;
+        // a scan's batches that update_add left where they were are staged by the in-place update's preparation -- when that
+        // can run; otherwise here, by their own kernels
+        if (e->upd.pend.on && !slab_fuses(e->map, e->grid, e->stats, e->upd.stage_n)) {
+            he = update_materialize(e->upd, e->stream);
+            if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "update_materialize", he);
+        }
         he = slab_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, e->upd.counters + kUpdSlabWord, merged, e->stream,
-                         update_stage_word(e->upd), &counted);
+                         update_stage_word(e->upd), &counted, &e->upd.pend, e->upd.stage, e->upd.counters + kUpdStageWord + (e->upd.stage_ops & 1));
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "slab_update", he);
         if (counted) e->upd.stage_deferred = false;  // (stage_n is the count now)
         if (merged) ++e->n_inplace;

@@ -122,11 +122,26 @@ hipError_t merge_update(MapBuffers &buf, Grid &g, MapStats &stats, const uint8_t
                         const float4 *stage, int64_t n_new, bool &merged, hipStream_t st, bool with_slack = false);
 // The same update in place when every touched brick still fits where it stands (s2m_mapedit.hip, slab_update): done = false and
 // nothing touched otherwise.  flags: five zeroed words of the update's counters.
+// Batches of update_add(defer) that have not been written to the staging list: a scan's batches are staged by the in-place
+// update's own preparation kernel (slab_prepare_kernel) -- or, when that cannot run, by update_materialize.
+struct StagePending {
+    const float4 *la = nullptr;            // the voxel rule's batch ...
+    const uint32_t *flag = nullptr;        // ... and which of it won its voxel (add_resolve_kernel)
+    int na = 0;
+    const uint64_t *vkey = nullptr;        // its winner table, still to be emptied
+    unsigned long long *vtab = nullptr;
+    const float4 *lb = nullptr;            // the batch that is added whole, behind the winners
+    int nb = 0;
+    bool on = false;
+};
+// can the in-place update prepare a batch of at most n_bound points in one workgroup (and stage pending batches itself)?
+bool slab_fuses(MapBuffers &buf, const Grid &g, const MapStats &stats, int64_t n_bound);
 // n_dev (optional): the device's word with the number of staged points when the host only knows the bound n_new (update_add
 // with defer): the points from *n_dev on are ignored, n_new comes back as that number and counted = true once the update's
 // hand-back has been read (also when the update could not be done in place).
 hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t &n_new,
-                       uint32_t *flags, bool &done, hipStream_t st, const uint32_t *n_dev = nullptr, bool *counted = nullptr);
+                       uint32_t *flags, bool &done, hipStream_t st, const uint32_t *n_dev = nullptr, bool *counted = nullptr,
+                       StagePending *pend = nullptr, float4 *stage_out = nullptr, uint32_t *count_out = nullptr);
 
 // ---- s2m_mapupd.hip : incremental map maintenance (map_incremental / Add_Points / Delete_Point_Boxes) ----
 struct UpdateBuffers {
@@ -144,6 +159,8 @@ struct UpdateBuffers {
     // bound of it until the update's commit reads it back with the hand-back it waits for anyway (update_stage_count)
     bool stage_deferred = false;
     int stage_ops = 0;
+    StagePending pend;           // deferred batches not yet written to `stage` (update_materialize / slab_prepare_kernel)
+    bool fuse_stage = true;      // (the engine: false under S2M_NO_FUSED_PREP)
     uint32_t deleted_reported = 0;  // box deletes already reported to the caller within this update
     // per-batch scratch
     uint64_t *key = nullptr, *key2 = nullptr;
@@ -186,6 +203,7 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
                       int64_t *n_added, hipStream_t st, const VoxBox *vox = nullptr, bool defer = false);
 // the staged count of a deferred update: its device word (nullptr when the host's stage_n is exact) / read back now
 const uint32_t *update_stage_word(const UpdateBuffers &u);
+hipError_t update_materialize(UpdateBuffers &u, hipStream_t st);  // pending batches into the staging list (no-op without any)
 hipError_t update_stage_count(UpdateBuffers &u, hipStream_t st);
 // false when no box of the call reaches the bricks in use (host arithmetic: such a call launches nothing and waits for nothing)
 bool delete_touches_map(const Grid &g, const float *boxes_host, int nb);

@@ -625,7 +625,14 @@ __device__ __forceinline__ uint32_t prep_div(uint32_t a, uint32_t d, float inv_d
     else if ((q + 1u) * d <= a) ++q;
     return q;
 }
-__global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4 *__restrict__ stage, int n, const uint32_t *__restrict__ n_dev,
+// The points: src_a[0 .. na) -- all of them, or the first *n_dev when the count stayed on the device, or (flag_a given: the
+// voxel rule's batch as update_add(defer) left it, StagePending) the ones whose flag is set -- followed by src_b[0 .. n_b).
+// With stage_out the kernel writes the staging list itself (the winners in batch order, then src_b) and leaves their number
+// in *count_out: the two launches that did that (compact1_kernel, append_kernel: 19 us of one-workgroup kernels) are gone.
+__global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4 *__restrict__ src_a, const uint32_t *__restrict__ flag_a, int na,
+                                                                    const float4 *__restrict__ src_b, int n_b, const uint32_t *__restrict__ n_dev,
+                                                                    const uint64_t *__restrict__ vkey, unsigned long long *__restrict__ vtab,
+                                                                    float4 *__restrict__ stage_out, uint32_t *__restrict__ count_out,
                                                                     Grid g, uint64_t *__restrict__ nk, uint32_t *__restrict__ nv,
                                                                     uint8_t *__restrict__ bmark, uint32_t *__restrict__ flags,
                                                                     uint2 *__restrict__ run, uint32_t *__restrict__ bricks_dev,
@@ -640,13 +647,48 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
     __shared__ int s_box[6];
     __shared__ uint32_t s_f;
     __shared__ uint32_t s_headbits[kPrepBricks / 32], s_headrank[kPrepBricks / 32];
+    __shared__ uint8_t s_flag[kPrepMax];
+    __shared__ uint32_t s_before[kPrepThreads];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n_act = n_dev ? min((int)*n_dev, n) : n;  // (n: the host's bound when the count stayed on the device)
+    const int n = na + n_b;                                      // the host's bound of the number of points
+    const int na_act = n_dev ? min((int)*n_dev, na) : na;        // (without flags: the first na_act of src_a)
     const uint32_t first_id = bricks_dev[0];
     auto half = [&](uint32_t e) { return (hist[e >> 1] >> ((e & 1u) * 16u)) & 0xffffu; };
-    // 1. the cells of the points (striped: thread t holds staged points t, t + 1024, ..), the batch's box of bricks
+    // 0. with flags: the winners' places in the staging list (their rank in batch order), the winner table emptied
+    uint32_t n_win = (uint32_t)na_act;
+    if (flag_a) {
+#pragma unroll
+        for (int j = 0; j < kPrepItems; ++j) {
+            const int i = j * kPrepThreads + tid;
+            const bool f = i < na && flag_a[i] != 0u;
+            s_flag[i] = f ? 1 : 0;
+            if (i < na && vtab) vtab[vkey[i]] = ~0ull;  // the voxel's slot of the winner table back to "empty"
+        }
+        __syncthreads();
+        uint32_t mine = 0u;
+#pragma unroll
+        for (int j = 0; j < kPrepItems; ++j) mine += s_flag[tid * kPrepItems + j];
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t a = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += a;
+        }
+        if (lane == 63) s_part[wave] = inc;
+        __syncthreads();
+        uint32_t before = inc - mine;
+        n_win = 0u;
+        for (int w = 0; w < kPrepThreads / 64; ++w) {
+            if (w < wave) before += s_part[w];
+            n_win += s_part[w];
+        }
+        s_before[tid] = before;  // winners in front of batch index tid * 8
+        __syncthreads();
+    }
+    if (tid == 0 && count_out) *count_out = n_win + (uint32_t)n_b;
+    // 1. the cells of the points (striped: thread t holds candidates t, t + 1024, ..), the batch's box of bricks
     int bx[kPrepItems], by[kPrepItems], bz[kPrepItems];
-    uint32_t cell[kPrepItems];
+    uint32_t cell[kPrepItems], tix[kPrepItems];  // tix: the point's index in the staging list
     int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
     uint32_t bad = 0u;
 #pragma unroll
@@ -654,8 +696,27 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
         const int i = j * kPrepThreads + tid;
         cell[j] = 0xffffffffu;  // (not a point)
         bx[j] = by[j] = bz[j] = 0;
-        if (i < n_act) {
-            const float4 p = stage[i];
+        tix[j] = 0u;
+        bool is = false;
+        if (i < na) {
+            if (flag_a) {
+                is = s_flag[i] != 0;
+                if (is) {
+                    uint32_t r = s_before[i >> 3];
+                    for (int q = i & ~7; q < i; ++q) r += s_flag[q];
+                    tix[j] = r;
+                }
+            } else {
+                is = i < na_act;
+                tix[j] = (uint32_t)i;
+            }
+        } else if (i < n) {
+            is = true;
+            tix[j] = n_win + (uint32_t)(i - na);
+        }
+        if (is) {
+            float4 p = i < na ? src_a[i] : src_b[i - na];
+            if (stage_out) { p.w = 0.0f; stage_out[tix[j]] = p; }
             const int cx = cell_coord(p.x, g.ox, g.inv_c), cy = cell_coord(p.y, g.oy, g.inv_c), cz = cell_coord(p.z, g.oz, g.inv_c);
             if (!cell_representable(cx, cy, cz)) bad = kSlabOutside;
             else {
@@ -773,20 +834,20 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
     // 4. every point into its brick's stretch, then to its place there: (cell, staged index) ascending
 #pragma unroll
     for (int j = 0; j < kPrepItems; ++j)
-        if (bidx[j] != 0xffffffffu) seg[half(bidx[j]) + arrival[j]] = (cell[j] << 13) | (uint32_t)(j * kPrepThreads + tid);
+        if (bidx[j] != 0xffffffffu) seg[half(bidx[j]) + arrival[j]] = (cell[j] << 13) | tix[j];
     __syncthreads();
     const uint32_t total = half(vol);
 #pragma unroll
     for (int j = 0; j < kPrepItems; ++j) {
         if (bidx[j] == 0xffffffffu) continue;
-        const uint32_t off = half(bidx[j]), end = half(bidx[j] + 1u), mine = (cell[j] << 13) | (uint32_t)(j * kPrepThreads + tid);
+        const uint32_t off = half(bidx[j]), end = half(bidx[j] + 1u), mine = (cell[j] << 13) | tix[j];
         uint32_t sp = off + arrival[j];
         if (fits) {
             sp = off;
             for (uint32_t q = off; q < end; ++q) sp += seg[q] < mine ? 1u : 0u;
         }
         nk[sp] = (brick_key(bx[j], by[j], bz[j]) << 9) | (uint64_t)cell[j];
-        nv[sp] = (uint32_t)(j * kPrepThreads + tid);
+        nv[sp] = tix[j];
     }
     for (uint32_t sp = total + (uint32_t)tid; sp < (uint32_t)n; sp += kPrepThreads) {  // behind the device's count: not points
         nk[sp] = ~0ull;
@@ -1195,29 +1256,45 @@ static hipError_t relay_top(MapBuffers &buf, Grid &g, MapStats &stats, int64_t b
 
 // flags: kSlabWords zeroed words of the update's counters.  done = the map was updated in place; otherwise nothing was
 // touched and the caller goes on to merge_update.
-hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t &n_new_io,
-                       uint32_t *flags, bool &done, hipStream_t st, const uint32_t *n_dev, bool *counted)
+// the conditions under which slab_update gets as far as its preparation, and that one workgroup can do it
+static bool slab_possible(const MapBuffers &buf, const Grid &g, const MapStats &stats, int64_t n_new)
 {
-    done = false;
-    if (counted) *counted = false;
-    const int64_t n_new = n_new_io;  // (a bound when n_dev is given)
     const int64_t m = g.m;
-    if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || !buf.bmark || !buf.bmove || stats.bricks <= 0 || m > buf.scratch_cap) return hipSuccess;
-    if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return hipSuccess;
-    if (buf.next_id + n_new >= ((int64_t)1 << 32) - 2) return hipSuccess;
-    const int n = (int)n_new;
-    uint32_t *bricks_dev = buf.counters + kBricksWord;
-    uint64_t *nk_sorted = buf.mk;
-    uint32_t *nv_sorted = buf.mv;
-    // a scan's batch is prepared by one workgroup (slab_prepare_kernel); larger ones -- and a handle made under S2M_NO_FUSED_PREP=1, for A/B and
-    // tests -- by the separate kernels
+    if (m <= 0 || !buf.keys_alt || g.pts != buf.pts || !buf.bmark || !buf.bmove || stats.bricks <= 0 || m > buf.scratch_cap) return false;
+    if (n_new >= ((int64_t)1 << 30) || n_new > buf.scratch_cap) return false;
+    if (buf.next_id + n_new >= ((int64_t)1 << 32) - 2) return false;
+    return true;
+}
+bool slab_fuses(MapBuffers &buf, const Grid &g, const MapStats &stats, int64_t n_bound)
+{
+    if (!slab_possible(buf, g, stats, n_bound) || n_bound <= 0 || n_bound > kPrepMax || buf.no_fused_prep) return false;
     if (buf.prep_lds == 0) {  // (its histogram wants 96 KB of dynamic LDS: granted once per handle like the crowded-brick rewrite's)
         const hipError_t ae = hipFuncSetAttribute(reinterpret_cast<const void *>(&slab_prepare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   (int)kPrepLds);
         if (ae != hipSuccess) (void)hipGetLastError();
         buf.prep_lds = ae == hipSuccess ? 1 : -1;
     }
-    bool fused = n > 0 && n <= kPrepMax && !buf.no_fused_prep && buf.prep_lds > 0;
+    return buf.prep_lds > 0;
+}
+
+hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive_s, const float4 *stage, int64_t &n_new_io,
+                       uint32_t *flags, bool &done, hipStream_t st, const uint32_t *n_dev, bool *counted, StagePending *pend,
+                       float4 *stage_out, uint32_t *count_out)
+{
+    done = false;
+    if (counted) *counted = false;
+    const int64_t n_new = n_new_io;  // (a bound when n_dev is given)
+    const int64_t m = g.m;
+    if (!slab_possible(buf, g, stats, n_new)) return hipSuccess;
+    const int n = (int)n_new;
+    uint32_t *bricks_dev = buf.counters + kBricksWord;
+    uint64_t *nk_sorted = buf.mk;
+    uint32_t *nv_sorted = buf.mv;
+    // a scan's batch is prepared by one workgroup (slab_prepare_kernel); larger ones -- and a handle made under S2M_NO_FUSED_PREP=1, for A/B and
+    // tests -- by the separate kernels
+    bool fused = slab_fuses(buf, g, stats, n_new);
+    const bool pending = pend && pend->on;
+    if (pending && !fused) return hipErrorInvalidValue;  // (the caller asks slab_fuses first and stages the batches itself otherwise)
     auto sort_keys = [&]() -> hipError_t {  // the separate kernels' keys, sorted
         const unsigned kbits = 9 + 3 * kBrickBits;
         size_t tmp = 0;
@@ -1264,8 +1341,16 @@ hipError_t slab_update(MapBuffers &buf, Grid &g, MapStats &stats, uint8_t *alive
     uint32_t v[kSlabWords + 2];
     for (int attempt = 0;; ++attempt) {
         if (n > 0 && fused) {
-            hipLaunchKernelGGL(slab_prepare_kernel, dim3(1), dim3(kPrepThreads), kPrepLds, st, stage, n, n_dev, g, nk_sorted, nv_sorted, buf.bmark, flags,
-                               buf.run, bricks_dev, buf.top, buf.tab, buf.bend, buf.bkey, max_new);
+            if (pend && pend->on) {  // the scan's batches as update_add left them: staged here (once: a second attempt finds them staged)
+                hipLaunchKernelGGL(slab_prepare_kernel, dim3(1), dim3(kPrepThreads), kPrepLds, st, pend->la, pend->flag, pend->na, pend->lb, pend->nb,
+                                   (const uint32_t *)nullptr, pend->vkey, pend->vtab, stage_out, count_out, g, nk_sorted, nv_sorted, buf.bmark, flags,
+                                   buf.run, bricks_dev, buf.top, buf.tab, buf.bend, buf.bkey, max_new);
+                *pend = StagePending();
+            } else {
+                hipLaunchKernelGGL(slab_prepare_kernel, dim3(1), dim3(kPrepThreads), kPrepLds, st, stage, (const uint32_t *)nullptr, n, (const float4 *)nullptr, 0,
+                                   n_dev, (const uint64_t *)nullptr, (unsigned long long *)nullptr, (float4 *)nullptr, (uint32_t *)nullptr, g, nk_sorted,
+                                   nv_sorted, buf.bmark, flags, buf.run, bricks_dev, buf.top, buf.tab, buf.bend, buf.bkey, max_new);
+            }
         } else if (n > 0) {
             hipLaunchKernelGGL(slab_head_kernel, dim3((n + 255) / 256), dim3(256), 0, st, nk_sorted, n, g, head, bricks_dev, flags, buf.run);
             size_t ts = buf.sort_tmp_bytes;

@@ -776,6 +776,7 @@ hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st)
     u.stage_n = 0;
     u.stage_deferred = false;
     u.stage_ops = 0;
+    u.pend = StagePending();
     u.deleted_reported = 0;
     return hipSuccess;
 }
@@ -784,8 +785,27 @@ const uint32_t *update_stage_word(const UpdateBuffers &u)
 {
     return u.stage_deferred ? u.counters + kUpdStageWord + (u.stage_ops & 1) : nullptr;
 }
+hipError_t update_materialize(UpdateBuffers &u, hipStream_t st)
+{
+    if (!u.pend.on) return hipSuccess;
+    const StagePending p = u.pend;
+    u.pend = StagePending();
+    if (p.na > 0) {
+        hipLaunchKernelGGL(compact1_kernel, dim3(1), dim3(kCompactThreads), 0, st, p.la, p.flag, p.na, (int64_t)0, u.stage, p.vkey, p.vtab,
+                           u.counters + kUpdStageWord + (u.stage_ops & 1), u.counters + kUpdStageWord + ((u.stage_ops + 1) & 1),
+                           u.counters + kUpdBatchWord);
+        ++u.stage_ops;
+    }
+    if (p.nb > 0) {
+        hipLaunchKernelGGL(append_kernel, dim3(nblk(p.nb)), dim3(256), 0, st, p.lb, (int64_t)p.nb, u.stage, u.counters + kUpdStageWord + (u.stage_ops & 1),
+                           u.counters + kUpdStageWord + ((u.stage_ops + 1) & 1));
+        ++u.stage_ops;
+    }
+    return hipGetLastError();
+}
 hipError_t update_stage_count(UpdateBuffers &u, hipStream_t st)
 {
+    S2M_TRY(update_materialize(u, st));
     if (!u.stage_deferred) return hipSuccess;
     const uint32_t *src[1] = {update_stage_word(u)};
     uint32_t v = 0;
@@ -804,6 +824,11 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
     // the host goes on launching with a bound (one round trip less per scan, and the launches behind it no longer wait for
     // the host: s2m_map_incremental)
     defer = defer && !n_added;
+    // a scan's two batches stay where they are (StagePending): the in-place update's preparation stages them itself
+    const bool can_pend = defer && u.fuse_stage && n <= kCompactMax / 2 && (downsample ? !u.pend.on && u.stage_n == 0
+                                                                                         : (u.pend.on ? u.pend.lb == nullptr && u.pend.na + n <= kCompactMax / 2
+                                                                                                      : u.stage_n == 0));
+    if (!can_pend) S2M_TRY(update_materialize(u, st));
     if (!defer && u.stage_deferred) S2M_TRY(update_stage_count(u, st));
     if (defer && !u.stage_deferred) {  // the count so far moves to the device
         if (u.stage_n != 0) defer = false;  // (an exact batch came first: stay exact)
@@ -813,7 +838,11 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
     const uint32_t *w_in = defer ? u.counters + kUpdStageWord + (u.stage_ops & 1) : nullptr;
     uint32_t *w_out = defer ? u.counters + kUpdStageWord + ((u.stage_ops + 1) & 1) : nullptr;
     if (!downsample) {  // Add_Points(points, false): every point is inserted (ikd_Tree.cpp:549-570)
-        if (defer) {
+        if (can_pend) {
+            u.pend.lb = np;
+            u.pend.nb = (int)n;
+            u.pend.on = true;
+        } else if (defer) {
             hipLaunchKernelGGL(append_kernel, dim3(nblk(n)), dim3(256), 0, st, np, n, u.stage, w_in, w_out);
             ++u.stage_ops;
         } else {
@@ -882,6 +911,16 @@ hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t
                        u.cnt, u.best_idx, u.best_pos, u.best_d, u.alive_s, u.add_flag, u.counters, vtab, u.bmark);
     // winners, in batch order, go to the staging list
     const bool one_group = n <= kCompactMax;
+    if (can_pend) {
+        u.pend.la = np;
+        u.pend.flag = u.add_flag;
+        u.pend.na = in;
+        u.pend.vkey = u.key;
+        u.pend.vtab = vtab;
+        u.pend.on = true;
+        u.stage_n += n;  // (a bound)
+        return hipGetLastError();
+    }
     if (one_group) {
         hipLaunchKernelGGL(compact1_kernel, dim3(1), dim3(kCompactThreads), 0, st, np, u.add_flag, in, u.stage_n, u.stage, u.key, vtab, w_in, w_out,
                            u.counters + kUpdBatchWord);
@@ -996,6 +1035,7 @@ static hipError_t order_by_id(UpdateBuffers &u, const Grid &g, const uint8_t *al
 // survivors (ascending id = caller order) followed by the staged appends -> u.list; *m_out = new size
 hipError_t update_finish(UpdateBuffers &u, const Grid &g, int64_t *m_out, hipStream_t st)
 {
+    S2M_TRY(update_stage_count(u, st));  // (pending batches staged, a count left on the device read)
     int64_t survivors = 0;
     S2M_TRY(order_by_id(u, g, u.alive_s, &survivors, st));
     S2M_TRY(grow(&u.list, &u.list_cap, survivors + u.stage_n));
