@@ -30,6 +30,15 @@ hipError_t mail_wait(Mailbox &mb, hipStream_t st);
 // bounding box of an AoS cloud (s2m_map.hip): scratch holds the per-workgroup partial boxes + the result
 constexpr int kBboxBlocks = 1024;
 constexpr int kBboxScratchFloats = (kBboxBlocks + 1) * 6;
+// the voxel grid's numbers (pcl::VoxelGrid: min_b, divb_mul) as the device derives them from a cloud's box
+struct VoxelDimsDev {
+    int min_b[3];
+    uint32_t too_fine;  // the voxel index would overflow int32 (PCL refuses such a leaf)
+    int64_t mul1, mul2;
+    uint32_t bits, pad;  // bits of the largest voxel index
+};
+// the box only, left on the device at scratch + kBboxBlocks * 6 (and, with dims, the voxel grid's numbers): no hand-back
+hipError_t cloud_bbox_launch(const float *xyz, int64_t stride, int64_t n, float *scratch, float inv_leaf, VoxelDimsDev *dims, hipStream_t st);
 hipError_t cloud_bbox(const float *xyz, int64_t stride, int64_t n, float *scratch, Mailbox &mail, float lo[3], float hi[3],
                       hipStream_t st);
 
@@ -248,6 +257,9 @@ struct VoxelBuffers {
     uint32_t *key = nullptr, *key2 = nullptr;  // voxel index (below 2^31: PCL's own limit)
     uint32_t *val = nullptr, *val2 = nullptr, *head = nullptr, *pos = nullptr;
     float *box = nullptr;  // cloud_bbox scratch
+    VoxelDimsDev *dims = nullptr;  // the grid's numbers on the device (the form without the box's hand-back)
+    int kbits_hint = 0;            // bits the last cloud's voxel indices had: the next one is sorted on as many before its box is known
+    int64_t n_respeculated = 0;    // (diagnostic: clouds whose indices had more bits than the hint -- done again the classic way)
     void *tmp = nullptr;
     size_t tmp_bytes = 0;
     int64_t cap = 0;

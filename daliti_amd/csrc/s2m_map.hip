@@ -70,8 +70,10 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restri
     block_minmax(mn, mx, partial + (int64_t)blockIdx.x * 6);
 }
 
+// (dims, optional: the voxel grid's numbers derived from the box right here -- s2m_voxel.hip, voxel_downsample -- so that the
+// host need not see the box before it launches the grid's kernels)
 __global__ __launch_bounds__(256) void bbox_final_kernel(const float *__restrict__ partial, int blocks,
-                                                         float *__restrict__ out6)
+                                                         float *__restrict__ out6, float inv_leaf, VoxelDimsDev *__restrict__ dims)
 {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int b = threadIdx.x; b < blocks; b += blockDim.x) {
@@ -82,6 +84,33 @@ __global__ __launch_bounds__(256) void bbox_final_kernel(const float *__restrict
         }
     }
     block_minmax(mn, mx, out6);
+    if (dims) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // pcl::VoxelGrid::applyFilter: min_b = floor(min * inv_leaf), div_b = max_b - min_b + 1, divb_mul = {1, div0, div0 * div1}
+            int64_t div[3];
+            for (int k = 0; k < 3; ++k) {
+                dims->min_b[k] = (int)floorf(out6[k] * inv_leaf);
+                div[k] = (int64_t)(int)floorf(out6[3 + k] * inv_leaf) - dims->min_b[k] + 1;
+            }
+            dims->mul1 = div[0];
+            dims->mul2 = div[0] * div[1];
+            const int64_t total = div[0] * div[1] * div[2];
+            dims->too_fine = total > (int64_t)2147483647 ? 1u : 0u;
+            uint32_t bits = 1u;
+            while (bits < 32u && ((int64_t)1 << bits) < total) ++bits;
+            dims->bits = bits;
+        }
+    }
+}
+
+hipError_t cloud_bbox_launch(const float *xyz, int64_t stride, int64_t n, float *scratch, float inv_leaf, VoxelDimsDev *dims, hipStream_t st)
+{
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, kBboxBlocks);
+    float *out = scratch + (int64_t)kBboxBlocks * 6;
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, n, scratch);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(256), 0, st, scratch, blocks, out, inv_leaf, dims);
+    return hipGetLastError();
 }
 
 hipError_t cloud_bbox(const float *xyz, int64_t stride, int64_t n, float *scratch, Mailbox &mail, float lo[3], float hi[3],
@@ -90,7 +119,7 @@ hipError_t cloud_bbox(const float *xyz, int64_t stride, int64_t n, float *scratc
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, kBboxBlocks);
     float *out = scratch + (int64_t)kBboxBlocks * 6;
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, n, scratch);
-    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(256), 0, st, scratch, blocks, out);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(256), 0, st, scratch, blocks, out, 0.0f, (VoxelDimsDev *)nullptr);
     const uint32_t *w = reinterpret_cast<const uint32_t *>(out);
     const uint32_t *src[6] = {w, w + 1, w + 2, w + 3, w + 4, w + 5};
     uint32_t bits[6];

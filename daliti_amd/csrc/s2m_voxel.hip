@@ -14,6 +14,7 @@
 // nothing else of feats_down is read on the registration path.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -45,6 +46,22 @@ __global__ __launch_bounds__(256) void vx_key_kernel(const float *__restrict__ x
     const int i1 = (int)(floorf(xyz[i * stride + 1] * d.inv_leaf) - (float)d.min_b[1]);
     const int i2 = (int)(floorf(xyz[i * stride + 2] * d.inv_leaf) - (float)d.min_b[2]);
     key[i] = (uint32_t)((int64_t)i0 + (int64_t)i1 * d.mul1 + (int64_t)i2 * d.mul2);  // < 2^31 (checked on the host)
+    val[i] = (uint32_t)i;
+}
+
+// the same with the grid's numbers read from the device (bbox_final_kernel left them there)
+__global__ __launch_bounds__(256) void vx_key_dev_kernel(const float *__restrict__ xyz, int64_t stride, int64_t n, float inv_leaf,
+                                                         const VoxelDimsDev *__restrict__ dims, uint32_t *__restrict__ key,
+                                                         uint32_t *__restrict__ val)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int m0 = dims->min_b[0], m1 = dims->min_b[1], m2 = dims->min_b[2];
+    const int64_t mul1 = dims->mul1, mul2 = dims->mul2;
+    const int i0 = (int)(floorf(xyz[i * stride] * inv_leaf) - (float)m0);
+    const int i1 = (int)(floorf(xyz[i * stride + 1] * inv_leaf) - (float)m1);
+    const int i2 = (int)(floorf(xyz[i * stride + 2] * inv_leaf) - (float)m2);
+    key[i] = (uint32_t)((int64_t)i0 + (int64_t)i1 * mul1 + (int64_t)i2 * mul2);  // (< 2^31 unless too_fine: then nobody reads it)
     val[i] = (uint32_t)i;
 }
 
@@ -108,7 +125,7 @@ __global__ __launch_bounds__(256) void vx_centroid_kernel(const float *__restric
 
 void free_voxel(VoxelBuffers &v)
 {
-    void *ptrs[] = {v.key, v.key2, v.val, v.val2, v.head, v.pos, v.tmp, v.box};
+    void *ptrs[] = {v.key, v.key2, v.val, v.val2, v.head, v.pos, v.tmp, v.box, v.dims};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     free_mailbox(v.mail);
@@ -133,7 +150,47 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
         v.cap = n;
     }
     if (!v.box) S2M_TRY(hipMalloc((void **)&v.box, kBboxScratchFloats * sizeof(float)));
+    if (!v.dims) S2M_TRY(hipMalloc((void **)&v.dims, sizeof(VoxelDimsDev)));
     const int nb = (int)((n + 255) / 256);
+    // The grid's numbers follow from the cloud's box.  A stream of sweeps from one sensor keeps the number of BITS of its voxel
+    // indices for thousands of frames: with a hint from the last cloud the box stays on the device (bbox_final_kernel derives
+    // the numbers there), the sort runs on as many bits as last time, and the one hand-back at the end says whether that was
+    // enough -- a round trip (25 us of the front half, which bounds a pipelined frame) less.  When it was not, the cloud is
+    // done again the classic way below.
+    static const bool no_hint = std::getenv("S2M_NO_VOXEL_HINT") != nullptr;  // (A/B)
+    if (v.kbits_hint > 0 && !no_hint) {
+        const float inv_leaf = 1.0f / leaf;
+        S2M_TRY(cloud_bbox_launch(xyz, stride, n, v.box, inv_leaf, v.dims, st));
+        hipLaunchKernelGGL(vx_key_dev_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, inv_leaf, v.dims, v.key, v.val);
+        const unsigned kbits = (unsigned)v.kbits_hint;
+        size_t bytes = 0, b2 = 0;
+        S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, v.key, v.key2, v.val, v.val2, (size_t)n, 0, kbits, st));
+        S2M_TRY(rocprim::exclusive_scan(nullptr, b2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+        bytes = std::max(bytes, b2);
+        if (bytes > v.tmp_bytes) {
+            if (v.tmp) S2M_TRY(hipFree(v.tmp));
+            v.tmp = nullptr;
+            S2M_TRY(hipMalloc(&v.tmp, bytes));
+            v.tmp_bytes = bytes;
+        }
+        size_t t1 = v.tmp_bytes;
+        S2M_TRY(rocprim::radix_sort_pairs(v.tmp, t1, v.key, v.key2, v.val, v.val2, (size_t)n, 0, kbits, st));
+        hipLaunchKernelGGL(vx_head_kernel, dim3(nb), dim3(256), 0, st, v.key2, n, v.head);
+        size_t t2 = v.tmp_bytes;
+        S2M_TRY(rocprim::exclusive_scan(v.tmp, t2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+        hipLaunchKernelGGL(vx_centroid_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, v.key2, v.val2, v.head, v.pos, ox, oy, oz);
+        const uint32_t *src[4] = {v.pos + (n - 1), v.head + (n - 1), &v.dims->bits, &v.dims->too_fine};
+        uint32_t ab[4] = {0, 0, 0, 0};
+        S2M_TRY(mail_fetch(v.mail, src, 4, ab, st));
+        if (ab[3] != 0u) { *too_fine = true; return hipSuccess; }
+        const bool enough = ab[2] <= kbits;
+        v.kbits_hint = (int)ab[2];
+        if (enough) {
+            *n_out = (int64_t)ab[0] + ab[1];
+            return hipGetLastError();
+        }
+        ++v.n_respeculated;  // (the cloud's extent crossed a power of two: sorted on too few bits)
+    }
     float blo[3], bhi[3];
     S2M_TRY(cloud_bbox(xyz, stride, n, v.box, v.mail, blo, bhi, st));
     VoxelDims d;
@@ -153,6 +210,7 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
     // the voxel index is below div0 * div1 * div2: sort only the bits it can have
     unsigned kbits = 1;
     while (kbits < 32 && ((int64_t)1 << kbits) < div[0] * div[1] * div[2]) ++kbits;
+    v.kbits_hint = (int)kbits;
     size_t bytes = 0, b2 = 0;
     S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, v.key, v.key2, v.val, v.val2, (size_t)n, 0, kbits, st));
     S2M_TRY(rocprim::exclusive_scan(nullptr, b2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
