@@ -1206,7 +1206,13 @@ def frame_pipeline_moving(torch, Engine, synth, a):
                                                  int((how == 1).sum()), int((how == 0).sum()), trims, t_gen))
     out = {"frames": int(frames), "untimed_warmup_frames": warm, "metres_per_frame": float(step), "metres_driven": float(step * (frames + warm)),
            "median_ms": med, "p99_ms": float(np.percentile(ms, 99)), "max_ms": float(ms.max()), "max_over_median": float(ms.max() / med),
-           "worst_frame": worst + warm, "frames_per_s": float(1e3 / med),
+           "worst_frame": worst, "frames_per_s": float(1e3 / med),
+           # every frame above 1.5 x the median, with what its map update did: a stall of the engine (a merge, a rebuild, an
+           # allocation, a trim) shows here by name; a frame that is slow and did none of that was slowed by the box's host
+           "frames_over_1p5x_median": [{"frame": int(i), "ms": float(ms[i]), "map_update": ("rebuilt", "merged", "in_place")[int(how[i])],
+                                        "device_allocations": int(r["allocs"][warm + i]), "points_trimmed": int(r["deleted"][warm + i])}
+                                       for i in np.argsort(-ms)[:8] if ms[i] > 1.5 * med],
+           "second_worst_ms": float(np.sort(ms)[-2]),
            "updates": {"in_place": int((how == 2).sum()), "merged": int((how == 1).sum()), "rebuilt": int((how == 0).sum()),
                        "regridded": int(st1["regridded"] - st0["regridded"]), "top_array_relaid": int(st1["relaid"] - st0["relaid"]),
                        "bricks_through_large_form": int(st1["big_bricks"] - st0["big_bricks"]),
