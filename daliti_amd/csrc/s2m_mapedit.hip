@@ -648,7 +648,7 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
     __shared__ uint32_t s_f;
     __shared__ uint32_t s_headbits[kPrepBricks / 32], s_headrank[kPrepBricks / 32];
     __shared__ uint8_t s_flag[kPrepMax];
-    __shared__ uint32_t s_before[kPrepThreads];
+    __shared__ uint16_t s_rank[kPrepMax];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = na + n_b;                                      // the host's bound of the number of points
     const int na_act = n_dev ? min((int)*n_dev, na) : na;        // (without flags: the first na_act of src_a)
@@ -657,12 +657,19 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
     // 0. with flags: the winners' places in the staging list (their rank in batch order), the winner table emptied
     uint32_t n_win = (uint32_t)na_act;
     if (flag_a) {
+        uint32_t fl[kPrepItems];
+        uint64_t vk[kPrepItems];
+#pragma unroll
+        for (int j = 0; j < kPrepItems; ++j) {  // (all the loads first: sixteen round trips in flight, not one after the other)
+            const int i = j * kPrepThreads + tid;
+            fl[j] = i < na ? flag_a[i] : 0u;
+            vk[j] = (i < na && vtab) ? vkey[i] : 0ull;
+        }
 #pragma unroll
         for (int j = 0; j < kPrepItems; ++j) {
             const int i = j * kPrepThreads + tid;
-            const bool f = i < na && flag_a[i] != 0u;
-            s_flag[i] = f ? 1 : 0;
-            if (i < na && vtab) vtab[vkey[i]] = ~0ull;  // the voxel's slot of the winner table back to "empty"
+            s_flag[i] = fl[j] != 0u ? 1 : 0;
+            if (i < na && vtab) vtab[vk[j]] = ~0ull;  // the voxel's slot of the winner table back to "empty"
         }
         __syncthreads();
         uint32_t mine = 0u;
@@ -682,7 +689,12 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
             if (w < wave) before += s_part[w];
             n_win += s_part[w];
         }
-        s_before[tid] = before;  // winners in front of batch index tid * 8
+        // every candidate's number of winners in front of it (its place in the staging list if it is one)
+#pragma unroll
+        for (int j = 0; j < kPrepItems; ++j) {
+            s_rank[tid * kPrepItems + j] = (uint16_t)before;
+            before += s_flag[tid * kPrepItems + j];
+        }
         __syncthreads();
     }
     if (tid == 0 && count_out) *count_out = n_win + (uint32_t)n_b;
@@ -701,11 +713,7 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
         if (i < na) {
             if (flag_a) {
                 is = s_flag[i] != 0;
-                if (is) {
-                    uint32_t r = s_before[i >> 3];
-                    for (int q = i & ~7; q < i; ++q) r += s_flag[q];
-                    tix[j] = r;
-                }
+                tix[j] = s_rank[i];
             } else {
                 is = i < na_act;
                 tix[j] = (uint32_t)i;
@@ -868,8 +876,10 @@ __global__ __launch_bounds__(kPrepThreads) void slab_prepare_kernel(const float4
         const uint32_t slot = top_slot(g, rx, ry, rz);
         run[slot] = make_uint2(off, end);
         const uint32_t idp1 = brick_in_bounds(g, rx, ry, rz) ? g.top[slot].x : 0u;
-        if (idp1 != 0u) bmark[idp1 - 1u] |= 2u;  // a brick that new points fall into
-        else atomicOr(&s_headbits[e >> 5], 1u << (e & 31u));
+        if (idp1 != 0u) {  // a brick that new points fall into: its mark, without waiting for the byte (an atomic OR on its word)
+            const uint32_t id = idp1 - 1u;
+            atomicOr(reinterpret_cast<uint32_t *>(bmark + (id & ~3u)), 2u << ((id & 3u) * 8u));
+        } else atomicOr(&s_headbits[e >> 5], 1u << (e & 31u));
     }
     __syncthreads();
     // the bricks that open, numbered in key order (= the order of the box's entries)
