@@ -280,6 +280,12 @@ struct UndistBuffers {
     int64_t cap = 0;
     uint32_t *perm = nullptr;  // sorted position -> input index, on request
     int64_t perm_cap = 0;
+    // records that arrive in time order (every spinning or scanning LiDAR driver delivers them so) need no sort: the key kernel
+    // counts the places where the order is broken, one hand-back says whether any
+    uint32_t *unsorted = nullptr;  // device counter, never reset: compared with what the host saw last
+    uint32_t unsorted_seen = 0;
+    int64_t n_sorted_input = 0, n_unsorted_input = 0;  // (diagnostic)
+    Mailbox mail;
 };
 void free_undist(UndistBuffers &u);
 hipError_t undistort(UndistBuffers &u, const float *pts, int64_t stride, int64_t n, int off_a, int off_b,

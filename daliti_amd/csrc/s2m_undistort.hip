@@ -17,6 +17,7 @@
 // differ from glibc in the last bit, which moves a float output by at most one ulp (tested).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -37,15 +38,29 @@ __device__ __forceinline__ float point_time(const float *rec, int off_a, int off
     return off_b >= 0 ? rec[off_a] * rec[off_b] : rec[off_a];  // normal_x * normal_z (:352)
 }
 
+__device__ __forceinline__ uint32_t time_key(const float *rec, int off_a, int off_b)
+{
+    const uint32_t b = __float_as_uint(point_time(rec, off_a, off_b));
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // order-preserving for any sign
+}
+// val2 = the identity (the time order of records that ARE in time order: a stable sort leaves them where they stand);
+// *unsorted += 1 per wave that holds a record earlier than the one in front of it
 __global__ __launch_bounds__(256) void undist_key_kernel(const float *__restrict__ pts, int64_t stride, int64_t n,
                                                          int off_a, int off_b, uint32_t *__restrict__ key,
-                                                         uint32_t *__restrict__ val)
+                                                         uint32_t *__restrict__ val, uint32_t *__restrict__ val2,
+                                                         uint32_t *__restrict__ unsorted)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t b = __float_as_uint(point_time(pts + i * stride, off_a, off_b));
-    key[i] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // order-preserving for any sign
-    val[i] = (uint32_t)i;
+    bool broken = false;
+    if (i < n) {
+        const uint32_t k = time_key(pts + i * stride, off_a, off_b);
+        key[i] = k;
+        val[i] = (uint32_t)i;
+        val2[i] = (uint32_t)i;
+        broken = i > 0 && time_key(pts + (i - 1) * stride, off_a, off_b) > k;
+    }
+    const unsigned long long any = __ballot(broken);
+    if (any != 0ull && (threadIdx.x & 63) == 0) atomicAdd(unsorted, 1u);
 }
 
 __device__ __forceinline__ void m3v(const double *A, const double *v, double *o)
@@ -148,9 +163,10 @@ __global__ __launch_bounds__(256) void undistort_kernel(const float *__restrict_
 
 void free_undist(UndistBuffers &u)
 {
-    void *ptrs[] = {u.key, u.key2, u.val, u.val2, u.tmp, u.poses, u.out, u.perm};
+    void *ptrs[] = {u.key, u.key2, u.val, u.val2, u.tmp, u.poses, u.out, u.perm, u.unsorted};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    free_mailbox(u.mail);
     u = UndistBuffers();
 }
 
@@ -176,7 +192,22 @@ hipError_t undistort_order(UndistBuffers &u, const float *pts, int64_t stride, i
     if (n <= 0) return hipSuccess;
     S2M_TRY(undist_reserve(u, n));
     const int nb = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(undist_key_kernel, dim3(nb), dim3(256), 0, st, pts, stride, n, off_a, off_b, u.key, u.val);
+    if (!u.unsorted) {
+        S2M_TRY(hipMalloc((void **)&u.unsorted, sizeof(uint32_t)));
+        S2M_TRY(hipMemsetAsync(u.unsorted, 0, sizeof(uint32_t), st));
+        u.unsorted_seen = 0;
+    }
+    hipLaunchKernelGGL(undist_key_kernel, dim3(nb), dim3(256), 0, st, pts, stride, n, off_a, off_b, u.key, u.val, u.val2, u.unsorted);
+    static const bool always_sort = std::getenv("S2M_NO_TIME_SHORTCUT") != nullptr;  // (A/B and tests)
+    if (!always_sort) {
+        const uint32_t *src[1] = {u.unsorted};
+        uint32_t v = 0;
+        S2M_TRY(mail_fetch(u.mail, src, 1, &v, st));
+        const bool in_order = v == u.unsorted_seen;
+        u.unsorted_seen = v;
+        if (in_order) { ++u.n_sorted_input; return hipGetLastError(); }  // (val2 is the order)
+        ++u.n_unsorted_input;
+    }
     size_t bytes = 0;
     S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, u.key, u.key2, u.val, u.val2, (size_t)n, 0, 32, st));
     if (bytes > u.tmp_bytes) {
