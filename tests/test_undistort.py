@@ -284,3 +284,46 @@ def test_prefetch_then_prepare_is_the_same_scan(oracle):
     assert e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3) == len(plain)
     assert (bits(e.scan_get()) == bits(plain)).all()
     e.close()
+
+
+@pytest.mark.gpu
+def test_records_in_and_out_of_time_order_alternate(oracle):
+    """Records that arrive in time order are not sorted (the key kernel counts the places where the order is broken, one
+    hand-back: s2m_undistort.hip, undistort_order); records that do not are sorted by a stable sort like the reference's
+    list after std::sort (IMU_Processing.hpp:216).  One handle, sweeps in order, out of order, with ties, in order again --
+    by the plain road and through the prefetching worker: every scan equals the oracle's."""
+    from daliti_amd import Engine, synth
+    sc = synth.make_small()
+    n = len(sc["scan"])
+    rs = np.random.RandomState(11)
+    K = 12
+    poses = np.zeros((K, 22)); poses[:, 0] = np.linspace(0.0, 0.101, K); poses[:, 13:22] = np.eye(3).ravel()
+    poses[:, 1:4] = rs.normal(0, 0.3, (K, 3)); poses[:, 4:7] = rs.normal(0, 0.2, (K, 3)); poses[:, 7:10] = rs.normal(0, 0.5, (K, 3))
+    end = np.zeros(36); end[0:9] = np.eye(3).ravel(); end[12:21] = np.eye(3).ravel()
+
+    def sweep(kind):
+        rec = np.zeros((n, 12), np.float32)
+        rec[:, :3] = sc["scan"] + rs.normal(0, 0.01, (n, 3)).astype(np.float32)
+        t = np.sort(rs.uniform(0, 1, n)).astype(np.float32)
+        if kind == "ties":
+            t = np.floor(t * 64) / np.float32(64)              # long runs of equal stamps, still in order
+        elif kind == "one_swap":
+            t[[n // 2, n // 2 + 1]] = t[[n // 2 + 1, n // 2]]  # a single pair out of order (in ONE wave)
+        elif kind == "shuffled":
+            t = rs.permutation(t)
+        rec[:, 4] = t
+        rec[:, 6] = 0.1
+        return rec
+
+    e = Engine()
+    e.map_build(sc["map"])
+    for k, kind in enumerate(["sorted", "shuffled", "sorted", "ties", "one_swap", "one_swap", "sorted", "shuffled", "sorted"]):
+        rec = sweep(kind)
+        und, _ = oracle.undistort(rec, 4, 6, poses, end, True)
+        want = oracle.voxel_downsample(und, 0.3)
+        if k % 2:
+            e.scan_prefetch_raw(rec, 4, 6)
+        got_n = e.scan_set_from_raw(rec, 4, 6, poses, end, 0.3)
+        assert got_n == len(want), (k, kind)
+        assert (bits(e.scan_get()) == bits(want)).all(), (k, kind)
+    e.close()
