@@ -143,6 +143,8 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
     e->exact_stage = std::getenv("S2M_EXACT_STAGE") != nullptr;
     e->map.no_fused_prep = std::getenv("S2M_NO_FUSED_PREP") != nullptr;
     e->upd.fuse_stage = !e->map.no_fused_prep && std::getenv("S2M_NO_FUSED_STAGE") == nullptr;
+    e->vox.no_hint = std::getenv("S2M_NO_VOXEL_HINT") != nullptr;
+    e->und.always_sort = std::getenv("S2M_NO_TIME_SHORTCUT") != nullptr;
     if (const char *g = std::getenv("S2M_FIRST_GAIN")) e->first_round_gain = std::max(1.5f, std::min(256.0f, (float)std::atof(g)));
     if (const char *g = std::getenv("S2M_BLIND_ROUNDS")) e->blind_rounds = std::max(0, std::min(8, std::atoi(g)));  // (A/B runs)
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;

@@ -258,6 +258,7 @@ struct VoxelBuffers {
     uint32_t *val = nullptr, *val2 = nullptr, *head = nullptr, *pos = nullptr;
     float *box = nullptr;  // cloud_bbox scratch
     VoxelDimsDev *dims = nullptr;  // the grid's numbers on the device (the form without the box's hand-back)
+    bool no_hint = false;          // (the engine: true under S2M_NO_VOXEL_HINT -- the box is fetched first, as before)
     int kbits_hint = 0;            // bits the last cloud's voxel indices had: the next one is sorted on as many before its box is known
     int64_t n_respeculated = 0;    // (diagnostic: clouds whose indices had more bits than the hint -- done again the classic way)
     void *tmp = nullptr;
@@ -282,6 +283,7 @@ struct UndistBuffers {
     int64_t perm_cap = 0;
     // records that arrive in time order (every spinning or scanning LiDAR driver delivers them so) need no sort: the key kernel
     // counts the places where the order is broken, one hand-back says whether any
+    bool always_sort = false;      // (the engine: true under S2M_NO_TIME_SHORTCUT)
     uint32_t *unsorted = nullptr;  // device counter, never reset: compared with what the host saw last
     uint32_t unsorted_seen = 0;
     int64_t n_sorted_input = 0, n_unsorted_input = 0;  // (diagnostic)

@@ -198,8 +198,7 @@ hipError_t undistort_order(UndistBuffers &u, const float *pts, int64_t stride, i
         u.unsorted_seen = 0;
     }
     hipLaunchKernelGGL(undist_key_kernel, dim3(nb), dim3(256), 0, st, pts, stride, n, off_a, off_b, u.key, u.val, u.val2, u.unsorted);
-    static const bool always_sort = std::getenv("S2M_NO_TIME_SHORTCUT") != nullptr;  // (A/B and tests)
-    if (!always_sort) {
+    if (!u.always_sort) {
         const uint32_t *src[1] = {u.unsorted};
         uint32_t v = 0;
         S2M_TRY(mail_fetch(u.mail, src, 1, &v, st));

@@ -157,8 +157,7 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
     // the numbers there), the sort runs on as many bits as last time, and the one hand-back at the end says whether that was
     // enough -- a round trip (25 us of the front half, which bounds a pipelined frame) less.  When it was not, the cloud is
     // done again the classic way below.
-    static const bool no_hint = std::getenv("S2M_NO_VOXEL_HINT") != nullptr;  // (A/B)
-    if (v.kbits_hint > 0 && !no_hint) {
+    if (v.kbits_hint > 0 && !v.no_hint) {
         const float inv_leaf = 1.0f / leaf;
         S2M_TRY(cloud_bbox_launch(xyz, stride, n, v.box, inv_leaf, v.dims, st));
         hipLaunchKernelGGL(vx_key_dev_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, inv_leaf, v.dims, v.key, v.val);

@@ -124,3 +124,40 @@ def test_sixty_frames_of_a_drive_match_the_oracle(oracle):
     near = od[:, 4] <= 5.0
     assert near.sum() > 100 and (bits(d2[near]) == bits(od[near])).all() and (idx[near] == oi[near]).all()
     e.close()
+
+
+@pytest.mark.gpu
+def test_the_drive_by_both_roads(monkeypatch):
+    """The same thirty frames through a handle as it comes (the scan's batches staged and prepared by one workgroup, counts
+    left on the device, the voxel grid launched before its box is known, sweeps in time order not sorted) and through one made
+    with every such shortcut switched off: the same poses, the same map in the same layout."""
+    from daliti_amd import Engine, synth
+    frames, beams, az, fs = 30, 16, 256, 0.5
+    w = _world()
+    seed = w.seed_map(30000)
+    sw = w.sweeps(0, frames, beams, az, threads=8)
+    _, _, P0 = synth.filter_inputs()
+    runs = []
+    for road in (0, 1):
+        if road == 1:
+            for k in ("S2M_NO_FUSED_PREP", "S2M_EXACT_STAGE", "S2M_NO_FUSED_STAGE", "S2M_NO_VOXEL_HINT", "S2M_NO_TIME_SHORTCUT"):
+                monkeypatch.setenv(k, "1")
+        e = Engine(max_iter=5, feat_threshold=50, cell_size=0.5)
+        e.map_build(seed)
+        xs = []
+        for f in range(frames):
+            n = int(sw["n"][f])
+            rec, poses, xp = sw["rec"][f][:n], sw["poses"][f], sw["x_prop"][f]
+            if f + 1 < frames:
+                e.scan_prefetch_raw(sw["rec"][f + 1][:int(sw["n"][f + 1])], 4, 6)
+            e.scan_set_from_raw(rec, 4, 6, poses, xp, fs)
+            got = e.iterated_update(xp, xp, P0)
+            e.map_incremental(got["x"], fs)
+            e.fov_segment(got["x"][9:12], 1000.0)
+            xs.append(got["x"].copy())
+        assert e.map_inplace_updates() >= frames // 2
+        runs.append((np.array(xs), e.map_points().copy(), e.map_ids().copy(), e.map_rank().copy()))
+        e.close()
+    for a, b in zip(runs[0], runs[1]):
+        assert a.shape == b.shape
+        assert (a.view(np.uint64) == b.view(np.uint64)).all() if a.dtype == np.float64 else (bits(a) == bits(b)).all() if a.dtype == np.float32 else (a == b).all()

@@ -58,3 +58,30 @@ def test_gpu_voxel_grid_matches_oracle(oracle, leaf):
                                 sc["x_prop"], sc["x_prop"], sc["P"])
     assert n == e.n and (r["effct"] == ro["effct"]).all() and np.abs(r["x"] - ro["x"]).max() < 1e-9
     e.close()
+
+
+@pytest.mark.gpu
+def test_voxel_grid_with_and_without_the_box_in_hand(oracle):
+    """The grid's kernels are launched before the host has seen the cloud's box when the last cloud's voxel indices had a
+    known number of bits (VoxelBuffers::kbits_hint): clouds of the same extent, a cloud eight times as wide (more bits
+    than the hint: sorted on too few, found out by the final hand-back and done again), a small one again, a leaf that
+    overflows PCL's index in between -- every result equals the oracle's, bit for bit and in order."""
+    from daliti_amd import Engine, S2MError, synth
+    rs = np.random.RandomState(23)
+    e = Engine()
+    e.map_build(synth.make_map(20000))
+
+    def cloud(n, half):
+        return (rs.uniform(-1, 1, (n, 3)) * [half, half, 0.1 * half]).astype(np.float32)
+
+    for k, (half, leaf) in enumerate([(20.0, 0.5), (20.0, 0.5), (21.0, 0.5), (160.0, 0.5), (160.0, 0.5), (5.0, 0.5), (5.0, 0.25), (40.0, 0.5)]):
+        pts = cloud(30000 + 500 * k, half)
+        ref = oracle.voxel_downsample(pts, leaf)
+        m = e.scan_set_downsampled(pts, leaf)
+        assert m == len(ref), (k, m, len(ref))
+        assert (bits(e.scan_get()) == bits(ref)).all(), k
+        if k == 4:
+            with pytest.raises(S2MError) as ei:
+                e.scan_set_downsampled(np.float32([[0, 0, 0], [3e4, 3e4, 3e4]]), 0.01)
+            assert ei.value.code == -5
+    e.close()
