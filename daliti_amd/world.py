@@ -60,6 +60,12 @@ class World:
         """`count` raw sweeps from frame f0 on: dict(rec = count x (beams * az) x 12 float32 (the first n[k] records of
         sweep k are valid), n, poses = count x 20 x 22 float64, x_prop / x_true = count x 36)."""
         rays = beams * az
+        # (the hall ends `length` metres behind its near wall, half a width behind the start: a sensor that has left it sees
+        # nothing the generator knows how to range)
+        last_x = (f0 + count) * float(self.p.step)
+        if last_x > float(self.p.len) - 0.5 * float(self.p.width) - 1.0:
+            raise ValueError("the drive leaves the hall after %.0f m: %d frames of %.2f m from frame %d do not fit" % (
+                float(self.p.len) - 0.5 * float(self.p.width) - 1.0, count, float(self.p.step), f0))
         rec = np.zeros((count, rays, 12), np.float32)
         n = np.zeros(count, np.int64)
         poses = np.zeros((count, N_POSES, 22))
