@@ -65,10 +65,19 @@ __global__ __launch_bounds__(256) void vx_key_dev_kernel(const float *__restrict
     val[i] = (uint32_t)i;
 }
 
-__global__ __launch_bounds__(256) void vx_head_kernel(const uint32_t *__restrict__ skey, int64_t n, uint32_t *__restrict__ head)
+// head[s] = the sorted position starts a voxel; blk[b] = the voxels that start in workgroup b (the centroid kernel adds up
+// the workgroups in front of its own: no device-wide scan -- two launches of rocprim -- between the two)
+__global__ __launch_bounds__(256) void vx_head_kernel(const uint32_t *__restrict__ skey, int64_t n, uint32_t *__restrict__ head,
+                                                      uint32_t *__restrict__ blk)
 {
+    __shared__ uint32_t s_c[4];
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n) head[s] = (s == 0 || skey[s - 1] != skey[s]) ? 1u : 0u;
+    const bool h = s < n && (s == 0 || skey[s - 1] != skey[s]);
+    if (s < n) head[s] = h ? 1u : 0u;
+    const uint32_t c = (uint32_t)__popcll(__ballot(h));
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
 }
 
 // one lane per voxel: float sum of its points in ascending input index, divided by the count
@@ -76,11 +85,28 @@ __global__ __launch_bounds__(256) void vx_centroid_kernel(const float *__restric
                                                           const uint32_t *__restrict__ skey,
                                                           const uint32_t *__restrict__ sval,
                                                           const uint32_t *__restrict__ head,
-                                                          const uint32_t *__restrict__ pos, float *__restrict__ ox,
-                                                          float *__restrict__ oy, float *__restrict__ oz)
+                                                          const uint32_t *__restrict__ blk, uint32_t *__restrict__ count2,
+                                                          float *__restrict__ ox, float *__restrict__ oy, float *__restrict__ oz)
 {
+    __shared__ uint32_t s_before[4], s_wave[4];
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n || !head[s]) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the voxel's place in the output: the voxels of the workgroups in front, then the ones in front inside this one
+    uint32_t before = 0u;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += blk[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    const bool is_head = s < n && head[s] != 0u;
+    const unsigned long long hm = __ballot(is_head);
+    if (lane == 0) { s_before[wave] = before; s_wave[wave] = (uint32_t)__popcll(hm); }
+    __syncthreads();
+    uint32_t o = s_before[0] + s_before[1] + s_before[2] + s_before[3] + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) o += s_wave[w];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {  // (the last thread of the launch: every voxel lies in front of it)
+        count2[0] = o + (is_head ? 1u : 0u);
+        count2[1] = 0u;
+    }
+    if (!is_head) return;
     float cx = 0.0f, cy = 0.0f, cz = 0.0f;
     int cnt = 0;
     // four positions per trip: their keys, indices and points are requested together and added in order (a near-field
@@ -117,7 +143,6 @@ __global__ __launch_bounds__(256) void vx_centroid_kernel(const float *__restric
         if (!more) break;
     }
     const float fn = (float)cnt;
-    const uint32_t o = pos[s];
     ox[o] = cx / fn;
     oy[o] = cy / fn;
     oz[o] = cz / fn;
@@ -145,7 +170,7 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
         for (int k = 0; k < 6; ++k) {
             if (*ps[k]) S2M_TRY(hipFree(*ps[k]));
             *ps[k] = nullptr;
-            S2M_TRY(hipMalloc(ps[k], (size_t)n * es[k]));
+            S2M_TRY(hipMalloc(ps[k], (size_t)(n + 64) * es[k]));  // (+64: v.pos also holds the two count words and the per-workgroup counts)
         }
         v.cap = n;
     }
@@ -174,11 +199,9 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
         }
         size_t t1 = v.tmp_bytes;
         S2M_TRY(rocprim::radix_sort_pairs(v.tmp, t1, v.key, v.key2, v.val, v.val2, (size_t)n, 0, kbits, st));
-        hipLaunchKernelGGL(vx_head_kernel, dim3(nb), dim3(256), 0, st, v.key2, n, v.head);
-        size_t t2 = v.tmp_bytes;
-        S2M_TRY(rocprim::exclusive_scan(v.tmp, t2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
-        hipLaunchKernelGGL(vx_centroid_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, v.key2, v.val2, v.head, v.pos, ox, oy, oz);
-        const uint32_t *src[4] = {v.pos + (n - 1), v.head + (n - 1), &v.dims->bits, &v.dims->too_fine};
+        hipLaunchKernelGGL(vx_head_kernel, dim3(nb), dim3(256), 0, st, v.key2, n, v.head, v.pos + 2);
+        hipLaunchKernelGGL(vx_centroid_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, v.key2, v.val2, v.head, v.pos + 2, v.pos, ox, oy, oz);
+        const uint32_t *src[4] = {v.pos, v.pos + 1, &v.dims->bits, &v.dims->too_fine};
         uint32_t ab[4] = {0, 0, 0, 0};
         S2M_TRY(mail_fetch(v.mail, src, 4, ab, st));
         if (ab[3] != 0u) { *too_fine = true; return hipSuccess; }
@@ -222,12 +245,10 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
     }
     size_t t1 = v.tmp_bytes;
     S2M_TRY(rocprim::radix_sort_pairs(v.tmp, t1, v.key, v.key2, v.val, v.val2, (size_t)n, 0, kbits, st));
-    hipLaunchKernelGGL(vx_head_kernel, dim3(nb), dim3(256), 0, st, v.key2, n, v.head);
-    size_t t2 = v.tmp_bytes;
-    S2M_TRY(rocprim::exclusive_scan(v.tmp, t2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
-    hipLaunchKernelGGL(vx_centroid_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, v.key2, v.val2, v.head, v.pos,
+    hipLaunchKernelGGL(vx_head_kernel, dim3(nb), dim3(256), 0, st, v.key2, n, v.head, v.pos + 2);
+    hipLaunchKernelGGL(vx_centroid_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, v.key2, v.val2, v.head, v.pos + 2, v.pos,
                        ox, oy, oz);
-    const uint32_t *src[2] = {v.pos + (n - 1), v.head + (n - 1)};
+    const uint32_t *src[2] = {v.pos, v.pos + 1};
     uint32_t ab[2] = {0, 0};
     S2M_TRY(mail_fetch(v.mail, src, 2, ab, st));
     *n_out = (int64_t)ab[0] + ab[1];
