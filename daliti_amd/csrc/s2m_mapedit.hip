@@ -515,16 +515,6 @@ __global__ __launch_bounds__(256) void slab_key_kernel(const float4 *__restrict_
     }
 }
 
-// first index in the sorted keys whose brick part is >= b
-__device__ __forceinline__ int slab_lower(const uint64_t *__restrict__ nk, int n, uint64_t b)
-{
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((nk[mid] >> 9) < b) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
 // the entry of brick key b in the top array, if the brick lies inside the bounds in use (else "no brick": 0)
 __device__ __forceinline__ uint32_t slab_brick_id(const Grid &g, uint64_t b)
 {

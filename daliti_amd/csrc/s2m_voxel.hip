@@ -18,7 +18,6 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "s2m_device.h"
 #include "s2m_kernels.h"
@@ -187,10 +186,8 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
         S2M_TRY(cloud_bbox_launch(xyz, stride, n, v.box, inv_leaf, v.dims, st));
         hipLaunchKernelGGL(vx_key_dev_kernel, dim3(nb), dim3(256), 0, st, xyz, stride, n, inv_leaf, v.dims, v.key, v.val);
         const unsigned kbits = (unsigned)v.kbits_hint;
-        size_t bytes = 0, b2 = 0;
+        size_t bytes = 0;
         S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, v.key, v.key2, v.val, v.val2, (size_t)n, 0, kbits, st));
-        S2M_TRY(rocprim::exclusive_scan(nullptr, b2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
-        bytes = std::max(bytes, b2);
         if (bytes > v.tmp_bytes) {
             if (v.tmp) S2M_TRY(hipFree(v.tmp));
             v.tmp = nullptr;
@@ -233,10 +230,8 @@ hipError_t voxel_downsample(VoxelBuffers &v, const float *xyz, int64_t stride, i
     unsigned kbits = 1;
     while (kbits < 32 && ((int64_t)1 << kbits) < div[0] * div[1] * div[2]) ++kbits;
     v.kbits_hint = (int)kbits;
-    size_t bytes = 0, b2 = 0;
+    size_t bytes = 0;
     S2M_TRY(rocprim::radix_sort_pairs(nullptr, bytes, v.key, v.key2, v.val, v.val2, (size_t)n, 0, kbits, st));
-    S2M_TRY(rocprim::exclusive_scan(nullptr, b2, v.head, v.pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
-    bytes = std::max(bytes, b2);
     if (bytes > v.tmp_bytes) {
         if (v.tmp) S2M_TRY(hipFree(v.tmp));
         v.tmp = nullptr;
