@@ -1184,16 +1184,28 @@ def frame_pipeline_moving(torch, Engine, synth, a):
     seed = w.seed_map(synth.CONFIGS["C3"]["M"])
     sw = w.sweeps(0, frames + warm, 64, 1024, threads=min(32, os.cpu_count() or 8))
     t_gen = time.perf_counter() - t0
-    eng = Engine(max_iter=a.max_iter, device=torch.cuda.current_device())
-    eng.map_build(seed)
-    info0 = eng.map_info()
     _, _, P0 = synth.filter_inputs()
-    st0 = eng.map_update_stats()
-    ip0 = eng.map_inplace_updates()
-    r = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2)
-    torch.cuda.synchronize()
-    st1 = eng.map_update_stats()
-    ip1 = eng.map_inplace_updates()
+    # three drives (a fresh handle and map each): the pool's boxes share their host, and a descheduled thread shows as one frame
+    # of milliseconds in one drive in three; the leg's figures are those of the drive with the median p99, all three are listed
+    drives = []
+    for _rep in range(3):
+        eng = Engine(max_iter=a.max_iter, device=torch.cuda.current_device())
+        eng.map_build(seed)
+        info0 = eng.map_info()
+        st0 = eng.map_update_stats()
+        ip0 = eng.map_inplace_updates()
+        r = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2)
+        torch.cuda.synchronize()
+        drives.append(dict(eng=eng, info0=info0, st0=st0, ip0=ip0, r=r, st1=eng.map_update_stats(), ip1=eng.map_inplace_updates(),
+                           p99=float(np.percentile(r["ms"][warm:], 99))))
+    order = sorted(range(3), key=lambda k: drives[k]["p99"])
+    repeats = [{"median_ms": float(np.median(d["r"]["ms"][warm:])), "p99_ms": d["p99"], "max_ms": float(d["r"]["ms"][warm:].max()),
+                "max_over_median": float(d["r"]["ms"][warm:].max() / np.median(d["r"]["ms"][warm:])),
+                "in_place": int((d["r"]["how"][warm:] == 2).sum())} for d in drives]
+    for k in (order[0], order[2]):
+        drives[k]["eng"].close()
+    chosen = drives[order[1]]
+    eng, info0, st0, ip0, r, st1, ip1 = (chosen[k] for k in ("eng", "info0", "st0", "ip0", "r", "st1", "ip1"))
     ms, how = r["ms"][warm:], r["how"][warm:]
     med = float(np.median(ms))
     err = np.linalg.norm(r["x"][warm:, 9:12] - sw["x_true"][warm:warm + frames, 9:12], axis=1)
@@ -1207,6 +1219,8 @@ def frame_pipeline_moving(torch, Engine, synth, a):
     out = {"frames": int(frames), "untimed_warmup_frames": warm, "metres_per_frame": float(step), "metres_driven": float(step * (frames + warm)),
            "median_ms": med, "p99_ms": float(np.percentile(ms, 99)), "max_ms": float(ms.max()), "max_over_median": float(ms.max() / med),
            "worst_frame": worst, "frames_per_s": float(1e3 / med),
+           "repeats": repeats, "repeat_reported": "the one with the median p99 of the three",
+
            # every frame above 1.5 x the median, with what its map update did: a stall of the engine (a merge, a rebuild, an
            # allocation, a trim) shows here by name; a frame that is slow and did none of that was slowed by the box's host
            "frames_over_1p5x_median": [{"frame": int(i), "ms": float(ms[i]), "map_update": ("rebuilt", "merged", "in_place")[int(how[i])],
@@ -1236,22 +1250,27 @@ def frame_pipeline_moving(torch, Engine, synth, a):
     # the same drive seeded at the REFERENCE's map density: the seed cloud through Add_Points(downsample 0.5 m), as config R1
     # (the node's map only ever holds voxel-filtered points; the 5 M-point seed above is the benchmark's density)
     try:
-        eng = Engine(max_iter=a.max_iter, device=torch.cuda.current_device())
-        m_ref = build_reference_density_map(eng, seed)
-        info_r = eng.map_info()
-        st0 = eng.map_update_stats()
-        rr = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2)
-        torch.cuda.synchronize()
-        st1 = eng.map_update_stats()
-        msr, howr = rr["ms"][warm:], rr["how"][warm:]
-        out["at_reference_map_density"] = {
-            "map_points_seed": int(m_ref), "cell_m": float(info_r["cell"]), "median_ms": float(np.median(msr)),
-            "p99_ms": float(np.percentile(msr, 99)), "max_ms": float(msr.max()), "max_over_median": float(msr.max() / np.median(msr)),
-            "updates": {"in_place": int((howr == 2).sum()), "merged": int((howr == 1).sum()), "rebuilt": int((howr == 0).sum()),
-                        "regridded": int(st1["regridded"] - st0["regridded"]), "not_in_place_because": st1["not_in_place"]},
-            "map_points_end": int(eng.map_size()),
-            "note": "same sweeps, same loop; the seed is C3's cloud of the hall's first section through s2m_map_add(downsample 0.5 m)"}
-        eng.close()
+        tries = []
+        for _rep in range(3):  # (three drives, the one with the median p99 reported: as above)
+            eng = Engine(max_iter=a.max_iter, device=torch.cuda.current_device())
+            m_ref = build_reference_density_map(eng, seed)
+            info_r = eng.map_info()
+            st0 = eng.map_update_stats()
+            rr = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2)
+            torch.cuda.synchronize()
+            st1 = eng.map_update_stats()
+            msr, howr = rr["ms"][warm:], rr["how"][warm:]
+            tries.append({
+                "map_points_seed": int(m_ref), "cell_m": float(info_r["cell"]), "median_ms": float(np.median(msr)),
+                "p99_ms": float(np.percentile(msr, 99)), "max_ms": float(msr.max()), "max_over_median": float(msr.max() / np.median(msr)),
+                "updates": {"in_place": int((howr == 2).sum()), "merged": int((howr == 1).sum()), "rebuilt": int((howr == 0).sum()),
+                            "regridded": int(st1["regridded"] - st0["regridded"]), "not_in_place_because": st1["not_in_place"]},
+                "map_points_end": int(eng.map_size()),
+                "note": "same sweeps, same loop; the seed is C3's cloud of the hall's first section through s2m_map_add(downsample 0.5 m)"})
+            eng.close()
+        tries.sort(key=lambda t: t["p99_ms"])
+        out["at_reference_map_density"] = dict(tries[1], repeats=[{k: t[k] for k in ("median_ms", "p99_ms", "max_ms", "max_over_median")} for t in tries],
+                                               repeat_reported="the one with the median p99 of the three")
     except Exception as ex:  # noqa: BLE001
         out["at_reference_map_density"] = {"error": str(ex)[:300]}
     # the same drive with /Laser_map kept up to date every frame (laserMapping.cpp:1170-1175, 1229-1235): a host mirror fed
