@@ -9,6 +9,18 @@ namespace s2m_eng {
 
 int fail(s2m_engine *e, int code, const char *what, hipError_t he)
 {
+    if (he == kWaitTimedOut) {  // a wait of s2m_wait.h expired somewhere below `what`
+        code = S2M_ERR_TIMEOUT;
+        if (e && !e->poisoned) {
+            const char *w = e->wait.expired.load();
+            char head[256];
+            std::snprintf(head, sizeof(head), "no answer after %.0f ms while waiting for %s (in %s); ",
+                          1e-3 * (double)e->wait.waited_us.load(), w ? w : what, what);
+            e->err = head + debug_state(e);
+            e->poisoned = true;
+        }
+        return code;
+    }
     if (e) {
         e->err = what;
         if (he != hipSuccess) {
@@ -17,6 +29,48 @@ int fail(s2m_engine *e, int code, const char *what, hipError_t he)
         }
     }
     return code;
+}
+
+int refuse_poisoned(s2m_engine *e)
+{
+    if (e->err.compare(0, 9, "given up:") != 0) e->err = "given up: " + e->err;
+    return S2M_ERR_TIMEOUT;
+}
+
+int sync_stream(s2m_engine *e, hipStream_t st, const char *what)
+{
+    e->step = what;
+    const hipError_t he = wait_stream(&e->wait, st, what);
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, what, he);
+    return S2M_OK;
+}
+
+// one line for a watchdog or an error message: where the caller is, what the streams and the side thread are doing, every
+// pinned hand-back word against the number the host expects.  Reads only; racy by design (diagnostic).
+std::string debug_state(const s2m_engine *e)
+{
+    char b[1024];
+    auto mail = [](const Mailbox &m, char *out, size_t cap, const char *name) {
+        if (m.h) std::snprintf(out, cap, " %s %u/%u", name, (unsigned)__atomic_load_n(m.h, __ATOMIC_ACQUIRE), (unsigned)m.seq);
+        else out[0] = 0;
+    };
+    char m0[48], m1[48], m2[48], m3[48], m4[48];
+    mail(e->mail, m0, sizeof(m0), "handle");
+    mail(e->map.mail, m1, sizeof(m1), "map");
+    mail(e->upd.mail, m2, sizeof(m2), "update");
+    mail(e->vox.mail, m3, sizeof(m3), "voxel");
+    mail(e->und.mail, m4, sizeof(m4), "undistort");
+    const hipError_t q0 = e->stream ? hipStreamQuery(e->stream) : hipSuccess;
+    const hipError_t q1 = e->pf.stream ? hipStreamQuery(e->pf.stream) : hipSuccess;
+    auto qs = [](hipError_t q) { return q == hipSuccess ? "idle" : q == hipErrorNotReady ? "busy" : hipGetErrorName(q); };
+    const unsigned long long flag = e->h_block ? __atomic_load_n(reinterpret_cast<const unsigned long long *>(e->h_block + S2M_BLOCK_DOUBLES), __ATOMIC_ACQUIRE) : 0ull;
+    std::snprintf(b, sizeof(b),
+                  "state: in %s%s%s; main stream %s, side stream %s; side thread busy=%d (flag %d) gpu_pending=%d ready=%d prepared=%d; "
+                  "block word %llu/%llu; hand-back words (seen/expected):%s%s%s%s%s; waits %lld (slow %lld), policy %d, deadline %lld ms",
+                  e->where[0] ? e->where : "(no call yet)", e->step[0] ? " / " : "", e->step, qs(q0), e->pf.stream ? qs(q1) : "none",
+                  (int)e->pf.busy, e->pf.busy_a.load(), (int)e->pf.gpu_pending, (int)e->pf.ready, (int)e->pf.prepared, flag, e->seq, m0, m1, m2, m3, m4,
+                  (long long)e->wait.n_waits.load(), (long long)e->wait.n_slow.load(), e->wait.policy, (long long)(e->wait.timeout_us / 1000));
+    return b;
 }
 
 
@@ -46,6 +100,7 @@ int check_config(const s2m_config *c)
     if (!c) return S2M_ERR_ARG;
     if (!(c->plane_thr >= 0.0f) || !(c->knn_d2_gate > 0.0f) || !(c->laser_point_cov > 0.0)) return S2M_ERR_ARG;
     if (c->max_iter < 1 || c->max_iter > 64) return S2M_ERR_ARG;
+    if (c->wait_policy < 0 || c->wait_policy > 2 || c->wait_timeout_ms < 0 || c->wait_spin_us < 0) return S2M_ERR_ARG;
     return S2M_OK;
 }
 
@@ -92,6 +147,9 @@ int s2m_config_default(s2m_config *c)
     c->device = -1;
     c->far_point_bet = 1;
     c->device_loop = 0;
+    c->wait_policy = 0;
+    c->wait_timeout_ms = 10000;
+    c->wait_spin_us = 40;
     return S2M_OK;
 }
 
@@ -105,9 +163,28 @@ const char *s2m_strerror(int code)
         case S2M_ERR_STATE: return "call order error";
         case S2M_ERR_CAPACITY: return "capacity exceeded";
         case S2M_ERR_NUMERIC: return "singular matrix";
+        case S2M_ERR_TIMEOUT: return "the device did not answer in time";
         default: return "unknown error";
     }
 }
+
+namespace {
+// s2m_config -> the handle's wait control.  S2M_WAIT_POLICY / S2M_WAIT_TIMEOUT_MS override the config (A/B runs, tests);
+// a zero deadline or spin time means the default
+void apply_wait_config(s2m_engine *e)
+{
+    int policy = e->cfg.wait_policy;
+    int64_t ms = e->cfg.wait_timeout_ms > 0 ? e->cfg.wait_timeout_ms : 10000;
+    if (const char *g = std::getenv("S2M_WAIT_POLICY")) {
+        const std::string v(g);
+        policy = v == "spin" ? 0 : v == "yield" ? 1 : (v == "sleep" || v == "block") ? 2 : std::max(0, std::min(2, std::atoi(g)));
+    }
+    if (const char *g = std::getenv("S2M_WAIT_TIMEOUT_MS")) ms = std::max<int64_t>(1, std::atoll(g));
+    e->wait.policy = policy;
+    e->wait.timeout_us = ms * 1000;
+    e->wait.spin_us = e->cfg.wait_spin_us > 0 ? e->cfg.wait_spin_us : 40;
+}
+}  // namespace
 
 int s2m_create(const s2m_config *cfg, s2m_engine **out)
 {
@@ -127,6 +204,15 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
     if (!e) return S2M_ERR_CAPACITY;
     e->cfg = *cfg;
     e->device = dev;
+    apply_wait_config(e);
+    if (const char *g = std::getenv("S2M_TEST_STALL")) {  // fault injection (tests): worker | mail | reduce [: hand-backs before the stall]
+        const std::string v(g);
+        const size_t colon = v.find(':');
+        const std::string kind = v.substr(0, colon);
+        e->wait.stall_kind = kind == "worker" ? kStallWorker : kind == "mail" ? kStallMail : kind == "reduce" ? kStallReduce : kStallNone;
+        e->wait.stall_after.store(colon == std::string::npos ? 0 : std::atol(v.c_str() + colon + 1));
+    }
+    e->wait.hosttime = std::getenv("S2M_HOSTTIME") != nullptr;
     if (const char *g = std::getenv("S2M_WIDE_ADDR"))  // test hook: 64-bit point addresses on a small map
         if (std::atoi(g) != 0) e->match_group |= 0x10000;
     if (const char *g = std::getenv("S2M_EASY_NB")) {  // test hook: both first-shell instantiations on any scan size
@@ -170,13 +256,23 @@ int s2m_destroy(s2m_engine *e)
 {
     if (!e) return S2M_ERR_ARG;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    tl_wait = &e->wait;
+    // Nothing here may block for ever either: the streams are given the handle's deadline to drain and the side thread to
+    // leave.  If either does not, the device (or the runtime under that thread) is not answering: the handle's memory is left
+    // where it is -- freeing it would wait on the same device -- and the caller is told.
+    bool drained = !e->stream || wait_stream(&e->wait, e->stream, "the main stream (s2m_destroy)") != kWaitTimedOut;
     if (e->pf.worker.joinable()) {
         { std::lock_guard<std::mutex> lk(e->pf.mu); e->pf.quit = true; }
+        e->pf.quit_a.store(1, std::memory_order_release);
         e->pf.cv.notify_all();
-        e->pf.worker.join();
+        const bool left = wait_until(&e->wait, [&] { return e->pf.exited.load(std::memory_order_acquire) != 0; }, "the side thread to leave (s2m_destroy)");
+        if (left) e->pf.worker.join();
+        else { e->pf.worker.detach(); drained = false; }
     }
-    if (e->pf.stream) { (void)hipStreamSynchronize(e->pf.stream); (void)hipStreamDestroy(e->pf.stream); }
+    if (drained && e->pf.stream) drained = wait_stream(&e->wait, e->pf.stream, "the side stream (s2m_destroy)") != kWaitTimedOut;
+    tl_wait = nullptr;
+    if (!drained) return S2M_ERR_TIMEOUT;  // (the handle is leaked on purpose)
+    if (e->pf.stream) (void)hipStreamDestroy(e->pf.stream);
     if (e->pf.done) (void)hipEventDestroy(e->pf.done);
     if (e->pf.d_buf) (void)hipFree(e->pf.d_buf);
     if (e->d_scan_alt) (void)hipFree(e->d_scan_alt);
@@ -204,6 +300,23 @@ int s2m_destroy(s2m_engine *e)
 
 const char *s2m_last_error(const s2m_engine *e) { return e ? e->err.c_str() : "null handle"; }
 
+int s2m_test_stall(s2m_engine *e, int32_t kind, int64_t after)
+{
+    if (!e || kind < 0 || kind > 3 || after < 0) return S2M_ERR_ARG;
+    e->wait.stall_kind = kStallNone;
+    e->wait.stall_after.store((long)after);
+    e->wait.stall_kind = kind;
+    return S2M_OK;
+}
+
+int s2m_debug_state(const s2m_engine *e, char *buf, int64_t capacity)
+{
+    if (!e || !buf || capacity < 1) return S2M_ERR_ARG;
+    const std::string s = debug_state(e);
+    std::snprintf(buf, (size_t)capacity, "%s", s.c_str());
+    return S2M_OK;
+}
+
 int s2m_set_config(s2m_engine *e, const s2m_config *cfg)
 {
     if (!e) return S2M_ERR_ARG;
@@ -214,6 +327,7 @@ int s2m_set_config(s2m_engine *e, const s2m_config *cfg)
     e->cfg = *cfg;
     e->cfg.cell_size = cell;
     e->cfg.device = dev;
+    apply_wait_config(e);
     if (e->cfg.far_point_bet >= 0 && e->cfg.far_point_bet <= 2 && !e->spec_env) e->spec_mode = e->cfg.far_point_bet;
     return S2M_OK;
 }
@@ -221,7 +335,9 @@ int s2m_set_config(s2m_engine *e, const s2m_config *cfg)
 int s2m_set_stream(s2m_engine *e, void *hip_stream)
 {
     if (!e) return S2M_ERR_ARG;
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    S2M_ENTER(e);
+    int rc = sync_stream(e, e->stream, "the stream that is being replaced");
+    if (rc) return rc;
     e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
     return S2M_OK;
 }
@@ -237,7 +353,7 @@ int s2m_comm_unique_id(uint8_t id[S2M_COMM_ID_BYTES])
 int s2m_comm_init(s2m_engine *e, const uint8_t id[S2M_COMM_ID_BYTES], int32_t nranks, int32_t rank)
 {
     if (!e || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(e, S2M_ERR_ARG, "s2m_comm_init: bad argument");
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     comm_destroy(e->comm);
     shm_exchange_destroy(e->shm);   // one exchange at a time
     std::string err;

@@ -44,6 +44,11 @@ using namespace s2m;
 struct s2m_engine {
     s2m_config cfg{};
     int device = 0;
+    // every wait of this handle's caller and of its side thread (s2m_wait.h): policy, deadline, the fault-injection hook
+    WaitCtl wait;
+    bool poisoned = false;          // a wait expired: the handle's state on the device is unknown; only s2m_destroy is served
+    const char *where = "";         // the entry point the caller is inside (or was last), and the step of it that is waiting:
+    const char *step = "";          // what s2m_debug_state and the message of an expired wait quote
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool timing = false;
@@ -89,6 +94,7 @@ struct s2m_engine {
         std::mutex mu;
         std::condition_variable cv;
         bool quit = false, busy = false, ready = false;
+        std::atomic<int> quit_a{0}, exited{0};  // mirrors for the waits with a deadline (s2m_destroy; a stalled job's sleep)
         bool gpu_pending = false;        // the last job's work on `stream` has not been ordered in front of the main stream yet
         std::atomic<int> busy_a{0};      // mirror of `busy` for the short spins in front of the condition-variable waits: a futex
                                          // sleep / wake is tens of microseconds at best and has been seen to cost 10 ms once
@@ -185,7 +191,13 @@ struct s2m_engine {
 
 // ---- helpers shared by the engine's translation units (defined in s2m_engine.cpp) -----------------------------------
 namespace s2m_eng {
+// he == kWaitTimedOut (a wait of s2m_wait.h expired): the code becomes S2M_ERR_TIMEOUT, the message names the wait and the
+// handle's state (s2m_debug_state), and the handle serves nothing but s2m_destroy from then on
 int fail(s2m_engine *e, int code, const char *what, hipError_t he = hipSuccess);
+int refuse_poisoned(s2m_engine *e);
+// everything enqueued on a stream of the handle has finished: hipStreamSynchronize under the handle's policy and deadline
+int sync_stream(s2m_engine *e, hipStream_t st, const char *what);
+std::string debug_state(const s2m_engine *e);
 s2m::Gates gates_of(const s2m_config &c);
 s2m::Pose pose_of(const double s[S2M_STATE_DOUBLES]);
 int check_config(const s2m_config *c);
@@ -199,6 +211,24 @@ int caller_index_table(s2m_engine *e, const uint32_t **rank);
     do {                                                                          \
         hipError_t he_ = (call);                                                  \
         if (he_ != hipSuccess) return s2m_eng::fail((e), S2M_ERR_HIP, #call, he_); \
+    } while (0)
+
+// On entry to a compute entry point: a handle that has given up refuses, the calling thread's waits take this handle's
+// policy and deadline, the device is selected
+#define S2M_ENTER(e)                                                    \
+    do {                                                                \
+        if ((e)->poisoned) return s2m_eng::refuse_poisoned(e);          \
+        s2m::tl_wait = &(e)->wait;                                      \
+        (e)->where = __func__;                                          \
+        (e)->step = "";                                                 \
+        S2M_HIP(e, hipSetDevice((e)->device));                          \
+    } while (0)
+// ... inside a helper that an entry point calls (the entry point's name stays in `where`)
+#define S2M_INNER(e)                                                    \
+    do {                                                                \
+        if ((e)->poisoned) return s2m_eng::refuse_poisoned(e);          \
+        s2m::tl_wait = &(e)->wait;                                      \
+        S2M_HIP(e, hipSetDevice((e)->device));                          \
     } while (0)
 
 namespace s2m_eng {

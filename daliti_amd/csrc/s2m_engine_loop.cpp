@@ -18,7 +18,7 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
     if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
     if (!rematch && !e->nn_valid) return fail(e, S2M_ERR_STATE, "first pass of a scan must be a rematch pass");
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_INNER(e);
     const Pose pose = pose_of(state);
     const Gates gates = gates_of(e->cfg);
     const int n = (int)e->n;
@@ -61,7 +61,8 @@ int run_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, 
     r.ticket = e->d_ticket; r.hard_count = e->d_hard + 3 * e->n_cap;
     r.qheads = e->d_qheads;
     r.spec = (rematch && skip_far) ? 1 : 0;
-    const bool publish = e->host_poll && d_out == e->d_block && !defer_publish;
+    // (fault injection, S2M_TEST_STALL=reduce: the kernel runs but its block never reaches the host)
+    const bool publish = e->host_poll && d_out == e->d_block && !defer_publish && !e->wait.withhold(kStallReduce);
     r.host_block = publish ? e->h_block_dev : nullptr;
     r.host_flag = publish ? reinterpret_cast<unsigned long long *>(e->h_block_dev + S2M_BLOCK_DOUBLES) : nullptr;
     r.seq = ++e->seq;
@@ -111,7 +112,7 @@ int finish_timing(s2m_engine *e)
 {
     if (!e->timing || !e->timed_this_pass) return S2M_OK;
     float a = 0.f, b = 0.f;
-    S2M_HIP(e, hipEventSynchronize(e->ev[2]));
+    S2M_HIP(e, wait_event(&e->wait, e->ev[2], "the timing event behind a pass"));
     S2M_HIP(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
     S2M_HIP(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
     e->last_ms[0] = e->last_rematch ? a : 0.0;
@@ -136,22 +137,17 @@ extern "C" {
 // spins on the flag (no D2H copy, no driver sync).  Fallback: D2H copy + stream synchronise.
 static int wait_block(s2m_engine *e, const double *d_src, const double **host)
 {
+    e->step = "the block of a pass";
     if (e->host_poll && d_src == e->d_block) {
-        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(e->h_block + S2M_BLOCK_DOUBLES);
-        bool seen = false;
-        for (long spin = 0; spin < 20000000L; ++spin) {
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == e->seq) { seen = true; break; }
-            __builtin_ia32_pause();
-        }
-        if (!seen) {  // kernel slow or failed: let the runtime tell us
-            S2M_HIP(e, hipStreamSynchronize(e->stream));
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != e->seq) return fail(e, S2M_ERR_HIP, "reduce kernel did not publish its block");
-        }
+        const volatile unsigned long long *flag = reinterpret_cast<const volatile unsigned long long *>(e->h_block + S2M_BLOCK_DOUBLES);
+        const hipError_t he = wait_word(&e->wait, flag, e->seq, e->stream, "the block of a pass (published by the reduce kernel)");
+        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "reduce kernel did not publish its block", he);
         *host = e->h_block;
         return S2M_OK;
     }
     S2M_HIP(e, hipMemcpyAsync(e->h_block, d_src, S2M_BLOCK_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    int rc = sync_stream(e, e->stream, "the block of a pass (copied)");
+    if (rc) return rc;
     *host = e->h_block;
     return S2M_OK;
 }
@@ -159,6 +155,7 @@ static int wait_block(s2m_engine *e, const double *d_src, const double **host)
 int s2m_residual_pass(s2m_engine *e, const double state[S2M_STATE_DOUBLES], int rematch, s2m_pass_out *out)
 {
     if (!out) return fail(e, S2M_ERR_ARG, "null output");
+    if (e) { e->where = __func__; e->step = ""; }
     int rc = run_pass(e, state, rematch, e ? e->d_block : nullptr);
     if (rc) return rc;
     const double *hb = nullptr;
@@ -186,7 +183,7 @@ int s2m_get_rows(s2m_engine *e, double *h_x, double *h, int32_t *scan_index, int
 {
     if (!e || !m_out) return fail(e, S2M_ERR_ARG, "null argument");
     if (!e->pass_done) return fail(e, S2M_ERR_STATE, "no pass yet");
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     if (e->rows_cap < e->n) {
         int rc = 0;
         rc = rc ? rc : grow(e, &e->d_hx, e->n_cap * 12);
@@ -204,55 +201,59 @@ int s2m_get_rows(s2m_engine *e, double *h_x, double *h, int32_t *scan_index, int
     uint32_t m = 0;
     S2M_HIP(e, hipMemcpyAsync(&m, e->d_block_off + rows_blocks((int)e->n), sizeof(uint32_t), hipMemcpyDeviceToHost,
                               e->stream));
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    int rc = sync_stream(e, e->stream, "the row count");
+    if (rc) return rc;
     *m_out = m;
     if ((h_x || h || scan_index) && capacity < (int64_t)m) return fail(e, S2M_ERR_CAPACITY, "row buffers too small");
-    if (h_x && m) S2M_HIP(e, hipMemcpy(h_x, e->d_hx, (size_t)m * 12 * sizeof(double), hipMemcpyDeviceToHost));
-    if (h && m) S2M_HIP(e, hipMemcpy(h, e->d_h, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
-    if (scan_index && m) S2M_HIP(e, hipMemcpy(scan_index, e->d_rowidx, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
-    return S2M_OK;
+    if (h_x && m) S2M_HIP(e, hipMemcpyAsync(h_x, e->d_hx, (size_t)m * 12 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (h && m) S2M_HIP(e, hipMemcpyAsync(h, e->d_h, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (scan_index && m) S2M_HIP(e, hipMemcpyAsync(scan_index, e->d_rowidx, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    return sync_stream(e, e->stream, "the rows on their way to the caller");
 }
 
 int s2m_get_point_state(s2m_engine *e, uint8_t *selected, uint8_t *effective, float *plane, float *pd2)
 {
     if (!e) return S2M_ERR_ARG;
     if (!e->pass_done) return fail(e, S2M_ERR_STATE, "no pass yet");
-    S2M_HIP(e, hipSetDevice(e->device));
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    S2M_ENTER(e);
     const size_t n = (size_t)e->n;
     if (n == 0) return S2M_OK;
-    if (selected) S2M_HIP(e, hipMemcpy(selected, e->d_sel, n, hipMemcpyDeviceToHost));
-    if (effective) S2M_HIP(e, hipMemcpy(effective, e->d_eff, n, hipMemcpyDeviceToHost));
-    if (plane) S2M_HIP(e, hipMemcpy(plane, e->d_plane, n * sizeof(float4), hipMemcpyDeviceToHost));
-    if (pd2) S2M_HIP(e, hipMemcpy(pd2, e->d_pd2, n * sizeof(float), hipMemcpyDeviceToHost));
-    return S2M_OK;
+    int rc = sync_stream(e, e->stream, "the last pass");  // (a copy into pageable memory waits for the stream inside the runtime: wait here, with the deadline)
+    if (rc) return rc;
+    if (selected) S2M_HIP(e, hipMemcpyAsync(selected, e->d_sel, n, hipMemcpyDeviceToHost, e->stream));
+    if (effective) S2M_HIP(e, hipMemcpyAsync(effective, e->d_eff, n, hipMemcpyDeviceToHost, e->stream));
+    if (plane) S2M_HIP(e, hipMemcpyAsync(plane, e->d_plane, n * sizeof(float4), hipMemcpyDeviceToHost, e->stream));
+    if (pd2) S2M_HIP(e, hipMemcpyAsync(pd2, e->d_pd2, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    return sync_stream(e, e->stream, "the per-point state on its way to the caller");
 }
 
 int s2m_get_neighbors(s2m_engine *e, int32_t *idx, float *d2)
 {
     if (!e) return S2M_ERR_ARG;
     if (!e->nn_valid) return fail(e, S2M_ERR_STATE, "no rematch pass yet");
-    S2M_HIP(e, hipSetDevice(e->device));
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    S2M_ENTER(e);
     const size_t n = (size_t)e->n;
     if (n == 0) return S2M_OK;
+    int rc = sync_stream(e, e->stream, "the last rematch pass");
+    if (rc) return rc;
     if (idx) {  // the engine identifies a neighbour by its sorted position; the caller's indices are looked up on request
         const int64_t words = (int64_t)n * S2M_K;
         if (words > e->stage_cap) {
-            int rc = grow(e, &e->d_stage, words);
+            rc = grow(e, &e->d_stage, words);
             if (rc) return rc;
             e->stage_cap = words;
         }
         int32_t *tmp = reinterpret_cast<int32_t *>(e->d_stage);
         const uint32_t *rank = nullptr;
-        int rc = caller_index_table(e, &rank);
+        rc = caller_index_table(e, &rank);
         if (rc) return rc;
         launch_positions_to_indices(e->d_nn_idx, rank, words, tmp, e->stream);
+        rc = sync_stream(e, e->stream, "the neighbour indices in caller order");
+        if (rc) return rc;
         S2M_HIP(e, hipMemcpyAsync(idx, tmp, (size_t)words * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
-        S2M_HIP(e, hipStreamSynchronize(e->stream));
     }
-    if (d2) S2M_HIP(e, hipMemcpy(d2, e->d_nn_d2, n * S2M_K * sizeof(float), hipMemcpyDeviceToHost));
-    return S2M_OK;
+    if (d2) S2M_HIP(e, hipMemcpyAsync(d2, e->d_nn_d2, n * S2M_K * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    return sync_stream(e, e->stream, "the neighbour lists on their way to the caller");
 }
 
 
@@ -411,15 +412,13 @@ bool loop_fill_init(s2m_engine *e, const double *x, const double *x_prop, const 
     return true;
 }
 
-int loop_wait(s2m_engine *e, unsigned long long seq)
+// st: the stream the loop's kernels were enqueued on (a batch's launch group runs on its lead's stream)
+int loop_wait(s2m_engine *e, unsigned long long seq, hipStream_t st = nullptr)
 {
-    volatile unsigned long long *flag = &e->h_rec->flag;
-    for (long spin = 0; spin < 40000000L; ++spin) {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return S2M_OK;
-        __builtin_ia32_pause();
-    }
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
-    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(e, S2M_ERR_HIP, "the device-resident loop did not publish its record");
+    e->step = "the record of the device-resident loop";
+    const hipError_t he = wait_word(&e->wait, (const volatile unsigned long long *)&e->h_rec->flag, seq, st ? st : e->stream,
+                                    "the record of the device-resident loop");
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "the device-resident loop did not publish its record", he);
     return S2M_OK;
 }
 
@@ -487,7 +486,7 @@ int loop_begin(s2m_engine *e, const double *x, const double *x_prop, const doubl
     used = false;
     if (!loop_eligible(e)) return S2M_OK;
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_INNER(e);
     int rc = ensure_loop(e);
     if (rc) return rc;
     if (!loop_fill_init(e, x, x_prop, P)) return S2M_OK;
@@ -504,7 +503,7 @@ int loop_begin(s2m_engine *e, const double *x, const double *x_prop, const doubl
 
 int loop_enqueue(s2m_engine *e, LoopRun &run)
 {
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_INNER(e);
     const int max_iter = e->cfg.max_iter;
     const Gates gates = gates_of(e->cfg);
     const int n = (int)e->n;
@@ -590,6 +589,9 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
     if (!e || !x || !x_prop || !P) return fail(e, S2M_ERR_ARG, "null argument");
     if (reduce && !d_block) return fail(e, S2M_ERR_ARG, "sharded update needs a device block");
     if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
+    if (e->poisoned) return refuse_poisoned(e);
+    e->where = "s2m_iterated_update";
+    e->step = "";
     if (!reduce && (!d_block || d_block == e->d_block)) {  // state on the device where the form allows it (s2m_loop.h)
         bool used = false;
         int rc = iterated_update_loop(e, x, x_prop, P, log, used);
@@ -598,7 +600,7 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
     if (!d_block) d_block = e->d_block;
     // a new scan starts with every point selected and no neighbours (laserMapping.cpp:810-818);
     // iteration 0 is always a rematch pass, whose gate rewrites point_selected_surf for every point
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_INNER(e);
     e->nn_valid = false;
     const int max_iter = e->cfg.max_iter;
     int rematch_num = 0, rematch_en = 0, it = 0, passes = 0;
@@ -641,9 +643,8 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
         if (reduce) {
             S2M_HIP(e, hipMemcpyAsync(e->h_block, d_block, S2M_BLOCK_DOUBLES * sizeof(double), hipMemcpyDeviceToHost,
                                       e->stream));
-            S2M_HIP(e, hipStreamSynchronize(e->stream));
+            rc = sync_stream(e, e->stream, "the summed block of a sharded pass");
             hb = e->h_block;
-            rc = S2M_OK;
         } else {
             rc = wait_block(e, d_block, &hb);
         }
@@ -730,6 +731,12 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
                               s2m_iter_log *logs)
 {
     if (!handles || k < 1 || k > 256 || !x || !x_prop || !P) return S2M_ERR_ARG;
+    for (int i = 0; i < k; ++i)
+        if (handles[i]) {
+            if (handles[i]->poisoned) return refuse_poisoned(handles[i]);
+            handles[i]->where = "s2m_iterated_update_batch";
+            handles[i]->step = "";
+        }
     {
         bool ok = true;
         for (int i = 0; i < k && ok; ++i) {
@@ -828,14 +835,15 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
     } clear_hint{handles, k};
     for (int i = 0; i < k; ++i) {
         s2m_engine *e = handles[i];
-        S2M_HIP(e, hipSetDevice(e->device));
+        S2M_INNER(e);
         e->nn_valid = false;
         reset_log(logs ? logs + i : nullptr, e->cfg.max_iter);
         int rc = launch(i);
         if (rc) return rc;
     }
     int active = k;
-    long idle_spins = 0;
+    IdleWait idle(&handles[0]->wait);
+    handles[0]->step = "the blocks of a batch";
     while (active > 0) {
         bool progress = false;
         for (int i = 0; i < k; ++i) {
@@ -866,12 +874,15 @@ int s2m_iterated_update_batch(s2m_engine *const *handles, int32_t k, double *x, 
                 if (rc) return rc;
             }
         }
-        if (progress) { idle_spins = 0; continue; }
-        __builtin_ia32_pause();
-        if (++idle_spins > 200000000L) {  // a kernel failed: let the runtime say which
+        if (progress) { idle.progress(); continue; }
+        if (idle.idle()) {  // no block for a whole deadline: a runtime error is reported as such, anything else as the timeout it is
             for (int i = 0; i < k; ++i)
-                if (slots[i].active) S2M_HIP(handles[i], hipStreamSynchronize(handles[i]->stream));
-            return fail(handles[0], S2M_ERR_HIP, "s2m_iterated_update_batch: a pass did not publish its block");
+                if (slots[i].active) {
+                    const hipError_t q = hipStreamQuery(handles[i]->stream);
+                    if (q != hipSuccess && q != hipErrorNotReady) return fail(handles[i], S2M_ERR_HIP, "s2m_iterated_update_batch: a pass failed", q);
+                }
+            wait_expired(&handles[0]->wait, "the blocks of a batch of scans", idle.us);
+            return fail(handles[0], S2M_ERR_HIP, "s2m_iterated_update_batch: a pass did not publish its block", kWaitTimedOut);
         }
     }
     return S2M_OK;
@@ -896,6 +907,9 @@ int s2m_iterated_update_multi(s2m_engine *const *handles, int32_t n, double x[S2
         if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
         if (e->comm.handle || e->shm.base || !e->host_poll)
             return fail(e, S2M_ERR_STATE, "s2m_iterated_update_multi: handles without a communicator, host-polled block only");
+        if (e->poisoned) return refuse_poisoned(e);
+        e->where = "s2m_iterated_update_multi";
+        e->step = "";
         e->nn_valid = false;
     }
     s2m_engine *e0 = handles[0];
@@ -985,7 +999,7 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
     auto xpk = [&](int i) { return x_prop + (size_t)i * S2M_STATE_DOUBLES; };
     auto Pk = [&](int i) { return P + (size_t)i * S2M_DIM * S2M_DIM; };
     s2m_engine *e0 = handles[0];
-    S2M_HIP(e0, hipSetDevice(e0->device));
+    S2M_INNER(e0);
     for (int g = 0, at = 0; g < ng; ++g) {
         Group &G = groups[g];
         G.first = at;
@@ -1033,7 +1047,10 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
             e->nn_valid = false;
             reset_log(logs ? logs + G.first + j : nullptr, e->cfg.max_iter);
             // the handle's own stream may still hold its scan hand-over: the group's launches go to the lead's stream
-            if (e != L && e->stream != L->stream) S2M_HIP(e, hipStreamSynchronize(e->stream));
+            if (e != L && e->stream != L->stream) {
+                int rc = sync_stream(e, e->stream, "a scan's own stream, before the group's launches");
+                if (rc) return rc;
+            }
         }
     }
     // one pass of every active scan of the group: the table's poses and flags, then the launches
@@ -1058,6 +1075,9 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
             d.rematch = s.c.rematch;
             d.pose = pose_of(xk(i));
             d.seq = s.seq = ++e->seq;
+            const bool lost = e->wait.withhold(kStallReduce);  // (fault injection: this scan's block never reaches the host)
+            d.host_block = lost ? nullptr : e->h_block_dev;
+            d.host_flag = lost ? nullptr : reinterpret_cast<unsigned long long *>(e->h_block_dev + S2M_BLOCK_DOUBLES);
             any_rematch = any_rematch || s.c.rematch;
             any_plain = any_plain || !s.c.rematch;
             s.waiting = true;
@@ -1087,7 +1107,8 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
         if (rc) return rc;
     }
     int groups_left = ng;
-    long idle_spins = 0;
+    IdleWait idle(&e0->wait);
+    e0->step = "the blocks of a batch (one grid per pass)";
     while (groups_left > 0) {
         bool progress = false;
         for (int g = 0; g < ng; ++g) {
@@ -1130,11 +1151,14 @@ int batch_fused(s2m_engine *const *handles, int32_t k, double *x, const double *
                 }
             }
         }
-        if (progress) { idle_spins = 0; continue; }
-        __builtin_ia32_pause();
-        if (++idle_spins > 200000000L) {  // a kernel failed: let the runtime say which
-            for (int g = 0; g < ng; ++g) S2M_HIP(groups[g].lead, hipStreamSynchronize(groups[g].lead->stream));
-            return fail(handles[0], S2M_ERR_HIP, "s2m_iterated_update_batch: a pass did not publish its block");
+        if (progress) { idle.progress(); continue; }
+        if (idle.idle()) {  // no block for a whole deadline: a runtime error is reported as such, anything else as the timeout it is
+            for (int g = 0; g < ng; ++g) {
+                const hipError_t q = hipStreamQuery(groups[g].lead->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(groups[g].lead, S2M_ERR_HIP, "s2m_iterated_update_batch: a pass failed", q);
+            }
+            wait_expired(&e0->wait, "the blocks of a batch of scans", idle.us);
+            return fail(e0, S2M_ERR_HIP, "s2m_iterated_update_batch: a pass did not publish its block", kWaitTimedOut);
         }
     }
     return S2M_OK;
@@ -1171,7 +1195,7 @@ int batch_fused_loop(s2m_engine *const *handles, int32_t k, double *x, const dou
     auto xpk = [&](int i) { return x_prop + (size_t)i * S2M_STATE_DOUBLES; };
     auto Pk = [&](int i) { return P + (size_t)i * S2M_DIM * S2M_DIM; };
     s2m_engine *e0 = handles[0];
-    S2M_HIP(e0, hipSetDevice(e0->device));
+    S2M_INNER(e0);
     for (int i = 0; i < k; ++i) {
         int rc = ensure_loop(handles[i]);
         if (rc) return rc;
@@ -1227,7 +1251,10 @@ int batch_fused_loop(s2m_engine *const *handles, int32_t k, double *x, const dou
             d.loop.record = e->h_rec_dev;
             e->nn_valid = false;
             reset_log(logs ? logs + G.first + j : nullptr, e->cfg.max_iter);
-            if (e != L && e->stream != L->stream) S2M_HIP(e, hipStreamSynchronize(e->stream));
+            if (e != L && e->stream != L->stream) {
+                int rc = sync_stream(e, e->stream, "a scan's own stream, before the group's launches");
+                if (rc) return rc;
+            }
         }
     }
     // A group's search kernels are enqueued in front of a pass only where some scan of the group is expected to search:
@@ -1292,7 +1319,10 @@ int batch_fused_loop(s2m_engine *const *handles, int32_t k, double *x, const dou
         for (int i = 0; i < k; ++i) {
             if (done[i]) continue;
             s2m_engine *e = handles[i];
-            int rc = loop_wait(e, e->loop_seq);
+            hipStream_t st = nullptr;
+            for (int g = 0; g < ng; ++g)
+                if (i >= groups[g].first && i < groups[g].first + groups[g].count) st = groups[g].lead->stream;
+            int rc = loop_wait(e, e->loop_seq, st);
             if (rc) return rc;
             const LoopRecord &rec = *e->h_rec;
             if (rec.finished) {

@@ -16,7 +16,7 @@ int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride, int64_t m, in
 {
     if (!e || m < 0 || stride < 3 || (m > 0 && !xyz)) return fail(e, S2M_ERR_ARG, "s2m_map_build: bad argument");
     if (m >= ((int64_t)1 << 31)) return fail(e, S2M_ERR_CAPACITY, "map too large (>= 2^31 points)");
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     const float *dev = nullptr;
     int rc = stage_cloud(e, xyz, stride, m, on_device, &dev);
     if (rc) return rc;
@@ -38,9 +38,11 @@ int s2m_map_share(s2m_engine *e, const s2m_engine *owner)
     if (!e || !owner || e == owner) return fail(e, S2M_ERR_ARG, "s2m_map_share: bad argument");
     if (!owner->map_ready) return fail(e, S2M_ERR_STATE, "s2m_map_share: the owner has no map");
     if (owner->device != e->device) return fail(e, S2M_ERR_ARG, "s2m_map_share: handles on different devices");
-    S2M_HIP(e, hipSetDevice(e->device));
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
-    S2M_HIP(e, hipStreamSynchronize(owner->stream));  // the owner's build has finished
+    S2M_ENTER(e);
+    int rc = sync_stream(e, e->stream, "the borrower's stream (s2m_map_share)");
+    if (rc) return rc;
+    rc = sync_stream(e, owner->stream, "the owner's stream (s2m_map_share)");  // the owner's build has finished
+    if (rc) return rc;
     {   // the counts of the owner's last merged update arrive lazily; several borrowers may ask at once
         s2m_engine *o = const_cast<s2m_engine *>(owner);
         std::lock_guard<std::mutex> lk(o->stats_mu);
@@ -159,7 +161,7 @@ int s2m_map_add(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int 
     if (downsample_on && !(downsample_size > 0.0f)) return fail(e, S2M_ERR_ARG, "s2m_map_add: downsample size must be > 0");
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
     if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     const float *dev = nullptr;
     int rc = stage_cloud(e, xyz, stride, n, on_device, &dev);
     if (rc) return rc;
@@ -180,7 +182,7 @@ int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *
     if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
     if (n_deleted) *n_deleted = 0;
     if (!delete_touches_map(e->grid, boxes, (int)n)) return S2M_OK;  // (the slab ahead of the sensor after a cube move)
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     bind_update(e);
     S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
     int64_t del = 0;
@@ -218,7 +220,7 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map: call s2m_map_build first");
     if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
     if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     const Pose pose = pose_of(state);
     float4 *la = nullptr, *lb = nullptr;
     int64_t na = 0, nb = 0;
@@ -290,7 +292,7 @@ int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity, int64_t *m)
     if (!xyz) return S2M_OK;
     if (capacity < e->grid.live) return fail(e, S2M_ERR_CAPACITY, "point buffer too small");
     if (e->grid.live == 0) return S2M_OK;
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     const int64_t floats = e->grid.live * 3;
     if (floats > e->stage_cap) {
         int rc = grow(e, &e->d_stage, floats);
@@ -301,9 +303,10 @@ int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity, int64_t *m)
     int rc = caller_index_table(e, &rank);
     if (rc) return rc;
     launch_map_to_xyz(e->grid.pts, rank, e->grid.m, e->d_stage, e->stream);  // caller order
+    rc = sync_stream(e, e->stream, "the map in caller order");  // (the copy into pageable memory would wait inside the runtime, without a deadline)
+    if (rc) return rc;
     S2M_HIP(e, hipMemcpyAsync(xyz, e->d_stage, (size_t)floats * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
-    return S2M_OK;
+    return sync_stream(e, e->stream, "the map's points on their way to the caller");
 }
 
 int s2m_map_size(const s2m_engine *e, int64_t *m)
@@ -346,7 +349,7 @@ int s2m_map_get_ids(s2m_engine *e, uint32_t *ids, int64_t capacity, int64_t *m)
     *m = e->grid.live;
     if (!ids || e->grid.live == 0) return S2M_OK;
     if (capacity < e->grid.live) return fail(e, S2M_ERR_CAPACITY, "id buffer too small");
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     if (e->grid.live > e->stage_cap) {
         int rc = grow(e, &e->d_stage, e->grid.live);
         if (rc) return rc;
@@ -356,9 +359,10 @@ int s2m_map_get_ids(s2m_engine *e, uint32_t *ids, int64_t capacity, int64_t *m)
     int rc = caller_index_table(e, &rank);
     if (rc) return rc;
     launch_ids_by_rank(e->grid.pidx, rank, e->grid.m, reinterpret_cast<uint32_t *>(e->d_stage), e->stream);
+    rc = sync_stream(e, e->stream, "the map's ids in caller order");
+    if (rc) return rc;
     S2M_HIP(e, hipMemcpyAsync(ids, e->d_stage, (size_t)e->grid.live * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
-    return S2M_OK;
+    return sync_stream(e, e->stream, "the map's ids on their way to the caller");
 }
 
 int s2m_map_get_changes(s2m_engine *e, uint64_t *token, float *added_xyz, uint32_t *added_ids, int64_t cap_added, int64_t *n_added,
@@ -367,7 +371,7 @@ int s2m_map_get_changes(s2m_engine *e, uint64_t *token, float *added_xyz, uint32
     if (!e || !token || !n_added || !n_removed || !resync) return fail(e, S2M_ERR_ARG, "null argument");
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map");
     if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     *n_added = 0; *n_removed = 0; *resync = 0;
     auto fresh = [&]() {
         e->log.on = true;
@@ -405,7 +409,8 @@ int s2m_map_get_changes(s2m_engine *e, uint64_t *token, float *added_xyz, uint32
     }
     if (v[1] > 0) S2M_HIP(e, hipMemcpyAsync(removed_ids, e->log.removed, (size_t)v[1] * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
     launch_log_reset(e->log, e->stream);
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    int rc = sync_stream(e, e->stream, "the map's changes on their way to the caller");
+    if (rc) return rc;
     for (uint32_t i = 0; i < v[0]; ++i) {
         const float *p = e->h_changes.data() + (size_t)i * 4;
         added_xyz[3 * (size_t)i] = p[0]; added_xyz[3 * (size_t)i + 1] = p[1]; added_xyz[3 * (size_t)i + 2] = p[2];
@@ -422,13 +427,14 @@ int s2m_map_get_order(s2m_engine *e, uint32_t *order, int64_t capacity, int64_t 
     *m = e->grid.m;
     if (!order || e->grid.m == 0) return S2M_OK;
     if (capacity < e->grid.m) return fail(e, S2M_ERR_CAPACITY, "order buffer too small");
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     const uint32_t *rank = nullptr;
     int rc = caller_index_table(e, &rank);
     if (rc) return rc;
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
-    S2M_HIP(e, hipMemcpy(order, rank, (size_t)e->grid.m * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    return S2M_OK;
+    rc = sync_stream(e, e->stream, "the map's order");
+    if (rc) return rc;
+    S2M_HIP(e, hipMemcpyAsync(order, rank, (size_t)e->grid.m * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    return sync_stream(e, e->stream, "the map's order on its way to the caller");
 }
 
 int s2m_map_grid(const s2m_engine *e, int32_t bricks[6])
@@ -543,7 +549,7 @@ int s2m_complete_neighbors(s2m_engine *e, int64_t *n_completed)
     if (n_completed) *n_completed = 0;
     if (!e) return S2M_ERR_ARG;
     if (!e->map_ready || !e->nn_valid) return fail(e, S2M_ERR_STATE, "no rematch pass yet");
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     if (e->n == 0 || e->grid.m == 0 || e->nn_complete) return S2M_OK;
     if (e->short_lists == 0) { e->nn_complete = true; return S2M_OK; }  // the last rematch pass counted them: none
     int rc = complete_lists(e, kK, 0, n_completed);

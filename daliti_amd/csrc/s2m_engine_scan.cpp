@@ -9,17 +9,17 @@ using namespace s2m_eng;
 extern "C" {
 
 namespace {
-void pf_drain(s2m_engine *e);  // the side thread (s2m_scan_prefetch_raw / s2m_scan_prepare_raw) is idle
-void pf_invalidate(s2m_engine *e);
+int pf_drain(s2m_engine *e);  // the side thread (s2m_scan_prefetch_raw / s2m_scan_prepare_raw) is idle
+int pf_invalidate(s2m_engine *e);
 
 int scan_reserve(s2m_engine *e, int64_t n)
 {
     if (n <= e->n_cap && e->n_cap > 0) return S2M_OK;
-    pf_drain(e);  // (a prepared scan was laid out for the old capacity: it is recognised as stale when it is picked up)
+    int rc = pf_drain(e);  // (a prepared scan was laid out for the old capacity: it is recognised as stale when it is picked up)
+    if (rc) return rc;
     // (an eighth more than asked: a stream's sweeps differ by a few hundred points, and a larger one must not re-allocate
     // fourteen arrays in the middle of a frame; an empty first scan still gets buffers)
     const int64_t cap = ((std::max<int64_t>(n + n / 8, 1) + 255) / 256) * 256;
-    int rc = 0;
     rc = rc ? rc : grow(e, &e->d_scan, 3 * cap);
     rc = rc ? rc : grow(e, &e->d_plane, cap);
     rc = rc ? rc : grow(e, &e->d_flags, cap);
@@ -43,6 +43,7 @@ int scan_reserve(s2m_engine *e, int64_t n)
 int scan_reset(s2m_engine *e, int64_t n, bool wait = true)
 {
     launch_scan_reset(n, e->d_sel, e->d_eff, e->d_flags, e->stream);
+    e->step = "the scan's hand-over";
     if (wait) S2M_HIP(e, mail_wait(e->mail, e->stream));  // the host buffer may be reused by the caller now
     e->n = n;
     e->scan_ready = true;
@@ -56,9 +57,10 @@ int s2m_scan_set(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int
 {
     if (!e || n < 0 || stride < 3 || (n > 0 && !xyz)) return fail(e, S2M_ERR_ARG, "s2m_scan_set: bad argument");
     if (n > (int64_t)1 << 28) return fail(e, S2M_ERR_CAPACITY, "scan too large");
-    S2M_HIP(e, hipSetDevice(e->device));
-    pf_invalidate(e);  // whatever the side thread holds was meant for a sweep that is not coming by this road
-    int rc = scan_reserve(e, n);
+    S2M_ENTER(e);
+    int rc = pf_invalidate(e);  // whatever the side thread holds was meant for a sweep that is not coming by this road
+    if (rc) return rc;
+    rc = scan_reserve(e, n);
     if (rc) return rc;
     const float *dev = nullptr;
     rc = stage_cloud(e, xyz, stride, n, on_device, &dev);
@@ -72,9 +74,10 @@ int s2m_scan_set_downsampled(s2m_engine *e, const float *xyz, int64_t stride, in
 {
     if (!e || n < 0 || stride < 3 || (n > 0 && !xyz) || !(leaf > 0.0f)) return fail(e, S2M_ERR_ARG, "s2m_scan_set_downsampled: bad argument");
     if (n > (int64_t)1 << 28) return fail(e, S2M_ERR_CAPACITY, "scan too large");
-    S2M_HIP(e, hipSetDevice(e->device));
-    pf_invalidate(e);  // the voxel-grid buffers are shared with the side thread; what it holds is stale
-    int rc = scan_reserve(e, n);  // the output cannot be larger than the input
+    S2M_ENTER(e);
+    int rc = pf_invalidate(e);  // the voxel-grid buffers are shared with the side thread; what it holds is stale
+    if (rc) return rc;
+    rc = scan_reserve(e, n);  // the output cannot be larger than the input
     if (rc) return rc;
     const float *dev = nullptr;
     rc = stage_cloud(e, xyz, stride, n, on_device, &dev);
@@ -109,8 +112,9 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride, int64_t n,
     if (rc) return rc;
     if (n > 0 && !out_xyz) return fail(e, S2M_ERR_ARG, "undistort: null output");
     if (n == 0) return S2M_OK;
-    S2M_HIP(e, hipSetDevice(e->device));
-    pf_drain(e);  // the undistortion buffers are shared with the side thread
+    S2M_ENTER(e);
+    rc = pf_drain(e);  // the undistortion buffers are shared with the side thread
+    if (rc) return rc;
     e->pf.ordered = false;  // (a time order the side thread left there is about to be overwritten)
     const float *dev = nullptr;
     // stage whole records (the time fields may sit anywhere in the record)
@@ -143,7 +147,7 @@ int s2m_undistort(s2m_engine *e, const float *points, int64_t stride, int64_t n,
         he = hipMemcpyAsync(out_xyz, e->und.out, (size_t)n * 3 * sizeof(float),
                             on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess && perm) he = hipMemcpyAsync(perm, d_perm, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream);
-    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he == hipSuccess) he = wait_stream(&e->wait, e->stream, "the undistorted points on their way to the caller");
     if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "undistort", he);
     return S2M_OK;
 }
@@ -157,6 +161,11 @@ void prefetch_worker(s2m_engine *e)
 {
     auto &p = e->pf;
     (void)hipSetDevice(e->device);
+    tl_wait = &e->wait;  // this thread's waits (the voxel grid's and the time sort's hand-backs) end at the handle's deadline too
+    struct Exited {
+        std::atomic<int> &f;
+        ~Exited() { f.store(1, std::memory_order_release); }
+    } exited{p.exited};
     std::unique_lock<std::mutex> lk(p.mu);
     for (;;) {
         if (!(p.quit || p.busy)) {  // the next job usually follows within a frame: poll for it before going to sleep
@@ -164,12 +173,19 @@ void prefetch_worker(s2m_engine *e)
             for (int spin = 0; spin < 20000 && p.busy_a.load(std::memory_order_acquire) == 0; ++spin) __builtin_ia32_pause();
             lk.lock();
         }
-        p.cv.wait(lk, [&] { return p.quit || p.busy; });
+        p.cv.wait(lk, [&] { return p.quit || p.busy; });  // (idle: the only wait of the handle without a deadline)
         if (p.quit) return;
         const float *src = p.src;
         const int64_t floats = p.floats;
         const bool prepare = p.prepare;
         lk.unlock();
+        if (e->wait.withhold(kStallWorker)) {  // fault injection: this job is never finished (the thread still leaves when told to)
+            while (p.quit_a.load(std::memory_order_acquire) == 0) {
+                struct timespec ts = {0, 1000000L};
+                nanosleep(&ts, nullptr);
+            }
+            return;
+        }
         hipError_t he = p.copied ? hipSuccess
                                  : hipMemcpyAsync(p.d_buf, src, (size_t)floats * sizeof(float), hipMemcpyHostToDevice, p.stream);
         int64_t m = p.n;
@@ -212,37 +228,52 @@ void prefetch_worker(s2m_engine *e)
 // the side thread is idle AND whatever its last job enqueued on the side stream is ordered in front of everything the
 // caller enqueues on the main stream from here on: the undistortion / voxel-grid scratch (e->und, e->vox) is shared by the
 // two streams, so a caller that goes on to sort in it must not overtake a job's kernels that are still running
-void pf_drain(s2m_engine *e)
+int pf_drain(s2m_engine *e)
 {
-    if (!e->pf.worker.joinable()) return;
-    for (int spin = 0; spin < 40000 && e->pf.busy_a.load(std::memory_order_acquire) != 0; ++spin) __builtin_ia32_pause();
-    std::unique_lock<std::mutex> lk(e->pf.mu);
-    e->pf.cv.wait(lk, [&] { return !e->pf.busy; });
-    if (e->pf.gpu_pending && e->pf.done) {
-        (void)hipStreamWaitEvent(e->stream, e->pf.done, 0);
-        e->pf.gpu_pending = false;
+    auto &p = e->pf;
+    if (!p.worker.joinable()) return S2M_OK;
+    // (busy_a mirrors `busy`, both written under the mutex: polled under the handle's wait policy and deadline -- a job is a
+    // copy and a dozen launches; a side thread that does not come back is stuck in the runtime or behind a dead device, and
+    // the caller must hear of it)
+    if (p.busy_a.load(std::memory_order_acquire) != 0) {
+        e->step = "the side thread's job";
+        if (!wait_until(&e->wait, [&] { return p.busy_a.load(std::memory_order_acquire) == 0; },
+                        "the handle's side thread to finish its job (copy, undistortion, voxel grid of the next sweep)"))
+            return fail(e, S2M_ERR_HIP, "pf_drain", kWaitTimedOut);
     }
+    std::unique_lock<std::mutex> lk(p.mu);  // (orders this thread behind the job's last writes)
+    if (p.busy) return fail(e, S2M_ERR_STATE, "pf_drain: the side thread took a job nobody gave it");
+    if (p.err == kWaitTimedOut) return fail(e, S2M_ERR_HIP, "the side thread's job", kWaitTimedOut);  // a wait of the side thread itself expired
+    if (p.gpu_pending && p.done) {
+        (void)hipStreamWaitEvent(e->stream, p.done, 0);
+        p.gpu_pending = false;
+    }
+    return S2M_OK;
 }
 // a scan arrives by another road than the one the side thread prepared for: what it holds is stale (a node that recycles
 // its host buffers may present NEW records at the address and size of a sweep that was prefetched and then dropped)
-void pf_invalidate(s2m_engine *e)
+int pf_invalidate(s2m_engine *e)
 {
-    pf_drain(e);
+    int rc = pf_drain(e);
+    if (rc) return rc;
     e->pf.ready = false;
     e->pf.prepared = false;
     e->pf.ordered = false;
+    return S2M_OK;
 }
 
 int pf_start(s2m_engine *e, const float *points, int64_t floats)
 {
     auto &p = e->pf;
-    pf_drain(e);
+    int rc = pf_drain(e);
+    if (rc) return rc;
     p.ready = false;
     p.prepared = false;
     if (!p.stream) S2M_HIP(e, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
     if (!p.done) S2M_HIP(e, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     if (floats > p.cap) {
-        S2M_HIP(e, hipStreamSynchronize(p.stream));
+        rc = sync_stream(e, p.stream, "the side stream, before its buffer is reallocated");
+        if (rc) return rc;
         if (p.d_buf) S2M_HIP(e, hipFree(p.d_buf));
         p.d_buf = nullptr;
         // (an eighth more than asked: sweeps differ by a few hundred returns, and a reallocation -- a device-wide stall of
@@ -262,12 +293,13 @@ int s2m_scan_prefetch_raw(s2m_engine *e, const float *points, int64_t stride, in
 {
     if (!e) return S2M_ERR_ARG;
     if (!points) {  // cancel: the sweep that was announced is not coming (dropped, skipped): forget its copy
-        pf_invalidate(e);
-        return S2M_OK;
+        if (e->poisoned) return refuse_poisoned(e);
+        tl_wait = &e->wait;
+        return pf_invalidate(e);
     }
     if (n < 0 || stride < 3 || oa >= stride || ob >= stride) return fail(e, S2M_ERR_ARG, "s2m_scan_prefetch_raw: bad argument");
     if (n == 0) return S2M_OK;
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     int rc = pf_start(e, points, n * stride);
     if (rc) return rc;
     {
@@ -291,11 +323,12 @@ int s2m_scan_prepare_raw(s2m_engine *e, const float *points, int64_t stride, int
     int rc = check_undistort_args(e, points, stride, n, oa, ob, poses, np, state_end);
     if (rc) return rc;
     if (n == 0) return S2M_OK;
-    S2M_HIP(e, hipSetDevice(e->device));
+    S2M_ENTER(e);
     // the prepared scan must fit the arrays of the current one (they are swapped, not copied); a first or larger sweep is
     // left to the synchronous call
     if (e->n_cap < n) return S2M_OK;
-    pf_drain(e);
+    rc = pf_drain(e);
+    if (rc) return rc;
     // the records may be on the device already: s2m_scan_prefetch_raw at the start of the frame, this call once the poses exist
     const bool have = e->pf.ready && e->pf.src == points && e->pf.floats == n * stride;
     const bool have_order = have && e->pf.ordered;
@@ -330,8 +363,9 @@ int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, in
 {
     int rc = check_undistort_args(e, points, stride, n, oa, ob, poses, np, state_end);
     if (rc) return rc;
-    S2M_HIP(e, hipSetDevice(e->device));
-    pf_drain(e);
+    S2M_ENTER(e);
+    rc = pf_drain(e);
+    if (rc) return rc;
     if (n > 0 && !on_device && e->pf.prepared) {  // has s2m_scan_prepare_raw done exactly this call already?
         auto &p = e->pf;
         const bool same = p.src == points && p.stride == stride && p.n == n && p.oa == oa && p.ob == ob && p.leaf == leaf &&
@@ -353,8 +387,7 @@ int s2m_scan_set_from_raw(s2m_engine *e, const float *points, int64_t stride, in
         if (!on_device && e->pf.worker.joinable()) {  // has s2m_scan_prefetch_raw brought exactly these records over already?
             auto &p = e->pf;
             std::unique_lock<std::mutex> lk(p.mu);
-            if (p.src == points && p.floats == n * stride && (p.busy || p.ready)) {
-                p.cv.wait(lk, [&] { return !p.busy; });
+            if (p.src == points && p.floats == n * stride && !p.busy) {  // (pf_drain above: the side thread is idle)
                 if (p.ready) {
                     p.ready = false;  // consumed
                     order_ready = p.ordered && p.order_oa == oa && p.order_ob == ob;
@@ -405,8 +438,9 @@ int s2m_scan_get(s2m_engine *e, float *xyz, int64_t capacity, int64_t *n)
     *n = e->n;
     if (!xyz || e->n == 0) return S2M_OK;
     if (capacity < e->n) return fail(e, S2M_ERR_CAPACITY, "scan buffer too small");
-    S2M_HIP(e, hipSetDevice(e->device));
-    S2M_HIP(e, hipStreamSynchronize(e->stream));
+    S2M_ENTER(e);
+    int rc = sync_stream(e, e->stream, "the stream, before the scan is copied out");
+    if (rc) return rc;
     // three strided copies SoA -> packed AoS
     for (int k = 0; k < 3; ++k)
         S2M_HIP(e, hipMemcpy2D(xyz + k, 3 * sizeof(float), e->d_scan + k * e->n_cap, sizeof(float), sizeof(float),

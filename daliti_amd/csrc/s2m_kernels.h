@@ -3,8 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "s2m_device.h"
 #include "s2m_loop.h"
+#include "s2m_wait.h"
 
 namespace s2m {
 
@@ -19,7 +22,8 @@ struct Mailbox {
 constexpr int kMailSlots = 16;
 void free_mailbox(Mailbox &mb);
 // out[i] = *src[i] for i < k (k <= kMailSlots); returns when the kernel -- and with it everything queued on the
-// stream before it -- has finished (the host polls the pinned sequence word instead of synchronising the stream)
+// stream before it -- has finished (the host polls the pinned sequence word instead of synchronising the stream), or
+// kWaitTimedOut when the handle's deadline passes first
 hipError_t mail_fetch(Mailbox &mb, const uint32_t *const *src, int k, uint32_t *out, hipStream_t st);
 // the same wait without a payload: returns when everything queued on the stream has finished
 hipError_t mail_post(Mailbox &mb, const uint32_t *const *src, int k, hipStream_t st);   // the two halves of mail_fetch
@@ -231,22 +235,36 @@ void launch_map_to_xyz(const float4 *pts, const uint32_t *rank, int64_t m, float
 // rank[position] = dense caller index of every live position (cold path: a sort of the ids), 0xffffffff for a removed one
 hipError_t caller_ranks(UpdateBuffers &u, const Grid &g, const uint8_t *alive_s, const uint32_t **rank, int64_t *live, hipStream_t st);
 // ---- the change log (s2m_map_get_changes): what the updates since the last report added and removed, by point id ----------
+constexpr int kLogMarks = 8;                      // box deletes a log can hold between two reports (each one: up to kLogBoxesPer boxes)
+constexpr int kLogBoxesPer = 8;
+constexpr int kLogWords = 4 + 2 * kLogMarks;      // [0] added, [1] removed, [2] overflow, [3] marks, then {added, removed} at every mark
 struct ChangeLog {
     float4 *added = nullptr;      // {x, y, z, bitcast(id)} of every point added
-    uint32_t *removed = nullptr;  // ids of the points removed
-    uint32_t *counts = nullptr;   // device: [0] added, [1] removed, [2] overflow
+    float4 *removed = nullptr;    // ... and of every point removed one by one (the voxel rule; not the box deletes)
+    uint32_t *counts = nullptr;   // device: kLogWords words
+    // the report on its way to the follower, in pinned host memory the flush kernels write: [0] sequence word, then `counts`
+    uint32_t *h_head = nullptr, *h_head_dev = nullptr;
+    float4 *h_added = nullptr, *h_added_dev = nullptr, *h_removed = nullptr, *h_removed_dev = nullptr;
+    uint32_t flush_seq = 0;
+    bool posted = false;          // a flush is on its way (or has landed) and has not been handed to the follower
+    bool landed = false;          // ... it has been waited for: h_head / h_added / h_removed hold it
+    std::vector<float> boxes_log, boxes_posted;      // the box deletes since the last post / of the posted report: 6 floats per box ...
+    std::vector<int32_t> boxes_per_log, boxes_per_posted;  // ... and how many boxes each marked delete had
     int64_t cap = 0;
     bool on = false;              // somebody follows the map (the first s2m_map_get_changes switches it on)
     uint64_t token = 0;           // the map state of the last report; 0: none yet
 };
 void free_changelog(ChangeLog &c);
 hipError_t changelog_ensure(ChangeLog &c, int64_t cap, hipStream_t st);
-// ids of the points this update removes (alive_s == 0 where a point was), found through the bricks the update marked as
+// the points this update removes one by one (alive_s == 0 where a point was), found through the bricks the update marked as
 // touched by a removal: cost proportional to the change.  Runs before the map is rewritten.
 void launch_log_removed(ChangeLog &c, const uint32_t *bricks_dev, int64_t bricks_bound, const uint8_t *bmark, const uint32_t *tab,
-                        const uint8_t *alive_s, const uint32_t *pidx, hipStream_t st);
+                        const uint8_t *alive_s, const uint32_t *pidx, const float4 *pts, hipStream_t st);
 void launch_log_added(ChangeLog &c, const float4 *stage, int64_t n, uint32_t first_id, hipStream_t st);
 void launch_log_reset(ChangeLog &c, hipStream_t st);
+void launch_log_mark(ChangeLog &c, hipStream_t st);  // a box delete takes its place in the sequence
+void changelog_post(ChangeLog &c, hipStream_t st);
+hipError_t changelog_collect(ChangeLog &c, hipStream_t st);
 // ids in caller order: ids[rank[j]] = pidx[j]
 void launch_ids_by_rank(const uint32_t *pidx, const uint32_t *rank, int64_t m, uint32_t *ids, hipStream_t st);
 // caller indices of a neighbour list: out[i] = nn[i] >= 0 ? pidx[nn[i]] : -1

@@ -370,7 +370,7 @@ hipError_t map_grow_scratch(MapBuffers &buf, int64_t need, int64_t keys_in_use, 
     void **ps[] = {(void **)&buf.keys, (void **)&buf.keys_alt, (void **)&buf.vals, (void **)&buf.vals_alt,
                    (void **)&buf.work_a, (void **)&buf.work_b, (void **)&buf.work_c};
     const size_t es[] = {8, 8, 4, 4, 4, 4, 4};
-    S2M_TRY(hipStreamSynchronize(st));  // (kernels in flight may still read the arrays about to be freed)
+    S2M_TRY(wait_stream(nullptr, st, "the stream, before the map's scratch arrays are reallocated"));  // (kernels in flight may still read them)
     for (int k = 0; k < 7; ++k) {
         int64_t c = 0;
         if (*ps[k]) { S2M_TRY(hipFree(*ps[k])); *ps[k] = nullptr; }
@@ -378,7 +378,7 @@ hipError_t map_grow_scratch(MapBuffers &buf, int64_t need, int64_t keys_in_use, 
     }
     if (old_sorted) {
         if (keys_in_use > 0) S2M_TRY(hipMemcpyAsync(buf.keys_alt, old_sorted, (size_t)keys_in_use * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-        S2M_TRY(hipStreamSynchronize(st));
+        S2M_TRY(wait_stream(nullptr, st, "the copy of the sorted keys into the grown scratch"));
         S2M_TRY(hipFree(old_sorted));
     }
     buf.scratch_cap = cap;
@@ -409,7 +409,7 @@ __global__ void stats_mail_kernel(const uint32_t *__restrict__ bricks, const uin
 hipError_t resolve_stats(MapBuffers &buf, MapStats &stats)
 {
     if (!buf.stats_pending) return hipSuccess;
-    S2M_TRY(hipEventSynchronize(buf.stats_event));
+    S2M_TRY(wait_event(nullptr, buf.stats_event, "the counts of the last merge"));
     buf.stats_pending = false;
     int64_t cells = 0;
     for (int k = 0; k < kOccShards; ++k) cells += buf.h_stats[1 + k];
@@ -625,7 +625,7 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     g.top = buf.top; g.tab = buf.tab; g.pts = buf.pts; g.pidx = buf.pidx;
     if (m == 0) {
         S2M_TRY(hipMemsetAsync(buf.top, 0, (size_t)(top_slots(g) + 1) * sizeof(uint4), st));
-        return hipStreamSynchronize(st);
+        return wait_stream(nullptr, st, "the build of an empty map");
     }
 
     const int blocks = (int)((m + 255) / 256);

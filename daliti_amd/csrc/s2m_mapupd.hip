@@ -615,22 +615,28 @@ void free_mailbox(Mailbox &mb)
     mb = Mailbox();
 }
 
+static hipError_t mail_ensure(Mailbox &mb)
+{
+    if (mb.h) return hipSuccess;
+    S2M_TRY(hipHostMalloc((void **)&mb.h, 64 * sizeof(uint32_t), hipHostMallocMapped));
+    S2M_TRY(hipHostGetDevicePointer((void **)&mb.dev, mb.h, 0));
+    mb.h[0] = 0u;
+    mb.seq = 0u;
+    return hipSuccess;
+}
+
 // a hand-back in two halves: mail_post enqueues the kernel that copies the words and raises the sequence number,
 // mail_collect waits for it -- whatever the caller enqueues in between runs while the words travel
 hipError_t mail_post(Mailbox &mb, const uint32_t *const *src, int k, hipStream_t st)
 {
     if (k <= 0 || k > kMailSlots) return hipErrorInvalidValue;
-    if (!mb.h) {
-        S2M_TRY(hipHostMalloc((void **)&mb.h, 64 * sizeof(uint32_t), hipHostMallocMapped));
-        S2M_TRY(hipHostGetDevicePointer((void **)&mb.dev, mb.h, 0));
-        mb.h[0] = 0u;
-        mb.seq = 0u;
-    }
+    S2M_TRY(mail_ensure(mb));
     MailArgs a;
     for (int i = 0; i < kMailSlots; ++i) a.src[i] = src[i < k ? i : 0];
     a.k = k;
     if (++mb.seq == 0u) mb.seq = 1u;
     a.seq = mb.seq;
+    if (cur_wait()->withhold(kStallMail)) return hipSuccess;  // (fault injection: this hand-back never leaves)
     hipLaunchKernelGGL(mail_kernel, dim3(1), dim3(64), 0, st, a, mb.dev);
     return hipSuccess;
 }
@@ -638,26 +644,9 @@ hipError_t mail_post(Mailbox &mb, const uint32_t *const *src, int k, hipStream_t
 hipError_t mail_collect(Mailbox &mb, int k, uint32_t *out, hipStream_t st)
 {
     // When the kernel's sequence number shows up in pinned memory everything enqueued before it has finished.  Polling it
-    // costs 2-3 us after the kernel ends; hipStreamSynchronize costs 10-20 us.
-    volatile uint32_t *flag = mb.h;
-    const uint32_t seq = mb.seq;
-    bool seen = false;
-    static const bool hosttime = std::getenv("S2M_HOSTTIME") != nullptr;  // (diagnostic: how long the host waits for the device)
-    const auto t0 = hosttime ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-    for (long spin = 0; spin < 20000000L; ++spin) {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { seen = true; break; }
-        __builtin_ia32_pause();
-    }
-    if (hosttime) {
-        static double total_us = 0.0;
-        static long calls = 0;
-        total_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        if (++calls % 2000 == 0) std::fprintf(stderr, "[hosttime] %ld hand-backs, %.1f us waited on average\n", calls, total_us / calls);
-    }
-    if (!seen) {  // slow or failed: let the runtime tell us
-        S2M_TRY(hipStreamSynchronize(st));
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return hipErrorUnknown;
-    }
+    // costs 2-3 us after the kernel ends; hipStreamSynchronize costs 10-20 us.  The wait follows the handle's policy and
+    // ends at its deadline (s2m_wait.h).
+    S2M_TRY(wait_word(nullptr, (const volatile uint32_t *)mb.h, mb.seq, st, "a hand-back of device words (mailbox)"));
     for (int i = 0; i < k; ++i) out[i] = mb.h[1 + i];
     return hipSuccess;
 }
@@ -670,12 +659,7 @@ hipError_t mail_fetch(Mailbox &mb, const uint32_t *const *src, int k, uint32_t *
 
 hipError_t mail_wait(Mailbox &mb, hipStream_t st)
 {
-    if (!mb.h) {  // allocate through the common path; the fetched word is the mailbox's own sequence word
-        S2M_TRY(hipHostMalloc((void **)&mb.h, 64 * sizeof(uint32_t), hipHostMallocMapped));
-        S2M_TRY(hipHostGetDevicePointer((void **)&mb.dev, mb.h, 0));
-        mb.h[0] = 0u;
-        mb.seq = 0u;
-    }
+    S2M_TRY(mail_ensure(mb));  // the fetched word is the mailbox's own sequence word
     const uint32_t *src[1] = {mb.dev};
     uint32_t v = 0;
     return mail_fetch(mb, src, 1, &v, st);
@@ -694,7 +678,7 @@ static hipError_t grow(T **p, int64_t *cap, int64_t need, bool keep = false, hip
     if (*p) {
         if (keep && *cap > 0) {
             S2M_TRY(hipMemcpyAsync(q, *p, (size_t)*cap * sizeof(T), hipMemcpyDeviceToDevice, st));
-            S2M_TRY(hipStreamSynchronize(st));
+            S2M_TRY(wait_stream(nullptr, st, "the copy into a grown update buffer"));
         }
         S2M_TRY(hipFree(*p));
     }
@@ -1167,13 +1151,16 @@ void launch_positions_to_indices(const int32_t *nn, const uint32_t *pidx, int64_
 
 // ---- the change log ---------------------------------------------------------------------------------------------------
 // The reference flattens and publishes the whole map every frame (laserMapping.cpp:1170-1175, 1229-1235); a node that follows
-// this engine's map keeps a mirror keyed by point id and asks for what changed (s2m_map_get_changes).  Removed ids come from
+// this engine's map keeps a mirror and asks for what changed (s2m_map_get_changes).  Removed points come from
 // the bricks the update's verdict kernels marked (bit 0 of bmark: a point of the brick was removed): one wave per brick id,
-// the marked ones walk their stretch -- the plan kernel of the in-place update does the same walk.
+// the marked ones walk their stretch -- the plan kernel of the in-place update does the same walk.  A removed point is logged
+// with its coordinates (the follower finds it by place, then by id).  Box deletes (the field-of-view trim: millions of points)
+// are not logged point by point at all: the boxes themselves are the entry, with the log's two counts at that moment
+// (log_mark_kernel) so that the follower applies them in sequence with the other entries.
 __global__ __launch_bounds__(256) void log_removed_kernel(const uint32_t *__restrict__ bricks_dev, const uint8_t *__restrict__ bmark,
                                                           const uint32_t *__restrict__ tab, const uint8_t *__restrict__ alive_s,
-                                                          const uint32_t *__restrict__ pidx, uint32_t *__restrict__ removed,
-                                                          uint32_t *__restrict__ counts, uint32_t cap)
+                                                          const uint32_t *__restrict__ pidx, const float4 *__restrict__ pts,
+                                                          float4 *__restrict__ removed, uint32_t *__restrict__ counts, uint32_t cap)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t id = (int64_t)blockIdx.x * 4 + wave;
@@ -1190,8 +1177,12 @@ __global__ __launch_bounds__(256) void log_removed_kernel(const uint32_t *__rest
         at = __shfl(at, 0, 64);
         const uint32_t mine = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         if (gone) {
-            if (mine < cap) removed[mine] = pid;
-            else counts[2] = 1u;
+            if (mine < cap) {
+                const float4 p = pts[j];
+                removed[mine] = make_float4(p.x, p.y, map_point_z(p), __uint_as_float(pid));
+            } else {
+                counts[2] = 1u;
+            }
         }
     }
 }
@@ -1211,8 +1202,44 @@ __global__ __launch_bounds__(256) void log_added_kernel(const float4 *__restrict
 }
 __global__ void log_count_kernel(uint32_t *counts, uint32_t add_n, int reset)
 {
-    if (reset) { counts[0] = 0u; counts[1] = 0u; counts[2] = 0u; }
+    if (reset) { counts[0] = 0u; counts[1] = 0u; counts[2] = 0u; counts[3] = 0u; }
     else counts[0] += add_n;
+}
+// a box delete at this point of the log: the counts as they stand are its place in the sequence
+__global__ void log_mark_kernel(uint32_t *counts)
+{
+    const uint32_t k = counts[3];
+    if (k < (uint32_t)kLogMarks) {
+        counts[4 + 2 * k] = counts[0];
+        counts[5 + 2 * k] = counts[1];
+        counts[3] = k + 1u;
+    } else {
+        counts[2] = 1u;
+    }
+}
+// The log on its way to the follower: the entries into pinned host memory (a fixed grid strides over them), then -- a second
+// launch, one workgroup -- the header (counts, marks), the sequence word the host polls for, and the log is empty again.
+__global__ __launch_bounds__(256) void log_flush_kernel(const float4 *__restrict__ added, const float4 *__restrict__ removed,
+                                                        const uint32_t *__restrict__ counts, uint32_t cap, float4 *__restrict__ h_added,
+                                                        float4 *__restrict__ h_removed)
+{
+    if (counts[2] != 0u) return;  // overflow: the follower will fetch the whole map
+    const uint32_t na = counts[0] < cap ? counts[0] : cap, nr = counts[1] < cap ? counts[1] : cap;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < na; i += stride) h_added[i] = added[i];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += stride) h_removed[i] = removed[i];
+}
+__global__ void log_seal_kernel(uint32_t *counts, uint32_t *__restrict__ h_head, uint32_t seq)
+{
+    const int i = threadIdx.x;
+    if (i < 4 + 2 * kLogMarks) __hip_atomic_store(h_head + 1 + i, counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (i == 0) {
+        __hip_atomic_store(h_head, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        counts[0] = 0u; counts[1] = 0u; counts[2] = 0u; counts[3] = 0u;
+    }
 }
 __global__ __launch_bounds__(256) void ids_by_rank_kernel(const uint32_t *__restrict__ pidx, const uint32_t *__restrict__ rank, int64_t m,
                                                           uint32_t *__restrict__ ids)
@@ -1226,6 +1253,9 @@ void free_changelog(ChangeLog &c)
     if (c.added) (void)hipFree(c.added);
     if (c.removed) (void)hipFree(c.removed);
     if (c.counts) (void)hipFree(c.counts);
+    if (c.h_head) (void)hipHostFree(c.h_head);
+    if (c.h_added) (void)hipHostFree(c.h_added);
+    if (c.h_removed) (void)hipHostFree(c.h_removed);
     c = ChangeLog();
 }
 hipError_t changelog_ensure(ChangeLog &c, int64_t cap, hipStream_t st)
@@ -1233,18 +1263,27 @@ hipError_t changelog_ensure(ChangeLog &c, int64_t cap, hipStream_t st)
     if (c.cap >= cap && c.added) return hipSuccess;
     free_changelog(c);
     S2M_TRY(hipMalloc((void **)&c.added, (size_t)cap * sizeof(float4)));
-    S2M_TRY(hipMalloc((void **)&c.removed, (size_t)cap * sizeof(uint32_t)));
-    S2M_TRY(hipMalloc((void **)&c.counts, 4 * sizeof(uint32_t)));
-    S2M_TRY(hipMemsetAsync(c.counts, 0, 4 * sizeof(uint32_t), st));
+    S2M_TRY(hipMalloc((void **)&c.removed, (size_t)cap * sizeof(float4)));
+    S2M_TRY(hipMalloc((void **)&c.counts, kLogWords * sizeof(uint32_t)));
+    S2M_TRY(hipMemsetAsync(c.counts, 0, kLogWords * sizeof(uint32_t), st));
+    S2M_TRY(hipHostMalloc((void **)&c.h_head, 64 * sizeof(uint32_t), hipHostMallocMapped));
+    S2M_TRY(hipHostGetDevicePointer((void **)&c.h_head_dev, c.h_head, 0));
+    S2M_TRY(hipHostMalloc((void **)&c.h_added, (size_t)cap * sizeof(float4), hipHostMallocMapped));
+    S2M_TRY(hipHostGetDevicePointer((void **)&c.h_added_dev, c.h_added, 0));
+    S2M_TRY(hipHostMalloc((void **)&c.h_removed, (size_t)cap * sizeof(float4), hipHostMallocMapped));
+    S2M_TRY(hipHostGetDevicePointer((void **)&c.h_removed_dev, c.h_removed, 0));
+    std::memset(c.h_head, 0, 64 * sizeof(uint32_t));
     c.cap = cap;
+    c.flush_seq = 0;
+    c.posted = false;
     return hipSuccess;
 }
 void launch_log_removed(ChangeLog &c, const uint32_t *bricks_dev, int64_t bricks_bound, const uint8_t *bmark, const uint32_t *tab,
-                        const uint8_t *alive_s, const uint32_t *pidx, hipStream_t st)
+                        const uint8_t *alive_s, const uint32_t *pidx, const float4 *pts, hipStream_t st)
 {
     if (bricks_bound > 0)
         hipLaunchKernelGGL(log_removed_kernel, dim3((unsigned)((bricks_bound + 3) / 4)), dim3(256), 0, st, bricks_dev, bmark, tab, alive_s, pidx,
-                           c.removed, c.counts, (uint32_t)c.cap);
+                           pts, c.removed, c.counts, (uint32_t)c.cap);
 }
 void launch_log_added(ChangeLog &c, const float4 *stage, int64_t n, uint32_t first_id, hipStream_t st)
 {
@@ -1253,6 +1292,23 @@ void launch_log_added(ChangeLog &c, const float4 *stage, int64_t n, uint32_t fir
     hipLaunchKernelGGL(log_count_kernel, dim3(1), dim3(1), 0, st, c.counts, (uint32_t)n, 0);
 }
 void launch_log_reset(ChangeLog &c, hipStream_t st) { hipLaunchKernelGGL(log_count_kernel, dim3(1), dim3(1), 0, st, c.counts, 0u, 1); }
+void launch_log_mark(ChangeLog &c, hipStream_t st) { hipLaunchKernelGGL(log_mark_kernel, dim3(1), dim3(1), 0, st, c.counts); }
+// post: the log leaves for pinned host memory and starts again empty; collect: wait for it (under the handle's wait policy and
+// deadline) -- whatever the caller enqueues or does in between runs while the entries travel
+void changelog_post(ChangeLog &c, hipStream_t st)
+{
+    if (++c.flush_seq == 0u) c.flush_seq = 1u;
+    hipLaunchKernelGGL(log_flush_kernel, dim3(32), dim3(256), 0, st, c.added, c.removed, c.counts, (uint32_t)c.cap, c.h_added_dev, c.h_removed_dev);
+    if (!cur_wait()->withhold(kStallMail))  // (fault injection: this hand-back never leaves)
+        hipLaunchKernelGGL(log_seal_kernel, dim3(1), dim3(64), 0, st, c.counts, c.h_head_dev, c.flush_seq);
+    c.posted = true;
+}
+hipError_t changelog_collect(ChangeLog &c, hipStream_t st)
+{
+    S2M_TRY(wait_word(nullptr, (const volatile uint32_t *)c.h_head, c.flush_seq, st, "the map's change log on its way to the host (a hand-back)"));
+    c.posted = false;
+    return hipSuccess;
+}
 void launch_ids_by_rank(const uint32_t *pidx, const uint32_t *rank, int64_t m, uint32_t *ids, hipStream_t st)
 {
     if (m > 0) hipLaunchKernelGGL(ids_by_rank_kernel, dim3(nblk(m)), dim3(256), 0, st, pidx, rank, m, ids);

@@ -18,7 +18,7 @@ MAX_LOG = 64
 # every symbol include/daliti_s2m.h declares
 ABI_SYMBOLS = [
     "s2m_abi_version", "s2m_config_default", "s2m_strerror", "s2m_create", "s2m_destroy",
-    "s2m_last_error", "s2m_set_config", "s2m_set_stream", "s2m_map_build", "s2m_map_size",
+    "s2m_last_error", "s2m_debug_state", "s2m_test_stall", "s2m_set_config", "s2m_set_stream", "s2m_map_build", "s2m_map_size",
     "s2m_map_info", "s2m_map_last_update", "s2m_map_share", "s2m_map_add", "s2m_map_delete_boxes", "s2m_map_incremental", "s2m_map_get_points",
     "s2m_fov_segment", "s2m_fov_reset",
     "s2m_scan_set", "s2m_scan_set_downsampled", "s2m_scan_get", "s2m_undistort", "s2m_scan_set_from_raw", "s2m_scan_prefetch_raw", "s2m_scan_prepare_raw", "s2m_residual_pass", "s2m_residual_pass_device", "s2m_get_rows",
@@ -41,7 +41,8 @@ class Config(C.Structure):
                 ("conv_rot_deg", C.c_double), ("conv_pos_cm", C.c_double),
                 ("extrinsic_est_en", C.c_int32), ("max_iter", C.c_int32),
                 ("feat_threshold", C.c_int32), ("cell_size", C.c_float), ("device", C.c_int32),
-                ("far_point_bet", C.c_int32), ("device_loop", C.c_int32)]
+                ("far_point_bet", C.c_int32), ("device_loop", C.c_int32), ("wait_policy", C.c_int32),
+                ("wait_timeout_ms", C.c_int32), ("wait_spin_us", C.c_int32)]
 
 
 class PassOut(C.Structure):
@@ -124,9 +125,12 @@ class Engine:
         self.n = 0
 
     def close(self):
+        """s2m_destroy; returns its code (0, or S2M_ERR_TIMEOUT when the device did not drain within the deadline)."""
+        rc = 0
         if getattr(self, "h", None):
-            self.lib.s2m_destroy(self.h)
+            rc = self.lib.s2m_destroy(self.h)
             self.h = None
+        return rc
 
     def __del__(self):
         try:
@@ -144,6 +148,18 @@ class Engine:
         for k, v in kw.items():
             setattr(self.cfg, k, v)
         self._ck(self.lib.s2m_set_config(self.h, C.byref(self.cfg)))
+
+    def debug_state(self):
+        """One line on what the handle is doing (s2m_debug_state): for watchdogs and error reports."""
+        buf = C.create_string_buffer(2048)
+        self._ck(self.lib.s2m_debug_state(self.h, buf, C.c_int64(len(buf))))
+        return buf.value.decode()
+
+    def test_stall(self, kind, after=0):
+        """Fault injection (tests): withhold the hand-backs of `kind` ('worker', 'mail', 'reduce'; None disarms) from the
+        `after`-th one on."""
+        k = {None: 0, "worker": 1, "mail": 2, "reduce": 3}[kind]
+        self._ck(self.lib.s2m_test_stall(self.h, C.c_int32(k), C.c_int64(after)))
 
     def set_stream(self, hip_stream):
         self._ck(self.lib.s2m_set_stream(self.h, C.c_void_p(hip_stream)))

@@ -34,8 +34,10 @@ extern "C" {
  * s2m_map_get_order, s2m_map_update_stats.  3 (round 4): s2m_config gained `device_loop`; new: s2m_bet_stats,
  * s2m_scan_prefetch_raw, s2m_scan_prepare_raw, s2m_map_inplace_updates; block[159] carries the count of neighbour lists
  * short of the gate; s2m_map_get_order may report positions that hold no point (0xffffffff).  A caller built against an
- * older version must be recompiled. */
-#define S2M_ABI_VERSION 4
+ * older version must be recompiled.  5 (round 6): s2m_config gained `wait_policy`, `wait_timeout_ms`, `wait_spin_us`; new code
+ * S2M_ERR_TIMEOUT; new: s2m_debug_state; s2m_map_get_changes reports the changes of the update BEFORE the last one when
+ * asked to (lag); s2m_map_update_stats writes 12 counters. */
+#define S2M_ABI_VERSION 5
 #define S2M_K 5            /* NUM_MATCH_POINTS, laserMapping.cpp:77 */
 #define S2M_DIM 24         /* DIM_OF_STATES, common_lib.h:23 */
 #define S2M_STATE_DOUBLES 36
@@ -49,7 +51,11 @@ enum {
     S2M_ERR_HIP = -3,        /* a HIP runtime call failed (see s2m_last_error)     */
     S2M_ERR_STATE = -4,      /* call order: no map / no scan / no pass yet         */
     S2M_ERR_CAPACITY = -5,   /* caller buffer too small, or grid too large         */
-    S2M_ERR_NUMERIC = -6     /* singular matrix in the Kalman update               */
+    S2M_ERR_NUMERIC = -6,    /* singular matrix in the Kalman update               */
+    S2M_ERR_TIMEOUT = -7     /* a wait for the device (or for the handle's side thread) passed s2m_config.wait_timeout_ms:
+                              * s2m_last_error names the wait and what the handle was doing.  What the device holds for this
+                              * handle is unknown from then on: every later compute call on it returns this code at once and
+                              * only s2m_destroy is served (the map can be rebuilt on a new handle from the node's mirror) */
 };
 
 typedef struct s2m_engine s2m_engine;
@@ -83,6 +89,15 @@ typedef struct {
                               * the slower one (C3 0.161 vs 0.145 ms/step, 22.8 k vs 25.9 k scans/s at 24 in flight:
                               * NOTEBOOK.md, round 4), hence opt-in.  Forms that sum blocks over ranks or handles
                               * (communicator, shared-memory exchange, _multi, _sharded) are always host-stepped. */
+    int32_t wait_policy;     /* how the calling thread waits for the device (several times per frame: the block of every pass,
+                              * the hand-backs of the map update).  0 (default) spin: poll with `pause` -- lowest latency, one
+                              * core busy for the duration of the call.  1 yield: poll for wait_spin_us, then sched_yield()
+                              * between polls.  2 sleep: poll for wait_spin_us, then nanosleep (50 us; 200 us after 5 ms)
+                              * between polls -- the core is free while the device works.  The reference's loop never blocks
+                              * on its map (laserMapping.cpp:726-731); a node whose CPU is busy wants 1 or 2.          */
+    int32_t wait_timeout_ms; /* deadline of every such wait (default 10000).  A wait that passes it returns
+                              * S2M_ERR_TIMEOUT; no entry point blocks for ever, whatever the device does.            */
+    int32_t wait_spin_us;    /* policies 1 and 2: how long a wait polls before it gives the core away (default 40)   */
 } s2m_config;
 
 int s2m_abi_version(void);
@@ -94,6 +109,17 @@ const char *s2m_strerror(int code);
 int s2m_create(const s2m_config *cfg, s2m_engine **out);
 int s2m_destroy(s2m_engine *e);
 const char *s2m_last_error(const s2m_engine *e);
+/* What the handle is doing, for a watchdog that sees no progress (design; callable from ANOTHER thread while the owner is
+ * inside an entry point -- it only reads): the entry point and step the owner is in, whether each of the handle's streams is
+ * idle, the side thread's job flags, every pinned hand-back word against the sequence number the host expects, the waits
+ * counted so far.  Writes a NUL-terminated line into buf (truncated to capacity). */
+int s2m_debug_state(const s2m_engine *e, char *buf, int64_t capacity);
+/* Fault injection for tests of the deadline path on a healthy device (design): from the `after`-th one on, the hand-backs of
+ * `kind` are withheld -- 1: the side thread never finishes its job (s2m_scan_prefetch_raw / s2m_scan_prepare_raw), 2: the
+ * kernel that hands device words to the host is not launched (map updates, voxel grid, scan hand-over), 3: the reduce kernel
+ * does not publish its block (every pass).  0 disarms.  The environment variable S2M_TEST_STALL=worker|mail|reduce[:after]
+ * arms the same hook when a handle is created (for callers that are not tests' own code, e.g. tools/replay_node). */
+int s2m_test_stall(s2m_engine *e, int32_t kind, int64_t after);
 /* Change gates between scans (e.g. feat_threshold, laserMapping.cpp:427-430). cell_size/device
  * are fixed at creation. */
 int s2m_set_config(s2m_engine *e, const s2m_config *cfg);

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_defaults(lib):
     from daliti_amd.engine import Config
-    assert lib.s2m_abi_version() == 4
+    assert lib.s2m_abi_version() == 5
     cfg = Config()
     assert lib.s2m_config_default(C.byref(cfg)) == 0
     # reference constants (laserMapping.cpp:76-77, 853, 863, 870, 889, 1040; feat.yaml)
@@ -48,7 +48,7 @@ def test_abi_version_and_defaults(lib):
 
 def test_struct_layouts_match_header(lib):
     from daliti_amd.engine import Config, PassOut, IterLog, DynShare
-    assert C.sizeof(Config) == 80
+    assert C.sizeof(Config) == 88
     assert C.sizeof(PassOut) == 144 * 8 + 12 * 8 + 8 + 8
     assert C.sizeof(IterLog) == 16 + 3 * 64 * 4 + 64 * 8 + 64 * 24 * 8
     assert C.sizeof(DynShare) == 48

@@ -33,7 +33,7 @@ def _oracle_pass(oracle, tree, scan, x, rematch, ps=None, ext=0):
 def test_library_is_native():
     from daliti_amd import library_path, load_library
     assert os.path.exists(library_path())
-    assert load_library().s2m_abi_version() == 4
+    assert load_library().s2m_abi_version() == 5
 
 
 def test_knn_exact(eng, oracle, small_scene):

@@ -177,8 +177,11 @@ int s2m_world_seed(const s2m_world *w, double span, int64_t m, float *xyz)
 }
 
 // A stall reporter for the frame loops: the loop leaves its frame and call numbers in two atomics, a side thread looks once a
-// second and says on stderr where the loop stands when nothing has moved for ten seconds (a frame takes well under a
-// millisecond; a stall seen once on a shared box left no trace of where it was).  Costs the loop two relaxed stores per call.
+// second and says on stderr where the loop stands -- and what the handle says it is doing (s2m_debug_state: streams, side
+// thread, every hand-back word against the number the host expects) -- when nothing has moved for two and for ten seconds (a
+// frame takes well under a millisecond; a stall seen once on a shared box left no trace of where it was).  Since round 6 every
+// wait inside the engine ends at its deadline with S2M_ERR_TIMEOUT, so the loop itself returns; the reporter stays for waits
+// outside the engine.  Costs the loop two relaxed stores per call.
 namespace {
 struct StallReporter {
     std::atomic<int64_t> beat{0};
@@ -188,7 +191,8 @@ struct StallReporter {
     bool stop = false;
     std::thread th;
     const char *const *names;
-    explicit StallReporter(const char *const *call_names) : names(call_names)
+    s2m_engine *eng;
+    StallReporter(const char *const *call_names, s2m_engine *e) : names(call_names), eng(e)
     {
         th = std::thread([this] {
             int64_t seen = -1;
@@ -198,10 +202,12 @@ struct StallReporter {
                 const int64_t b = beat.load(std::memory_order_relaxed);
                 idle = b == seen ? idle + 1 : 0;
                 seen = b;
-                if (idle == 10 || (idle > 10 && idle % 60 == 0)) {
+                if (idle == 2 || idle == 10 || (idle > 10 && idle % 60 == 0)) {
                     const int c = call.load(std::memory_order_relaxed);
-                    std::fprintf(stderr, "[bench_loop] no progress for %d s: frame %d, inside %s\n", idle, frame.load(std::memory_order_relaxed),
-                                 c >= 0 ? names[c] : "(start)");
+                    char st[2048] = "";
+                    if (eng) (void)s2m_debug_state(eng, st, (int64_t)sizeof(st));  // (reads only: callable beside the loop's thread)
+                    std::fprintf(stderr, "[bench_loop] no progress for %d s: frame %d, inside %s; %s\n", idle, frame.load(std::memory_order_relaxed),
+                                 c >= 0 ? names[c] : "(start)", st);
                     std::fflush(stderr);
                 }
             }
@@ -253,7 +259,7 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
     }
     static const char *const call_names[7] = {"s2m_scan_set_from_raw", "s2m_scan_prefetch_raw", "s2m_iterated_update", "s2m_scan_prepare_raw",
                                               "s2m_map_incremental", "s2m_fov_segment", "the map mirror"};
-    StallReporter stall(call_names);
+    StallReporter stall(call_names, e);
     for (int f = 0; f < total; ++f) {
         const auto t0 = std::chrono::steady_clock::now();
         const float *r = rec + (int64_t)f * rec_stride_floats;
