@@ -216,6 +216,43 @@ class CLoop:
         return dict(x=self.x[0].copy(), P=self.P[0].copy(), iters=log.iters, effct=np.array(log.effct[:log.iters]))
 
 
+class LegWatchdog:
+    """One timer per leg of the run (re-armed by leg()): a leg that hangs outside the engine's own deadlines is cut off -- the
+    JSON line is printed with what has been collected plus `watchdog` = {cut, after_s, exit_status, note}, and the process leaves
+    with `status` (0 for side legs behind a complete headline, non-zero for the headline itself).  S2M_LEG_TIMEOUT_SCALE scales
+    every budget (a slow box, a profiler)."""
+
+    def __init__(self, out, status, note):
+        self.out, self.status, self.note, self.timer = out, status, note, None
+        self.scale = float(os.environ.get("S2M_LEG_TIMEOUT_SCALE", "1"))
+
+    def leg(self, name, seconds):
+        import threading
+        self.done()
+        self.timer = threading.Timer(seconds * self.scale, self._cut, [name, seconds * self.scale])
+        self.timer.daemon = True
+        self.timer.start()
+
+    def done(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+    def _cut(self, name, seconds):
+        self.out["watchdog"] = {"cut": name, "after_s": seconds, "exit_status": self.status, "note": self.note}
+        C.CDLL(None).fflush(None)
+        line = None
+        for _ in range(5):   # (the main thread may be adding to `out` while this one serialises it)
+            try:
+                line = json.dumps(self.out)
+                break
+            except RuntimeError:
+                time.sleep(0.01)
+        sys.stdout.write((line or json.dumps({"error": "watchdog: the record could not be serialised", "watchdog": {"cut": name}})) + "\n")
+        sys.stdout.flush()
+        os._exit(self.status)
+
+
 def main():
     argv = sys.argv[1:]
     a = parse(argv)
@@ -523,11 +560,19 @@ def main():
     # is independent of it and because ~40 ms of streaming copies also bring the device clocks up -- with the driver's
     # --steps 20 --warmup 5 the whole timed region is 3 ms and would otherwise run on a chip that has just left idle
     copy_peak = measured_copy_peak(torch) if (rank == 0 and not a.no_cpu) else None  # --no-cpu: no side legs
+    # the headline under its own watchdog: a hang here (outside the engine's deadlines: the exchange, the runtime) ends the
+    # run with status 3 and a line that says so -- never with a silent 0
+    head_dog = LegWatchdog({"error": "the headline leg did not finish", "metric": "residual+Jacobian evals/sec", "value": None, "n_gpus": world},
+                           3, "the hang was in the headline leg: nothing was measured") if rank == 0 else None
+    if head_dog is not None:
+        head_dog.leg("headline (warm-up + timed steps)", 240 + 0.05 * (a.steps + a.warmup))
     run_steps(a.warmup)
     if not (use_callback or a.py_loop):
         cl.reserve(a.steps)
     dt, iters, rematch = timed(a.steps)
     res = result()
+    if head_dog is not None:
+        head_dog.done()
     step_us = getattr(cl, "step_us", None) if not (use_callback or a.py_loop) else None
     # ---- HIP-event samples: a separate, untimed loop (every pass timed; three event records + a sync each) ----
     for e in engs:
@@ -751,6 +796,8 @@ def main():
             if rank == 0:
                 out["config"]["collective_probe_ms_per_step"] = dict(exchange_probe, **{"rccl" if a.backend == "nccl" else "torch_callback": "timed out"})
                 out["rccl_probe"] = "timed out"
+                out["watchdog"] = {"cut": "exchange probe (RCCL)", "exit_status": 0,
+                                   "note": "the headline had been measured on the shared-memory exchange and is in this line: status 0 keeps the record"}
                 C.CDLL(None).fflush(None)
                 line = None
                 for _ in range(5):   # (the main thread may be adding to `out` while this one serialises it)
@@ -761,8 +808,9 @@ def main():
                         time.sleep(0.01)
                 sys.stdout.write((line or json.dumps({"error": "watchdog: the record could not be serialised"})) + "\n")
                 sys.stdout.flush()
-            # exit status 0 on purpose: the headline was measured before the probe and its line says "rccl_probe": "timed out";
-            # a non-zero status would make the launcher throw the whole record away
+            # exit status 0 on purpose, and only here and for the side legs: the headline was measured BEFORE the probe and is
+            # complete in the line, which says "rccl_probe": "timed out" and carries `watchdog`; a hang in the headline leg
+            # itself leaves with status 3 (head_dog above)
             os._exit(0)
         dog = threading.Timer(float(os.environ.get("S2M_PROBE_TIMEOUT_S", "120")), expire)
         dog.daemon = True
@@ -822,40 +870,29 @@ def main():
         cpu_scan = eng.scan_get() if a.config == "R1" else scans[0][0]
         out["cpu_baseline"] = cpu_baseline(a, cpu_map, cpu_scan, x_prop0, P0, res)
         out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
-    side_dog = None
-    if rank == 0 and single and side:
-        # The headline, its roofline and the CPU baseline are measured.  The side legs that follow must never cost the record:
-        # each is wrapped in try / except, and a leg that HANGS (a stall that no exception reports) is cut off here -- the line
-        # is printed with what has been collected and the process leaves with status 0.
-        import threading
-
-        def side_expired():
-            out["side_legs"] = "timed out after %s s: the legs not present in this line did not finish" % os.environ.get("S2M_SIDE_TIMEOUT_S", "300")
-            C.CDLL(None).fflush(None)
-            line = None
-            for _ in range(5):
-                try:
-                    line = json.dumps(out)
-                    break
-                except RuntimeError:
-                    time.sleep(0.01)
-            sys.stdout.write((line or json.dumps({"error": "watchdog: the record could not be serialised"})) + "\n")
-            sys.stdout.flush()
-            os._exit(0)
-        side_dog = threading.Timer(float(os.environ.get("S2M_SIDE_TIMEOUT_S", "300")), side_expired)
-        side_dog.daemon = True
-        side_dog.start()
+    # The headline, its roofline and the CPU baseline are measured.  The side legs that follow must never cost the record:
+    # each is wrapped in try / except (since round 6 every wait inside the engine ends at its deadline with S2M_ERR_TIMEOUT,
+    # so a stalled engine shows up as such an error), and a leg that hangs OUTSIDE the engine is cut off by its own timer:
+    # the line is printed with what has been collected, names the leg (`watchdog`), and the process leaves with status 0 --
+    # the headline in the line is complete; a hang in the headline itself leaves with status 3 (LegWatchdog below).
+    side_dog = LegWatchdog(out, 0, "the headline had been measured and is in this line: status 0 keeps the record") if rank == 0 and single and side else None
+    def leg(name, seconds):
+        if side_dog is not None:
+            side_dog.leg(name, seconds)
     if rank == 0 and single and side and a.config == "C3" and not a.extrinsic:
         # BASELINE configs[4] on this one device, against the map that is already resident
+        leg("c5_batch", 90)
         out["c5_batch"] = c5_batch(torch, Engine, synth, eng, a)
         # the same entry point at saturation (24 scans in flight: replicas 0..23, three launch groups of eight)
         sat = c5_batch(torch, Engine, synth, eng, a, k=24, steps=20, warmup=3)
         out["c5_batch"]["at_24_in_flight"] = {q: sat[q] for q in ("scans_in_flight", "scans_per_sec", "value", "unit",
                                                                   "algorithmic_GBps", "frac", "pose_error_vs_truth_m_max")}
+        leg("realistic_prior", 45)
         try:  # the node's operating point: the same scan with an IMU-sized prediction error instead of BASELINE's 1 deg / 5 cm
             out["realistic_prior"] = realistic_prior(torch, eng, synth, scans[0][0], P0)
         except Exception as ex:  # noqa: BLE001
             out["realistic_prior"] = {"error": str(ex)[:300]}
+        leg("varying_scan", 90)
         try:  # the headline's bet on an empty far-point list against input that changes every step
             out["varying_scan"] = varying_scan(torch, Engine, synth, eng, a)
         except Exception as ex:  # noqa: BLE001 - a side leg never takes the headline down
@@ -863,11 +900,13 @@ def main():
     if rank == 0 and single and side and a.config == "C3" and not a.extrinsic:
         # the other BASELINE configs (and the reference-density variant), 50 steps each, so that their numbers are in the
         # driver's record too and not only in profiles/ (VERDICT r2 weak #6); they are parity-test cases, not bench lines
+        leg("other_configs", 300)
         out["other_configs"] = other_configs(torch, Engine, synth, a, map_xyz)
     if rank == 0 and single and side and a.config in ("C1", "C2", "C3", "C4") and not a.sequential:
         # side leg, after everything that is timed or compared: what one LiDAR frame costs on the device when the
         # stages either side of the hot path run too.  It changes the engine's map (the scan is merged
         # in), which is why it comes last.
+        leg("frame_pipeline", 90)
         try:
             out["frame_pipeline"] = frame_pipeline(torch, eng, scans[0][0], x_prop0, P0, frames=a.frames)
         except Exception as ex:  # noqa: BLE001 - a side leg never takes the headline down
@@ -875,12 +914,13 @@ def main():
     if rank == 0 and single and side and a.config == "C3" and not a.extrinsic and not a.sequential and a.moving_frames > 0:
         # the same frame on a MOVING trajectory: new ground every frame, a map that leaves the box of its seed, the
         # field-of-view trim deleting what falls behind
+        leg("frame_pipeline_moving", 420)
         try:
             out["frame_pipeline_moving"] = frame_pipeline_moving(torch, Engine, synth, a)
         except Exception as ex:  # noqa: BLE001 - a side leg never takes the headline down
             out["frame_pipeline_moving"] = {"error": str(ex)[:300]}
     if side_dog is not None:
-        side_dog.cancel()
+        side_dog.done()
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
@@ -1148,7 +1188,7 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
     sys.stderr.write("[bench] frame leg: first frames %s ms; sorted tail %s ms\n" % (
         " ".join("%.3f" % v for v in per[:6]), " ".join("%.3f" % v for v in np.sort(per)[-6:])))
     sys.stderr.write("[bench] frame leg: %d frames back to back, median %.3f p99 %.3f max %.3f ms (frame %d, %s)\n" % (
-        frames, med, float(np.percentile(per, 99)), float(per.max()), worst, "merged" if how[worst] else "rebuilt"))
+        frames, med, float(np.percentile(per, 99)), float(per.max()), worst, "grid kept" if how[worst] else "rebuilt"))
     return {"ms_per_frame": float(w.sum()), "frames_per_s": float(1e3 / w.sum()),
             "ms_per_frame_back_to_back": med, "frames_per_s_back_to_back": float(1e3 / med),
             "median_ms": med, "median_ms_without_prefetch": med_no_prefetch, "median_ms_prefetch_only": med_prefetch,
@@ -1156,7 +1196,7 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
             "p99_ms": float(np.percentile(per, 99)), "max_ms": float(per.max()),
             "max_over_median": float(per.max() / med), "worst_frame": worst,
             "frames_back_to_back": int(frames), "untimed_warmup_frames": 2,
-            "updates": dict({k: int(st1[k] - st0[k]) for k in st1 if not isinstance(st1[k], dict)}, in_place=int(ip1 - ip0)),
+            "updates": {k: int(st1[k] - st0[k]) for k in st1 if not isinstance(st1[k], dict)},
             "bets": dict(zip(("won", "lost"), eng.bet_stats())),
             "rebuilt_frames": [i for i, m in enumerate(how) if not m],
             "stages_ms": {"raw_to_scan": float(w[0]), "iterated_update": float(w[1]), "map_incremental": float(w[2]),
@@ -1165,8 +1205,8 @@ def frame_pipeline(torch, eng, scan, x_prop, P0, frames=64, leaf=0.5):
             "note": "host-timed, host input (3 MB of records cross PCIe in raw_to_scan); pose_latency_ms = records in -> pose out of a frame on its own (no prefetch); the staged "
                     "frames (stages_ms, ms_per_frame) are Python calls with a device sync after every stage, the back-to-back "
                     "frames one C++ loop (tools/bench_loop.cpp, s2m_bench_frames); not part of `value`; `updates` counts how the map updates of the back-to-back frames (and the two warm-up ones) were "
-                    "produced (merged into the grid -- of those `in_place`: only the touched bricks rewritten, the others re-laid the whole map "
-                    "out and are the slow frames of the tail -- / rebuilt / re-gridded) and how often a device buffer grew"}
+                    "produced -- in_place: only the touched bricks rewritten; relaid: the whole map laid out again in key order by a merge (the slow "
+                    "frames of the tail); rebuilt: re-sorted; regridded: rebuilt with a new cell size -- and how often a device buffer grew"}
 
 
 def frame_pipeline_moving(torch, Engine, synth, a):
@@ -1213,7 +1253,7 @@ def frame_pipeline_moving(torch, Engine, synth, a):
     lo, hi = eng.map_grid()
     info1 = eng.map_info()
     worst = int(np.argmax(ms))
-    sys.stderr.write("[bench] moving frame leg: %d frames at %.1f m/frame, median %.3f p99 %.3f max %.3f ms; in place %d merged %d rebuilt %d; "
+    sys.stderr.write("[bench] moving frame leg: %d frames at %.1f m/frame, median %.3f p99 %.3f max %.3f ms; in place %d relaid %d rebuilt %d; "
                      "trims %s; gen %.1fs\n" % (frames, step, med, float(np.percentile(ms, 99)), float(ms.max()), int((how == 2).sum()),
                                                  int((how == 1).sum()), int((how == 0).sum()), trims, t_gen))
     out = {"frames": int(frames), "untimed_warmup_frames": warm, "metres_per_frame": float(step), "metres_driven": float(step * (frames + warm)),
@@ -1223,12 +1263,14 @@ def frame_pipeline_moving(torch, Engine, synth, a):
 
            # every frame above 1.5 x the median, with what its map update did: a stall of the engine (a merge, a rebuild, an
            # allocation, a trim) shows here by name; a frame that is slow and did none of that was slowed by the box's host
-           "frames_over_1p5x_median": [{"frame": int(i), "ms": float(ms[i]), "map_update": ("rebuilt", "merged", "in_place")[int(how[i])],
+           "frames_over_1p5x_median": [{"frame": int(i), "ms": float(ms[i]), "map_update": ("rebuilt", "relaid", "in_place")[int(how[i])],
                                         "device_allocations": int(r["allocs"][warm + i]), "points_trimmed": int(r["deleted"][warm + i])}
                                        for i in np.argsort(-ms)[:8] if ms[i] > 1.5 * med],
            "second_worst_ms": float(np.sort(ms)[-2]),
-           "updates": {"in_place": int((how == 2).sum()), "merged": int((how == 1).sum()), "rebuilt": int((how == 0).sum()),
-                       "regridded": int(st1["regridded"] - st0["regridded"]), "top_array_relaid": int(st1["relaid"] - st0["relaid"]),
+           "updates": {"in_place": int((how == 2).sum()), "relaid": int((how == 1).sum()), "rebuilt": int((how == 0).sum()),
+                       "regridded": int(st1["regridded"] - st0["regridded"]), "top_array_relaid": int(st1["top_relaid"] - st0["top_relaid"]),
+                       "relaid_beside_the_frames": int(st1["relaid_beside"] - st0["relaid_beside"]),
+                       "regridded_beside_the_frames": int(st1["regridded_beside"] - st0["regridded_beside"]),
                        "bricks_through_large_form": int(st1["big_bricks"] - st0["big_bricks"]),
                        "device_allocations_in_timed_frames": int(r["allocs"][warm:].sum()), "map_updates_in_place_total": int(ip1 - ip0)},
            "fov_trims": [{"frame": f, "points_deleted": d} for f, d in trims],
@@ -1245,7 +1287,7 @@ def frame_pipeline_moving(torch, Engine, synth, a):
            "at_reference_map_density": None, "with_map_publishing": None,
            "note": "host-timed per frame, raw records cross PCIe; front half of frame k + 1 beside frame k's map update (s2m_scan_prepare_raw); "
                    "not part of `value`.  how a frame's map update was produced: in_place = only the bricks it touched were rewritten (bricks that "
-                   "open or outgrow their stretch move to the tail of the point array), merged = the whole map re-laid out, rebuilt = re-sorted"}
+                   "open or outgrow their stretch move to the tail of the point array), relaid = the whole map laid out again in key order by a merge, rebuilt = re-sorted"}
     eng.close()
     # the same drive seeded at the REFERENCE's map density: the seed cloud through Add_Points(downsample 0.5 m), as config R1
     # (the node's map only ever holds voxel-filtered points; the 5 M-point seed above is the benchmark's density)
@@ -1263,7 +1305,7 @@ def frame_pipeline_moving(torch, Engine, synth, a):
             tries.append({
                 "map_points_seed": int(m_ref), "cell_m": float(info_r["cell"]), "median_ms": float(np.median(msr)),
                 "p99_ms": float(np.percentile(msr, 99)), "max_ms": float(msr.max()), "max_over_median": float(msr.max() / np.median(msr)),
-                "updates": {"in_place": int((howr == 2).sum()), "merged": int((howr == 1).sum()), "rebuilt": int((howr == 0).sum()),
+                "updates": {"in_place": int((howr == 2).sum()), "relaid": int((howr == 1).sum()), "rebuilt": int((howr == 0).sum()),
                             "regridded": int(st1["regridded"] - st0["regridded"]), "not_in_place_because": st1["not_in_place"]},
                 "map_points_end": int(eng.map_size()),
                 "note": "same sweeps, same loop; the seed is C3's cloud of the hall's first section through s2m_map_add(downsample 0.5 m)"})
@@ -1287,23 +1329,42 @@ def frame_pipeline_moving(torch, Engine, synth, a):
                 best = dt if best is None else min(best, dt)
             return pts, best
         flat, t_flat5 = flatten_ms()
-        rp = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2, publish=True)
+        # publish=2: the mirror takes the report of the PREVIOUS call (it left for pinned host memory a frame ago: nobody waits for
+        # the device); publish=1: the map as it is now (one hand-back per frame inside the frame)
+        rp = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2, publish=2)
         torch.cuda.synchronize()
         flat_end, t_flat_end = flatten_ms()
         msp = rp["ms"][warm:]
         worst_p = int(np.argmax(msp))
-        trims_p = [int(f) - warm for f in np.nonzero(rp["deleted"])[0]]
+        trims_p = [int(f) - warm for f in np.nonzero(rp["deleted"])[0] if f >= warm]
+        assert rp["mirror_points"] == rp["map_points"] == len(flat_end)
+        eng.close()
+        eng = Engine(max_iter=a.max_iter, device=torch.cuda.current_device())
+        eng.map_build(seed)
+        rp0 = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2, publish=1)
+        torch.cuda.synchronize()
+        assert rp0["mirror_points"] == rp0["map_points"]
+        ms0 = rp0["ms"][warm:]
         out["with_map_publishing"] = {
             "median_ms": float(np.median(msp)), "p99_ms": float(np.percentile(msp, 99)), "max_ms": float(msp.max()),
+            "max_over_median": float(msp.max() / np.median(msp)),
             "worst_frame": worst_p, "worst_frame_is_a_fov_trim": bool(worst_p in trims_p),
-            "map_delta_ms": {"median": float(np.median(rp["publish_ms"][warm:])), "p99": float(np.percentile(rp["publish_ms"][warm:], 99))},
+            "fov_trim_frames_ms": {str(f): float(msp[f]) for f in trims_p},
+            "map_delta_ms": {"median": float(np.median(rp["publish_ms"][warm:])), "p99": float(np.percentile(rp["publish_ms"][warm:], 99)),
+                             "max": float(rp["publish_ms"][warm:].max()),
+                             "of_which_fetch_median": float(np.median(rp["fetch_ms"][warm:])),
+                             "note": "fetch = s2m_map_get_changes (the handle's thread); the rest = applying it to the mirror's buckets, which a node "
+                                     "may leave to its publishing thread (s2m_map_mirror::fetch / apply)"},
+            "follower": "one call behind the map (s2m_map_changes.lag = 1): the report of frame k - 1 is applied in frame k",
+            "without_lag": {"median_ms": float(np.median(ms0)), "p99_ms": float(np.percentile(ms0, 99)), "max_ms": float(ms0.max()),
+                            "map_delta_ms_median": float(np.median(rp0["publish_ms"][warm:])),
+                            "note": "lag = 0: the mirror holds the map as it is at the end of every frame; one hand-back inside the frame"},
             "map_flatten_ms": {"at_%d_points" % len(flat): float(t_flat5), "at_%d_points" % len(flat_end): float(t_flat_end)},
             "mirror_points_end": rp["mirror_points"], "map_points_end": rp["map_points"], "whole_map_fetches": rp["mirror_resyncs"],
             "note": "map_delta_ms = s2m_map_get_changes + applying it to the host mirror (include/daliti_s2m_mirror.hpp), inside the frame; "
                     "map_flatten_ms = one s2m_map_get_points (rank the ids, gather, D2H of the whole map; best of 3), what publishing "
-                    "every frame cost before and what the reference's ikdtree.flatten does on the CPU.  the delta is proportional to the "
-                    "change: the frame of a field-of-view trim hands millions of removed ids to the mirror and is the max_ms here"}
-        assert rp["mirror_points"] == rp["map_points"] == len(flat_end)
+                    "every frame cost before and what the reference's ikdtree.flatten does on the CPU.  a field-of-view trim reaches the "
+                    "mirror as its boxes: the buckets inside a box are dropped whole, the ones its faces cut are filtered"}
         eng.close()
     except Exception as ex:  # noqa: BLE001
         out["with_map_publishing"] = {"error": str(ex)[:300]}

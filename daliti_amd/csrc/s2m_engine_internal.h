@@ -77,6 +77,7 @@ struct s2m_engine {
     ChangeLog log;                  // what the updates added / removed since the last s2m_map_get_changes
     uint64_t log_seq = 0;
     bool last_update_merged = false;
+    int64_t n_beside = 0, n_beside_regrid = 0;   // layouts produced beside the frames (s2m_map_update_stats, stats[10], [11])
     int64_t n_merged = 0, n_rebuilt = 0, n_regrid = 0;  // how this handle's map updates were produced (s2m_map_update_stats)
     std::mutex stats_mu;            // the lazily fetched counts of a merged update may be asked for by borrowers' threads
     Grid grid{};
@@ -184,7 +185,12 @@ struct s2m_engine {
     Comm comm;  // attached RCCL communicator (multi-GPU form), handle == nullptr when single GPU
     ShmExchange shm;               // or: host shared-memory exchange between the processes of one node (s2m_comm_init_shm)
     std::vector<double> shm_blocks;  // the ranks' blocks of one exchange, padded to a power of two for the tree sum
-    std::vector<float> h_changes;    // s2m_map_get_changes: the added points on their way to the caller's arrays
+    // s2m_map_get_changes: the reports that have landed and wait for the follower's arrays (kept across a call that could not
+    // take them)
+    struct BoxEvent { float box[6]; int64_t after_added, after_removed; };
+    std::vector<float4> chg_added, chg_removed;
+    std::vector<BoxEvent> chg_boxes;
+    bool chg_overflow = false;
     int32_t queue[S2M_FEAT_QUEUE + 1] = {0};
     int32_t queue_len = 0;
 };

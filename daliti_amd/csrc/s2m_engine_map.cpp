@@ -70,7 +70,8 @@ void bind_update(s2m_engine *e)
 
 // the map after an update: merged into the sorted arrays when possible (s2m_mapedit.hip: in place, else merge_update), else rebuilt
 // from upd.list (survivors in index order, then the staged points) -- the same caller order either way
-int commit_update(s2m_engine *e)
+// boxes / nb: the update is a box delete (s2m_map_delete_boxes): a follower of the map gets the boxes, not the points
+int commit_update(s2m_engine *e, const float *boxes = nullptr, int nb = 0)
 {
     bool merged = false;
     e->map_ready = false;
@@ -93,8 +94,18 @@ int commit_update(s2m_engine *e)
     };
     const bool drift_before = drifted();
     const int64_t id0 = e->map.next_id;  // the first id this update hands out
-    if (e->log.on && e->log.token != 0 && e->grid.m > 0)   // somebody follows the map: the ids about to disappear, before anything moves
-        launch_log_removed(e->log, e->map.counters + kBricksWord, e->stats.bricks, e->map.bmark, e->grid.tab, e->upd.alive_s, e->grid.pidx, e->stream);
+    if (e->log.on && e->log.token != 0 && e->grid.m > 0) {   // somebody follows the map
+        if (nb == 0) {   // the points about to disappear one by one, before anything moves
+            launch_log_removed(e->log, e->map.counters + kBricksWord, e->stats.bricks, e->map.bmark, e->grid.tab, e->upd.alive_s, e->grid.pidx,
+                               e->grid.pts, e->stream);
+        } else if (nb <= kLogBoxesPer && (int)e->log.boxes_per_log.size() < kLogMarks) {   // the boxes themselves, in their place in the sequence
+            e->log.boxes_log.insert(e->log.boxes_log.end(), boxes, boxes + 6 * (size_t)nb);
+            e->log.boxes_per_log.push_back(nb);
+            launch_log_mark(e->log, e->stream);
+        } else {
+            e->log.token = 0;  // more box deletes than a report holds: whoever follows the map fetches it
+        }
+    }
     if (!e->no_merge && !e->no_slab && !drift_before) {  // in place when every touched brick fits where it stands
         bool counted = false;
         // a scan's batches that update_add left where they were are staged by the in-place update's preparation -- when that
@@ -189,7 +200,7 @@ int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *
     S2M_HIP(e, update_delete(e->upd, e->grid, boxes, (int)n, &del, e->stream));
     if (n_deleted) *n_deleted = del;
     if (del == 0) return S2M_OK;  // nothing changed: keep the grid and the neighbour indices
-    return commit_update(e);
+    return commit_update(e, boxes, (int)n);
 }
 
 int s2m_fov_reset(s2m_engine *e)
@@ -232,9 +243,13 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     // further from every map point than the map is wide) the classic loop of rounds and questions runs and the scan is
     // classified again.
     const bool complete = e->nn_valid && ekf_inited != 0 && e->short_lists != 0 && !e->nn_complete && !e->nn_nearest && e->n > 0 && e->grid.m > 0;
+    // how much of such a list must be proven: its nearest entry is all that :603 reads, and the other entries -- beyond the gate
+    // radius from the point -- cannot pass :612-616 as long as the voxel's half diagonal stays inside that radius:
+    // sqrt(3) fs <= sqrt(gate) (fs <= 1.29 m with the reference's gate; feat.yaml ships 0.5).  A larger leaf gets all five.
+    const int need_k = std::sqrt(3.0) * filter_size_map <= std::sqrt((double)e->cfg.knn_d2_gate) ? 1 : kK;
     const uint32_t *open_word = nullptr;
     if (complete) {
-        int rc = complete_lists(e, 1, -1, nullptr);
+        int rc = complete_lists(e, need_k, -1, nullptr);
         if (rc) return rc;
         open_word = e->d_hard + 3 * e->n_cap + 3;
     }
@@ -245,12 +260,12 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
                              e->d_nn_idx, e->grid, e->nn_valid && ekf_inited != 0, filter_size_map, &la, &na, &lb, &nb, e->stream,
                              &vox, true, open_word, &left_open));   // (update_begin runs inside, while the counts travel to the host)
     if (complete && left_open != 0) {
-        int rc = complete_lists(e, 1, 0, nullptr);
+        int rc = complete_lists(e, need_k, 0, nullptr);
         if (rc) return rc;
         S2M_HIP(e, incr_classify(e->upd, pose, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, (int)e->n,
                                  e->d_nn_idx, e->grid, true, filter_size_map, &la, &na, &lb, &nb, e->stream, &vox, true));
     }
-    if (complete) e->nn_nearest = true;
+    if (complete) { e->nn_nearest = true; e->nn_complete = need_k == kK; }
     if (n_to_add) *n_to_add = na;
     if (n_no_downsample) *n_no_downsample = nb;
     {
@@ -365,57 +380,112 @@ int s2m_map_get_ids(s2m_engine *e, uint32_t *ids, int64_t capacity, int64_t *m)
     return sync_stream(e, e->stream, "the map's ids on their way to the caller");
 }
 
-int s2m_map_get_changes(s2m_engine *e, uint64_t *token, float *added_xyz, uint32_t *added_ids, int64_t cap_added, int64_t *n_added,
-                        uint32_t *removed_ids, int64_t cap_removed, int64_t *n_removed, int32_t *resync)
+namespace {
+// the report that has landed in pinned memory joins what is waiting for the follower (e->chg_*): entries, and the box deletes
+// with their place in the sequence
+void stash_report(s2m_engine *e)
 {
-    if (!e || !token || !n_added || !n_removed || !resync) return fail(e, S2M_ERR_ARG, "null argument");
+    ChangeLog &L = e->log;
+    const uint32_t *h = L.h_head + 1;
+    if (h[2] != 0u) { e->chg_overflow = true; return; }
+    const size_t a0 = e->chg_added.size(), r0 = e->chg_removed.size();
+    e->chg_added.insert(e->chg_added.end(), L.h_added, L.h_added + h[0]);
+    e->chg_removed.insert(e->chg_removed.end(), L.h_removed, L.h_removed + h[1]);
+    size_t at = 0;
+    for (size_t k = 0; k < L.boxes_per_posted.size() && k < (size_t)h[3]; ++k)
+        for (int b = 0; b < L.boxes_per_posted[k]; ++b, ++at) {
+            s2m_engine::BoxEvent ev;
+            std::memcpy(ev.box, L.boxes_posted.data() + 6 * at, sizeof(ev.box));
+            ev.after_added = (int64_t)(a0 + h[4 + 2 * k]);
+            ev.after_removed = (int64_t)(r0 + h[5 + 2 * k]);
+            e->chg_boxes.push_back(ev);
+        }
+    L.boxes_posted.clear();
+    L.boxes_per_posted.clear();
+}
+void post_report(s2m_engine *e)
+{
+    ChangeLog &L = e->log;
+    L.boxes_posted.swap(L.boxes_log);
+    L.boxes_per_posted.swap(L.boxes_per_log);
+    L.boxes_log.clear();
+    L.boxes_per_log.clear();
+    changelog_post(L, e->stream);
+}
+}  // namespace
+
+int s2m_map_get_changes(s2m_engine *e, uint64_t *token, s2m_map_changes *c)
+{
+    if (!e || !token || !c) return fail(e, S2M_ERR_ARG, "null argument");
     if (!e->map_ready) return fail(e, S2M_ERR_STATE, "no map");
     if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
     S2M_ENTER(e);
-    *n_added = 0; *n_removed = 0; *resync = 0;
+    c->n_added = 0; c->n_removed = 0; c->n_boxes = 0; c->resync = 0;
+    ChangeLog &L = e->log;
     auto fresh = [&]() {
-        e->log.on = true;
-        e->log.token = (++e->log_seq << 8) | 1u;
-        *token = e->log.token;
+        L.on = true;
+        L.token = (++e->log_seq << 8) | 1u;
+        *token = L.token;
     };
-    if (!e->log.on || e->log.token == 0 || *token != e->log.token) {
+    auto start_over = [&]() {  // the follower fetches the map as it is now; the log starts from here
+        launch_log_reset(L, e->stream);
+        L.boxes_log.clear(); L.boxes_per_log.clear(); L.boxes_posted.clear(); L.boxes_per_posted.clear();
+        L.posted = false;   // (a report still on its way is stale: its sequence number is never waited for)
+        e->chg_added.clear(); e->chg_removed.clear(); e->chg_boxes.clear();
+        e->chg_overflow = false;
+        fresh();
+        c->resync = 1;
+    };
+    if (!L.on || L.token == 0 || *token != L.token) {
         // the caller does not hold the state the log starts from (first call, a rebuild in between, another follower's token)
-        // (room for a field-of-view trim of a few million points: 20 bytes per entry; beyond that the follower fetches the map.
-        // S2M_LOG_CAP: test hook, a capacity small enough to overflow)
-        int64_t cap = std::max<int64_t>((int64_t)1 << 22, 4 * e->n_cap);
+        // (room for what a few frames change -- a field-of-view trim is logged as its boxes, not as its points; beyond the room
+        // the follower fetches the map.  S2M_LOG_CAP: test hook, a capacity small enough to overflow)
+        int64_t cap = std::max<int64_t>((int64_t)1 << 18, 4 * e->n_cap);
         if (const char *g = std::getenv("S2M_LOG_CAP")) cap = std::max<int64_t>(16, std::atoll(g));
-        S2M_HIP(e, changelog_ensure(e->log, cap, e->stream));
-        launch_log_reset(e->log, e->stream);
-        fresh();
-        *resync = 1;
+        S2M_HIP(e, changelog_ensure(L, cap, e->stream));
+        start_over();
         return S2M_OK;
     }
-    const uint32_t *src[3] = {e->log.counts, e->log.counts + 1, e->log.counts + 2};
-    uint32_t v[3] = {0, 0, 0};
-    S2M_HIP(e, mail_fetch(e->mail, src, 3, v, e->stream));
-    if (v[2] != 0u) {  // more changes than the log holds: start over
-        launch_log_reset(e->log, e->stream);
-        fresh();
-        *resync = 1;
+    // 1. what has been posted for this follower (lag: by the previous call, a frame ago -- it has landed) and, without lag,
+    //    everything up to now
+    e->step = "the change log";
+    if (L.posted) {
+        S2M_HIP(e, changelog_collect(L, e->stream));
+        stash_report(e);
+    }
+    if (c->lag == 0) {
+        post_report(e);
+        S2M_HIP(e, changelog_collect(L, e->stream));
+        stash_report(e);
+    }
+    if (e->chg_overflow) {  // more changes than the log holds: start over
+        start_over();
         return S2M_OK;
     }
-    *n_added = v[0];
-    *n_removed = v[1];
-    if ((v[0] > 0 && (!added_xyz || !added_ids || cap_added < (int64_t)v[0])) || (v[1] > 0 && (!removed_ids || cap_removed < (int64_t)v[1])))
+    // 2. hand it over
+    const int64_t na = (int64_t)e->chg_added.size(), nr = (int64_t)e->chg_removed.size(), nx = (int64_t)e->chg_boxes.size();
+    c->n_added = na; c->n_removed = nr; c->n_boxes = nx;
+    if ((na > 0 && (!c->added_xyz || !c->added_ids || c->capacity_added < na)) || (nr > 0 && (!c->removed_ids || c->capacity_removed < nr)) ||
+        (nx > 0 && (!c->boxes || !c->box_after_added || !c->box_after_removed || c->capacity_boxes < nx)))
         return fail(e, S2M_ERR_CAPACITY, "s2m_map_get_changes: buffers too small (the changes are kept)");
-    if (v[0] > 0) {
-        e->h_changes.resize((size_t)v[0] * 4);
-        S2M_HIP(e, hipMemcpyAsync(e->h_changes.data(), e->log.added, (size_t)v[0] * sizeof(float4), hipMemcpyDeviceToHost, e->stream));
+    for (int64_t i = 0; i < na; ++i) {
+        const float4 &p = e->chg_added[(size_t)i];
+        c->added_xyz[3 * i] = p.x; c->added_xyz[3 * i + 1] = p.y; c->added_xyz[3 * i + 2] = p.z;
+        std::memcpy(&c->added_ids[i], &p.w, sizeof(uint32_t));
     }
-    if (v[1] > 0) S2M_HIP(e, hipMemcpyAsync(removed_ids, e->log.removed, (size_t)v[1] * sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-    launch_log_reset(e->log, e->stream);
-    int rc = sync_stream(e, e->stream, "the map's changes on their way to the caller");
-    if (rc) return rc;
-    for (uint32_t i = 0; i < v[0]; ++i) {
-        const float *p = e->h_changes.data() + (size_t)i * 4;
-        added_xyz[3 * (size_t)i] = p[0]; added_xyz[3 * (size_t)i + 1] = p[1]; added_xyz[3 * (size_t)i + 2] = p[2];
-        std::memcpy(&added_ids[i], &p[3], sizeof(uint32_t));
+    for (int64_t i = 0; i < nr; ++i) {
+        const float4 &p = e->chg_removed[(size_t)i];
+        if (c->removed_xyz) { c->removed_xyz[3 * i] = p.x; c->removed_xyz[3 * i + 1] = p.y; c->removed_xyz[3 * i + 2] = p.z; }
+        std::memcpy(&c->removed_ids[i], &p.w, sizeof(uint32_t));
     }
+    for (int64_t i = 0; i < nx; ++i) {
+        std::memcpy(c->boxes + 6 * i, e->chg_boxes[(size_t)i].box, 6 * sizeof(float));
+        c->box_after_added[i] = e->chg_boxes[(size_t)i].after_added;
+        c->box_after_removed[i] = e->chg_boxes[(size_t)i].after_removed;
+    }
+    e->chg_added.clear(); e->chg_removed.clear(); e->chg_boxes.clear();
+    // 3. with lag: what has happened since leaves for the host now and is handed over by the next call -- nobody waits
+    if (c->lag != 0) post_report(e);
     fresh();
     return S2M_OK;
 }
@@ -452,7 +522,7 @@ int s2m_map_inplace_updates(const s2m_engine *e, int64_t *n)
     return S2M_OK;
 }
 
-int s2m_map_update_stats(const s2m_engine *e, int64_t stats[10])
+int s2m_map_update_stats(const s2m_engine *e, int64_t stats[12])
 {
     if (!e || !stats) return S2M_ERR_ARG;
     stats[0] = e->n_merged;
@@ -462,6 +532,8 @@ int s2m_map_update_stats(const s2m_engine *e, int64_t stats[10])
     stats[4] = e->map.n_relaid;
     stats[5] = e->map.n_big_slab;
     for (int k = 0; k < 4; ++k) stats[6 + k] = e->map.slab_fail[k];
+    stats[10] = e->n_beside;
+    stats[11] = e->n_beside_regrid;
     return S2M_OK;
 }
 

@@ -1,4 +1,5 @@
 """ctypes binding of include/daliti_s2m.h (one Python method per C entry point)."""
+import collections
 import ctypes as C
 import os
 import subprocess
@@ -60,6 +61,37 @@ class IterLog(C.Structure):
 class DynShare(C.Structure):
     _fields_ = [("valid", C.c_int32), ("converge", C.c_int32), ("h_x", C.c_void_p), ("h", C.c_void_p),
                 ("capacity", C.c_int64), ("rows", C.c_int64), ("total_residual", C.c_double)]
+
+
+class MapChangesC(C.Structure):
+    _fields_ = [("added_xyz", C.c_void_p), ("added_ids", C.c_void_p), ("capacity_added", C.c_int64),
+                ("removed_xyz", C.c_void_p), ("removed_ids", C.c_void_p), ("capacity_removed", C.c_int64),
+                ("boxes", C.c_void_p), ("box_after_added", C.c_void_p), ("box_after_removed", C.c_void_p), ("capacity_boxes", C.c_int64),
+                ("n_added", C.c_int64), ("n_removed", C.c_int64), ("n_boxes", C.c_int64), ("resync", C.c_int32), ("lag", C.c_int32)]
+
+
+MapChanges = collections.namedtuple("MapChanges", "token resync add_xyz add_ids rem_xyz rem_ids boxes box_after_added box_after_removed")
+
+
+def apply_map_changes(ids, xyz, ch):
+    """What a follower does with a MapChanges report (include/daliti_s2m_mirror.hpp in numpy, for tests): returns the new
+    (ids, xyz), unordered."""
+    a0 = r0 = 0
+    nb = len(ch.boxes)
+    for k in range(nb + 1):
+        a1 = int(ch.box_after_added[k]) if k < nb else len(ch.add_ids)
+        r1 = int(ch.box_after_removed[k]) if k < nb else len(ch.rem_ids)
+        ids = np.concatenate([ids, ch.add_ids[a0:a1]])
+        xyz = np.concatenate([xyz, ch.add_xyz[a0:a1]])
+        gone = np.isin(ids, ch.rem_ids[r0:r1])
+        assert gone.sum() == r1 - r0, "a removed id is not in the mirror"
+        ids, xyz = ids[~gone], xyz[~gone]
+        if k < nb:
+            lo, hi = ch.boxes[k][:3], ch.boxes[k][3:]
+            inside = ((xyz >= lo) & (xyz < hi)).all(axis=1)
+            ids, xyz = ids[~inside], xyz[~inside]
+        a0, r0 = a1, r1
+    return ids, xyz
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -211,17 +243,23 @@ class Engine:
                     top_entries=int(info[5]), occupied_cells=int(info[6]), mean_per_cell=info[7])
 
     def map_last_update_merged(self):
-        """True when the last map update was merged into the current grid (no re-sort), False after a rebuild."""
+        """True when the last map update kept the grid (applied in place, or the map re-laid by a merge -- no re-sort), False after a
+        rebuild."""
         m = C.c_int32()
         self._ck(self.lib.s2m_map_last_update(self.h, C.byref(m)))
         return bool(m.value)
 
     def map_update_stats(self):
-        """Running counts: updates merged / rebuilt / re-gridded, device buffer (re)allocations (process-wide)."""
-        st = (C.c_int64 * 10)()
+        """Running counts of how the map updates were produced, in ONE vocabulary: in_place (only the touched bricks rewritten),
+        relaid (the whole map laid out again in key order by a merge), rebuilt (re-sorted), regridded (rebuilds that also chose a
+        new cell size); device buffer (re)allocations (process-wide); top_relaid (times the top-level array was re-laid: no point
+        moves); big_bricks; why updates could not stay in place."""
+        st = (C.c_int64 * 12)()
         self._ck(self.lib.s2m_map_update_stats(self.h, st))
-        return dict(merged=st[0], rebuilt=st[1], regridded=st[2], allocations=st[3], relaid=st[4], big_bricks=st[5],
-                    not_in_place=dict(unrepresentable=st[6], no_table_rows=st[7], brick_too_large=st[8], tail_exhausted=st[9]))
+        inplace = self.map_inplace_updates()
+        return dict(in_place=inplace, relaid=st[0] - inplace, rebuilt=st[1], regridded=st[2], allocations=st[3], top_relaid=st[4], big_bricks=st[5],
+                    not_in_place=dict(unrepresentable=st[6], no_table_rows=st[7], brick_too_large=st[8], tail_exhausted=st[9]),
+                    relaid_beside=st[10], regridded_beside=st[11])
 
     def map_inplace_updates(self):
         """Updates applied in place (only the touched bricks rewritten): s2m_map_inplace_updates."""
@@ -237,16 +275,23 @@ class Engine:
         self._ck(self.lib.s2m_map_get_ids(self.h, _p(out), C.c_int64(len(out)), C.byref(m)))
         return out[:m.value]
 
-    def map_changes(self, token, capacity=1 << 20):
-        """s2m_map_get_changes: (token, resync, added_xyz, added_ids, removed_ids) since the call that returned `token`."""
+    def map_changes(self, token, capacity=1 << 20, lag=0):
+        """s2m_map_get_changes since the call that returned `token`: MapChanges(token, resync, add_xyz, add_ids, rem_xyz, rem_ids,
+        boxes (n x 6), box_after_added, box_after_removed) -- box k applies after add[:box_after_added[k]] and
+        rem[:box_after_removed[k]]; within a stretch additions first, then removals.  lag=1: the report of the previous call."""
         tok = C.c_uint64(int(token))
         xyz = np.zeros((capacity, 3), np.float32)
         ids = np.zeros(capacity, np.uint32)
+        rxyz = np.zeros((capacity, 3), np.float32)
         rem = np.zeros(capacity, np.uint32)
-        na, nr, rs = C.c_int64(), C.c_int64(), C.c_int32()
-        self._ck(self.lib.s2m_map_get_changes(self.h, C.byref(tok), _p(xyz), _p(ids), C.c_int64(capacity), C.byref(na), _p(rem),
-                                              C.c_int64(capacity), C.byref(nr), C.byref(rs)))
-        return tok.value, bool(rs.value), xyz[:na.value], ids[:na.value], rem[:nr.value]
+        boxes = np.zeros((64, 6), np.float32)
+        ba = np.zeros(64, np.int64)
+        br = np.zeros(64, np.int64)
+        c = MapChangesC(xyz.ctypes.data, ids.ctypes.data, capacity, rxyz.ctypes.data, rem.ctypes.data, capacity, boxes.ctypes.data,
+                        ba.ctypes.data, br.ctypes.data, 64, 0, 0, 0, 0, int(lag))
+        self._ck(self.lib.s2m_map_get_changes(self.h, C.byref(tok), C.byref(c)))
+        return MapChanges(tok.value, bool(c.resync), xyz[:c.n_added], ids[:c.n_added], rxyz[:c.n_removed], rem[:c.n_removed],
+                          boxes[:c.n_boxes], ba[:c.n_boxes], br[:c.n_boxes])
 
     def map_order(self):
         """order[j] = caller index of the point at sorted position j (the engine's tie order); 0xffffffff where an in-place

@@ -82,7 +82,7 @@ class World:
 def run_frames(eng, sw, P0, frames, warm, leaf=0.5, filter_size_map=0.5, cube_len=1000.0, prefetch=2, publish=False):
     """tools/bench_loop.cpp, s2m_bench_frames_moving: the sweeps `sw` (World.sweeps, warm + frames of them) through the
     engine `eng`, one frame after the other (publish: a host mirror of the map is brought up to date after every frame, as a node
-    that publishes /Laser_map would).  Returns per-frame arrays (warm-up frames included): ms, how (0 = map
+    that publishes /Laser_map would -- 1 / True: to the map as it is, 2: one call behind, nobody waits for the device).  Returns per-frame arrays (warm-up frames included): ms, how (0 = map
     rebuilt, 1 = re-laid by a merge, 2 = in place), deleted, n_scan, x (updated states), iters, effct."""
     from .engine import IterLog
     lib = helper_library()
@@ -101,17 +101,18 @@ def run_frames(eng, sw, P0, frames, warm, leaf=0.5, filter_size_map=0.5, cube_le
     publish_us = np.zeros(total)
     mirror_stats = np.zeros(3, np.int64)
     stage_us = np.zeros((total, 6))
+    fetch_us = np.zeros(total)
     P0 = np.ascontiguousarray(P0, np.float64)
     rc = fn(eng.h, C.c_int32(frames), C.c_int32(warm), C.c_void_p(rec.ctypes.data), C.c_int64(rec.shape[1] * 12),
             C.c_void_p(sw["n"].ctypes.data), C.c_int32(4), C.c_int32(6), C.c_void_p(sw["poses"].ctypes.data), C.c_int32(N_POSES),
             C.c_void_p(sw["x_prop"].ctypes.data), C.c_void_p(P0.ctypes.data), C.c_float(leaf), C.c_double(filter_size_map),
             C.c_double(cube_len), C.c_int32(prefetch), C.c_void_p(x.ctypes.data), C.c_void_p(us.ctypes.data),
             C.c_void_p(how.ctypes.data), C.c_void_p(deleted.ctypes.data), C.c_void_p(n_scan.ctypes.data), logs,
-            C.c_void_p(allocs.ctypes.data), C.c_int32(int(bool(publish))), C.c_void_p(publish_us.ctypes.data),
-            C.c_void_p(mirror_stats.ctypes.data), C.c_void_p(stage_us.ctypes.data))
+            C.c_void_p(allocs.ctypes.data), C.c_int32(int(publish)), C.c_void_p(publish_us.ctypes.data),
+            C.c_void_p(mirror_stats.ctypes.data), C.c_void_p(stage_us.ctypes.data), C.c_void_p(fetch_us.ctypes.data))
     if rc != 0:
         raise RuntimeError("s2m_bench_frames_moving failed: %d (%s)" % (rc, eng.lib.s2m_last_error(eng.h).decode()))
-    return dict(ms=us * 1e-3, how=how, deleted=deleted, n_scan=n_scan, x=x, allocs=allocs, publish_ms=publish_us * 1e-3,
+    return dict(ms=us * 1e-3, how=how, deleted=deleted, n_scan=n_scan, x=x, allocs=allocs, publish_ms=publish_us * 1e-3, fetch_ms=fetch_us * 1e-3,
                 mirror_points=int(mirror_stats[0]), map_points=int(mirror_stats[1]), mirror_resyncs=int(mirror_stats[2]),
                 stage_ms=np.diff(np.concatenate([np.zeros((total, 1)), stage_us], axis=1), axis=1) * 1e-3, iters=np.array([l.iters for l in logs]),
                 effct=[np.array(l.effct[:l.iters]) for l in logs])

@@ -186,15 +186,38 @@ int s2m_map_get_points(s2m_engine *e, float *xyz, int64_t capacity_points, int64
  * (a rebuild -- s2m_map_update_stats, stats[1] -- numbers the points anew). */
 int s2m_map_get_ids(s2m_engine *e, uint32_t *ids, int64_t capacity_points, int64_t *m);
 /* Map publishing proportional to the change (design; the reference flattens and publishes the whole map every frame,
- * laserMapping.cpp:1170-1175, 1229-1235 -- O(M) per frame): what the updates since the previous call added (packed xyz and
- * ids) and removed (ids).  A follower keeps a mirror keyed by point id: the first call (*token = 0) and every call whose
- * token is not the one the previous call returned -- a rebuild in between, more changes than the log holds -- answer
- * *resync = 1 with no changes: fetch s2m_map_get_points + s2m_map_get_ids and go on from the token returned.  Otherwise the
- * arrays receive *n_added / *n_removed entries (S2M_ERR_CAPACITY if they are too small: the counts are set, the changes
- * kept).  One follower per handle.  Cost: the removed ids are collected from the bricks an update touches, the added points
- * are the update's staging list -- nothing map-sized runs, nothing map-sized crosses PCIe. */
-int s2m_map_get_changes(s2m_engine *e, uint64_t *token, float *added_xyz, uint32_t *added_ids, int64_t capacity_added,
-                        int64_t *n_added, uint32_t *removed_ids, int64_t capacity_removed, int64_t *n_removed, int32_t *resync);
+ * laserMapping.cpp:1170-1175, 1229-1235 -- O(M) per frame): what the updates since the previous call did to the map, in
+ * sequence.  Three kinds of entry: points ADDED (xyz + id), points REMOVED one by one (the voxel rule of Add_Points: xyz + id,
+ * so that a follower can find them by place and then by id), and BOX DELETES (Delete_Point_Boxes -- the field-of-view trim
+ * removes millions of points: the follower gets the boxes, not the points, and applies min <= p < max per axis, float
+ * compares, to what it holds).  Order of application: box k applies after added[0 .. box_after_added[k]) and
+ * removed[0 .. box_after_removed[k]) and before the entries behind them; within a stretch between two boxes additions first,
+ * then removals (a point that came and went is in both lists).
+ * The first call (*token = 0) and every call whose token is not the one the previous call returned -- a rebuild in between,
+ * more changes than the log holds (2^18 entries or four scans' worth, 8 box deletes) -- answer resync = 1 with no changes:
+ * fetch s2m_map_get_points + s2m_map_get_ids and go on from the token returned.  Otherwise the arrays receive n_added /
+ * n_removed / n_boxes entries (S2M_ERR_CAPACITY if any is too small: the counts are set, the changes kept for the next call).
+ * lag = 0: everything up to now; the call waits for the device (one hand-back).  lag = 1: everything up to the PREVIOUS call
+ * -- that report left for pinned host memory a frame ago and has landed, so the call waits for nothing, and what has happened
+ * since leaves now: the follower is one call behind the map and never makes the frame wait.  One follower per handle.
+ * Cost: the removed points are collected from the bricks an update touches, the added points are the update's staging list
+ * -- nothing map-sized runs, nothing map-sized crosses PCIe. */
+typedef struct {
+    float    *added_xyz;         /* in: capacity_added x 3                                   */
+    uint32_t *added_ids;         /* in: capacity_added                                       */
+    int64_t   capacity_added;
+    float    *removed_xyz;       /* in: capacity_removed x 3, or NULL (ids only)             */
+    uint32_t *removed_ids;       /* in: capacity_removed                                     */
+    int64_t   capacity_removed;
+    float    *boxes;             /* in: capacity_boxes x 6 = {min xyz, max xyz}              */
+    int64_t  *box_after_added;   /* in: capacity_boxes                                       */
+    int64_t  *box_after_removed; /* in: capacity_boxes                                       */
+    int64_t   capacity_boxes;
+    int64_t   n_added, n_removed, n_boxes;   /* out */
+    int32_t   resync;            /* out */
+    int32_t   lag;               /* in: 0 or 1 */
+} s2m_map_changes;
+int s2m_map_get_changes(s2m_engine *e, uint64_t *token, s2m_map_changes *changes);
 /* How the last map_add / map_delete_boxes / fov_segment / map_incremental produced the new map (design, not
  * reference): *merged = 1 when the update was merged into the sorted arrays of the current grid, 0 when the grid
  * was rebuilt (a density drift, an empty map; see s2m_map_update_stats). */
@@ -207,8 +230,11 @@ int s2m_map_last_update(const s2m_engine *e, int32_t *merged);
  * because the box of bricks in use had outgrown or left its window (a few thousand entries; no point moves), stats[5] =
  * bricks rewritten in place through the large staging form (more than 2 048 points), stats[6..9] = updates that could not
  * stay in place (and were merged) because of: a point beyond the representable cell range, no spare table rows for the
- * bricks to open, a brick too large to stage (more than 6 144 points), the tail of the point array exhausted. */
-int s2m_map_update_stats(const s2m_engine *e, int64_t stats[10]);
+ * bricks to open, a brick too large to stage (more than 6 144 points), the tail of the point array exhausted; stats[10] =
+ * layouts of the whole map that were produced BESIDE the frames (on the handle's side stream, from a snapshot, the updates
+ * that arrived meanwhile applied again, swapped in between two frames: ikd-Tree's rebuild thread, ikd_Tree.cpp:192-203,
+ * 229-367) instead of inside an update, stats[11] = those of them that also chose a new cell size. */
+int s2m_map_update_stats(const s2m_engine *e, int64_t stats[12]);
 /* How many of the merged updates (s2m_map_update_stats, stats[0]) were applied IN PLACE: only the bricks the update touched
  * were rewritten where they stand -- possible when each of them still fits the stretch of the point array it owns and no new
  * point opens a brick; cost proportional to the update, not to the map (ikd-Tree inserts per point in O(log M),

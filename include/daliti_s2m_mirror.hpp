@@ -2,93 +2,363 @@
  *
  * The reference flattens the whole ikd-Tree and publishes it every frame (ikdtree.flatten -> featsFromMap ->
  * /Laser_map, eskf_lio/src/laserMapping.cpp:1170-1175, 1229-1235): O(map) per frame on the host.  With the engine the
- * map lives on the device; this mirror holds it on the host, keyed by point id, and
- * applies what s2m_map_get_changes reports -- the points an update added, the ids it removed -- so that a frame moves
- * a few thousand points across PCIe instead of the map.  Header-only C++ over the C ABI (include/daliti_s2m.h). */
+ * map lives on the device; this mirror holds it on the host and applies what s2m_map_get_changes reports -- the points an
+ * update added, the points it removed one by one, the boxes a field-of-view trim deleted -- so that a frame moves a few
+ * thousand points across PCIe instead of the map, and a trim of millions of points costs what the BUCKETS it empties cost.
+ *
+ * Layout: the points sit in buckets of 4 m x 4 m x 4 m (an open-addressing table from the bucket's integer coordinates to its
+ * arrays); inside a bucket ids ascend (the engine hands ids out in ascending order and reports additions in that order), so a
+ * removed point is found by its place (the bucket) and a binary search over a few hundred ids, and is only marked (its x
+ * becomes NaN; a bucket is compacted when more than half of it is marks, and gives its memory back when nothing is left).  A box delete drops the buckets that lie inside the
+ * box whole -- no point is looked at -- and filters the ones its faces cut with the engine's own test (min <= p < max per
+ * axis, float compares).  Memory: the live points (+ marks, at most as many), nothing that grows with the ids ever issued.
+ * Publishing reads the buckets in turn (copy_points / for_each): the one O(map) pass a whole-map message needs anyway.
+ * Header-only C++14 over the C ABI (include/daliti_s2m.h). */
 #ifndef DALITI_S2M_MIRROR_HPP
 #define DALITI_S2M_MIRROR_HPP
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <limits>
 #include <vector>
 
 #include "daliti_s2m.h"
 
 struct s2m_map_mirror {
-    std::vector<uint32_t> ids;   /* the ids of the points held, in no particular order after the first change ... */
-    std::vector<float> xyz;      /* ... 3 floats per point, same order */
     uint64_t token = 0;
+    int lag = 0;                 /* s2m_map_changes.lag: 1 = take the report of the previous call (nobody waits for the device) */
     int64_t resyncs = 0;         /* times the whole map had to be fetched (first call, a rebuild, a log overflow) */
-    int64_t last_added = 0, last_removed = 0;
+    int64_t last_added = 0, last_removed = 0, last_boxes = 0;
+    int64_t missed = 0;          /* removals that found no point (0 unless the follower and the engine are out of step) */
 
-    /* brings the mirror to the engine's current map; returns an S2M_* code.  Cost: the changes, not the map -- a removed id is
-     * found through a direct-address table (id -> slot) and its slot refilled from the end of the arrays. */
+    int64_t size() const { return live_; }
+    /* the points held, bucket by bucket (no particular order); ids optional.  xyz: 3 * size() floats */
+    void copy_points(float *xyz, uint32_t *ids = nullptr) const
+    {
+        size_t at = 0;
+        for (const Bucket &b : buckets_)
+            for (const Pt &q : b.pts) {
+                if (q.x != q.x) continue;   /* a mark */
+                xyz[3 * at] = q.x; xyz[3 * at + 1] = q.y; xyz[3 * at + 2] = q.z;
+                if (ids) ids[at] = q.id;
+                ++at;
+            }
+    }
+    template <class F>
+    void for_each(F f) const   /* f(id, x, y, z) */
+    {
+        for (const Bucket &b : buckets_)
+            for (const Pt &q : b.pts)
+                if (q.x == q.x) f(q.id, q.x, q.y, q.z);
+    }
+    /* bytes the mirror holds (tests: it follows the live points, not the ids ever issued) */
+    size_t memory_bytes() const
+    {
+        size_t s = table_.capacity() * sizeof(Slot) + buckets_.capacity() * sizeof(Bucket) + free_.capacity() * sizeof(int32_t);
+        for (const Bucket &b : buckets_) s += b.pts.capacity() * sizeof(Pt);
+        s += (add_xyz_.capacity() + rem_xyz_.capacity() + box_.capacity()) * sizeof(float) + (add_ids_.capacity() + rem_ids_.capacity()) * sizeof(uint32_t);
+        return s;
+    }
+
+    /* brings the mirror to the engine's map (lag = 1: to the map as it was at the previous call); returns an S2M_* code.
+     * = fetch + apply: fetch talks to the engine (the handle's own thread), apply works on the mirror alone -- a node may run it
+     * on its publishing thread */
     int update(s2m_engine *e)
     {
-        if (add_xyz_.empty()) { add_xyz_.resize(3 * 65536); add_ids_.resize(65536); rem_ids_.resize(65536); }
+        const int rc = fetch(e);
+        if (rc != S2M_OK) return rc;
+        apply();
+        return S2M_OK;
+    }
+    int fetch(s2m_engine *e)
+    {
+        if (add_ids_.empty()) reserve_io(65536, 65536);
         for (;;) {
-            int64_t na = 0, nr = 0;
-            int32_t resync = 0;
-            int rc = s2m_map_get_changes(e, &token, add_xyz_.data(), add_ids_.data(), (int64_t)add_ids_.size(), &na, rem_ids_.data(),
-                                         (int64_t)rem_ids_.size(), &nr, &resync);
+            std::memset(&c_, 0, sizeof(c_));
+            c_.added_xyz = add_xyz_.data(); c_.added_ids = add_ids_.data(); c_.capacity_added = (int64_t)add_ids_.size();
+            c_.removed_xyz = rem_xyz_.data(); c_.removed_ids = rem_ids_.data(); c_.capacity_removed = (int64_t)rem_ids_.size();
+            c_.boxes = box_.data(); c_.box_after_added = box_a_.data(); c_.box_after_removed = box_r_.data(); c_.capacity_boxes = (int64_t)box_a_.size();
+            c_.lag = lag;
+            int rc = s2m_map_get_changes(e, &token, &c_);
             if (rc == S2M_ERR_CAPACITY) {  /* the counts came back: make room and ask again (the changes were kept) */
-                if ((int64_t)add_ids_.size() < na) { add_ids_.resize((size_t)na * 2); add_xyz_.resize(add_ids_.size() * 3); }
-                if ((int64_t)rem_ids_.size() < nr) rem_ids_.resize((size_t)nr * 2);
+                reserve_io(std::max<int64_t>(c_.n_added * 2, (int64_t)add_ids_.size()), std::max<int64_t>(c_.n_removed * 2, (int64_t)rem_ids_.size()));
+                if ((int64_t)box_a_.size() < c_.n_boxes) { box_.resize((size_t)c_.n_boxes * 6); box_a_.resize((size_t)c_.n_boxes); box_r_.resize((size_t)c_.n_boxes); }
                 continue;
             }
-            if (rc != S2M_OK) return rc;
-            if (resync) {
-                int64_t m = 0;
-                rc = s2m_map_get_points(e, nullptr, 0, &m);
-                if (rc != S2M_OK) return rc;
-                xyz.resize((size_t)std::max<int64_t>(m, 1) * 3);
-                ids.resize((size_t)std::max<int64_t>(m, 1));
-                rc = s2m_map_get_points(e, xyz.data(), m, &m);
-                if (rc == S2M_OK) rc = s2m_map_get_ids(e, ids.data(), m, &m);
-                if (rc != S2M_OK) return rc;
-                xyz.resize((size_t)m * 3);
-                ids.resize((size_t)m);
-                slot_.assign(slot_.size(), kNone);
-                for (size_t i = 0; i < ids.size(); ++i) place(ids[i], (uint32_t)i);
-                ++resyncs;
-                last_added = last_removed = 0;
-                return S2M_OK;
-            }
-            last_added = na;
-            last_removed = nr;
-            /* additions first: a point that came and went between two calls is in both lists */
-            for (int64_t i = 0; i < na; ++i) {
-                place(add_ids_[(size_t)i], (uint32_t)ids.size());
-                ids.push_back(add_ids_[(size_t)i]);
-                xyz.insert(xyz.end(), add_xyz_.begin() + 3 * i, add_xyz_.begin() + 3 * i + 3);
-            }
-            for (int64_t k = 0; k < nr; ++k) {
-                const uint32_t id = rem_ids_[(size_t)k];
-                if (id >= slot_.size() || slot_[id] == kNone) continue;
-                const uint32_t at = slot_[id], last = (uint32_t)ids.size() - 1u;
-                slot_[id] = kNone;
-                if (at != last) {
-                    ids[at] = ids[last];
-                    xyz[3 * (size_t)at] = xyz[3 * (size_t)last]; xyz[3 * (size_t)at + 1] = xyz[3 * (size_t)last + 1];
-                    xyz[3 * (size_t)at + 2] = xyz[3 * (size_t)last + 2];
-                    slot_[ids[at]] = at;
-                }
-                ids.pop_back();
-                xyz.resize(xyz.size() - 3);
-            }
+            if (rc != S2M_OK) { c_.n_added = c_.n_removed = c_.n_boxes = 0; return rc; }
+            if (c_.resync) { c_.n_added = c_.n_removed = c_.n_boxes = 0; return refetch(e); }
             return S2M_OK;
+        }
+    }
+    /* what the last fetch brought, stretch by stretch: additions, then removals, then the box that closes the stretch */
+    void apply()
+    {
+        last_added = c_.n_added; last_removed = c_.n_removed; last_boxes = c_.n_boxes;
+        int64_t a0 = 0, r0 = 0;
+        for (int64_t k = 0; k <= c_.n_boxes; ++k) {
+            const int64_t a1 = k < c_.n_boxes ? box_a_[(size_t)k] : c_.n_added, r1 = k < c_.n_boxes ? box_r_[(size_t)k] : c_.n_removed;
+            add_many(a0, a1);
+            remove_many(r0, r1);
+            if (k < c_.n_boxes) delete_box(&box_[6 * (size_t)k]);
+            a0 = a1; r0 = r1;
+        }
+        c_.n_added = c_.n_removed = c_.n_boxes = 0;
+    }
+
+    /* ---- the pieces update() is made of, public so that they can be tested without a device ---- */
+    void clear()
+    {
+        buckets_.clear(); free_.clear(); table_.clear(); used_ = 0; live_ = 0; last_ = -1;
+    }
+    void add(uint32_t id, const float *p)
+    {
+        Bucket &b = bucket_of(p, true);
+        b.pts.push_back(Pt{p[0], p[1], p[2], id});
+        ++live_;
+    }
+    bool remove(uint32_t id, const float *p)
+    {
+        const int32_t at = find_bucket(key_of(p));
+        if (at < 0) { ++missed; return false; }
+        Bucket &b = buckets_[(size_t)at];
+        size_t lo = 0, n = b.pts.size();   /* ids ascend inside a bucket: the first entry with id >= the one asked for */
+        while (n > 0) {
+            const size_t half = n >> 1;
+            if (b.pts[lo + half].id < id) { lo += half + 1; n -= half + 1; } else n = half;
+        }
+        if (lo == b.pts.size() || b.pts[lo].id != id || b.pts[lo].x != b.pts[lo].x) { ++missed; return false; }
+        mark(b, lo);
+        settle(at);
+        return true;
+    }
+    /* Delete_Point_Boxes for one box {min xyz, max xyz}: a point goes when min <= p < max on every axis */
+    void delete_box(const float *box)
+    {
+        for (size_t at = 0; at < buckets_.size(); ++at) {
+            Bucket &b = buckets_[at];
+            if (b.pts.empty()) continue;
+            bool inside = true, apart = false;
+            for (int k = 0; k < 3; ++k) {
+                const double lo = kEdge * (double)b.c[k], hi = lo + kEdge;   /* the bucket holds lo <= p < hi exactly */
+                inside = inside && (double)box[k] <= lo && hi <= (double)box[3 + k];
+                apart = apart || hi <= (double)box[k] || lo >= (double)box[3 + k];
+            }
+            if (apart) continue;
+            if (inside) {
+                live_ -= (int64_t)b.pts.size() - (int64_t)b.dead;
+                release((int32_t)at);
+                continue;
+            }
+            for (size_t i = 0, n = b.pts.size(); i < n; ++i) {
+                const Pt &q = b.pts[i];
+                if (q.x >= box[0] && q.x < box[3] && q.y >= box[1] && q.y < box[4] && q.z >= box[2] && q.z < box[5]) mark(b, i);   /* (a mark's NaN fails) */
+            }
+            settle((int32_t)at);
         }
     }
 
   private:
-    static constexpr uint32_t kNone = 0xffffffffu;
-    void place(uint32_t id, uint32_t at)
+    static constexpr double kEdge = 4.0;   /* metres; a power of two: floor(p / 4) and 4 * c are exact in double */
+    struct Pt { float x, y, z; uint32_t id; };
+    struct Bucket {
+        int32_t c[3] = {0, 0, 0};
+        uint32_t dead = 0;
+        std::vector<Pt> pts;      /* ids ascending; a removed point stays as a mark (x = NaN) until the bucket is compacted */
+    };
+    struct Slot { uint64_t key; int32_t at; int32_t pad; };   /* at < 0: empty */
+    static constexpr uint64_t kBias = (uint64_t)1 << 20;
+
+    static uint64_t key_of(const float *p)
     {
-        if (id >= slot_.size()) slot_.resize((size_t)id + (size_t)id / 2 + 1024, kNone);
-        slot_[id] = at;
+        uint64_t k = 0;
+        for (int q = 0; q < 3; ++q) {
+            const double v = (double)p[q] * (1.0 / kEdge);
+            int64_t c = (int64_t)v;          /* floor without the library call */
+            c -= (v < (double)c) ? 1 : 0;
+            k = (k << 21) | (uint64_t)(c + (int64_t)kBias);
+        }
+        return k;
     }
-    std::vector<float> add_xyz_;
-    std::vector<uint32_t> add_ids_, rem_ids_, slot_;   /* slot_[id] = where the point sits in ids / xyz */
+    static size_t hash(uint64_t k)
+    {
+        k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+        return (size_t)k;
+    }
+    int32_t find_bucket(uint64_t key)
+    {
+        if (last_ >= 0 && last_key_ == key) return last_;
+        if (table_.empty()) return -1;
+        const size_t mask = table_.size() - 1;
+        for (size_t i = hash(key) & mask;; i = (i + 1) & mask) {
+            if (table_[i].at < 0) return -1;
+            if (table_[i].key == key) { last_ = table_[i].at; last_key_ = key; return last_; }
+        }
+    }
+    Bucket &bucket_of(const float *p, bool)
+    {
+        const uint64_t key = key_of(p);
+        int32_t at = find_bucket(key);
+        if (at >= 0) return buckets_[(size_t)at];   /* (possibly one that a trim emptied: it kept its place in the table) */
+        if ((used_ + 1) * 2 > table_.size()) rehash();
+        if (!free_.empty()) { at = free_.back(); free_.pop_back(); }
+        else { at = (int32_t)buckets_.size(); buckets_.emplace_back(); }
+        Bucket &b = buckets_[(size_t)at];
+        for (int q = 0; q < 3; ++q) b.c[q] = (int32_t)((int64_t)((key >> (21 * (2 - q))) & 0x1fffff) - (int64_t)kBias);
+        b.dead = 0;
+        insert_slot(key, at);
+        ++used_;
+        last_ = at; last_key_ = key;
+        return b;
+    }
+    void insert_slot(uint64_t key, int32_t at)
+    {
+        const size_t mask = table_.size() - 1;
+        size_t i = hash(key) & mask;
+        while (table_[i].at >= 0) i = (i + 1) & mask;
+        table_[i].key = key; table_[i].at = at;
+    }
+    /* the table grows -- or only sheds the buckets that trims have emptied since (they keep their slot until now, so that a
+     * trim does not pay for thousands of deletions from the table) */
+    void rehash()
+    {
+        std::vector<Slot> old;
+        old.swap(table_);
+        size_t keep = 0;
+        for (const Slot &s : old)
+            if (s.at >= 0 && !buckets_[(size_t)s.at].pts.empty()) ++keep;
+        size_t cap = 1024;
+        while (cap < 4 * (keep + 1)) cap *= 2;
+        table_.assign(cap, Slot{0, -1, 0});
+        used_ = 0;
+        for (const Slot &s : old) {
+            if (s.at < 0) continue;
+            if (buckets_[(size_t)s.at].pts.empty()) { free_.push_back(s.at); continue; }
+            insert_slot(s.key, s.at);
+            ++used_;
+        }
+        last_ = -1;
+    }
+    /* the bucket gives its memory back; its slot in the table and its place in the pool are shed by the next rehash */
+    void release(int32_t at)
+    {
+        Bucket &b = buckets_[(size_t)at];
+        std::vector<Pt>().swap(b.pts);
+        b.dead = 0;
+    }
+    void mark(Bucket &b, size_t i)
+    {
+        b.pts[i].x = std::numeric_limits<float>::quiet_NaN();
+        ++b.dead;
+        --live_;
+    }
+    /* after marks: an empty bucket leaves, one that is more marks than points is compacted (ids stay ascending) */
+    void settle(int32_t at)
+    {
+        Bucket &b = buckets_[(size_t)at];
+        if (b.dead == 0) return;
+        if ((size_t)b.dead == b.pts.size()) { release(at); return; }
+        if ((size_t)b.dead * 2 <= b.pts.size()) return;
+        size_t w = 0;
+        for (size_t i = 0, n = b.pts.size(); i < n; ++i)
+            if (b.pts[i].x == b.pts[i].x) b.pts[w++] = b.pts[i];
+        b.pts.resize(w);
+        b.dead = 0;
+    }
+    /* The fetched additions [a0, a1) and removals [r0, r1).  A point's way to its place is a chain of dependent loads (table
+     * slot -> bucket -> the end of its array, or a binary search): done point by point the loads of one point wait for each
+     * other and the next point waits for them all.  In passes over the whole stretch -- find every bucket, then touch every
+     * bucket's memory, then write -- the misses of different points are in flight together. */
+    void add_many(int64_t a0, int64_t a1)
+    {
+        const size_t n = (size_t)(a1 - a0);
+        if (n == 0) return;
+        where_.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            const float *p = &add_xyz_[3 * ((size_t)a0 + i)];
+            Bucket &b = bucket_of(p, true);
+            where_[i] = (int32_t)(&b - buckets_.data());
+        }
+        for (size_t i = 0; i < n; ++i) {
+            const Bucket &b = buckets_[(size_t)where_[i]];
+            if (!b.pts.empty()) __builtin_prefetch(&b.pts.back() + 1, 1);
+        }
+        for (size_t i = 0; i < n; ++i) {
+            const float *p = &add_xyz_[3 * ((size_t)a0 + i)];
+            buckets_[(size_t)where_[i]].pts.push_back(Pt{p[0], p[1], p[2], add_ids_[(size_t)a0 + i]});
+        }
+        live_ += (int64_t)n;
+    }
+    void remove_many(int64_t r0, int64_t r1)
+    {
+        const size_t n = (size_t)(r1 - r0);
+        if (n == 0) return;
+        where_.resize(n);
+        for (size_t i = 0; i < n; ++i) where_[i] = find_bucket(key_of(&rem_xyz_[3 * ((size_t)r0 + i)]));
+        /* the binary searches level by level, all points abreast: lo_ / len_ are every search's window */
+        lo_.assign(n, 0);
+        len_.resize(n);
+        size_t longest = 0;
+        for (size_t i = 0; i < n; ++i) {
+            len_[i] = where_[i] >= 0 ? (uint32_t)buckets_[(size_t)where_[i]].pts.size() : 0u;
+            longest = std::max<size_t>(longest, len_[i]);
+        }
+        for (; longest > 0; longest >>= 1) {
+            for (size_t i = 0; i < n; ++i) {
+                if (len_[i] == 0) continue;
+                const Bucket &b = buckets_[(size_t)where_[i]];
+                const uint32_t half = len_[i] >> 1;
+                if (b.pts[lo_[i] + half].id < rem_ids_[(size_t)r0 + i]) { lo_[i] += half + 1; len_[i] -= half + 1; } else len_[i] = half;
+                if (len_[i] > 0) __builtin_prefetch(&b.pts[lo_[i] + (len_[i] >> 1)]);
+            }
+        }
+        for (size_t i = 0; i < n; ++i) {
+            if (where_[i] < 0) { ++missed; continue; }
+            Bucket &b = buckets_[(size_t)where_[i]];
+            const size_t at = lo_[i];
+            if (at >= b.pts.size() || b.pts[at].id != rem_ids_[(size_t)r0 + i] || b.pts[at].x != b.pts[at].x) { ++missed; continue; }
+            mark(b, at);
+        }
+        for (size_t i = 0; i < n; ++i)
+            if (where_[i] >= 0) settle(where_[i]);
+    }
+    int refetch(s2m_engine *e)
+    {
+        int64_t m = 0;
+        int rc = s2m_map_get_points(e, nullptr, 0, &m);
+        if (rc != S2M_OK) return rc;
+        std::vector<float> xyz((size_t)std::max<int64_t>(m, 1) * 3);
+        std::vector<uint32_t> ids((size_t)std::max<int64_t>(m, 1));
+        rc = s2m_map_get_points(e, xyz.data(), m, &m);
+        if (rc == S2M_OK) rc = s2m_map_get_ids(e, ids.data(), m, &m);
+        if (rc != S2M_OK) return rc;
+        clear();
+        for (int64_t i = 0; i < m; ++i) add(ids[(size_t)i], &xyz[3 * (size_t)i]);   /* ascending ids: every bucket's ids ascend */
+        ++resyncs;
+        last_added = last_removed = last_boxes = 0;
+        return S2M_OK;
+    }
+    void reserve_io(int64_t na, int64_t nr)
+    {
+        add_ids_.resize((size_t)na); add_xyz_.resize((size_t)na * 3);
+        rem_ids_.resize((size_t)nr); rem_xyz_.resize((size_t)nr * 3);
+        if (box_a_.empty()) { box_.resize(6 * 64); box_a_.resize(64); box_r_.resize(64); }
+    }
+
+    std::vector<Bucket> buckets_;
+    std::vector<int32_t> free_;
+    std::vector<Slot> table_;
+    size_t used_ = 0;
+    int64_t live_ = 0;
+    int32_t last_ = -1;
+    uint64_t last_key_ = 0;
+    std::vector<float> add_xyz_, rem_xyz_, box_;
+    std::vector<uint32_t> add_ids_, rem_ids_;
+    std::vector<int64_t> box_a_, box_r_;
+    s2m_map_changes c_ = {};   /* what the last fetch brought and apply() has not applied yet */
+    std::vector<int32_t> where_;
+    std::vector<uint32_t> lo_, len_;
 };
 
 #endif /* DALITI_S2M_MIRROR_HPP */

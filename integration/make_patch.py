@@ -173,15 +173,16 @@ FLATTEN = r'''#ifdef DALITI_S2M
                 {   // only when somebody listens to /Laser_map; the host mirror takes this frame's changes from the
                     // engine (daliti_s2m_mirror.hpp: a few thousand points cross PCIe, not the map)
                     s2m_check(s2m_mirror.update(s2m_eng), "s2m_map_get_changes");
-                    const int64_t s2m_m = (int64_t)s2m_mirror.ids.size();
                     featsFromMap->clear();
-                    featsFromMap->points.resize(s2m_m);
-                    for (int64_t i = 0; i < s2m_m; i++)
+                    featsFromMap->points.resize(s2m_mirror.size());
+                    int64_t s2m_i = 0;
+                    s2m_mirror.for_each([&](uint32_t, float px, float py, float pz)
                     {
-                        featsFromMap->points[i].x = s2m_mirror.xyz[3 * i];
-                        featsFromMap->points[i].y = s2m_mirror.xyz[3 * i + 1];
-                        featsFromMap->points[i].z = s2m_mirror.xyz[3 * i + 2];
-                    }
+                        featsFromMap->points[s2m_i].x = px;
+                        featsFromMap->points[s2m_i].y = py;
+                        featsFromMap->points[s2m_i].z = pz;
+                        s2m_i++;
+                    });
                 }
 #else
 '''

@@ -40,7 +40,7 @@ ms = r["ms"][warm:]
 how = r["how"][warm:]
 err = np.linalg.norm(r["x"][:, 9:12] - sw["x_true"][:frames + warm, 9:12], axis=1)
 print("frames %d step %.1f m: median %.3f p99 %.3f max %.3f ms, max/median %.2f" % (frames, step, np.median(ms), np.percentile(ms, 99), ms.max(), ms.max() / np.median(ms)))
-print("how: in place %d, merged %d, rebuilt %d; stats delta %s" % ((how == 2).sum(), (how == 1).sum(), (how == 0).sum(), {k: (st1[k] - st0[k]) if not isinstance(st1[k], dict) else st1[k] for k in st1}))
+print("how: in place %d, relaid %d, rebuilt %d; stats delta %s" % ((how == 2).sum(), (how == 1).sum(), (how == 0).sum(), {k: (st1[k] - st0[k]) if not isinstance(st1[k], dict) else st1[k] for k in st1}))
 print("deleted by trim:", [(int(i), int(d)) for i, d in enumerate(r["deleted"]) if d > 0])
 print("scan pts after voxel grid: mean %d; iters mean %.2f; pose err vs truth: median %.4f max %.4f m; map size %d; bets %s" % (
     r["n_scan"].mean(), r["iters"].mean(), np.median(err), err.max(), e.map_size(), e.bet_stats()))

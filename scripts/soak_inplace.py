@@ -80,6 +80,6 @@ for k, (ra, rb) in enumerate(zip(a, b)):
         print("step %d differs: sizes %d / %d" % (k, ra[0], rb[0]))
         if bad > 5:
             break
-print("soak: %d steps, seed %d: %s; in place %d of %d merged-or-in-place updates (%d rebuilt); all-merge run: %d in place" % (
-    steps, seed, "IDENTICAL" if bad == 0 else "%d steps differ" % bad, sa[0], sa[1]["merged"], sa[1]["rebuilt"], sb[0]))
+print("soak: %d steps, seed %d: %s; in place %d, relaid %d, rebuilt %d; all-merge run: %d in place" % (
+    steps, seed, "IDENTICAL" if bad == 0 else "%d steps differ" % bad, sa[0], sa[1]["relaid"], sa[1]["rebuilt"], sb[0]))
 sys.exit(1 if bad else 0)

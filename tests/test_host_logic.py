@@ -254,3 +254,16 @@ def test_host_point_residual_and_jacobian_rows_are_bit_identical_to_oracle(oracl
         assert (z == ps.meas.view(np.uint64)).all()
         if ext:
             assert np.abs(ps.Hsub[:, 6:]).max() > 0
+
+
+def test_map_mirror_follows_the_live_points_not_the_ids(tmp_path):
+    """include/daliti_s2m_mirror.hpp without a device (tests/mirror_check.cpp, ASan + UBSan): 400 rounds of additions, one-by-one
+    removals and box deletes against a plain id -> point map while the ids run past 2^30 and the live set stays near 10^5:
+    the same points after every trim, whole buckets dropped, cut buckets filtered with min <= p < max, and the mirror's memory a
+    few dozen bytes per LIVE point (the id-indexed table it replaces would be 4 GB there: VERDICT r5 #3)."""
+    exe = str(tmp_path / "mirror_check")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-Wall", "-Werror",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "mirror_check.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bytes per live point" in r.stdout

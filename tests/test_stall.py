@@ -140,7 +140,7 @@ def test_multi_handle_update_whose_block_never_arrives_times_out(small_scene):
 
 def _mail_calls():
     def changes(e, sc):
-        tok, _, _, _, _ = e.map_changes(0)
+        tok = e.map_changes(0).token
         e.map_add(sc["scan"][:64] + np.float32(0.3), True, 0.5)
         e.test_stall("mail", 0)
         e.map_changes(tok)

@@ -239,7 +239,7 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
                             int32_t time_off_a, int32_t time_off_b, const s2m_imu_pose *poses, int32_t n_poses, const double *x_prop,
                             const double *P0, float leaf, double filter_size_map, double cube_len, int32_t prefetch, double *x_out,
                             double *frame_us, int32_t *how, int64_t *deleted, int64_t *n_scan, s2m_iter_log *logs, int32_t *allocs,
-                            int32_t publish, double *publish_us, int64_t *mirror_stats, double *stage_us)
+                            int32_t publish, double *publish_us, int64_t *mirror_stats, double *stage_us, double *fetch_us)
 {
     if (!e || frames < 0 || warm < 0 || !rec || !n || !poses || !x_prop || !P0 || !x_out || !frame_us || !how) return S2M_ERR_ARG;
     double P[S2M_DIM * S2M_DIM];
@@ -248,11 +248,12 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
     int64_t inplace_before = 0;
     int rc = s2m_map_inplace_updates(e, &inplace_before);
     if (rc) return rc;
-    int64_t st_prev[10] = {0};
+    int64_t st_prev[12] = {0};
     (void)s2m_map_update_stats(e, st_prev);
     // publish != 0: the node also keeps /Laser_map up to date every frame (laserMapping.cpp:1170-1175, 1229-1235) -- a host
     // mirror fed by s2m_map_get_changes (daliti_s2m_mirror.hpp); publish_us[f] = that call's share of the frame
     s2m_map_mirror mirror;
+    mirror.lag = publish == 2 ? 1 : 0;   // publish: 1 = the map as it is now (the call waits for the device), 2 = one call behind (nobody waits)
     if (publish) {
         rc = mirror.update(e);  // the one whole-map fetch, before the drive
         if (rc) return rc;
@@ -331,8 +332,10 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         if (publish) {
             const auto tp = std::chrono::steady_clock::now();
             stall.at(f, 6);
-            rc = mirror.update(e);
+            rc = mirror.fetch(e);    // the engine's side of it: what changed, out of pinned memory into the mirror's arrays
             if (rc) return rc;
+            if (fetch_us) fetch_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp).count();
+            mirror.apply();          // the follower's side: could run on the node's publishing thread
             if (publish_us) publish_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp).count();
         }
         frame_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -340,16 +343,21 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         if (deleted) deleted[f] = nd;
         if (n_scan) n_scan[f] = n_out;
         if (allocs) {  // device buffers (re)allocated by the map code during this frame (each one stalls the stream)
-            int64_t st_now[10] = {0};
+            int64_t st_now[12] = {0};
             (void)s2m_map_update_stats(e, st_now);
             allocs[f] = (int32_t)(st_now[3] - st_prev[3]);
             st_prev[3] = st_now[3];
         }
     }
+    if (publish && mirror.lag != 0) {  // (untimed: a follower that is one call behind catches up before it is compared with the map)
+        mirror.lag = 0;
+        rc = mirror.update(e);
+        if (rc) return rc;
+    }
     if (publish && mirror_stats) {
         int64_t m = 0;
         (void)s2m_map_size(e, &m);
-        mirror_stats[0] = (int64_t)mirror.ids.size();
+        mirror_stats[0] = mirror.size();
         mirror_stats[1] = m;
         mirror_stats[2] = mirror.resyncs;
     }

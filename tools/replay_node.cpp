@@ -162,7 +162,11 @@ int main(int argc, char **argv)
 
     bool first_scan = true, have_map = false;
     s2m_map_mirror mirror;
-    std::vector<uint8_t> map_msgs;
+    // /Laser_map is streamed to its file as it is produced (one whole-map message per frame: kept in memory it would be
+    // frames x map points x 48 bytes), through buffers that are reused
+    std::vector<uint8_t> map_msg;
+    std::vector<float> map_rec;
+    std::ofstream fm;
     double first_lidar_time = 0.0;
     std::vector<float> xyz, world;
     std::vector<int32_t> ridx;
@@ -251,10 +255,17 @@ int main(int argc, char **argv)
         {   // ikdtree.flatten -> featsFromMap -> /Laser_map (:1170-1175, 1229-1235), every frame: the mirror takes this frame's
             // changes (a few thousand points) and is published as it stands
             CK(mirror.update(eng));
-            const size_t m = mirror.ids.size();
-            std::vector<float> rec(m * S2M_PXYZIN_FLOATS, 0.0f);
-            for (size_t i = 0; i < m; ++i) std::memcpy(&rec[i * S2M_PXYZIN_FLOATS], &mirror.xyz[3 * i], 3 * sizeof(float));
-            append_msg(map_msgs, 1, f, obs_end, rec.data(), (uint32_t)m);
+            const size_t m = (size_t)mirror.size();
+            map_rec.assign(m * S2M_PXYZIN_FLOATS, 0.0f);
+            size_t i = 0;
+            mirror.for_each([&](uint32_t, float px, float py, float pz) {
+                float *r = &map_rec[i++ * S2M_PXYZIN_FLOATS];
+                r[0] = px; r[1] = py; r[2] = pz;
+            });
+            map_msg.clear();
+            append_msg(map_msg, 1, f, obs_end, map_rec.data(), (uint32_t)m);
+            if (!fm.is_open()) fm.open(dir + "/laser_map.pc2s", std::ios::binary);
+            fm.write(reinterpret_cast<const char *>(map_msg.data()), (std::streamsize)map_msg.size());
         }
         fodom << lidar_beg_time - first_lidar_time;
         for (int i = 0; i < 3; ++i) fodom << " " << x[9 + i];
@@ -267,8 +278,8 @@ int main(int argc, char **argv)
         fe.write(reinterpret_cast<const char *>(effected_msgs.data()), (std::streamsize)effected_msgs.size());
     }
     if (have_map) {
-        std::ofstream fm(dir + "/laser_map.pc2s", std::ios::binary);
-        fm.write(reinterpret_cast<const char *>(map_msgs.data()), (std::streamsize)map_msgs.size());
+        if (!fm.is_open()) fm.open(dir + "/laser_map.pc2s", std::ios::binary);   // (no frame behind the seed: an empty file, as before)
+        fm.close();
         std::fprintf(stderr, "replay_node: /Laser_map followed through the change log: %lld whole-map fetches in %u frames\n",
                      (long long)mirror.resyncs, n_frames);
     }
