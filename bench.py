@@ -116,7 +116,9 @@ def parse(argv=None):
     ap.add_argument("--py-loop", action="store_true",
                     help="drive the timed steps from Python (one ctypes call per step) instead of tools/bench_loop.cpp")
     ap.add_argument("--frames", type=int, default=64, help="frames of the frame_pipeline side leg")
-    ap.add_argument("--moving-frames", type=int, default=520, help="frames of the frame_pipeline_moving side leg (0: skip it)")
+    ap.add_argument("--moving-frames", type=int, default=1100,
+                    help="frames of the frame_pipeline_moving side leg (0: skip it); 1100 at 1 m per frame is what the hall holds, and past "
+                         "the point (~ frame 770) where round 5's engine ran out of spare table rows and re-laid the map inside a frame")
     ap.add_argument("--moving-step", type=float, default=1.0, help="metres the sensor advances per frame in that leg")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="skip the two child rocprofv3 --pmc passes that measure roofline.traffic in this run")
@@ -1214,7 +1216,9 @@ def frame_pipeline_moving(torch, Engine, synth, a):
     times as long, seeded with C3's 5 M points over its first square section; a 64-beam sensor sweeps 65 536 rays per
     frame while it advances `--moving-step` metres (returns beyond 150 m dropped), every frame's predicted pose = truth [+]
     an IMU-sized error (2 cm, 0.1 deg); cube_len 1000 m (feat.yaml) so that lasermap_fov_segment moves the local-map cube
-    every 150 m and deletes the slab behind it.  One C++ loop (tools/bench_loop.cpp, s2m_bench_frames_moving), front half of
+    every 150 m and deletes the slab behind it.  The drive is long enough to wear the layout out (tail, spare table rows) and, once
+    the trim has removed the dense seed, to leave the grid a factor of two too fine for what the voxel rule keeps: the new layouts
+    are produced beside the frames (s2m_engine_relay.cpp; `updates.relaid_beside_the_frames`).  One C++ loop (tools/bench_loop.cpp, s2m_bench_frames_moving), front half of
     frame k + 1 beside frame k's map update as in `frame_pipeline`.  Host-timed per frame."""
     from daliti_amd.world import World, run_frames
     frames, step, warm = a.moving_frames, a.moving_step, 8

@@ -150,6 +150,7 @@ int s2m_config_default(s2m_config *c)
     c->wait_policy = 0;
     c->wait_timeout_ms = 10000;
     c->wait_spin_us = 40;
+    c->layout_beside = 1;
     return S2M_OK;
 }
 
@@ -213,6 +214,11 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
         e->wait.stall_after.store(colon == std::string::npos ? 0 : std::atol(v.c_str() + colon + 1));
     }
     e->wait.hosttime = std::getenv("S2M_HOSTTIME") != nullptr;
+    e->relay.enabled = std::getenv("S2M_NO_BESIDE") == nullptr;
+    if (const char *g = std::getenv("S2M_BESIDE_AT")) {   // test hook: a layout beside the frames behind the n-th update [",regrid": with a new cell size]
+        e->relay.force_at = std::atol(g);
+        e->relay.force_regrid = std::strstr(g, "regrid") != nullptr;
+    }
     if (const char *g = std::getenv("S2M_WIDE_ADDR"))  // test hook: 64-bit point addresses on a small map
         if (std::atoi(g) != 0) e->match_group |= 0x10000;
     if (const char *g = std::getenv("S2M_EASY_NB")) {  // test hook: both first-shell instantiations on any scan size
@@ -270,6 +276,10 @@ int s2m_destroy(s2m_engine *e)
         else { e->pf.worker.detach(); drained = false; }
     }
     if (drained && e->pf.stream) drained = wait_stream(&e->wait, e->pf.stream, "the side stream (s2m_destroy)") != kWaitTimedOut;
+    if (drained) {
+        relay_shutdown(e);
+        drained = e->relay.exited.load() != 0 || !e->relay.worker.joinable();
+    }
     tl_wait = nullptr;
     if (!drained) return S2M_ERR_TIMEOUT;  // (the handle is leaked on purpose)
     if (e->pf.stream) (void)hipStreamDestroy(e->pf.stream);

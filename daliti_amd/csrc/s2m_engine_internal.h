@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <new>
@@ -34,6 +35,11 @@
 #include "s2m_kernels.h"
 
 namespace s2m {
+// s2m_relay.hip
+void launch_snapshot(const float4 *pts, const uint32_t *pidx, int64_t m, float4 *out, uint32_t *count, int64_t cap, hipStream_t st);
+void launch_remap_ids(uint32_t *pidx, int64_t m, const float4 *snap, hipStream_t st);
+void launch_count_cells(const uint32_t *bricks_dev, int64_t bricks_bound, const uint32_t *tab, uint32_t *cells_dev, uint32_t *host_dev, uint32_t seq,
+                        hipStream_t st);
 void launch_deinterleave(const float *src, int64_t stride, int64_t n, float *sx, float *sy, float *sz,
                          hipStream_t st);
 void launch_scan_reset(int64_t n, uint8_t *sel, uint8_t *eff, uint8_t *flags, hipStream_t st);
@@ -181,6 +187,52 @@ struct s2m_engine {
     int32_t loop_gen = 0;              // generation of the enqueued plan (a re-plan after a wrong prediction takes a new one)
     std::vector<int8_t> sched_hist;    // which iterations of the last scan searched: the plan for the next one
 
+    // ---- the layout beside the frames (s2m_engine_relay.cpp): a second map that a worker thread builds from a snapshot on
+    // its own stream and brings up to date by running the update calls that arrived meanwhile again; swapped in between two
+    // updates.  What ikd-Tree's rebuild thread does for a subtree (ikd_Tree.cpp:192-203, 229-367).
+    struct Relay {
+        enum State { kIdle = 0, kStarting, kSnapReady, kBuilding, kCaughtUp, kFailed };
+        struct Op {
+            int kind = 0;                  // 0: lists (update_add x 1 or 2), 1: boxes (update_delete)
+            int64_t off_a = 0, na = 0, off_b = 0, nb = 0;   // the lists' places in the arena
+            bool ds_a = false;
+            float fs = 0.0f;
+            bool has_vox = false;
+            VoxBox vox;
+            std::vector<float> boxes;
+            int64_t arena_end = 0;         // the arena is free up to here once the op is done
+        };
+        std::thread worker;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<Op> ops;                // under mu
+        std::atomic<int> state{kIdle}, busy{0}, quit{0}, exited{0}, cancel{0};
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_main = nullptr;      // recorded on the main stream behind what the worker is about to read
+        hipEvent_t ev_side = nullptr;      // recorded on the layout stream behind what it has written
+        MapBuffers map;                    // the other map: being built, or the previous live one waiting for the next turn
+        UpdateBuffers upd;
+        Grid grid{};
+        MapStats stats;
+        float built_cell = 0.0f;
+        float4 *snap = nullptr;            // the snapshot: live points with their ids
+        int64_t snap_cap = 0, snap_bound = 0;
+        uint32_t *snap_count = nullptr;    // device word
+        int64_t id_snap = 0;               // next_id of the live map at the snapshot
+        bool regrid = false;               // the new layout chooses its cell size from the density
+        float4 *arena = nullptr;           // the update calls' point lists on their way to the worker (a ring)
+        int64_t arena_cap = 0, arena_head = 0, arena_tail = 0;
+        // triggers
+        int64_t commits = 0, since_layout = 0, force_at = -1;
+        bool force_regrid = false, enabled = true;
+        uint32_t *d_cells = nullptr, *h_cells = nullptr, *h_cells_dev = nullptr;
+        uint32_t cells_seq = 0;
+        bool cells_posted = false;
+        int64_t cells_live = 0;            // live points when the count was posted
+        double density = 0.0;              // points per occupied cell, last count (0: not known)
+        std::string why;                   // what triggered the last layout (diagnostic)
+    } relay;
+
     EskfWork work;
     Comm comm;  // attached RCCL communicator (multi-GPU form), handle == nullptr when single GPU
     ShmExchange shm;               // or: host shared-memory exchange between the processes of one node (s2m_comm_init_shm)
@@ -204,6 +256,26 @@ int refuse_poisoned(s2m_engine *e);
 // everything enqueued on a stream of the handle has finished: hipStreamSynchronize under the handle's policy and deadline
 int sync_stream(s2m_engine *e, hipStream_t st, const char *what);
 std::string debug_state(const s2m_engine *e);
+// one of the handle's two maps with what belongs to it (s2m_engine_map.cpp)
+struct MapSide {
+    s2m::MapBuffers *map;
+    s2m::UpdateBuffers *upd;
+    s2m::Grid *grid;
+    s2m::MapStats *stats;
+    float *built_cell;
+    hipStream_t st;
+    bool live;
+};
+MapSide live_side(s2m_engine *e);
+void bind_update(s2m_engine *e, MapSide s);
+int commit_update(s2m_engine *e, MapSide s, const float *boxes, int nb);
+// the layout beside the frames (s2m_engine_relay.cpp)
+int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid);   // end of every update of the live map: triggers, snapshot
+int relay_record_lists(s2m_engine *e, const float4 *la, int64_t na, bool ds_a, float fs, const s2m::VoxBox *vox, const float4 *lb, int64_t nb);
+int relay_record_boxes(s2m_engine *e, const float *boxes, int nb);
+int relay_poll(s2m_engine *e);      // start of every update of the live map: swap when the other map has caught up
+int relay_cancel(s2m_engine *e);    // the live map is being replaced: whatever is in flight is dropped (waits for the worker to let go)
+void relay_shutdown(s2m_engine *e); // s2m_destroy
 s2m::Gates gates_of(const s2m_config &c);
 s2m::Pose pose_of(const double s[S2M_STATE_DOUBLES]);
 int check_config(const s2m_config *c);

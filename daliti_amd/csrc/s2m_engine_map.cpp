@@ -20,6 +20,8 @@ int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride, int64_t m, in
     const float *dev = nullptr;
     int rc = stage_cloud(e, xyz, stride, m, on_device, &dev);
     if (rc) return rc;
+    rc = relay_cancel(e);   // (a layout beside the frames belongs to the map that is being replaced)
+    if (rc) return rc;
     e->map_ready = false;
     e->map_borrowed = false;
     bool too_large = false;
@@ -39,7 +41,9 @@ int s2m_map_share(s2m_engine *e, const s2m_engine *owner)
     if (!owner->map_ready) return fail(e, S2M_ERR_STATE, "s2m_map_share: the owner has no map");
     if (owner->device != e->device) return fail(e, S2M_ERR_ARG, "s2m_map_share: handles on different devices");
     S2M_ENTER(e);
-    int rc = sync_stream(e, e->stream, "the borrower's stream (s2m_map_share)");
+    int rc = relay_cancel(e);
+    if (rc) return rc;
+    rc = sync_stream(e, e->stream, "the borrower's stream (s2m_map_share)");
     if (rc) return rc;
     rc = sync_stream(e, owner->stream, "the owner's stream (s2m_map_share)");  // the owner's build has finished
     if (rc) return rc;
@@ -59,28 +63,46 @@ int s2m_map_share(s2m_engine *e, const s2m_engine *owner)
     return S2M_OK;
 }
 
-namespace {
+}  // extern "C"
+namespace s2m_eng {
 // what the update kernels need to know about the map's layout (s2m_kernels.h, UpdateBuffers)
-void bind_update(s2m_engine *e)
+void bind_update(s2m_engine *e, MapSide s)
 {
-    e->upd.bmark = e->map.bmark;
-    e->upd.layout_gen = e->map.layout_gen;
-    e->upd.reserve_hint = std::max(e->upd.reserve_hint, e->n_cap);
+    s.upd->bmark = s.map->bmark;
+    s.upd->layout_gen = s.map->layout_gen;
+    s.upd->reserve_hint = std::max(s.upd->reserve_hint, e->n_cap);
 }
 
+MapSide live_side(s2m_engine *e) { return MapSide{&e->map, &e->upd, &e->grid, &e->stats, &e->built_cell, e->stream, true}; }
+
 // the map after an update: merged into the sorted arrays when possible (s2m_mapedit.hip: in place, else merge_update), else rebuilt
-// from upd.list (survivors in index order, then the staged points) -- the same caller order either way
-// boxes / nb: the update is a box delete (s2m_map_delete_boxes): a follower of the map gets the boxes, not the points
-int commit_update(s2m_engine *e, const float *boxes = nullptr, int nb = 0)
+// from upd.list (survivors in index order, then the staged points) -- the same caller order either way.
+// boxes / nb: the update is a box delete (s2m_map_delete_boxes): a follower of the map gets the boxes, not the points.
+// s: the live map -- or the one that is being laid out beside the frames (s2m_engine_relay.cpp), which receives the same update
+// calls a little later: no follower, no counters, its own stream.
+int commit_update(s2m_engine *e, MapSide s, const float *boxes, int nb)
 {
-    bool merged = false;
-    e->map_ready = false;
+    MapBuffers &map = *s.map;
+    UpdateBuffers &upd = *s.upd;
+    Grid &grid = *s.grid;
+    MapStats &stats = *s.stats;
+    const hipStream_t st = s.st;
+    bool merged = false, inplace = false;
+    // (the map beside the frames belongs to the worker thread: its failures go back as codes, the handle's message and state are
+    // the caller's thread's)
+    auto bad = [&](int code, const char *what, hipError_t he = hipSuccess) {
+        if (s.live) return fail(e, code, what, he);
+        return he == kWaitTimedOut ? (int)S2M_ERR_TIMEOUT : code;
+    };
+    if (s.live) e->map_ready = false;
     hipError_t he;
-    {
+    if (s.live) {
         std::lock_guard<std::mutex> lk(e->stats_mu);
-        he = resolve_stats(e->map, e->stats);  // counts of the previous build / merge
+        he = resolve_stats(map, stats);  // counts of the previous build / merge
+    } else {
+        he = resolve_stats(map, stats);
     }
-    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "resolve_stats", he);
+    if (he != hipSuccess) return bad(S2M_ERR_HIP, "resolve_stats", he);
     // The cell size is kept across updates (a stable grid) unless the density has drifted by more than 2x from
     // the ~11 points per occupied cell it was chosen for -- e.g. a map seeded from a handful of points and then
     // grown, or a dense seed thinned by the voxel rule: then it is chosen again from the density.  A merged update
@@ -88,20 +110,20 @@ int commit_update(s2m_engine *e, const float *boxes = nullptr, int nb = 0)
     // Judged from the counts of the last build or merge and THAT layout's point count (in-place updates change the number
     // of points and of occupied cells alike, and only a layout counts the cells).
     auto drifted = [&]() {
-        if (e->cfg.cell_size > 0.0f || e->stats.occupied_cells <= 0 || e->stats.layout_points <= 0) return false;
-        const double mean = (double)e->stats.layout_points / (double)e->stats.occupied_cells;
+        if (e->cfg.cell_size > 0.0f || stats.occupied_cells <= 0 || stats.layout_points <= 0) return false;
+        const double mean = (double)stats.layout_points / (double)stats.occupied_cells;
         return mean < 5.5 || mean > 22.0;
     };
     const bool drift_before = drifted();
-    const int64_t id0 = e->map.next_id;  // the first id this update hands out
-    if (e->log.on && e->log.token != 0 && e->grid.m > 0) {   // somebody follows the map
+    const int64_t id0 = map.next_id;  // the first id this update hands out
+    if (s.live && e->log.on && e->log.token != 0 && grid.m > 0) {   // somebody follows the map
         if (nb == 0) {   // the points about to disappear one by one, before anything moves
-            launch_log_removed(e->log, e->map.counters + kBricksWord, e->stats.bricks, e->map.bmark, e->grid.tab, e->upd.alive_s, e->grid.pidx,
-                               e->grid.pts, e->stream);
+            launch_log_removed(e->log, map.counters + kBricksWord, stats.bricks, map.bmark, grid.tab, upd.alive_s, grid.pidx,
+                               grid.pts, st);
         } else if (nb <= kLogBoxesPer && (int)e->log.boxes_per_log.size() < kLogMarks) {   // the boxes themselves, in their place in the sequence
             e->log.boxes_log.insert(e->log.boxes_log.end(), boxes, boxes + 6 * (size_t)nb);
             e->log.boxes_per_log.push_back(nb);
-            launch_log_mark(e->log, e->stream);
+            launch_log_mark(e->log, st);
         } else {
             e->log.token = 0;  // more box deletes than a report holds: whoever follows the map fetches it
         }
@@ -110,60 +132,71 @@ int commit_update(s2m_engine *e, const float *boxes = nullptr, int nb = 0)
         bool counted = false;
         // a scan's batches that update_add left where they were are staged by the in-place update's preparation -- when that
         // can run; otherwise here, by their own kernels
-        if (e->upd.pend.on && !slab_fuses(e->map, e->grid, e->stats, e->upd.stage_n)) {
-            he = update_materialize(e->upd, e->stream);
-            if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "update_materialize", he);
+        if (upd.pend.on && !slab_fuses(map, grid, stats, upd.stage_n)) {
+            he = update_materialize(upd, st);
+            if (he != hipSuccess) return bad(S2M_ERR_HIP, "update_materialize", he);
         }
-        he = slab_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, e->upd.counters + kUpdSlabWord, merged, e->stream,
-                         update_stage_word(e->upd), &counted, &e->upd.pend, e->upd.stage, e->upd.counters + kUpdStageWord + (e->upd.stage_ops & 1));
-        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "slab_update", he);
-        if (counted) e->upd.stage_deferred = false;  // (stage_n is the count now)
-        if (merged) ++e->n_inplace;
+        he = slab_update(map, grid, stats, upd.alive_s, upd.stage, upd.stage_n, upd.counters + kUpdSlabWord, merged, st,
+                         update_stage_word(upd), &counted, &upd.pend, upd.stage, upd.counters + kUpdStageWord + (upd.stage_ops & 1));
+        if (he != hipSuccess) return bad(S2M_ERR_HIP, "slab_update", he);
+        if (counted) upd.stage_deferred = false;  // (stage_n is the count now)
+        inplace = merged;
+        if (merged && s.live) ++e->n_inplace;
     }
     // (a count that stayed on the device and did not come back with the in-place update's hand-back)
-    he = update_stage_count(e->upd, e->stream);
-    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "update_stage_count", he);
+    he = update_stage_count(upd, st);
+    if (he != hipSuccess) return bad(S2M_ERR_HIP, "update_stage_count", he);
     if (!e->no_merge && !drift_before && !merged) {
-        he = merge_update(e->map, e->grid, e->stats, e->upd.alive_s, e->upd.stage, e->upd.stage_n, merged, e->stream, !e->no_slab);
-        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "merge_update", he);
+        he = merge_update(map, grid, stats, upd.alive_s, upd.stage, upd.stage_n, merged, st, !e->no_slab);
+        if (he != hipSuccess) return bad(S2M_ERR_HIP, "merge_update", he);
     }
-    e->last_update_merged = merged;
-    if (merged) ++e->n_merged; else ++e->n_rebuilt;
-    if (e->log.on && e->log.token != 0) {
-        if (merged) launch_log_added(e->log, e->upd.stage, e->upd.stage_n, (uint32_t)id0, e->stream);
-        else e->log.token = 0;  // a rebuild numbers the points anew: whoever follows the map starts over
+    if (s.live) {
+        e->last_update_merged = merged;
+        if (merged) ++e->n_merged; else ++e->n_rebuilt;
+        if (e->log.on && e->log.token != 0) {
+            if (merged) launch_log_added(e->log, upd.stage, upd.stage_n, (uint32_t)id0, st);
+            else e->log.token = 0;  // a rebuild numbers the points anew: whoever follows the map starts over
+        }
+    } else if (!merged) {
+        // the map beside the frames must keep the ids the live one hands out: a rebuild would number its points anew.  Give it up;
+        // the next trigger starts another one
+        return bad(S2M_ERR_STATE, "the layout beside the frames could not take an update without a rebuild");
     }
     if (!merged) {
         int64_t m_new = 0;
         bool too_large = false;
-        he = update_finish(e->upd, e->grid, &m_new, e->stream);
-        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "update_finish", he);
-        if (m_new >= ((int64_t)1 << 31)) return fail(e, S2M_ERR_CAPACITY, "map too large (>= 2^31 points)");
-        const float cell = e->cfg.cell_size > 0.0f ? e->cfg.cell_size : e->built_cell;
+        he = update_finish(upd, grid, &m_new, st);
+        if (he != hipSuccess) return bad(S2M_ERR_HIP, "update_finish", he);
+        if (m_new >= ((int64_t)1 << 31)) return bad(S2M_ERR_CAPACITY, "map too large (>= 2^31 points)");
+        const float cell = e->cfg.cell_size > 0.0f ? e->cfg.cell_size : *s.built_cell;
         // the cells stay where they are (same origin) unless the map was empty or has wandered beyond the representable range
-        const float origin[3] = {e->grid.ox, e->grid.oy, e->grid.oz};
-        const bool keep = e->grid.m > 0 && cell == e->grid.c;
-        he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, cell, e->map, e->grid, e->stats, too_large,
-                       e->stream, keep ? origin : nullptr);
+        const float origin[3] = {grid.ox, grid.oy, grid.oz};
+        const bool keep = grid.m > 0 && cell == grid.c;
+        he = build_map(reinterpret_cast<const float *>(upd.list), 4, m_new, cell, map, grid, stats, too_large,
+                       st, keep ? origin : nullptr);
         if (he == hipSuccess && too_large && keep)   // beyond the range of the old origin: a new one
-            he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, cell, e->map, e->grid, e->stats, too_large, e->stream);
-        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
-        if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
+            he = build_map(reinterpret_cast<const float *>(upd.list), 4, m_new, cell, map, grid, stats, too_large, st);
+        if (he != hipSuccess) return bad(S2M_ERR_HIP, "build_map", he);
+        if (too_large) return bad(S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
         if (drifted()) {
-            he = build_map(reinterpret_cast<const float *>(e->upd.list), 4, m_new, 0.0f, e->map, e->grid, e->stats, too_large,
-                           e->stream);
-            if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "build_map", he);
-            if (too_large) return fail(e, S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
-            e->built_cell = e->grid.c;
+            he = build_map(reinterpret_cast<const float *>(upd.list), 4, m_new, 0.0f, map, grid, stats, too_large,
+                           st);
+            if (he != hipSuccess) return bad(S2M_ERR_HIP, "build_map", he);
+            if (too_large) return bad(S2M_ERR_CAPACITY, "map bounding box too large for the cell size");
+            *s.built_cell = grid.c;
             ++e->n_regrid;
         }
     }
-    e->map_ready = true;
-    e->nn_valid = false;  // neighbour indices referred to the old point list
-    if (e->built_cell <= 0.0f) e->built_cell = e->grid.c;
+    if (*s.built_cell <= 0.0f) *s.built_cell = grid.c;
+    if (s.live) {
+        e->map_ready = true;
+        e->nn_valid = false;  // neighbour indices referred to the old point list
+        return relay_after_commit(e, inplace, merged);   // (the layout beside the frames: triggers, and what a re-lay of the live map means for one in flight)
+    }
     return S2M_OK;
 }
-}  // namespace
+}  // namespace s2m_eng
+extern "C" {
 
 int s2m_map_add(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int downsample_on, float downsample_size,
                 int on_device, int64_t *n_added)
@@ -176,14 +209,18 @@ int s2m_map_add(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int 
     const float *dev = nullptr;
     int rc = stage_cloud(e, xyz, stride, n, on_device, &dev);
     if (rc) return rc;
+    rc = relay_poll(e);   // (a layout that was produced beside the frames takes the live map's place here, between two updates)
+    if (rc) return rc;
     float4 *np = nullptr;
     S2M_HIP(e, xyz_to_float4(e->upd, dev, stride, n, &np, e->stream));
-    bind_update(e);
+    rc = relay_record_lists(e, np, n, downsample_on != 0, downsample_size, nullptr, nullptr, 0);
+    if (rc) return rc;
+    bind_update(e, live_side(e));
     S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
     int64_t added = 0;
     S2M_HIP(e, update_add(e->upd, e->grid, np, n, downsample_on != 0, downsample_size, &added, e->stream));
     if (n_added) *n_added = added;
-    return commit_update(e);
+    return commit_update(e, live_side(e), nullptr, 0);
 }
 
 int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *n_deleted)
@@ -194,13 +231,17 @@ int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *
     if (n_deleted) *n_deleted = 0;
     if (!delete_touches_map(e->grid, boxes, (int)n)) return S2M_OK;  // (the slab ahead of the sensor after a cube move)
     S2M_ENTER(e);
-    bind_update(e);
+    int rc = relay_poll(e);
+    if (rc) return rc;
+    bind_update(e, live_side(e));
     S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
     int64_t del = 0;
     S2M_HIP(e, update_delete(e->upd, e->grid, boxes, (int)n, &del, e->stream));
     if (n_deleted) *n_deleted = del;
     if (del == 0) return S2M_OK;  // nothing changed: keep the grid and the neighbour indices
-    return commit_update(e, boxes, (int)n);
+    rc = relay_record_boxes(e, boxes, (int)n);
+    if (rc) return rc;
+    return commit_update(e, live_side(e), boxes, (int)n);
 }
 
 int s2m_fov_reset(s2m_engine *e)
@@ -232,6 +273,10 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     if (e->map_borrowed) return fail(e, S2M_ERR_STATE, "the map belongs to another handle (s2m_map_share)");
     if (!e->scan_ready) return fail(e, S2M_ERR_STATE, "no scan: call s2m_scan_set first");
     S2M_ENTER(e);
+    {
+        int rc = relay_poll(e);   // (a layout that was produced beside the frames takes the live map's place here, between two updates)
+        if (rc) return rc;
+    }
     const Pose pose = pose_of(state);
     float4 *la = nullptr, *lb = nullptr;
     int64_t na = 0, nb = 0;
@@ -254,7 +299,7 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
         open_word = e->d_hard + 3 * e->n_cap + 3;
     }
     VoxBox vox;
-    bind_update(e);
+    bind_update(e, live_side(e));
     uint32_t left_open = 0;
     S2M_HIP(e, incr_classify(e->upd, pose, e->d_scan, e->d_scan + e->n_cap, e->d_scan + 2 * e->n_cap, (int)e->n,
                              e->d_nn_idx, e->grid, e->nn_valid && ekf_inited != 0, filter_size_map, &la, &na, &lb, &nb, e->stream,
@@ -278,9 +323,13 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     }
     // (nobody asks for the number of points each call adds: the count stays on the device until the commit's own hand-back)
     const bool defer = !e->exact_stage;
+    {   // the same two lists for the map that is being laid out beside the frames, if one is
+        int rc = relay_record_lists(e, la, na, true, (float)filter_size_map, &vox, lb, nb);
+        if (rc) return rc;
+    }
     S2M_HIP(e, update_add(e->upd, e->grid, la, na, true, (float)filter_size_map, nullptr, e->stream, &vox, defer));   // :627
     S2M_HIP(e, update_add(e->upd, e->grid, lb, nb, false, 0.0f, nullptr, e->stream, nullptr, defer));           // :628
-    return commit_update(e);
+    return commit_update(e, live_side(e), nullptr, 0);
 }
 
 }  // extern "C"

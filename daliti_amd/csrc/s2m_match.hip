@@ -254,7 +254,7 @@ __device__ __forceinline__ void match_rows_body(const MatchArgs &a, uint2 *__res
 }
 
 template <int G, bool WIDE, int NB>
-__global__ __launch_bounds__(256) void match_rows(MatchArgs a)
+__global__ __launch_bounds__(256, NB == 2 ? 4 : 3) void match_rows(MatchArgs a)
 {
     __shared__ uint2 runs[kRunSlots * 256];  // [slot][thread]: conflict-free whatever the per-lane fill
     match_rows_body<G, WIDE, NB>(a, runs);
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void match_rows(MatchArgs a)
 // and has workgroup 0 bring the init record over; a later one runs only if the device decided to search again, at the
 // pose the last update left
 template <int G, bool WIDE, int NB>
-__global__ __launch_bounds__(256) void match_rows_loop(MatchArgs a)
+__global__ __launch_bounds__(256, NB == 2 ? 4 : 3) void match_rows_loop(MatchArgs a)
 {
     __shared__ uint2 runs[kRunSlots * 256];
     if (a.loop.init) {
@@ -290,7 +290,7 @@ __device__ __forceinline__ MatchArgs batch_match_args(const BatchArgs &b, uint32
 }
 // K scans, one grid: blockIdx.y = scan.  The scans that do not search in this pass leave at once.
 template <int G, bool WIDE, int NB>
-__global__ __launch_bounds__(256) void match_rows_batch(BatchArgs b)
+__global__ __launch_bounds__(256, NB == 2 ? 4 : 3) void match_rows_batch(BatchArgs b)
 {
     __shared__ uint2 runs[kRunSlots * 256];
     const ScanDesc &d = b.d[blockIdx.y];

@@ -43,7 +43,7 @@ class Config(C.Structure):
                 ("extrinsic_est_en", C.c_int32), ("max_iter", C.c_int32),
                 ("feat_threshold", C.c_int32), ("cell_size", C.c_float), ("device", C.c_int32),
                 ("far_point_bet", C.c_int32), ("device_loop", C.c_int32), ("wait_policy", C.c_int32),
-                ("wait_timeout_ms", C.c_int32), ("wait_spin_us", C.c_int32)]
+                ("wait_timeout_ms", C.c_int32), ("wait_spin_us", C.c_int32), ("layout_beside", C.c_int32)]
 
 
 class PassOut(C.Structure):
@@ -126,6 +126,8 @@ def load_library():
     lib.s2m_last_error.restype = C.c_char_p
     lib.s2m_last_error.argtypes = [C.c_void_p]
     for name in ABI_SYMBOLS:
+        if os.environ.get("S2M_LIB") and not hasattr(lib, name):
+            continue        # (an A/B build of an OLDER ABI, scripts/ab.sh: the legs it is run on use what it has)
         getattr(lib, name)  # AttributeError if the ABI is incomplete
     _lib = lib
     return lib

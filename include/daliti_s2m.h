@@ -34,7 +34,7 @@ extern "C" {
  * s2m_map_get_order, s2m_map_update_stats.  3 (round 4): s2m_config gained `device_loop`; new: s2m_bet_stats,
  * s2m_scan_prefetch_raw, s2m_scan_prepare_raw, s2m_map_inplace_updates; block[159] carries the count of neighbour lists
  * short of the gate; s2m_map_get_order may report positions that hold no point (0xffffffff).  A caller built against an
- * older version must be recompiled.  5 (round 6): s2m_config gained `wait_policy`, `wait_timeout_ms`, `wait_spin_us`; new code
+ * older version must be recompiled.  5 (round 6): s2m_config gained `wait_policy`, `wait_timeout_ms`, `wait_spin_us`, `layout_beside`; new code
  * S2M_ERR_TIMEOUT; new: s2m_debug_state; s2m_map_get_changes reports the changes of the update BEFORE the last one when
  * asked to (lag); s2m_map_update_stats writes 12 counters. */
 #define S2M_ABI_VERSION 5
@@ -98,6 +98,13 @@ typedef struct {
     int32_t wait_timeout_ms; /* deadline of every such wait (default 10000).  A wait that passes it returns
                               * S2M_ERR_TIMEOUT; no entry point blocks for ever, whatever the device does.            */
     int32_t wait_spin_us;    /* policies 1 and 2: how long a wait polls before it gives the core away (default 40)   */
+    int32_t layout_beside;   /* 1 (default): when the layout an in-place map update works on wears out -- the tail of the point
+                              * array or the brick table's spare rows three quarters used, the points per occupied cell a factor
+                              * two off what the cell size was chosen for -- a new layout of the whole map is built BESIDE the
+                              * frames: snapshot, build on a worker thread and stream of the handle, the update calls that arrive
+                              * meanwhile run again on the new map, swap between two updates (ikd-Tree's rebuild thread,
+                              * ikd_Tree.cpp:192-203, 229-367).  0: the layout is renewed inside the update that hits the limit
+                              * (a merge, a re-grid: milliseconds in that frame).  Same map, same ids either way.            */
 } s2m_config;
 
 int s2m_abi_version(void);

@@ -6,7 +6,7 @@
 #   scripts/ab.sh run <tag> "<variants>" "<legs>" [reps] [env for the variant legs]   (GPU box)
 #       runs every leg alternately with the in-tree library ("base") and with each variant, `reps` times (default 2),
 #       and prints one line per run; JSON lines under gpurun_out/<tag>/.
-#       legs: C1 C2 C3 C4 R1 (one scan in flight), K8 K16 K24 ... (C5 with that many scans in flight), FRAME (C3 with
+#       legs: C1 C2 C3 C4 R1 (one scan in flight), K8 K16 K24 ... (C5 with that many scans in flight), B8 B24 (the same against C4's 20 M-point map), FRAME (C3 with
 #       the frame_pipeline side leg); a variant named "-" means "the in-tree library again" with the given env and with the
 #       extra bench.py arguments in $AB_ARGS (e.g. AB_ARGS=--device-loop: an A/B of two forms inside one library)
 #   scripts/ab.sh counters <tag> "<variants>" "<leg>"    (GPU box) SQ / TA / TCP counters of one leg, base and variants
@@ -18,6 +18,7 @@ leg_args() {
   case $1 in
     C1|C2|C3|C4|R1) echo "--config $1 --no-cpu --no-side" ;;
     K*) echo "--config C5 --replicas ${1#K} --no-cpu --steps 100" ;;
+    B*) echo "--config C5b --replicas ${1#B} --no-cpu --steps 40" ;;
     FRAME) echo "--config C3 --no-cpu --steps 50" ;;
     *) echo "unknown leg $1" >&2; exit 2 ;;
   esac

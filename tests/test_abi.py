@@ -48,7 +48,7 @@ def test_abi_version_and_defaults(lib):
 
 def test_struct_layouts_match_header(lib):
     from daliti_amd.engine import Config, PassOut, IterLog, DynShare
-    assert C.sizeof(Config) == 88
+    assert C.sizeof(Config) == 96
     assert C.sizeof(PassOut) == 144 * 8 + 12 * 8 + 8 + 8
     assert C.sizeof(IterLog) == 16 + 3 * 64 * 4 + 64 * 8 + 64 * 24 * 8
     assert C.sizeof(DynShare) == 48

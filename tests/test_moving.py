@@ -50,8 +50,18 @@ def test_world_sweeps_are_deterministic_and_undistort_onto_the_world(oracle):
 
 
 @pytest.mark.gpu
-def test_sixty_frames_of_a_drive_match_the_oracle(oracle):
+@pytest.mark.parametrize("beside", [None, "12", "25,regrid"])
+def test_sixty_frames_of_a_drive_match_the_oracle(oracle, monkeypatch, beside):
+    """beside: a new layout of the whole map is produced BESIDE the frames behind the n-th update (S2M_BESIDE_AT: snapshot, build
+    on the handle's layout thread -- with a new cell size for "regrid" --, the update calls that arrive meanwhile run again on
+    it, swap between two updates: s2m_engine_relay.cpp; ikd-Tree's rebuild thread, ikd_Tree.cpp:192-203, 229-367).  Every
+    stage of every frame still equals the oracle's, the follower of the change log notices nothing (same ids), and the final
+    map and neighbour lists are the oracle's."""
     from daliti_amd import Engine, synth
+    if beside:
+        monkeypatch.setenv("S2M_BESIDE_AT", beside)
+    else:
+        monkeypatch.setenv("S2M_NO_BESIDE", "1")
     frames, beams, az, fs = 60, 16, 256, 0.5
     w = _world()
     seed = w.seed_map(30000)
@@ -108,12 +118,17 @@ def test_sixty_frames_of_a_drive_match_the_oracle(oracle):
         mirror_ids, mirror_xyz = mirror_ids[order], mirror_xyz[order]
         assert len(mirror_ids) == e.map_size() and (np.diff(mirror_ids.astype(np.int64)) > 0).all(), f
     st = e.map_update_stats()
+    if beside:   # the layout beside the frames happened, once, and no update waited for it
+        assert st["relaid_beside"] == 1 and st["regridded_beside"] == (1 if "regrid" in beside else 0), st
+    else:
+        assert st["relaid_beside"] == 0, st
     # the drive left the seed's box far behind, the trim removed map points, nothing was rebuilt -- and most updates touched
     # only the bricks they changed
     lo, hi = e.map_grid()
     assert sw["x_true"][frames - 1][9] > 20 * (seed_box[1][0] - seed_box[0][0]) and trimmed >= 1
     assert st["rebuilt"] == 0 and st["regridded"] == 0 and e.map_inplace_updates() >= frames // 2, (st, e.map_inplace_updates())
-    assert hi[0] - lo[0] > 50 and st["top_relaid"] >= 1, (lo, hi, st)     # 4 m bricks: the box of bricks grew 20 x and the window followed
+    # 4 m bricks: the box of bricks grew 20 x and the window followed (a layout beside the frames sizes its own window)
+    assert (hi[0] - lo[0]) * e.map_info()["cell"] * 8 > 200 and (beside or st["top_relaid"] >= 1), (lo, hi, st)
     pts = e.map_points()
     assert (bits(_rows(pts)) == bits(_rows(om.points()))).all()
     # the mirror that only ever saw the changes IS the map: same ids, same points, same (ascending id) order
