@@ -592,6 +592,12 @@ int s2m_iterated_update_sharded(s2m_engine *e, double x[S2M_STATE_DOUBLES], cons
     if (e->poisoned) return refuse_poisoned(e);
     e->where = "s2m_iterated_update";
     e->step = "";
+    e->nn_valid = false;   // a new scan's first pass searches: the lists of the last one are over
+    {
+        tl_wait = &e->wait;
+        int rc = relay_poll(e);   // (... which is when a layout produced beside the frames may take the live map's place)
+        if (rc) return rc;
+    }
     if (!reduce && (!d_block || d_block == e->d_block)) {  // state on the device where the form allows it (s2m_loop.h)
         bool used = false;
         int rc = iterated_update_loop(e, x, x_prop, P, log, used);

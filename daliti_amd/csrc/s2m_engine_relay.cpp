@@ -338,6 +338,9 @@ int relay_poll(s2m_engine *e)
     Relay &r = e->relay;
     const int st = r.state.load();
     if (st == Relay::kIdle || (st != Relay::kCaughtUp && st != Relay::kFailed)) return S2M_OK;
+    // Nearest_Points of the current scan are positions in the live map, and map_incremental classifies the scan from them: the
+    // maps change places only while no such list is in use -- behind an update, or when a new scan arrives
+    if (e->nn_valid) return S2M_OK;
     std::unique_lock<std::mutex> lk(r.mu);
     if (r.state.load() == Relay::kFailed) {
         const bool timed_out = r.why == "timeout";
@@ -351,6 +354,7 @@ int relay_poll(s2m_engine *e)
     }
     if (r.state.load() != Relay::kCaughtUp || !r.ops.empty() || r.busy.load() != 0 || r.cancel.load() != 0) return S2M_OK;
     // ---- the swap: the other map holds the live map's points, ids and all, in a fresh layout
+    S2M_HIP(e, hipSetDevice(e->device));
     S2M_HIP(e, hipStreamWaitEvent(e->stream, r.ev_side, 0));
     {
         std::lock_guard<std::mutex> sk(e->stats_mu);

@@ -49,7 +49,7 @@ int scan_reset(s2m_engine *e, int64_t n, bool wait = true)
     e->scan_ready = true;
     e->pass_done = false;
     e->nn_valid = false;
-    return S2M_OK;
+    return relay_poll(e);   // (a layout produced beside the frames takes the live map's place between two scans)
 }
 }  // namespace
 
