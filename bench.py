@@ -1341,7 +1341,7 @@ def frame_pipeline_moving(torch, Engine, synth, a):
         msp = rp["ms"][warm:]
         worst_p = int(np.argmax(msp))
         trims_p = [int(f) - warm for f in np.nonzero(rp["deleted"])[0] if f >= warm]
-        assert rp["mirror_points"] == rp["map_points"] == len(flat_end)
+        assert rp["mirror_points"] == rp["map_points"] == len(flat_end) and rp["mirror_missed"] == 0, (rp["mirror_points"], rp["map_points"], len(flat_end), rp["mirror_missed"])
         eng.close()
         eng = Engine(max_iter=a.max_iter, device=torch.cuda.current_device())
         eng.map_build(seed)
@@ -1371,7 +1371,7 @@ def frame_pipeline_moving(torch, Engine, synth, a):
                     "mirror as its boxes: the buckets inside a box are dropped whole, the ones its faces cut are filtered"}
         eng.close()
     except Exception as ex:  # noqa: BLE001
-        out["with_map_publishing"] = {"error": str(ex)[:300]}
+        out["with_map_publishing"] = {"error": (type(ex).__name__ + ": " + str(ex))[:300]}
     return out
 
 

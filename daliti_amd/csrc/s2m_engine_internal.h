@@ -36,8 +36,11 @@
 
 namespace s2m {
 // s2m_relay.hip
-void launch_snapshot(const float4 *pts, const uint32_t *pidx, int64_t m, float4 *out, uint32_t *count, int64_t cap, hipStream_t st);
+int64_t snapshot_blocks(int64_t m);
+void launch_snapshot(const float4 *pts, const uint32_t *pidx, int64_t m, float4 *out, uint32_t *count, int64_t cap, uint32_t *blk, hipStream_t st);
 void launch_remap_ids(uint32_t *pidx, int64_t m, const float4 *snap, hipStream_t st);
+size_t snapshot_sort_tmp_bytes(int64_t n);
+hipError_t snapshot_sort_by_id(const float4 *snap, int64_t n, float4 *out, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t st);
 void launch_count_cells(const uint32_t *bricks_dev, int64_t bricks_bound, const uint32_t *tab, uint32_t *cells_dev, uint32_t *host_dev, uint32_t seq,
                         hipStream_t st);
 void launch_deinterleave(const float *src, int64_t stride, int64_t n, float *sx, float *sy, float *sz,
@@ -218,6 +221,12 @@ struct s2m_engine {
         float4 *snap = nullptr;            // the snapshot: live points with their ids
         int64_t snap_cap = 0, snap_bound = 0;
         uint32_t *snap_count = nullptr;    // device word
+        float4 *snap2 = nullptr;           // ... in ascending id order (what the build reads)
+        uint32_t *snap_work = nullptr;     // 4 words per point: the id sort's keys and values
+        void *snap_tmp = nullptr;
+        size_t snap_tmp_bytes = 0;
+        uint32_t *snap_blk = nullptr;      // per block of positions: live points in front of it (scratch of the snapshot)
+        int64_t snap_blk_cap = 0, extent_bound = 0;
         int64_t id_snap = 0;               // next_id of the live map at the snapshot
         bool regrid = false;               // the new layout chooses its cell size from the density
         float4 *arena = nullptr;           // the update calls' point lists on their way to the worker (a ring)
@@ -274,6 +283,7 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid);   // end of
 int relay_record_lists(s2m_engine *e, const float4 *la, int64_t na, bool ds_a, float fs, const s2m::VoxBox *vox, const float4 *lb, int64_t nb);
 int relay_record_boxes(s2m_engine *e, const float *boxes, int nb);
 int relay_poll(s2m_engine *e);      // start of every update of the live map: swap when the other map has caught up
+int relay_rehearse(s2m_engine *e, const float *cloud_dev, int64_t stride, int64_t m);   // behind s2m_map_build: the other map's buffers, now
 int relay_cancel(s2m_engine *e);    // the live map is being replaced: whatever is in flight is dropped (waits for the worker to let go)
 void relay_shutdown(s2m_engine *e); // s2m_destroy
 s2m::Gates gates_of(const s2m_config &c);

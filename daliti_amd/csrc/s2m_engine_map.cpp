@@ -32,7 +32,7 @@ int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride, int64_t m, in
     e->nn_valid = false;
     e->built_cell = e->grid.c;
     e->log.token = 0;  // (a follower of the old map starts over)
-    return S2M_OK;
+    return relay_rehearse(e, dev, stride, m);   // (what a layout beside the frames will need is allocated here, not beside a frame)
 }
 
 int s2m_map_share(s2m_engine *e, const s2m_engine *owner)

@@ -8,7 +8,8 @@
 // meanwhile, swap the subtree in); this is the same for the whole map:
 //   trigger   at the end of an update, EARLY: tail or spare rows three quarters used, or the points per occupied cell (counted
 //             every 64 updates by one kernel over the brick tables) a factor two off what the cell size was chosen for
-//   snapshot  one pass over the live map on the main stream, behind an update: every point with its id, unordered
+//   snapshot  three small launches over the live map on the main stream, behind an update: every point with its id, in position
+//             order (inside a cell that is id order: the new layout keeps the documented order of ties)
 //   build     the worker thread of this file, on its own stream: a complete build from the snapshot (a new cell size when the
 //             density asked for it), the ids put back
 //   replay    the update CALLS that arrive meanwhile (map_incremental's two lists, map_add's list, delete_boxes' boxes) are kept
@@ -48,7 +49,14 @@ MapSide other_side(s2m_engine *e)
 hipError_t worker_prepare(s2m_engine *e)
 {
     Relay &r = e->relay;
-    if (!r.stream) S2M_TRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    if (!r.stream) {   // the lowest priority the device offers: a frame's kernels go first wherever the two streams meet
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        if (hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, least) != hipSuccess) {
+            (void)hipGetLastError();
+            S2M_TRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+        }
+    }
     if (!r.ev_side) S2M_TRY(hipEventCreateWithFlags(&r.ev_side, hipEventDisableTiming));
     if (!r.snap_count) S2M_TRY(hipMalloc((void **)&r.snap_count, sizeof(uint32_t)));
     if (r.snap_cap < r.snap_bound) {
@@ -57,7 +65,25 @@ hipError_t worker_prepare(s2m_engine *e)
         r.snap_cap = 0;
         const int64_t want = r.snap_bound + r.snap_bound / 4 + 65536;
         S2M_TRY(hipMalloc((void **)&r.snap, (size_t)want * sizeof(float4)));
+        if (r.snap2) S2M_TRY(hipFree(r.snap2));
+        r.snap2 = nullptr;
+        S2M_TRY(hipMalloc((void **)&r.snap2, (size_t)want * sizeof(float4)));
+        if (r.snap_work) S2M_TRY(hipFree(r.snap_work));
+        r.snap_work = nullptr;
+        S2M_TRY(hipMalloc((void **)&r.snap_work, (size_t)want * 4 * sizeof(uint32_t)));
+        if (r.snap_tmp) S2M_TRY(hipFree(r.snap_tmp));
+        r.snap_tmp = nullptr;
+        r.snap_tmp_bytes = snapshot_sort_tmp_bytes(want);
+        S2M_TRY(hipMalloc(&r.snap_tmp, std::max<size_t>(r.snap_tmp_bytes, 256)));
         r.snap_cap = want;
+    }
+    const int64_t blocks = snapshot_blocks(r.extent_bound) + 1;
+    if (r.snap_blk_cap < blocks) {
+        if (r.snap_blk) S2M_TRY(hipFree(r.snap_blk));
+        r.snap_blk = nullptr;
+        r.snap_blk_cap = 0;
+        S2M_TRY(hipMalloc((void **)&r.snap_blk, (size_t)(blocks + blocks / 4) * sizeof(uint32_t)));
+        r.snap_blk_cap = blocks + blocks / 4;
     }
     // room for the lists of a few hundred updates (two lists of at most a scan each); a queue that outgrows it gives the layout up
     const int64_t want = std::max<int64_t>((int64_t)1 << 22, 64 * std::max<int64_t>(e->n_cap, 4096));
@@ -83,6 +109,10 @@ int worker_build(s2m_engine *e, const float origin[3], float cell_live)
     if ((int64_t)n > r.snap_cap || n == 0) return S2M_ERR_CAPACITY;
     const float cell = r.regrid ? 0.0f : cell_live;
     bool too_large = false;
+    // in ascending id order: whatever cells the new grid has, the points of a cell then stand in the documented order
+    he = snapshot_sort_by_id(r.snap, (int64_t)n, r.snap2, r.snap_work, r.snap_tmp, r.snap_tmp_bytes, r.stream);
+    if (he != hipSuccess) return S2M_ERR_HIP;
+    std::swap(r.snap, r.snap2);
     he = build_map(reinterpret_cast<const float *>(r.snap), 4, (int64_t)n, cell, r.map, r.grid, r.stats, too_large, r.stream,
                    (!r.regrid && cell > 0.0f) ? origin : nullptr);
     if (he != hipSuccess) return he == kWaitTimedOut ? S2M_ERR_TIMEOUT : S2M_ERR_HIP;
@@ -230,9 +260,9 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
     }
     if (st == Relay::kSnapReady && r.cancel.load() == 0) {
         // the snapshot, behind this update: every live point with its id; the worker builds from it
-        if (e->grid.live > r.snap_cap) { relay_drop(e); return S2M_OK; }
+        if (e->grid.live > r.snap_cap || snapshot_blocks(e->grid.m) > r.snap_blk_cap) { relay_drop(e); return S2M_OK; }
         if (!r.ev_main) S2M_HIP(e, hipEventCreateWithFlags(&r.ev_main, hipEventDisableTiming));
-        launch_snapshot(e->grid.pts, e->grid.pidx, e->grid.m, r.snap, r.snap_count, r.snap_cap, e->stream);
+        launch_snapshot(e->grid.pts, e->grid.pidx, e->grid.m, r.snap, r.snap_count, r.snap_cap, r.snap_blk, e->stream);
         S2M_HIP(e, hipEventRecord(r.ev_main, e->stream));
         std::lock_guard<std::mutex> lk(r.mu);
         r.id_snap = e->map.next_id;
@@ -277,12 +307,47 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
         r.why = why;
         r.regrid = regrid;
         r.snap_bound = e->grid.live + e->grid.live / 8 + 65536;   // (the snapshot is taken a frame or two from now)
+        r.extent_bound = e->grid.m + e->grid.m / 8 + 65536;
         r.density = 0.0;
         r.state.store(Relay::kStarting);
         if (!r.worker.joinable()) r.worker = std::thread(relay_worker, e);
         r.cv.notify_all();
     }
     return S2M_OK;
+}
+
+// Behind s2m_map_build: everything a layout beside the frames will need is allocated NOW -- the other map is built once from the
+// same cloud and given two dummy updates (the first one of a dense build merges and lays the room and the tail out, the second
+// one goes through the in-place path), so that its buffers exist at the sizes the live map's will have.  A device allocation
+// stalls every queue of the process for a fraction of a millisecond (the driver remaps them); a dozen of them beside a frame
+// were that frame's 6 and 14 ms (round 6, first version).  Costs the build about as much again, once.
+int relay_rehearse(s2m_engine *e, const float *cloud_dev, int64_t stride, int64_t m)
+{
+    Relay &r = e->relay;
+    if (!r.enabled || e->cfg.layout_beside == 0 || e->no_merge || e->no_slab || m < 4096 || r.state.load() != Relay::kIdle) return S2M_OK;
+    r.snap_bound = m + m / 8 + 65536;
+    r.extent_bound = 4 * m + ((int64_t)1 << 23);
+    hipError_t he = worker_prepare(e);
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "the buffers of the layout beside the frames", he);
+    if (!r.ev_main) S2M_HIP(e, hipEventCreateWithFlags(&r.ev_main, hipEventDisableTiming));
+    S2M_HIP(e, hipEventRecord(r.ev_main, e->stream));
+    S2M_HIP(e, hipStreamWaitEvent(r.stream, r.ev_main, 0));   // (the cloud is staged on the main stream)
+    const float origin[3] = {e->grid.ox, e->grid.oy, e->grid.oz};
+    bool too_large = false;
+    he = build_map(cloud_dev, stride, m, e->grid.c, r.map, r.grid, r.stats, too_large, r.stream, origin);
+    if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "the rehearsal of the layout beside the frames", he);
+    if (too_large) return S2M_OK;
+    r.built_cell = r.grid.c;
+    const MapSide s = other_side(e);
+    for (int round = 0; round < 2; ++round) {
+        S2M_HIP(e, hipMemcpy2DAsync(r.arena, sizeof(float4), cloud_dev, (size_t)stride * sizeof(float), 3 * sizeof(float), 1, hipMemcpyDeviceToDevice, r.stream));
+        bind_update(e, s);
+        he = update_begin(r.upd, r.grid, r.stream);
+        if (he == hipSuccess) he = update_add(r.upd, r.grid, r.arena, 1, false, 0.0f, nullptr, r.stream, nullptr, true);
+        if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "the rehearsal of the layout beside the frames", he);
+        if (commit_update(e, s, nullptr, 0) != S2M_OK) break;   // (not fatal: the first real layout allocates what is missing)
+    }
+    return sync_stream(e, r.stream, "the rehearsal of the layout beside the frames");
 }
 
 int relay_record_lists(s2m_engine *e, const float4 *la, int64_t na, bool ds_a, float fs, const VoxBox *vox, const float4 *lb, int64_t nb)
@@ -356,6 +421,42 @@ int relay_poll(s2m_engine *e)
     // ---- the swap: the other map holds the live map's points, ids and all, in a fresh layout
     S2M_HIP(e, hipSetDevice(e->device));
     S2M_HIP(e, hipStreamWaitEvent(e->stream, r.ev_side, 0));
+    static const bool check = std::getenv("S2M_BESIDE_CHECK") != nullptr;   // (debug: are the two maps the same set of (id, point)?)
+    if (check) {
+        auto fetch = [&](const Grid &g, std::vector<float4> &out) -> hipError_t {
+            float4 *d = nullptr; uint32_t *cnt = nullptr, *blk = nullptr;
+            S2M_TRY(hipMalloc((void **)&d, (size_t)std::max<int64_t>(g.live + 1024, 1) * sizeof(float4)));
+            S2M_TRY(hipMalloc((void **)&cnt, sizeof(uint32_t)));
+            S2M_TRY(hipMalloc((void **)&blk, (size_t)(snapshot_blocks(g.m) + 1) * sizeof(uint32_t)));
+            launch_snapshot(g.pts, g.pidx, g.m, d, cnt, g.live + 1024, blk, e->stream);
+            uint32_t n = 0;
+            S2M_TRY(hipMemcpyAsync(&n, cnt, sizeof(n), hipMemcpyDeviceToHost, e->stream));
+            S2M_TRY(hipStreamSynchronize(e->stream));
+            out.resize(std::min<int64_t>(n, g.live + 1024));
+            S2M_TRY(hipMemcpy(out.data(), d, out.size() * sizeof(float4), hipMemcpyDeviceToHost));
+            (void)hipFree(d); (void)hipFree(cnt); (void)hipFree(blk);
+            std::sort(out.begin(), out.end(), [](const float4 &a, const float4 &b) { uint32_t x, y; std::memcpy(&x, &a.w, 4); std::memcpy(&y, &b.w, 4); return x < y; });
+            return hipSuccess;
+        };
+        std::vector<float4> a, b;
+        S2M_HIP(e, hipStreamSynchronize(r.stream));
+        S2M_HIP(e, fetch(e->grid, a));
+        S2M_HIP(e, fetch(r.grid, b));
+        size_t diff = 0, shown = 0;
+        for (size_t i = 0, j = 0; i < a.size() || j < b.size();) {
+            uint32_t x = 0xffffffffu, y = 0xffffffffu;
+            if (i < a.size()) std::memcpy(&x, &a[i].w, 4);
+            if (j < b.size()) std::memcpy(&y, &b[j].w, 4);
+            if (x == y) {
+                if (std::memcmp(&a[i], &b[j], 12) != 0) { ++diff; if (shown++ < 6) std::fprintf(stderr, "[beside check] id %u: live (%g %g %g) other (%g %g %g)\n", x, a[i].x, a[i].y, a[i].z, b[j].x, b[j].y, b[j].z); }
+                ++i; ++j;
+            } else if (x < y) { ++diff; if (shown++ < 6) std::fprintf(stderr, "[beside check] id %u (%g %g %g) only in the live map\n", x, a[i].x, a[i].y, a[i].z); ++i; }
+            else { ++diff; if (shown++ < 6) std::fprintf(stderr, "[beside check] id %u (%g %g %g) only in the other map\n", y, b[j].x, b[j].y, b[j].z); ++j; }
+        }
+        std::fprintf(stderr, "[beside check] swap at update %lld: live %zu points (live count %lld, next id %lld), other %zu (%lld, next id %lld): %zu differences; snapshot at id %lld\n",
+                     (long long)r.commits, a.size(), (long long)e->grid.live, (long long)e->map.next_id, b.size(), (long long)r.grid.live, (long long)r.map.next_id, diff,
+                     (long long)r.id_snap);
+    }
     {
         std::lock_guard<std::mutex> sk(e->stats_mu);
         std::swap(e->map, r.map);
@@ -415,6 +516,10 @@ void relay_shutdown(s2m_engine *e)
     free_update(r.upd);
     if (r.snap) (void)hipFree(r.snap);
     if (r.snap_count) (void)hipFree(r.snap_count);
+    if (r.snap_blk) (void)hipFree(r.snap_blk);
+    if (r.snap2) (void)hipFree(r.snap2);
+    if (r.snap_work) (void)hipFree(r.snap_work);
+    if (r.snap_tmp) (void)hipFree(r.snap_tmp);
     if (r.arena) (void)hipFree(r.arena);
     if (r.d_cells) (void)hipFree(r.d_cells);
     if (r.h_cells) (void)hipHostFree(r.h_cells);

@@ -2,36 +2,116 @@
 //
 // ikd-Tree moves every large rebuild to a second thread (ikd_Tree.cpp:192-203, 229-367): the tree is flattened, rebuilt beside
 // the node's loop, the operations that arrived meanwhile are applied again from a log (Rebuild_Logger) and the new subtree is
-// swapped in.  The same here for the whole map: a snapshot of the live points with their ids (one pass, unordered compaction),
+// swapped in.  The same here for the whole map: a snapshot of the live points with their ids (in position order),
 // a complete build from it on the handle's layout stream, the ids put back, the update calls that arrived meanwhile run again
 // on the new map (the voxel rule is a function of the point SET: the same calls give the same set and the same ids), swap
 // between two frames.  Also: the count of occupied cells of the live map, to see the density drift away from what the cell
 // size was chosen for without waiting for a merge to count them.
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "s2m_map_internal.h"
 
 namespace s2m {
 
-// every position that holds a point -> {x, y, z, bitcast(id)}, in no particular order (the build sorts anyway)
-__global__ __launch_bounds__(256) void snapshot_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx, int64_t m,
-                                                       float4 *__restrict__ out, uint32_t *__restrict__ count, uint32_t cap)
+// every position that holds a point -> {x, y, z, bitcast(id)}, IN POSITION ORDER: inside a cell the live map's positions ascend
+// with the point id, the build's sort is stable, so the new layout has the documented order (brick, cell, id) again -- the order
+// ties at the same float distance are ranked by.  Three launches: live positions per block of 1 024, their exclusive sums (one
+// workgroup), the write.
+constexpr int kSnapPer = 4, kSnapBlock = 256 * kSnapPer;
+__global__ __launch_bounds__(256) void snapshot_count_kernel(const uint32_t *__restrict__ pidx, int64_t m, uint32_t *__restrict__ blk)
 {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    uint32_t id = 0xffffffffu;
-    const bool live = j < m && (id = pidx[j]) != 0xffffffffu;
-    const unsigned long long bal = __ballot(live);
-    if (bal == 0ull) return;
-    uint32_t at = 0;
-    if (lane == __ffsll((long long)bal) - 1) at = atomicAdd(count, (uint32_t)__popcll(bal));
-    at = __shfl(at, __ffsll((long long)bal) - 1, 64);
-    if (live) {
-        const uint32_t mine = at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (mine < cap) {
-            const float4 p = pts[j];
-            out[mine] = make_float4(p.x, p.y, map_point_z(p), __uint_as_float(id));
+    __shared__ uint32_t s[4];
+    const int64_t j0 = (int64_t)blockIdx.x * kSnapBlock + (int64_t)threadIdx.x * kSnapPer;
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < kSnapPer; ++k) c += (j0 + k < m && pidx[j0 + k] != 0xffffffffu) ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(1024) void snapshot_scan_kernel(uint32_t *__restrict__ blk, int nb, uint32_t *__restrict__ total)
+{
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x, per = (nb + 1023) / 1024, lo = t * per, hi = min(lo + per, nb);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += blk[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan of the 1 024 partial sums
+        const uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int i = lo; i < hi; ++i) { const uint32_t c = blk[i]; blk[i] = run; run += c; }
+    if (t == 1023) *total = part[1023];
+}
+__global__ __launch_bounds__(256) void snapshot_write_kernel(const float4 *__restrict__ pts, const uint32_t *__restrict__ pidx, int64_t m,
+                                                             const uint32_t *__restrict__ blk, float4 *__restrict__ out, uint32_t cap)
+{
+    __shared__ uint32_t s[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j0 = (int64_t)blockIdx.x * kSnapBlock + (int64_t)threadIdx.x * kSnapPer;
+    uint32_t id[kSnapPer], c = 0;
+#pragma unroll
+    for (int k = 0; k < kSnapPer; ++k) {
+        id[k] = j0 + k < m ? pidx[j0 + k] : 0xffffffffu;
+        c += id[k] != 0xffffffffu ? 1u : 0u;
+    }
+    uint32_t inc = c;   // inclusive prefix over the wave's lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) s[wave] = inc;
+    __syncthreads();
+    uint32_t at = blk[blockIdx.x] + inc - c;
+    for (int w = 0; w < wave; ++w) at += s[w];
+#pragma unroll
+    for (int k = 0; k < kSnapPer; ++k) {
+        if (id[k] == 0xffffffffu) continue;
+        if (at < cap) {
+            const float4 p = pts[j0 + k];
+            out[at] = make_float4(p.x, p.y, map_point_z(p), __uint_as_float(id[k]));
         }
+        ++at;
     }
 }
+// The snapshot in ascending id order: the build's sort is stable, so inside a cell of the NEW grid -- whatever its size -- the
+// points then stand in id order, the documented order of ties (s2m_map_get_order).  (Position order gives that only while the
+// cells stay the same.)
+__global__ __launch_bounds__(256) void snap_keys_kernel(const float4 *__restrict__ snap, int64_t n, uint32_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { key[i] = __float_as_uint(snap[i].w); val[i] = (uint32_t)i; }
+}
+__global__ __launch_bounds__(256) void snap_gather_kernel(const float4 *__restrict__ snap, const uint32_t *__restrict__ val, int64_t n, float4 *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = snap[val[i]];
+}
+size_t snapshot_sort_tmp_bytes(int64_t n)
+{
+    size_t tmp = 0;
+    uint32_t *p = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, p, p, p, p, (size_t)std::max<int64_t>(n, 1), 0, 32, (hipStream_t) nullptr);
+    return tmp;
+}
+// work: 4 n words (keys, sorted keys, values, sorted values); out: n points
+hipError_t snapshot_sort_by_id(const float4 *snap, int64_t n, float4 *out, uint32_t *work, void *tmp, size_t tmp_bytes, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    uint32_t *key = work, *key2 = work + n, *val = work + 2 * n, *val2 = work + 3 * n;
+    hipLaunchKernelGGL(snap_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, snap, n, key, val);
+    S2M_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, key, key2, val, val2, (size_t)n, 0, 32, st));
+    hipLaunchKernelGGL(snap_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, snap, val2, n, out);
+    return hipGetLastError();
+}
+
 // a map built from a snapshot numbers its points by their place in the snapshot: back to the ids they had
 __global__ __launch_bounds__(256) void remap_ids_kernel(uint32_t *__restrict__ pidx, int64_t m, const float4 *__restrict__ snap)
 {
@@ -65,10 +145,16 @@ __global__ void cells_home_kernel(uint32_t *__restrict__ cells, uint32_t *__rest
     *cells = 0u;
 }
 
-void launch_snapshot(const float4 *pts, const uint32_t *pidx, int64_t m, float4 *out, uint32_t *count, int64_t cap, hipStream_t st)
+int64_t snapshot_blocks(int64_t m) { return (m + kSnapBlock - 1) / kSnapBlock; }
+// blk: snapshot_blocks(m) words of scratch; *count = the number of points written (the live points of the map)
+void launch_snapshot(const float4 *pts, const uint32_t *pidx, int64_t m, float4 *out, uint32_t *count, int64_t cap, uint32_t *blk, hipStream_t st)
 {
     (void)hipMemsetAsync(count, 0, sizeof(uint32_t), st);
-    if (m > 0) hipLaunchKernelGGL(snapshot_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, pts, pidx, m, out, count, (uint32_t)cap);
+    if (m <= 0) return;
+    const int nb = (int)snapshot_blocks(m);
+    hipLaunchKernelGGL(snapshot_count_kernel, dim3((unsigned)nb), dim3(256), 0, st, pidx, m, blk);
+    hipLaunchKernelGGL(snapshot_scan_kernel, dim3(1), dim3(1024), 0, st, blk, nb, count);
+    hipLaunchKernelGGL(snapshot_write_kernel, dim3((unsigned)nb), dim3(256), 0, st, pts, pidx, m, blk, out, (uint32_t)cap);
 }
 void launch_remap_ids(uint32_t *pidx, int64_t m, const float4 *snap, hipStream_t st)
 {

@@ -32,6 +32,16 @@ struct s2m_map_mirror {
     int64_t resyncs = 0;         /* times the whole map had to be fetched (first call, a rebuild, a log overflow) */
     int64_t last_added = 0, last_removed = 0, last_boxes = 0;
     int64_t missed = 0;          /* removals that found no point (0 unless the follower and the engine are out of step) */
+    std::vector<uint32_t> missed_ids;   /* ... the first few of them (diagnostic) */
+    std::vector<float> missed_xyz;      /* ... with the coordinates the report gave */
+    /* diagnostic, O(map): where the mirror holds point `id`, if anywhere */
+    bool find_anywhere(uint32_t id, float *xyz) const
+    {
+        for (const Bucket &b : buckets_)
+            for (const Pt &q : b.pts)
+                if (q.id == id && q.x == q.x) { xyz[0] = q.x; xyz[1] = q.y; xyz[2] = q.z; return true; }
+        return false;
+    }
 
     int64_t size() const { return live_; }
     /* the points held, bucket by bucket (no particular order); ids optional.  xyz: 3 * size() floats */
@@ -165,6 +175,7 @@ struct s2m_map_mirror {
     struct Bucket {
         int32_t c[3] = {0, 0, 0};
         uint32_t dead = 0;
+        uint32_t pending = 0;     /* points of the stretch being applied that have found this bucket and are not written yet */
         std::vector<Pt> pts;      /* ids ascending; a removed point stays as a mark (x = NaN) until the bucket is compacted */
     };
     struct Slot { uint64_t key; int32_t at; int32_t pad; };   /* at < 0: empty */
@@ -207,6 +218,7 @@ struct s2m_map_mirror {
         Bucket &b = buckets_[(size_t)at];
         for (int q = 0; q < 3; ++q) b.c[q] = (int32_t)((int64_t)((key >> (21 * (2 - q))) & 0x1fffff) - (int64_t)kBias);
         b.dead = 0;
+        b.pending = 0;
         insert_slot(key, at);
         ++used_;
         last_ = at; last_key_ = key;
@@ -227,14 +239,14 @@ struct s2m_map_mirror {
         old.swap(table_);
         size_t keep = 0;
         for (const Slot &s : old)
-            if (s.at >= 0 && !buckets_[(size_t)s.at].pts.empty()) ++keep;
+            if (s.at >= 0 && (!buckets_[(size_t)s.at].pts.empty() || buckets_[(size_t)s.at].pending != 0)) ++keep;
         size_t cap = 1024;
         while (cap < 4 * (keep + 1)) cap *= 2;
         table_.assign(cap, Slot{0, -1, 0});
         used_ = 0;
         for (const Slot &s : old) {
             if (s.at < 0) continue;
-            if (buckets_[(size_t)s.at].pts.empty()) { free_.push_back(s.at); continue; }
+            if (buckets_[(size_t)s.at].pts.empty() && buckets_[(size_t)s.at].pending == 0) { free_.push_back(s.at); continue; }
             insert_slot(s.key, s.at);
             ++used_;
         }
@@ -278,6 +290,7 @@ struct s2m_map_mirror {
         for (size_t i = 0; i < n; ++i) {
             const float *p = &add_xyz_[3 * ((size_t)a0 + i)];
             Bucket &b = bucket_of(p, true);
+            ++b.pending;   /* (a bucket this stretch has just opened is still empty: the table must not shed it before the points are in) */
             where_[i] = (int32_t)(&b - buckets_.data());
         }
         for (size_t i = 0; i < n; ++i) {
@@ -286,7 +299,9 @@ struct s2m_map_mirror {
         }
         for (size_t i = 0; i < n; ++i) {
             const float *p = &add_xyz_[3 * ((size_t)a0 + i)];
-            buckets_[(size_t)where_[i]].pts.push_back(Pt{p[0], p[1], p[2], add_ids_[(size_t)a0 + i]});
+            Bucket &b = buckets_[(size_t)where_[i]];
+            b.pts.push_back(Pt{p[0], p[1], p[2], add_ids_[(size_t)a0 + i]});
+            --b.pending;
         }
         live_ += (int64_t)n;
     }
@@ -314,10 +329,18 @@ struct s2m_map_mirror {
             }
         }
         for (size_t i = 0; i < n; ++i) {
-            if (where_[i] < 0) { ++missed; continue; }
+            if (where_[i] < 0) {
+                if (missed_ids.size() < 64) { missed_ids.push_back(rem_ids_[(size_t)r0 + i]); missed_xyz.insert(missed_xyz.end(), &rem_xyz_[3 * ((size_t)r0 + i)], &rem_xyz_[3 * ((size_t)r0 + i)] + 3); }
+                ++missed;
+                continue;
+            }
             Bucket &b = buckets_[(size_t)where_[i]];
             const size_t at = lo_[i];
-            if (at >= b.pts.size() || b.pts[at].id != rem_ids_[(size_t)r0 + i] || b.pts[at].x != b.pts[at].x) { ++missed; continue; }
+            if (at >= b.pts.size() || b.pts[at].id != rem_ids_[(size_t)r0 + i] || b.pts[at].x != b.pts[at].x) {
+                if (missed_ids.size() < 64) { missed_ids.push_back(rem_ids_[(size_t)r0 + i]); missed_xyz.insert(missed_xyz.end(), &rem_xyz_[3 * ((size_t)r0 + i)], &rem_xyz_[3 * ((size_t)r0 + i)] + 3); }
+                ++missed;
+                continue;
+            }
             mark(b, at);
         }
         for (size_t i = 0; i < n; ++i)

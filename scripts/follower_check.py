@@ -1,0 +1,31 @@
+"""The follower of the change log on the bench's long drive, with and without layouts beside the frames, lag 1 and 0:
+python scripts/follower_check.py [frames]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from daliti_amd import Engine, synth
+from daliti_amd.world import World, run_frames
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1100
+warm = 8
+L = synth.CONFIGS["C3"]["L"]
+w = World(L, 6.0 * L, 1.0)
+seed = w.seed_map(5_000_000)
+sw = w.sweeps(0, frames + warm, 64, 1024, threads=32)
+_, _, P0 = synth.filter_inputs()
+cases = (("inside, lag 1", "S2M_NO_BESIDE", 2), ("beside, lag 1", None, 2), ("beside, lag 0", None, 1))
+if os.environ.get("ONLY"):
+    cases = tuple(c for c in cases if c[0] == os.environ["ONLY"])
+for name, env, publish in cases:
+    if env:
+        os.environ[env] = "1"
+    e = Engine(max_iter=5)
+    if env:
+        del os.environ[env]
+    e.map_build(seed)
+    r = run_frames(e, sw, P0, frames, warm, publish=publish)
+    ms = r["ms"][warm:]
+    st = e.map_update_stats()
+    print("%-14s median %.3f p99 %.3f max %.3f ms; publish median %.3f (fetch %.3f) ms; beside %d; mirror %d map %d resyncs %d missed %d; trims at %s" % (
+        name, np.median(ms), np.percentile(ms, 99), ms.max(), np.median(r["publish_ms"][warm:]), np.median(r["fetch_ms"][warm:]), st["relaid_beside"],
+        r["mirror_points"], r["map_points"], r["mirror_resyncs"], r["mirror_missed"], [int(i) for i in np.nonzero(r["deleted"])[0]]), flush=True)
+    e.close()

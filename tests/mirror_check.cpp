@@ -9,7 +9,9 @@
 #include <random>
 #include <vector>
 
+#define private public   /* (the batched passes update() applies a report with are private: the check drives them directly) */
 #include "daliti_s2m_mirror.hpp"
+#undef private
 
 // the ABI entries update() calls are not reached here; give the linker something
 extern "C" {
@@ -52,15 +54,19 @@ int main()
     for (int r = 0; r < rounds; ++r) {
         // ids leap ahead: the engine's ids ascend for ever (here by 2^30 over the history)
         next_id += (uint32_t)(((uint64_t)1 << 30) / rounds);
-        // add ~3000 points in the window [x0, x0 + 200) x [-50, 50) x [0, 10)
+        // add ~3000 points in the window [x0, x0 + 200) x [-50, 50) x [0, 10): every other round through the batched pass a report
+        // is applied with (new buckets open -- and the table grows -- in the middle of a stretch)
+        m.reserve_io(65536, 65536);
         for (int i = 0; i < 3000; ++i) {
             P p{(float)(x0 + 200.0 * (rng() % 100000) / 100000.0), (float)(-50.0 + 100.0 * (rng() % 100000) / 100000.0), (float)(10.0 * (rng() % 100000) / 100000.0)};
             const float q[3] = {p.x, p.y, p.z};
-            m.add(next_id, q);
+            if (r & 1) { m.add_ids_[(size_t)i] = next_id; m.add_xyz_[3 * (size_t)i] = q[0]; m.add_xyz_[3 * (size_t)i + 1] = q[1]; m.add_xyz_[3 * (size_t)i + 2] = q[2]; }
+            else m.add(next_id, q);
             ref[next_id] = p;
             live.push_back(next_id);
             ++next_id;
         }
+        if (r & 1) m.add_many(0, 3000);
         // remove ~1500 one by one (the voxel rule), some of them twice (the second one must miss)
         for (int i = 0; i < 1500 && !live.empty(); ++i) {
             const size_t k = rng() % live.size();

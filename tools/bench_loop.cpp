@@ -335,7 +335,18 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
             rc = mirror.fetch(e);    // the engine's side of it: what changed, out of pinned memory into the mirror's arrays
             if (rc) return rc;
             if (fetch_us) fetch_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp).count();
+            const int64_t missed_before = mirror.missed;
             mirror.apply();          // the follower's side: could run on the node's publishing thread
+            if (mirror.missed != missed_before) {
+                std::fprintf(stderr, "[bench_loop] frame %d: the follower missed %lld removals (added %lld removed %lld boxes %lld in this report)\n", f,
+                             (long long)(mirror.missed - missed_before), (long long)mirror.last_added, (long long)mirror.last_removed, (long long)mirror.last_boxes);
+                for (size_t k = (size_t)std::min<int64_t>(missed_before, 64); k < mirror.missed_ids.size(); ++k) {
+                    float at[3] = {0, 0, 0};
+                    const bool have = mirror.find_anywhere(mirror.missed_ids[k], at);
+                    std::fprintf(stderr, "    id %u reported at (%.4f %.4f %.4f); the mirror holds it %s (%.4f %.4f %.4f)\n", mirror.missed_ids[k], mirror.missed_xyz[3 * k],
+                                 mirror.missed_xyz[3 * k + 1], mirror.missed_xyz[3 * k + 2], have ? "at" : "nowhere", at[0], at[1], at[2]);
+                }
+            }
             if (publish_us) publish_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp).count();
         }
         frame_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -360,6 +371,12 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         mirror_stats[0] = mirror.size();
         mirror_stats[1] = m;
         mirror_stats[2] = mirror.resyncs;
+        mirror_stats[3] = mirror.missed;
+        if (mirror.missed > 0) {   // (the follower is out of step: say which removals found nothing)
+            std::fprintf(stderr, "[bench_loop] the map's follower missed %lld removals; first ids:", (long long)mirror.missed);
+            for (uint32_t id : mirror.missed_ids) std::fprintf(stderr, " %u", id);
+            std::fprintf(stderr, "\n");
+        }
     }
     return S2M_OK;
 }
