@@ -1349,6 +1349,13 @@ def frame_pipeline_moving(torch, Engine, synth, a):
         torch.cuda.synchronize()
         assert rp0["mirror_points"] == rp0["map_points"]
         ms0 = rp0["ms"][warm:]
+        eng.close()
+        eng = Engine(max_iter=a.max_iter, device=torch.cuda.current_device())
+        eng.map_build(seed)
+        rp3 = run_frames(eng, sw, P0, frames, warm, cube_len=1000.0, prefetch=2, publish=3)
+        torch.cuda.synchronize()
+        assert rp3["mirror_points"] == rp3["map_points"] and rp3["mirror_missed"] == 0
+        ms3 = rp3["ms"][warm:]
         out["with_map_publishing"] = {
             "median_ms": float(np.median(msp)), "p99_ms": float(np.percentile(msp, 99)), "max_ms": float(msp.max()),
             "max_over_median": float(msp.max() / np.median(msp)),
@@ -1360,6 +1367,12 @@ def frame_pipeline_moving(torch, Engine, synth, a):
                              "note": "fetch = s2m_map_get_changes (the handle's thread); the rest = applying it to the mirror's buckets, which a node "
                                      "may leave to its publishing thread (s2m_map_mirror::fetch / apply)"},
             "follower": "one call behind the map (s2m_map_changes.lag = 1): the report of frame k - 1 is applied in frame k",
+            "applied_on_a_publisher_thread": {"median_ms": float(np.median(ms3)), "p99_ms": float(np.percentile(ms3, 99)), "max_ms": float(ms3.max()),
+                                              "max_over_median": float(ms3.max() / np.median(ms3)),
+                                              "fov_trim_frames_ms": {str(f): float(ms3[f]) for f in trims_p},
+                                              "in_frame_ms_median": float(np.median(rp3["publish_ms"][warm:])),
+                                              "note": "the node's publishing thread applies the report (s2m_map_mirror::fetch + hand_over on the engine's "
+                                                      "thread, apply_report on the publisher's): the frame pays for the fetch"},
             "without_lag": {"median_ms": float(np.median(ms0)), "p99_ms": float(np.percentile(ms0, 99)), "max_ms": float(ms0.max()),
                             "map_delta_ms_median": float(np.median(rp0["publish_ms"][warm:])),
                             "note": "lag = 0: the mirror holds the map as it is at the end of every frame; one hand-back inside the frame"},

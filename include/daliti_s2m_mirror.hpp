@@ -68,13 +68,16 @@ struct s2m_map_mirror {
     {
         size_t s = table_.capacity() * sizeof(Slot) + buckets_.capacity() * sizeof(Bucket) + free_.capacity() * sizeof(int32_t);
         for (const Bucket &b : buckets_) s += b.pts.capacity() * sizeof(Pt);
-        s += (add_xyz_.capacity() + rem_xyz_.capacity() + box_.capacity()) * sizeof(float) + (add_ids_.capacity() + rem_ids_.capacity()) * sizeof(uint32_t);
+        for (const IO &io : io_)
+            s += (io.add_xyz.capacity() + io.rem_xyz.capacity() + io.box.capacity()) * sizeof(float) + (io.add_ids.capacity() + io.rem_ids.capacity()) * sizeof(uint32_t);
         return s;
     }
 
     /* brings the mirror to the engine's map (lag = 1: to the map as it was at the previous call); returns an S2M_* code.
-     * = fetch + apply: fetch talks to the engine (the handle's own thread), apply works on the mirror alone -- a node may run it
-     * on its publishing thread */
+     * = fetch + apply.  fetch talks to the engine (the handle's own thread) and fills one of two report buffers; apply works on
+     * the mirror alone.  A node that publishes from its own thread calls fetch + hand_over on the engine's thread and
+     * apply_report(k) on the publisher's -- the two must not run for the SAME buffer at once, and copy_points / for_each belong to
+     * the thread that applies. */
     int update(s2m_engine *e)
     {
         const int rc = fetch(e);
@@ -84,37 +87,69 @@ struct s2m_map_mirror {
     }
     int fetch(s2m_engine *e)
     {
-        if (add_ids_.empty()) reserve_io(65536, 65536);
+        IO &io = io_[cur_];
+        if (io.add_ids.empty()) reserve_io(65536, 65536);
+        io.resync = false;
         for (;;) {
-            std::memset(&c_, 0, sizeof(c_));
-            c_.added_xyz = add_xyz_.data(); c_.added_ids = add_ids_.data(); c_.capacity_added = (int64_t)add_ids_.size();
-            c_.removed_xyz = rem_xyz_.data(); c_.removed_ids = rem_ids_.data(); c_.capacity_removed = (int64_t)rem_ids_.size();
-            c_.boxes = box_.data(); c_.box_after_added = box_a_.data(); c_.box_after_removed = box_r_.data(); c_.capacity_boxes = (int64_t)box_a_.size();
-            c_.lag = lag;
-            int rc = s2m_map_get_changes(e, &token, &c_);
+            s2m_map_changes &c = io.c;
+            std::memset(&c, 0, sizeof(c));
+            c.added_xyz = io.add_xyz.data(); c.added_ids = io.add_ids.data(); c.capacity_added = (int64_t)io.add_ids.size();
+            c.removed_xyz = io.rem_xyz.data(); c.removed_ids = io.rem_ids.data(); c.capacity_removed = (int64_t)io.rem_ids.size();
+            c.boxes = io.box.data(); c.box_after_added = io.box_a.data(); c.box_after_removed = io.box_r.data(); c.capacity_boxes = (int64_t)io.box_a.size();
+            c.lag = lag;
+            int rc = s2m_map_get_changes(e, &token, &c);
             if (rc == S2M_ERR_CAPACITY) {  /* the counts came back: make room and ask again (the changes were kept) */
-                reserve_io(std::max<int64_t>(c_.n_added * 2, (int64_t)add_ids_.size()), std::max<int64_t>(c_.n_removed * 2, (int64_t)rem_ids_.size()));
-                if ((int64_t)box_a_.size() < c_.n_boxes) { box_.resize((size_t)c_.n_boxes * 6); box_a_.resize((size_t)c_.n_boxes); box_r_.resize((size_t)c_.n_boxes); }
+                reserve_io(std::max<int64_t>(c.n_added * 2, (int64_t)io.add_ids.size()), std::max<int64_t>(c.n_removed * 2, (int64_t)io.rem_ids.size()));
+                if ((int64_t)io.box_a.size() < c.n_boxes) { io.box.resize((size_t)c.n_boxes * 6); io.box_a.resize((size_t)c.n_boxes); io.box_r.resize((size_t)c.n_boxes); }
                 continue;
             }
-            if (rc != S2M_OK) { c_.n_added = c_.n_removed = c_.n_boxes = 0; return rc; }
-            if (c_.resync) { c_.n_added = c_.n_removed = c_.n_boxes = 0; return refetch(e); }
+            if (rc != S2M_OK) { c.n_added = c.n_removed = c.n_boxes = 0; return rc; }
+            if (c.resync) {   /* the whole map, once: fetched here (the engine's thread), put into buckets by apply */
+                c.n_added = c.n_removed = c.n_boxes = 0;
+                int64_t m = 0;
+                rc = s2m_map_get_points(e, nullptr, 0, &m);
+                if (rc != S2M_OK) return rc;
+                io.full_xyz.resize((size_t)std::max<int64_t>(m, 1) * 3);
+                io.full_ids.resize((size_t)std::max<int64_t>(m, 1));
+                rc = s2m_map_get_points(e, io.full_xyz.data(), m, &m);
+                if (rc == S2M_OK) rc = s2m_map_get_ids(e, io.full_ids.data(), m, &m);
+                if (rc != S2M_OK) return rc;
+                io.full_xyz.resize((size_t)m * 3);
+                io.full_ids.resize((size_t)m);
+                io.resync = true;
+            }
             return S2M_OK;
         }
     }
-    /* what the last fetch brought, stretch by stretch: additions, then removals, then the box that closes the stretch */
-    void apply()
+    void apply() { apply_report(cur_); }
+    /* the report just fetched is handed to whoever applies it; the next fetch fills the other buffer.  Returns its number */
+    int hand_over() { const int k = cur_; cur_ ^= 1; return k; }
+    /* what fetch brought into buffer k, stretch by stretch: additions, then removals, then the box that closes the stretch */
+    void apply_report(int k)
     {
-        last_added = c_.n_added; last_removed = c_.n_removed; last_boxes = c_.n_boxes;
+        IO &io = io_[k];
+        ap_ = &io;
+        if (io.resync) {
+            clear();
+            for (size_t i = 0; i < io.full_ids.size(); ++i) add(io.full_ids[i], &io.full_xyz[3 * i]);   /* ascending ids: every bucket's ids ascend */
+            std::vector<float>().swap(io.full_xyz);
+            std::vector<uint32_t>().swap(io.full_ids);
+            io.resync = false;
+            ++resyncs;
+            last_added = last_removed = last_boxes = 0;
+            return;
+        }
+        const s2m_map_changes &c = io.c;
+        last_added = c.n_added; last_removed = c.n_removed; last_boxes = c.n_boxes;
         int64_t a0 = 0, r0 = 0;
-        for (int64_t k = 0; k <= c_.n_boxes; ++k) {
-            const int64_t a1 = k < c_.n_boxes ? box_a_[(size_t)k] : c_.n_added, r1 = k < c_.n_boxes ? box_r_[(size_t)k] : c_.n_removed;
+        for (int64_t q = 0; q <= c.n_boxes; ++q) {
+            const int64_t a1 = q < c.n_boxes ? io.box_a[(size_t)q] : c.n_added, r1 = q < c.n_boxes ? io.box_r[(size_t)q] : c.n_removed;
             add_many(a0, a1);
             remove_many(r0, r1);
-            if (k < c_.n_boxes) delete_box(&box_[6 * (size_t)k]);
+            if (q < c.n_boxes) delete_box(&io.box[6 * (size_t)q]);
             a0 = a1; r0 = r1;
         }
-        c_.n_added = c_.n_removed = c_.n_boxes = 0;
+        io.c.n_added = io.c.n_removed = io.c.n_boxes = 0;
     }
 
     /* ---- the pieces update() is made of, public so that they can be tested without a device ---- */
@@ -288,7 +323,7 @@ struct s2m_map_mirror {
         if (n == 0) return;
         where_.resize(n);
         for (size_t i = 0; i < n; ++i) {
-            const float *p = &add_xyz_[3 * ((size_t)a0 + i)];
+            const float *p = &ap_->add_xyz[3 * ((size_t)a0 + i)];
             Bucket &b = bucket_of(p, true);
             ++b.pending;   /* (a bucket this stretch has just opened is still empty: the table must not shed it before the points are in) */
             where_[i] = (int32_t)(&b - buckets_.data());
@@ -298,9 +333,9 @@ struct s2m_map_mirror {
             if (!b.pts.empty()) __builtin_prefetch(&b.pts.back() + 1, 1);
         }
         for (size_t i = 0; i < n; ++i) {
-            const float *p = &add_xyz_[3 * ((size_t)a0 + i)];
+            const float *p = &ap_->add_xyz[3 * ((size_t)a0 + i)];
             Bucket &b = buckets_[(size_t)where_[i]];
-            b.pts.push_back(Pt{p[0], p[1], p[2], add_ids_[(size_t)a0 + i]});
+            b.pts.push_back(Pt{p[0], p[1], p[2], ap_->add_ids[(size_t)a0 + i]});
             --b.pending;
         }
         live_ += (int64_t)n;
@@ -310,7 +345,7 @@ struct s2m_map_mirror {
         const size_t n = (size_t)(r1 - r0);
         if (n == 0) return;
         where_.resize(n);
-        for (size_t i = 0; i < n; ++i) where_[i] = find_bucket(key_of(&rem_xyz_[3 * ((size_t)r0 + i)]));
+        for (size_t i = 0; i < n; ++i) where_[i] = find_bucket(key_of(&ap_->rem_xyz[3 * ((size_t)r0 + i)]));
         /* the binary searches level by level, all points abreast: lo_ / len_ are every search's window */
         lo_.assign(n, 0);
         len_.resize(n);
@@ -324,20 +359,20 @@ struct s2m_map_mirror {
                 if (len_[i] == 0) continue;
                 const Bucket &b = buckets_[(size_t)where_[i]];
                 const uint32_t half = len_[i] >> 1;
-                if (b.pts[lo_[i] + half].id < rem_ids_[(size_t)r0 + i]) { lo_[i] += half + 1; len_[i] -= half + 1; } else len_[i] = half;
+                if (b.pts[lo_[i] + half].id < ap_->rem_ids[(size_t)r0 + i]) { lo_[i] += half + 1; len_[i] -= half + 1; } else len_[i] = half;
                 if (len_[i] > 0) __builtin_prefetch(&b.pts[lo_[i] + (len_[i] >> 1)]);
             }
         }
         for (size_t i = 0; i < n; ++i) {
             if (where_[i] < 0) {
-                if (missed_ids.size() < 64) { missed_ids.push_back(rem_ids_[(size_t)r0 + i]); missed_xyz.insert(missed_xyz.end(), &rem_xyz_[3 * ((size_t)r0 + i)], &rem_xyz_[3 * ((size_t)r0 + i)] + 3); }
+                if (missed_ids.size() < 64) { missed_ids.push_back(ap_->rem_ids[(size_t)r0 + i]); missed_xyz.insert(missed_xyz.end(), &ap_->rem_xyz[3 * ((size_t)r0 + i)], &ap_->rem_xyz[3 * ((size_t)r0 + i)] + 3); }
                 ++missed;
                 continue;
             }
             Bucket &b = buckets_[(size_t)where_[i]];
             const size_t at = lo_[i];
-            if (at >= b.pts.size() || b.pts[at].id != rem_ids_[(size_t)r0 + i] || b.pts[at].x != b.pts[at].x) {
-                if (missed_ids.size() < 64) { missed_ids.push_back(rem_ids_[(size_t)r0 + i]); missed_xyz.insert(missed_xyz.end(), &rem_xyz_[3 * ((size_t)r0 + i)], &rem_xyz_[3 * ((size_t)r0 + i)] + 3); }
+            if (at >= b.pts.size() || b.pts[at].id != ap_->rem_ids[(size_t)r0 + i] || b.pts[at].x != b.pts[at].x) {
+                if (missed_ids.size() < 64) { missed_ids.push_back(ap_->rem_ids[(size_t)r0 + i]); missed_xyz.insert(missed_xyz.end(), &ap_->rem_xyz[3 * ((size_t)r0 + i)], &ap_->rem_xyz[3 * ((size_t)r0 + i)] + 3); }
                 ++missed;
                 continue;
             }
@@ -346,27 +381,12 @@ struct s2m_map_mirror {
         for (size_t i = 0; i < n; ++i)
             if (where_[i] >= 0) settle(where_[i]);
     }
-    int refetch(s2m_engine *e)
-    {
-        int64_t m = 0;
-        int rc = s2m_map_get_points(e, nullptr, 0, &m);
-        if (rc != S2M_OK) return rc;
-        std::vector<float> xyz((size_t)std::max<int64_t>(m, 1) * 3);
-        std::vector<uint32_t> ids((size_t)std::max<int64_t>(m, 1));
-        rc = s2m_map_get_points(e, xyz.data(), m, &m);
-        if (rc == S2M_OK) rc = s2m_map_get_ids(e, ids.data(), m, &m);
-        if (rc != S2M_OK) return rc;
-        clear();
-        for (int64_t i = 0; i < m; ++i) add(ids[(size_t)i], &xyz[3 * (size_t)i]);   /* ascending ids: every bucket's ids ascend */
-        ++resyncs;
-        last_added = last_removed = last_boxes = 0;
-        return S2M_OK;
-    }
     void reserve_io(int64_t na, int64_t nr)
     {
-        add_ids_.resize((size_t)na); add_xyz_.resize((size_t)na * 3);
-        rem_ids_.resize((size_t)nr); rem_xyz_.resize((size_t)nr * 3);
-        if (box_a_.empty()) { box_.resize(6 * 64); box_a_.resize(64); box_r_.resize(64); }
+        IO &io = io_[cur_];
+        io.add_ids.resize((size_t)na); io.add_xyz.resize((size_t)na * 3);
+        io.rem_ids.resize((size_t)nr); io.rem_xyz.resize((size_t)nr * 3);
+        if (io.box_a.empty()) { io.box.resize(6 * 64); io.box_a.resize(64); io.box_r.resize(64); }
     }
 
     std::vector<Bucket> buckets_;
@@ -376,10 +396,16 @@ struct s2m_map_mirror {
     int64_t live_ = 0;
     int32_t last_ = -1;
     uint64_t last_key_ = 0;
-    std::vector<float> add_xyz_, rem_xyz_, box_;
-    std::vector<uint32_t> add_ids_, rem_ids_;
-    std::vector<int64_t> box_a_, box_r_;
-    s2m_map_changes c_ = {};   /* what the last fetch brought and apply() has not applied yet */
+    struct IO {   /* one report: what fetch filled and apply has not applied yet */
+        std::vector<float> add_xyz, rem_xyz, box, full_xyz;
+        std::vector<uint32_t> add_ids, rem_ids, full_ids;
+        std::vector<int64_t> box_a, box_r;
+        s2m_map_changes c = {};
+        bool resync = false;
+    };
+    IO io_[2];
+    int cur_ = 0;
+    IO *ap_ = &io_[0];   /* the report being applied */
     std::vector<int32_t> where_;
     std::vector<uint32_t> lo_, len_;
 };

@@ -60,7 +60,7 @@ int main()
         for (int i = 0; i < 3000; ++i) {
             P p{(float)(x0 + 200.0 * (rng() % 100000) / 100000.0), (float)(-50.0 + 100.0 * (rng() % 100000) / 100000.0), (float)(10.0 * (rng() % 100000) / 100000.0)};
             const float q[3] = {p.x, p.y, p.z};
-            if (r & 1) { m.add_ids_[(size_t)i] = next_id; m.add_xyz_[3 * (size_t)i] = q[0]; m.add_xyz_[3 * (size_t)i + 1] = q[1]; m.add_xyz_[3 * (size_t)i + 2] = q[2]; }
+            if (r & 1) { m.io_[0].add_ids[(size_t)i] = next_id; m.io_[0].add_xyz[3 * (size_t)i] = q[0]; m.io_[0].add_xyz[3 * (size_t)i + 1] = q[1]; m.io_[0].add_xyz[3 * (size_t)i + 2] = q[2]; }
             else m.add(next_id, q);
             ref[next_id] = p;
             live.push_back(next_id);

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -253,7 +254,39 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
     // publish != 0: the node also keeps /Laser_map up to date every frame (laserMapping.cpp:1170-1175, 1229-1235) -- a host
     // mirror fed by s2m_map_get_changes (daliti_s2m_mirror.hpp); publish_us[f] = that call's share of the frame
     s2m_map_mirror mirror;
-    mirror.lag = publish == 2 ? 1 : 0;   // publish: 1 = the map as it is now (the call waits for the device), 2 = one call behind (nobody waits)
+    // publish: 1 = the map as it is now (the call waits for the device), 2 = one call behind (nobody waits), 3 = one call behind
+    // and the report applied by a publisher thread (the node's publishing thread): the frame pays for the fetch only
+    mirror.lag = publish >= 2 ? 1 : 0;
+    struct Publisher {   // applies the reports the frame loop hands over, one at a time
+        s2m_map_mirror &m;
+        std::mutex mu;
+        std::condition_variable cv;
+        int job = -1;
+        bool busy = false, stop = false;
+        std::thread th;
+        explicit Publisher(s2m_map_mirror &mm) : m(mm)
+        {
+            th = std::thread([this] {
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    cv.wait(lk, [this] { return stop || job >= 0; });
+                    if (stop) return;
+                    const int k = job;
+                    job = -1;
+                    lk.unlock();
+                    m.apply_report(k);
+                    lk.lock();
+                    busy = false;
+                    cv.notify_all();
+                }
+            });
+        }
+        void idle() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return !busy; }); }
+        void give(int k) { { std::lock_guard<std::mutex> lk(mu); job = k; busy = true; } cv.notify_all(); }
+        ~Publisher() { idle(); { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); th.join(); }
+    };
+    std::unique_ptr<Publisher> pub;
+    if (publish == 3) pub.reset(new Publisher(mirror));
     if (publish) {
         rc = mirror.update(e);  // the one whole-map fetch, before the drive
         if (rc) return rc;
@@ -332,11 +365,13 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
         if (publish) {
             const auto tp = std::chrono::steady_clock::now();
             stall.at(f, 6);
+            if (pub) pub->idle();    // (the previous report has been applied: its buffer is free again in two fetches' time, this waits for nothing)
             rc = mirror.fetch(e);    // the engine's side of it: what changed, out of pinned memory into the mirror's arrays
             if (rc) return rc;
             if (fetch_us) fetch_us[f] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp).count();
             const int64_t missed_before = mirror.missed;
-            mirror.apply();          // the follower's side: could run on the node's publishing thread
+            if (pub) pub->give(mirror.hand_over());   // the follower's side on the publisher's thread ...
+            else mirror.apply();                      // ... or here
             if (mirror.missed != missed_before) {
                 std::fprintf(stderr, "[bench_loop] frame %d: the follower missed %lld removals (added %lld removed %lld boxes %lld in this report)\n", f,
                              (long long)(mirror.missed - missed_before), (long long)mirror.last_added, (long long)mirror.last_removed, (long long)mirror.last_boxes);
@@ -360,6 +395,7 @@ int s2m_bench_frames_moving(s2m_engine *e, int32_t frames, int32_t warm, const f
             st_prev[3] = st_now[3];
         }
     }
+    if (pub) pub.reset();
     if (publish && mirror.lag != 0) {  // (untimed: a follower that is one call behind catches up before it is compared with the map)
         mirror.lag = 0;
         rc = mirror.update(e);
