@@ -213,6 +213,8 @@ struct s2m_engine {
         hipStream_t stream = nullptr;
         hipEvent_t ev_main = nullptr;      // recorded on the main stream behind what the worker is about to read
         hipEvent_t ev_side = nullptr;      // recorded on the layout stream behind what it has written
+        hipEvent_t ev_snap = nullptr;      // ... behind the snapshot (which reads the live map: the next update of it waits)
+        bool snap_fence = false;
         MapBuffers map;                    // the other map: being built, or the previous live one waiting for the next turn
         UpdateBuffers upd;
         Grid grid{};
@@ -233,6 +235,7 @@ struct s2m_engine {
         int64_t arena_cap = 0, arena_head = 0, arena_tail = 0;
         // triggers
         int64_t commits = 0, since_layout = 0, force_at = -1;
+        int64_t n_started = 0, n_dropped = 0, n_failed = 0;   // layouts begun / given up / failed (diagnostic: s2m_debug_state)
         bool force_regrid = false, enabled = true;
         uint32_t *d_cells = nullptr, *h_cells = nullptr, *h_cells_dev = nullptr;
         uint32_t cells_seq = 0;
@@ -282,7 +285,8 @@ int commit_update(s2m_engine *e, MapSide s, const float *boxes, int nb);
 int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid);   // end of every update of the live map: triggers, snapshot
 int relay_record_lists(s2m_engine *e, const float4 *la, int64_t na, bool ds_a, float fs, const s2m::VoxBox *vox, const float4 *lb, int64_t nb);
 int relay_record_boxes(s2m_engine *e, const float *boxes, int nb);
-int relay_poll(s2m_engine *e);      // start of every update of the live map: swap when the other map has caught up
+int relay_poll(s2m_engine *e);      // when a new scan arrives / an update begins: swap when the other map has caught up
+int relay_fence(s2m_engine *e);     // before an update writes the live map: the snapshot that reads it is over
 int relay_rehearse(s2m_engine *e, const float *cloud_dev, int64_t stride, int64_t m);   // behind s2m_map_build: the other map's buffers, now
 int relay_cancel(s2m_engine *e);    // the live map is being replaced: whatever is in flight is dropped (waits for the worker to let go)
 void relay_shutdown(s2m_engine *e); // s2m_destroy

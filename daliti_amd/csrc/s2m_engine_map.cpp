@@ -211,6 +211,8 @@ int s2m_map_add(s2m_engine *e, const float *xyz, int64_t stride, int64_t n, int 
     if (rc) return rc;
     rc = relay_poll(e);   // (a layout that was produced beside the frames takes the live map's place here, between two updates)
     if (rc) return rc;
+    rc = relay_fence(e);
+    if (rc) return rc;
     float4 *np = nullptr;
     S2M_HIP(e, xyz_to_float4(e->upd, dev, stride, n, &np, e->stream));
     rc = relay_record_lists(e, np, n, downsample_on != 0, downsample_size, nullptr, nullptr, 0);
@@ -232,6 +234,8 @@ int s2m_map_delete_boxes(s2m_engine *e, const float *boxes, int64_t n, int64_t *
     if (!delete_touches_map(e->grid, boxes, (int)n)) return S2M_OK;  // (the slab ahead of the sensor after a cube move)
     S2M_ENTER(e);
     int rc = relay_poll(e);
+    if (rc) return rc;
+    rc = relay_fence(e);
     if (rc) return rc;
     bind_update(e, live_side(e));
     S2M_HIP(e, update_begin(e->upd, e->grid, e->stream));
@@ -275,6 +279,8 @@ int s2m_map_incremental(s2m_engine *e, const double state[S2M_STATE_DOUBLES], do
     S2M_ENTER(e);
     {
         int rc = relay_poll(e);   // (a layout that was produced beside the frames takes the live map's place here, between two updates)
+        if (rc) return rc;
+        rc = relay_fence(e);
         if (rc) return rc;
     }
     const Pose pose = pose_of(state);

@@ -49,15 +49,36 @@ MapSide other_side(s2m_engine *e)
 hipError_t worker_prepare(s2m_engine *e)
 {
     Relay &r = e->relay;
-    if (!r.stream) {   // the lowest priority the device offers: a frame's kernels go first wherever the two streams meet
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-        if (hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, least) != hipSuccess) {
-            (void)hipGetLastError();
-            S2M_TRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    if (!r.stream) {
+        // The layout's kernels (a radix sort of millions of keys) should not take the chip from a frame's: the layout stream has
+        // the lowest priority the device offers.  Measured and not kept as the default: a stream that owns only 32 or 64 of the 256
+        // compute units (hipExtStreamCreateWithCUMask, S2M_BESIDE_CUS=n) -- the frames beside the build were no faster (0.59 -
+        // 0.66 ms either way: they wait for the snapshot and for the update calls' copies, not for compute units) and the build,
+        // eight times longer, slowed two hundred frames by 10 % instead of sixty (NOTEBOOK round 6).
+        int cus = 0, want = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, e->device) == hipSuccess) cus = prop.multiProcessorCount;
+        if (const char *g = std::getenv("S2M_BESIDE_CUS")) want = std::atoi(g);
+        if (want > 0 && want < cus) {
+            std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+            for (int i = 0; i < want; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+            if (hipExtStreamCreateWithCUMask(&r.stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                r.stream = nullptr;
+            }
+        }
+        if (!r.stream) {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+            if (hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, least) != hipSuccess) {
+                (void)hipGetLastError();
+                S2M_TRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+            }
         }
     }
     if (!r.ev_side) S2M_TRY(hipEventCreateWithFlags(&r.ev_side, hipEventDisableTiming));
+    if (!r.ev_main) S2M_TRY(hipEventCreateWithFlags(&r.ev_main, hipEventDisableTiming));
+    if (!r.ev_snap) S2M_TRY(hipEventCreateWithFlags(&r.ev_snap, hipEventDisableTiming));
     if (!r.snap_count) S2M_TRY(hipMalloc((void **)&r.snap_count, sizeof(uint32_t)));
     if (r.snap_cap < r.snap_bound) {
         if (r.snap) S2M_TRY(hipFree(r.snap));
@@ -76,6 +97,13 @@ hipError_t worker_prepare(s2m_engine *e)
         r.snap_tmp_bytes = snapshot_sort_tmp_bytes(want);
         S2M_TRY(hipMalloc(&r.snap_tmp, std::max<size_t>(r.snap_tmp_bytes, 256)));
         r.snap_cap = want;
+    }
+    if (!r.d_cells) {   // the density probe's words (a device word, a pinned pair): here, not beside a frame (a pinned allocation is milliseconds)
+        S2M_TRY(hipMalloc((void **)&r.d_cells, sizeof(uint32_t)));
+        S2M_TRY(hipMemset(r.d_cells, 0, sizeof(uint32_t)));
+        S2M_TRY(hipHostMalloc((void **)&r.h_cells, 16 * sizeof(uint32_t), hipHostMallocMapped));
+        S2M_TRY(hipHostGetDevicePointer((void **)&r.h_cells_dev, r.h_cells, 0));
+        r.h_cells[0] = 0u;
     }
     const int64_t blocks = snapshot_blocks(r.extent_bound) + 1;
     if (r.snap_blk_cap < blocks) {
@@ -239,6 +267,7 @@ void relay_drop(s2m_engine *e)
     Relay &r = e->relay;
     std::lock_guard<std::mutex> lk(r.mu);
     if (r.state.load() == Relay::kIdle) return;
+    ++r.n_dropped;
     r.cancel.store(1);
     r.cv.notify_all();
 }
@@ -261,9 +290,16 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
     if (st == Relay::kSnapReady && r.cancel.load() == 0) {
         // the snapshot, behind this update: every live point with its id; the worker builds from it
         if (e->grid.live > r.snap_cap || snapshot_blocks(e->grid.m) > r.snap_blk_cap) { relay_drop(e); return S2M_OK; }
+        // ... on the layout stream, behind this update (event) -- the registration of the next scan only READS the live map and runs
+        // beside it; the next update of the live map, the first thing that writes it, waits for the snapshot's event (relay_fence:
+        // a quarter of a millisecond later, long done)
         if (!r.ev_main) S2M_HIP(e, hipEventCreateWithFlags(&r.ev_main, hipEventDisableTiming));
-        launch_snapshot(e->grid.pts, e->grid.pidx, e->grid.m, r.snap, r.snap_count, r.snap_cap, r.snap_blk, e->stream);
+        if (!r.ev_snap) S2M_HIP(e, hipEventCreateWithFlags(&r.ev_snap, hipEventDisableTiming));
         S2M_HIP(e, hipEventRecord(r.ev_main, e->stream));
+        S2M_HIP(e, hipStreamWaitEvent(r.stream, r.ev_main, 0));
+        launch_snapshot(e->grid.pts, e->grid.pidx, e->grid.m, r.snap, r.snap_count, r.snap_cap, r.snap_blk, r.stream);
+        S2M_HIP(e, hipEventRecord(r.ev_snap, r.stream));
+        r.snap_fence = true;
         std::lock_guard<std::mutex> lk(r.mu);
         r.id_snap = e->map.next_id;
         r.grid.ox = e->grid.ox; r.grid.oy = e->grid.oy; r.grid.oz = e->grid.oz;   // (what the build keeps unless it re-grids)
@@ -305,6 +341,7 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
     {
         std::lock_guard<std::mutex> lk(r.mu);
         r.why = why;
+        ++r.n_started;
         r.regrid = regrid;
         r.snap_bound = e->grid.live + e->grid.live / 8 + 65536;   // (the snapshot is taken a frame or two from now)
         r.extent_bound = e->grid.m + e->grid.m / 8 + 65536;
@@ -325,29 +362,32 @@ int relay_rehearse(s2m_engine *e, const float *cloud_dev, int64_t stride, int64_
 {
     Relay &r = e->relay;
     if (!r.enabled || e->cfg.layout_beside == 0 || e->no_merge || e->no_slab || m < 4096 || r.state.load() != Relay::kIdle) return S2M_OK;
+    static const bool off = std::getenv("S2M_NO_REHEARSAL") != nullptr;   // (A/B runs)
+    if (off) return S2M_OK;
     r.snap_bound = m + m / 8 + 65536;
     r.extent_bound = 4 * m + ((int64_t)1 << 23);
     hipError_t he = worker_prepare(e);
     if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "the buffers of the layout beside the frames", he);
     if (!r.ev_main) S2M_HIP(e, hipEventCreateWithFlags(&r.ev_main, hipEventDisableTiming));
-    S2M_HIP(e, hipEventRecord(r.ev_main, e->stream));
-    S2M_HIP(e, hipStreamWaitEvent(r.stream, r.ev_main, 0));   // (the cloud is staged on the main stream)
+    // (on the main stream: the whole chip, and the cloud is staged there)
+    const hipStream_t st = e->stream;
     const float origin[3] = {e->grid.ox, e->grid.oy, e->grid.oz};
     bool too_large = false;
-    he = build_map(cloud_dev, stride, m, e->grid.c, r.map, r.grid, r.stats, too_large, r.stream, origin);
+    he = build_map(cloud_dev, stride, m, e->grid.c, r.map, r.grid, r.stats, too_large, st, origin);
     if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "the rehearsal of the layout beside the frames", he);
     if (too_large) return S2M_OK;
     r.built_cell = r.grid.c;
-    const MapSide s = other_side(e);
+    MapSide s = other_side(e);
+    s.st = st;
     for (int round = 0; round < 2; ++round) {
-        S2M_HIP(e, hipMemcpy2DAsync(r.arena, sizeof(float4), cloud_dev, (size_t)stride * sizeof(float), 3 * sizeof(float), 1, hipMemcpyDeviceToDevice, r.stream));
+        S2M_HIP(e, hipMemcpy2DAsync(r.arena, sizeof(float4), cloud_dev, (size_t)stride * sizeof(float), 3 * sizeof(float), 1, hipMemcpyDeviceToDevice, st));
         bind_update(e, s);
-        he = update_begin(r.upd, r.grid, r.stream);
-        if (he == hipSuccess) he = update_add(r.upd, r.grid, r.arena, 1, false, 0.0f, nullptr, r.stream, nullptr, true);
+        he = update_begin(r.upd, r.grid, st);
+        if (he == hipSuccess) he = update_add(r.upd, r.grid, r.arena, 1, false, 0.0f, nullptr, st, nullptr, true);
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "the rehearsal of the layout beside the frames", he);
         if (commit_update(e, s, nullptr, 0) != S2M_OK) break;   // (not fatal: the first real layout allocates what is missing)
     }
-    return sync_stream(e, r.stream, "the rehearsal of the layout beside the frames");
+    return sync_stream(e, st, "the rehearsal of the layout beside the frames");
 }
 
 int relay_record_lists(s2m_engine *e, const float4 *la, int64_t na, bool ds_a, float fs, const VoxBox *vox, const float4 *lb, int64_t nb)
@@ -398,6 +438,16 @@ int relay_record_boxes(s2m_engine *e, const float *boxes, int nb)
     return S2M_OK;
 }
 
+// before anything writes the live map: a snapshot that is still being read must be over
+int relay_fence(s2m_engine *e)
+{
+    Relay &r = e->relay;
+    if (!r.snap_fence) return S2M_OK;
+    r.snap_fence = false;
+    S2M_HIP(e, hipStreamWaitEvent(e->stream, r.ev_snap, 0));
+    return S2M_OK;
+}
+
 int relay_poll(s2m_engine *e)
 {
     Relay &r = e->relay;
@@ -409,6 +459,7 @@ int relay_poll(s2m_engine *e)
     std::unique_lock<std::mutex> lk(r.mu);
     if (r.state.load() == Relay::kFailed) {
         const bool timed_out = r.why == "timeout";
+        ++r.n_failed;
         r.ops.clear();
         r.arena_head = r.arena_tail = 0;
         r.state.store(Relay::kIdle);
@@ -512,6 +563,7 @@ void relay_shutdown(s2m_engine *e)
     if (r.stream) { (void)wait_stream(&e->wait, r.stream, "the layout stream (s2m_destroy)"); (void)hipStreamDestroy(r.stream); r.stream = nullptr; }
     if (r.ev_main) (void)hipEventDestroy(r.ev_main);
     if (r.ev_side) (void)hipEventDestroy(r.ev_side);
+    if (r.ev_snap) (void)hipEventDestroy(r.ev_snap);
     free_map(r.map);
     free_update(r.upd);
     if (r.snap) (void)hipFree(r.snap);

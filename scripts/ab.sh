@@ -19,7 +19,7 @@ leg_args() {
     C1|C2|C3|C4|R1) echo "--config $1 --no-cpu --no-side" ;;
     K*) echo "--config C5 --replicas ${1#K} --no-cpu --steps 100" ;;
     B*) echo "--config C5b --replicas ${1#B} --no-cpu --steps 40" ;;
-    FRAME) echo "--config C3 --no-cpu --steps 50" ;;
+    FRAME) echo "--config C3 --cpu-steps 0 --steps 50 --moving-frames 0" ;;
     *) echo "unknown leg $1" >&2; exit 2 ;;
   esac
 }

@@ -48,3 +48,5 @@ for frame in range(N):
     e.fov_segment(r["x"][9:12], 1000.0)
 sync(); dt = (time.perf_counter() - t0) / N * 1e3
 print("back to back, no per-stage sync: %.3f ms per frame -> %.0f frames/s" % (dt, 1e3 / dt))
+print(e.debug_state())
+print(e.map_update_stats())

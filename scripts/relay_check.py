@@ -16,7 +16,10 @@ seed = w.seed_map(5_000_000)
 sw = w.sweeps(0, frames + warm, 64, 1024, threads=32)
 _, _, P0 = synth.filter_inputs()
 out = {}
-for name, env, publish in (("beside", None, 0), ("inside", "S2M_NO_BESIDE", 0), ("beside+follower", None, 2)):
+cases = (("beside", None, 0), ("inside", "S2M_NO_BESIDE", 0), ("beside+follower", None, 2))
+if os.environ.get("ONLY"):
+    cases = tuple(c for c in cases if c[0] == os.environ["ONLY"])
+for name, env, publish in cases:
     if env:
         os.environ[env] = "1"
     e = Engine(max_iter=5)
@@ -39,6 +42,8 @@ for name, env, publish in (("beside", None, 0), ("inside", "S2M_NO_BESIDE", 0), 
     if os.environ.get("PER100"):
         print("   median per 100 frames:", " ".join("%.3f" % np.median(ms[k:k + 100]) for k in range(0, frames, 100)))
     e.close()
+if len(out) < 3:
+    sys.exit(0)
 a, b = out["beside"], out["inside"]
 dx = np.abs(a[0] - b[0]).max(axis=1)
 print("poses: max |beside - inside| = %.3e (first frame that differs: %s)" % (dx.max(), int(np.argmax(dx > 0)) if (dx > 0).any() else None))
