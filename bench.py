@@ -894,6 +894,11 @@ def main():
             out["realistic_prior"] = realistic_prior(torch, eng, synth, scans[0][0], P0)
         except Exception as ex:  # noqa: BLE001
             out["realistic_prior"] = {"error": str(ex)[:300]}
+        leg("wait_policies", 45)
+        try:
+            out["wait_policies"] = wait_policies(torch, eng, synth, P0)
+        except Exception as ex:  # noqa: BLE001
+            out["wait_policies"] = {"error": str(ex)[:300]}
         leg("varying_scan", 90)
         try:  # the headline's bet on an empty far-point list against input that changes every step
             out["varying_scan"] = varying_scan(torch, Engine, synth, eng, a)
@@ -1060,6 +1065,31 @@ def realistic_prior(torch, eng, synth, scan, P0, steps=60, warmup=10):
                       "bets": dict(zip(("won", "lost"), eng.bet_stats()))}
     out["note"] = ("one handle, the C3 scan against the resident map, s2m_iterated_update per step from tools/bench_loop.cpp; the "
                    "IMU-sized prior is what frame_pipeline_moving feeds every frame")
+    return out
+
+
+def wait_policies(torch, eng, synth, P0, steps=60, warmup=10):
+    """how the calling thread waits for the device (s2m_config.wait_policy) against the headline's step -- the
+    same scan, map and loop under spin (the headline's), yield and sleep; median of three runs each."""
+    _, x_prop, _ = synth.filter_inputs()
+    out = {}
+    try:
+        for pol, name in ((0, "spin"), (1, "yield"), (2, "sleep")):
+            eng.set_config(wait_policy=pol)
+            cl = CLoop([eng], [x_prop], [P0], 0)
+            cl.run(warmup)
+            runs = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                cl.run(steps)
+                torch.cuda.synchronize()
+                runs.append(time.perf_counter() - t0)
+            out[name] = {"ms_per_step": 1e3 * sorted(runs)[1] / steps}
+    finally:
+        eng.set_config(wait_policy=0)
+    out["note"] = ("spin: poll with `pause` (one core busy); yield: 40 us of that, then sched_yield between polls; sleep: then nanosleep "
+                   "(50 us quanta) -- the frame under each policy: scripts/hang_hunt.py, profiles/r06_hang_hunt.txt")
     return out
 
 

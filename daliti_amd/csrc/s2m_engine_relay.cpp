@@ -387,6 +387,9 @@ int relay_rehearse(s2m_engine *e, const float *cloud_dev, int64_t stride, int64_
         if (he != hipSuccess) return fail(e, S2M_ERR_HIP, "the rehearsal of the layout beside the frames", he);
         if (commit_update(e, s, nullptr, 0) != S2M_OK) break;   // (not fatal: the first real layout allocates what is missing)
     }
+    // (and the code object of s2m_relay.hip is loaded by its first launch -- milliseconds, seen as frame 23 of every drive, where
+    // the first density count fell: here instead)
+    launch_count_cells(r.map.counters + kBricksWord, r.stats.bricks, r.grid.tab, r.d_cells, r.h_cells_dev, 0u, st);
     return sync_stream(e, st, "the rehearsal of the layout beside the frames");
 }
 
