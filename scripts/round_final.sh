@@ -20,6 +20,7 @@ b C5_K16 --config C5 --replicas 16 --no-cpu
 b C5_K24 --config C5 --replicas 24 --no-cpu
 b C5_K32 --config C5 --replicas 32 --no-cpu
 b C5_K24_device_loop --config C5 --replicas 24 --no-cpu --device-loop
+b C5b_K24 --config C5b --replicas 24 --no-cpu
 b host2 --collective host --shards 2 --no-cpu
 b host8 --collective host --shards 8 --no-cpu
 bash scripts/profile_round.sh ${TAG}_C3 > /dev/null 2>&1; echo "prof C3 rc=$?"

@@ -1,6 +1,8 @@
 """Incremental map maintenance against the oracle's sequential restatement of
 map_incremental / Add_Points / Delete_Point_Boxes.  Maps are compared as sets of points (the two
 sides keep different insertion orders); poses of a multi-frame run must still agree to 1e-9."""
+import time
+
 import numpy as np
 import pytest
 
@@ -955,3 +957,81 @@ def test_update_roads_agree(oracle, small_scene, monkeypatch):
         e.close()
     for a, b in zip(layouts[0], layouts[1]):
         assert a.shape == b.shape and (bits(a) == bits(b)).all() if a.dtype == np.float32 else (a == b).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hook", ["3", "3,regrid", "6"])
+def test_updates_with_a_layout_beside_them_equal_updates_without(small_scene, monkeypatch, hook):
+    """A sequence of Add_Points (with and without the voxel rule) and Delete_Point_Boxes calls through a handle that renews its
+    layout beside the updates (forced behind the n-th one: snapshot, build on the layout thread, the calls that arrive meanwhile
+    run again on the new map, swap when a new scan arrives) and through one that never does: the same map after every call --
+    the same points under the same ids -- and the follower of the change log sees no break."""
+    from daliti_amd import Engine
+    from daliti_amd.engine import apply_map_changes
+    rs = np.random.RandomState(31)
+    base = small_scene["map"]
+    calls = []
+    for k in range(14):
+        if k % 5 == 4:
+            c = base[rs.randint(len(base))]
+            calls.append(("box", np.float32([c[0] - 0.8, c[1] - 0.8, c[2] - 0.8, c[0] + 0.8, c[1] + 0.8, c[2] + 0.8])))
+        else:
+            pts = (base[rs.choice(len(base), 700)] + rs.normal(0, 0.25, (700, 3))).astype(np.float32)
+            calls.append(("add", pts, k % 2 == 0))
+    states = {}
+    for road in ("beside", "inside"):
+        if road == "beside":
+            monkeypatch.setenv("S2M_BESIDE_AT", hook)
+            monkeypatch.delenv("S2M_NO_BESIDE", raising=False)
+        else:
+            monkeypatch.delenv("S2M_BESIDE_AT", raising=False)
+            monkeypatch.setenv("S2M_NO_BESIDE", "1")
+        e = Engine(cell_size=0.0 if "regrid" in hook else 0.5)
+        e.map_build(base)
+        ch = e.map_changes(0)
+        token, ids, xyz = ch.token, e.map_ids(), e.map_points().copy()
+        out = []
+        for call in calls:
+            if call[0] == "box":
+                e.map_delete_boxes([call[1]])
+            else:
+                e.map_add(call[1], call[2], 0.5)
+            e.scan_set(small_scene["scan"])            # (a new scan arrives: the moment a finished layout is swapped in)
+            time.sleep(0.01)                           # (... and the layout thread gets a moment, as it would between two frames)
+            ch = e.map_changes(token)
+            token = ch.token
+            assert not ch.resync
+            ids, xyz = apply_map_changes(ids, xyz, ch)
+            order = np.argsort(ids)
+            ids, xyz = ids[order], xyz[order]
+            out.append((e.map_ids(), e.map_points().copy()))
+            assert (ids == out[-1][0]).all() and (bits(xyz) == bits(out[-1][1])).all()
+        states[road] = (out, e.map_update_stats())
+        assert e.close() == 0
+    a, b = states["beside"], states["inside"]
+    assert a[1]["relaid_beside"] == 1 and b[1]["relaid_beside"] == 0, (a[1], b[1])
+    assert a[1]["regridded_beside"] == (1 if "regrid" in hook else 0), a[1]
+    for k, ((ia, pa), (ib, pb)) in enumerate(zip(a[0], b[0])):
+        assert (ia == ib).all() and (bits(pa) == bits(pb)).all(), k
+
+
+@pytest.mark.gpu
+def test_layout_in_flight_is_dropped_when_the_map_is_replaced_or_the_handle_destroyed(small_scene, monkeypatch):
+    from daliti_amd import Engine
+    rs = np.random.RandomState(5)
+    base = small_scene["map"]
+    monkeypatch.setenv("S2M_BESIDE_AT", "1")
+    e = Engine(cell_size=0.5)
+    e.map_build(base)
+    e.map_add((base[:500] + np.float32(0.11)), True, 0.5)              # the layout beside begins behind this update ...
+    e.map_build(base[:9000])                                           # ... and the map it belongs to is replaced
+    assert e.map_size() == 9000
+    e.map_add((base[:300] + np.float32(0.07)), False)
+    assert e.map_size() == 9300 and "state 0" in e.debug_state().split("layout beside")[1]
+    assert e.close() == 0
+    f = Engine(cell_size=0.5)
+    f.map_build(base)
+    f.map_add((base[:500] + np.float32(0.11)), True, 0.5)              # a layout is begun ...
+    f.map_add((base[rs.choice(len(base), 400)] + np.float32(0.05)), False)
+    t0 = time.perf_counter()
+    assert f.close() == 0 and time.perf_counter() - t0 < 2.0           # ... and the handle destroyed with it in flight
