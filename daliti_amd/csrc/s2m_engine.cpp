@@ -243,13 +243,7 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
     e->und.always_sort = std::getenv("S2M_NO_TIME_SHORTCUT") != nullptr;
     if (const char *g = std::getenv("S2M_FIRST_GAIN")) e->first_round_gain = std::max(1.5f, std::min(256.0f, (float)std::atof(g)));
     if (const char *g = std::getenv("S2M_BLIND_ROUNDS")) e->blind_rounds = std::max(0, std::min(8, std::atoi(g)));  // (A/B runs)
-    // The handle's streams are created together: the runtime maps a new stream onto the least used of a few hardware queues, and two
-    // streams that are meant to run side by side (the frame's and the next frame's front half) must not end up in one of them --
-    // a side stream created later, between other handles' streams, has been seen to land on the main stream's queue and to turn
-    // the frame pipeline into a sequence (0.30 -> 0.44 ms per frame).
-    bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&e->pf.stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&e->pf.done, hipEventDisableTiming) == hipSuccess;
+    bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&e->ev[i]) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_block, S2M_BLOCK_DOUBLES * sizeof(double)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&e->h_block, (S2M_BLOCK_DOUBLES + 8) * sizeof(double), hipHostMallocMapped) == hipSuccess;

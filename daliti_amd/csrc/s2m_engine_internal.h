@@ -235,6 +235,7 @@ struct s2m_engine {
         int64_t arena_cap = 0, arena_head = 0, arena_tail = 0;
         // triggers
         int64_t commits = 0, since_layout = 0, force_at = -1;
+        int64_t min_gap = 32;              // updates between two layouts: doubled by every layout that failed or was dropped, 32 again after a swap
         int64_t n_started = 0, n_dropped = 0, n_failed = 0;   // layouts begun / given up / failed (diagnostic: s2m_debug_state)
         bool force_regrid = false, enabled = true;
         uint32_t *d_cells = nullptr, *h_cells = nullptr, *h_cells_dev = nullptr;

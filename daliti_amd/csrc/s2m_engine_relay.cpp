@@ -268,6 +268,8 @@ void relay_drop(s2m_engine *e)
     std::lock_guard<std::mutex> lk(r.mu);
     if (r.state.load() == Relay::kIdle) return;
     ++r.n_dropped;
+    r.min_gap = std::min<int64_t>(2 * r.min_gap, 4096);   // (a layout that keeps being overtaken is not begun again at once)
+    r.since_layout = 0;
     r.cancel.store(1);
     r.cv.notify_all();
 }
@@ -331,7 +333,7 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
     const char *why = nullptr;
     bool regrid = false;
     if (r.force_at >= 0 && r.commits == r.force_at) { why = "forced (test hook)"; regrid = r.force_regrid; }
-    else if (r.since_layout >= 32) {
+    else if (r.since_layout >= r.min_gap) {
         const int64_t tail = e->grid.m - e->map.main_ext, rows = spare_rows(e->map);
         if (e->map.main_ext > 0 && tail > 0 && e->map.tail_used * 4 >= tail * 3) why = "the tail of the point array is three quarters used";
         else if (rows > 0 && e->stats.bricks * 4 >= rows * 3) why = "the brick table's spare rows are three quarters used";
@@ -463,6 +465,7 @@ int relay_poll(s2m_engine *e)
     if (r.state.load() == Relay::kFailed) {
         const bool timed_out = r.why == "timeout";
         ++r.n_failed;
+        r.min_gap = std::min<int64_t>(2 * r.min_gap, 4096);
         r.ops.clear();
         r.arena_head = r.arena_tail = 0;
         r.state.store(Relay::kIdle);
@@ -525,6 +528,7 @@ int relay_poll(s2m_engine *e)
     ++e->n_beside;
     if (r.regrid) ++e->n_beside_regrid;
     r.since_layout = 0;
+    r.min_gap = 32;
     r.cells_posted = false;
     r.density = 0.0;
     r.arena_head = r.arena_tail = 0;

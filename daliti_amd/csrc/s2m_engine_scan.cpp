@@ -269,7 +269,22 @@ int pf_start(s2m_engine *e, const float *points, int64_t floats)
     if (rc) return rc;
     p.ready = false;
     p.prepared = false;
-    if (!p.stream) S2M_HIP(e, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+    if (!p.stream) {
+        // The side stream must run BESIDE the main stream.  The runtime maps every new stream onto the least used of a few hardware
+        // queues per priority; a side stream of the main stream's priority, created when the first sweep is announced -- i.e. after
+        // whatever other handles and streams the process has made in between --, has been seen to land on the main stream's own
+        // queue and to turn the frame pipeline into a sequence (0.30 -> 0.44 ms per frame); created together with the main stream
+        // it took the queues the launch groups of a batch of handles need to overlap (25.9 k -> 22.1 k scans/s at 24 in flight).
+        // A stream of another priority lives in another pool of queues: it can share one with neither.  (S2M_PF_STREAM=normal: the
+        // main stream's priority, for A/B runs; profiles/r06_side_stream_ab.txt.)
+        static const bool normal = [] { const char *g = std::getenv("S2M_PF_STREAM"); return g && std::string(g) == "normal"; }();
+        int least = 0, greatest = 0;
+        if (normal || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&p.stream, hipStreamNonBlocking, least) != hipSuccess) {
+            (void)hipGetLastError();
+            S2M_HIP(e, hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+        }
+    }
     if (!p.done) S2M_HIP(e, hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
     if (floats > p.cap) {
         rc = sync_stream(e, p.stream, "the side stream, before its buffer is reallocated");
