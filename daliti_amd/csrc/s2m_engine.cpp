@@ -73,7 +73,7 @@ std::string debug_state(const s2m_engine *e)
     std::string out = b;
     std::snprintf(b, sizeof(b), "; layout beside the frames: state %d, %lld begun, %lld swapped in, %lld dropped, %lld failed, last reason \"%s\", density %.1f",
                   e->relay.state.load(), (long long)e->relay.n_started, (long long)e->n_beside, (long long)e->relay.n_dropped, (long long)e->relay.n_failed,
-                  e->relay.why.c_str(), e->relay.density);
+                  e->relay.why.load(), e->relay.density);
     return out + b;
 }
 

@@ -243,7 +243,8 @@ struct s2m_engine {
         bool cells_posted = false;
         int64_t cells_live = 0;            // live points when the count was posted
         double density = 0.0;              // points per occupied cell, last count (0: not known)
-        std::string why;                   // what triggered the last layout (diagnostic)
+        std::atomic<const char *> why{""};  // what triggered the last layout / why it failed (string literals only: read by s2m_debug_state from any thread)
+        std::atomic<int> timed_out{0};     // ... a wait of the worker expired
     } relay;
 
     EskfWork work;

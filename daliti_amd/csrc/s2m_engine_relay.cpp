@@ -227,7 +227,7 @@ void relay_worker(s2m_engine *e)
             const int rc = worker_build(e, origin, cell_live);
             lk.lock();
             built = rc == S2M_OK;
-            if (rc) { r.why = rc == S2M_ERR_TIMEOUT ? "timeout" : "the build beside the frames failed"; r.state.store(Relay::kFailed); }
+            if (rc) { r.timed_out.store(rc == S2M_ERR_TIMEOUT); r.why.store(rc == S2M_ERR_TIMEOUT ? "a wait of the layout worker expired" : "the build beside the frames failed"); r.state.store(Relay::kFailed); }
             else if (r.ops.empty() && r.cancel.load() == 0) r.state.store(Relay::kCaughtUp);
         } else {
             Relay::Op op = std::move(r.ops.front());
@@ -236,7 +236,7 @@ void relay_worker(s2m_engine *e)
             const int rc = worker_replay(e, op);
             lk.lock();
             r.arena_tail = op.arena_end;
-            if (rc) { r.why = rc == S2M_ERR_TIMEOUT ? "timeout" : "an update could not be applied to the map beside the frames"; r.state.store(Relay::kFailed); }
+            if (rc) { r.timed_out.store(rc == S2M_ERR_TIMEOUT); r.why.store(rc == S2M_ERR_TIMEOUT ? "a wait of the layout worker expired" : "an update could not be applied to the map beside the frames"); r.state.store(Relay::kFailed); }
             else if (r.ops.empty() && r.cancel.load() == 0) r.state.store(Relay::kCaughtUp);
         }
         r.busy.store(0);
@@ -283,6 +283,13 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
     if (!r.enabled || e->no_merge || e->no_slab || e->cfg.layout_beside == 0) return S2M_OK;
     ++r.commits;
     ++r.since_layout;
+    // the third update after a build (a warm-up frame: the live map has allocated what a scan's batches need by now): the other
+    // map's update buffers get the same capacities, here and not beside the frame of its first real update
+    if (r.commits == 3 && r.state.load() == Relay::kIdle && r.map.pts && r.stream) {
+        S2M_HIP(e, update_reserve_like(r.upd, e->upd, e->stream));
+        int rc = sync_stream(e, e->stream, "the other map's update buffers");
+        if (rc) return rc;
+    }
     const int st = r.state.load();
     if (st == Relay::kFailed) return S2M_OK;   // (relay_poll deals with it)
     if (st != Relay::kIdle && (!inplace || !kept_grid)) {   // the live map has just laid itself out again (or was rebuilt: new ids)
@@ -342,7 +349,8 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
     if (!why || e->grid.live <= 0) return S2M_OK;
     {
         std::lock_guard<std::mutex> lk(r.mu);
-        r.why = why;
+        r.why.store(why);
+        r.timed_out.store(0);
         ++r.n_started;
         r.regrid = regrid;
         r.snap_bound = e->grid.live + e->grid.live / 8 + 65536;   // (the snapshot is taken a frame or two from now)
@@ -365,6 +373,8 @@ int relay_rehearse(s2m_engine *e, const float *cloud_dev, int64_t stride, int64_
     Relay &r = e->relay;
     if (!r.enabled || e->cfg.layout_beside == 0 || e->no_merge || e->no_slab || m < 4096 || r.state.load() != Relay::kIdle) return S2M_OK;
     static const bool off = std::getenv("S2M_NO_REHEARSAL") != nullptr;   // (A/B runs)
+    r.commits = 0;   // (updates are counted from the build)
+    r.since_layout = 0;
     if (off) return S2M_OK;
     r.snap_bound = m + m / 8 + 65536;
     r.extent_bound = 4 * m + ((int64_t)1 << 23);
@@ -463,7 +473,7 @@ int relay_poll(s2m_engine *e)
     if (e->nn_valid) return S2M_OK;
     std::unique_lock<std::mutex> lk(r.mu);
     if (r.state.load() == Relay::kFailed) {
-        const bool timed_out = r.why == "timeout";
+        const bool timed_out = r.timed_out.load() != 0;
         ++r.n_failed;
         r.min_gap = std::min<int64_t>(2 * r.min_gap, 4096);
         r.ops.clear();

@@ -211,6 +211,7 @@ struct VoxBox {
     int bits = 0;
 };
 void free_update(UpdateBuffers &u);
+hipError_t update_reserve_like(UpdateBuffers &dst, const UpdateBuffers &src, hipStream_t st);  // dst's batch / staging capacities >= src's
 hipError_t update_begin(UpdateBuffers &u, const Grid &g, hipStream_t st);
 hipError_t update_add(UpdateBuffers &u, const Grid &g, const float4 *np, int64_t n, bool downsample, float ds,
                       int64_t *n_added, hipStream_t st, const VoxBox *vox = nullptr, bool defer = false);

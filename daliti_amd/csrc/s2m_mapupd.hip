@@ -711,6 +711,41 @@ static hipError_t ensure_tmp(UpdateBuffers &u, size_t bytes)
     return hipSuccess;
 }
 
+// dst gets the per-batch and staging capacities src has grown to (the other map of a handle, s2m_engine_relay.cpp: what its first
+// real update would otherwise allocate beside a frame)
+hipError_t update_reserve_like(UpdateBuffers &dst, const UpdateBuffers &src, hipStream_t st)
+{
+    if (src.batch_cap > dst.batch_cap) {
+        const int64_t want = src.batch_cap;
+        int64_t c;
+        c = dst.batch_cap; S2M_TRY(grow(&dst.key, &c, want));
+        c = dst.batch_cap; S2M_TRY(grow(&dst.key2, &c, want));
+        c = dst.batch_cap; S2M_TRY(grow(&dst.val, &c, want));
+        c = dst.batch_cap; S2M_TRY(grow(&dst.val2, &c, want));
+        c = dst.batch_cap; S2M_TRY(grow(&dst.dnew, &c, want));
+        c = dst.batch_cap; S2M_TRY(grow(&dst.cnt, &c, want));
+        c = dst.batch_cap; S2M_TRY(grow(&dst.best_idx, &c, want));
+        c = dst.batch_cap; S2M_TRY(grow(&dst.best_pos, &c, want));
+        c = dst.batch_cap; S2M_TRY(grow(&dst.best_d, &c, want));
+        c = dst.batch_cap; S2M_TRY(grow(&dst.add_flag, &c, want));
+        c = dst.batch_cap; S2M_TRY(grow(&dst.pos, &c, want));
+        dst.batch_cap = c;
+    }
+    if (src.stage_cap > dst.stage_cap) S2M_TRY(grow(&dst.stage, &dst.stage_cap, src.stage_cap, true, st));
+    if (src.tmp_bytes > dst.tmp_bytes) S2M_TRY(ensure_tmp(dst, src.tmp_bytes / 2 + 1));
+    if (src.vtab_cap > dst.vtab_cap) {
+        if (dst.vtab) S2M_TRY(hipFree(dst.vtab));
+        dst.vtab = nullptr;
+        dst.vtab_cap = 0;
+        S2M_TRY(hipMalloc((void **)&dst.vtab, (size_t)src.vtab_cap * sizeof(unsigned long long)));
+        note_allocation("voxel table (the other map)", (size_t)src.vtab_cap * sizeof(unsigned long long));
+        S2M_TRY(hipMemsetAsync(dst.vtab, 0xff, (size_t)src.vtab_cap * sizeof(unsigned long long), st));
+        dst.vtab_cap = src.vtab_cap;
+    }
+    dst.reserve_hint = std::max(dst.reserve_hint, src.reserve_hint);
+    return hipSuccess;
+}
+
 static hipError_t scan_u32(UpdateBuffers &u, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st)
 {
     size_t bytes = 0;
