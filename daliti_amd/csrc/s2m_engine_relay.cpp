@@ -402,6 +402,10 @@ int relay_rehearse(s2m_engine *e, const float *cloud_dev, int64_t stride, int64_
     // (and the code object of s2m_relay.hip is loaded by its first launch -- milliseconds, seen as frame 23 of every drive, where
     // the first density count fell: here instead)
     launch_count_cells(r.map.counters + kBricksWord, r.stats.bricks, r.grid.tab, r.d_cells, r.h_cells_dev, 0u, st);
+    // (and a stream's hardware queue is made by its first submission, with the same stall as an allocation: one word on the layout stream)
+    S2M_HIP(e, hipMemsetAsync(r.snap_count, 0, sizeof(uint32_t), r.stream));
+    int rc = sync_stream(e, r.stream, "the layout stream's first submission");
+    if (rc) return rc;
     return sync_stream(e, st, "the rehearsal of the layout beside the frames");
 }
 

@@ -39,6 +39,11 @@ for name, env, publish in cases:
               st["regridded_beside"], st["regridded"], len(ids), e.map_info()["cell"], np.median(err), err.max(), int(err.argmax()),
               [(int(i), round(float(ms[i]), 2), int(r["allocs"][warm + i])) for i in np.argsort(ms)[-6:][::-1]],
               (r["mirror_points"], r["map_points"], r["mirror_resyncs"], r["mirror_missed"]) if publish else "-"), flush=True)
+    if os.environ.get("STAGES"):   # host wall time of the slow frames' calls: set_from_raw, prefetch, iterated_update, prepare, map_incremental, fov
+        med = np.median(r["stage_ms"][warm:], axis=0)
+        print("   median stages (ms):", np.round(med, 3))
+        for i in np.argsort(ms)[-8:][::-1]:
+            print("   frame %d: %.3f ms, stages %s" % (i, ms[i], np.round(r["stage_ms"][warm + i], 3)))
     if os.environ.get("PER100"):
         print("   median per 100 frames:", " ".join("%.3f" % np.median(ms[k:k + 100]) for k in range(0, frames, 100)))
     e.close()
