@@ -205,6 +205,7 @@ struct s2m_engine {
             std::vector<float> boxes;
             int64_t arena_end = 0;         // the arena is free up to here once the op is done
         };
+        WaitCtl wait;                      // how the worker waits (it yields its core between polls; the handle's deadline)
         std::thread worker;
         std::mutex mu;
         std::condition_variable cv;

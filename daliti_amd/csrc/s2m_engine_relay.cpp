@@ -190,7 +190,18 @@ void relay_worker(s2m_engine *e)
 {
     Relay &r = e->relay;
     (void)hipSetDevice(e->device);
-    tl_wait = &e->wait;
+    // the worker's own way of waiting: a short spin, then it yields the core between polls -- the build's kernels take hundreds of
+    // microseconds, nobody waits for them, and the frames' thread is the one that should have a core.  (Naps are too coarse: a
+    // replayed update is four hand-backs, and with a nap behind each the worker falls behind the frames and never catches up --
+    // measured, NOTEBOOK round 6.)
+    r.wait.policy = kWaitYield;
+    r.wait.spin_us = 5;
+    r.wait.timeout_us = e->wait.timeout_us;
+    if (const char *g = std::getenv("S2M_BESIDE_WAIT")) {   // (A/B)
+        if (std::strcmp(g, "spin") == 0) { r.wait.policy = e->wait.policy; r.wait.spin_us = e->wait.spin_us; }
+        else if (std::strcmp(g, "sleep") == 0) r.wait.policy = kWaitSleep;
+    }
+    tl_wait = &r.wait;
     struct Exited {
         std::atomic<int> &f;
         ~Exited() { f.store(1, std::memory_order_release); }
@@ -485,7 +496,11 @@ int relay_poll(s2m_engine *e)
         r.state.store(Relay::kIdle);
         r.since_layout = 0;   // (not again at once)
         lk.unlock();
-        if (timed_out) return fail(e, S2M_ERR_HIP, "the layout beside the frames", kWaitTimedOut);
+        if (timed_out) {
+            const char *none = nullptr;
+            if (e->wait.expired.compare_exchange_strong(none, r.wait.expired.load())) e->wait.waited_us.store(r.wait.waited_us.load());
+            return fail(e, S2M_ERR_HIP, "the layout beside the frames", kWaitTimedOut);
+        }
         return S2M_OK;
     }
     if (r.state.load() != Relay::kCaughtUp || !r.ops.empty() || r.busy.load() != 0 || r.cancel.load() != 0) return S2M_OK;

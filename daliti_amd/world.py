@@ -114,5 +114,5 @@ def run_frames(eng, sw, P0, frames, warm, leaf=0.5, filter_size_map=0.5, cube_le
         raise RuntimeError("s2m_bench_frames_moving failed: %d (%s)" % (rc, eng.lib.s2m_last_error(eng.h).decode()))
     return dict(ms=us * 1e-3, how=how, deleted=deleted, n_scan=n_scan, x=x, allocs=allocs, publish_ms=publish_us * 1e-3, fetch_ms=fetch_us * 1e-3,
                 mirror_points=int(mirror_stats[0]), map_points=int(mirror_stats[1]), mirror_resyncs=int(mirror_stats[2]), mirror_missed=int(mirror_stats[3]),
-                stage_ms=np.diff(np.concatenate([np.zeros((total, 1)), stage_us], axis=1), axis=1) * 1e-3, iters=np.array([l.iters for l in logs]),
+                stage_ms=np.diff(np.concatenate([np.zeros((total, 1)), stage_us], axis=1), axis=1) * 1e-3, iters=np.array([l.iters for l in logs]), rematch_passes=np.array([l.rematch_passes for l in logs]),
                 effct=[np.array(l.effct[:l.iters]) for l in logs])

@@ -68,6 +68,7 @@ struct s2m_map_mirror {
     {
         size_t s = table_.capacity() * sizeof(Slot) + buckets_.capacity() * sizeof(Bucket) + free_.capacity() * sizeof(int32_t);
         for (const Bucket &b : buckets_) s += b.pts.capacity() * sizeof(Pt);
+        s += later_.capacity() * sizeof(int32_t) + (group_.capacity() + touched_.capacity()) * sizeof(uint32_t);
         for (const IO &io : io_)
             s += (io.add_xyz.capacity() + io.rem_xyz.capacity() + io.box.capacity()) * sizeof(float) + (io.add_ids.capacity() + io.rem_ids.capacity()) * sizeof(uint32_t);
         return s;
@@ -141,6 +142,7 @@ struct s2m_map_mirror {
         }
         const s2m_map_changes &c = io.c;
         last_added = c.n_added; last_removed = c.n_removed; last_boxes = c.n_boxes;
+        if (c.n_boxes == 0) give_back(64);
         int64_t a0 = 0, r0 = 0;
         for (int64_t q = 0; q <= c.n_boxes; ++q) {
             const int64_t a1 = q < c.n_boxes ? io.box_a[(size_t)q] : c.n_added, r1 = q < c.n_boxes ? io.box_r[(size_t)q] : c.n_removed;
@@ -155,7 +157,16 @@ struct s2m_map_mirror {
     /* ---- the pieces update() is made of, public so that they can be tested without a device ---- */
     void clear()
     {
-        buckets_.clear(); free_.clear(); table_.clear(); used_ = 0; live_ = 0; last_ = -1;
+        buckets_.clear(); free_.clear(); later_.clear(); table_.clear(); used_ = 0; live_ = 0; last_ = -1;
+    }
+    /* the arrays of up to n buckets that a box delete emptied go back to the allocator (unless points have moved in since) */
+    void give_back(size_t n)
+    {
+        for (; n > 0 && !later_.empty(); --n) {
+            Bucket &b = buckets_[(size_t)later_.back()];
+            later_.pop_back();
+            if (b.pts.empty() && b.pts.capacity() != 0) std::vector<Pt>().swap(b.pts);
+        }
     }
     void add(uint32_t id, const float *p)
     {
@@ -191,9 +202,11 @@ struct s2m_map_mirror {
                 apart = apart || hi <= (double)box[k] || lo >= (double)box[3 + k];
             }
             if (apart) continue;
-            if (inside) {
+            if (inside) {   /* (its memory is given back over the next reports: a thousand free() calls are most of a trim otherwise) */
                 live_ -= (int64_t)b.pts.size() - (int64_t)b.dead;
-                release((int32_t)at);
+                b.pts.clear();
+                b.dead = 0;
+                later_.push_back((int32_t)at);
                 continue;
             }
             for (size_t i = 0, n = b.pts.size(); i < n; ++i) {
@@ -211,6 +224,7 @@ struct s2m_map_mirror {
         int32_t c[3] = {0, 0, 0};
         uint32_t dead = 0;
         uint32_t pending = 0;     /* points of the stretch being applied that have found this bucket and are not written yet */
+        uint32_t want = 0, off = 0; /* remove_many: removals of the stretch that fall into this bucket; their place in group_ */
         std::vector<Pt> pts;      /* ids ascending; a removed point stays as a mark (x = NaN) until the bucket is compacted */
     };
     struct Slot { uint64_t key; int32_t at; int32_t pad; };   /* at < 0: empty */
@@ -345,15 +359,49 @@ struct s2m_map_mirror {
         const size_t n = (size_t)(r1 - r0);
         if (n == 0) return;
         where_.resize(n);
-        for (size_t i = 0; i < n; ++i) where_[i] = find_bucket(key_of(&ap_->rem_xyz[3 * ((size_t)r0 + i)]));
-        /* the binary searches level by level, all points abreast: lo_ / len_ are every search's window */
+        touched_.clear();
+        for (size_t i = 0; i < n; ++i) {
+            where_[i] = find_bucket(key_of(&ap_->rem_xyz[3 * ((size_t)r0 + i)]));
+            if (where_[i] >= 0 && buckets_[(size_t)where_[i]].want++ == 0) touched_.push_back((uint32_t)where_[i]);
+        }
+        /* A bucket that loses a good part of its points in this stretch (the voxel rule thinning a dense map, laserMapping.cpp:
+         * 590-640: a dozen old points per new one) is walked ONCE beside its removals in id order -- sequential memory -- instead
+         * of one binary search per removal; group_ collects those removals bucket by bucket */
+        size_t grouped = 0;
+        for (uint32_t at : touched_) {
+            Bucket &b = buckets_[at];
+            if (b.want >= 8 && (size_t)b.want * 96 >= b.pts.size()) { b.off = (uint32_t)grouped; grouped += b.want; }
+            else b.off = 0xffffffffu;
+            b.want = 0;   /* (from here on: how many of the group are in) */
+        }
         lo_.assign(n, 0);
         len_.resize(n);
         size_t longest = 0;
+        if (grouped) group_.resize(grouped);
         for (size_t i = 0; i < n; ++i) {
-            len_[i] = where_[i] >= 0 ? (uint32_t)buckets_[(size_t)where_[i]].pts.size() : 0u;
+            len_[i] = 0;
+            if (where_[i] < 0) continue;
+            Bucket &b = buckets_[(size_t)where_[i]];
+            if (b.off != 0xffffffffu) { group_[b.off + b.want++] = (uint32_t)i; lo_[i] = 0xffffffffu; continue; }
+            len_[i] = (uint32_t)b.pts.size();
             longest = std::max<size_t>(longest, len_[i]);
         }
+        for (uint32_t at : touched_) {
+            Bucket &b = buckets_[at];
+            if (b.off == 0xffffffffu) continue;
+            uint32_t *g = &group_[b.off];
+            const size_t k = b.want;
+            b.want = 0;
+            std::sort(g, g + k, [&](uint32_t x, uint32_t y) { return ap_->rem_ids[(size_t)r0 + x] < ap_->rem_ids[(size_t)r0 + y]; });
+            size_t j = 0;
+            const size_t m = b.pts.size();
+            for (size_t q = 0; q < k; ++q) {
+                const uint32_t id = ap_->rem_ids[(size_t)r0 + g[q]];
+                while (j < m && b.pts[j].id < id) ++j;
+                lo_[g[q]] = (j < m && b.pts[j].id == id && b.pts[j].x == b.pts[j].x) ? (uint32_t)j : (uint32_t)m;   /* (m: not there) */
+            }
+        }
+        /* the binary searches level by level, all points abreast: lo_ / len_ are every search's window */
         for (; longest > 0; longest >>= 1) {
             for (size_t i = 0; i < n; ++i) {
                 if (len_[i] == 0) continue;
@@ -378,8 +426,7 @@ struct s2m_map_mirror {
             }
             mark(b, at);
         }
-        for (size_t i = 0; i < n; ++i)
-            if (where_[i] >= 0) settle(where_[i]);
+        for (uint32_t at : touched_) settle((int32_t)at);
     }
     void reserve_io(int64_t na, int64_t nr)
     {
@@ -407,7 +454,8 @@ struct s2m_map_mirror {
     int cur_ = 0;
     IO *ap_ = &io_[0];   /* the report being applied */
     std::vector<int32_t> where_;
-    std::vector<uint32_t> lo_, len_;
+    std::vector<uint32_t> lo_, len_, group_, touched_;
+    std::vector<int32_t> later_;   /* buckets a box delete emptied whose arrays are still to be given back */
 };
 
 #endif /* DALITI_S2M_MIRROR_HPP */

@@ -12,7 +12,7 @@ w = World(L, 6.0 * L, 1.0)
 seed = w.seed_map(5_000_000)
 sw = w.sweeps(0, frames + warm, 64, 1024, threads=32)
 _, _, P0 = synth.filter_inputs()
-cases = (("inside, lag 1", "S2M_NO_BESIDE", 2), ("beside, lag 1", None, 2), ("beside, lag 0", None, 1))
+cases = (("inside, lag 1", "S2M_NO_BESIDE", 2), ("beside, lag 1", None, 2), ("beside, lag 0", None, 1), ("beside, thread", None, 3))
 if os.environ.get("ONLY"):
     cases = tuple(c for c in cases if c[0] == os.environ["ONLY"])
 for name, env, publish in cases:
@@ -28,4 +28,12 @@ for name, env, publish in cases:
     print("%-14s median %.3f p99 %.3f max %.3f ms; publish median %.3f (fetch %.3f) ms; beside %d; mirror %d map %d resyncs %d missed %d; trims at %s" % (
         name, np.median(ms), np.percentile(ms, 99), ms.max(), np.median(r["publish_ms"][warm:]), np.median(r["fetch_ms"][warm:]), st["relaid_beside"],
         r["mirror_points"], r["map_points"], r["mirror_resyncs"], r["mirror_missed"], [int(i) for i in np.nonzero(r["deleted"])[0]]), flush=True)
+    if os.environ.get("TOP"):   # the slowest frames: frame, ms, of which the follower's part (and of that the fetch), the calls' wall times
+        pm, fm = r["publish_ms"][warm:], r["fetch_ms"][warm:]
+        for i in np.argsort(ms)[-int(os.environ["TOP"]):][::-1]:
+            print("   frame %4d: %.3f ms, follower %.3f (fetch %.3f), calls %s" % (i, ms[i], pm[i], fm[i], np.round(r["stage_ms"][warm + i], 3)))
+        print("   follower's part of the frame: median %.3f p90 %.3f p99 %.3f max %.3f ms; frames above 2 x the median: %d" % (
+            np.median(pm), np.percentile(pm, 90), np.percentile(pm, 99), pm.max(), int((ms > 2 * np.median(ms)).sum())))
+        print("   median per 100 frames: frame", " ".join("%.3f" % np.median(ms[k:k + 100]) for k in range(0, frames, 100)))
+        print("                       follower", " ".join("%.3f" % np.median(pm[k:k + 100]) for k in range(0, frames, 100)))
     e.close()

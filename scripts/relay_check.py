@@ -43,7 +43,11 @@ for name, env, publish in cases:
         med = np.median(r["stage_ms"][warm:], axis=0)
         print("   median stages (ms):", np.round(med, 3))
         for i in np.argsort(ms)[-8:][::-1]:
-            print("   frame %d: %.3f ms, stages %s" % (i, ms[i], np.round(r["stage_ms"][warm + i], 3)))
+            print("   frame %d: %.3f ms, stages %s, %d iterations, %d rematch passes, %d scan points" % (i, ms[i], np.round(r["stage_ms"][warm + i], 3), r["iters"][warm + i], r["rematch_passes"][warm + i], r["n_scan"][warm + i]))
+        it, rp = r["iters"][warm:], r["rematch_passes"][warm:]
+        for k in sorted(set(zip(it.tolist(), rp.tolist()))):
+            sel = (it == k[0]) & (rp == k[1])
+            print("   %d iterations / %d rematch passes: %d frames, median %.3f ms (iterated_update %.3f)" % (k[0], k[1], sel.sum(), np.median(ms[sel]), np.median(r["stage_ms"][warm:][sel, 2])))
     if os.environ.get("PER100"):
         print("   median per 100 frames:", " ".join("%.3f" % np.median(ms[k:k + 100]) for k in range(0, frames, 100)))
     e.close()

@@ -56,6 +56,7 @@ int main()
         next_id += (uint32_t)(((uint64_t)1 << 30) / rounds);
         // add ~3000 points in the window [x0, x0 + 200) x [-50, 50) x [0, 10): every other round through the batched pass a report
         // is applied with (new buckets open -- and the table grows -- in the middle of a stretch)
+        m.give_back(64);   // (what apply_report does at the start of a report without boxes: a trim's emptied buckets return their memory over the next reports)
         m.reserve_io(65536, 65536);
         for (int i = 0; i < 3000; ++i) {
             P p{(float)(x0 + 200.0 * (rng() % 100000) / 100000.0), (float)(-50.0 + 100.0 * (rng() % 100000) / 100000.0), (float)(10.0 * (rng() % 100000) / 100000.0)};
@@ -103,6 +104,7 @@ int main()
         }
         peak_bytes = std::max(peak_bytes, m.memory_bytes());
     }
+    for (int k = 0; k < 64; ++k) m.give_back(64);   // (the reports after the last trim)
     const double per_point = (double)m.memory_bytes() / (double)std::max<int64_t>(m.size(), 1);
     std::printf("ids issued up to %u, live %lld, mirror %zu bytes (peak %zu) = %.1f bytes per live point, missed %lld\n", next_id, (long long)m.size(),
                 m.memory_bytes(), peak_bytes, per_point, (long long)m.missed);
