@@ -206,6 +206,9 @@ struct s2m_engine {
             int64_t arena_end = 0;         // the arena is free up to here once the op is done
         };
         WaitCtl wait;                      // how the worker waits (it yields its core between polls; the handle's deadline)
+        bool late_tried = false;           // the rehearsal of a map that was built too small for one has been made (or tried)
+        int64_t sized_live = 0;            // the live count the other map's buffers were last sized for
+        int64_t allocs_seen = 0;           // map_allocations() when the other map's buffers were last matched to the live map's
         std::thread worker;
         std::mutex mu;
         std::condition_variable cv;

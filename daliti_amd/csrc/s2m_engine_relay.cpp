@@ -300,6 +300,7 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
         S2M_HIP(e, update_reserve_like(r.upd, e->upd, e->stream));
         int rc = sync_stream(e, e->stream, "the other map's update buffers");
         if (rc) return rc;
+        r.allocs_seen = map_allocations();
     }
     const int st = r.state.load();
     if (st == Relay::kFailed) return S2M_OK;   // (relay_poll deals with it)
@@ -329,7 +330,47 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
         return S2M_OK;
     }
     if (st != Relay::kIdle) return S2M_OK;
-    // ---- idle: how worn is the layout?
+    // ---- idle.  Has the live map (or its update buffers) grown in this call?  Then the frame has stalled for its allocations
+    // anyway, and the other map's buffers follow NOW: a map that has outgrown them would otherwise have them allocated by the
+    // worker beside the frames of its next layout -- a dozen allocations, 3 - 6 ms of stalled frames (NOTEBOOK round 6).
+    if (!r.map.pts && !r.late_tried && e->grid.live >= 4096) {
+        // a map that was BUILT too small for a rehearsal (a node's first scan, one point of a test) and has grown by updates: the
+        // rehearsal now, from the live map's own points
+        r.late_tried = true;
+        r.snap_bound = 2 * e->grid.live + 65536;
+        r.extent_bound = std::max<int64_t>(2 * e->grid.m, e->map.pts_cap) + 65536;
+        S2M_HIP(e, worker_prepare(e));
+        launch_snapshot(e->grid.pts, e->grid.pidx, e->grid.m, r.snap, r.snap_count, r.snap_cap, r.snap_blk, e->stream);
+        uint32_t n = 0;
+        S2M_HIP(e, hipMemcpyAsync(&n, r.snap_count, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+        int rc = sync_stream(e, e->stream, "the live map's points for the rehearsal");
+        if (rc) return rc;
+        const int64_t commits = r.commits, since = r.since_layout;
+        rc = relay_rehearse(e, reinterpret_cast<const float *>(r.snap), 4, (int64_t)n);
+        r.late_tried = true;
+        r.commits = commits;
+        r.since_layout = since;
+        if (rc) return rc;
+    }
+    if (map_allocations() != r.allocs_seen && r.stream && r.map.pts) {
+        // (only for a map that has GROWN by a quarter beyond what the other map was last sized for: after a layout the two maps
+        // have changed places and each holds arrays the other never needed -- matching those would be a dozen allocations in a
+        // frame for nothing)
+        if (e->grid.live > r.sized_live + r.sized_live / 4) {
+            S2M_HIP(e, map_reserve_like(r.map, e->map));
+            S2M_HIP(e, update_reserve_like(r.upd, e->upd, e->stream));
+            if (e->grid.live + e->grid.live / 4 + 65536 > r.snap_cap || snapshot_blocks(e->grid.m + e->grid.m / 4) + 1 > r.snap_blk_cap) {
+                r.snap_bound = 2 * e->grid.live + 65536;
+                r.extent_bound = std::max<int64_t>(2 * e->grid.m, e->map.pts_cap) + 65536;
+                S2M_HIP(e, worker_prepare(e));
+            }
+            int rc = sync_stream(e, e->stream, "the other map's buffers following the live map's");
+            if (rc) return rc;
+            r.sized_live = e->grid.live;
+        }
+        r.allocs_seen = map_allocations();
+    }
+    // ---- how worn is the layout?
     if (r.cells_posted && r.h_cells && __atomic_load_n(r.h_cells, __ATOMIC_ACQUIRE) == r.cells_seq) {   // the count posted a while ago has landed
         const uint32_t cells = r.h_cells[1];
         r.density = cells > 0 ? (double)r.cells_live / (double)cells : 0.0;
@@ -382,6 +423,7 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
 int relay_rehearse(s2m_engine *e, const float *cloud_dev, int64_t stride, int64_t m)
 {
     Relay &r = e->relay;
+    r.late_tried = false;
     if (!r.enabled || e->cfg.layout_beside == 0 || e->no_merge || e->no_slab || m < 4096 || r.state.load() != Relay::kIdle) return S2M_OK;
     static const bool off = std::getenv("S2M_NO_REHEARSAL") != nullptr;   // (A/B runs)
     r.commits = 0;   // (updates are counted from the build)
@@ -417,7 +459,10 @@ int relay_rehearse(s2m_engine *e, const float *cloud_dev, int64_t stride, int64_
     S2M_HIP(e, hipMemsetAsync(r.snap_count, 0, sizeof(uint32_t), r.stream));
     int rc = sync_stream(e, r.stream, "the layout stream's first submission");
     if (rc) return rc;
-    return sync_stream(e, st, "the rehearsal of the layout beside the frames");
+    rc = sync_stream(e, st, "the rehearsal of the layout beside the frames");
+    r.allocs_seen = map_allocations();
+    r.sized_live = m;
+    return rc;
 }
 
 int relay_record_lists(s2m_engine *e, const float4 *la, int64_t na, bool ds_a, float fs, const VoxBox *vox, const float4 *lb, int64_t nb)
@@ -554,6 +599,7 @@ int relay_poll(s2m_engine *e)
     e->map.no_fused_prep = r.map.no_fused_prep;
     e->upd.fuse_stage = r.upd.fuse_stage;
     e->nn_valid = false;
+    r.sized_live = std::max<int64_t>(r.sized_live, e->grid.live);   // (the other map is now the one that held these points)
     ++e->n_beside;
     if (r.regrid) ++e->n_beside_regrid;
     r.since_layout = 0;

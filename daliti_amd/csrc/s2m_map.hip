@@ -358,6 +358,50 @@ static hipError_t ensure_scratch(MapBuffers &buf, int64_t m)
     return hipSuccess;
 }
 
+// The arrays of `dst` get (at least) the capacities of `src`: the map a layout beside the frames will be built into follows the
+// live map's growth at the moment the live map allocates -- a frame that has stalled for its allocations anyway -- instead of
+// allocating beside the frames of the next layout (s2m_engine_relay.cpp).  What `dst` held is lost where an array grows: only for
+// a map that is not in use and will be built from scratch.
+hipError_t map_reserve_like(MapBuffers &dst, const MapBuffers &src)
+{
+    struct Arr { void **p; int64_t *cap; int64_t want; size_t elem; };
+    const Arr arrs[] = {
+        {(void **)&dst.pts, &dst.pts_cap, src.pts_cap, sizeof(float4)},       {(void **)&dst.pidx, &dst.pidx_cap, src.pidx_cap, sizeof(uint32_t)},
+        {(void **)&dst.pts2, &dst.pts2_cap, src.pts2_cap, sizeof(float4)},    {(void **)&dst.pidx2, &dst.pidx2_cap, src.pidx2_cap, sizeof(uint32_t)},
+        {(void **)&dst.top, &dst.top_cap, src.top_cap, sizeof(uint4)},        {(void **)&dst.top2, &dst.top2_cap, src.top2_cap, sizeof(uint4)},
+        {(void **)&dst.tab, &dst.tab_cap, src.tab_cap, sizeof(uint32_t)},     {(void **)&dst.bstart, &dst.bstart_cap, src.bstart_cap, sizeof(uint32_t)},
+        {(void **)&dst.bkey, &dst.bkey_cap, src.bkey_cap, sizeof(uint64_t)},  {(void **)&dst.bmark, &dst.bmark_cap, src.bmark_cap, sizeof(uint8_t)},
+        {(void **)&dst.bend, &dst.bend_cap, src.bend_cap, sizeof(uint32_t)},  {(void **)&dst.bmove, &dst.bmove_cap, src.bmove_cap, sizeof(uint32_t)},
+        {(void **)&dst.bplan, &dst.bplan_cap, src.bplan_cap, 32},             {(void **)&dst.blist, &dst.blist_cap, src.blist_cap, sizeof(uint32_t)},
+        {(void **)&dst.run, &dst.run_cap, src.run_cap, sizeof(uint2)},        {(void **)&dst.grow, &dst.grow_cap, src.grow_cap, sizeof(uint32_t)},
+        {(void **)&dst.mk, &dst.mk_cap, src.mk_cap, sizeof(uint64_t)},        {(void **)&dst.mv, &dst.mv_cap, src.mv_cap, sizeof(uint32_t)},
+        {(void **)&dst.dword, &dst.dword_cap, src.dword_cap, sizeof(unsigned long long)},
+    };
+    for (const Arr &a : arrs)
+        if (a.want > 0 && *a.cap < a.want) S2M_TRY(map_ensure(a.p, a.cap, a.want, a.elem, 0));
+    if (dst.scratch_cap < src.scratch_cap) {
+        void **ps[] = {(void **)&dst.keys, (void **)&dst.keys_alt, (void **)&dst.vals, (void **)&dst.vals_alt,
+                       (void **)&dst.work_a, (void **)&dst.work_b, (void **)&dst.work_c};
+        const size_t es[] = {8, 8, 4, 4, 4, 4, 4};
+        dst.scratch_cap = 0;
+        for (int k = 0; k < 7; ++k) {
+            int64_t c = 0;
+            if (*ps[k]) { S2M_TRY(hipFree(*ps[k])); *ps[k] = nullptr; }
+            S2M_TRY(map_ensure(ps[k], &c, src.scratch_cap + 1, es[k], 0));
+        }
+        dst.scratch_cap = src.scratch_cap;
+    }
+    if (dst.sort_tmp_bytes < src.sort_tmp_bytes) {   // (exactly as much: the two maps change places, neither may outbid the other)
+        if (dst.sort_tmp) S2M_TRY(hipFree(dst.sort_tmp));
+        dst.sort_tmp = nullptr;
+        dst.sort_tmp_bytes = 0;
+        S2M_TRY(hipMalloc(&dst.sort_tmp, src.sort_tmp_bytes));
+        note_allocation("map sort_tmp (the other map)", src.sort_tmp_bytes);
+        dst.sort_tmp_bytes = src.sort_tmp_bytes;
+    }
+    return hipSuccess;
+}
+
 // The same arrays for a map that has outgrown them in the middle of an update: everything is re-allocated (room for twice the
 // need: a map that is driven through keeps growing), the sorted keys of the current map -- the one array an update reads --
 // carried over.  A slow frame (allocations stall the stream) instead of a rebuild; the reference's tree allocates per node.
