@@ -71,9 +71,10 @@ std::string debug_state(const s2m_engine *e)
                   (int)e->pf.busy, e->pf.busy_a.load(), (int)e->pf.gpu_pending, (int)e->pf.ready, (int)e->pf.prepared, flag, e->seq, m0, m1, m2, m3, m4,
                   (long long)e->wait.n_waits.load(), (long long)e->wait.n_slow.load(), e->wait.policy, (long long)(e->wait.timeout_us / 1000));
     std::string out = b;
-    std::snprintf(b, sizeof(b), "; layout beside the frames: state %d, %lld begun, %lld swapped in, %lld dropped, %lld failed, last reason \"%s\", density %.1f",
+    std::snprintf(b, sizeof(b), "; layout beside the frames: state %d, %lld begun, %lld swapped in, %lld dropped, %lld failed, last reason \"%s\", density %.1f"
+                  "; map code allocations (all handles): %lld, %.1f MB",
                   e->relay.state.load(), (long long)e->relay.n_started, (long long)e->n_beside, (long long)e->relay.n_dropped, (long long)e->relay.n_failed,
-                  e->relay.why.load(), e->relay.density);
+                  e->relay.why.load(), e->relay.density, (long long)map_allocations(), (double)map_allocated_bytes() / 1048576.0);
     return out + b;
 }
 

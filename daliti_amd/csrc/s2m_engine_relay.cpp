@@ -357,7 +357,7 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
         // have changed places and each holds arrays the other never needed -- matching those would be a dozen allocations in a
         // frame for nothing)
         if (e->grid.live > r.sized_live + r.sized_live / 4) {
-            S2M_HIP(e, map_reserve_like(r.map, e->map));
+            S2M_HIP(e, map_reserve_like(r.map, e->map, 2 * e->grid.live + 65536));
             S2M_HIP(e, update_reserve_like(r.upd, e->upd, e->stream));
             if (e->grid.live + e->grid.live / 4 + 65536 > r.snap_cap || snapshot_blocks(e->grid.m + e->grid.m / 4) + 1 > r.snap_blk_cap) {
                 r.snap_bound = 2 * e->grid.live + 65536;

@@ -123,7 +123,8 @@ struct MapStats {
 hipError_t build_map(const float *xyz_dev, int64_t stride, int64_t m, float cell, MapBuffers &buf, Grid &grid,
                      MapStats &stats, bool &too_large, hipStream_t st, const float *keep_origin = nullptr);
 void free_map(MapBuffers &buf);
-hipError_t map_reserve_like(MapBuffers &dst, const MapBuffers &src);   // dst's arrays at least as large as src's (dst not in use)
+hipError_t map_reserve_like(MapBuffers &dst, const MapBuffers &src, int64_t build_points);   // dst's arrays at least as large as src's, and room to BUILD build_points points (dst not in use)
+int64_t map_allocated_bytes();   // ... and their bytes
 int64_t map_allocations();  // device (re)allocations by the map build / merge / update code so far (all handles; diagnostic)
 void note_allocation(const char *what = "", size_t bytes = 0);
 // bricks / occupied_cells of the last build or merge (a merge does not wait for them: they arrive behind it)

@@ -289,11 +289,13 @@ __global__ __launch_bounds__(256) void brick_table_kernel(const uint32_t *__rest
 // little with every scan does not reallocate -- two device-wide syncs and ~100 MB of hipMalloc at 5 M points --
 // on every update (round 2 compared the stored capacity against need + headroom: the headroom was never usable)
 static int64_t g_map_allocations = 0;  // diagnostic only (s2m_map_update_stats); racy increments are harmless
+static int64_t g_map_alloc_bytes = 0;
 // S2M_TRACE_ALLOC=1: every (re)allocation of the map / update code is reported on stderr (a device allocation stalls the
 // stream for ~0.1-1 ms: in a frame loop each one is a slow frame, and this is how they are found)
 static void trace_alloc(const char *what, size_t bytes)
 {
     static const bool on = std::getenv("S2M_TRACE_ALLOC") != nullptr;
+    g_map_alloc_bytes += (int64_t)bytes;
     if (on) std::fprintf(stderr, "[s2m alloc] %s: %.1f MB (allocation %lld)\n", what, (double)bytes / 1048576.0, (long long)g_map_allocations);
 }
 hipError_t map_ensure(void **p, int64_t *cap, int64_t need, size_t elem, int64_t headroom)
@@ -310,6 +312,7 @@ hipError_t map_ensure(void **p, int64_t *cap, int64_t need, size_t elem, int64_t
     return hipSuccess;
 }
 int64_t map_allocations() { return g_map_allocations; }
+int64_t map_allocated_bytes() { return g_map_alloc_bytes; }
 void note_allocation(const char *what, size_t bytes) { ++g_map_allocations; trace_alloc(what, bytes); }
 // (with room for the slack and the tail a maintained map is laid out with: s2m_mapedit.hip)
 int64_t map_headroom_for(int64_t m) { return m + ((int64_t)1 << 20); }
@@ -362,7 +365,7 @@ static hipError_t ensure_scratch(MapBuffers &buf, int64_t m)
 // live map's growth at the moment the live map allocates -- a frame that has stalled for its allocations anyway -- instead of
 // allocating beside the frames of the next layout (s2m_engine_relay.cpp).  What `dst` held is lost where an array grows: only for
 // a map that is not in use and will be built from scratch.
-hipError_t map_reserve_like(MapBuffers &dst, const MapBuffers &src)
+hipError_t map_reserve_like(MapBuffers &dst, const MapBuffers &src, int64_t build_points)
 {
     struct Arr { void **p; int64_t *cap; int64_t want; size_t elem; };
     const Arr arrs[] = {
@@ -391,13 +394,22 @@ hipError_t map_reserve_like(MapBuffers &dst, const MapBuffers &src)
         }
         dst.scratch_cap = src.scratch_cap;
     }
-    if (dst.sort_tmp_bytes < src.sort_tmp_bytes) {   // (exactly as much: the two maps change places, neither may outbid the other)
+    // the temporary storage a BUILD of build_points points sorts with (the live map may never have been built at its present size:
+    // its own storage is what its merges needed)
+    size_t want_tmp = src.sort_tmp_bytes;
+    if (build_points > 0) {
+        size_t t = 0;
+        uint64_t *k = nullptr;
+        uint32_t *v = nullptr;
+        if (rocprim::radix_sort_pairs(nullptr, t, k, k, v, v, (size_t)build_points, 0, 64u, (hipStream_t) nullptr) == hipSuccess) want_tmp = std::max(want_tmp, t);
+    }
+    if (dst.sort_tmp_bytes < want_tmp) {   // (exactly as much: the two maps change places, neither may outbid the other)
         if (dst.sort_tmp) S2M_TRY(hipFree(dst.sort_tmp));
         dst.sort_tmp = nullptr;
         dst.sort_tmp_bytes = 0;
-        S2M_TRY(hipMalloc(&dst.sort_tmp, src.sort_tmp_bytes));
-        note_allocation("map sort_tmp (the other map)", src.sort_tmp_bytes);
-        dst.sort_tmp_bytes = src.sort_tmp_bytes;
+        S2M_TRY(hipMalloc(&dst.sort_tmp, want_tmp));
+        note_allocation("map sort_tmp (the other map)", want_tmp);
+        dst.sort_tmp_bytes = want_tmp;
     }
     return hipSuccess;
 }

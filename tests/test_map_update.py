@@ -1037,3 +1037,47 @@ def test_layout_in_flight_is_dropped_when_the_map_is_replaced_or_the_handle_dest
     f.map_add((base[rs.choice(len(base), 400)] + np.float32(0.05)), False)
     t0 = time.perf_counter()
     assert f.close() == 0 and time.perf_counter() - t0 < 2.0           # ... and the handle destroyed with it in flight
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("first", [1, 8192])
+def test_the_other_map_follows_the_growth_of_the_live_map(monkeypatch, first):
+    """A map built small (one point: too small for the rehearsal at the build; 8 192 points: a rehearsal for 8 192) and grown by
+    Add_Points to 300 000: the map a layout beside the updates is built into has its buffers allocated in the calls that grew
+    the live map -- the layout itself, forced behind a later update, allocates nothing beside the updates (s2m_engine_relay.cpp,
+    relay_after_commit; ikd-Tree's rebuild thread allocates its nodes one by one, ikd_Tree.cpp:229-367) -- and the map is the
+    one the same calls leave without it."""
+    from daliti_amd import Engine, synth
+    cloud = synth.make_map(300_000, seed=4)
+    rs = np.random.RandomState(9)
+    grow = [cloud[first:60_000], cloud[60_000:160_000], cloud[160_000:]]
+    later = [(cloud[rs.choice(len(cloud), 400)] + rs.normal(0, 0.2, (400, 3))).astype(np.float32) for _ in range(10)]
+    out = {}
+    for road in ("beside", "inside"):
+        if road == "beside":
+            monkeypatch.setenv("S2M_BESIDE_AT", str(len(grow) + 4))   # (updates are counted from the build)
+            monkeypatch.delenv("S2M_NO_BESIDE", raising=False)
+        else:
+            monkeypatch.delenv("S2M_BESIDE_AT", raising=False)
+            monkeypatch.setenv("S2M_NO_BESIDE", "1")
+        e = Engine(cell_size=0.5)
+        e.map_build(cloud[:first])
+        for g in grow:
+            e.map_add(g, False)
+        for p in later[:3]:                       # (warm: the update buffers have seen a batch of this size)
+            e.map_add(p, True, 0.5)
+        def allocated_mb():
+            return float(e.debug_state().split("map code allocations (all handles):")[1].split(",")[1].split("MB")[0])
+        mb = allocated_mb()
+        for p in later[3:]:
+            e.map_add(p, True, 0.5)
+            e.scan_set(cloud[:2048])              # (a new scan arrives: the moment a finished layout is swapped in)
+            time.sleep(0.02)
+        st = e.map_update_stats()
+        if road == "beside":
+            assert st["relaid_beside"] == 1, (st, e.debug_state())
+            # (a few table windows of kilobytes may differ between the two grids; the arrays that scale with the map may not)
+            assert allocated_mb() - mb < 2.0, "the layout beside the updates allocated %.1f MB" % (allocated_mb() - mb)
+        out[road] = (e.map_ids(), e.map_points().copy())
+        assert e.close() == 0
+    assert (out["beside"][0] == out["inside"][0]).all() and (bits(out["beside"][1]) == bits(out["inside"][1])).all()
