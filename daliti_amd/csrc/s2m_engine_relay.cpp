@@ -69,7 +69,8 @@ hipError_t worker_prepare(s2m_engine *e)
         }
         if (!r.stream) {
             int least = 0, greatest = 0;
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+            if (const char *g = std::getenv("S2M_BESIDE_PRIO")) least = std::strcmp(g, "normal") == 0 ? 0 : std::strcmp(g, "high") == 0 ? greatest : least;   // (A/B)
             if (hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, least) != hipSuccess) {
                 (void)hipGetLastError();
                 S2M_TRY(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
