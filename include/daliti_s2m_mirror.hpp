@@ -66,7 +66,7 @@ struct s2m_map_mirror {
     /* bytes the mirror holds (tests: it follows the live points, not the ids ever issued) */
     size_t memory_bytes() const
     {
-        size_t s = table_.capacity() * sizeof(Slot) + buckets_.capacity() * sizeof(Bucket) + free_.capacity() * sizeof(int32_t);
+        size_t s = (table_.capacity() + spare_.capacity()) * sizeof(Slot) + buckets_.capacity() * sizeof(Bucket) + free_.capacity() * sizeof(int32_t);
         for (const Bucket &b : buckets_) s += b.pts.capacity() * sizeof(Pt);
         s += later_.capacity() * sizeof(int32_t) + (group_.capacity() + touched_.capacity()) * sizeof(uint32_t);
         for (const IO &io : io_)
@@ -157,7 +157,7 @@ struct s2m_map_mirror {
     /* ---- the pieces update() is made of, public so that they can be tested without a device ---- */
     void clear()
     {
-        buckets_.clear(); free_.clear(); later_.clear(); table_.clear(); used_ = 0; live_ = 0; last_ = -1;
+        buckets_.clear(); free_.clear(); later_.clear(); table_.clear(); spare_.clear(); used_ = 0; live_ = 0; last_ = -1;
     }
     /* the arrays of up to n buckets that a box delete emptied go back to the allocator (unless points have moved in since) */
     void give_back(size_t n)
@@ -263,7 +263,11 @@ struct s2m_map_mirror {
         if (at >= 0) return buckets_[(size_t)at];   /* (possibly one that a trim emptied: it kept its place in the table) */
         if ((used_ + 1) * 2 > table_.size()) rehash();
         if (!free_.empty()) { at = free_.back(); free_.pop_back(); }
-        else { at = (int32_t)buckets_.size(); buckets_.emplace_back(); }
+        else {
+            if (buckets_.capacity() == 0) buckets_.reserve((size_t)1 << 14);   /* (a drive opens a few dozen buckets per frame: not a reallocation of the pool every few hundred frames) */
+            at = (int32_t)buckets_.size();
+            buckets_.emplace_back();
+        }
         Bucket &b = buckets_[(size_t)at];
         for (int q = 0; q < 3; ++q) b.c[q] = (int32_t)((int64_t)((key >> (21 * (2 - q))) & 0x1fffff) - (int64_t)kBias);
         b.dead = 0;
@@ -284,16 +288,22 @@ struct s2m_map_mirror {
      * trim does not pay for thousands of deletions from the table) */
     void rehash()
     {
-        std::vector<Slot> old;
-        old.swap(table_);
         size_t keep = 0;
-        for (const Slot &s : old)
+        for (size_t i = 0; i < table_.size(); ++i) {   /* (every bucket is looked at, in table order = at random: the look-ups abreast) */
+            if (i + 16 < table_.size() && table_[i + 16].at >= 0) __builtin_prefetch(&buckets_[(size_t)table_[i + 16].at]);
+            const Slot &s = table_[i];
             if (s.at >= 0 && (!buckets_[(size_t)s.at].pts.empty() || buckets_[(size_t)s.at].pending != 0)) ++keep;
+        }
         size_t cap = 1024;
         while (cap < 4 * (keep + 1)) cap *= 2;
-        table_.assign(cap, Slot{0, -1, 0});
+        /* into the spare table: the two change places at every rehash, so that one that only sheds emptied buckets (the usual
+         * case on a drive: the table keeps its size) writes into memory it has written before -- a fresh megabyte from the
+         * allocator is a few hundred page faults, a millisecond on the publishing thread */
+        spare_.assign(cap, Slot{0, -1, 0});
+        spare_.swap(table_);
         used_ = 0;
-        for (const Slot &s : old) {
+        for (size_t i = 0; i < spare_.size(); ++i) {
+            const Slot &s = spare_[i];
             if (s.at < 0) continue;
             if (buckets_[(size_t)s.at].pts.empty() && buckets_[(size_t)s.at].pending == 0) { free_.push_back(s.at); continue; }
             insert_slot(s.key, s.at);
@@ -438,7 +448,7 @@ struct s2m_map_mirror {
 
     std::vector<Bucket> buckets_;
     std::vector<int32_t> free_;
-    std::vector<Slot> table_;
+    std::vector<Slot> table_, spare_;
     size_t used_ = 0;
     int64_t live_ = 0;
     int32_t last_ = -1;

@@ -114,6 +114,18 @@ int main(int argc, char **argv)
                     phase == 0 ? "dense seed being thinned" : "steady state", frames, (double)na / frames, (double)nr / frames, med(ta) * 1e-3, pct(ta, 0.99) * 1e-3,
                     med(ta) * 1e3 / std::max(1.0, (double)na / frames), med(tr) * 1e-3, pct(tr, 0.99) * 1e-3, med(tr) * 1e3 / std::max(1.0, (double)nr / frames), (long long)m.missed);
     }
+    {   // the table growing (or shedding emptied buckets): every bucket is looked at
+        // (cold: walk something large first)
+        std::vector<char> big(256 << 20, 1);
+        size_t sum = 0;
+        for (size_t i = 0; i < big.size(); i += 64) sum += big[i];
+        for (int k = 0; k < 3; ++k) {   // (the first one writes a table the allocator has just handed out; the later ones the spare)
+            for (size_t i = 0; i < big.size(); i += 64) sum += big[i];
+            const double t = now_us();
+            m.rehash();
+            std::printf("rehash %d with %zu buckets: %.3f ms (%zu)\n", k, m.buckets_.size(), (now_us() - t) * 1e-3, sum & 1);
+        }
+    }
     // the trim: everything behind x = 150
     const float box[6] = {-1000.0f, -1000.0f, -1000.0f, 150.0f, 1000.0f, 1000.0f};
     const int64_t before = m.size();

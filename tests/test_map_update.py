@@ -1073,6 +1073,11 @@ def test_the_other_map_follows_the_growth_of_the_live_map(monkeypatch, first):
             e.map_add(p, True, 0.5)
             e.scan_set(cloud[:2048])              # (a new scan arrives: the moment a finished layout is swapped in)
             time.sleep(0.02)
+        for _ in range(300):                      # (a busy host: the layout thread may need longer than the calls took)
+            if road != "beside" or e.map_update_stats()["relaid_beside"] == 1:
+                break
+            e.scan_set(cloud[:2048])
+            time.sleep(0.01)
         st = e.map_update_stats()
         if road == "beside":
             assert st["relaid_beside"] == 1, (st, e.debug_state())
