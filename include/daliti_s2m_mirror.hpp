@@ -157,7 +157,7 @@ struct s2m_map_mirror {
     /* ---- the pieces update() is made of, public so that they can be tested without a device ---- */
     void clear()
     {
-        buckets_.clear(); free_.clear(); later_.clear(); table_.clear(); spare_.clear(); used_ = 0; live_ = 0; last_ = -1;
+        buckets_.clear(); free_.clear(); later_.clear(); table_.clear(); spare_.clear(); used_ = 0; gone_ = 0; live_ = 0; last_ = -1;
     }
     /* the arrays of up to n buckets that a box delete emptied go back to the allocator (unless points have moved in since) */
     void give_back(size_t n)
@@ -206,6 +206,7 @@ struct s2m_map_mirror {
                 live_ -= (int64_t)b.pts.size() - (int64_t)b.dead;
                 b.pts.clear();
                 b.dead = 0;
+                mark_gone((int32_t)at);
                 later_.push_back((int32_t)at);
                 continue;
             }
@@ -223,11 +224,10 @@ struct s2m_map_mirror {
     struct Bucket {
         int32_t c[3] = {0, 0, 0};
         uint32_t dead = 0;
-        uint32_t pending = 0;     /* points of the stretch being applied that have found this bucket and are not written yet */
         uint32_t want = 0, off = 0; /* remove_many: removals of the stretch that fall into this bucket; their place in group_ */
         std::vector<Pt> pts;      /* ids ascending; a removed point stays as a mark (x = NaN) until the bucket is compacted */
     };
-    struct Slot { uint64_t key; int32_t at; int32_t pad; };   /* at < 0: empty */
+    struct Slot { uint64_t key; int32_t at; int32_t gone; };   /* at < 0: empty; gone: the bucket holds nothing (it leaves at the next rehash) */
     static constexpr uint64_t kBias = (uint64_t)1 << 20;
 
     static uint64_t key_of(const float *p)
@@ -253,14 +253,17 @@ struct s2m_map_mirror {
         const size_t mask = table_.size() - 1;
         for (size_t i = hash(key) & mask;; i = (i + 1) & mask) {
             if (table_[i].at < 0) return -1;
-            if (table_[i].key == key) { last_ = table_[i].at; last_key_ = key; return last_; }
+            if (table_[i].key == key) { last_ = table_[i].at; last_key_ = key; last_slot_ = i; return last_; }
         }
     }
     Bucket &bucket_of(const float *p, bool)
     {
         const uint64_t key = key_of(p);
         int32_t at = find_bucket(key);
-        if (at >= 0) return buckets_[(size_t)at];   /* (possibly one that a trim emptied: it kept its place in the table) */
+        if (at >= 0) {   /* (possibly one that a trim emptied: it kept its place in the table) */
+            if (table_[last_slot_].gone) { table_[last_slot_].gone = 0; --gone_; }
+            return buckets_[(size_t)at];
+        }
         if ((used_ + 1) * 2 > table_.size()) rehash();
         if (!free_.empty()) { at = free_.back(); free_.pop_back(); }
         else {
@@ -271,52 +274,66 @@ struct s2m_map_mirror {
         Bucket &b = buckets_[(size_t)at];
         for (int q = 0; q < 3; ++q) b.c[q] = (int32_t)((int64_t)((key >> (21 * (2 - q))) & 0x1fffff) - (int64_t)kBias);
         b.dead = 0;
-        b.pending = 0;
-        insert_slot(key, at);
+        last_slot_ = insert_slot(key, at);
         ++used_;
         last_ = at; last_key_ = key;
         return b;
     }
-    void insert_slot(uint64_t key, int32_t at)
+    size_t insert_slot(uint64_t key, int32_t at)
     {
         const size_t mask = table_.size() - 1;
         size_t i = hash(key) & mask;
         while (table_[i].at >= 0) i = (i + 1) & mask;
-        table_[i].key = key; table_[i].at = at;
+        table_[i].key = key; table_[i].at = at; table_[i].gone = 0;
+        return i;
+    }
+    /* the bucket holds nothing any more: its slot says so (the rehash sheds it without looking at the bucket) */
+    void mark_gone(int32_t at)
+    {
+        const Bucket &b = buckets_[(size_t)at];
+        uint64_t key = 0;
+        for (int q = 0; q < 3; ++q) key = (key << 21) | (uint64_t)((int64_t)b.c[q] + (int64_t)kBias);
+        const size_t mask = table_.size() - 1;
+        for (size_t i = hash(key) & mask;; i = (i + 1) & mask) {
+            if (table_[i].at < 0) return;   /* (not in the table: cannot happen) */
+            if (table_[i].key == key) {
+                if (!table_[i].gone) { table_[i].gone = 1; ++gone_; }
+                return;
+            }
+        }
     }
     /* the table grows -- or only sheds the buckets that trims have emptied since (they keep their slot until now, so that a
      * trim does not pay for thousands of deletions from the table) */
     void rehash()
     {
-        size_t keep = 0;
-        for (size_t i = 0; i < table_.size(); ++i) {   /* (every bucket is looked at, in table order = at random: the look-ups abreast) */
-            if (i + 16 < table_.size() && table_[i + 16].at >= 0) __builtin_prefetch(&buckets_[(size_t)table_[i + 16].at]);
-            const Slot &s = table_[i];
-            if (s.at >= 0 && (!buckets_[(size_t)s.at].pts.empty() || buckets_[(size_t)s.at].pending != 0)) ++keep;
-        }
+        /* (the slots know which buckets hold nothing: no bucket is looked at -- tens of thousands of them at random places were a
+         * millisecond of cache misses on the publishing thread every few hundred frames of a drive) */
+        const size_t keep = used_ - gone_;
         size_t cap = 1024;
         while (cap < 4 * (keep + 1)) cap *= 2;
         /* into the spare table: the two change places at every rehash, so that one that only sheds emptied buckets (the usual
          * case on a drive: the table keeps its size) writes into memory it has written before -- a fresh megabyte from the
-         * allocator is a few hundred page faults, a millisecond on the publishing thread */
+         * allocator is a few hundred page faults */
         spare_.assign(cap, Slot{0, -1, 0});
         spare_.swap(table_);
         used_ = 0;
+        gone_ = 0;
         for (size_t i = 0; i < spare_.size(); ++i) {
             const Slot &s = spare_[i];
             if (s.at < 0) continue;
-            if (buckets_[(size_t)s.at].pts.empty() && buckets_[(size_t)s.at].pending == 0) { free_.push_back(s.at); continue; }
+            if (s.gone) { free_.push_back(s.at); continue; }
             insert_slot(s.key, s.at);
             ++used_;
         }
         last_ = -1;
     }
-    /* the bucket gives its memory back; its slot in the table and its place in the pool are shed by the next rehash */
+    /* the bucket gives its memory back; its slot in the table (marked) and its place in the pool are shed by the next rehash */
     void release(int32_t at)
     {
         Bucket &b = buckets_[(size_t)at];
         std::vector<Pt>().swap(b.pts);
         b.dead = 0;
+        mark_gone(at);
     }
     void mark(Bucket &b, size_t i)
     {
@@ -349,7 +366,6 @@ struct s2m_map_mirror {
         for (size_t i = 0; i < n; ++i) {
             const float *p = &ap_->add_xyz[3 * ((size_t)a0 + i)];
             Bucket &b = bucket_of(p, true);
-            ++b.pending;   /* (a bucket this stretch has just opened is still empty: the table must not shed it before the points are in) */
             where_[i] = (int32_t)(&b - buckets_.data());
         }
         for (size_t i = 0; i < n; ++i) {
@@ -360,7 +376,6 @@ struct s2m_map_mirror {
             const float *p = &ap_->add_xyz[3 * ((size_t)a0 + i)];
             Bucket &b = buckets_[(size_t)where_[i]];
             b.pts.push_back(Pt{p[0], p[1], p[2], ap_->add_ids[(size_t)a0 + i]});
-            --b.pending;
         }
         live_ += (int64_t)n;
     }
@@ -449,7 +464,8 @@ struct s2m_map_mirror {
     std::vector<Bucket> buckets_;
     std::vector<int32_t> free_;
     std::vector<Slot> table_, spare_;
-    size_t used_ = 0;
+    size_t used_ = 0, gone_ = 0;   /* slots in use; of those, buckets that hold nothing */
+    size_t last_slot_ = 0;
     int64_t live_ = 0;
     int32_t last_ = -1;
     uint64_t last_key_ = 0;
