@@ -57,6 +57,8 @@ for d in range(drives):
         d, names[pol], time.time() - t1, np.median(ms), np.percentile(ms, 99), ms.max(), (ms > 1.0).sum(), (ms > 5.0).sum(),
         (how == 2).sum(), (how == 1).sum(), (how == 0).sum(),
         [(int(i), round(float(ms[i]), 2)) for i in np.argsort(ms)[-3:][::-1]]), flush=True)
+    for i in np.nonzero(ms > 2.0)[0]:   # where a frame of milliseconds went: the wall times of its calls (set_from_raw, prefetch, iterated_update, prepare, map_incremental, fov)
+        print("   frame %d: %.3f ms, calls %s, %d device allocations" % (i, ms[i], np.round(r["stage_ms"][warm + i], 3), r["allocs"][warm + i]), flush=True)
 if e is not None:
     e.close()
 for pol in range(3):
