@@ -172,6 +172,25 @@ int commit_update(s2m_engine *e, MapSide s, const float *boxes, int nb)
         // the cells stay where they are (same origin) unless the map was empty or has wandered beyond the representable range
         const float origin[3] = {grid.ox, grid.oy, grid.oz};
         const bool keep = grid.m > 0 && cell == grid.c;
+        if (grid.m > 0 && m_new > 0 && map.bbox) {
+            // the map in hand is given up by the build: first make sure the build will not refuse the new box (a coordinate of
+            // hundreds of kilometres in one scan must not cost a node its map -- ikd-Tree has no such limit, ikd_Tree.cpp:477-573)
+            float lo[3], hi[3];
+            he = cloud_bbox(reinterpret_cast<const float *>(upd.list), 4, m_new, map.bbox, map.mail, lo, hi, st);
+            if (he != hipSuccess) return bad(S2M_ERR_HIP, "cloud_bbox", he);
+            if (!(keep && map_build_would_fit(lo, hi, cell, origin)) && !map_build_would_fit(lo, hi, cell, nullptr)) {
+                // what the abandoned update left in the update state: its removal marks (the next update starts from the ids again)
+                // and the bricks it had flagged
+                upd.alive_gen = ~0ull;
+                if (map.bmark && map.bmark_cap > 0) S2M_HIP(e, hipMemsetAsync(map.bmark, 0, (size_t)map.bmark_cap, st));
+                if (s.live) {
+                    e->map_ready = true;                    // the map is as it was: nothing of it has been written
+                    if (e->log.on) e->log.token = 0;        // (the removals already logged did not happen: a follower starts over)
+                }
+                return bad(S2M_ERR_CAPACITY, "a point of this update lies beyond what the map can represent at its cell size: the update "
+                                             "was not applied, the map is as it was");
+            }
+        }
         he = build_map(reinterpret_cast<const float *>(upd.list), 4, m_new, cell, map, grid, stats, too_large,
                        st, keep ? origin : nullptr);
         if (he == hipSuccess && too_large && keep)   // beyond the range of the old origin: a new one

@@ -124,6 +124,7 @@ hipError_t build_map(const float *xyz_dev, int64_t stride, int64_t m, float cell
                      MapStats &stats, bool &too_large, hipStream_t st, const float *keep_origin = nullptr);
 void free_map(MapBuffers &buf);
 hipError_t map_reserve_like(MapBuffers &dst, const MapBuffers &src, int64_t build_points);   // dst's arrays at least as large as src's, and room to BUILD build_points points (dst not in use)
+bool map_build_would_fit(const float lo[3], const float hi[3], float cell, const float *keep_origin);   // build_map's verdict on a box, nothing touched
 int64_t map_allocated_bytes();   // ... and their bytes
 int64_t map_allocations();  // device (re)allocations by the map build / merge / update code so far (all handles; diagnostic)
 void note_allocation(const char *what = "", size_t bytes = 0);

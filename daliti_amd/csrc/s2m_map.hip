@@ -626,6 +626,30 @@ hipError_t map_build_tables(MapBuffers &buf, Grid &g, const uint64_t *keys, int6
     return hipSuccess;
 }
 
+// Would a build of a cloud with the box [lo, hi] at this cell size (around keep_origin, or around an origin of its own) find the
+// box representable?  The checks of build_once / map_window_for without touching anything: an update that has to fall back
+// to a rebuild asks BEFORE the map it holds is given up (one absurd coordinate in a scan must not cost a node its map).
+bool map_build_would_fit(const float lo[3], const float hi[3], float cell, const float *keep_origin)
+{
+    if (!(cell > 0.0f)) return true;   // (chosen from the density by the build itself)
+    const float shift[3] = {0.37f, 0.41f, 0.29f};
+    const float inv_c = 1.0f / cell;
+    int blo[3], bhi[3];
+    double box_bricks = 1.0;
+    for (int k = 0; k < 3; ++k) {
+        const float o = keep_origin ? keep_origin[k] : std::floor(lo[k] / cell) * cell - cell - shift[k] * cell;
+        const int c0 = cell_coord(lo[k], o, inv_c), c1 = cell_coord(hi[k], o, inv_c);
+        if (!(lo[k] <= hi[k]) || c0 <= -kCellLimit || c1 >= kCellLimit) return false;
+        blo[k] = c0 >> 3; bhi[k] = c1 >> 3;
+        box_bricks *= (double)std::max(bhi[k] - blo[k] + 1, 1);
+    }
+    if (box_bricks >= 9.0e15) return false;
+    Grid g;
+    bool too_large = false;
+    if (map_window_for(g, blo, bhi, too_large, nullptr) != hipSuccess) return false;
+    return !too_large;
+}
+
 // The grid's origin is chosen by the FIRST build of a map (keep_origin == nullptr) and kept by every later one: a cell's
 // box-independent coordinates -- and with them the order of the points -- never change while the cell size stands.
 static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float cell, const float lo[3],

@@ -154,7 +154,12 @@ int s2m_map_info(const s2m_engine *e, double info[8]);
  * ikdtree.Add_Points(points, downsample_on) (ikd-Tree/ikd_Tree.cpp:477-573): with downsample_on the
  * voxel [min, max) of edge downsample_size around each new point keeps only the point closest to
  * its centre (ties: a new point beats an old one, the later of two new ones wins).
- * *n_added = voxels rewritten (downsample_on) or n. */
+ * *n_added = voxels rewritten (downsample_on) or n.
+ * A coordinate the grid cannot address at its cell size (beyond +-2^20 cells of the origin AND of any origin that would still
+ * hold the rest of the map: thousands of kilometres -- corrupt input, ikd-Tree would take it) makes the update fail with
+ * S2M_ERR_CAPACITY; the map is then exactly as it was before the call and the handle goes on working (the same holds for
+ * s2m_map_incremental).  Non-finite coordinates are stored in a clamped cell, where they are nobody's neighbour, or refused
+ * the same way. */
 int s2m_map_add(s2m_engine *e, const float *xyz, int64_t stride_floats, int64_t n, int downsample_on,
                 float downsample_size, int on_device, int64_t *n_added);
 /* ikdtree.Delete_Point_Boxes(cub_needrm) (ikd_Tree.cpp:631-658; lasermap_fov_segment,

@@ -1086,3 +1086,47 @@ def test_the_other_map_follows_the_growth_of_the_live_map(monkeypatch, first):
         out[road] = (e.map_ids(), e.map_points().copy())
         assert e.close() == 0
     assert (out["beside"][0] == out["inside"][0]).all() and (bits(out["beside"][1]) == bits(out["inside"][1])).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", ["map_add", "map_incremental"])
+def test_a_point_beyond_the_representable_range_does_not_cost_the_map(small_scene, entry):
+    """One absurd coordinate (thousands of kilometres: corrupt input, nothing a LiDAR returns) in an update: ikd-Tree would take the
+    point (ikd_Tree.cpp:477-573 knows no range); the brick grid cannot address it at its cell size.  The update is refused with
+    S2M_ERR_CAPACITY -- and the map stays exactly as it was, the handle goes on working; a non-finite coordinate is either
+    stored (in a clamped cell, never anybody's neighbour) or refused the same way."""
+    from daliti_amd import Engine, S2MError
+    sc = small_scene
+    e = Engine(max_iter=5)
+    e.map_build(sc["map"])
+    e.scan_set(sc["scan"])
+    before = e.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
+    ids0, pts0 = e.map_ids(), e.map_points().copy()
+    far = np.float32([5e5, -5e5, 2e6])
+    with pytest.raises(S2MError) as ei:
+        if entry == "map_add":
+            e.map_add(np.vstack([sc["map"][:50] + np.float32(0.03), far[None]]), True, 0.5)
+        else:
+            scan = sc["scan"].copy()
+            scan[100] = far
+            e.scan_set(scan)
+            r = e.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
+            e.map_incremental(r["x"], 0.5)
+    assert ei.value.code == -5 and "the map is as it was" in str(ei.value), ei.value
+    assert (e.map_ids() == ids0).all() and (bits(e.map_points()) == bits(pts0)).all()
+    e.scan_set(sc["scan"])
+    again = e.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
+    assert np.array_equal(again["x"], before["x"]) and list(again["effct"]) == list(before["effct"])
+    n0 = e.map_size()
+    e.map_add(sc["map"][:200] + np.float32(0.21), False)          # ... and takes the next update
+    assert e.map_size() == n0 + 200
+    for bad in (np.nan, np.inf):      # non-finite coordinates: stored in a clamped cell (nobody's neighbour) or refused -- never the map's end
+        try:
+            e.map_add(np.float32([[bad, 0.0, 1.0], [0.3, 0.2, 0.1]]), False)
+        except S2MError as ex:
+            assert ex.code == -5 and "the map is as it was" in str(ex), ex
+    assert n0 + 200 <= e.map_size() <= n0 + 204
+    e.scan_set(sc["scan"])
+    r = e.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
+    assert np.isfinite(r["x"]).all() and r["effct"][0] > 1000
+    assert e.close() == 0
