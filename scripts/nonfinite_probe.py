@@ -30,3 +30,33 @@ for what, vals in (("nan", [np.nan]*3), ("inf", [np.inf, -np.inf, np.inf]), ("hu
     except S2MError as ex:
         print(what, "map_build S2MError", ex.code, str(ex)[:200])
     print(what, "close", e.close(), flush=True)
+
+# the raw path: records with non-finite coordinates / times, a non-finite state
+rs = np.random.RandomState(3)
+n = 4096
+rec = np.zeros((n, 12), np.float32)
+rec[:, :3] = sc["scan"][rs.randint(0, len(sc["scan"]), n)]
+rec[:, 4] = np.sort(rs.uniform(0, 1, n)).astype(np.float32)
+rec[:, 6] = 0.1
+poses = np.zeros((4, 22)); poses[:, 0] = np.linspace(0.0, 0.11, 4); poses[:, 13:22] = np.eye(3).ravel()
+end = np.zeros(36); end[0:9] = np.eye(3).ravel(); end[12:21] = np.eye(3).ravel()
+for what in ("nan xyz", "inf xyz", "nan time", "inf time", "nan state", "nan P"):
+    e = Engine(max_iter=5, wait_timeout_ms=3000)
+    e.map_build(sc["map"])
+    r2 = rec.copy()
+    if what == "nan xyz": r2[10:20, :3] = np.nan
+    if what == "inf xyz": r2[10:20, 1] = np.inf
+    if what == "nan time": r2[10:20, 4] = np.nan
+    if what == "inf time": r2[10:20, 4] = np.inf
+    try:
+        m = e.scan_set_from_raw(r2, 4, 6, poses, end, 0.5)
+        xp = sc["x_prop"].copy(); P = sc["P"].copy()
+        if what == "nan state": xp[9] = np.nan
+        if what == "nan P": P[3, 3] = np.nan
+        r = e.iterated_update(xp.copy(), xp, P)
+        print(what, "ok: scan", m, "iters", r["iters"], "effct", list(r["effct"])[:2], "x finite", bool(np.isfinite(r["x"]).all()))
+        if np.isfinite(r["x"]).all():
+            print(what, "map_incremental", e.map_incremental(r["x"], 0.5))
+    except S2MError as ex:
+        print(what, "S2MError", ex.code, str(ex)[:160])
+    print(what, "close", e.close(), flush=True)
