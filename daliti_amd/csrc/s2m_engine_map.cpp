@@ -32,6 +32,10 @@ int s2m_map_build(s2m_engine *e, const float *xyz, int64_t stride, int64_t m, in
     e->nn_valid = false;
     e->built_cell = e->grid.c;
     e->log.token = 0;  // (a follower of the old map starts over)
+    if (const char *g = std::getenv("S2M_TEST_NEXT_ID")) {   // test hook: the ids of later points begin here (a node reaches 2^32 after a day)
+        const long long v = std::atoll(g);
+        if (v > (long long)e->map.next_id && v < ((long long)1 << 32)) { e->map.next_id = v; e->map.ids_dense = false; }
+    }
     return relay_rehearse(e, dev, stride, m);   // (what a layout beside the frames will need is allocated here, not beside a frame)
 }
 

@@ -1130,3 +1130,56 @@ def test_a_point_beyond_the_representable_range_does_not_cost_the_map(small_scen
     r = e.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
     assert np.isfinite(r["x"]).all() and r["effct"][0] > 1000
     assert e.close() == 0
+
+
+@pytest.mark.gpu
+def test_the_ids_run_out_and_the_map_goes_on(small_scene, monkeypatch):
+    """Point ids ascend for ever (uint32): a node at 10 Hz that adds 5 000 points per scan reaches 2^32 after a day.  With the ids
+    of new points starting just below the limit (test hook), the update that would cross it rebuilds the map -- ids dense
+    again, a follower of the change log is told to start over -- and every call leaves the same point set as on a handle that
+    is nowhere near the limit (ikd-Tree has no ids; Add_Points / Delete_Point_Boxes, ikd_Tree.cpp:477-573, :575-620)."""
+    from daliti_amd import Engine
+    rs = np.random.RandomState(17)
+    base = small_scene["map"]
+    calls = []
+    for k in range(10):
+        if k == 6:
+            c = base[rs.randint(len(base))]
+            calls.append(("box", np.float32([c[0] - 1.0, c[1] - 1.0, c[2] - 1.0, c[0] + 1.0, c[1] + 1.0, c[2] + 1.0])))
+        else:
+            calls.append(("add", (base[rs.choice(len(base), 700)] + rs.normal(0, 0.25, (700, 3))).astype(np.float32), k % 2 == 0))
+    limit = (1 << 32) - 2
+    out = {}
+    for road in ("near the limit", "far from it"):
+        if road == "near the limit":
+            monkeypatch.setenv("S2M_TEST_NEXT_ID", str(limit - 2500))   # (the fourth or fifth call crosses)
+        else:
+            monkeypatch.delenv("S2M_TEST_NEXT_ID", raising=False)
+        e = Engine(cell_size=0.5)
+        e.map_build(base)
+        token = e.map_changes(0).token
+        rebuilt0 = e.map_update_stats()["rebuilt"]
+        sets, resyncs, top = [], 0, []
+        for call in calls:
+            if call[0] == "box":
+                e.map_delete_boxes([call[1]])
+            else:
+                e.map_add(call[1], call[2], 0.5)
+            ch = e.map_changes(token)
+            token = ch.token
+            resyncs += int(ch.resync)
+            ids, pts = e.map_ids(), e.map_points()
+            assert len(np.unique(ids)) == len(ids) and int(ids.max()) < limit
+            top.append(int(ids.max()))
+            sets.append(pts[np.lexsort(pts.T)].copy())
+        e.scan_set(small_scene["scan"])
+        r = e.iterated_update(small_scene["x_prop"], small_scene["x_prop"], small_scene["P"])
+        out[road] = (sets, resyncs, e.map_update_stats()["rebuilt"] - rebuilt0, top, r["x"].copy(), list(r["effct"]))
+        assert e.close() == 0
+    a, b = out["near the limit"], out["far from it"]
+    assert a[2] == 1 and b[2] == 0, (a[2], b[2])               # one rebuild, where the ids ran out
+    assert a[1] == 1 and b[1] == 0                             # ... and the follower was told once
+    assert max(a[3][:3]) > limit - 2500 and a[3][-1] < len(base) + 10 * 700   # ids near the limit first, dense afterwards
+    for k, (sa, sb) in enumerate(zip(a[0], b[0])):
+        assert sa.shape == sb.shape and (bits(sa) == bits(sb)).all(), k
+    assert a[5] == b[5] and np.allclose(a[4], b[4], rtol=0, atol=1e-9)
