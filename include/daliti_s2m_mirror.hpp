@@ -426,14 +426,27 @@ struct s2m_map_mirror {
                 lo_[g[q]] = (j < m && b.pts[j].id == id && b.pts[j].x == b.pts[j].x) ? (uint32_t)j : (uint32_t)m;   /* (m: not there) */
             }
         }
-        /* the binary searches level by level, all points abreast: lo_ / len_ are every search's window */
-        for (; longest > 0; longest >>= 1) {
-            for (size_t i = 0; i < n; ++i) {
+        /* the binary searches level by level, a few hundred points abreast (lo_ / len_ are every search's window): the probes of
+         * one level are independent loads, the next level's are requested while this one's are compared -- and a few hundred
+         * windows' lines stay in the first-level cache, which a whole report's do not */
+        base_.resize(n);
+        (void)longest;
+        for (size_t c0 = 0; c0 < n; c0 += kAbreast) {
+            const size_t c1 = std::min(n, c0 + kAbreast);
+            uint32_t deepest = 0;
+            for (size_t i = c0; i < c1; ++i) {
                 if (len_[i] == 0) continue;
-                const Bucket &b = buckets_[(size_t)where_[i]];
-                const uint32_t half = len_[i] >> 1;
-                if (b.pts[lo_[i] + half].id < ap_->rem_ids[(size_t)r0 + i]) { lo_[i] += half + 1; len_[i] -= half + 1; } else len_[i] = half;
-                if (len_[i] > 0) __builtin_prefetch(&b.pts[lo_[i] + (len_[i] >> 1)]);
+                base_[i] = buckets_[(size_t)where_[i]].pts.data();
+                deepest = std::max(deepest, len_[i]);
+                __builtin_prefetch(&base_[i][len_[i] >> 1]);
+            }
+            for (; deepest > 0; deepest >>= 1) {
+                for (size_t i = c0; i < c1; ++i) {
+                    if (len_[i] == 0) continue;
+                    const uint32_t half = len_[i] >> 1;
+                    if (base_[i][lo_[i] + half].id < ap_->rem_ids[(size_t)r0 + i]) { lo_[i] += half + 1; len_[i] -= half + 1; } else len_[i] = half;
+                    if (len_[i] > 0) __builtin_prefetch(&base_[i][lo_[i] + (len_[i] >> 1)]);
+                }
             }
         }
         for (size_t i = 0; i < n; ++i) {
@@ -481,6 +494,8 @@ struct s2m_map_mirror {
     IO *ap_ = &io_[0];   /* the report being applied */
     std::vector<int32_t> where_;
     std::vector<uint32_t> lo_, len_, group_, touched_;
+    std::vector<const Pt *> base_;
+    static constexpr size_t kAbreast = 256;
     std::vector<int32_t> later_;   /* buckets a box delete emptied whose arrays are still to be given back */
 };
 
