@@ -244,7 +244,15 @@ int s2m_create(const s2m_config *cfg, s2m_engine **out)
     e->und.always_sort = std::getenv("S2M_NO_TIME_SHORTCUT") != nullptr;
     if (const char *g = std::getenv("S2M_FIRST_GAIN")) e->first_round_gain = std::max(1.5f, std::min(256.0f, (float)std::atof(g)));
     if (const char *g = std::getenv("S2M_BLIND_ROUNDS")) e->blind_rounds = std::max(0, std::min(8, std::atoi(g)));  // (A/B runs)
-    bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipSetDevice(dev) == hipSuccess;
+    if (ok) {
+        int least = 0, greatest = 0;
+        const char *g = std::getenv("S2M_MAIN_PRIO");   // (A/B: the handle's own stream at the highest priority)
+        if (g && std::strcmp(g, "high") == 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+            ok = hipStreamCreateWithPriority(&e->own_stream, hipStreamNonBlocking, greatest) == hipSuccess;
+        else
+            ok = hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) == hipSuccess;
+    }
     for (int i = 0; ok && i < 3; ++i) ok = hipEventCreate(&e->ev[i]) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_block, S2M_BLOCK_DOUBLES * sizeof(double)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&e->h_block, (S2M_BLOCK_DOUBLES + 8) * sizeof(double), hipHostMallocMapped) == hipSuccess;

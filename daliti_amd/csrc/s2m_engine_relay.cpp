@@ -299,6 +299,9 @@ int relay_after_commit(s2m_engine *e, bool inplace, bool kept_grid)
     // map's update buffers get the same capacities, here and not beside the frame of its first real update
     if (r.commits == 3 && r.state.load() == Relay::kIdle && r.map.pts && r.stream) {
         S2M_HIP(e, update_reserve_like(r.upd, e->upd, e->stream));
+        // (and the ring of recorded update calls is sized by the scan's capacity, which did not exist at the build: the worker
+        // would free and allocate it where the first layout starts -- a hipFree waits for the whole device, 0.85 ms in the trace)
+        S2M_HIP(e, worker_prepare(e));
         int rc = sync_stream(e, e->stream, "the other map's update buffers");
         if (rc) return rc;
         r.allocs_seen = map_allocations();
