@@ -361,6 +361,11 @@ static hipError_t ensure_scratch(MapBuffers &buf, int64_t m)
     return hipSuccess;
 }
 
+// The build's sort: rocprim would take a merge sort (a block sort and ~20 merge passes, one or two launches each) for up to
+// 2^20 points; a build beside the frames (s2m_engine_relay.cpp) competes with the frame's and the side thread's launches for
+// the runtime, so few launches matter more than the last microsecond: the radix passes above 4096 points.  Both are stable.
+using BuildSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
+
 // The arrays of `dst` get (at least) the capacities of `src`: the map a layout beside the frames will be built into follows the
 // live map's growth at the moment the live map allocates -- a frame that has stalled for its allocations anyway -- instead of
 // allocating beside the frames of the next layout (s2m_engine_relay.cpp).  What `dst` held is lost where an array grows: only for
@@ -401,7 +406,7 @@ hipError_t map_reserve_like(MapBuffers &dst, const MapBuffers &src, int64_t buil
         size_t t = 0;
         uint64_t *k = nullptr;
         uint32_t *v = nullptr;
-        if (rocprim::radix_sort_pairs(nullptr, t, k, k, v, v, (size_t)build_points, 0, 64u, (hipStream_t) nullptr) == hipSuccess) want_tmp = std::max(want_tmp, t);
+        if (rocprim::radix_sort_pairs<BuildSortConfig>(nullptr, t, k, k, v, v, (size_t)build_points, 0, 64u, (hipStream_t) nullptr) == hipSuccess) want_tmp = std::max(want_tmp, t);
     }
     if (dst.sort_tmp_bytes < want_tmp) {   // (exactly as much: the two maps change places, neither may outbid the other)
         if (dst.sort_tmp) S2M_TRY(hipFree(dst.sort_tmp));
@@ -713,11 +718,11 @@ static hipError_t build_once(const float *xyz, int64_t stride, int64_t m, float 
     int bits = 9 + log2_ceil((int64_t)box_bricks);
     bits = std::min(bits + 1, 64);
     size_t tmp = 0;
-    S2M_TRY(rocprim::radix_sort_pairs(nullptr, tmp, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m, 0,
+    S2M_TRY(rocprim::radix_sort_pairs<BuildSortConfig>(nullptr, tmp, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m, 0,
                                       (unsigned)bits, st));
     S2M_TRY(map_ensure_sort_tmp(buf, tmp));
     size_t t1 = buf.sort_tmp_bytes;
-    S2M_TRY(rocprim::radix_sort_pairs(buf.sort_tmp, t1, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m,
+    S2M_TRY(rocprim::radix_sort_pairs<BuildSortConfig>(buf.sort_tmp, t1, buf.keys, buf.keys_alt, buf.vals, buf.vals_alt, (size_t)m,
                                       0, (unsigned)bits, st));
     hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(256), 0, st, xyz, stride, m, buf.vals_alt, bb, buf.pts, buf.pidx, buf.keys_alt);
     buf.next_id = m;        // the ids of a fresh build are the caller's indices

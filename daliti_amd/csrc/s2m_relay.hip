@@ -94,11 +94,18 @@ __global__ __launch_bounds__(256) void snap_gather_kernel(const float4 *__restri
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = snap[val[i]];
 }
+// (rocprim sorts up to 2^20 items by a merge sort: a block sort and twenty merge passes -- twenty-odd launches of a few
+// microseconds each.  Beside the frames every launch of the worker competes with the frame's and the side thread's for the
+// runtime, and a burst of them slows all three; the radix passes are six launches)
+using SnapSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
 size_t snapshot_sort_tmp_bytes(int64_t n)
 {
     size_t tmp = 0;
     uint32_t *p = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp, p, p, p, p, (size_t)std::max<int64_t>(n, 1), 0, 32, (hipStream_t) nullptr);
+    (void)rocprim::radix_sort_pairs<SnapSortConfig>(nullptr, tmp, p, p, p, p, (size_t)std::max<int64_t>(n, 1), 0, 32, (hipStream_t) nullptr);
+    size_t tmp2 = 0;   // (either road's storage: the limit above is compared with the count at run time)
+    (void)rocprim::radix_sort_pairs<SnapSortConfig>(nullptr, tmp2, p, p, p, p, (size_t)4096, 0, 32, (hipStream_t) nullptr);
+    tmp = std::max(tmp, tmp2);
     return tmp;
 }
 // work: 4 n words (keys, sorted keys, values, sorted values); out: n points
@@ -107,7 +114,7 @@ hipError_t snapshot_sort_by_id(const float4 *snap, int64_t n, float4 *out, uint3
     if (n <= 0) return hipSuccess;
     uint32_t *key = work, *key2 = work + n, *val = work + 2 * n, *val2 = work + 3 * n;
     hipLaunchKernelGGL(snap_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, snap, n, key, val);
-    S2M_TRY(rocprim::radix_sort_pairs(tmp, tmp_bytes, key, key2, val, val2, (size_t)n, 0, 32, st));
+    S2M_TRY(rocprim::radix_sort_pairs<SnapSortConfig>(tmp, tmp_bytes, key, key2, val, val2, (size_t)n, 0, 32, st));
     hipLaunchKernelGGL(snap_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, snap, val2, n, out);
     return hipGetLastError();
 }
