@@ -362,8 +362,8 @@ static hipError_t ensure_scratch(MapBuffers &buf, int64_t m)
 }
 
 // The build's sort: rocprim would take a merge sort (a block sort and ~20 merge passes, one or two launches each) for up to
-// 2^20 points; a build beside the frames (s2m_engine_relay.cpp) competes with the frame's and the side thread's launches for
-// the runtime, so few launches matter more than the last microsecond: the radix passes above 4096 points.  Both are stable.
+// 2^20 points; a build beside the frames (s2m_engine_relay.cpp) is a third queue whose chain of tiny kernels delays the
+// dispatch of the frame's own, so few launches matter more than the last microsecond: the radix passes above 4096 points.  Both are stable.
 using BuildSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
 
 // The arrays of `dst` get (at least) the capacities of `src`: the map a layout beside the frames will be built into follows the

@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void snap_gather_kernel(const float4 *__restri
     if (i < n) out[i] = snap[val[i]];
 }
 // (rocprim sorts up to 2^20 items by a merge sort: a block sort and twenty merge passes -- twenty-odd launches of a few
-// microseconds each.  Beside the frames every launch of the worker competes with the frame's and the side thread's for the
-// runtime, and a burst of them slows all three; the radix passes are six launches)
+// microseconds each.  Beside the frames such a chain of tiny dependent kernels on a third queue delays the dispatch of the
+// frame's and the side stream's kernels (15 - 50 us between kernels instead of 0 - 5: NOTEBOOK round 6); the radix passes are
+// six launches)
 using SnapSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 4096>;
 size_t snapshot_sort_tmp_bytes(int64_t n)
 {

@@ -22,3 +22,14 @@ for k, sn in enumerate(snaps):
     for s, e, fn, th in api:
         if t0 - win * 1e6 <= s <= t0 + win * 1e6 and (e - s) * 1e-3 >= thr:
             print("   %+8.3f ms  %8.1f us  %s  %s" % ((s - t0) * 1e-6, (e - s) * 1e-3, th, fn))
+
+# launch calls per thread inside the snapshot's first 1.2 ms against the 3 ms before it: is a launch slower on the HOST beside a layout?
+import statistics
+for k, sn in enumerate(snaps):
+    t0 = sn[0]
+    for name, lo, hi in (("before", t0 - 3.2e6, t0 - 0.2e6), ("beside", t0 + 0.15e6, t0 + 1.2e6)):
+        per = collections.defaultdict(list)
+        for s, e, fn, th in api:
+            if lo <= s <= hi and fn in ("hipLaunchKernel", "hipModuleLaunchKernel", "hipExtModuleLaunchKernel", "hipLaunchKernelGGL"):
+                per[th].append((e - s) * 1e-3)
+        print("snapshot %d, %s: " % (k, name) + "; ".join("thread %s: %d launches, median %.1f us, mean %.1f, max %.1f" % (th, len(v), statistics.median(v), sum(v) / len(v), max(v)) for th, v in sorted(per.items())))
