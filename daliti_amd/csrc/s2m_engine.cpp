@@ -325,7 +325,14 @@ const char *s2m_last_error(const s2m_engine *e) { return e ? e->err.c_str() : "n
 
 int s2m_test_stall(s2m_engine *e, int32_t kind, int64_t after)
 {
-    if (!e || kind < 0 || kind > 3 || after < 0) return S2M_ERR_ARG;
+    if (!e || kind < 0 || kind > 4 || after < 0) return S2M_ERR_ARG;
+    if (kind == 4) {   // the hand-backs of the layout worker (its own wait control: it has its own way of waiting)
+        e->relay.wait.stall_kind = kStallNone;
+        e->relay.wait.stall_after.store((long)after);
+        e->relay.wait.stall_kind = kStallMail;
+        return S2M_OK;
+    }
+    e->relay.wait.stall_kind = kStallNone;
     e->wait.stall_kind = kStallNone;
     e->wait.stall_after.store((long)after);
     e->wait.stall_kind = kind;

@@ -190,9 +190,9 @@ class Engine:
         return buf.value.decode()
 
     def test_stall(self, kind, after=0):
-        """Fault injection (tests): withhold the hand-backs of `kind` ('worker', 'mail', 'reduce'; None disarms) from the
+        """Fault injection (tests): withhold the hand-backs of `kind` ('worker', 'mail', 'reduce', 'layout'; None disarms) from the
         `after`-th one on."""
-        k = {None: 0, "worker": 1, "mail": 2, "reduce": 3}[kind]
+        k = {None: 0, "worker": 1, "mail": 2, "reduce": 3, "layout": 4}[kind]
         self._ck(self.lib.s2m_test_stall(self.h, C.c_int32(k), C.c_int64(after)))
 
     def set_stream(self, hip_stream):

@@ -124,7 +124,8 @@ int s2m_debug_state(const s2m_engine *e, char *buf, int64_t capacity);
 /* Fault injection for tests of the deadline path on a healthy device (design): from the `after`-th one on, the hand-backs of
  * `kind` are withheld -- 1: the side thread never finishes its job (s2m_scan_prefetch_raw / s2m_scan_prepare_raw), 2: the
  * kernel that hands device words to the host is not launched (map updates, voxel grid, scan hand-over), 3: the reduce kernel
- * does not publish its block (every pass).  0 disarms.  The environment variable S2M_TEST_STALL=worker|mail|reduce[:after]
+ * does not publish its block (every pass), 4: the hand-backs of the worker that lays the map out beside the frames (the frames
+ * go on; the layout's own deadline reports it).  0 disarms.  The environment variable S2M_TEST_STALL=worker|mail|reduce[:after]
  * arms the same hook when a handle is created (for callers that are not tests' own code, e.g. tools/replay_node). */
 int s2m_test_stall(s2m_engine *e, int32_t kind, int64_t after);
 /* Change gates between scans (e.g. feat_threshold, laserMapping.cpp:427-430). cell_size/device

@@ -242,3 +242,43 @@ def test_debug_state_from_another_thread(small_scene):
     t.join()
     assert any("in s2m_iterated_update" in s for s in seen)
     e.close()
+
+
+@pytest.mark.gpu
+def test_a_layout_whose_worker_stalls_does_not_stop_the_frames(small_scene, monkeypatch):
+    """The map is laid out again BESIDE the updates by a worker thread of the handle (ikd-Tree's rebuild thread,
+    ikd_Tree.cpp:192-203, 229-367).  Its first hand-back never comes: registration and map updates go on at their usual pace --
+    nobody waits for the layout -- until the layout's own deadline has passed; then the next call that looks after it reports
+    S2M_ERR_TIMEOUT with the worker's wait by name, the handle refuses further work and can be destroyed."""
+    from daliti_amd import Engine
+    sc = small_scene
+    monkeypatch.setenv("S2M_BESIDE_AT", "3")
+    e = Engine(max_iter=5, wait_timeout_ms=TIMEOUT_MS, cell_size=0.5)
+    e.map_build(sc["map"])
+    e.scan_set(sc["scan"])
+    rs = np.random.RandomState(2)
+    for _ in range(2):   # (the first update of a dense build lays the room and the tail out: a layout in flight would be let go for it)
+        e.map_add((sc["map"][rs.choice(len(sc["map"]), 100)] + rs.normal(0, 0.2, (100, 3))).astype(np.float32), False)
+    e.test_stall("layout", 0)
+    t0 = time.perf_counter()
+    e.map_add(sc["map"][:300] + np.float32(0.11), True, 0.5)      # the layout begins behind this update
+    done, slowest = 0, 0.0
+    while time.perf_counter() - t0 < 0.06:      # (a wait whose stream has gone idle without the word is given up after 0.1 s: s2m_wait.h)
+        t1 = time.perf_counter()
+        e.scan_set(sc["scan"])
+        r = e.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
+        e.map_add((sc["map"][rs.choice(len(sc["map"]), 100)] + rs.normal(0, 0.2, (100, 3))).astype(np.float32), False)
+        assert r["effct"][0] > 1000
+        slowest = max(slowest, time.perf_counter() - t1)
+        done += 1
+    assert done >= 5 and slowest < 0.05, (done, slowest)            # (a frame of this size takes a millisecond or two)
+    st = e.debug_state()
+    assert "1 begun" in st.split("layout beside")[1] and "0 dropped" in st.split("layout beside")[1], st
+    time.sleep(max(0.0, 1.3 * TIMEOUT_MS * 1e-3 - (time.perf_counter() - t0)))
+
+    def look_after_it():
+        e.scan_set(sc["scan"])                                    # (a new scan arrives: the moment a finished -- or failed -- layout is dealt with)
+        e.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
+    msg = _expect_timeout(look_after_it, e, "the layout beside the frames")
+    assert "hand-back" in msg, msg
+    _after(e, small_scene)
