@@ -263,7 +263,7 @@ def test_a_layout_whose_worker_stalls_does_not_stop_the_frames(small_scene, monk
     t0 = time.perf_counter()
     e.map_add(sc["map"][:300] + np.float32(0.11), True, 0.5)      # the layout begins behind this update
     done, slowest = 0, 0.0
-    while time.perf_counter() - t0 < 0.06:      # (a wait whose stream has gone idle without the word is given up after 0.1 s: s2m_wait.h)
+    while time.perf_counter() - t0 < 0.04:      # (a wait whose stream has gone idle without the word is given up after 0.1 s: s2m_wait.h)
         t1 = time.perf_counter()
         e.scan_set(sc["scan"])
         r = e.iterated_update(sc["x_prop"], sc["x_prop"], sc["P"])
@@ -271,7 +271,7 @@ def test_a_layout_whose_worker_stalls_does_not_stop_the_frames(small_scene, monk
         assert r["effct"][0] > 1000
         slowest = max(slowest, time.perf_counter() - t1)
         done += 1
-    assert done >= 5 and slowest < 0.05, (done, slowest)            # (a frame of this size takes a millisecond or two)
+    assert done >= 3 and slowest < 0.05, (done, slowest)            # (a frame of this size takes a millisecond or two)
     st = e.debug_state()
     assert "1 begun" in st.split("layout beside")[1] and "0 dropped" in st.split("layout beside")[1], st
     time.sleep(max(0.0, 1.3 * TIMEOUT_MS * 1e-3 - (time.perf_counter() - t0)))
